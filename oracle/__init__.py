@@ -1,0 +1,19 @@
+"""CPU oracle for the AIDE FuseUNet/UNet training hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in ``aide_amd/`` (the product path) may
+import this package; only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` use it, and only as the checker.
+
+The oracle is a plain-PyTorch (stock aten, CPU, fp32) restatement of the
+reference algorithm.  Each function cites the reference file:line it follows.
+It is pinned by ``tests/golden/*.npz`` which were produced by importing the
+real reference (``oracle/gen_golden.py``, run in the build container where
+``/root/reference`` exists); see DESIGN.md "Oracle pinning".
+"""
+from .nets import fuseunet, UNet  # noqa: F401
+from .losses import (  # noqa: F401
+    CrossEntropyLoss2d, DiceLoss, MulticlassDiceLoss, MulticlassMSELoss,
+    CEMDiceLoss, CEMDiceLossImage, Coteachingloss_dropimage,
+    Coteachingloss_weightimage, Dice_fn, sharpen,
+)
+from .steps import comparison_step, proposed_step  # noqa: F401

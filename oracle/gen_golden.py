@@ -1,0 +1,349 @@
+"""Generate tests/golden/*.npz by importing the REAL reference (/root/reference).
+
+Run only in the build container (the reference does not travel to the GPU box):
+
+    python -B oracle/gen_golden.py
+
+For every fixture it (1) runs the imported reference, (2) runs this repo's oracle
+restatement on the same seeds/inputs and asserts bit-equality on CPU, and (3) stores the
+reference's inputs/outputs as data.  Only numbers are stored — no reference source.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _import_reference():
+    """Import reference packages under private names so they do not shadow ours."""
+    import importlib
+    import matplotlib
+    matplotlib.use('Agg')
+    sys.path.insert(0, REF)
+    ref_f = importlib.import_module('models_twomodalinputs')
+    ref_u = importlib.import_module('models_singlemodalinput')
+    ref_utils = importlib.import_module('utils')
+    sys.path.remove(REF)
+    return ref_f, ref_u, ref_utils
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _sub(t, limit=8192):
+    """Full tensor when small, else the deterministic flat subsample t.flatten()[::stride]
+    with stride = ceil(numel/limit) (tests recompute the same stride)."""
+    a = _np(t)
+    if a.size <= limit:
+        return a
+    stride = -(-a.size // limit)
+    return a.reshape(-1)[::stride].copy()
+
+
+def _same(a, b, what):
+    assert torch.equal(a, b), 'oracle != reference for %s (max abs diff %g)' % (
+        what, (a.double() - b.double()).abs().max().item())
+
+
+def tiny_inputs(two_modal, n=2, size=32):
+    g = torch.Generator().manual_seed(1234)
+    xs = [torch.randn(n, 3, size, size, generator=g) for _ in range(2 if two_modal else 1)]
+    t = (torch.rand(n, size, size, generator=g) > 0.7).long()
+    return xs, t
+
+
+def g1_model(name, ref_ctor, ora_ctor, kwargs, two_modal, ref_utils):
+    import oracle
+    fx = {}
+    torch.manual_seed(2)
+    rnet = ref_ctor(2, **kwargs)
+    torch.manual_seed(2)
+    onet = ora_ctor(2, **kwargs)
+    rsd, osd = rnet.state_dict(), onet.state_dict()
+    assert list(rsd.keys()) == list(osd.keys()), 'state_dict keys differ for ' + name
+    for k in rsd:
+        _same(rsd[k], osd[k], name + ' init ' + k)
+    xs, t = tiny_inputs(two_modal)
+    w = torch.tensor([1.0, 1.0])
+    res = {}
+    for tag, net, crit_mod in (('ref', rnet, ref_utils), ('ora', onet, oracle)):
+        net.train()
+        out = net(*xs)
+        crit = crit_mod.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
+        crit_i = crit_mod.CEMDiceLossImage(cediceweight=w, ceclassweight=w, diceclassweight=w)
+        loss = crit(out, t)
+        per_img = crit_i(out, t)
+        net.zero_grad()
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, amsgrad=True)
+        opt.step()
+        after1 = {k: p.detach().clone() for k, p in net.named_parameters()}
+        bufs = {k: b.clone() for k, b in net.named_buffers()}
+        net.eval()
+        with torch.no_grad():
+            ev = net(*xs)
+        res[tag] = dict(out=out.detach(), loss=loss.detach(), per_img=per_img.detach(),
+                        grads=grads, after1=after1, bufs=bufs, ev=ev)
+    r, o = res['ref'], res['ora']
+    for k in ('out', 'loss', 'per_img', 'ev'):
+        _same(r[k], o[k], name + ' ' + k)
+    for k in r['grads']:
+        _same(r['grads'][k], o['grads'][k], name + ' grad ' + k)
+        _same(r['after1'][k], o['after1'][k], name + ' adam1 ' + k)
+    for k in r['bufs']:
+        _same(r['bufs'][k], o['bufs'][k], name + ' buf ' + k)
+    names = list(r['grads'].keys())
+    for i, x in enumerate(xs):
+        fx['x%d' % i] = _np(x)
+    fx['targets'] = _np(t)
+    fx['logits'] = _np(r['out'])
+    fx['loss'] = _np(r['loss'])
+    fx['per_image_loss'] = _np(r['per_img'])
+    fx['eval_logits'] = _np(r['ev'])
+    fx['param_names'] = np.array(names)
+    fx['grad_norms'] = np.array([r['grads'][k].double().norm().item() for k in names])
+    fx['grad_absmax'] = np.array([r['grads'][k].abs().max().item() for k in names])
+    fx['param_sum'] = np.array(sum(p.double().sum().item() for p in rnet.state_dict().values()
+                                   if p.dtype.is_floating_point))
+    first = names[0]
+    head_w = 'last_conv1.weight'
+    full = [first, names[1], head_w, 'last_conv1.bias',
+            [k for k in names if k.startswith('up_block4.block.conv2.weight')][0],
+            [k for k in names if k.startswith('up_block1.bilinear_up') and k.endswith('weight')][0]]
+    for k in full:
+        fx['grad/' + k] = _sub(r['grads'][k])
+        fx['adam1/' + k] = _sub(r['after1'][k])
+    for k, b in r['bufs'].items():
+        if k.startswith('up_block4.block.bn2') or k.startswith(first.rsplit('.', 2)[0] + '.bn1'):
+            fx['buf/' + k] = _np(b)
+    np.savez_compressed(os.path.join(OUT, 'g1_%s.npz' % name), **fx)
+    print('g1', name, 'loss', float(r['loss']), 'sum logits', float(r['out'].double().sum()),
+          'gradL2', float(np.sqrt((fx['grad_norms'] ** 2).sum())))
+
+
+def g3_losses(ref_utils):
+    import oracle
+    from aide_amd.synthetic import chaos_batch
+    fx = {}
+    g = torch.Generator().manual_seed(77)
+    n, s = 4, 64
+    _, _, t = chaos_batch(n, s, seed=5)
+    t[0, 10:30, 12:40] = 1                      # guarantee non-empty images too
+    z1 = torch.randn(n, 2, s, s, generator=g) * 2.0
+    z2 = torch.randn(n, 2, s, s, generator=g) * 2.0
+    # make the per-image losses well separated so that the argsort is well defined
+    z1 += torch.tensor([0.0, 0.6, -0.5, 1.1]).view(n, 1, 1, 1) * (2 * t.unsqueeze(1).float() - 1) * \
+        torch.tensor([-1.0, 1.0]).view(1, 2, 1, 1)
+    z2 += torch.tensor([0.9, -0.4, 0.3, -1.0]).view(n, 1, 1, 1) * (2 * t.unsqueeze(1).float() - 1) * \
+        torch.tensor([-1.0, 1.0]).view(1, 2, 1, 1)
+    pseudo = torch.softmax(torch.randn(n, 2, s, s, generator=g), dim=1)
+    wmap = (1.0 - 4.0 * pseudo[:, 0] * pseudo[:, 1]).unsqueeze(1)
+    fx.update(z1=_np(z1), z2=_np(z2), targets=_np(t), pseudo=_np(pseudo), wmap=_np(wmap))
+    for wname, cw in (('w11', torch.tensor([1.0, 1.0])), ('w13', torch.tensor([1.0, 3.0]))):
+        cdw = torch.tensor([1.0, 1.0]) if wname == 'w11' else torch.tensor([0.7, 1.6])
+        for lname, kw in (('CrossEntropyLoss2d', dict(weight=cw)),
+                          ('MulticlassDiceLoss', dict(weight=cw)),
+                          ('DiceLoss', dict()),
+                          ('CEMDiceLoss', dict(cediceweight=cdw, ceclassweight=cw, diceclassweight=cw)),
+                          ('CEMDiceLossImage', dict(cediceweight=cdw, ceclassweight=cw, diceclassweight=cw))):
+            vals = {}
+            for tag, mod in (('ref', ref_utils), ('ora', oracle)):
+                zz = z1.clone().requires_grad_(True)
+                v = getattr(mod, lname)(**kw)(zz, t)
+                (v.sum() if v.dim() else v).backward()
+                vals[tag] = (v.detach(), zz.grad.clone())
+            _same(vals['ref'][0], vals['ora'][0], lname + wname)
+            _same(vals['ref'][1], vals['ora'][1], lname + wname + ' grad')
+            fx['%s/%s' % (lname, wname)] = _np(vals['ref'][0])
+            fx['%s/%s/grad' % (lname, wname)] = _np(vals['ref'][1])
+    # CE 'none' reduction (per-pixel map) and 'sum'
+    for red in ('none', 'sum'):
+        a = ref_utils.CrossEntropyLoss2d(weight=torch.tensor([1.0, 3.0]), reduction=red)(z1, t)
+        b = oracle.CrossEntropyLoss2d(weight=torch.tensor([1.0, 3.0]), reduction=red)(z1, t)
+        _same(a, b, 'CE ' + red)
+        fx['CrossEntropyLoss2d/w13/' + red] = _np(a)
+    # MSE consistency (a13) with weightmap, caller-side mean
+    vals = {}
+    for tag, mod in (('ref', ref_utils), ('ora', oracle)):
+        zz = z1.clone().requires_grad_(True)
+        v = (wmap * mod.MulticlassMSELoss(reduction='none')(zz, pseudo)).mean()
+        v.backward()
+        vals[tag] = (v.detach(), zz.grad.clone())
+    _same(vals['ref'][0], vals['ora'][0], 'mse')
+    _same(vals['ref'][1], vals['ora'][1], 'mse grad')
+    fx['mse_wm_mean'] = _np(vals['ref'][0])
+    fx['mse_wm_mean/grad'] = _np(vals['ref'][1])
+    # co-teaching operators (a16, a17-weightimage)
+    for cname in ('Coteachingloss_dropimage', 'Coteachingloss_weightimage'):
+        for fr in (0.0, 0.25, 0.5):
+            vals = {}
+            for tag, mod in (('ref', ref_utils), ('ora', oracle)):
+                a1 = z1.clone().requires_grad_(True)
+                a2 = z2.clone().requires_grad_(True)
+                l1, l2 = getattr(mod, cname)(weight=1.0, reduction='none')(a1, a2, t, fr)
+                (l1 + l2).backward()
+                vals[tag] = (l1.detach(), l2.detach(), a1.grad.clone(), a2.grad.clone())
+            for i in range(4):
+                _same(vals['ref'][i], vals['ora'][i], '%s fr=%g #%d' % (cname, fr, i))
+            key = '%s/fr%g' % (cname, fr)
+            fx[key + '/loss1'], fx[key + '/loss2'] = _np(vals['ref'][0]), _np(vals['ref'][1])
+            fx[key + '/grad1'], fx[key + '/grad2'] = _np(vals['ref'][2]), _np(vals['ref'][3])
+    crit = ref_utils.Coteachingloss_dropimage(weight=1.0, reduction='none')
+    l1 = crit.weight * torch.mean(crit.ce(z1, t), dim=[1, 2]) + crit.dice(z1, t)
+    l2 = crit.weight * torch.mean(crit.ce(z2, t), dim=[1, 2]) + crit.dice(z2, t)
+    fx['coteach/per_image1'], fx['coteach/per_image2'] = _np(l1), _np(l2)
+    fx['coteach/argsort1'] = np.asarray(np.argsort(l1.cpu().data))
+    fx['coteach/argsort2'] = np.asarray(np.argsort(l2.cpu().data))
+    fx['coteach/min_gap1'] = np.diff(np.sort(_np(l1))).min()
+    fx['coteach/min_gap2'] = np.diff(np.sort(_np(l2))).min()
+    # hard Dice metric (sum over the batch)
+    d_ref = ref_utils.Dice_fn(z1.clone(), t)
+    d_ora = oracle.Dice_fn(z1.clone(), t)
+    _same(torch.as_tensor(d_ref), torch.as_tensor(d_ora), 'Dice_fn')
+    fx['Dice_fn'] = _np(torch.as_tensor(d_ref))
+    np.savez_compressed(os.path.join(OUT, 'g3_losses.npz'), **fx)
+    print('g3 losses ok; coteach gaps', fx['coteach/min_gap1'], fx['coteach/min_gap2'])
+
+
+def g4_proposed(ref_f, ref_utils):
+    """Proposed co-teaching step on tiny inputs: reference modules/losses driven by the restated
+    step (oracle.steps), compared with the all-oracle run."""
+    import oracle
+    from oracle import steps
+    fx = {}
+    n, s = 4, 32
+    g = torch.Generator().manual_seed(4321)
+    xin = torch.randn(n, 3, s, s, generator=g)
+    xout = torch.randn(n, 3, s, s, generator=g)
+    t1 = (torch.rand(n, s, s, generator=g) > 0.7).long()
+    t2 = (torch.rand(n, s, s, generator=g) > 0.65).long()
+    augs = [(xin + 0.05 * torch.randn(n, 3, s, s, generator=g),
+             xout + 0.05 * torch.randn(n, 3, s, s, generator=g)) for _ in range(4)]
+    fx.update(xin=_np(xin), xout=_np(xout), t1=_np(t1), t2=_np(t2))
+    for i, (a, b) in enumerate(augs):
+        fx['aug%d_in' % i], fx['aug%d_out' % i] = _np(a), _np(b)
+    w = torch.tensor([1.0, 1.0])
+    for rate in (0.0, 0.25, 1.0):
+        res = {}
+        for tag, fmod, umod in (('ref', ref_f, ref_utils), ('ora', oracle, oracle)):
+            torch.manual_seed(2)
+            net1 = fmod.fuseunet(2)
+            net2 = fmod.fuseunet(2)
+            net1.train(), net2.train()
+            crit = umod.CEMDiceLossImage(cediceweight=w, ceclassweight=w, diceclassweight=w)
+            corr = umod.MulticlassMSELoss(reduction='none')
+            o1 = torch.optim.Adam(net1.parameters(), lr=1e-4, amsgrad=True)
+            o2 = torch.optim.Adam(net2.parameters(), lr=1e-4, amsgrad=True)
+            r = steps.proposed_step(net1, net2, crit, corr, o1, o2, xin, xout, augs, t1, t2, rate)
+            r['g1'] = torch.stack([p.grad.double().norm() for p in net1.parameters()])
+            r['g2'] = torch.stack([p.grad.double().norm() for p in net2.parameters()])
+            r['nbt'] = net1.modal1_downblock1.block.bn1.num_batches_tracked.clone()
+            r['head1'] = net1.last_conv1.weight.detach().clone()
+            res[tag] = r
+        for k in ('outputs1', 'outputs2', 'loss1', 'loss2', 'indx1', 'indx2', 'g1', 'g2', 'head1'):
+            _same(res['ref'][k], res['ora'][k], 'proposed r=%g %s' % (rate, k))
+        r = res['ref']
+        key = 'r%g/' % rate
+        for k in ('outputs1', 'outputs2', 'loss1', 'loss2', 'indx1', 'indx2', 'loss1_pre',
+                  'loss2_pre', 'g1', 'g2', 'nbt', 'head1'):
+            fx[key + k] = _np(r[k])
+        fx[key + 'min_gap1'] = np.diff(np.sort(_np(r['loss1_pre']))).min()
+        fx[key + 'min_gap2'] = np.diff(np.sort(_np(r['loss2_pre']))).min()
+        print('g4 r=%g' % rate, float(r['loss1']), float(r['loss2']), r['indx1'].tolist(),
+              r['indx2'].tolist(), 'gaps', fx[key + 'min_gap1'], fx[key + 'min_gap2'])
+    np.savez_compressed(os.path.join(OUT, 'g4_proposed.npz'), **fx)
+
+
+def g5_adam(ref_f, ref_utils):
+    """Three comparison steps (trainchaos_comparison_1case.py:190-199) on the tiny inputs."""
+    import oracle
+    from oracle import steps
+    fx = {}
+    xs, t = tiny_inputs(True)
+    w = torch.tensor([1.0, 1.0])
+    res = {}
+    for tag, fmod, umod in (('ref', ref_f, ref_utils), ('ora', oracle, oracle)):
+        torch.manual_seed(2)
+        net = fmod.fuseunet(2)
+        net.train()
+        crit = umod.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, amsgrad=True)
+        losses, snaps = [], []
+        for _ in range(3):
+            _, loss = steps.comparison_step(net, crit, opt, xs[0], xs[1], t)
+            losses.append(loss)
+            snaps.append({k: p.detach().clone() for k, p in net.named_parameters()})
+        res[tag] = (torch.stack(losses), snaps)
+    _same(res['ref'][0], res['ora'][0], 'adam losses')
+    keys = ['last_conv1.weight', 'last_conv1.bias', 'up_block4.block.conv2.weight',
+            'up_block4.block.bn2.weight', 'up_block4.block.bn2.bias',
+            'modal1_downblock1.block.conv1.weight']
+    for i in (0, 2):
+        for k in keys:
+            _same(res['ref'][1][i][k], res['ora'][1][i][k], 'adam step%d %s' % (i + 1, k))
+            fx['step%d/%s' % (i + 1, k)] = _sub(res['ref'][1][i][k])
+    fx['losses'] = _np(res['ref'][0])
+    np.savez_compressed(os.path.join(OUT, 'g5_adam.npz'), **fx)
+    print('g5 losses', fx['losses'])
+
+
+def g2_config(ref_f, ref_utils):
+    """BASELINE config 2 digests: FuseUNet N=4, 256x256, synthetic CHAOS-shaped batch."""
+    import oracle
+    from aide_amd.synthetic import chaos_batch
+    fx = {}
+    xin, xout, t = chaos_batch(4, 256, seed=1234)
+    w = torch.tensor([1.0, 1.0])
+    res = {}
+    for tag, fmod, umod in (('ref', ref_f, ref_utils), ('ora', oracle, oracle)):
+        torch.manual_seed(2)
+        net = fmod.fuseunet(2)
+        net.train()
+        out = net(xin, xout)
+        loss = umod.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)(out, t)
+        per = umod.CEMDiceLossImage(cediceweight=w, ceclassweight=w, diceclassweight=w)(out, t)
+        loss.backward()
+        res[tag] = (out.detach(), loss.detach(), per.detach(),
+                    torch.stack([p.grad.double().norm() for p in net.parameters()]),
+                    [k for k, _ in net.named_parameters()])
+    for i in range(4):
+        _same(res['ref'][i], res['ora'][i], 'g2 #%d' % i)
+    out, loss, per, gn, names = res['ref']
+    fx['logits_sum'] = np.array(out.double().sum().item())
+    fx['logits_abs_sum'] = np.array(out.double().abs().sum().item())
+    fx['logits_rows'] = _np(out[:, :, ::37, :])          # 7 rows per image/class
+    fx['loss'], fx['per_image_loss'] = _np(loss), _np(per)
+    fx['grad_norms'], fx['param_names'] = _np(gn), np.array(names)
+    fx['seed'] = np.array(1234)
+    np.savez_compressed(os.path.join(OUT, 'g2_config2.npz'), **fx)
+    print('g2 loss', float(loss), 'per-image', per.tolist())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref_f, ref_u, ref_utils = _import_reference()
+    import oracle
+    g1_model('fuseunet', ref_f.fuseunet, oracle.fuseunet, {}, True, ref_utils)
+    g1_model('fuseunet_learned', ref_f.fuseunet, oracle.fuseunet, dict(learned_bilinear=True), True, ref_utils)
+    g1_model('unet', ref_u.UNet, oracle.UNet, {}, False, ref_utils)
+    g1_model('unet_learned', ref_u.UNet, oracle.UNet, dict(learned_bilinear=True), False, ref_utils)
+    g3_losses(ref_utils)
+    g4_proposed(ref_f, ref_utils)
+    g5_adam(ref_f, ref_utils)
+    g2_config(ref_f, ref_utils)
+    print('all golden fixtures written to', OUT)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,206 @@
+"""Oracle (test infrastructure): restatement of the reference's segmentation
+losses and co-teaching selection on CPU with stock aten ops.
+
+Reference:
+  utils/loss2d.py:5-13     CrossEntropyLoss2d
+  utils/loss2d.py:35-61    DiceLoss
+  utils/loss2d.py:87-107   MulticlassDiceLoss (index targets -> class-1 Dice only)
+  utils/loss2d.py:109-117  MulticlassMSELoss
+  utils/loss2d.py:119-135  CEMDiceLoss
+  utils/loss2d.py:137-154  CEMDiceLossImage
+  utils/coteach_loss.py:94-119   Coteachingloss_dropimage
+  utils/coteach_loss.py:121-161  Coteachingloss_weightimage
+  utils/metrics2d.py:8-29  Dice_fn
+  train_files/trainchaos_proposed_30cases1labeled.py:97-101 sharpen
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+def _ce(inputs, targets, weight, reduction, ignore_index=255):
+    # loss2d.py:8,10-13 : one-hot (4-D) targets are arg-maxed first
+    if targets.dim() > 3:
+        targets = torch.argmax(targets.float(), dim=1)
+    return F.cross_entropy(inputs, targets, weight=weight, reduction=reduction,
+                           ignore_index=ignore_index)
+
+
+def _reduce(per_image, n, reduction):
+    # loss2d.py:53-60
+    if reduction == 'mean':
+        return per_image.sum() / n
+    if reduction == 'sum':
+        return per_image.sum()
+    if reduction == 'none':
+        return per_image
+    raise ValueError(reduction)
+
+
+def _dice_from_prob(prob_fg, target, smooth, reduction):
+    # loss2d.py:42-52 : operands are down-cast with .float()
+    n = target.size(0)
+    p = prob_fg.reshape(n, -1).float()
+    t = target.reshape(n, -1).float()
+    per = 1.0 - (2.0 * (p * t).sum(1) + smooth) / (p.sum(1) + t.sum(1) + smooth)
+    return _reduce(per, n, reduction)
+
+
+class CrossEntropyLoss2d(nn.Module):
+    def __init__(self, weight=None, reduction='mean', ignore_index=255):
+        super().__init__()
+        self.register_buffer('weight', weight)
+        self.reduction, self.ignore_index = reduction, ignore_index
+
+    def forward(self, inputs, targets):
+        return _ce(inputs, targets, self.weight, self.reduction, self.ignore_index)
+
+
+class DiceLoss(nn.Module):
+    def __init__(self, weight=None, smooth=1.0, reduction='mean'):
+        super().__init__()
+        self.weight, self.smooth, self.reduction = weight, smooth, reduction
+
+    def forward(self, input, target):
+        # loss2d.py:44-48 : 4-D input = logits -> softmax -> class 1; 3-D input = probability
+        if input.dim() > 3:
+            input = F.softmax(input, dim=1)[:, 1]
+        return _dice_from_prob(input, target, self.smooth, self.reduction)
+
+
+class MulticlassDiceLoss(nn.Module):
+    def __init__(self, weight=None, smooth=1.0, reduction='mean'):
+        super().__init__()
+        self.weight, self.smooth, self.reduction = weight, smooth, reduction
+
+    def forward(self, input, target):
+        prob = F.softmax(input, dim=1)                      # loss2d.py:96
+        if target.dim() > 3:                                # loss2d.py:98-104 one-hot targets
+            total = 0
+            for c in range(target.shape[1]):
+                d = _dice_from_prob(prob[:, c], target[:, c], self.smooth, self.reduction)
+                if self.weight is not None:
+                    d = d * self.weight[c]
+                total = total + d
+            return total
+        return _dice_from_prob(prob[:, 1], target, self.smooth, self.reduction)  # :106
+
+
+class MulticlassMSELoss(nn.Module):
+    def __init__(self, reduction='mean'):
+        super().__init__()
+        self.reduction = reduction
+
+    def forward(self, input, target):
+        return F.mse_loss(F.softmax(input, dim=1), target, reduction=self.reduction)
+
+
+class CEMDiceLoss(nn.Module):
+    def __init__(self, cediceweight=None, ceclassweight=None, diceclassweight=None,
+                 reduction='mean'):
+        super().__init__()
+        self.cediceweight = cediceweight
+        self.ce = CrossEntropyLoss2d(ceclassweight, reduction)
+        self.multidice = MulticlassDiceLoss(diceclassweight, reduction=reduction)
+
+    def forward(self, inputs, targets):
+        ce, dice = self.ce(inputs, targets), self.multidice(inputs, targets)
+        if self.cediceweight is not None:                   # loss2d.py:131-134
+            return ce * self.cediceweight[0] + dice * self.cediceweight[1]
+        return ce + dice
+
+
+class CEMDiceLossImage(nn.Module):
+    def __init__(self, cediceweight=None, ceclassweight=None, diceclassweight=None,
+                 reduction='mean'):
+        super().__init__()
+        self.cediceweight = cediceweight
+        self.ce = CrossEntropyLoss2d(ceclassweight, 'none')
+        self.multidice = MulticlassDiceLoss(diceclassweight, reduction='none')
+
+    def forward(self, inputs, targets):
+        ce = self.ce(inputs, targets).mean(dim=[1, 2])      # loss2d.py:147-148 plain pixel mean
+        dice = self.multidice(inputs, targets)
+        if self.cediceweight is not None:
+            return ce * self.cediceweight[0] + dice * self.cediceweight[1]
+        return ce + dice
+
+
+def _ct_image_loss(weight, inputs, targets):
+    # coteach_loss.py:102 : w * mean_hw(NLL(log_softmax)) + Dice_i ; reduction='none' variant
+    ce = F.nll_loss(F.log_softmax(inputs, dim=1), targets, reduction='none', ignore_index=255)
+    prob = F.softmax(inputs, dim=1)[:, 1]
+    return weight * ce.mean(dim=[1, 2]) + _dice_from_prob(prob, targets, 1.0, 'none')
+
+
+def _argsort_host(loss):
+    # coteach_loss.py:104-105 : numpy argsort of the per-image losses on the host (stable for ties
+    # at these sizes: lower index first)
+    return torch.from_numpy(np.argsort(loss.detach().cpu().numpy(), kind='stable'))
+
+
+class Coteachingloss_dropimage(nn.Module):
+    """coteach_loss.py:94-119. Only meaningful with reduction='none' (SURVEY §2.1 #5)."""
+
+    def __init__(self, weight=1.0, reduction='mean'):
+        super().__init__()
+        if reduction != 'none':
+            # reference raises IndexError from torch.mean(dim=[1,2]) on a scalar; restate loudly
+            raise IndexError("Coteachingloss_* require reduction='none' (reference behaviour)")
+        self.weight = weight
+
+    def forward(self, inputs1, inputs2, targets, forget_rate):
+        l1 = _ct_image_loss(self.weight, inputs1, targets)
+        l2 = _ct_image_loss(self.weight, inputs2, targets)
+        i1, i2 = _argsort_host(l1), _argsort_host(l2)
+        keep = int((1 - forget_rate) * l1.shape[0])         # :107-108 truncation
+        k1, k2 = i1[:keep], i2[:keep]
+        u1 = _ct_image_loss(self.weight, inputs1[k2], targets[k2])   # cross selection :114-117
+        u2 = _ct_image_loss(self.weight, inputs2[k1], targets[k1])
+        return u1.mean(dim=0), u2.mean(dim=0)
+
+
+class Coteachingloss_weightimage(nn.Module):
+    """coteach_loss.py:121-161: dropped images kept with weight 0.1 (shape-broadcast as in the
+    reference: valid when |keep| == |drop| or one of them has one element)."""
+
+    def __init__(self, weight=1.0, reduction='mean'):
+        super().__init__()
+        if reduction != 'none':
+            raise IndexError("Coteachingloss_* require reduction='none' (reference behaviour)")
+        self.weight = weight
+
+    def forward(self, inputs1, inputs2, targets, forget_rate):
+        l1 = _ct_image_loss(self.weight, inputs1, targets)
+        l2 = _ct_image_loss(self.weight, inputs2, targets)
+        i1, i2 = _argsort_host(l1), _argsort_host(l2)
+        keep = int((1 - forget_rate) * l1.shape[0])
+        k1, d1, k2, d2 = i1[:keep], i1[keep:], i2[:keep], i2[keep:]
+        u1 = _ct_image_loss(self.weight, inputs1[k2], targets[k2])
+        if len(d1) > 0:                                      # :141 (quirk: tests ind_1_drop)
+            u1 = u1 + 0.1 * _ct_image_loss(self.weight, inputs1[d2], targets[d2])
+        u2 = _ct_image_loss(self.weight, inputs2[k1], targets[k1])
+        if len(d2) > 0:
+            u2 = u2 + 0.1 * _ct_image_loss(self.weight, inputs2[d1], targets[d1])
+        return u1.mean(dim=0), u2.mean(dim=0)
+
+
+def Dice_fn(inputs, targets, threshold=0.5):
+    """metrics2d.py:8-29 — hard Dice, returns the SUM over the batch."""
+    fg = (F.softmax(inputs, dim=1)[:, 1] >= threshold).float()
+    total = 0.0
+    for p, t in zip(fg, targets):
+        p, t = p.reshape(-1), t.reshape(-1).float()
+        if t.sum() == 0:
+            d = torch.tensor(1.0) if p.sum() == 0 else torch.tensor(0.0)
+        else:
+            d = 2.0 * (p * t).sum() / (p.sum() + t.sum())
+        total = total + d
+    return total
+
+
+def sharpen(mask, temperature):
+    """trainchaos_proposed_30cases1labeled.py:97-101 — p^T / sum_c p^T."""
+    m = torch.pow(mask, temperature)
+    return m / m.sum(dim=1, keepdim=True)

@@ -1,0 +1,119 @@
+"""Oracle (test infrastructure): plain-PyTorch restatement of the two networks.
+
+Module attribute names and construction order equal the reference's so that
+(i) ``state_dict()`` keys/shapes are identical and (ii) seeding the global RNG
+and constructing reproduces the reference's initial weights bit-for-bit
+(SURVEY.md §8c "seeded-init trick").
+
+Reference:
+  models_twomodalinputs/netblocks.py:9-19   up path (bilinear+conv3x3 | ConvT 2x2)
+  models_twomodalinputs/netblocks.py:21-33  basic_block (conv-bn-relu x2)
+  models_twomodalinputs/netblocks.py:128-147 down / up blocks
+  models_twomodalinputs/fuseunet.py:6-91    fuseunet
+  models_singlemodalinput/UNet.py:110-165   UNet (pool inside the down block)
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _DoubleConv(nn.Module):
+    # netblocks.py:21-33 ; registration order conv1, bn1, conv2, bn2 matters for seeding
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.bn2 = nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)))
+        return F.relu(self.bn2(self.conv2(x)))
+
+
+class _Down(nn.Module):
+    # netblocks.py:128-135 (pool=False) ; UNet.py:110-121 (pool inside when down_size)
+    def __init__(self, cin, cout, pool=False):
+        super().__init__()
+        self.block = _DoubleConv(cin, cout)
+        self.pool = pool
+
+    def forward(self, x):
+        if self.pool:
+            x = F.max_pool2d(x, 2, 2)
+        return self.block(x)
+
+
+def _up_path(cin, cout, learned):
+    # netblocks.py:9-19 — Sequential indices are part of the state_dict keys
+    if learned:
+        return nn.Sequential(nn.ConvTranspose2d(cin, cout, kernel_size=2, stride=2),
+                             nn.BatchNorm2d(cout), nn.ReLU())
+    return nn.Sequential(nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True),
+                         nn.Conv2d(cin, cout, kernel_size=3, padding=1),
+                         nn.BatchNorm2d(cout), nn.ReLU())
+
+
+class _Up(nn.Module):
+    # netblocks.py:137-147 — cat order is (upsampled, skip)
+    def __init__(self, cin, cprev, cout, learned=False):
+        super().__init__()
+        self.bilinear_up = _up_path(cin, cprev, learned)
+        self.block = _DoubleConv(cprev * 2, cout)
+
+    def forward(self, skip, x):
+        return self.block(torch.cat((self.bilinear_up(x), skip), dim=1))
+
+
+class fuseunet(nn.Module):
+    """fuseunet.py:6-91. ``reduction``/``dilation`` accepted and ignored (fuseunet.py:7)."""
+    M1 = [(3, 32), (64, 64), (128, 128), (256, 256), (512, 512)]     # fuseunet.py:12-20
+    M2 = [(3, 32), (32, 64), (64, 128), (128, 256), (256, 512)]      # fuseunet.py:24-32
+    UP = [(1024, 512, 512), (512, 256, 256), (256, 128, 128), (128, 64, 64)]  # :36-39
+
+    def __init__(self, num_classes=2, reduction=16, dilation=4, learned_bilinear=False):
+        super().__init__()
+        for i, (a, b) in enumerate(self.M1, 1):
+            setattr(self, 'modal1_downblock%d' % i, _Down(a, b))
+        for i, (a, b) in enumerate(self.M2, 1):
+            setattr(self, 'modal2_downblock%d' % i, _Down(a, b))
+        for i, (a, p, o) in enumerate(self.UP, 1):
+            setattr(self, 'up_block%d' % i, _Up(a, p, o, learned_bilinear))
+        self.last_conv1 = nn.Conv2d(64, num_classes, 1, padding=0)
+
+    def forward(self, modal1_inputs, modal2_inputs):
+        y, x = modal1_inputs, modal2_inputs
+        skips = []
+        for i in range(1, 6):                                         # fuseunet.py:45-81
+            if i > 1:
+                y = F.max_pool2d(skips[-1], 2, 2)   # modal-1 consumes the fused tensor
+                x = F.max_pool2d(x, 2, 2)
+            y = getattr(self, 'modal1_downblock%d' % i)(y)
+            x = getattr(self, 'modal2_downblock%d' % i)(x)
+            skips.append(torch.cat((y, x), dim=1))  # (modal1, modal2)
+        y = skips[4]
+        for i in range(1, 5):                                         # fuseunet.py:85-88
+            y = getattr(self, 'up_block%d' % i)(skips[4 - i], y)
+        return self.last_conv1(y)                                     # fuseunet.py:89
+
+
+class UNet(nn.Module):
+    """UNet.py:135-165."""
+    ENC = [(3, 64), (64, 128), (128, 256), (256, 512), (512, 1024)]  # UNet.py:139-143
+
+    def __init__(self, num_classes=2, learned_bilinear=False):
+        super().__init__()
+        for i, (a, b) in enumerate(self.ENC, 1):
+            setattr(self, 'down_block%d' % i, _Down(a, b, pool=(i > 1)))
+        for i, (a, p, o) in enumerate(fuseunet.UP, 1):
+            setattr(self, 'up_block%d' % i, _Up(a, p, o, learned_bilinear))
+        self.last_conv1 = nn.Conv2d(64, num_classes, 1, padding=0)
+
+    def forward(self, x):
+        feats = []
+        for i in range(1, 6):
+            x = getattr(self, 'down_block%d' % i)(x)
+            feats.append(x)
+        for i in range(1, 5):
+            x = getattr(self, 'up_block%d' % i)(feats[4 - i], x)
+        return self.last_conv1(x)

@@ -1,0 +1,85 @@
+"""Oracle (test infrastructure): the two training inner steps, restated.
+
+The reference's train scripts cannot be imported (they import skimage/pydicom
+and run argparse/mkdir at import — SURVEY.md §8c), so the inner loops are
+restated here line by line and validated in ``oracle/gen_golden.py`` by running
+them with the *imported reference* modules/losses plugged in.
+
+Reference:
+  train_files/trainchaos_comparison_1case.py:190-202          comparison step
+  train_files/trainchaos_proposed_30cases1labeled.py:260-330  AIDE proposed step
+"""
+import torch
+import torch.nn.functional as F
+
+from .losses import sharpen
+
+
+def comparison_step(net, criterion, optimizer, inphase, outphase, targets):
+    """trainchaos_comparison_1case.py:195-199. ``outphase=None`` -> single-modal net(x)."""
+    optimizer.zero_grad()
+    outputs = net(inphase, outphase) if outphase is not None else net(inphase)
+    loss = criterion(outputs, targets)
+    loss.backward()
+    optimizer.step()
+    return outputs.detach(), loss.detach()
+
+
+def pseudo_labels(aug_logits, temperature):
+    """trainchaos_proposed_30cases1labeled.py:274-292 — mean softmax over the (already
+    reverse-augmented) passes, sharpen, weightmap = 1 - 4 p0 p1."""
+    acc = None
+    for lg in aug_logits:
+        sm = F.softmax(lg, dim=1)
+        acc = sm if acc is None else acc + sm
+    pl = sharpen(acc / float(len(aug_logits)), temperature)
+    wm = (1.0 - 4.0 * pl[:, 0] * pl[:, 1]).unsqueeze(1)
+    return pl, wm
+
+
+def proposed_losses(criterion, corr, outputs1, outputs2, targets1, targets2,
+                    pl1, wm1, pl2, wm2, rate, segcor_weight=(1.0, 10.0), keep=2):
+    """trainchaos_proposed_30cases1labeled.py:303-321. ``criterion`` = CEMDiceLossImage,
+    ``corr`` = MulticlassMSELoss('none'). Returns (loss1, loss2, indx1, indx2, seg1pre, seg2pre)."""
+    l1pre = criterion(outputs1, targets2)          # net1 scored against net2's labels (:303)
+    l2pre = criterion(outputs2, targets1)
+    _, indx1 = l1pre.sort()
+    _, indx2 = l2pre.sort()
+    k2, d2, k1, d1 = indx2[:keep], indx2[keep:], indx1[:keep], indx1[keep:]
+    l1_s1 = criterion(outputs1[k2], targets2[k2]).mean()
+    l2_s1 = criterion(outputs2[k1], targets1[k1]).mean()
+    l1_s2 = criterion(outputs1[d2], targets2[d2]).mean()
+    l2_s2 = criterion(outputs2[d1], targets1[d1]).mean()
+    l1_cor = (wm2[d2] * corr(outputs1[d2], pl2[d2])).mean()
+    l2_cor = (wm1[d1] * corr(outputs2[d1], pl1[d1])).mean()
+    loss1 = segcor_weight[0] * (l1_s1 + (1.0 - rate) * l1_s2) + segcor_weight[1] * rate * l1_cor
+    loss2 = segcor_weight[0] * (l2_s1 + (1.0 - rate) * l2_s2) + segcor_weight[1] * rate * l2_cor
+    return loss1, loss2, indx1, indx2, l1pre.detach(), l2pre.detach()
+
+
+def proposed_step(net1, net2, criterion, corr, opt1, opt2, inphase, outphase, aug_pairs,
+                  targets1, targets2, rate, temperature=1.0, segcor_weight=(1.0, 10.0),
+                  reverse=None):
+    """One AIDE co-teaching step. ``aug_pairs`` = list of (imgmodal1_k, imgmodal2_k);
+    ``reverse`` = callable(list_of_logits)->list_of_logits (identity when None; the PIL
+    reverse-augmentation of :81-95 is outside the hot path for parity runs)."""
+    a1, a2 = [], []
+    for xin, xout in aug_pairs:                                   # :265-269 (train-mode BN!)
+        a1.append(net1(xin, xout).detach())
+        a2.append(net2(xin, xout).detach())
+    if reverse is not None:
+        a1, a2 = reverse(a1), reverse(a2)
+    pl1, wm1 = pseudo_labels(a1, temperature)
+    pl2, wm2 = pseudo_labels(a2, temperature)
+    opt1.zero_grad()
+    opt2.zero_grad()
+    o1 = net1(inphase, outphase)
+    o2 = net2(inphase, outphase)
+    loss1, loss2, indx1, indx2, l1pre, l2pre = proposed_losses(
+        criterion, corr, o1, o2, targets1, targets2, pl1, wm1, pl2, wm2, rate, segcor_weight)
+    loss1.backward(retain_graph=True)                             # :322-325
+    opt1.step()
+    loss2.backward()
+    opt2.step()
+    return dict(outputs1=o1.detach(), outputs2=o2.detach(), loss1=loss1.detach(),
+                loss2=loss2.detach(), indx1=indx1, indx2=indx2, loss1_pre=l1pre, loss2_pre=l2pre)
