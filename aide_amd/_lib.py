@@ -1,0 +1,74 @@
+"""ctypes binding of libaide_hip.so. Prototypes are parsed from include/aide_hip.h so the header is
+the single source of truth for the C ABI. There is NO fallback: if the library is missing the
+import of any compute entry point fails loudly."""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HEADER = os.path.join(ROOT, 'include', 'aide_hip.h')
+LIB_PATH = os.path.join(HERE, 'libaide_hip.so')
+
+_SCALARS = {
+    'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float, 'size_t': ctypes.c_size_t,
+    'aide_stream_t': ctypes.c_void_p,
+}
+
+
+def _ctype(decl):
+    decl = re.sub(r'/\*.*?\*/', '', decl).strip()
+    if '*' in decl:
+        return ctypes.c_void_p
+    toks = [t for t in decl.split() if t != 'const']
+    ty = toks[0] if len(toks) <= 2 else ' '.join(toks[:-1])
+    if ty not in _SCALARS:
+        raise ValueError('unknown C type in header: %r' % decl)
+    return _SCALARS[ty]
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every function declared in the header."""
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
+    src = re.sub(r'//[^\n]*', ' ', src)
+    protos = {}
+    for m in re.finditer(r'\b(int|size_t)\s+(aide_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        argl = [a.strip() for a in args.split(',')] if args.strip() and args.strip() != 'void' else []
+        protos[name] = (_SCALARS[ret], [_ctype(a) for a in argl])
+    return protos
+
+
+class _Lib(object):
+    def __init__(self):
+        self._dll = None
+        self.protos = parse_header()
+
+    def load(self):
+        if self._dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    'aide_amd: %s is missing. Build it with `python -m aide_amd.build` '
+                    '(hipcc, gfx950). There is no CPU/eager fallback.' % LIB_PATH)
+            dll = ctypes.CDLL(LIB_PATH)
+            for name, (ret, args) in self.protos.items():
+                fn = getattr(dll, name)          # AttributeError if the symbol is not exported
+                fn.restype = ret
+                fn.argtypes = args
+            self._dll = dll
+        return self._dll
+
+    def __getattr__(self, name):
+        if name.startswith('aide_'):
+            return getattr(self.load(), name)
+        raise AttributeError(name)
+
+
+lib = _Lib()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('aide_amd: %s failed with code %d (%s)' % (
+            what, rc, 'bad argument' if rc < 0 else 'hipError'))

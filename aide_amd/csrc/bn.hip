@@ -1,0 +1,286 @@
+// Training-mode BatchNorm2d + ReLU, forward and backward, as HBM-bound streaming kernels (gfx950).
+//
+// Replaces (reference): nn.BatchNorm2d (train) + nn.ReLU at models_twomodalinputs/netblocks.py:
+// 25,27,28,18 / UNet.py:20,22,23,13 and their autograd backward.
+//
+//   forward : mean_c, var_c (biased) over (N,H,W);  a = relu(gamma*(z-mean)*rstd + beta)
+//             running_mean <- (1-m) rm + m mean ; running_var <- (1-m) rv + m var n/(n-1) ; nbt += 1
+//   backward: dy = dA * (a > 0);  dbeta = sum dy;  dgamma = sum dy*xhat
+//             dz = gamma*rstd*(dy - dbeta/n - xhat*dgamma/n);  dbias_conv = sum dz (== 0 up to rounding)
+//
+// All tensors are NCHW planes with an explicit batch stride, so a tensor may be a channel slice of a
+// larger (concatenation) buffer; this is how torch.cat is eliminated (fuseunet.py:49, netblocks.py:145).
+// Reductions: fp64 accumulation per thread -> fixed-order tree -> per-(channel,split) partials ->
+// finalize in channel order.  No atomics: results are bit-reproducible run to run.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- statistics (sum, sum of squares)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, long z_bs, int N, int C,
+                                                       int HW, int splits, double* __restrict__ partials) {
+    __shared__ double sm[2 * 4];
+    const int c = blockIdx.x % C, s = blockIdx.x / C;
+    const long total4 = (long)N * HW / 4;
+    const long per = (total4 + splits - 1) / splits;
+    const long beg = s * per, end = min(beg + per, total4);
+    const int hw4 = HW / 4;
+    double acc[2] = {0.0, 0.0};
+    for (long i = beg + threadIdx.x; i < end; i += 256) {
+        const long n = i / hw4, p = i - n * hw4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(z + n * z_bs + (long)c * HW + p * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double d = (double)v[k];
+            acc[0] += d;
+            acc[1] += d * d;
+        }
+    }
+    block_sum_d<2>(acc, sm);
+    if (threadIdx.x == 0) {
+        partials[((long)c * splits + s) * 2 + 0] = acc[0];
+        partials[((long)c * splits + s) * 2 + 1] = acc[1];
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ partials, int splits, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, long long* __restrict__ nbt,
+                                   float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < splits; ++k) {
+        s += partials[((long)c * splits + k) * 2 + 0];
+        ss += partials[((long)c * splits + k) * 2 + 1];
+    }
+    const double mean = s / count;
+    double var = ss / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+    mean_out[c] = (float)mean;
+    rstd_out[c] = rstd;
+    const float sc = g * rstd;
+    scale_out[c] = sc;
+    shift_out[c] = b - (float)mean * sc;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// eval mode: scale/shift from running statistics
+__global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                     float* __restrict__ scale_out, float* __restrict__ shift_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rstd = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.0f) * rstd;
+    scale_out[c] = sc;
+    shift_out[c] = (beta ? beta[c] : 0.0f) - rm[c] * sc;
+}
+
+// ---------------------------------------------------------------- a = relu(z*scale + shift)
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ z, long z_bs,
+                                                            float* __restrict__ a, long a_bs, int C, int HW,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu) {
+    const int plane = blockIdx.y;                 // n*C + c
+    const int n = plane / C, c = plane - n * C;
+    const float sc = scale[c], sh = shift[c];
+    const float* zp = z + (long)n * z_bs + (long)c * HW;
+    float* ap = a + (long)n * a_bs + (long)c * HW;
+    const int hw4 = HW / 4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw4; i += gridDim.x * 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(zp + i * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float y = fmaf(v[k], sc, sh);
+            v[k] = relu ? fmaxf(y, 0.0f) : y;
+        }
+        *reinterpret_cast<f32x4*>(ap + i * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------- backward reductions
+// partials[c][s] = { sum dy, sum dy*xhat } with dy = dA * (z*scale+shift > 0)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dA, long d_bs,
+                                                            const float* __restrict__ z, long z_bs, int N,
+                                                            int C, int HW, int splits,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu,
+                                                            double* __restrict__ partials) {
+    __shared__ double sm[2 * 4];
+    const int c = blockIdx.x % C, s = blockIdx.x / C;
+    const long total4 = (long)N * HW / 4;
+    const long per = (total4 + splits - 1) / splits;
+    const long beg = s * per, end = min(beg + per, total4);
+    const int hw4 = HW / 4;
+    const float mu = mean[c], rs = rstd[c], sc = scale[c], sh = shift[c];
+    double acc[2] = {0.0, 0.0};
+    for (long i = beg + threadIdx.x; i < end; i += 256) {
+        const long n = i / hw4, p = i - n * hw4;
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + n * z_bs + (long)c * HW + p * 4);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dA + n * d_bs + (long)c * HW + p * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool on = !relu || fmaf(zv[k], sc, sh) > 0.0f;
+            const float dy = on ? dv[k] : 0.0f;
+            const float xh = (zv[k] - mu) * rs;
+            acc[0] += (double)dy;
+            acc[1] += (double)dy * (double)xh;
+        }
+    }
+    block_sum_d<2>(acc, sm);
+    if (threadIdx.x == 0) {
+        partials[((long)c * splits + s) * 2 + 0] = acc[0];
+        partials[((long)c * splits + s) * 2 + 1] = acc[1];
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int splits, int C, double count,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ coef /* [2][C]: dbeta/n, dgamma/n */) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, sx = 0.0;
+    for (int k = 0; k < splits; ++k) {
+        s += partials[((long)c * splits + k) * 2 + 0];
+        sx += partials[((long)c * splits + k) * 2 + 1];
+    }
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)sx;
+    coef[c] = (float)(s / count);
+    coef[C + c] = (float)(sx / count);
+}
+
+// dz = scale*(dy - c0 - xhat*c1); also per-(channel,split) partial of sum dz (conv bias gradient)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dA, long d_bs,
+                                                           const float* __restrict__ z, long z_bs,
+                                                           float* __restrict__ dz, long dz_bs, int N, int C,
+                                                           int HW, int splits, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int relu,
+                                                           const float* __restrict__ coef,
+                                                           double* __restrict__ dzsum_partials) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x % C, s = blockIdx.x / C;
+    const long total4 = (long)N * HW / 4;
+    const long per = (total4 + splits - 1) / splits;
+    const long beg = s * per, end = min(beg + per, total4);
+    const int hw4 = HW / 4;
+    const float mu = mean[c], rs = rstd[c], sc = scale[c], sh = shift[c];
+    const float c0 = coef[c], c1 = coef[C + c];
+    double acc[1] = {0.0};
+    for (long i = beg + threadIdx.x; i < end; i += 256) {
+        const long n = i / hw4, p = i - n * hw4;
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + n * z_bs + (long)c * HW + p * 4);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dA + n * d_bs + (long)c * HW + p * 4);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool on = !relu || fmaf(zv[k], sc, sh) > 0.0f;
+            const float dy = on ? dv[k] : 0.0f;
+            const float xh = (zv[k] - mu) * rs;
+            o[k] = sc * (dy - c0 - xh * c1);
+            acc[0] += (double)o[k];
+        }
+        *reinterpret_cast<f32x4*>(dz + n * dz_bs + (long)c * HW + p * 4) = o;
+    }
+    block_sum_d<1>(acc, sm);
+    if (threadIdx.x == 0 && dzsum_partials) dzsum_partials[(long)c * splits + s] = acc[0];
+}
+
+__global__ void channel_partials_finalize_kernel(const double* __restrict__ partials, int splits, int C,
+                                                 float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < splits; ++k) s += partials[(long)c * splits + k];
+    out[c] = (float)s;
+}
+
+int pick_splits(int N, int C, int HW) {
+    const long total4 = (long)N * HW / 4;
+    int s = (int)((2048 + C - 1) / C);
+    const long maxs = (total4 + 255) / 256;       // at least one float4 per thread
+    if (s > maxs) s = (int)maxs;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+// workspace doubles needed by the BN kernels for a C-channel tensor
+size_t aide_bn_ws_bytes(int C) { return (size_t)C * 64 * 2 * sizeof(double) + (size_t)2 * C * sizeof(float); }
+
+// Batch statistics + running-stat update + (scale, shift) for the apply kernel.
+int aide_bn_train_stats(const float* z, int64_t z_bs, int N, int C, int H, int W, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean,
+                        float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                        float* scale, float* shift, void* ws, hipStream_t stream) {
+    const int HW = H * W;
+    if (!z || !ws || HW % 4 != 0 || z_bs % 4 != 0) return AIDE_ERR_ARG;
+    const int splits = pick_splits(N, C, HW);
+    double* partials = (double*)ws;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW,
+                       splits, partials);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, partials, splits, C,
+                       (double)N * HW, gamma, beta, eps, momentum, running_mean, running_var,
+                       num_batches_tracked, mean, rstd, scale, shift);
+    return aide_launch_status();
+}
+
+int aide_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, C, gamma, beta,
+                       running_mean, running_var, eps, scale, shift);
+    return aide_launch_status();
+}
+
+int aide_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
+                       const float* scale, const float* shift, int relu, hipStream_t stream) {
+    const int HW = H * W;
+    if (HW % 4 != 0 || z_bs % 4 != 0 || a_bs % 4 != 0) return AIDE_ERR_ARG;
+    const int gx = max(1, min((HW / 4 + 255) / 256, 16));
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a,
+                       (long)a_bs, C, HW, scale, shift, relu);
+    return aide_launch_status();
+}
+
+// Backward of relu(bn(z)): dA -> dz, dgamma, dbeta, and the (mathematically zero) conv-bias grad.
+int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs, float* dz, int64_t dz_bs,
+                     int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
+                     const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws,
+                     hipStream_t stream) {
+    const int HW = H * W;
+    if (HW % 4 != 0 || z_bs % 4 != 0 || d_bs % 4 != 0 || dz_bs % 4 != 0 || !ws) return AIDE_ERR_ARG;
+    const int splits = pick_splits(N, C, HW);
+    double* partials = (double*)ws;
+    float* coef = (float*)((char*)ws + (size_t)C * 64 * 2 * sizeof(double));
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z,
+                       (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, partials, splits, C,
+                       (double)N * HW, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z,
+                       (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, coef,
+                       dbias ? partials : (double*)nullptr);
+    if (dbias)
+        hipLaunchKernelGGL(channel_partials_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream,
+                           partials, splits, C, dbias);
+    return aide_launch_status();
+}
+
+}  // extern "C"

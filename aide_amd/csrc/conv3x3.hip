@@ -1,0 +1,370 @@
+// 3x3 / stride 1 / pad 1 convolution as an fp32 MFMA implicit GEMM for gfx950 (CDNA4).
+//
+// Replaces (reference): nn.Conv2d(ci, co, 3, padding=1) forward and its autograd dgrad at
+//   models_twomodalinputs/netblocks.py:17,24,26 and models_singlemodalinput/UNet.py:12,19,21.
+//
+// GEMM view (per image):  D[co][pix] = sum_{ci,tap} Wp[ci][tap][co] * X[ci][pix shifted by tap]
+//   * output channels sit on the MFMA *row* index i, pixels on the *column* index j, so that
+//     one accumulator register of a wave covers 32 consecutive pixels of one NCHW row
+//     (128-B contiguous stores, no transposition);
+//   * v_mfma_f32_32x32x2_f32: exact fp32 FMA chain, 64 cycles/instruction/SIMD; the two K slots
+//     of one instruction are an even/odd input-channel pair at the same filter tap, so every
+//     LDS fragment address is  lane_base + compile-time immediate  (no VALU in the k-loop);
+//   * a workgroup (4 waves) owns TCO output channels x (PT_H x PT_W) pixels of one image and
+//     walks the input channels CK at a time: halo tile [CK][PT_H+2][PT_W+2] and filter block
+//     [CK][9][TCO] are staged global -> registers -> LDS, the next chunk's global loads are in
+//     flight while the MFMAs of the current chunk run;
+//   * dgrad is the same kernel on the packed, 180-degree-rotated, channel-transposed filter;
+//   * deep layers with few pixels use split-K over input-channel chunks into slabs that a
+//     second kernel sums in a fixed order (deterministic).
+//
+// Weights are consumed in the packed layout Wp[Cin_pad][9][Cout] produced by
+// aide_conv3x3_pack_weights (Cin padded with zero rows up to the chunk size).
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* x;
+    const float* wp;
+    const float* bias;
+    float* y;
+    long x_bs, y_bs, split_stride;
+    int N, Cin, H, W, Cout, ldw;
+    int tiles_w, tiles_h, n_co_tiles, splitk, chunks_total, accumulate;
+};
+
+template <int TCO, int WAVES_M, int WM, int WN, int PT_W, int CK>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) {
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int RPT = 32 / PT_W;                 // image rows covered by one 32-pixel MFMA tile
+    constexpr int PT_H = WAVES_N * WN * RPT;
+    constexpr int RS = PT_W + 2;                   // LDS row stride of the halo tile
+    constexpr int CS = (PT_H + 2) * RS;            // LDS channel stride
+    constexpr int XL = ((CK * CS + 3) / 4) * 4;    // halo tile floats (16-B aligned end)
+    constexpr int WL = CK * 9 * TCO;               // filter block floats
+    constexpr int EX = (CK * CS + 255) / 256;      // halo elements per thread
+    constexpr int WV = (WL / 4 + 255) / 256;       // filter float4 per thread
+    static_assert(TCO == WAVES_M * WM * 32, "tile mismatch");
+    static_assert(CK % 2 == 0, "channel pairs");
+
+    __shared__ __attribute__((aligned(16))) float lds[XL + WL];
+    float* xl = lds;
+    float* wl = lds + XL;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    const int wave_m = wid / WAVES_N, wave_n = wid % WAVES_N;
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int co_tile = b % a.n_co_tiles; b /= a.n_co_tiles;
+    const int split = b % a.splitk;       b /= a.splitk;
+    const int tw = b % a.tiles_w;         b /= a.tiles_w;
+    const int th = b % a.tiles_h;
+    const int n = b / a.tiles_h;
+    const int h0 = th * PT_H, w0 = tw * PT_W, co0 = co_tile * TCO;
+    const int HW = a.H * a.W;
+
+    const int cps = (a.chunks_total + a.splitk - 1) / a.splitk;
+    const int c_begin = split * cps;
+    const int c_end = min(c_begin + cps, a.chunks_total);
+
+    // ---- per-thread staging descriptors (identical for every chunk) ----
+    // Descriptor base sits (W+1) floats before the block's first pixel so that all halo offsets are
+    // non-negative; out-of-image elements carry the BUF_OOB offset and read as 0.0f in hardware.
+    unsigned goff[EX];
+#pragma unroll
+    for (int e = 0; e < EX; ++e) {
+        const int idx = tid + e * 256;
+        const int c = idx / CS, rem = idx - c * CS;
+        const int r = rem / RS, col = rem - r * RS;
+        const int ih = h0 - 1 + r, iw = w0 - 1 + col;
+        const bool ok = (idx < CK * CS) && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        goff[e] = ok ? (unsigned)(c * HW + r * a.W + col) * 4u : BUF_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t xrs =
+        make_rsrc(a.x + (long)n * a.x_bs + (long)h0 * a.W + w0 - (a.W + 1));
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.wp + co0);
+    unsigned woff[WV];
+#pragma unroll
+    for (int v = 0; v < WV; ++v) {
+        const int f = tid + v * 256;
+        const int row = f / (TCO / 4), c4 = f - row * (TCO / 4);
+        woff[v] = (f < WL / 4) ? (unsigned)(row * a.ldw + c4 * 4) * 4u : BUF_OOB;
+    }
+    const bool ragged_c = (a.Cin % CK) != 0;   // only the 3-channel stems
+
+    float xr[EX];
+    f32x4 wr[WV];
+    auto load_chunk = [&](int chunk) {
+        const int ci0 = chunk * CK;
+        const unsigned xs = (unsigned)ci0 * (unsigned)HW * 4u;
+#pragma unroll
+        for (int e = 0; e < EX; ++e) {
+            unsigned off = goff[e];
+            if (ragged_c && (ci0 + (tid + e * 256) / CS) >= a.Cin) off = BUF_OOB;
+            xr[e] = buf_load_f32(xrs, off, xs);
+        }
+        const unsigned wsoff = (unsigned)ci0 * 9u * (unsigned)a.ldw * 4u;
+#pragma unroll
+        for (int v = 0; v < WV; ++v) wr[v] = buf_load_f32x4(wrs, woff[v], wsoff);
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int e = 0; e < EX; ++e) {
+            const int idx = tid + e * 256;
+            if (idx < CK * CS) xl[idx] = xr[e];
+        }
+#pragma unroll
+        for (int v = 0; v < WV; ++v) {
+            const int f = tid + v * 256;
+            if (f < WL / 4) *reinterpret_cast<f32x4*>(wl + f * 4) = wr[v];
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.0f;
+
+    // lane bases of the MFMA operand fragments
+    const float* la = wl + half * 9 * TCO + wave_m * WM * 32 + j;
+    const float* lb = xl + half * CS + (wave_n * WN * RPT + j / PT_W) * RS + (j % PT_W);
+
+    if (c_begin < c_end) load_chunk(c_begin);
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        __syncthreads();                       // previous chunk's fragments fully consumed
+        store_chunk();
+        __syncthreads();
+        if (chunk + 1 < c_end) load_chunk(chunk + 1);   // in flight during the MFMAs below
+        {
+            // explicit one-step-ahead fragment pipeline over the CK/2 * 9 (channel pair, tap) steps
+            constexpr int STEPS = (CK / 2) * 9;
+            float af[2][WM], bf[2][WN];
+            auto frag = [&](int s, int buf) {
+                const int q = s / 9, t = s % 9;          // compile-time after unrolling
+                const int kh = t / 3, kw = t % 3;
+#pragma unroll
+                for (int m = 0; m < WM; ++m) af[buf][m] = la[(2 * q * 9 + t) * TCO + m * 32];
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt)
+                    bf[buf][nt] = lb[2 * q * CS + (kh + nt * RPT) * RS + kw];
+            };
+            frag(0, 0);
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                if (s + 1 < STEPS) frag(s + 1, (s + 1) & 1);
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < WN; ++nt)
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][m], bf[s & 1][nt],
+                                                                          acc[m][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue: D layout row i = (r&3) + 8*(r>>2) + 4*half, col j ----
+    float* yn = a.y + (long)split * a.split_stride + (long)n * a.y_bs;
+    const bool add_bias = (a.bias != nullptr) && (split == 0);
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+        const int oh = h0 + (wave_n * WN + nt) * RPT + j / PT_W;
+        const int ow = w0 + (j % PT_W);
+        const bool pok = oh < a.H && ow < a.W;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (pok && co < a.Cout) {
+                    float v = acc[m][nt][r];
+                    if (add_bias) v += a.bias[co];
+                    float* p = yn + (long)co * HW + oh * a.W + ow;
+                    if (a.accumulate) v += *p;
+                    *p = v;
+                }
+            }
+        }
+    }
+}
+
+// y[n][c][p] (+)= bias[c] + sum_s slab[s][n][c][p]   (fixed summation order)
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long split_stride, int splitk,
+                                     float* __restrict__ y, long y_bs, int C, int HW,
+                                     const float* __restrict__ bias, int accumulate, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const long chw = (long)C * HW;
+        const long n = i / chw, rem = i - n * chw;
+        float v = slabs[i];
+        for (int s = 1; s < splitk; ++s) v += slabs[(long)s * split_stride + i];
+        if (bias) v += bias[rem / HW];
+        float* p = y + n * y_bs + rem;
+        if (accumulate) v += *p;
+        *p = v;
+    }
+}
+
+// w[Co][Ci][9] -> wf[Ci_pad][9][Co] (forward) and wd[Co_pad][9][Ci] with the taps reversed
+// (dgrad: 180-degree rotation + channel transpose). Padding rows are zero.
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                                    float* __restrict__ wd, int Co, int Ci, int ci_pad, int co_pad) {
+    const long nf = (long)ci_pad * 9 * Co, nd = wd ? (long)co_pad * 9 * Ci : 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd;
+         i += (long)gridDim.x * blockDim.x) {
+        if (i < nf) {
+            const int co = (int)(i % Co);
+            const long r = i / Co;
+            const int t = (int)(r % 9), ci = (int)(r / 9);
+            wf[i] = (ci < Ci) ? w[((long)co * Ci + ci) * 9 + t] : 0.0f;
+        } else {
+            const long k = i - nf;
+            const int ci = (int)(k % Ci);
+            const long r = k / Ci;
+            const int t = (int)(r % 9), co = (int)(r / 9);
+            wd[k] = (co < Co) ? w[((long)co * Ci + ci) * 9 + (8 - t)] : 0.0f;
+        }
+    }
+}
+
+template <int TCO, int WAVES_M, int WM, int WN, int PT_W, int CK>
+int launch_cfg(ConvArgs a, hipStream_t stream) {
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int PT_H = WAVES_N * WN * (32 / PT_W);
+    a.tiles_w = (a.W + PT_W - 1) / PT_W;
+    a.tiles_h = (a.H + PT_H - 1) / PT_H;
+    a.n_co_tiles = (a.Cout + TCO - 1) / TCO;
+    a.chunks_total = (a.Cin + CK - 1) / CK;
+    const long nb = (long)a.tiles_w * a.tiles_h * a.N * a.n_co_tiles * a.splitk;
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TCO, WAVES_M, WM, WN, PT_W, CK>), dim3((unsigned)nb),
+                       dim3(256), 0, stream, a);
+    return aide_launch_status();
+}
+
+template <int PT_W>
+int launch_ptw(int variant, int ck, const ConvArgs& a, hipStream_t s) {
+    // variant: 0 = 32co x 256px, 1 = 64co x 256px, 2 = 128co x 256px, 3 = 64co x 128px,
+    //          4 = 64co x 64px, 5 = 128co x 128px
+    if (ck == 4) {
+        switch (variant) {
+            case 0: return launch_cfg<32, 1, 1, 2, PT_W, 4>(a, s);
+            case 1: return launch_cfg<64, 2, 1, 4, PT_W, 4>(a, s);
+            default: return AIDE_ERR_ARG;
+        }
+    }
+    switch (variant) {
+        case 0: return launch_cfg<32, 1, 1, 2, PT_W, 8>(a, s);
+        case 1: return launch_cfg<64, 2, 1, 4, PT_W, 8>(a, s);
+        case 2: return launch_cfg<128, 2, 2, 4, PT_W, 8>(a, s);
+        case 3: return launch_cfg<64, 2, 1, 2, PT_W, 8>(a, s);
+        case 4: return launch_cfg<64, 2, 1, 1, PT_W, 8>(a, s);
+        case 5: return launch_cfg<128, 2, 2, 2, PT_W, 8>(a, s);
+        default: return AIDE_ERR_ARG;
+    }
+}
+
+int pick_ptw(int W) {
+    int best = 32, waste = ((W + 31) / 32) * 32;
+    for (int p : {16, 8}) {
+        const int cover = ((W + p - 1) / p) * p;
+        if (cover < waste) { waste = cover; best = p; }
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Chunk size (input-channel padding granule) the packed weights must use for a given Cin.
+int aide_conv3x3_chunk(int Cin) { return Cin < 8 ? 4 : 8; }
+
+int aide_conv3x3_pack_weights(const float* w, float* wf, float* wd, int Co, int Ci, int ci_pad,
+                              int co_pad, hipStream_t stream) {
+    const long total = (long)ci_pad * 9 * Co + (wd ? (long)co_pad * 9 * Ci : 0);
+    const int blocks = (int)min((total + 255) / 256, (long)4096);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, w, wf, wd, Co, Ci,
+                       ci_pad, co_pad);
+    return aide_launch_status();
+}
+
+// Heuristic plan for one conv problem: returns variant | (splitk << 8).
+int aide_conv3x3_plan(int N, int Cin, int H, int W, int Cout) {
+    const int ptw = pick_ptw(W);
+    auto nblocks = [&](int tco, int px) {
+        const int pth = px / ptw;
+        return (long)((W + ptw - 1) / ptw) * ((H + pth - 1) / pth) * N * ((Cout + tco - 1) / tco);
+    };
+    const int ck = aide_conv3x3_chunk(Cin);
+    int variant;
+    if (Cout % 64 != 0) variant = 0;
+    else if (ck == 4) variant = 1;
+    else if (Cout % 128 == 0 && nblocks(128, 256) >= 512) variant = 2;
+    else if (nblocks(64, 256) >= 512) variant = 1;
+    else if (Cout % 128 == 0 && nblocks(128, 128) >= 512) variant = 5;
+    else if (nblocks(64, 128) >= 384) variant = 3;
+    else variant = 4;
+    int splitk = 1;
+    if (variant == 4) {
+        const long nb = nblocks(64, 64);
+        const int chunks = (Cin + ck - 1) / ck;
+        while (nb * splitk < 384 && splitk * 2 <= chunks / 8) splitk *= 2;
+    }
+    return variant | (splitk << 8);
+}
+
+size_t aide_conv3x3_ws_bytes(int N, int H, int W, int Cout, int splitk) {
+    return splitk > 1 ? (size_t)splitk * N * Cout * H * W * sizeof(float) : 0;
+}
+
+// Implicit-GEMM 3x3 convolution on packed weights. Used for forward (wp = forward pack, bias) and
+// for dgrad (x = dY, wp = dgrad pack, bias = NULL, Cin/Cout swapped by the caller).
+//   x  : [N][Cin][H][W] with batch stride x_bs (floats)    y : [N][Cout][H][W], batch stride y_bs
+//   plan: value from aide_conv3x3_plan (or -1 = choose here); ws: split-K slabs (may be NULL if
+//   the plan has splitk == 1). accumulate != 0 -> y += result.
+int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, const float* bias,
+                       float* y, int64_t y_bs, int N, int Cin, int H, int W, int Cout,
+                       int accumulate, int plan, float* ws, hipStream_t stream) {
+    if (!x || !wp || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return AIDE_ERR_ARG;
+    if (Cout % 32 != 0) return AIDE_ERR_ARG;
+    if (plan < 0) plan = aide_conv3x3_plan(N, Cin, H, W, Cout);
+    const int variant = plan & 0xff;
+    int splitk = plan >> 8;
+    if (splitk < 1) splitk = 1;
+    if (splitk > 1 && !ws) return AIDE_ERR_ARG;
+    const int ck = aide_conv3x3_chunk(Cin);
+    const int chunks = (Cin + ck - 1) / ck;
+    if (splitk > chunks) splitk = chunks;
+    ConvArgs a;
+    a.x = x; a.wp = wp; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
+    a.ldw = ldw; a.splitk = splitk;
+    if (splitk > 1) {
+        a.y = ws; a.y_bs = (long)Cout * H * W; a.split_stride = (long)N * Cout * H * W;
+        a.bias = nullptr; a.accumulate = 0;
+    } else {
+        a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = accumulate;
+    }
+    int rc;
+    switch (pick_ptw(W)) {
+        case 32: rc = launch_ptw<32>(variant, ck, a, stream); break;
+        case 16: rc = launch_ptw<16>(variant, ck, a, stream); break;
+        default: rc = launch_ptw<8>(variant, ck, a, stream); break;
+    }
+    if (rc != 0) return rc;
+    if (splitk > 1) {
+        const long total = (long)N * Cout * H * W;
+        const int blocks = (int)min((total + 255) / 256, (long)2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws,
+                           (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias,
+                           accumulate, total);
+        rc = aide_launch_status();
+    }
+    return rc;
+}
+
+}  // extern "C"

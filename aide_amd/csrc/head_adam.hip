@@ -1,0 +1,232 @@
+// 1x1 head convolution (64 -> num_classes) forward/backward and fused multi-tensor Adam(amsgrad).
+//
+// Replaces (reference):
+//   last_conv1 = nn.Conv2d(64, num_classes, 1)  models_twomodalinputs/fuseunet.py:41,89,
+//                                               models_singlemodalinput/UNet.py:150,164
+//   torch.optim.Adam(net.parameters(), lr, amsgrad=True)  train_files/trainchaos_comparison_1case.py:170
+// Both are HBM-bound: the head reads 64 planes once (MFMA is pointless at N = 2 output channels);
+// Adam streams 20 B/param in and 16 B/param out.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXK = 4;      // num_classes supported by the head kernels (reference uses 2)
+
+template <int K>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, long x_bs,
+                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                       float* __restrict__ y, long y_bs, int C, int HW,
+                                                       long total4) {
+    extern __shared__ float ws[];                 // [K][C]
+    for (int i = threadIdx.x; i < K * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int hw4 = HW / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long n = i / hw4, p = i - n * hw4;
+        const float* xp = x + n * x_bs + p * 4;
+        f32x4 acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { const float bk = b ? b[k] : 0.f; acc[k] = f32x4{bk, bk, bk, bk}; }
+        for (int c = 0; c < C; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (long)c * HW);
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += ws[k * C + c] * v;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) *reinterpret_cast<f32x4*>(y + n * y_bs + (long)k * HW + p * 4) = acc[k];
+    }
+}
+
+// dx[n][c][p] = sum_k dy[n][k][p] w[k][c]
+template <int K>
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dy, long dy_bs,
+                                                         const float* __restrict__ w, float* __restrict__ dx,
+                                                         long dx_bs, int C, int HW, long total4) {
+    extern __shared__ float ws[];
+    for (int i = threadIdx.x; i < K * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int hw4 = HW / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long n = i / hw4, p = i - n * hw4;
+        f32x4 g[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) g[k] = *reinterpret_cast<const f32x4*>(dy + n * dy_bs + (long)k * HW + p * 4);
+        float* xp = dx + n * dx_bs + p * 4;
+        for (int c = 0; c < C; ++c) {
+            f32x4 v = ws[c] * g[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) v += ws[k * C + c] * g[k];
+            *reinterpret_cast<f32x4*>(xp + (long)c * HW) = v;
+        }
+    }
+}
+
+// partial[b][k][c] = sum over this block's pixels of dy[k] * x[c];  partial[b][K*C + k] = sum dy[k]
+template <int K>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dy, long dy_bs,
+                                                         const float* __restrict__ x, long x_bs, int C, int HW,
+                                                         long total4, double* __restrict__ partials) {
+    __shared__ double sm[4][K + 1];
+    const int hw4 = HW / 4;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // each thread keeps dy of its pixels; channels are walked in the outer loop so that the block
+    // reduction cost (K shuffles-trees per channel) is amortised over all of the block's pixels
+    const int stride = gridDim.x * 256;
+    double bsum[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) bsum[k] = 0.0;
+    for (int c = -1; c < C; ++c) {
+        double acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = 0.0;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+            const long n = i / hw4, p = i - n * hw4;
+            f32x4 v = {1.f, 1.f, 1.f, 1.f};
+            if (c >= 0) v = *reinterpret_cast<const f32x4*>(x + n * x_bs + (long)c * HW + p * 4);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(dy + n * dy_bs + (long)k * HW + p * 4);
+                acc[k] += (double)(g[0] * v[0]) + (double)(g[1] * v[1]) + (double)(g[2] * v[2]) + (double)(g[3] * v[3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = wave_sum_d(acc[k]);
+        __syncthreads();
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < K; ++k) sm[wid][k] = acc[k];
+        __syncthreads();
+        if (threadIdx.x < K) {
+            const double s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+            const int slot = (c >= 0) ? threadIdx.x * C + c : K * C + threadIdx.x;
+            partials[(long)blockIdx.x * (K * C + K) + slot] = s;
+        }
+    }
+}
+
+__global__ void head_wgrad_finalize_kernel(const double* __restrict__ partials, int nblocks, int KC, int K,
+                                           float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= KC + K) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partials[(long)b * (KC + K) + i];
+    if (i < KC) dw[i] = (float)s;
+    else if (db) db[i - KC] = (float)s;
+}
+
+// ---------------------------------------------------------------- Adam (amsgrad), multi-tensor
+struct AdamArgs {
+    float* const* p; const float* const* g; float* const* m; float* const* v; float* const* vmax;
+    const long* sizes; const long* block_start;      // prefix of 1024-element blocks per tensor
+    int ntensors;
+    float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt;
+    int amsgrad;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
+    // binary search the tensor owning this 1024-element block
+    const long blk = blockIdx.x;
+    int lo = 0, hi = a.ntensors - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.block_start[mid] <= blk) lo = mid; else hi = mid - 1;
+    }
+    const int t = lo;
+    const long base = (blk - a.block_start[t]) * 1024;
+    const long n = a.sizes[t];
+    float* p = a.p[t]; const float* g = a.g[t];
+    float* m = a.m[t]; float* v = a.v[t]; float* vm = a.vmax[t];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long i = base + k * 256 + threadIdx.x;
+        if (i < n) {
+            float gi = g[i];
+            const float pi = p[i];
+            if (a.weight_decay != 0.f) gi += a.weight_decay * pi;
+            const float mi = a.beta1 * m[i] + (1.f - a.beta1) * gi;
+            const float vi = a.beta2 * v[i] + (1.f - a.beta2) * gi * gi;
+            m[i] = mi; v[i] = vi;
+            float vhat = vi;
+            if (a.amsgrad) { vhat = fmaxf(vm[i], vi); vm[i] = vhat; }
+            const float denom = sqrtf(vhat) / a.bc2_sqrt + a.eps;
+            p[i] = pi - (a.lr / a.bc1) * (mi / denom);
+        }
+    }
+}
+
+int grid_for(long total) { return (int)max(1L, min((total + 255) / 256, 4096L)); }
+
+template <int K>
+int head_wgrad_launch(const float* dy, long dy_bs, const float* x, long x_bs, int C, int HW, long total4,
+                      double* partials, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(head_wgrad_kernel<K>, dim3(nblocks), dim3(256), 0, s, dy, dy_bs, x, x_bs, C, HW,
+                       total4, partials);
+    return aide_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int aide_head1x1_fwd(const float* x, int64_t x_bs, const float* w, const float* b, float* y, int64_t y_bs,
+                     int N, int C, int K, int H, int W, hipStream_t stream) {
+    const int HW = H * W;
+    if (K < 1 || K > MAXK || HW % 4 || x_bs % 4 || y_bs % 4) return AIDE_ERR_ARG;
+    const long total4 = (long)N * HW / 4;
+    const int grid = grid_for(total4);
+    const size_t sh = (size_t)K * C * sizeof(float);
+#define AIDE_HEAD_FWD(KK) hipLaunchKernelGGL(head_fwd_kernel<KK>, dim3(grid), dim3(256), sh, stream, x, (long)x_bs, w, b, y, (long)y_bs, C, HW, total4)
+    switch (K) { case 1: AIDE_HEAD_FWD(1); break; case 2: AIDE_HEAD_FWD(2); break; case 3: AIDE_HEAD_FWD(3); break; default: AIDE_HEAD_FWD(4); }
+#undef AIDE_HEAD_FWD
+    return aide_launch_status();
+}
+
+size_t aide_head1x1_ws_bytes(int C, int K) { return (size_t)256 * (K * C + K) * sizeof(double); }
+
+// dy: [N][K][HW] -> dx [N][C][HW] (may be NULL), dw [K][C], db [K]
+int aide_head1x1_bwd(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, const float* w, float* dx,
+                     int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
+                     hipStream_t stream) {
+    const int HW = H * W;
+    if (K < 1 || K > MAXK || HW % 4 || x_bs % 4 || dy_bs % 4 || (dx && dx_bs % 4) || !ws) return AIDE_ERR_ARG;
+    const long total4 = (long)N * HW / 4;
+    const size_t sh = (size_t)K * C * sizeof(float);
+    if (dx) {
+        const int grid = grid_for(total4);
+#define AIDE_HEAD_DG(KK) hipLaunchKernelGGL(head_dgrad_kernel<KK>, dim3(grid), dim3(256), sh, stream, dy, (long)dy_bs, w, dx, (long)dx_bs, C, HW, total4)
+        switch (K) { case 1: AIDE_HEAD_DG(1); break; case 2: AIDE_HEAD_DG(2); break; case 3: AIDE_HEAD_DG(3); break; default: AIDE_HEAD_DG(4); }
+#undef AIDE_HEAD_DG
+    }
+    const int nblocks = (int)max(1L, min((total4 + 255) / 256, 256L));
+    int rc;
+    switch (K) {
+        case 1: rc = head_wgrad_launch<1>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
+        case 2: rc = head_wgrad_launch<2>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
+        case 3: rc = head_wgrad_launch<3>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
+        default: rc = head_wgrad_launch<4>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream);
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_wgrad_finalize_kernel, dim3((K * C + K + 63) / 64), dim3(64), 0, stream,
+                       (const double*)ws, nblocks, K * C, K, dw, db);
+    return aide_launch_status();
+}
+
+// Pointer tables (device memory): p,g,m,v,vmax [ntensors]; sizes, block_start [ntensors] (int64).
+// `step` is the 1-based step count; bias corrections are folded on the host like torch.optim.Adam.
+int aide_adam_amsgrad_multi(float* const* p, const float* const* g, float* const* m, float* const* v,
+                            float* const* vmax, const int64_t* sizes, const int64_t* block_start,
+                            int ntensors, int64_t total_blocks, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int amsgrad, int64_t step, hipStream_t stream) {
+    if (ntensors <= 0 || total_blocks <= 0 || step < 1) return AIDE_ERR_ARG;
+    AdamArgs a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.vmax = vmax;
+    a.sizes = (const long*)sizes; a.block_start = (const long*)block_start; a.ntensors = ntensors;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    a.amsgrad = amsgrad;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, a);
+    return aide_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,212 @@
+// MaxPool2d(2,2) and bilinear x2 (align_corners=True) up-sampling, forward and backward (gfx950).
+//
+// Replaces (reference): nn.MaxPool2d(2,2) at models_twomodalinputs/fuseunet.py:13-31 (call sites
+// :51-78) and UNet.py:114; nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) at
+// netblocks.py:16 / UNet.py:11.  Semantics per SURVEY.md §A.2:
+//   * pool backward routes the gradient to the FIRST maximum in row-major window order
+//     ((0,0),(0,1),(1,0),(1,1); aten's test is `val > maxval`), ties are common on CHAOS data;
+//   * bilinear: src = dst*(in-1)/(out-1) in fp32, i0 = floor(src), i1 = min(i0+1, in-1).
+// All kernels are HBM-bound streaming kernels on NCHW planes with explicit batch strides.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void maxpool2x2_fwd_kernel(const float* __restrict__ x, long x_bs,
+                                                             float* __restrict__ y, long y_bs, int C, int H,
+                                                             int W, long total) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ow2 = (int)(i % (Wo / 2));               // two outputs per thread (float4 in, float2 out)
+        long r = i / (Wo / 2);
+        const int oh = (int)(r % Ho); r /= Ho;
+        const int c = (int)(r % C);
+        const long n = r / C;
+        const float* p = x + n * x_bs + (long)c * H * W + (long)(2 * oh) * W + 4 * ow2;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p + W);
+        float2 o;
+        o.x = fmaxf(fmaxf(a[0], a[1]), fmaxf(b[0], b[1]));
+        o.y = fmaxf(fmaxf(a[2], a[3]), fmaxf(b[2], b[3]));
+        *reinterpret_cast<float2*>(y + n * y_bs + (long)c * Ho * Wo + (long)oh * Wo + 2 * ow2) = o;
+    }
+}
+
+__device__ __forceinline__ int first_argmax4(float v0, float v1, float v2, float v3) {
+    int k = 0; float m = v0;
+    if (v1 > m) { m = v1; k = 1; }
+    if (v2 > m) { m = v2; k = 2; }
+    if (v3 > m) { m = v3; k = 3; }
+    return k;
+}
+
+// dx (+)= scatter of dy to the first arg-max of each window (windows do not overlap -> no atomics)
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const float* __restrict__ x, long x_bs,
+                                                             const float* __restrict__ dy, long dy_bs,
+                                                             float* __restrict__ dx, long dx_bs, int C, int H,
+                                                             int W, int accumulate, long total) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ow2 = (int)(i % (Wo / 2));
+        long r = i / (Wo / 2);
+        const int oh = (int)(r % Ho); r /= Ho;
+        const int c = (int)(r % C);
+        const long n = r / C;
+        const long in_off = (long)c * H * W + (long)(2 * oh) * W + 4 * ow2;
+        const float* p = x + n * x_bs + in_off;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p + W);
+        const float2 g = *reinterpret_cast<const float2*>(dy + n * dy_bs + (long)c * Ho * Wo + (long)oh * Wo + 2 * ow2);
+        const int k0 = first_argmax4(a[0], a[1], b[0], b[1]);
+        const int k1 = first_argmax4(a[2], a[3], b[2], b[3]);
+        f32x4 ta = {k0 == 0 ? g.x : 0.f, k0 == 1 ? g.x : 0.f, k1 == 0 ? g.y : 0.f, k1 == 1 ? g.y : 0.f};
+        f32x4 tb = {k0 == 2 ? g.x : 0.f, k0 == 3 ? g.x : 0.f, k1 == 2 ? g.y : 0.f, k1 == 3 ? g.y : 0.f};
+        float* q = dx + n * dx_bs + in_off;
+        if (accumulate) {
+            ta += *reinterpret_cast<const f32x4*>(q);
+            tb += *reinterpret_cast<const f32x4*>(q + W);
+        }
+        *reinterpret_cast<f32x4*>(q) = ta;
+        *reinterpret_cast<f32x4*>(q + W) = tb;
+    }
+}
+
+__device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+    const float src = scale * (float)dst;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, long x_bs,
+                                                             float* __restrict__ y, long y_bs, int C, int H,
+                                                             int W, long total) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ow = (int)(i % Wo);
+        long r = i / Wo;
+        const int oh = (int)(r % Ho); r /= Ho;
+        const int c = (int)(r % C);
+        const long n = r / C;
+        int h0, h1, w0, w1; float lh, lw;
+        src_index(oh, sh, H, h0, h1, lh);
+        src_index(ow, sw, W, w0, w1, lw);
+        const float* p = x + n * x_bs + (long)c * H * W;
+        const float v00 = p[h0 * W + w0], v01 = p[h0 * W + w1], v10 = p[h1 * W + w0], v11 = p[h1 * W + w1];
+        const float top = (1.f - lw) * v00 + lw * v01, bot = (1.f - lw) * v10 + lw * v11;
+        y[n * y_bs + (long)c * Ho * Wo + (long)oh * Wo + ow] = (1.f - lh) * top + lh * bot;
+    }
+}
+
+// gather form of the transpose: each source pixel sums the destination pixels that referenced it
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, long dy_bs,
+                                                             float* __restrict__ dx, long dx_bs, int C, int H,
+                                                             int W, int accumulate, long total) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int iw = (int)(i % W);
+        long r = i / W;
+        const int ih = (int)(r % H); r /= H;
+        const int c = (int)(r % C);
+        const long n = r / C;
+        // candidate destination rows/cols: dst with floor(scale*dst) in {ih-1, ih}
+        float wh[6], ww[6];
+        const int oh_lo = max(0, 2 * ih - 2), ow_lo = max(0, 2 * iw - 2);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            int a0, a1; float l;
+            const int oh = oh_lo + k;
+            wh[k] = 0.f;
+            if (oh < Ho) {
+                src_index(oh, sh, H, a0, a1, l);
+                if (a0 == ih) wh[k] += 1.f - l;
+                if (a1 == ih) wh[k] += (a1 != a0) ? l : l;      // i1 == i0 only at the last row (l == 0)
+            }
+            const int ow = ow_lo + k;
+            ww[k] = 0.f;
+            if (ow < Wo) {
+                src_index(ow, sw, W, a0, a1, l);
+                if (a0 == iw) ww[k] += 1.f - l;
+                if (a1 == iw) ww[k] += l;
+            }
+        }
+        const float* g = dy + n * dy_bs + (long)c * Ho * Wo;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (wh[k] == 0.f) continue;
+            float rowacc = 0.f;
+#pragma unroll
+            for (int l = 0; l < 6; ++l)
+                if (ww[l] != 0.f) rowacc += ww[l] * g[(long)(oh_lo + k) * Wo + ow_lo + l];
+            acc += wh[k] * rowacc;
+        }
+        float* q = dx + n * dx_bs + (long)c * H * W + (long)ih * W + iw;
+        *q = accumulate ? (*q + acc) : acc;
+    }
+}
+
+// zero a channel slice [N][C][HW] of a strided tensor
+__global__ __launch_bounds__(256) void fill_zero_kernel(float* __restrict__ p, long bs, long chw4, long total4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long n = i / chw4, r = i - n * chw4;
+        *reinterpret_cast<f32x4*>(p + n * bs + r * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+int grid_for(long total) { return (int)max(1L, min((total + 255) / 256, 8192L)); }
+
+}  // namespace
+
+extern "C" {
+
+int aide_maxpool2x2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int N, int C, int H, int W,
+                        hipStream_t stream) {
+    if (H % 2 || W % 4 || x_bs % 4 || y_bs % 2) return AIDE_ERR_ARG;
+    const long total = (long)N * C * (H / 2) * (W / 4);
+    hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
+                       (long)y_bs, C, H, W, total);
+    return aide_launch_status();
+}
+
+// x: the pool INPUT (used to recompute the arg-max), dy: grad of the pooled output, dx: grad of x.
+int aide_maxpool2x2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx,
+                        int64_t dx_bs, int N, int C, int H, int W, int accumulate, hipStream_t stream) {
+    if (H % 2 || W % 4 || x_bs % 4 || dx_bs % 4 || dy_bs % 2) return AIDE_ERR_ARG;
+    const long total = (long)N * C * (H / 2) * (W / 4);
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, dy,
+                       (long)dy_bs, dx, (long)dx_bs, C, H, W, accumulate, total);
+    return aide_launch_status();
+}
+
+int aide_upsample2x_bilinear_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int N, int C, int H,
+                                 int W, hipStream_t stream) {
+    const long total = (long)N * C * 4 * H * W;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
+                       (long)y_bs, C, H, W, total);
+    return aide_launch_status();
+}
+
+// dy: [N][C][2H][2W]  ->  dx: [N][C][H][W]
+int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int N, int C,
+                                 int H, int W, int accumulate, hipStream_t stream) {
+    const long total = (long)N * C * H * W;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, (long)dy_bs,
+                       dx, (long)dx_bs, C, H, W, accumulate, total);
+    return aide_launch_status();
+}
+
+int aide_fill_zero(float* p, int64_t bs, int N, int C, int H, int W, hipStream_t stream) {
+    const long chw = (long)C * H * W;
+    if (chw % 4 || bs % 4) return AIDE_ERR_ARG;
+    const long total4 = (long)N * chw / 4;
+    hipLaunchKernelGGL(fill_zero_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, p, (long)bs, chw / 4,
+                       total4);
+    return aide_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,246 @@
+"""Tensor-level wrappers over the C ABI (include/aide_hip.h).
+
+PyTorch is used here only for device memory and the current HIP stream; every function below
+launches hand-written gfx950 kernels from libaide_hip.so and nothing else. Inputs must live on a
+HIP device: there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from ._lib import lib, check
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('aide_amd ops need HIP device tensors (got %s); there is no CPU fallback'
+                           % (t.device if isinstance(t, torch.Tensor) else type(t)))
+    if t.dtype != dtype:
+        raise RuntimeError('aide_amd: expected dtype %s, got %s' % (dtype, t.dtype))
+    return t
+
+
+def planes(t):
+    """(data_ptr, batch_stride) of an NCHW fp32 tensor whose channel planes are dense
+    (a channel slice of a contiguous buffer qualifies)."""
+    _req(t)
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    ok = (sw == 1 or w == 1) and (sh == w or h == 1) and (sc == h * w or c == 1)
+    if not ok:
+        raise RuntimeError('aide_amd: tensor must be NCHW with dense channel planes, got strides %s'
+                           % (t.stride(),))
+    if n == 1:
+        sn = c * h * w
+    return ctypes.c_void_p(t.data_ptr()), sn
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+# ------------------------------------------------------------------------------- conv 3x3
+def conv_chunk(cin):
+    return lib.aide_conv3x3_chunk(cin)
+
+
+def pad_to(c, g):
+    return (c + g - 1) // g * g
+
+
+def pack_weights(w, need_dgrad=True):
+    """w [Co,Ci,3,3] -> (wf [ci_pad,9,Co], wd [co_pad,9,Ci] | None)."""
+    _req(w)
+    co, ci = w.shape[0], w.shape[1]
+    ci_pad, co_pad = pad_to(ci, conv_chunk(ci)), pad_to(co, conv_chunk(co))
+    wf = torch.empty(ci_pad, 9, co, device=w.device, dtype=torch.float32)
+    wd = torch.empty(co_pad, 9, ci, device=w.device, dtype=torch.float32) if need_dgrad else None
+    check(lib.aide_conv3x3_pack_weights(ptr(w), ptr(wf), ptr(wd), co, ci, ci_pad, co_pad, stream_ptr()),
+          'conv3x3_pack_weights')
+    return wf, wd
+
+
+def pack_weights_into(w, wf, wd):
+    co, ci = w.shape[0], w.shape[1]
+    check(lib.aide_conv3x3_pack_weights(ptr(w), ptr(wf), ptr(wd), co, ci, wf.shape[0],
+                                        wd.shape[0] if wd is not None else 0, stream_ptr()),
+          'conv3x3_pack_weights')
+
+
+def conv3x3_igemm(x, wp, bias, y, accumulate=False, plan=-1, ws=None):
+    """y (+)= conv3x3(x) with packed weights wp [cin_pad, 9, cout] (forward pack or dgrad pack)."""
+    xp, xbs = planes(x)
+    yp, ybs = planes(y)
+    n, cin, h, w = x.shape
+    cout = y.shape[1]
+    assert wp.shape[2] == cout and wp.shape[0] >= cin and y.shape[0] == n and y.shape[2:] == x.shape[2:]
+    if plan < 0:
+        plan = lib.aide_conv3x3_plan(n, cin, h, w, cout)
+    splitk = plan >> 8
+    if splitk > 1 and ws is None:
+        ws = torch.empty(lib.aide_conv3x3_ws_bytes(n, h, w, cout, splitk) // 4, device=x.device,
+                         dtype=torch.float32)
+    check(lib.aide_conv3x3_igemm(xp, xbs, ptr(wp), cout, ptr(bias), yp, ybs, n, cin, h, w, cout,
+                                 int(accumulate), plan, ptr(ws), stream_ptr()), 'conv3x3_igemm')
+    return y
+
+
+def conv3x3_wgrad(dz, a, dw, ws=None):
+    dp, dbs = planes(dz)
+    ap, abs_ = planes(a)
+    n, co, h, w = dz.shape
+    ci = a.shape[1]
+    assert tuple(dw.shape) == (co, ci, 3, 3) and dw.is_contiguous()
+    if ws is None:
+        ws = torch.empty(lib.aide_conv3x3_wgrad_ws_bytes(n, co, ci, h, w) // 4, device=dz.device,
+                         dtype=torch.float32)
+    check(lib.aide_conv3x3_wgrad(dp, dbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), stream_ptr()),
+          'conv3x3_wgrad')
+    return dw
+
+
+# ------------------------------------------------------------------------------- conv transpose 2x2
+def convT2x2_fwd(x, w, b, y):
+    xp, xbs = planes(x)
+    yp, ybs = planes(y)
+    n, ci, h, wd = x.shape
+    co = w.shape[1]
+    check(lib.aide_convT2x2_fwd(xp, xbs, ptr(w), ptr(b), yp, ybs, n, ci, co, h, wd, stream_ptr()),
+          'convT2x2_fwd')
+    return y
+
+
+def convT2x2_dgrad(dy, w, dx):
+    gp, gbs = planes(dy)
+    dp, dbs = planes(dx)
+    n, ci, h, wd = dx.shape
+    co = w.shape[1]
+    check(lib.aide_convT2x2_dgrad(gp, gbs, ptr(w), dp, dbs, n, ci, co, h, wd, stream_ptr()),
+          'convT2x2_dgrad')
+    return dx
+
+
+def convT2x2_wgrad(x, dy, dw, ws=None):
+    xp, xbs = planes(x)
+    gp, gbs = planes(dy)
+    n, ci, h, wd = x.shape
+    co = dy.shape[1]
+    if ws is None:
+        ws = torch.empty(lib.aide_convT2x2_wgrad_ws_bytes(n, ci, co, h, wd) // 4, device=x.device,
+                         dtype=torch.float32)
+    check(lib.aide_convT2x2_wgrad(xp, xbs, gp, gbs, ptr(dw), n, ci, co, h, wd, ptr(ws), stream_ptr()),
+          'convT2x2_wgrad')
+    return dw
+
+
+# ------------------------------------------------------------------------------- batch norm
+def bn_ws(c, device):
+    return torch.empty(lib.aide_bn_ws_bytes(c) // 8, device=device, dtype=torch.float64)
+
+
+def bn_train_stats(z, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, rstd, scale,
+                   shift, ws):
+    zp, zbs = planes(z)
+    n, c, h, w = z.shape
+    check(lib.aide_bn_train_stats(zp, zbs, n, c, h, w, ptr(gamma), ptr(beta), eps, momentum,
+                                  ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd),
+                                  ptr(scale), ptr(shift), ptr(ws), stream_ptr()), 'bn_train_stats')
+
+
+def bn_eval_coeff(gamma, beta, running_mean, running_var, eps, scale, shift):
+    check(lib.aide_bn_eval_coeff(scale.numel(), ptr(gamma), ptr(beta), ptr(running_mean),
+                                 ptr(running_var), eps, ptr(scale), ptr(shift), stream_ptr()),
+          'bn_eval_coeff')
+
+
+def bn_relu_apply(z, a, scale, shift, relu=True):
+    zp, zbs = planes(z)
+    ap, abs_ = planes(a)
+    n, c, h, w = z.shape
+    check(lib.aide_bn_relu_apply(zp, zbs, ap, abs_, n, c, h, w, ptr(scale), ptr(shift), int(relu),
+                                 stream_ptr()), 'bn_relu_apply')
+    return a
+
+
+def bn_relu_bwd(dA, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, relu=True):
+    gp, gbs = planes(dA)
+    zp, zbs = planes(z)
+    dp, dbs = planes(dz)
+    n, c, h, w = z.shape
+    check(lib.aide_bn_relu_bwd(gp, gbs, zp, zbs, dp, dbs, n, c, h, w, ptr(mean), ptr(rstd), ptr(scale),
+                               ptr(shift), int(relu), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws),
+                               stream_ptr()), 'bn_relu_bwd')
+    return dz
+
+
+# ------------------------------------------------------------------------------- pool / upsample
+def maxpool2x2_fwd(x, y):
+    xp, xbs = planes(x)
+    yp, ybs = planes(y)
+    n, c, h, w = x.shape
+    check(lib.aide_maxpool2x2_fwd(xp, xbs, yp, ybs, n, c, h, w, stream_ptr()), 'maxpool2x2_fwd')
+    return y
+
+
+def maxpool2x2_bwd(x, dy, dx, accumulate=False):
+    xp, xbs = planes(x)
+    gp, gbs = planes(dy)
+    dp, dbs = planes(dx)
+    n, c, h, w = x.shape
+    check(lib.aide_maxpool2x2_bwd(xp, xbs, gp, gbs, dp, dbs, n, c, h, w, int(accumulate), stream_ptr()),
+          'maxpool2x2_bwd')
+    return dx
+
+
+def upsample2x_fwd(x, y):
+    xp, xbs = planes(x)
+    yp, ybs = planes(y)
+    n, c, h, w = x.shape
+    check(lib.aide_upsample2x_bilinear_fwd(xp, xbs, yp, ybs, n, c, h, w, stream_ptr()), 'upsample2x_fwd')
+    return y
+
+
+def upsample2x_bwd(dy, dx, accumulate=False):
+    gp, gbs = planes(dy)
+    dp, dbs = planes(dx)
+    n, c, h, w = dx.shape
+    check(lib.aide_upsample2x_bilinear_bwd(gp, gbs, dp, dbs, n, c, h, w, int(accumulate), stream_ptr()),
+          'upsample2x_bwd')
+    return dx
+
+
+def fill_zero(t):
+    p, bs = planes(t)
+    n, c, h, w = t.shape
+    check(lib.aide_fill_zero(p, bs, n, c, h, w, stream_ptr()), 'fill_zero')
+    return t
+
+
+# ------------------------------------------------------------------------------- head 1x1
+def head1x1_fwd(x, w, b, y):
+    xp, xbs = planes(x)
+    yp, ybs = planes(y)
+    n, c, h, wd = x.shape
+    k = w.shape[0]
+    check(lib.aide_head1x1_fwd(xp, xbs, ptr(w), ptr(b), yp, ybs, n, c, k, h, wd, stream_ptr()),
+          'head1x1_fwd')
+    return y
+
+
+def head1x1_bwd(dy, x, w, dx, dw, db, ws=None):
+    gp, gbs = planes(dy)
+    xp, xbs = planes(x)
+    n, c, h, wd = x.shape
+    k = w.shape[0]
+    if dx is not None:
+        dp, dbs = planes(dx)
+    else:
+        dp, dbs = ctypes.c_void_p(0), 0
+    if ws is None:
+        ws = torch.empty(lib.aide_head1x1_ws_bytes(c, k) // 8, device=x.device, dtype=torch.float64)
+    check(lib.aide_head1x1_bwd(gp, gbs, xp, xbs, ptr(w), dp, dbs, ptr(dw), ptr(db), n, c, k, h, wd,
+                               ptr(ws), stream_ptr()), 'head1x1_bwd')

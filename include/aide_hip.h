@@ -1,0 +1,131 @@
+/* C ABI of libaide_hip.so — the MI355X (gfx950) drop-in for AIDE's FuseUNet/UNet training hot path.
+ *
+ * The reference (lich0031/AIDE) has no native code and no FFI: the replaceable seam is its Python
+ * nn.Module / loss-module API.  Each entry point below is what a Python binding
+ * for that seam calls; the "replaces" note cites the reference call site (path:line under the
+ * reference tree).  Conventions:
+ *   - plain pointers + sizes only; no torch types.  All pointers are DEVICE pointers unless noted.
+ *   - tensors are NCHW fp32 planes; `*_bs` is the batch stride in ELEMENTS, so a tensor may be a
+ *     channel slice of a larger concatenation buffer (this is how torch.cat is eliminated).
+ *   - every call is asynchronous on `stream`, never allocates, never synchronises.
+ *   - return value: 0 = ok, <0 = bad argument, >0 = hipError_t of the launch.
+ */
+#ifndef AIDE_HIP_H
+#define AIDE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* aide_stream_t; /* == hipStream_t */
+
+/* ---- 3x3 convolution, pad 1 (MFMA implicit GEMM) -----------------------------------------------
+ * replaces nn.Conv2d(ci, co, 3, padding=1): models_twomodalinputs/netblocks.py:17,24,26 and
+ * models_singlemodalinput/UNet.py:12,19,21 (forward) and autograd's convolution_backward. */
+int aide_conv3x3_chunk(int Cin);                                  /* channel padding granule */
+int aide_conv3x3_pack_weights(const float* w /*[Co][Ci][3][3]*/, float* wf /*[ci_pad][9][Co]*/,
+                              float* wd /*[co_pad][9][Ci] or NULL*/, int Co, int Ci, int ci_pad,
+                              int co_pad, aide_stream_t stream);
+int aide_conv3x3_plan(int N, int Cin, int H, int W, int Cout);    /* variant | splitk<<8 */
+size_t aide_conv3x3_ws_bytes(int N, int H, int W, int Cout, int splitk);
+int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, const float* bias,
+                       float* y, int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate,
+                       int plan, float* ws, aide_stream_t stream);   /* forward and dgrad */
+int aide_conv3x3_wgrad_splits(int N, int Co, int Ci, int H, int W);
+size_t aide_conv3x3_wgrad_ws_bytes(int N, int Co, int Ci, int H, int W);
+int aide_conv3x3_wgrad(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs,
+                       float* dw /*[Co][Ci][3][3]*/, int N, int Co, int Ci, int H, int W, float* ws,
+                       aide_stream_t stream);
+
+/* ---- ConvTranspose2d(k=2, s=2) (learned_bilinear=True up path) ---------------------------------
+ * replaces nn.ConvTranspose2d: netblocks.py:12, UNet.py:7 */
+int aide_convT2x2_fwd(const float* x, int64_t x_bs, const float* w /*[Ci][Co][2][2]*/, const float* b,
+                      float* y, int64_t y_bs, int N, int Ci, int Co, int H, int W, aide_stream_t stream);
+int aide_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* w, float* dx, int64_t dx_bs, int N,
+                        int Ci, int Co, int H, int W, aide_stream_t stream);
+size_t aide_convT2x2_wgrad_ws_bytes(int N, int Ci, int Co, int H, int W);
+int aide_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dw, int N,
+                        int Ci, int Co, int H, int W, float* ws, aide_stream_t stream);
+
+/* ---- BatchNorm2d (+ReLU) -----------------------------------------------------------------------
+ * replaces nn.BatchNorm2d + nn.ReLU: netblocks.py:25,27,28,18 ; UNet.py:20,22,23,13 */
+size_t aide_bn_ws_bytes(int C);
+int aide_bn_train_stats(const float* z, int64_t z_bs, int N, int C, int H, int W, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean,
+                        float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                        float* scale, float* shift, void* ws, aide_stream_t stream);
+int aide_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift,
+                       aide_stream_t stream);
+int aide_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
+                       const float* scale, const float* shift, int relu, aide_stream_t stream);
+int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs, float* dz,
+                     int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
+                     const float* scale, const float* shift, int relu, float* dgamma, float* dbeta,
+                     float* dbias, void* ws, aide_stream_t stream);
+
+/* ---- MaxPool2d(2,2), bilinear x2 (align_corners=True) -------------------------------------------
+ * replaces nn.MaxPool2d: fuseunet.py:13-31 (calls :51-78), UNet.py:114 ;
+ *          nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True): netblocks.py:16 */
+int aide_maxpool2x2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int N, int C, int H, int W,
+                        aide_stream_t stream);
+int aide_maxpool2x2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx,
+                        int64_t dx_bs, int N, int C, int H, int W, int accumulate, aide_stream_t stream);
+int aide_upsample2x_bilinear_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int N, int C, int H,
+                                 int W, aide_stream_t stream);
+int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int N, int C,
+                                 int H, int W, int accumulate, aide_stream_t stream);
+int aide_fill_zero(float* p, int64_t bs, int N, int C, int H, int W, aide_stream_t stream);
+
+/* ---- 1x1 head convolution -----------------------------------------------------------------------
+ * replaces last_conv1 = nn.Conv2d(64, num_classes, 1): fuseunet.py:41,89 ; UNet.py:150,164 */
+int aide_head1x1_fwd(const float* x, int64_t x_bs, const float* w, const float* b, float* y, int64_t y_bs,
+                     int N, int C, int K, int H, int W, aide_stream_t stream);
+size_t aide_head1x1_ws_bytes(int C, int K);
+int aide_head1x1_bwd(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, const float* w,
+                     float* dx, int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W,
+                     void* ws, aide_stream_t stream);
+
+/* ---- fused segmentation losses / co-teaching selection -----------------------------------------
+ * replaces utils/loss2d.py:5-154, utils/coteach_loss.py:94-161, utils/metrics2d.py:8-29 and the
+ * inline selection of train_files/trainchaos_proposed_30cases1labeled.py:274-321 */
+int aide_seg_loss_blocks(int HW);
+size_t aide_seg_loss_ws_bytes(int N, int HW);
+int aide_seg_stats(const float* logits, int64_t l_bs, const long long* targets, int64_t t_bs, float w0,
+                   float w1, int ignore_index, const float* pseudo, int64_t p_bs, const float* wmap,
+                   int64_t w_bs, int N, int HW, double* partials, aide_stream_t stream);
+int aide_seg_loss_finalize(const double* partials, int N, int HW, int reduction, float w_ce, float w_dice,
+                           float smooth, double* stats, float* out, float* per_image, long long* idx,
+                           float* coef, float* hard_dice, aide_stream_t stream);
+int aide_coteach_finalize(const double* partials1, const double* partials2, int N, int HW, int variant,
+                          int keep, float w_ce, float w_dice, float smooth, float rate, float w_seg,
+                          float w_cor, double* stats1, double* stats2, float* loss, float* per_image1,
+                          float* per_image2, long long* idx1, long long* idx2, float* coef1, float* coef2,
+                          float* hard_dice, aide_stream_t stream);
+int aide_seg_loss_bwd(const float* logits, int64_t l_bs, const long long* targets, int64_t t_bs, float w0,
+                      float w1, int ignore_index, const float* pseudo, int64_t p_bs, const float* wmap,
+                      int64_t w_bs, int N, int HW, const double* stats, const float* coef, float smooth,
+                      const float* gout, int g_stride, float* dlogits, int64_t d_bs, aide_stream_t stream);
+int aide_ce_map(const float* logits, int64_t l_bs, const long long* targets, int64_t t_bs, float w0,
+                float w1, int ignore_index, int N, int HW, float* out, const float* gout, float* dlogits,
+                int64_t d_bs, aide_stream_t stream);
+int aide_mse_map(const float* logits, int64_t l_bs, const float* target, int64_t q_bs, int N, int HW,
+                 float* out, const float* gout, float* dlogits, int64_t d_bs, aide_stream_t stream);
+int aide_pseudo_label(const float* const* logits /* HOST array of K device pointers */, int K,
+                      int64_t l_bs, int N, int HW, float temperature, float* pl, float* wm,
+                      aide_stream_t stream);
+
+/* ---- Adam(amsgrad), one launch for all parameter tensors ----------------------------------------
+ * replaces torch.optim.Adam(net.parameters(), lr, amsgrad=True): trainchaos_comparison_1case.py:170 */
+int aide_adam_amsgrad_multi(float* const* p, const float* const* g, float* const* m, float* const* v,
+                            float* const* vmax, const int64_t* sizes, const int64_t* block_start,
+                            int ntensors, int64_t total_blocks, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int amsgrad, int64_t step,
+                            aide_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIDE_HIP_H */

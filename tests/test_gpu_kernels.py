@@ -1,0 +1,206 @@
+"""Kernel-level parity (-m gpu): every C-ABI kernel family against the stock-aten CPU op it replaces
+(the same ops the oracle in oracle/nets.py is built from). Tolerances: fp32, 1e-3 relative is the
+north-star bound; these kernels are exact-fp32 FMA chains so we hold them to ~1e-5."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, rtol=2e-5, atol=None, what=''):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    tol = rtol * scale if atol is None else atol
+    assert err <= tol, '%s: max abs err %.3e > %.3e (ref scale %.3e)' % (what, err, tol, scale)
+
+
+CONV_CASES = [
+    # N, Cin, Cout, H, W
+    (2, 3, 32, 32, 32), (1, 32, 32, 64, 64), (2, 64, 64, 32, 32), (1, 128, 64, 64, 64),
+    (2, 64, 128, 16, 16), (1, 256, 256, 16, 16), (2, 24, 96, 20, 20), (1, 40, 32, 40, 24),
+    (1, 64, 128, 80, 80), (4, 512, 512, 16, 16),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv3x3_fwd_dgrad_wgrad(dev, case):
+    from aide_amd import ops
+    n, ci, co, h, w = case
+    g = torch.Generator().manual_seed(ci * 131 + co)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) * (1.0 / (3.0 * ci ** 0.5))
+    b = torch.randn(co, generator=g)
+    dy = torch.randn(n, co, h, w, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b, padding=1)
+    yr.backward(dy)
+
+    xd, wd_, bd, dyd = x.to(dev), wt.to(dev), b.to(dev), dy.to(dev)
+    wf, wdg = ops.pack_weights(wd_, need_dgrad=(ci % 32 == 0))
+    y = torch.empty(n, co, h, w, device=dev)
+    ops.conv3x3_igemm(xd, wf, bd, y)
+    _close(y, yr, what='fwd %s' % (case,))
+    for variant in range(6):                       # every tile variant must agree
+        if variant in (2, 5) and co % 128:
+            continue
+        if variant != 0 and co % 64:
+            continue
+        if ci < 8 and variant > 1:
+            continue
+        for splitk in (1, 2):
+            y2 = torch.zeros_like(y)
+            ops.conv3x3_igemm(xd, wf, bd, y2, plan=variant | (splitk << 8))
+            _close(y2, yr, what='fwd variant %d splitk %d %s' % (variant, splitk, case))
+    if wdg is not None:
+        dx = torch.empty(n, ci, h, w, device=dev)
+        ops.conv3x3_igemm(dyd, wdg, None, dx)
+        _close(dx, xr.grad, what='dgrad %s' % (case,))
+        dx2 = torch.ones_like(dx)
+        ops.conv3x3_igemm(dyd, wdg, None, dx2, accumulate=True)
+        _close(dx2, xr.grad + 1.0, what='dgrad accumulate %s' % (case,))
+    dw = torch.empty(co, ci, 3, 3, device=dev)
+    ops.conv3x3_wgrad(dyd, xd, dw)
+    _close(dw, wr.grad, what='wgrad %s' % (case,))
+
+
+def test_conv3x3_channel_slices(dev):
+    """inputs/outputs that are channel slices of concatenation buffers (torch.cat elimination)."""
+    from aide_amd import ops
+    g = torch.Generator().manual_seed(5)
+    big_in = torch.randn(2, 96, 32, 32, generator=g)
+    wt = torch.randn(64, 32, 3, 3, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    ref = F.conv2d(big_in[:, 32:64], wt, b, padding=1)
+    bi = big_in.to(dev)
+    big_out = torch.full((2, 160, 32, 32), 7.0, device=dev)
+    wf, _ = ops.pack_weights(wt.to(dev))
+    ops.conv3x3_igemm(bi[:, 32:64], wf, b.to(dev), big_out[:, 64:128])
+    _close(big_out[:, 64:128], ref, what='slice conv')
+    assert (big_out[:, :64] == 7.0).all() and (big_out[:, 128:] == 7.0).all()
+
+
+@pytest.mark.parametrize('shape', [(4, 32, 64, 64), (2, 64, 16, 16), (3, 8, 20, 20)])
+def test_bn_relu_fwd_bwd(dev, shape):
+    from aide_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c)
+    z = torch.randn(n, c, h, w, generator=g) * 2.0 + torch.randn(1, c, 1, 1, generator=g)
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g) * 0.3
+    dA = torch.randn(n, c, h, w, generator=g)
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    bn.train()
+    zr = z.clone().requires_grad_(True)
+    ar = F.relu(bn(zr))
+    ar.backward(dA)
+
+    zd = z.to(dev)
+    rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    mean, rstd, scale, shift = (torch.empty(c, device=dev) for _ in range(4))
+    ws = ops.bn_ws(c, dev)
+    ops.bn_train_stats(zd, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rm, rv, nbt, mean, rstd, scale, shift, ws)
+    a = torch.empty_like(zd)
+    ops.bn_relu_apply(zd, a, scale, shift, True)
+    _close(a, ar, what='bn+relu fwd')
+    _close(rm, bn.running_mean, what='running_mean')
+    _close(rv, bn.running_var, what='running_var')
+    assert int(nbt.item()) == 1
+    dz = torch.empty_like(zd)
+    dg, db, dbias = (torch.empty(c, device=dev) for _ in range(3))
+    ops.bn_relu_bwd(dA.to(dev), zd, dz, mean, rstd, scale, shift, dg, db, dbias, ws, True)
+    _close(dz, zr.grad, rtol=5e-5, what='bn bwd dz')
+    _close(dg, bn.weight.grad, rtol=5e-5, what='dgamma')
+    _close(db, bn.bias.grad, rtol=5e-5, what='dbeta')
+    assert dbias.abs().max().item() < 1e-3      # mathematically zero (dead conv bias)
+
+
+def test_maxpool_ties_and_backward(dev):
+    from aide_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 16, 24, generator=g)
+    x[:, :, :6, :] = 0.25                  # constant background -> exact ties in every window
+    x[0, 0, 8:10, 4:6] = 1.5
+    dy = torch.randn(2, 8, 8, 12, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    yr.backward(dy)
+    xd = x.to(dev)
+    y = torch.empty(2, 8, 8, 12, device=dev)
+    ops.maxpool2x2_fwd(xd, y)
+    assert torch.equal(y.cpu(), yr.detach())
+    dx = torch.empty_like(xd)
+    ops.maxpool2x2_bwd(xd, dy.to(dev), dx, accumulate=False)
+    assert torch.equal(dx.cpu(), xr.grad)          # first-max tie rule, bit exact
+    dx2 = torch.ones_like(xd)
+    ops.maxpool2x2_bwd(xd, dy.to(dev), dx2, accumulate=True)
+    assert torch.equal(dx2.cpu(), xr.grad + 1.0)
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 16, 16), (1, 4, 20, 12), (2, 3, 1, 1)])
+def test_upsample_bilinear(dev, shape):
+    from aide_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(h)
+    x = torch.randn(n, c, h, w, generator=g)
+    dy = torch.randn(n, c, 2 * h, 2 * w, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=True)
+    yr.backward(dy)
+    y = torch.empty(n, c, 2 * h, 2 * w, device=dev)
+    ops.upsample2x_fwd(x.to(dev), y)
+    _close(y, yr, rtol=1e-6, what='upsample fwd')
+    dx = torch.empty(n, c, h, w, device=dev)
+    ops.upsample2x_bwd(dy.to(dev), dx)
+    _close(dx, xr.grad, rtol=1e-5, what='upsample bwd')
+
+
+@pytest.mark.parametrize('case', [(2, 64, 32, 16, 16), (1, 128, 64, 8, 12), (2, 24, 40, 10, 10)])
+def test_convT2x2(dev, case):
+    from aide_amd import ops
+    n, ci, co, h, w = case
+    g = torch.Generator().manual_seed(ci)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(ci, co, 2, 2, generator=g) * 0.1
+    b = torch.randn(co, generator=g)
+    dy = torch.randn(n, co, 2 * h, 2 * w, generator=g)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, b, stride=2)
+    yr.backward(dy)
+    y = torch.empty(n, co, 2 * h, 2 * w, device=dev)
+    ops.convT2x2_fwd(x.to(dev), wt.to(dev), b.to(dev), y)
+    _close(y, yr, what='convT fwd')
+    dx = torch.empty(n, ci, h, w, device=dev)
+    ops.convT2x2_dgrad(dy.to(dev), wt.to(dev), dx)
+    _close(dx, xr.grad, what='convT dgrad')
+    dw = torch.empty(ci, co, 2, 2, device=dev)
+    ops.convT2x2_wgrad(x.to(dev), dy.to(dev), dw)
+    _close(dw, wr.grad, what='convT wgrad')
+
+
+def test_head1x1(dev):
+    from aide_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 64, 32, 32, generator=g)
+    wt = torch.randn(2, 64, 1, 1, generator=g) * 0.2
+    b = torch.randn(2, generator=g)
+    dy = torch.randn(2, 2, 32, 32, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br)
+    yr.backward(dy)
+    y = torch.empty(2, 2, 32, 32, device=dev)
+    w2 = wt.view(2, 64).to(dev)
+    ops.head1x1_fwd(x.to(dev), w2, b.to(dev), y)
+    _close(y, yr, what='head fwd')
+    dx = torch.empty(2, 64, 32, 32, device=dev)
+    dw, db = torch.empty(2, 64, device=dev), torch.empty(2, device=dev)
+    ops.head1x1_bwd(dy.to(dev), x.to(dev), w2, dx, dw, db)
+    _close(dx, xr.grad, what='head dgrad')
+    _close(dw, wr.grad.view(2, 64), what='head wgrad')
+    _close(db, br.grad, what='head dbias')
