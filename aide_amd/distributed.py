@@ -1,0 +1,133 @@
+"""Data-parallel replicas over RCCL/xGMI: one process per GPU, per-replica BatchNorm statistics and
+per-replica small-loss selection, gradient MEAN all-reduce of the flat gradient arena.
+
+The whole-network backward runs as one launch sequence, so gradient buckets are carved out of the
+flat arena (contiguous parameter ranges, ~25 MB) and each bucket's all-reduce is issued on a side
+stream as soon as the last kernel writing into it has been enqueued — it overlaps the remaining
+dgrad/wgrad kernels.  With world_size == 1 nothing is installed.
+
+The reference only has single-process nn.DataParallel (trainchaos_comparison_1case.py:131-134); this
+is the multi-process replacement BASELINE.json asks for.
+"""
+import torch
+import torch.distributed as dist
+
+
+def make_buckets(offsets, numels, bucket_elems):
+    """Greedy contiguous buckets over the flat arena. -> list of (start, end, [param indices])."""
+    buckets, cur, start = [], [], None
+    for i, (o, n) in enumerate(zip(offsets, numels)):
+        if start is None:
+            start = o
+        cur.append(i)
+        end = o + n
+        if end - start >= bucket_elems:
+            buckets.append((start, end, cur))
+            cur, start = [], None
+    if cur:
+        buckets.append((start, offsets[cur[-1]] + numels[cur[-1]], cur))
+    return buckets
+
+
+class BucketScheduler(object):
+    """Tracks which parameters' gradients are complete during a backward pass and yields buckets
+    that have become fully ready (pure host logic; unit-tested on CPU)."""
+
+    def __init__(self, buckets, nparams):
+        self.buckets = buckets
+        self.owner = [None] * nparams
+        for b, (_, _, idxs) in enumerate(buckets):
+            for i in idxs:
+                self.owner[i] = b
+        self.reset()
+
+    def reset(self):
+        self.pending = [len(idxs) for _, _, idxs in self.buckets]
+        self.done = set()
+
+    def mark(self, param_indices):
+        ready = []
+        for i in param_indices:
+            if i in self.done:
+                continue
+            self.done.add(i)
+            b = self.owner[i]
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                ready.append(b)
+        return ready
+
+
+def broadcast_module(module, src=0):
+    """Make every replica start from rank `src`'s parameters and buffers."""
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
+class GradAllReduce(object):
+    """Installs the bucketed, overlapped gradient mean all-reduce on an aide_amd model's engine."""
+
+    def __init__(self, model, bucket_mb=25.0, process_group=None):
+        self.engine = model.engine
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.bucket_elems = int(bucket_mb * 1e6 / 4)
+        self.sched = None
+        self.flat = None
+        self.works = []
+        self.comm_stream = None
+        if self.world > 1:
+            self.engine.after_backward_op = self._after_op
+            self.engine.grad_hook = self._finish
+            self.engine.before_backward = self._begin
+
+    def _ensure(self):
+        eng = self.engine
+        if self.sched is None or self._params is not eng.params:
+            numels = [p.numel() for p in eng.params]
+            self.sched = BucketScheduler(make_buckets(eng.offsets, numels, self.bucket_elems), len(numels))
+            self._params = eng.params
+            self._pidx = {id(p): i for i, p in enumerate(eng.params)}
+
+    def _begin(self, flat):
+        self._ensure()
+        self.sched.reset()
+        self.flat = flat
+        self.works = []
+        if flat.is_cuda and self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=flat.device)
+
+    def _launch(self, b):
+        start, end, _ = self.sched.buckets[b]
+        view = self.flat[start:end]
+        if view.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()                                    # all kernels writing this bucket are enqueued
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                # RCCL averages in the collective itself: no extra elementwise pass over the arena
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
+        else:
+            # gloo (CPU unit tests only) has no AVG: pre-scale, then SUM
+            view.div_(self.world)
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _after_op(self, st):
+        idxs = []
+        for key in ('conv', 'bn'):
+            m = st.get(key)
+            if m is not None:
+                idxs += [self._pidx[id(p)] for p in m.parameters()]
+        for b in self.sched.mark(idxs):
+            self._launch(b)
+
+    def _finish(self, flat):
+        # anything not yet launched (should be nothing), then make the compute stream wait for comm
+        for b, pend in enumerate(self.sched.pending):
+            if pend > 0:
+                self.sched.pending[b] = 0
+                self._launch(b)
+        for w in self.works:
+            w.wait()
+        if flat.is_cuda:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)

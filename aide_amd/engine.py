@@ -1,0 +1,380 @@
+"""Whole-network executor for the U-Net family on MI355X.
+
+A model describes itself once as a small static graph (conv+BN+ReLU, ConvT+BN+ReLU, max-pool,
+bilinear x2, 1x1 head) over *channel-slice views* of pre-planned NCHW buffers.  Because every
+producer writes straight into its slice of the consumer's concatenation buffer, torch.cat
+(models_twomodalinputs/fuseunet.py:49-81, netblocks.py:145) never materialises.  For each
+(N, H, W, mode) the graph is compiled into a Plan: buffers, packed filters, split-K workspaces and
+the backward schedule with statically resolved overwrite/accumulate decisions for tensors that have
+several consumers (skip connections).  The forward and the backward of the whole network are then two
+flat launch sequences on the current HIP stream, wrapped in ONE torch.autograd.Function so the
+reference training loops (`net(...)`, `loss.backward()`, `optimizer.step()`) work unchanged.
+
+All arithmetic is in libaide_hip.so (see include/aide_hip.h); torch only owns memory and streams.
+"""
+import torch
+
+from . import ops
+from ._lib import lib
+
+# bumped by aide_amd.optim.Adam (which updates parameters through raw pointers, invisible to
+# tensor._version) so that cached packed filters are refreshed
+PARAM_EPOCH = [0]
+
+
+class GTensor(object):
+    """A [N, C, H>>level, W>>level] activation: either a root buffer or a channel slice of one."""
+
+    def __init__(self, name, channels, level, root=None, c0=0, is_input=False):
+        self.name, self.C, self.level = name, channels, level
+        self.root = root if root is not None else self
+        self.c0 = c0
+        self.is_input = is_input
+
+    def slice(self, c0, channels, name=None):
+        assert 0 <= c0 and c0 + channels <= self.C
+        return GTensor(name or '%s[%d:%d]' % (self.name, c0, c0 + channels), channels, self.level,
+                       self.root, self.c0 + c0)
+
+
+class Graph(object):
+    def __init__(self):
+        self.roots, self.inputs, self.ops = [], [], []
+        self.output = None
+
+    def tensor(self, name, channels, level):
+        t = GTensor(name, channels, level)
+        self.roots.append(t)
+        return t
+
+    def input(self, name, channels):
+        t = GTensor(name, channels, 0, is_input=True)
+        self.inputs.append(t)
+        return t
+
+    def conv_bn_relu(self, src, dst, conv, bn):
+        self.ops.append(dict(kind='conv', src=src, dst=dst, conv=conv, bn=bn))
+
+    def convT_bn_relu(self, src, dst, conv, bn):
+        self.ops.append(dict(kind='convT', src=src, dst=dst, conv=conv, bn=bn))
+
+    def pool(self, src, dst):
+        self.ops.append(dict(kind='pool', src=src, dst=dst))
+
+    def upsample(self, src, dst):
+        self.ops.append(dict(kind='up', src=src, dst=dst))
+
+    def head(self, src, conv):
+        self.ops.append(dict(kind='head', src=src, conv=conv))
+
+
+class _Cover(object):
+    """Tracks which channel ranges of a gradient buffer have been written during the backward
+    schedule: first writer overwrites, later writers accumulate, gaps are zero-filled once."""
+
+    def __init__(self):
+        self.iv = []
+
+    def write(self, c0, c1):
+        """-> (accumulate, [uncovered sub-intervals to zero-fill first])"""
+        covered = [(max(a, c0), min(b, c1)) for a, b in self.iv if a < c1 and b > c0]
+        if not covered:
+            self._add(c0, c1)
+            return False, []
+        gaps, cur = [], c0
+        for a, b in sorted(covered):
+            if a > cur:
+                gaps.append((cur, a))
+            cur = max(cur, b)
+        if cur < c1:
+            gaps.append((cur, c1))
+        self._add(c0, c1)
+        return True, gaps
+
+    def _add(self, c0, c1):
+        iv = sorted(self.iv + [(c0, c1)])
+        out = [iv[0]]
+        for a, b in iv[1:]:
+            if a <= out[-1][1]:
+                out[-1] = (out[-1][0], max(out[-1][1], b))
+            else:
+                out.append((a, b))
+        self.iv = out
+
+
+class Plan(object):
+    def __init__(self, graph, params, n, h, w, device, training):
+        self.g, self.N, self.H, self.W, self.dev, self.training = graph, n, h, w, device, training
+        self.pindex = {id(p): i for i, p in enumerate(params)}
+        f32 = dict(device=device, dtype=torch.float32)
+        self.act = {}
+        for t in graph.roots:
+            self.act[id(t)] = torch.empty(n, t.C, h >> t.level, w >> t.level, **f32)
+        self.grad = {}
+        self.steps = []
+        max_dz = max_wg = max_bnc = max_sk = 0
+        for op in graph.ops:
+            st = dict(op)
+            if op['kind'] in ('conv', 'convT'):
+                conv, src, dst = op['conv'], op['src'], op['dst']
+                hh, ww = h >> dst.level, w >> dst.level
+                cout = dst.C
+                st['z'] = torch.empty(n, cout, hh, ww, **f32)
+                for k in ('mean', 'rstd', 'scale', 'shift'):
+                    st[k] = torch.empty(cout, **f32)
+                max_dz = max(max_dz, n * cout * hh * ww)
+                max_bnc = max(max_bnc, cout)
+                if op['kind'] == 'conv':
+                    cin = src.C
+                    need_dg = not src.root.is_input
+                    st['wf'] = torch.empty(ops.pad_to(cin, ops.conv_chunk(cin)), 9, cout, **f32)
+                    st['wd'] = torch.empty(ops.pad_to(cout, ops.conv_chunk(cout)), 9, cin, **f32) if need_dg else None
+                    st['plan_f'] = lib.aide_conv3x3_plan(n, cin, hh, ww, cout)
+                    st['plan_d'] = lib.aide_conv3x3_plan(n, cout, hh, ww, cin) if need_dg else 0
+                    max_sk = max(max_sk, lib.aide_conv3x3_ws_bytes(n, hh, ww, cout, st['plan_f'] >> 8),
+                                 lib.aide_conv3x3_ws_bytes(n, hh, ww, cin, st['plan_d'] >> 8) if need_dg else 0)
+                    max_wg = max(max_wg, lib.aide_conv3x3_wgrad_ws_bytes(n, cout, cin, hh, ww))
+                    st['pack_key'] = None
+                    st['flops'] = 2.0 * n * hh * ww * cout * cin * 9      # algorithmic, per launch
+                else:
+                    cin = src.C
+                    max_wg = max(max_wg, lib.aide_convT2x2_wgrad_ws_bytes(n, cin, cout, h >> src.level, w >> src.level))
+            elif op['kind'] == 'head':
+                src = op['src']
+                k = op['conv'].out_channels
+                max_wg = max(max_wg, lib.aide_head1x1_ws_bytes(src.C, k))
+            self.steps.append(st)
+        self.bn_ws = ops.bn_ws(max(max_bnc, 1), device)
+        self.sk_ws = torch.empty(max(max_sk // 4, 1), **f32)
+        self._max_dz, self._max_wg = max_dz, max_wg
+        self.dz = None
+        self.wg_ws = None
+        self._bwd_ready = False
+        self.profiler = None             # set by Engine (bench.py's per-kernel HIP-event timing)
+
+    # ------------------------------------------------------------------ helpers
+    def view(self, t, inputs=None):
+        if t.root.is_input:
+            x = inputs[self.g.inputs.index(t.root)]
+            return x if (t.c0 == 0 and t.C == t.root.C) else x[:, t.c0:t.c0 + t.C]
+        buf = self.act[id(t.root)]
+        return buf if (t.c0 == 0 and t.C == t.root.C) else buf[:, t.c0:t.c0 + t.C]
+
+    def gview(self, t):
+        buf = self.grad[id(t.root)]
+        return buf if (t.c0 == 0 and t.C == t.root.C) else buf[:, t.c0:t.c0 + t.C]
+
+    def _prepare_backward(self):
+        """Allocate gradient buffers and resolve overwrite/accumulate per backward write."""
+        f32 = dict(device=self.dev, dtype=torch.float32)
+        n, h, w = self.N, self.H, self.W
+        for t in self.g.roots:
+            self.grad[id(t)] = torch.empty(n, t.C, h >> t.level, w >> t.level, **f32)
+        self.dz = torch.empty(max(self._max_dz, 1), **f32)
+        self.wg_ws = torch.empty(max(self._max_wg // 4, 1), **f32)
+        cover = {id(t): _Cover() for t in self.g.roots}
+        for st in reversed(self.steps):
+            src = st['src']
+            if src.root.is_input:
+                st['src_grad'] = None
+                continue
+            acc, gaps = cover[id(src.root)].write(src.c0, src.c0 + src.C)
+            st['src_grad'] = dict(accumulate=acc, gaps=[src.root.slice(a, b - a) for a, b in gaps])
+            if st['kind'] == 'convT' and acc:
+                raise NotImplementedError('ConvTranspose input with several consumers')
+        self._bwd_ready = True
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, inputs, out):
+        n = self.N
+        for st in self.steps:
+            kind = st['kind']
+            if kind == 'conv':
+                conv, bn = st['conv'], st['bn']
+                key = (conv.weight.data_ptr(), conv.weight._version, PARAM_EPOCH[0])
+                if st['pack_key'] != key:
+                    ops.pack_weights_into(conv.weight, st['wf'], st['wd'])
+                    st['pack_key'] = key
+                x = self.view(st['src'], inputs)
+                prof = self.profiler
+                if prof is not None:
+                    prof.begin('conv3x3_igemm', st['flops'])
+                ops.conv3x3_igemm(x, st['wf'], conv.bias, st['z'], plan=st['plan_f'], ws=self.sk_ws)
+                if prof is not None:
+                    prof.end()
+                self._bn_apply(st, bn)
+            elif kind == 'convT':
+                conv, bn = st['conv'], st['bn']
+                ops.convT2x2_fwd(self.view(st['src'], inputs), conv.weight, conv.bias, st['z'])
+                self._bn_apply(st, bn)
+            elif kind == 'pool':
+                ops.maxpool2x2_fwd(self.view(st['src'], inputs), self.view(st['dst']))
+            elif kind == 'up':
+                ops.upsample2x_fwd(self.view(st['src'], inputs), self.view(st['dst']))
+            elif kind == 'head':
+                conv = st['conv']
+                ops.head1x1_fwd(self.view(st['src'], inputs), conv.weight.view(conv.out_channels, -1),
+                                conv.bias, out)
+        return out
+
+    def _bn_apply(self, st, bn):
+        if self.training:
+            ops.bn_train_stats(st['z'], bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
+                               bn.running_var, bn.num_batches_tracked, st['mean'], st['rstd'],
+                               st['scale'], st['shift'], self.bn_ws)
+        else:
+            ops.bn_eval_coeff(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, st['scale'],
+                              st['shift'])
+        ops.bn_relu_apply(st['z'], self.view(st['dst']), st['scale'], st['shift'], True)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, inputs, dlogits, flat, offsets, after_op=None):
+        """flat: 1-D fp32 buffer receiving every parameter gradient at offsets[param index]."""
+        if not self._bwd_ready:
+            self._prepare_backward()
+
+        def gslot(p):
+            i = self.pindex[id(p)]
+            return flat[offsets[i]:offsets[i] + p.numel()].view(p.shape)
+
+        for st in reversed(self.steps):
+            kind = st['kind']
+            sg = st.get('src_grad')
+            if sg is not None:
+                for gap in sg['gaps']:
+                    ops.fill_zero(self.gview(gap))
+            if kind == 'head':
+                conv = st['conv']
+                k = conv.out_channels
+                ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1),
+                                self.gview(st['src']) if sg is not None else None,
+                                gslot(conv.weight).view(k, -1), gslot(conv.bias), ws=self.wg_ws)
+                assert sg is None or not sg['accumulate']
+            elif kind in ('conv', 'convT'):
+                conv, bn = st['conv'], st['bn']
+                z = st['z']
+                dz = self.dz[:z.numel()].view(z.shape)
+                ops.bn_relu_bwd(self.gview(st['dst']), z, dz, st['mean'], st['rstd'], st['scale'],
+                                st['shift'], gslot(bn.weight), gslot(bn.bias), gslot(conv.bias),
+                                self.bn_ws, True)
+                x = self.view(st['src'], inputs)
+                if kind == 'conv':
+                    prof = self.profiler
+                    if prof is not None:
+                        prof.begin('conv3x3_wgrad', st['flops'])
+                    ops.conv3x3_wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
+                    if prof is not None:
+                        prof.end()
+                    if sg is not None:
+                        if prof is not None:
+                            prof.begin('conv3x3_igemm', st['flops'])
+                        ops.conv3x3_igemm(dz, st['wd'], None, self.gview(st['src']),
+                                          accumulate=sg['accumulate'], plan=st['plan_d'], ws=self.sk_ws)
+                        if prof is not None:
+                            prof.end()
+                else:
+                    ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=self.wg_ws)
+                    if sg is not None:
+                        ops.convT2x2_dgrad(dz, conv.weight, self.gview(st['src']))
+            elif kind == 'pool':
+                if sg is not None:
+                    ops.maxpool2x2_bwd(self.view(st['src'], inputs), self.gview(st['dst']),
+                                       self.gview(st['src']), accumulate=sg['accumulate'])
+            elif kind == 'up':
+                if sg is not None:
+                    ops.upsample2x_bwd(self.gview(st['dst']), self.gview(st['src']),
+                                       accumulate=sg['accumulate'])
+            if after_op is not None:
+                after_op(st)
+
+
+class _NetFunction(torch.autograd.Function):
+    """forward/backward of the whole network as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, engine, n_inputs, *tensors):
+        inputs = tensors[:n_inputs]
+        plan = engine.plan_for(inputs)
+        plan.profiler = engine.profiler
+        k = engine.num_classes
+        n, _, h, w = inputs[0].shape
+        out = torch.empty(n, k, h, w, device=inputs[0].device, dtype=torch.float32)
+        plan.forward(inputs, out)
+        engine.forward_serial += 1
+        ctx.engine, ctx.plan, ctx.serial, ctx.inputs = engine, plan, engine.forward_serial, inputs
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng, plan = ctx.engine, ctx.plan
+        if ctx.serial != eng.forward_serial:
+            raise RuntimeError('aide_amd: backward() after a newer forward() of the same module — its '
+                               'activations were overwritten (the engine keeps one set per module)')
+        if not plan.training:
+            raise RuntimeError('aide_amd: backward through an eval-mode forward is not supported')
+        dlogits = dlogits.contiguous()
+        flat = torch.empty(eng.flat_numel, device=dlogits.device, dtype=torch.float32)
+        if eng.before_backward is not None:
+            eng.before_backward(flat)
+        plan.backward(ctx.inputs, dlogits, flat, eng.offsets, eng.after_backward_op)
+        if eng.grad_hook is not None:
+            eng.grad_hook(flat)
+        grads = tuple(flat[o:o + p.numel()].view(p.shape) for o, p in zip(eng.offsets, eng.params))
+        return (None, None) + (None,) * len(ctx.inputs) + grads
+
+
+class Engine(object):
+    """Owned by a model (fuseunet / UNet); compiles and caches plans, runs forward/backward."""
+
+    def __init__(self, module, build_graph, num_classes):
+        self.module, self.build_graph, self.num_classes = module, build_graph, num_classes
+        self.plans = {}
+        self.forward_serial = 0
+        self.params = None
+        self.grad_hook = None            # callable(flat_grad) e.g. DDP all-reduce of the whole arena
+        self.after_backward_op = None    # callable(step) e.g. bucketed all-reduce overlap
+        self.profiler = None             # object with begin(tag, flops) / end(): per-kernel HIP events
+        self.before_backward = None      # callable(flat_grad) at the start of every backward
+        self.graph = None
+
+    def _refresh_params(self):
+        params = list(self.module.parameters())
+        if self.params is None or len(params) != len(self.params) or \
+                any(a is not b for a, b in zip(params, self.params)):
+            self.params = params
+            self.offsets, off = [], 0
+            for p in params:
+                self.offsets.append(off)
+                off += (p.numel() + 3) // 4 * 4          # 16-byte aligned slots
+            self.flat_numel = off
+            self.graph = self.build_graph()
+            self.plans = {}
+
+    def plan_for(self, inputs):
+        self._refresh_params()
+        x = inputs[0]
+        n, _, h, w = x.shape
+        if h % 16 or w % 16:
+            raise RuntimeError('aide_amd: H and W must be multiples of 16 (got %dx%d)' % (h, w))
+        key = (n, h, w, x.device.index, bool(self.module.training))
+        plan = self.plans.get(key)
+        if plan is None:
+            plan = Plan(self.graph, self.params, n, h, w, x.device, bool(self.module.training))
+            self.plans[key] = plan
+        return plan
+
+    def run(self, *inputs):
+        ins = []
+        for x in inputs:
+            if not isinstance(x, torch.Tensor) or not x.is_cuda:
+                raise RuntimeError('aide_amd models run on a HIP device only (input on %s); there is no '
+                                   'CPU fallback — use the reference for CPU runs'
+                                   % (x.device if isinstance(x, torch.Tensor) else type(x)))
+            if x.dtype != torch.float32 or x.dim() != 4:
+                raise RuntimeError('aide_amd: inputs must be fp32 NCHW tensors')
+            ins.append(x.contiguous())
+        self._refresh_params()
+        for p in self.params:
+            if not p.is_cuda:
+                raise RuntimeError('aide_amd: module parameters are on %s; call .to(device) first' % p.device)
+        return _NetFunction.apply(self, len(ins), *(tuple(ins) + tuple(self.params)))

@@ -1,0 +1,53 @@
+"""MI355X-native drop-in for the reference's single-modality `UNet`
+(models_singlemodalinput/UNet.py:135-165): identical names, signatures and state_dict keys;
+forward/backward run as HIP kernels through aide_amd.engine."""
+import torch.nn as nn
+
+from ..engine import Engine, Graph
+from ..models_twomodalinputs.netblocks import UNet_basic_down_block, UNet_basic_up_block, add_decoder
+
+
+class UNet(nn.Module):
+    _ENC = ((3, 64), (64, 128), (128, 256), (256, 512), (512, 1024))             # UNet.py:139-143
+    _UP = ((1024, 512, 512), (512, 256, 256), (256, 128, 128), (128, 64, 64))    # UNet.py:145-148
+
+    def __init__(self, num_classes=2, learned_bilinear=False):
+        super(UNet, self).__init__()
+        for i, (a, b) in enumerate(self._ENC, 1):
+            blk = UNet_basic_down_block(a, b, i > 1)
+            blk.max_pool = nn.MaxPool2d(2, 2)          # parameter-free; kept for module-tree parity
+            setattr(self, 'down_block%d' % i, blk)
+        for i, (a, p, o) in enumerate(self._UP, 1):
+            setattr(self, 'up_block%d' % i, UNet_basic_up_block(a, p, o, learned_bilinear))
+        self.last_conv1 = nn.Conv2d(64, num_classes, 1, padding=0)
+        self._engine = [Engine(self, self._build_graph, num_classes)]
+
+    @property
+    def engine(self):
+        return self._engine[0]
+
+    def _build_graph(self):
+        """UNet.py:152-165; the pool sits at the start of down blocks 2-5 (UNet.py:117-121)."""
+        g = Graph()
+        x = g.input('image', 3)
+        prev = [p for _, p, _ in self._UP]
+        enc_c = [b for _, b in self._ENC]
+        cats = [g.tensor('cat_s%d' % s, 2 * prev[4 - s], s - 1) for s in range(1, 5)]
+        x5 = g.tensor('x5', enc_c[4], 4)
+        src = x
+        for s in range(1, 6):
+            dst = cats[s - 1].slice(prev[4 - s], enc_c[s - 1], 'x%d' % s) if s <= 4 else x5
+            blk = getattr(self, 'down_block%d' % s).block
+            t = g.tensor('enc_s%d_mid' % s, enc_c[s - 1], s - 1)
+            g.conv_bn_relu(src, t, blk.conv1, blk.bn1)
+            g.conv_bn_relu(t, dst, blk.conv2, blk.bn2)
+            if s < 5:
+                p = g.tensor('pool_s%d' % s, dst.C, s)
+                g.pool(dst, p)
+                src = p
+        skips = [(cats[4 - k], prev[k - 1]) for k in range(1, 5)]
+        add_decoder(g, self, skips, x5, [o for _, _, o in self._UP])
+        return g
+
+    def forward(self, x):
+        return self.engine.run(x)

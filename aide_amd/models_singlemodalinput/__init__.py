@@ -1,0 +1,1 @@
+from .UNet import UNet  # noqa: F401  (reference: models_singlemodalinput/__init__.py:1)

@@ -1,0 +1,80 @@
+"""MI355X-native drop-in for the reference's dual-modality `fuseunet`
+(models_twomodalinputs/fuseunet.py:6-91): same class name, constructor and forward signature,
+parameter registration order and state_dict keys; forward/backward run as hand-written HIP kernels
+through aide_amd.engine."""
+import torch.nn as nn
+
+from ..engine import Engine, Graph
+from .netblocks import UNet_basic_down_block, UNet_basic_up_block, add_decoder
+
+
+class fuseunet(nn.Module):
+    _M1 = ((3, 32), (64, 64), (128, 128), (256, 256), (512, 512))      # fuseunet.py:12-20
+    _M2 = ((3, 32), (32, 64), (64, 128), (128, 256), (256, 512))       # fuseunet.py:24-32
+    _UP = ((1024, 512, 512), (512, 256, 256), (256, 128, 128), (128, 64, 64))   # fuseunet.py:36-39
+
+    def __init__(self, num_classes=2, reduction=16, dilation=4, learned_bilinear=False):
+        super(fuseunet, self).__init__()
+        # `reduction` / `dilation` are accepted and ignored, as in the reference (fuseunet.py:7)
+        for i, (a, b) in enumerate(self._M1, 1):
+            setattr(self, 'modal1_downblock%d' % i, UNet_basic_down_block(a, b))
+            if i < 5:
+                setattr(self, 'modal1_maxpool%d' % i, nn.MaxPool2d(kernel_size=2, stride=2))
+        for i, (a, b) in enumerate(self._M2, 1):
+            setattr(self, 'modal2_downblock%d' % i, UNet_basic_down_block(a, b))
+            if i < 5:
+                setattr(self, 'modal2_maxpool%d' % i, nn.MaxPool2d(kernel_size=2, stride=2))
+        for i, (a, p, o) in enumerate(self._UP, 1):
+            setattr(self, 'up_block%d' % i, UNet_basic_up_block(a, p, o, learned_bilinear))
+        self.last_conv1 = nn.Conv2d(64, num_classes, 1, padding=0)
+        self._engine = [Engine(self, self._build_graph, num_classes)]   # list: not a sub-module/buffer
+
+    @property
+    def engine(self):
+        return self._engine[0]
+
+    def _build_graph(self):
+        """fuseunet.py:43-91 as a static graph over concatenation buffers.
+
+        Stage-s fused skip y_s = cat(modal1_s, modal2_s) lives in the second half of the decoder's
+        cat buffer [up | modal1_s | modal2_s]; pool(y_s) feeds modal1 (all channels) and modal2 (its
+        own slice — max-pool is per-channel, so pool(x) == pool(y_s)[:, c1:])."""
+        g = Graph()
+        x1, x2 = g.input('modal1', 3), g.input('modal2', 3)
+        c1 = [b for _, b in self._M1]
+        c2 = [b for _, b in self._M2]
+        prev = [p for _, p, _ in self._UP]
+        cats = []
+        for s in range(1, 5):                      # decoder k = 5 - s consumes skip s
+            cats.append(g.tensor('cat_s%d' % s, 2 * prev[4 - s], s - 1))
+        y5 = g.tensor('y5', c1[4] + c2[4], 4)
+        src1, src2 = x1, x2
+        for s in range(1, 6):
+            if s <= 4:
+                up_c = prev[4 - s]
+                skip = cats[s - 1].slice(up_c, c1[s - 1] + c2[s - 1], 'y%d' % s)
+            else:
+                skip = y5
+            d1 = skip.slice(0, c1[s - 1])
+            d2 = skip.slice(c1[s - 1], c2[s - 1])
+            lvl = s - 1
+            # modal-2 first: in the backward schedule modal-1 (which reads all channels of the pooled
+            # tensor) then writes the gradient first and modal-2 accumulates into its slice
+            b2 = getattr(self, 'modal2_downblock%d' % s).block
+            t2 = g.tensor('m2_s%d_mid' % s, c2[s - 1], lvl)
+            g.conv_bn_relu(src2, t2, b2.conv1, b2.bn1)
+            g.conv_bn_relu(t2, d2, b2.conv2, b2.bn2)
+            b1 = getattr(self, 'modal1_downblock%d' % s).block
+            t1 = g.tensor('m1_s%d_mid' % s, c1[s - 1], lvl)
+            g.conv_bn_relu(src1, t1, b1.conv1, b1.bn1)
+            g.conv_bn_relu(t1, d1, b1.conv2, b1.bn2)
+            if s < 5:
+                p = g.tensor('pool_s%d' % s, skip.C, s)
+                g.pool(skip, p)
+                src1, src2 = p, p.slice(c1[s - 1], c2[s - 1])
+        skips = [(cats[4 - k], prev[k - 1]) for k in range(1, 5)]
+        add_decoder(g, self, skips, y5, [o for _, _, o in self._UP])
+        return g
+
+    def forward(self, modal1_inputs, modal2_inputs):
+        return self.engine.run(modal1_inputs, modal2_inputs)

@@ -1,0 +1,6 @@
+# mirrors the reference's utils/__init__.py:1-10 for the hot-path symbols
+from .loss2d import (CrossEntropyLoss2d, DiceLoss, CEMDiceLoss, MulticlassDiceLoss, MulticlassMSELoss,  # noqa: F401
+                     CEMDiceLossImage)
+from .metrics2d import Dice_fn  # noqa: F401
+from .coteach_loss import (Coteachingloss_dropimage, Coteachingloss_weightimage, CoTeachingProposedLoss,  # noqa: F401
+                           pseudo_label_ensemble)

@@ -1,0 +1,154 @@
+"""Drop-in loss modules with the reference's names, constructor and forward signatures
+(utils/loss2d.py:5-154), computed by the fused HIP loss kernels (csrc/loss.hip).
+
+Scope: the reference's hot-path configuration — 2 classes, int64 index targets [N,H,W].
+`cediceweight` / `ceclassweight` may be CPU tensors exactly as the reference scripts pass them
+(trainchaos_comparison_1case.py:157-166); they are read as host scalars at construction."""
+import torch
+from torch import nn
+
+from . import _seg
+from .._lib import lib, check
+from ..ops import stream_ptr, ptr
+
+_RED = {'mean': 0, 'sum': 1}
+
+
+class _CEMap(torch.autograd.Function):
+    """reduction='none' cross-entropy map (utils/loss2d.py:8 with reduction='none')."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, t_bs, w0, w1, ignore):
+        n, _, h, w = logits.shape
+        out = torch.empty(n, h, w, device=logits.device, dtype=torch.float32)
+        check(lib.aide_ce_map(ptr(logits), 2 * h * w, ptr(targets), t_bs, w0, w1, ignore, n, h * w, ptr(out),
+                              None, None, 0, stream_ptr()), 'ce_map')
+        ctx.save_for_backward(logits, targets)
+        ctx.cfg = (t_bs, w0, w1, ignore)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, targets = ctx.saved_tensors
+        t_bs, w0, w1, ignore = ctx.cfg
+        n, _, h, w = logits.shape
+        dl = torch.empty_like(logits)
+        check(lib.aide_ce_map(ptr(logits), 2 * h * w, ptr(targets), t_bs, w0, w1, ignore, n, h * w, None,
+                              ptr(g.contiguous()), ptr(dl), 2 * h * w, stream_ptr()), 'ce_map_bwd')
+        return dl, None, None, None, None, None
+
+
+class _MSEMap(torch.autograd.Function):
+    """(softmax(input) - target)^2, elementwise (utils/loss2d.py:115-117 with reduction='none')."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        n, _, h, w = logits.shape
+        out = torch.empty_like(logits)
+        check(lib.aide_mse_map(ptr(logits), 2 * h * w, ptr(target), 2 * h * w, n, h * w, ptr(out), None, None,
+                               0, stream_ptr()), 'mse_map')
+        ctx.save_for_backward(logits, target)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target = ctx.saved_tensors
+        n, _, h, w = logits.shape
+        dl = torch.empty_like(logits)
+        check(lib.aide_mse_map(ptr(logits), 2 * h * w, ptr(target), 2 * h * w, n, h * w, None,
+                               ptr(g.contiguous()), ptr(dl), 2 * h * w, stream_ptr()), 'mse_map_bwd')
+        return dl, None
+
+
+class CrossEntropyLoss2d(nn.Module):
+    def __init__(self, weight=None, reduction='mean', ignore_index=255):
+        super(CrossEntropyLoss2d, self).__init__()
+        self.w0, self.w1 = _seg.class_weights(weight)
+        self.reduction, self.ignore_index = reduction, ignore_index
+
+    def forward(self, inputs, targets):
+        if self.reduction == 'none':
+            logits = _seg._logits(inputs)
+            t, t_bs = _seg._targets(targets, logits)
+            return _CEMap.apply(logits, t, t_bs, self.w0, self.w1, self.ignore_index)
+        loss, self.last = _seg.seg_loss(inputs, targets, self.w0, self.w1, self.ignore_index,
+                                        _RED[self.reduction], 1.0, 0.0, 1.0)
+        return loss
+
+
+class DiceLoss(nn.Module):
+    def __init__(self, weight=None, smooth=1.0, reduction='mean'):
+        super(DiceLoss, self).__init__()
+        self.weight, self.smooth, self.reduction = weight, smooth, reduction
+
+    def forward(self, input, target):
+        if input.dim() <= 3:
+            raise NotImplementedError('aide_amd.DiceLoss takes logits [N,2,H,W] (utils/loss2d.py:44-46); the '
+                                      'probability-input branch is only used inside MulticlassDiceLoss, '
+                                      'which is fused here')
+        red = 2 if self.reduction == 'none' else _RED[self.reduction]
+        loss, self.last = _seg.seg_loss(input, target, 1.0, 1.0, 255, red, 0.0, 1.0 if red else 1.0,
+                                        float(self.smooth))
+        return loss
+
+
+class MulticlassDiceLoss(nn.Module):
+    def __init__(self, weight=None, smooth=1.0, reduction='mean'):
+        super(MulticlassDiceLoss, self).__init__()
+        self.weight, self.smooth, self.reduction = weight, smooth, reduction
+
+    def forward(self, input, target):
+        if target.dim() > 3:
+            raise NotImplementedError('aide_amd.MulticlassDiceLoss: one-hot targets (utils/loss2d.py:98-104) '
+                                      'are not on the hot path; pass int64 index targets')
+        red = 2 if self.reduction == 'none' else _RED[self.reduction]
+        # index targets: class-1 Dice only, class weights ignored (utils/loss2d.py:105-106)
+        loss, self.last = _seg.seg_loss(input, target, 1.0, 1.0, 255, red, 0.0, 1.0, float(self.smooth))
+        return loss
+
+
+class MulticlassMSELoss(nn.Module):
+    def __init__(self, reduction='mean'):
+        super(MulticlassMSELoss, self).__init__()
+        self.reduction = reduction
+
+    def forward(self, input, target):
+        logits = _seg._logits(input)
+        tgt = _seg._dense(target, logits.shape, 'MSE target')
+        m = _MSEMap.apply(logits, tgt)
+        if self.reduction == 'none':
+            return m
+        return m.mean() if self.reduction == 'mean' else m.sum()    # off the hot path
+
+
+def _pair(w):
+    if w is None:
+        return 1.0, 1.0
+    return float(w[0]), float(w[1])
+
+
+class CEMDiceLoss(nn.Module):
+    def __init__(self, cediceweight=None, ceclassweight=None, diceclassweight=None, reduction='mean'):
+        super(CEMDiceLoss, self).__init__()
+        self.w_ce, self.w_dice = _pair(cediceweight)
+        self.w0, self.w1 = _seg.class_weights(ceclassweight)
+        if reduction not in _RED:
+            raise ValueError("CEMDiceLoss: reduction must be 'mean' or 'sum' (the reference's 'none' mixes a "
+                             "[N,H,W] map with a [N] vector)")
+        self.reduction = reduction
+
+    def forward(self, inputs, targets):
+        loss, self.last = _seg.seg_loss(inputs, targets, self.w0, self.w1, 255, _RED[self.reduction],
+                                        self.w_ce, self.w_dice, 1.0)
+        return loss
+
+
+class CEMDiceLossImage(nn.Module):
+    def __init__(self, cediceweight=None, ceclassweight=None, diceclassweight=None, reduction='mean'):
+        super(CEMDiceLossImage, self).__init__()
+        self.w_ce, self.w_dice = _pair(cediceweight)
+        self.w0, self.w1 = _seg.class_weights(ceclassweight)
+
+    def forward(self, inputs, targets):
+        loss, self.last = _seg.seg_loss(inputs, targets, self.w0, self.w1, 255, 2, self.w_ce, self.w_dice, 1.0)
+        return loss

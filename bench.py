@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""Headline benchmark: training images/sec of the FuseUNet hot path on N MI355X (BASELINE.json).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one optimizer step of the comparison loop (train_files/trainchaos_comparison_1case.py:
+195-199): zero_grad, FuseUNet forward, CEMDiceLoss, backward, Adam(amsgrad) [+ gradient all-reduce],
+on a synthetic CHAOS-shaped batch (bs 4/GPU, 2 x 3 x 256 x 256, fp32) already resident in HBM.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md chip table
+WORKLOADS = {
+    # name: (model, per-GPU batch, image size, fwd+bwd algorithmic GFLOP / image)
+    'c2': ('fuseunet', 4, 256, 348.40),
+    'c4': ('UNet', 4, 320, 612.32),
+    'c2-512': ('fuseunet', 4, 512, 1393.58),
+    'tiny': ('fuseunet', 2, 64, 348.40 / 16),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch_size', type=int, default=None, help='per-GPU batch (default: workload)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--no-kernel-events', action='store_true',
+                    help='do not bracket the MFMA conv launches with HIP events (roofline -> null)')
+    return ap.parse_args()
+
+
+def build(model_name, device):
+    from aide_amd.models_twomodalinputs import fuseunet
+    from aide_amd.models_singlemodalinput import UNet
+    torch.manual_seed(2)                                  # reference default --torch_seed 2
+    net = fuseunet(2) if model_name == 'fuseunet' else UNet(2)
+    return net.to(device)
+
+
+def cpu_baseline(model_name, batch, size, steps):
+    """The oracle (plain aten, CPU) timed on the host cores on the SAME workload, bounded sample."""
+    import oracle
+    from aide_amd.synthetic import chaos_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(2)
+    net = oracle.fuseunet(2) if model_name == 'fuseunet' else oracle.UNet(2)
+    net.train()
+    w = torch.tensor([1.0, 1.0])
+    crit = oracle.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, amsgrad=True)
+    xin, xout, t = chaos_batch(batch, size, seed=1234, single_modal=(model_name != 'fuseunet'))
+    oracle.comparison_step(net, crit, opt, xin, xout, t)          # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        oracle.comparison_step(net, crit, opt, xin, xout, t)
+    dt = (time.time() - t0) / steps
+    return dict(value=batch / dt, unit='images/sec', cores=torch.get_num_threads(), kind='port',
+                sample='%d optimizer steps of the same %s bs=%d %dx%d fp32 step (oracle = aten CPU '
+                       'restatement, bit-equal to the reference; 1 warm-up)' % (steps, model_name, batch, size, size),
+                sec_per_step=dt)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=device)
+
+    from aide_amd import utils as U
+    from aide_amd.optim import Adam
+    from aide_amd.synthetic import chaos_batch
+    from aide_amd.profiling import KernelTimer
+    from aide_amd.distributed import GradAllReduce, broadcast_module
+
+    model_name, batch, size, gflop_img = WORKLOADS[args.workload]
+    if args.batch_size:
+        batch = args.batch_size
+    net = build(model_name, device)
+    net.train()
+    if world > 1:
+        broadcast_module(net)
+    reducer = GradAllReduce(net) if world > 1 else None
+    w = torch.tensor([1.0, 1.0])
+    crit = U.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
+    opt = Adam(net.parameters(), lr=1e-4, amsgrad=True)
+    xin, xout, tgt = chaos_batch(batch, size, seed=1234 + rank, single_modal=(model_name != 'fuseunet'))
+    xin, tgt = xin.to(device), tgt.to(device)
+    xout = xout.to(device) if xout is not None else None
+
+    def step():
+        opt.zero_grad()
+        out = net(xin, xout) if xout is not None else net(xin)
+        loss = crit(out, tgt)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    timer = None if args.no_kernel_events else KernelTimer()
+    net.engine.profiler = timer
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    net.engine.profiler = None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = batch * world * args.steps / elapsed
+        roof = None
+        kernels = {}
+        if timer is not None:
+            agg = timer.summary()
+            for k, a in agg.items():
+                kernels[k] = dict(launches=a['launches'], avg_ms=round(a['avg_ms'], 5),
+                                  total_ms_per_step=round(a['ms'] / args.steps, 4),
+                                  tflops=round(a['tflops'], 2))
+            if agg:
+                dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
+                a = dom[1]
+                roof = dict(bound='mfma', kernel=dom[0], achieved=round(a['tflops'], 2),
+                            peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                            frac=round(a['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                            launches_per_step=a['launches'] // args.steps,
+                            avg_launch_ms=round(a['avg_ms'], 5),
+                            alg_gflop_per_launch=round(a['flops'] / a['launches'] / 1e9, 3))
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(model_name, batch, size, args.cpu_steps)
+        line = dict(metric='training images/sec %s %dx%dx2 bs=%d/GPU' % (
+                        'FuseUNet' if model_name == 'fuseunet' else 'UNet', size, size, batch),
+                    value=round(value, 2), unit='images/sec', n_gpus=world, steps=args.steps,
+                    warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True,
+                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    config=dict(workload='%s %s fwd+loss+bwd+Adam(amsgrad), %dx%d %s, bs=%d/GPU, fp32'
+                                         % (args.workload, model_name, size, size,
+                                            '2-modal' if model_name == 'fuseunet' else '1-modal', batch),
+                                global_batch=batch * world, parallelism='dp%d' % world,
+                                alg_gflop_per_image=gflop_img),
+                    step_tflops=round(value * gflop_img / 1e3, 2),
+                    step_mfma_frac=round(value * gflop_img / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+                    final_loss=round(final_loss, 6), roofline=roof, kernels=kernels, cpu_baseline=cpu)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

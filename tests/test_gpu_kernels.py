@@ -155,7 +155,7 @@ def test_upsample_bilinear(dev, shape):
     yr.backward(dy)
     y = torch.empty(n, c, 2 * h, 2 * w, device=dev)
     ops.upsample2x_fwd(x.to(dev), y)
-    _close(y, yr, rtol=1e-6, what='upsample fwd')
+    _close(y, yr, rtol=5e-6, what='upsample fwd')
     dx = torch.empty(n, c, h, w, device=dev)
     ops.upsample2x_bwd(dy.to(dev), dx)
     _close(dx, xr.grad, rtol=1e-5, what='upsample bwd')
