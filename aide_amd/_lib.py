@@ -51,6 +51,10 @@ class _Lib(object):
                 raise RuntimeError(
                     'aide_amd: %s is missing. Build it with `python -m aide_amd.build` '
                     '(hipcc, gfx950). There is no CPU/eager fallback.' % LIB_PATH)
+            # torch must map ITS libamdhip64 first: the kernels launch on torch's streams, so both
+            # have to share one HIP runtime (the dynamic linker then resolves our DT_NEEDED entry to
+            # the already-loaded library of the same SONAME instead of /opt/rocm's copy)
+            import torch  # noqa: F401
             dll = ctypes.CDLL(LIB_PATH)
             for name, (ret, args) in self.protos.items():
                 fn = getattr(dll, name)          # AttributeError if the symbol is not exported
