@@ -8,7 +8,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, 'include', 'aide_hip.h')
-LIB_PATH = os.path.join(HERE, 'libaide_hip.so')
+LIB_PATH = os.environ.get('AIDE_HIP_LIB', os.path.join(HERE, 'libaide_hip.so'))   # override: probe builds
 
 _SCALARS = {
     'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float, 'size_t': ctypes.c_size_t,

@@ -16,7 +16,8 @@ OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libaide_hip.so')
 SOURCES = ['conv3x3.hip', 'conv3x3_wgrad.hip', 'bn.hip', 'spatial.hip', 'loss.hip', 'head_adam.hip',
            'convt.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast'] + \
+    os.environ.get('AIDE_EXTRA_HIPCC_FLAGS', '').split()      # probe builds only (ablation macros)
 
 
 def _hipcc():

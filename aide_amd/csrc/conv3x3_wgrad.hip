@@ -27,22 +27,38 @@ struct WgradArgs {
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int WAVES_CO, int WAVES_CI, int WAVES_PX>
+template <int WAVES_CO, int WAVES_CI, int WAVES_PX, bool RAGGED>
 __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs g) {
     static_assert(WAVES_CO * WAVES_CI * WAVES_PX == 4, "4 waves");
     constexpr int TCO = WAVES_CO * 32, TCI = WAVES_CI * 32;
     constexpr int PT_H = 4, PT_W = 16, NPX = PT_H * PT_W;
-    constexpr int DS = NPX + 1;                       // odd strides: conflict-free fragment reads
+    // dz tile [TCO][4][16]: channel stride 68 keeps 16-B alignment for ds_write_b128 (the A-fragment
+    // read is then 4-way conflicted, one read per 9 MFMAs: irrelevant).  Halo tile [TCI][6][18]:
+    // odd channel stride 109 -> the nine B-fragment reads per k-step are conflict-free.
+    constexpr int DS = NPX + 4;
     constexpr int RS = PT_W + 2, CSR = (PT_H + 2) * RS, CS = CSR + 1;
-    constexpr int DL = TCO * DS, AL = TCI * CS;
-    constexpr int ED = (TCO * NPX + 255) / 256;
-    constexpr int EA = (TCI * CSR + 255) / 256;
+    constexpr int DL = TCO * DS, AL = TCI * CS, BUF = DL + AL;
     constexpr int RED = (WAVES_PX > 1) ? (WAVES_CO * WAVES_CI) * 9 * 16 * 64 : 0;
     constexpr int KSTEPS = NPX / 2 / WAVES_PX;         // pixel pairs per wave per tile
+    constexpr int HALF = KSTEPS / 2;
+    // Staged units per thread and tile.  Dense sizes (H % 4 == 0, W % 16 == 0) use 16-byte loads:
+    //   A: dz rows            TCO*4*4 float4        B: halo interior cols 0..15   TCI*6*4 float4
+    //   C: halo edge columns -1 and 16              TCI*6*2 dwords
+    // RAGGED sizes (deep UNet-320 levels) fall back to one dword per unit with full bounds tests.
+    constexpr int NA = RAGGED ? (TCO * NPX + 255) / 256 : (TCO * 16 + 255) / 256;
+    constexpr int NB = RAGGED ? (TCI * CSR + 255) / 256 : (TCI * 24 + 255) / 256;
+    constexpr int NC = RAGGED ? 0 : (TCI * 12 + 255) / 256;
+    constexpr int NL = NA + NB + NC;                   // global loads per thread per tile
+    constexpr int NW = RAGGED ? NL : NA + 4 * NB + NC; // LDS stores per thread per tile
+    constexpr int PERL = (NL + HALF - 1) / HALF;
+    constexpr int PERW = (NW + HALF - 1) / HALF;
+    static_assert(PERL <= 9 && PERW <= 9, "one staging op per MFMA slot");
 
-    __shared__ float lds[cmax(DL + AL, RED)];
-    float* dl = lds;
-    float* al = lds + DL;
+    // Two LDS tile buffers: while the MFMAs chew on buffer `cur`, the next tile is fetched to
+    // registers during the first half of the k-steps and written to the other buffer during the
+    // second half, so the matrix pipe never waits for a staging burst (one wave per SIMD here).
+    __shared__ __attribute__((aligned(16))) float lds[cmax(2 * BUF, RED)];
+    static_assert(BUF % 4 == 0 && DL % 4 == 0, "16-byte aligned tile buffers");
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int half = lane >> 5, j = lane & 31;
@@ -60,49 +76,122 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs g
     const int tps = (g.tiles_total + g.splits - 1) / g.splits;
     const int t_begin = split * tps, t_end = min(t_begin + tps, g.tiles_total);
 
-    // Element offsets are recomputed per tile from the thread id (constant divisions on the VALU,
-    // which idles beside the MFMA pipe) instead of living in ~90 registers. Loads are SRSRC buffer
-    // loads: 32-bit offsets, and out-of-image / out-of-channel elements read 0.0f via BUF_OOB.
+    // SRSRC buffer loads: 32-bit offsets; units that must read as zero carry the BUF_OOB offset
+    // (hardware returns 0, no branch, no memory traffic).
     const __amdgpu_buffer_rsrc_t drs = make_rsrc(g.dz + (long)co0 * HW);
     const __amdgpu_buffer_rsrc_t ars = make_rsrc(g.a + (long)ci0 * HW - (g.W + 1));
-    float dr[ED], ar[EA];
-    auto load_tile = [&](int t) {
+
+    // ---- tile-invariant per-thread unit descriptors (VGPRs; 512-register budget at 1 wave/SIMD) ----
+    unsigned offA[NA], ldsA[NA];
+    unsigned offB[NB], ldsB[NB], brdB[NB];
+    unsigned offC[NC > 0 ? NC : 1], ldsC[NC > 0 ? NC : 1], brdC[NC > 0 ? NC : 1];
+#pragma unroll
+    for (int e = 0; e < NA; ++e) {
+        const int q = tid + e * 256;
+        if (RAGGED) {
+            const int c = q / NPX, p = q - c * NPX, ph = p / PT_W, pw = p - ph * PT_W;
+            const bool ok = q < TCO * NPX && (co0 + c) < g.Co;
+            offA[e] = ok ? (unsigned)(c * HW + ph * g.W + pw) * 4u : BUF_OOB;
+            ldsA[e] = q < TCO * NPX ? (unsigned)(c * DS + p) : 0xffffffffu;
+        } else {
+            const int c = q / 16, rem = q - c * 16, ph = rem / 4, s4 = rem - ph * 4;
+            const bool ok = q < TCO * 16 && (co0 + c) < g.Co;
+            offA[e] = ok ? (unsigned)(c * HW + ph * g.W + 4 * s4) * 4u : BUF_OOB;
+            ldsA[e] = q < TCO * 16 ? (unsigned)(c * DS + ph * 16 + 4 * s4) : 0xffffffffu;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+        const int q = tid + e * 256;
+        if (RAGGED) {
+            const int c = q / CSR, rem = q - c * CSR;
+            const bool ok = q < TCI * CSR && (ci0 + c) < g.Ci;
+            offB[e] = ok ? (unsigned)(c * HW + (rem / RS) * g.W + rem % RS) * 4u : BUF_OOB;
+            ldsB[e] = q < TCI * CSR ? (unsigned)(DL + c * CS + rem) : 0xffffffffu;
+            brdB[e] = 0;
+        } else {
+            const int c = q / 24, rem = q - c * 24, r = rem / 4, s4 = rem - r * 4;
+            const bool ok = q < TCI * 24 && (ci0 + c) < g.Ci;
+            offB[e] = ok ? (unsigned)(c * HW + r * g.W + 1 + 4 * s4) * 4u : BUF_OOB;
+            ldsB[e] = q < TCI * 24 ? (unsigned)(DL + c * CS + r * RS + 1 + 4 * s4) : 0xffffffffu;
+            brdB[e] = (r == 0 ? 1u : 0u) | (r == PT_H + 1 ? 2u : 0u);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NC; ++e) {
+        const int q = tid + e * 256;
+        const int c = q / 12, rem = q - c * 12, r = rem / 2, side = rem - r * 2;
+        const int col = side ? PT_W + 1 : 0;
+        const bool ok = q < TCI * 12 && (ci0 + c) < g.Ci;
+        offC[e] = ok ? (unsigned)(c * HW + r * g.W + col) * 4u : BUF_OOB;
+        ldsC[e] = q < TCI * 12 ? (unsigned)(DL + c * CS + r * RS + col) : 0xffffffffu;
+        brdC[e] = (r == 0 ? 1u : 0u) | (r == PT_H + 1 ? 2u : 0u) | (side ? 8u : 4u);
+    }
+
+    int th0 = 0, tw0 = 0;                  // origin of the tile being fetched
+    unsigned dso = 0, aso = 0, tcode = 0;
+    auto set_tile = [&](int t) {
+        t = min(t, t_end - 1);             // past the end: refetch the last tile (never consumed)
         const int tw = t % g.tiles_w;
         const int r2 = t / g.tiles_w;
-        const int th = r2 % g.tiles_h, n = r2 / g.tiles_h;
-        const int h0 = th * PT_H, w0 = tw * PT_W;
-        const unsigned dso = (unsigned)((long)n * g.dz_bs + h0 * g.W + w0) * 4u;
-#pragma unroll
-        for (int e = 0; e < ED; ++e) {
-            const int idx = tid + e * 256;
-            const int c = idx / NPX, p = idx - c * NPX;
-            const int ph = p / PT_W, pw = p - ph * PT_W;
-            const bool ok = idx < TCO * NPX && (co0 + c) < g.Co && (h0 + ph) < g.H && (w0 + pw) < g.W;
-            dr[e] = buf_load_f32(drs, ok ? (unsigned)(c * HW + ph * g.W + pw) * 4u : BUF_OOB, dso);
-        }
-        const unsigned aso = (unsigned)((long)n * g.a_bs + h0 * g.W + w0) * 4u;
-#pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            const int idx = tid + e * 256;
-            const int c = idx / CSR, rem = idx - c * CSR;
-            const int r = rem / RS, col = rem - r * RS;
-            const int ih = h0 - 1 + r, iw = w0 - 1 + col;
-            const bool ok = idx < TCI * CSR && (ci0 + c) < g.Ci && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-            ar[e] = buf_load_f32(ars, ok ? (unsigned)(c * HW + r * g.W + col) * 4u : BUF_OOB, aso);
+        const int th = r2 % g.tiles_h;
+        const int tn = r2 / g.tiles_h;
+        th0 = th * PT_H; tw0 = tw * PT_W;
+        dso = (unsigned)((long)tn * g.dz_bs + th0 * g.W + tw0) * 4u;
+        aso = (unsigned)((long)tn * g.a_bs + th0 * g.W + tw0) * 4u;
+        // which image borders the tile touches: {top, bottom, left, right}
+        tcode = (th0 == 0 ? 1u : 0u) | (th0 + PT_H >= g.H ? 2u : 0u) | (tw0 == 0 ? 4u : 0u) |
+                (tw0 + PT_W >= g.W ? 8u : 0u);
+    };
+
+    f32x4 stA[NA], stB[NB];      // RAGGED uses only component 0
+    float stC[NC > 0 ? NC : 1];
+    // global load number l (compile-time) of the current set_tile()
+    auto fetch = [&](int l) {
+        if (l < NA) {
+            unsigned off = offA[l];
+            if (RAGGED) {
+                const int p = (tid + l * 256) % NPX;
+                if ((th0 + p / PT_W) >= g.H || (tw0 + p % PT_W) >= g.W) off = BUF_OOB;
+                stA[l][0] = buf_load_f32(drs, off, dso);
+            } else {
+                stA[l] = buf_load_f32x4(drs, off, dso);
+            }
+        } else if (l < NA + NB) {
+            const int e = l - NA;
+            unsigned off = offB[e];
+            if (RAGGED) {
+                const int rem = (tid + e * 256) % CSR;
+                const int ih = th0 - 1 + rem / RS, iw = tw0 - 1 + rem % RS;
+                if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) off = BUF_OOB;
+                stB[e][0] = buf_load_f32(ars, off, aso);
+            } else {
+                if ((brdB[e] & tcode) != 0u) off = BUF_OOB;
+                stB[e] = buf_load_f32x4(ars, off, aso);
+            }
+        } else {
+            const int e = l - NA - NB;
+            unsigned off = offC[e];
+            if ((brdC[e] & tcode) != 0u) off = BUF_OOB;
+            stC[e] = buf_load_f32(ars, off, aso);
         }
     };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int e = 0; e < ED; ++e) {
-            const int idx = tid + e * 256;
-            const int c = idx / NPX, p = idx - c * NPX;
-            if (idx < TCO * NPX) dl[c * DS + p] = dr[e];
-        }
-#pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            const int idx = tid + e * 256;
-            const int c = idx / CSR, rem = idx - c * CSR;
-            if (idx < TCI * CSR) al[c * CS + rem] = ar[e];
+    // LDS store number w (compile-time) into tile buffer `buf`
+    auto put = [&](int w, float* buf) {
+        if (w < NA) {
+            if (ldsA[w] != 0xffffffffu) {
+                if (RAGGED) buf[ldsA[w]] = stA[w][0];
+                else *reinterpret_cast<f32x4*>(buf + ldsA[w]) = stA[w];
+            }
+        } else if (RAGGED) {
+            const int e = w - NA;
+            if (ldsB[e] != 0xffffffffu) buf[ldsB[e]] = stB[e][0];
+        } else if (w < NA + 4 * NB) {
+            const int e = (w - NA) / 4, i = (w - NA) % 4;
+            if (ldsB[e] != 0xffffffffu) buf[ldsB[e] + i] = stB[e][i];
+        } else {
+            const int e = w - NA - 4 * NB;
+            if (ldsC[e] != 0xffffffffu) buf[ldsC[e]] = stC[e];
         }
     };
 
@@ -113,38 +202,59 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs g
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     // this wave handles pixel pairs s = wave_px + WAVES_PX*u ; first pixel 2*s + half
-    const float* la = dl + (wave_co * 32 + j) * DS + 2 * wave_px + half;
-    const float* lb = al + (wave_ci * 32 + j) * CS + 2 * wave_px + half;
-    const bool active = (co0 + wave_co * 32) < g.Co && (ci0 + wave_ci * 32) < g.Ci;
+    const int la_off = (wave_co * 32 + j) * DS + 2 * wave_px + half;
+    const int lb_off = DL + (wave_ci * 32 + j) * CS + 2 * wave_px + half;
+    const bool active = __builtin_amdgcn_readfirstlane(
+        (int)((co0 + wave_co * 32) < g.Co && (ci0 + wave_ci * 32) < g.Ci)) != 0;   // wave-uniform
 
-    if (t_begin < t_end) load_tile(t_begin);
+    // prologue: first tile straight into buffer 0
+    set_tile(t_begin);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) fetch(l);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) put(w, lds);
+    __syncthreads();
+
+    int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
-        __syncthreads();
-        store_tile();
-        __syncthreads();
-        if (t + 1 < t_end) load_tile(t + 1);
-        if (active) {
-            // explicit one-step-ahead fragment pipeline; the sched_barrier keeps hipcc from hoisting
-            // all KSTEPS*10 LDS reads above the MFMAs (which blew the register budget)
-            constexpr int STEP = 2 * WAVES_PX;           // pixels advanced per u (divides PT_W)
-            float af[2], bf[2][9];
-            auto frag = [&](int u, int buf) {
-                const int p = u * STEP;                  // compile-time after unrolling
-                const int ph = p / PT_W, pw = p % PT_W;
-                af[buf] = la[p];
+        const float* la = lds + cur * BUF + la_off;
+        const float* lb = lds + cur * BUF + lb_off;
+        float* nxt = lds + (cur ^ 1) * BUF;
+        set_tile(t + 1);
+        constexpr int STEP = 2 * WAVES_PX;                // pixels advanced per u (divides PT_W)
+        // Issue order is pinned slot by slot: ONE MFMA, then a small slice of the other work (one
+        // fragment read for the next k-step, at most one global fetch or one LDS store), so every
+        // non-matrix instruction issues in the shadow of a 64-cycle MFMA.
+        // (two separately named fragment sets: an array indexed by u&1 gets demoted to memory)
+        float afA, afB, bfA[9], bfB[9];
+        afA = la[0];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) bf[buf][k] = lb[(ph + k / 3) * RS + pw + (k % 3)];
-            };
-            frag(0, 0);
+        for (int k = 0; k < 9; ++k) bfA[k] = lb[(k / 3) * RS + (k % 3)];
+        auto kstep = [&](int u, float& afc, float (&bfc)[9], float& afn, float (&bfn)[9]) {
+            const int pn = (u + 1) * STEP;                // first pixel of the next k-step
+            const int phn = pn / PT_W, pwn = pn % PT_W;
 #pragma unroll
-            for (int u = 0; u < KSTEPS; ++u) {
-                if (u + 1 < KSTEPS) frag(u + 1, (u + 1) & 1);
-#pragma unroll
-                for (int k = 0; k < 9; ++k)
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1], bf[u & 1][k], acc[k], 0, 0, 0);
+            for (int k = 0; k < 9; ++k) {
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(afc, bfc[k], acc[k], 0, 0, 0);
+                if (u + 1 < KSTEPS) {
+                    if (k == 0) afn = la[phn * 16 + pwn];
+                    bfn[k] = lb[(phn + k / 3) * RS + pwn + (k % 3)];
+                }
+                if (u < HALF) {
+                    if (k < PERL && u * PERL + k < NL) fetch(u * PERL + k);
+                } else {
+                    if (k < PERW && (u - HALF) * PERW + k < NW) put((u - HALF) * PERW + k, nxt);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+#pragma unroll
+        for (int u = 0; u < KSTEPS; u += 2) {
+            kstep(u, afA, bfA, afB, bfB);
+            kstep(u + 1, afB, bfB, afA, bfA);
         }
+        __syncthreads();
+        cur ^= 1;
     }
 
     // ---- sum the WAVES_PX partial accumulators of each (co,ci) wave block through LDS ----
@@ -168,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs g
         }
     }
 
-    if (wave_px == 0 && active) {
+    if (wave_px == 0 && active) {   // partial (co,ci) blocks: idle waves multiplied zeros
         float* slab = g.slabs + (long)split * 9 * g.Co * g.Ci;
         const int ci = ci0 + wave_ci * 32 + j;
 #pragma unroll
@@ -182,22 +292,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs g
     }
 }
 
-// dW[co][ci][t] = sum_s slab[s][t][co][ci]   (thread per (co,ci); fixed order)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, int Co, int Ci,
-                                    float* __restrict__ dw) {
-    const long total = (long)Co * Ci;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long)gridDim.x * blockDim.x) {
-        float v[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) v[t] = slabs[(long)t * total + i];
-        for (int s = 1; s < splits; ++s) {
-            const float* sl = slabs + (long)s * 9 * total;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) v[t] += sl[(long)t * total + i];
-        }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) dw[i * 9 + t] = v[t];
+// dW[co][ci][t] = sum_s slab[s][t][co][ci].  Block = 64 elements x 4 split-slices: every thread sums
+// a contiguous quarter of the splits (coalesced along ci), the four partial sums are combined in a
+// fixed order through LDS (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, int Co,
+                                                           int Ci, float* __restrict__ dw) {
+    __shared__ float sm[4][64];
+    const long cc = (long)Co * Ci, total = 9 * cc;
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + x;                 // e = (t*Co + co)*Ci + ci
+    const int per = (splits + 3) / 4;
+    const int s0 = y * per, s1 = min(s0 + per, splits);
+    float v = 0.f;
+    if (e < total)
+        for (int s = s0; s < s1; ++s) v += slabs[(long)s * total + e];
+    sm[y][x] = v;
+    __syncthreads();
+    if (y == 0 && e < total) {
+        const float r = ((sm[0][x] + sm[1][x]) + sm[2][x]) + sm[3][x];
+        const long t = e / cc, rem = e - t * cc;              // rem = co*Ci + ci
+        dw[rem * 9 + t] = r;
     }
 }
 
@@ -206,8 +320,12 @@ int launch_wgrad(WgradArgs g, hipStream_t stream) {
     g.n_co_tiles = (g.Co + WAVES_CO * 32 - 1) / (WAVES_CO * 32);
     g.n_ci_tiles = (g.Ci + WAVES_CI * 32 - 1) / (WAVES_CI * 32);
     const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
-    hipLaunchKernelGGL((conv3x3_wgrad_kernel<WAVES_CO, WAVES_CI, WAVES_PX>), dim3((unsigned)nb),
-                       dim3(256), 0, stream, g);
+    if (g.H % 4 != 0 || g.W % 16 != 0)
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<WAVES_CO, WAVES_CI, WAVES_PX, true>), dim3((unsigned)nb),
+                           dim3(256), 0, stream, g);
+    else
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<WAVES_CO, WAVES_CI, WAVES_PX, false>), dim3((unsigned)nb),
+                           dim3(256), 0, stream, g);
     return aide_launch_status();
 }
 
@@ -234,7 +352,10 @@ int aide_conv3x3_wgrad_splits(int N, int Co, int Ci, int H, int W) {
     int nco, nci;
     wgrad_tiles(wgrad_variant(Co, Ci), Co, Ci, &nco, &nci);
     const long tiles = (long)N * ((H + 3) / 4) * ((W + 15) / 16);
-    long s = (512 + (long)nco * nci - 1) / ((long)nco * nci);   // ~2 workgroups per CU
+    // one workgroup per CU (two 45 KB tile buffers + 144 accumulator registers per lane): aim for
+    // one full round of 256 workgroups, each paying the tile-pipeline prologue only once
+    const long blocks = (long)nco * nci;
+    long s = (256 + blocks - 1) / blocks;
     if (s > tiles) s = tiles;
     if (s < 1) s = 1;
     return (int)s;
@@ -263,9 +384,9 @@ int aide_conv3x3_wgrad(const float* dz, int64_t dz_bs, const float* a, int64_t a
         default: rc = launch_wgrad<1, 1, 4>(g, stream); break;
     }
     if (rc != 0) return rc;
-    const long total = (long)Co * Ci;
-    const int blocks = (int)min((total + 255) / 256, (long)2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, g.splits, Co, Ci, dw);
+    const long total = 9L * Co * Ci;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, ws,
+                       g.splits, Co, Ci, dw);
     return aide_launch_status();
 }
 
