@@ -1,0 +1,113 @@
+"""Comparison training loop on MI355X with the reference's CLI.
+
+Mirrors train_files/trainchaos_comparison_1case.py: the flag names and defaults of parse_args()
+(:21-49), build_model() and its ValueError (:61-66), seeding (:108-112), criterion selection
+(:157-168), Adam(amsgrad)+StepLR (:170-176) and the inner step (:190-202).  Dataset I/O, per-case
+evaluation and checkpoint bookkeeping are out of scope: batches come from the
+synthetic CHAOS-shaped generator, and unlike the reference nothing runs at import time.
+
+    python -m aide_amd.train_files.trainchaos_comparison_1case --model_name fuseunet --batch_size 4
+"""
+import argparse
+import logging
+import random
+import time
+
+import numpy as np
+import torch
+from torch.optim.lr_scheduler import StepLR
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description='CHAOS segmentation, comparison model (MI355X HIP engine)')
+    p.add_argument('--model_name', default='fuseunet', type=str, help='fuseunet')
+    p.add_argument('--data_mean', default=None, nargs='+', type=float)
+    p.add_argument('--data_std', default=None, nargs='+', type=float)
+    p.add_argument('--batch_size', default=4, type=int)
+    p.add_argument('--gpu_order', default='0', type=str)
+    p.add_argument('--torch_seed', default=2, type=int)
+    p.add_argument('--lr', default=1e-4, type=float)
+    p.add_argument('--num_epoch', default=100, type=int)
+    p.add_argument('--loss', default='cedice', type=str, help='ce, dice, cedice')
+    p.add_argument('--img_size', default=256, type=int)
+    p.add_argument('--lr_policy', default='StepLR', type=str)
+    p.add_argument('--cedice_weight', default=[1.0, 1.0], nargs='+', type=float)
+    p.add_argument('--ceclass_weight', default=[1.0, 1.0], nargs='+', type=float)
+    p.add_argument('--diceclass_weight', default=[1.0, 1.0], nargs='+', type=float)
+    p.add_argument('--checkpoint', default='checkpoint_comparison_1case/')
+    p.add_argument('--history', default='history_comparison_1case')
+    p.add_argument('--cudnn', default=0, type=int)
+    p.add_argument('--repetition', default=2, type=int)
+    # not in the reference: size of the synthetic epoch (there is no dataset on this path)
+    p.add_argument('--steps_per_epoch', default=16, type=int)
+    return p.parse_args(argv)
+
+
+def build_model(model_name, num_classes):
+    if model_name == 'fuseunet':
+        from aide_amd.models_twomodalinputs import fuseunet
+        return fuseunet(num_classes=num_classes)
+    if model_name == 'UNet':
+        from aide_amd.models_singlemodalinput import UNet
+        return UNet(num_classes=num_classes)
+    raise ValueError('Model not implemented')
+
+
+def Train(args=None):
+    from aide_amd import utils as U
+    from aide_amd.optim import Adam
+    from aide_amd.synthetic import chaos_batch
+    args = args or parse_args()
+    torch.manual_seed(args.torch_seed)
+    torch.cuda.manual_seed_all(args.torch_seed)
+    np.random.seed(args.torch_seed)
+    random.seed(args.torch_seed)
+    device = torch.device('cuda:%d' % int(args.gpu_order.split(',')[0]))
+    num_classes = 2
+    net = build_model(args.model_name, num_classes).to(device)
+    cedice_weight = torch.tensor(args.cedice_weight)
+    ceclass_weight = torch.tensor(args.ceclass_weight)
+    diceclass_weight = torch.tensor(args.diceclass_weight)
+    if args.loss == 'ce':
+        criterion = U.CrossEntropyLoss2d(weight=ceclass_weight)
+    elif args.loss == 'dice':
+        criterion = U.MulticlassDiceLoss(weight=diceclass_weight)
+    elif args.loss == 'cedice':
+        criterion = U.CEMDiceLoss(cediceweight=cedice_weight, ceclassweight=ceclass_weight,
+                                  diceclassweight=diceclass_weight)
+    else:
+        raise ValueError('Do not have this loss')
+    optimizer = Adam(net.parameters(), lr=args.lr, amsgrad=True)
+    scheduler = StepLR(optimizer, step_size=30, gamma=0.5)
+    single = args.model_name != 'fuseunet'
+    history = {'train_loss': [], 'train_dice': []}
+    for epoch in range(args.num_epoch):
+        ts = time.time()
+        net.train()
+        loss_sum = torch.zeros((), device=device)
+        dice_sum = torch.zeros((), device=device)
+        count = 0
+        for it in range(args.steps_per_epoch):
+            inphase, outphase, targets = chaos_batch(args.batch_size, args.img_size,
+                                                     seed=args.torch_seed * 100003 + epoch * 1009 + it,
+                                                     single_modal=single)
+            inphase, targets = inphase.to(device), targets.to(device)
+            optimizer.zero_grad()
+            outputs = net(inphase) if single else net(inphase, outphase.to(device))
+            loss = criterion(outputs, targets)
+            loss.backward()
+            optimizer.step()
+            count += inphase.shape[0]
+            loss_sum += loss.detach() * inphase.shape[0]      # device-side accumulation: one host
+            dice_sum += U.Dice_fn(outputs, targets)           # sync per epoch instead of two per step
+        scheduler.step()
+        history['train_loss'].append(float(loss_sum) / count)
+        history['train_dice'].append(float(dice_sum) / count)
+        logging.info('epoch %d train_loss %.4f train_dice %.4f time %.1fs', epoch + 1,
+                     history['train_loss'][-1], history['train_dice'][-1], time.time() - ts)
+    return net, history
+
+
+if __name__ == '__main__':
+    logging.basicConfig(level=logging.INFO, format='%(message)s')
+    Train()

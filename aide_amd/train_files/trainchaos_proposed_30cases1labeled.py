@@ -1,0 +1,117 @@
+"""AIDE proposed co-teaching loop on MI355X with the reference's CLI
+(train_files/trainchaos_proposed_30cases1labeled.py: parse_args :21-57, inner step :260-330).
+
+Two FuseUNets are co-trained; per step each net does 4 augmented forwards (train-mode BatchNorm, as
+in the reference) + 1 training forward + 1 backward.  Pseudo-label ensemble, sharpening, weight
+maps, both per-image CE+Dice vectors, the two ascending sorts, the keep/drop split and the composite
+losses run as fused HIP kernels (aide_amd.utils.coteach_loss).  The PIL reverse-augmentation
+(:81-95) is a "next" row: synthetic augmentations here are intensity-only, so the
+reverse map is the identity.
+"""
+import argparse
+import logging
+import random
+import time
+
+import numpy as np
+import torch
+from torch.optim.lr_scheduler import StepLR
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description='CHAOS segmentation, AIDE proposed (MI355X HIP engine)')
+    p.add_argument('--model_name', default='fuseunet', type=str)
+    p.add_argument('--data_mean', default=None, nargs='+', type=float)
+    p.add_argument('--data_std', default=None, nargs='+', type=float)
+    p.add_argument('--batch_size', default=4, type=int)
+    p.add_argument('--gpu_order', default='0', type=str)
+    p.add_argument('--torch_seed', default=2, type=int)
+    p.add_argument('--lr', default=1e-4, type=float)
+    p.add_argument('--num_epoch', default=100, type=int)
+    p.add_argument('--loss', default='cedice', type=str)
+    p.add_argument('--img_size', default=256, type=int)
+    p.add_argument('--lr_policy', default='StepLR', type=str)
+    p.add_argument('--cedice_weight', default=[1.0, 1.0], nargs='+', type=float)
+    p.add_argument('--ceclass_weight', default=[1.0, 1.0], nargs='+', type=float)
+    p.add_argument('--diceclass_weight', default=[1.0, 1.0], nargs='+', type=float)
+    p.add_argument('--rotation', default=60.0, type=float)
+    p.add_argument('--warmup_epoch', default=20, type=int)
+    p.add_argument('--temperature', default=1.0, type=float)
+    p.add_argument('--segcor_weight', default=[1.0, 10.0], nargs='+', type=float)
+    p.add_argument('--checkpoint', default='checkpoint_proposed/')
+    p.add_argument('--history', default='history_proposed')
+    p.add_argument('--cudnn', default=0, type=int)
+    p.add_argument('--repetition', default=1, type=int)
+    p.add_argument('--steps_per_epoch', default=8, type=int)
+    return p.parse_args(argv)
+
+
+def coteach_step(net1, net2, opt1, opt2, loss_op, inphase, outphase, aug_pairs, targets1, targets2, rate,
+                 temperature=1.0):
+    """One step of trainchaos_proposed_30cases1labeled.py:260-325 on device tensors."""
+    from aide_amd.utils import pseudo_label_ensemble
+    a1, a2 = [], []
+    for xin, xout in aug_pairs:                                   # :265-269
+        a1.append(net1(xin, xout).detach())
+        a2.append(net2(xin, xout).detach())
+    pl1, wm1 = pseudo_label_ensemble(a1, temperature)             # :274-292
+    pl2, wm2 = pseudo_label_ensemble(a2, temperature)
+    opt1.zero_grad()
+    opt2.zero_grad()
+    o1 = net1(inphase, outphase)                                  # :301-302
+    o2 = net2(inphase, outphase)
+    loss1, loss2, indx1, indx2 = loss_op(o1, o2, targets1, targets2, pl1, wm1, pl2, wm2, rate)   # :303-321
+    loss1.backward()                                              # :322-325 (graphs are disjoint)
+    opt1.step()
+    loss2.backward()
+    opt2.step()
+    return dict(outputs1=o1.detach(), outputs2=o2.detach(), loss1=loss1.detach(), loss2=loss2.detach(),
+                indx1=indx1, indx2=indx2, extra=loss_op.last)
+
+
+def Train(args=None):
+    from aide_amd.models_twomodalinputs import fuseunet
+    from aide_amd.optim import Adam
+    from aide_amd.synthetic import chaos_batch
+    from aide_amd.utils import CoTeachingProposedLoss
+    args = args or parse_args()
+    if args.model_name != 'fuseunet':
+        raise ValueError('Model not implemented')
+    torch.manual_seed(args.torch_seed)
+    torch.cuda.manual_seed_all(args.torch_seed)
+    np.random.seed(args.torch_seed)
+    random.seed(args.torch_seed)
+    device = torch.device('cuda:%d' % int(args.gpu_order.split(',')[0]))
+    net1, net2 = fuseunet(2).to(device), fuseunet(2).to(device)
+    loss_op = CoTeachingProposedLoss(cediceweight=args.cedice_weight, ceclassweight=args.ceclass_weight,
+                                     segcor_weight=args.segcor_weight, keep=2)
+    opt1 = Adam(net1.parameters(), lr=args.lr, amsgrad=True)
+    opt2 = Adam(net2.parameters(), lr=args.lr, amsgrad=True)
+    sch1, sch2 = StepLR(opt1, 30, 0.5), StepLR(opt2, 30, 0.5)
+    g = torch.Generator(device='cpu').manual_seed(args.torch_seed)
+    for epoch in range(args.num_epoch):
+        ts = time.time()
+        rate = min((float(epoch) / float(args.warmup_epoch)) ** 2, 1.0)          # :248
+        net1.train()
+        net2.train()
+        l1 = torch.zeros((), device=device)
+        l2 = torch.zeros((), device=device)
+        for it in range(args.steps_per_epoch):
+            xin, xout, t = chaos_batch(args.batch_size, args.img_size,
+                                       seed=args.torch_seed * 100003 + epoch * 1009 + it)
+            augs = [((xin * (1 + 0.1 * torch.randn(1, generator=g))).to(device),
+                     (xout * (1 + 0.1 * torch.randn(1, generator=g))).to(device)) for _ in range(4)]
+            xin, xout, t = xin.to(device), xout.to(device), t.to(device)
+            r = coteach_step(net1, net2, opt1, opt2, loss_op, xin, xout, augs, t, t, rate, args.temperature)
+            l1 += r['loss1']
+            l2 += r['loss2']
+        sch1.step()
+        sch2.step()
+        logging.info('epoch %d loss1 %.4f loss2 %.4f time %.1fs', epoch + 1, float(l1) / args.steps_per_epoch,
+                     float(l2) / args.steps_per_epoch, time.time() - ts)
+    return net1, net2
+
+
+if __name__ == '__main__':
+    logging.basicConfig(level=logging.INFO, format='%(message)s')
+    Train()

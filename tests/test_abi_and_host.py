@@ -1,0 +1,143 @@
+"""CPU: the C-ABI library loads and exports every symbol include/aide_hip.h declares (no compute
+calls without a GPU), plus the pure host logic (planner heuristics, backward write analysis, graph
+construction, DDP bucket scheduling, synthetic data contract, loud failure on CPU tensors)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built():
+    from aide_amd.build import build
+    return build(verbose=False)
+
+
+def test_header_symbols_exported(built):
+    from aide_amd._lib import lib, parse_header
+    protos = parse_header()
+    assert len(protos) >= 35
+    out = subprocess.run(['nm', '-D', '--defined-only', built], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    missing = [n for n in protos if n not in exported]
+    assert not missing, 'declared in include/aide_hip.h but not exported: %s' % missing
+    extra = [n for n in exported if n.startswith('aide_') and n not in protos]
+    assert not extra, 'exported but not declared in include/aide_hip.h: %s' % extra
+    lib.load()          # dlopen + prototype binding of every entry point
+
+
+def test_host_side_planners(built):
+    """Pure host functions of the ABI (no device needed)."""
+    from aide_amd._lib import lib
+    assert lib.aide_conv3x3_chunk(3) == 4 and lib.aide_conv3x3_chunk(64) == 8
+    for (n, ci, h, co) in [(4, 3, 256, 32), (4, 128, 256, 64), (4, 1024, 32, 512), (4, 512, 16, 512),
+                           (4, 512, 20, 1024), (1, 64, 16, 64), (8, 128, 512, 64)]:
+        plan = lib.aide_conv3x3_plan(n, ci, h, h, co)
+        variant, splitk = plan & 255, plan >> 8
+        assert 0 <= variant <= 5 and splitk >= 1
+        tco = {0: 32, 1: 64, 2: 128, 3: 64, 4: 64, 5: 128}[variant]
+        assert co % tco == 0
+        assert lib.aide_conv3x3_ws_bytes(n, h, h, co, splitk) == (0 if splitk == 1 else splitk * n * co * h * h * 4)
+        s = lib.aide_conv3x3_wgrad_splits(n, co, ci, h, h)
+        assert 1 <= s <= n * ((h + 3) // 4) * ((h + 15) // 16)
+        assert lib.aide_conv3x3_wgrad_ws_bytes(n, co, ci, h, h) == s * 9 * co * ci * 4
+    assert lib.aide_seg_loss_blocks(256 * 256) >= 1
+    assert lib.aide_bn_ws_bytes(64) > 0 and lib.aide_head1x1_ws_bytes(64, 2) > 0
+
+
+def test_cover_analysis():
+    from aide_amd.engine import _Cover
+    c = _Cover()
+    assert c.write(0, 128) == (False, [])
+    assert c.write(64, 128) == (True, [])
+    c = _Cover()
+    assert c.write(32, 64) == (False, [])
+    acc, gaps = c.write(0, 64)
+    assert acc and gaps == [(0, 32)]
+    acc, gaps = c.write(0, 96)
+    assert acc and gaps == [(64, 96)]
+
+
+@pytest.mark.parametrize('learned', [False, True])
+def test_graphs(learned):
+    from aide_amd.models_twomodalinputs import fuseunet
+    from aide_amd.models_singlemodalinput import UNet
+    for ctor, nconv, npool in ((fuseunet, 32, 4), (UNet, 22, 4)):
+        net = ctor(2, learned_bilinear=learned)
+        net.engine._refresh_params()
+        g = net.engine.graph
+        kinds = [op['kind'] for op in g.ops]
+        assert kinds.count('head') == 1 and kinds[-1] == 'head'
+        assert kinds.count('pool') == npool
+        assert kinds.count('up') == (0 if learned else 4)
+        assert kinds.count('convT') == (4 if learned else 0)
+        assert kinds.count('conv') == nconv - (4 if learned else 0)
+        # every parameter is owned by exactly one op
+        owned = []
+        for op in g.ops:
+            for key in ('conv', 'bn'):
+                if op.get(key) is not None:
+                    owned += [id(p) for p in op[key].parameters()]
+        assert sorted(owned) == sorted(id(p) for p in net.parameters())
+        # cat elimination: the decoder reads [up | skip] buffers that producers wrote in place
+        cat_reads = [op for op in g.ops if op['kind'] == 'conv' and op['src'].root.name.startswith('cat_')
+                     and op['src'].C == op['src'].root.C]
+        assert len(cat_reads) == 4
+
+
+def test_state_dict_and_init_match_oracle():
+    import oracle
+    from aide_amd.models_twomodalinputs import fuseunet
+    torch.manual_seed(2)
+    a = fuseunet(2)
+    torch.manual_seed(2)
+    b = oracle.fuseunet(2)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa) == list(sb) and len(sa) == 226
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    a.load_state_dict(sb)          # reference-format checkpoints load
+
+
+def test_no_cpu_fallback():
+    from aide_amd.models_twomodalinputs import fuseunet
+    from aide_amd import utils as U
+    net = fuseunet(2)
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        net(torch.zeros(1, 3, 32, 32), torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        U.CEMDiceLoss()(torch.zeros(1, 2, 8, 8), torch.zeros(1, 8, 8, dtype=torch.int64))
+    with pytest.raises(RuntimeError):
+        net.modal1_downblock1(torch.zeros(1, 3, 32, 32))      # blocks are parameter containers
+    with pytest.raises(IndexError):
+        U.Coteachingloss_dropimage()                           # reference: default 'mean' cannot work
+    with pytest.raises(ValueError):
+        from aide_amd.train_files.trainchaos_comparison_1case import build_model
+        build_model('nope', 2)
+
+
+def test_bucket_scheduler():
+    from aide_amd.distributed import make_buckets, BucketScheduler
+    offsets, numels, off = [], [10, 1000, 5, 5000, 20, 3000], 0
+    for n in numels:
+        offsets.append(off)
+        off += (n + 3) // 4 * 4
+    buckets = make_buckets(offsets, numels, 2000)
+    assert [b[2] for b in buckets] == [[0, 1, 2, 3], [4, 5]]
+    sch = BucketScheduler(buckets, len(numels))
+    assert sch.mark([5]) == [] and sch.mark([4]) == [1]
+    assert sch.mark([3, 2, 1]) == [] and sch.mark([0, 0]) == [0]
+
+
+def test_synthetic_contract():
+    from aide_amd.synthetic import chaos_batch
+    a, b, t = chaos_batch(8, 64, seed=3)
+    assert a.shape == (8, 3, 64, 64) and a.dtype == torch.float32 and t.dtype == torch.int64
+    assert torch.equal(a[:, 0], a[:, 1]) and torch.equal(a[:, 1], a[:, 2])      # grey replicated x3
+    assert abs(a[0, 0].mean().item()) < 1e-5 and abs(a[0, 0].std().item() - 1) < 1e-4
+    assert set(np.unique(t.numpy()).tolist()) <= {0, 1}
+    a2, _, t2 = chaos_batch(8, 64, seed=3)
+    assert torch.equal(a, a2) and torch.equal(t, t2)

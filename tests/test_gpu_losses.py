@@ -1,0 +1,166 @@
+"""-m gpu: fused loss / co-teaching kernels through the drop-in modules, against the golden vectors
+produced by the real reference (tests/golden/g3_losses.npz) and against the oracle on fresh inputs.
+fp32 tolerance 1e-4 relative (north star: 1e-3); selection indices bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def close(a, b, rtol=1e-4, what=''):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a)).double()
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b)).double()
+    err = (a - b).abs().max().item()
+    assert err <= rtol * (b.abs().max().item() + 1e-12) + 1e-9, '%s: err %.3e (scale %.3e)' % (what, err, b.abs().max().item())
+
+
+@pytest.fixture(scope='module')
+def fx():
+    return np.load(os.path.join(GOLD, 'g3_losses.npz'))
+
+
+def test_golden_losses(dev, fx):
+    from aide_amd import utils as U
+    z1 = torch.from_numpy(fx['z1']).to(dev)
+    t = torch.from_numpy(fx['targets']).to(dev)
+    for wname, cw, cdw in (('w11', [1.0, 1.0], [1.0, 1.0]), ('w13', [1.0, 3.0], [0.7, 1.6])):
+        cw, cdw = torch.tensor(cw), torch.tensor(cdw)            # CPU tensors, as the reference scripts pass them
+        for lname, kw in (('CrossEntropyLoss2d', dict(weight=cw)), ('MulticlassDiceLoss', dict(weight=cw)),
+                          ('DiceLoss', {}), ('CEMDiceLoss', dict(cediceweight=cdw, ceclassweight=cw, diceclassweight=cw)),
+                          ('CEMDiceLossImage', dict(cediceweight=cdw, ceclassweight=cw, diceclassweight=cw))):
+            zz = z1.clone().requires_grad_(True)
+            v = getattr(U, lname)(**kw)(zz, t)
+            (v.sum() if v.dim() else v).backward()
+            close(v, fx['%s/%s' % (lname, wname)], what=lname + wname)
+            close(zz.grad, fx['%s/%s/grad' % (lname, wname)], what=lname + wname + ' grad')
+    for red in ('none', 'sum'):
+        v = U.CrossEntropyLoss2d(weight=torch.tensor([1.0, 3.0]), reduction=red)(z1, t)
+        close(v, fx['CrossEntropyLoss2d/w13/' + red], what='CE ' + red)
+    close(U.Dice_fn(z1, t), fx['Dice_fn'], what='Dice_fn')
+
+
+def test_golden_mse_consistency(dev, fx):
+    from aide_amd import utils as U
+    zz = torch.from_numpy(fx['z1']).to(dev).requires_grad_(True)
+    pseudo, wmap = torch.from_numpy(fx['pseudo']).to(dev), torch.from_numpy(fx['wmap']).to(dev)
+    m = U.MulticlassMSELoss(reduction='none')(zz, pseudo)
+    v = (wmap * m).mean()                       # the caller-side reduction of the reference loop (:311-313)
+    v.backward()
+    close(v, fx['mse_wm_mean'], what='mse')
+    close(zz.grad, fx['mse_wm_mean/grad'], what='mse grad')
+
+
+@pytest.mark.parametrize('cname', ['Coteachingloss_dropimage', 'Coteachingloss_weightimage'])
+@pytest.mark.parametrize('fr', [0.0, 0.25, 0.5])
+def test_golden_coteaching(dev, fx, cname, fr):
+    from aide_amd import utils as U
+    a1 = torch.from_numpy(fx['z1']).to(dev).requires_grad_(True)
+    a2 = torch.from_numpy(fx['z2']).to(dev).requires_grad_(True)
+    t = torch.from_numpy(fx['targets']).to(dev)
+    op = getattr(U, cname)(weight=1.0, reduction='none')
+    l1, l2 = op(a1, a2, t, fr)
+    (l1 + l2).backward()
+    key = '%s/fr%g' % (cname, fr)
+    close(l1, fx[key + '/loss1'], what=key + ' loss1')
+    close(l2, fx[key + '/loss2'], what=key + ' loss2')
+    close(a1.grad, fx[key + '/grad1'], what=key + ' grad1')
+    close(a2.grad, fx[key + '/grad2'], what=key + ' grad2')
+    # the argsort mask is bit-exact (adjacent-loss gaps recorded in the fixture are >> fp32 noise)
+    assert op.last['argsort1'].cpu().tolist() == fx['coteach/argsort1'].tolist()
+    assert op.last['argsort2'].cpu().tolist() == fx['coteach/argsort2'].tolist()
+    close(op.last['per_image1'], fx['coteach/per_image1'])
+    assert float(fx['coteach/min_gap1']) > 1e-3 and float(fx['coteach/min_gap2']) > 1e-3
+
+
+def test_coteaching_edge_cases(dev, fx):
+    from aide_amd import utils as U
+    a1, a2 = torch.from_numpy(fx['z1']).to(dev), torch.from_numpy(fx['z2']).to(dev)
+    t = torch.from_numpy(fx['targets']).to(dev)
+    l1, l2 = U.Coteachingloss_dropimage(reduction='none')(a1, a2, t, 0.9)      # num_remember == 0
+    assert torch.isnan(l1).item() and torch.isnan(l2).item()                    # reference: mean of empty -> NaN
+    # ties: identical images -> stable ascending order, lower index first
+    z = a1[:1].repeat(4, 1, 1, 1).contiguous()
+    tt = t[:1].repeat(4, 1, 1).contiguous()
+    op = U.Coteachingloss_dropimage(reduction='none')
+    op(z, z.clone(), tt, 0.5)
+    assert op.last['argsort1'].cpu().tolist() == [0, 1, 2, 3]
+    # non-contiguous targets view (mask[:, 1] of a one-hot [N,5,H,W] tensor)
+    onehot = torch.zeros(4, 5, 64, 64, dtype=torch.int64, device=dev)
+    onehot[:, 1] = t
+    view = onehot[:, 1, :, :]
+    assert not view.is_contiguous()
+    w = torch.tensor([1.0, 1.0])
+    v1 = U.CEMDiceLoss(w, w, w)(a1, view)
+    v2 = U.CEMDiceLoss(w, w, w)(a1, t)
+    assert torch.equal(v1, v2)
+    # ignore_index pixels drop out of the CE term
+    ti = t.clone()
+    ti[:, :8] = 255
+    ref = oracle.CrossEntropyLoss2d()(a1.cpu(), ti.cpu())
+    close(U.CrossEntropyLoss2d()(a1, ti), ref, what='ignore_index')
+
+
+def test_pseudo_label_and_proposed_selection(dev):
+    """Inline selection of trainchaos_proposed_30cases1labeled.py:274-321 vs the oracle restatement."""
+    from aide_amd import utils as U
+    from oracle import steps
+    g = torch.Generator().manual_seed(11)
+    n, s = 4, 64
+    augs = [torch.randn(n, 2, s, s, generator=g) for _ in range(4)]
+    o1 = torch.randn(n, 2, s, s, generator=g) * 1.5
+    o2 = torch.randn(n, 2, s, s, generator=g) * 1.5
+    o1 += torch.tensor([0.0, 0.7, -0.6, 1.3]).view(n, 1, 1, 1) * torch.tensor([-1.0, 1.0]).view(1, 2, 1, 1)
+    o2 += torch.tensor([1.0, -0.5, 0.4, -1.2]).view(n, 1, 1, 1) * torch.tensor([-1.0, 1.0]).view(1, 2, 1, 1)
+    t1 = (torch.rand(n, s, s, generator=g) > 0.7).long()
+    t2 = (torch.rand(n, s, s, generator=g) > 0.6).long()
+    for temp in (1.0, 0.5):
+        pl_r, wm_r = steps.pseudo_labels(augs, temp)
+        pl, wm = U.pseudo_label_ensemble([a.to(dev) for a in augs], temp)
+        close(pl, pl_r, what='pseudo label')
+        close(wm, wm_r, rtol=1e-4, what='weightmap')
+    pl1, wm1 = steps.pseudo_labels(augs, 1.0)
+    pl2, wm2 = steps.pseudo_labels(list(reversed(augs)), 1.0)
+    pl2 = pl2.flip(0).contiguous(); wm2 = wm2.flip(0).contiguous()
+    w = torch.tensor([1.0, 1.0])
+    for rate in (0.0, 0.25, 1.0):
+        r1, r2 = o1.clone().requires_grad_(True), o2.clone().requires_grad_(True)
+        l1r, l2r, i1r, i2r, p1r, p2r = steps.proposed_losses(oracle.CEMDiceLossImage(w, w, w), oracle.MulticlassMSELoss('none'),
+                                                             r1, r2, t1, t2, pl1, wm1, pl2, wm2, rate)
+        l1r.backward(); l2r.backward()
+        d1, d2 = o1.to(dev).requires_grad_(True), o2.to(dev).requires_grad_(True)
+        op = U.CoTeachingProposedLoss(cediceweight=w, ceclassweight=w, segcor_weight=(1.0, 10.0), keep=2)
+        l1, l2, i1, i2 = op(d1, d2, t1.to(dev), t2.to(dev), pl1.to(dev), wm1.to(dev), pl2.to(dev), wm2.to(dev), rate)
+        assert i1.cpu().tolist() == i1r.tolist() and i2.cpu().tolist() == i2r.tolist()      # bit-exact mask
+        close(l1, l1r, what='loss1 r=%g' % rate); close(l2, l2r, what='loss2 r=%g' % rate)
+        l1.backward()                      # loss1 only touches net 1's logits
+        assert d2.grad is None
+        l2.backward()
+        close(d1.grad, r1.grad, what='dlogits1 r=%g' % rate)
+        close(d2.grad, r2.grad, what='dlogits2 r=%g' % rate)
+
+
+def test_full_size_properties(dev):
+    """BASELINE size (4 x 2 x 256 x 256): size-independent identities instead of an oracle run."""
+    from aide_amd import utils as U
+    g = torch.Generator().manual_seed(3)
+    z = (torch.randn(4, 2, 256, 256, generator=g) * 2).to(dev)
+    t = (torch.rand(4, 256, 256, generator=g) > 0.9).long().to(dev)
+    w = torch.tensor([1.0, 1.0])
+    per = U.CEMDiceLossImage(w, w, w)(z, t)
+    # permuting the batch permutes the per-image losses bit-exactly (fixed-order reductions) ...
+    perm = torch.tensor([2, 0, 3, 1], device=dev)
+    per_p = U.CEMDiceLossImage(w, w, w)(z[perm].contiguous(), t[perm].contiguous())
+    assert torch.equal(per_p, per[perm])
+    # ... CE-mean + Dice-mean equals the mean of the per-image values for unit class weights
+    tot = U.CEMDiceLoss(w, w, w)(z, t)
+    close(tot, per.mean(), rtol=1e-5)
+    # ... shifting both logits by a constant changes nothing (softmax invariance)
+    close(U.CEMDiceLossImage(w, w, w)(z + 3.0, t), per, rtol=1e-5)
+    # ... and two runs are bit-identical (no atomics)
+    assert torch.equal(U.CEMDiceLossImage(w, w, w)(z, t), per)

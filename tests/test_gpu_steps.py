@@ -1,0 +1,83 @@
+"""-m gpu: the two training inner steps end to end (models + fused losses + fused Adam) against the
+golden trajectories recorded from the real reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_comparison_three_steps(dev):
+    """trainchaos_comparison_1case.py:195-199 x3: loss trajectory 1.3329 -> 1.2752 -> 1.2272."""
+    from aide_amd import utils as U
+    from aide_amd.models_twomodalinputs import fuseunet
+    from aide_amd.optim import Adam
+    fx, g1 = np.load(os.path.join(GOLD, 'g5_adam.npz')), np.load(os.path.join(GOLD, 'g1_fuseunet.npz'))
+    x1, x2 = torch.from_numpy(g1['x0']).to(dev), torch.from_numpy(g1['x1']).to(dev)
+    t = torch.from_numpy(g1['targets']).to(dev)
+    w = torch.tensor([1.0, 1.0])
+    torch.manual_seed(2)
+    net = fuseunet(2).to(dev)
+    net.train()
+    crit = U.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
+    opt = Adam(net.parameters(), lr=1e-4, amsgrad=True)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = crit(net(x1, x2), t)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert np.max(np.abs(np.array(losses) - fx['losses']) / fx['losses']) < 1e-3, (losses, fx['losses'])
+    assert losses[0] > losses[1] > losses[2]
+    hw = net.last_conv1.weight.detach().cpu().numpy()
+    assert np.abs(hw - fx['step3/last_conv1.weight']).max() < 1e-4     # three lr=1e-4 steps
+
+
+def test_proposed_coteaching_step(dev):
+    """trainchaos_proposed_30cases1labeled.py:260-325 vs the reference run (g4_proposed.npz)."""
+    from aide_amd.models_twomodalinputs import fuseunet
+    from aide_amd.optim import Adam
+    from aide_amd.utils import CoTeachingProposedLoss
+    from aide_amd.train_files.trainchaos_proposed_30cases1labeled import coteach_step
+    fx = np.load(os.path.join(GOLD, 'g4_proposed.npz'))
+    T = lambda k: torch.from_numpy(fx[k]).to(dev)
+    augs = [(T('aug%d_in' % i), T('aug%d_out' % i)) for i in range(4)]
+    for rate in (0.0, 0.25, 1.0):
+        key = 'r%g/' % rate
+        torch.manual_seed(2)
+        n1, n2 = fuseunet(2).to(dev), fuseunet(2).to(dev)
+        n1.train(); n2.train()
+        o1, o2 = Adam(n1.parameters(), lr=1e-4, amsgrad=True), Adam(n2.parameters(), lr=1e-4, amsgrad=True)
+        op = CoTeachingProposedLoss(cediceweight=[1.0, 1.0], ceclassweight=[1.0, 1.0], segcor_weight=[1.0, 10.0])
+        r = coteach_step(n1, n2, o1, o2, op, T('xin'), T('xout'), augs, T('t1'), T('t2'), rate)
+        pre1, pre2 = r['extra']['per_image1'].cpu().numpy(), r['extra']['per_image2'].cpu().numpy()
+        assert np.abs(pre1 - fx[key + 'loss1_pre']).max() < 1e-3 * np.abs(fx[key + 'loss1_pre']).max()
+        assert np.abs(pre2 - fx[key + 'loss2_pre']).max() < 1e-3 * np.abs(fx[key + 'loss2_pre']).max()
+        # the sort is bit-exact whenever the reference's adjacent-loss gap exceeds fp32 noise; this
+        # fixture's gaps (5.5e-4, 7.7e-4) are ~100x our per-image loss error
+        err = max(np.abs(pre1 - fx[key + 'loss1_pre']).max(), np.abs(pre2 - fx[key + 'loss2_pre']).max())
+        assert err * 10 < min(float(fx[key + 'min_gap1']), float(fx[key + 'min_gap2']))
+        assert r['indx1'].cpu().tolist() == fx[key + 'indx1'].tolist()
+        assert r['indx2'].cpu().tolist() == fx[key + 'indx2'].tolist()
+        assert abs(r['loss1'].item() - float(fx[key + 'loss1'])) < 1e-3 * abs(float(fx[key + 'loss1']))
+        assert abs(r['loss2'].item() - float(fx[key + 'loss2'])) < 1e-3 * abs(float(fx[key + 'loss2']))
+        assert int(n1.modal1_downblock1.block.bn1.num_batches_tracked) == int(fx[key + 'nbt']) == 5
+        live = fx[key + 'g1'] > 1e-5
+        gn = np.array([p.grad.double().norm().item() for p in n1.parameters()])
+        assert np.median(np.abs(gn[live] - fx[key + 'g1'][live]) / fx[key + 'g1'][live]) < 1e-3
+
+
+def test_cli_smoke(dev):
+    """The restated CLI (--model_name / --batch_size as in README.md:32) trains and the loss falls."""
+    from aide_amd.train_files.trainchaos_comparison_1case import parse_args, Train, build_model
+    args = parse_args(['--model_name', 'fuseunet', '--batch_size', '2', '--img_size', '64', '--num_epoch', '3',
+                       '--steps_per_epoch', '4'])
+    assert args.lr == 1e-4 and args.torch_seed == 2 and args.loss == 'cedice'
+    _, hist = Train(args)
+    assert hist['train_loss'][-1] < hist['train_loss'][0]
+    with pytest.raises(ValueError, match='Model not implemented'):
+        build_model('resnet', 2)
