@@ -16,21 +16,34 @@
 
 namespace {
 
+// planes whose size is not a multiple of 4 (e.g. the 3x2 bottom level of a 48x32 input) take the
+// scalar instantiation V = 1; everything on the BASELINE shapes runs the 16-byte V = 4 form
+template <int V> __device__ __forceinline__ void ldv(const float* p, float (&o)[V]) {
+    if constexpr (V == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(p); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+    else { o[0] = p[0]; }
+}
+template <int V> __device__ __forceinline__ void stv(float* p, const float (&o)[V]) {
+    if constexpr (V == 4) { *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]}; }
+    else { p[0] = o[0]; }
+}
+
 // ---------------------------------------------------------------- statistics (sum, sum of squares)
+template <int V>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, long z_bs, int N, int C,
                                                        int HW, int splits, double* __restrict__ partials) {
     __shared__ double sm[2 * 4];
     const int c = blockIdx.x % C, s = blockIdx.x / C;
-    const long total4 = (long)N * HW / 4;
+    const long total4 = (long)N * HW / V;
     const long per = (total4 + splits - 1) / splits;
     const long beg = s * per, end = min(beg + per, total4);
-    const int hw4 = HW / 4;
+    const int hw4 = HW / V;
     double acc[2] = {0.0, 0.0};
     for (long i = beg + threadIdx.x; i < end; i += 256) {
         const long n = i / hw4, p = i - n * hw4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(z + n * z_bs + (long)c * HW + p * 4);
+        float v[V];
+        ldv<V>(z + n * z_bs + (long)c * HW + p * V, v);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < V; ++k) {
             const double d = (double)v[k];
             acc[0] += d;
             acc[1] += d * d;
@@ -87,6 +100,7 @@ __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, con
 }
 
 // ---------------------------------------------------------------- a = relu(z*scale + shift)
+template <int V>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ z, long z_bs,
                                                             float* __restrict__ a, long a_bs, int C, int HW,
                                                             const float* __restrict__ scale,
@@ -96,20 +110,22 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
     const float sc = scale[c], sh = shift[c];
     const float* zp = z + (long)n * z_bs + (long)c * HW;
     float* ap = a + (long)n * a_bs + (long)c * HW;
-    const int hw4 = HW / 4;
+    const int hw4 = HW / V;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < hw4; i += gridDim.x * 256) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(zp + i * 4);
+        float v[V];
+        ldv<V>(zp + i * V, v);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < V; ++k) {
             float y = fmaf(v[k], sc, sh);
             v[k] = relu ? fmaxf(y, 0.0f) : y;
         }
-        *reinterpret_cast<f32x4*>(ap + i * 4) = v;
+        stv<V>(ap + i * V, v);
     }
 }
 
 // ---------------------------------------------------------------- backward reductions
 // partials[c][s] = { sum dy, sum dy*xhat } with dy = dA * (z*scale+shift > 0)
+template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dA, long d_bs,
                                                             const float* __restrict__ z, long z_bs, int N,
                                                             int C, int HW, int splits,
@@ -120,18 +136,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             double* __restrict__ partials) {
     __shared__ double sm[2 * 4];
     const int c = blockIdx.x % C, s = blockIdx.x / C;
-    const long total4 = (long)N * HW / 4;
+    const long total4 = (long)N * HW / V;
     const long per = (total4 + splits - 1) / splits;
     const long beg = s * per, end = min(beg + per, total4);
-    const int hw4 = HW / 4;
+    const int hw4 = HW / V;
     const float mu = mean[c], rs = rstd[c], sc = scale[c], sh = shift[c];
     double acc[2] = {0.0, 0.0};
     for (long i = beg + threadIdx.x; i < end; i += 256) {
         const long n = i / hw4, p = i - n * hw4;
-        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + n * z_bs + (long)c * HW + p * 4);
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(dA + n * d_bs + (long)c * HW + p * 4);
+        float zv[V], dv[V];
+        ldv<V>(z + n * z_bs + (long)c * HW + p * V, zv);
+        ldv<V>(dA + n * d_bs + (long)c * HW + p * V, dv);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < V; ++k) {
             const bool on = !relu || fmaf(zv[k], sc, sh) > 0.0f;
             const float dy = on ? dv[k] : 0.0f;
             const float xh = (zv[k] - mu) * rs;
@@ -163,6 +180,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int 
 }
 
 // dz = scale*(dy - c0 - xhat*c1); also per-(channel,split) partial of sum dz (conv bias gradient)
+template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dA, long d_bs,
                                                            const float* __restrict__ z, long z_bs,
                                                            float* __restrict__ dz, long dz_bs, int N, int C,
@@ -174,27 +192,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            double* __restrict__ dzsum_partials) {
     __shared__ double sm[4];
     const int c = blockIdx.x % C, s = blockIdx.x / C;
-    const long total4 = (long)N * HW / 4;
+    const long total4 = (long)N * HW / V;
     const long per = (total4 + splits - 1) / splits;
     const long beg = s * per, end = min(beg + per, total4);
-    const int hw4 = HW / 4;
+    const int hw4 = HW / V;
     const float mu = mean[c], rs = rstd[c], sc = scale[c], sh = shift[c];
     const float c0 = coef[c], c1 = coef[C + c];
     double acc[1] = {0.0};
     for (long i = beg + threadIdx.x; i < end; i += 256) {
         const long n = i / hw4, p = i - n * hw4;
-        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + n * z_bs + (long)c * HW + p * 4);
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(dA + n * d_bs + (long)c * HW + p * 4);
-        f32x4 o;
+        float zv[V], dv[V], o[V];
+        ldv<V>(z + n * z_bs + (long)c * HW + p * V, zv);
+        ldv<V>(dA + n * d_bs + (long)c * HW + p * V, dv);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < V; ++k) {
             const bool on = !relu || fmaf(zv[k], sc, sh) > 0.0f;
             const float dy = on ? dv[k] : 0.0f;
             const float xh = (zv[k] - mu) * rs;
             o[k] = sc * (dy - c0 - xh * c1);
             acc[0] += (double)o[k];
         }
-        *reinterpret_cast<f32x4*>(dz + n * dz_bs + (long)c * HW + p * 4) = o;
+        stv<V>(dz + n * dz_bs + (long)c * HW + p * V, o);
     }
     block_sum_d<1>(acc, sm);
     if (threadIdx.x == 0 && dzsum_partials) dzsum_partials[(long)c * splits + s] = acc[0];
@@ -210,7 +228,7 @@ __global__ void channel_partials_finalize_kernel(const double* __restrict__ part
 }
 
 int pick_splits(int N, int C, int HW) {
-    const long total4 = (long)N * HW / 4;
+    const long total4 = (long)N * HW / ((HW % 4 == 0) ? 4 : 1);
     int s = (int)((2048 + C - 1) / C);
     const long maxs = (total4 + 255) / 256;       // at least one float4 per thread
     if (s > maxs) s = (int)maxs;
@@ -232,11 +250,12 @@ int aide_bn_train_stats(const float* z, int64_t z_bs, int N, int C, int H, int W
                         float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
                         float* scale, float* shift, void* ws, hipStream_t stream) {
     const int HW = H * W;
-    if (!z || !ws || HW % 4 != 0 || z_bs % 4 != 0) return AIDE_ERR_ARG;
+    if (!z || !ws) return AIDE_ERR_ARG;
+    const bool v4 = HW % 4 == 0 && z_bs % 4 == 0;
     const int splits = pick_splits(N, C, HW);
     double* partials = (double*)ws;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW,
-                       splits, partials);
+    if (v4) hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
+    else hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, partials, splits, C,
                        (double)N * HW, gamma, beta, eps, momentum, running_mean, running_var,
                        num_batches_tracked, mean, rstd, scale, shift);
@@ -253,10 +272,10 @@ int aide_bn_eval_coeff(int C, const float* gamma, const float* beta, const float
 int aide_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
                        const float* scale, const float* shift, int relu, hipStream_t stream) {
     const int HW = H * W;
-    if (HW % 4 != 0 || z_bs % 4 != 0 || a_bs % 4 != 0) return AIDE_ERR_ARG;
-    const int gx = max(1, min((HW / 4 + 255) / 256, 16));
-    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a,
-                       (long)a_bs, C, HW, scale, shift, relu);
+    const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && a_bs % 4 == 0;
+    const int gx = max(1, min((HW / (v4 ? 4 : 1) + 255) / 256, 16));
+    if (v4) hipLaunchKernelGGL(bn_relu_apply_kernel<4>, dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
+    else hipLaunchKernelGGL(bn_relu_apply_kernel<1>, dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
     return aide_launch_status();
 }
 
@@ -266,17 +285,17 @@ int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs
                      const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws,
                      hipStream_t stream) {
     const int HW = H * W;
-    if (HW % 4 != 0 || z_bs % 4 != 0 || d_bs % 4 != 0 || dz_bs % 4 != 0 || !ws) return AIDE_ERR_ARG;
+    if (!ws) return AIDE_ERR_ARG;
+    const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && d_bs % 4 == 0 && dz_bs % 4 == 0;
     const int splits = pick_splits(N, C, HW);
     double* partials = (double*)ws;
     float* coef = (float*)((char*)ws + (size_t)C * 64 * 2 * sizeof(double));
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z,
-                       (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
+    if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, partials, splits, C,
                        (double)N * HW, dgamma, dbeta, coef);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z,
-                       (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, coef,
-                       dbias ? partials : (double*)nullptr);
+    if (v4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, coef, dbias ? partials : (double*)nullptr);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, coef, dbias ? partials : (double*)nullptr);
     if (dbias)
         hipLaunchKernelGGL(channel_partials_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream,
                            partials, splits, C, dbias);

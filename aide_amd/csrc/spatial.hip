@@ -150,6 +150,53 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
     }
 }
 
+// scalar forms for widths that are not a multiple of 4 (tiny bottom levels of odd-sized inputs)
+__global__ __launch_bounds__(256) void maxpool2x2_fwd_scalar_kernel(const float* __restrict__ x, long x_bs,
+                                                                    float* __restrict__ y, long y_bs, int C,
+                                                                    int H, int W, long total) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ow = (int)(i % Wo);
+        long r = i / Wo;
+        const int oh = (int)(r % Ho); r /= Ho;
+        const int c = (int)(r % C);
+        const long n = r / C;
+        const float* p = x + n * x_bs + (long)c * H * W + (long)(2 * oh) * W + 2 * ow;
+        y[n * y_bs + (long)c * Ho * Wo + (long)oh * Wo + ow] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[W], p[W + 1]));
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_scalar_kernel(const float* __restrict__ x, long x_bs,
+                                                                    const float* __restrict__ dy, long dy_bs,
+                                                                    float* __restrict__ dx, long dx_bs, int C,
+                                                                    int H, int W, int accumulate, long total) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ow = (int)(i % Wo);
+        long r = i / Wo;
+        const int oh = (int)(r % Ho); r /= Ho;
+        const int c = (int)(r % C);
+        const long n = r / C;
+        const long off = (long)c * H * W + (long)(2 * oh) * W + 2 * ow;
+        const float* p = x + n * x_bs + off;
+        const float g = dy[n * dy_bs + (long)c * Ho * Wo + (long)oh * Wo + ow];
+        const int k = first_argmax4(p[0], p[1], p[W], p[W + 1]);
+        float* q = dx + n * dx_bs + off;
+        const float v[4] = {k == 0 ? g : 0.f, k == 1 ? g : 0.f, k == 2 ? g : 0.f, k == 3 ? g : 0.f};
+        q[0] = accumulate ? q[0] + v[0] : v[0];
+        q[1] = accumulate ? q[1] + v[1] : v[1];
+        q[W] = accumulate ? q[W] + v[2] : v[2];
+        q[W + 1] = accumulate ? q[W + 1] + v[3] : v[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_zero_scalar_kernel(float* __restrict__ p, long bs, long chw, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / chw, r = i - n * chw;
+        p[n * bs + r] = 0.f;
+    }
+}
+
 // zero a channel slice [N][C][HW] of a strided tensor
 __global__ __launch_bounds__(256) void fill_zero_kernel(float* __restrict__ p, long bs, long chw4, long total4) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
@@ -166,7 +213,13 @@ extern "C" {
 
 int aide_maxpool2x2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int N, int C, int H, int W,
                         hipStream_t stream) {
-    if (H % 2 || W % 4 || x_bs % 4 || y_bs % 2) return AIDE_ERR_ARG;
+    if (H % 2 || W % 2) return AIDE_ERR_ARG;
+    if (W % 4 || x_bs % 4 || y_bs % 2) {
+        const long total = (long)N * C * (H / 2) * (W / 2);
+        hipLaunchKernelGGL(maxpool2x2_fwd_scalar_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x,
+                           (long)x_bs, y, (long)y_bs, C, H, W, total);
+        return aide_launch_status();
+    }
     const long total = (long)N * C * (H / 2) * (W / 4);
     hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
                        (long)y_bs, C, H, W, total);
@@ -176,7 +229,13 @@ int aide_maxpool2x2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, in
 // x: the pool INPUT (used to recompute the arg-max), dy: grad of the pooled output, dx: grad of x.
 int aide_maxpool2x2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx,
                         int64_t dx_bs, int N, int C, int H, int W, int accumulate, hipStream_t stream) {
-    if (H % 2 || W % 4 || x_bs % 4 || dx_bs % 4 || dy_bs % 2) return AIDE_ERR_ARG;
+    if (H % 2 || W % 2) return AIDE_ERR_ARG;
+    if (W % 4 || x_bs % 4 || dx_bs % 4 || dy_bs % 2) {
+        const long total = (long)N * C * (H / 2) * (W / 2);
+        hipLaunchKernelGGL(maxpool2x2_bwd_scalar_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x,
+                           (long)x_bs, dy, (long)dy_bs, dx, (long)dx_bs, C, H, W, accumulate, total);
+        return aide_launch_status();
+    }
     const long total = (long)N * C * (H / 2) * (W / 4);
     hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, dy,
                        (long)dy_bs, dx, (long)dx_bs, C, H, W, accumulate, total);
@@ -202,7 +261,11 @@ int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int6
 
 int aide_fill_zero(float* p, int64_t bs, int N, int C, int H, int W, hipStream_t stream) {
     const long chw = (long)C * H * W;
-    if (chw % 4 || bs % 4) return AIDE_ERR_ARG;
+    if (chw % 4 || bs % 4) {
+        const long total = (long)N * chw;
+        hipLaunchKernelGGL(fill_zero_scalar_kernel, dim3(grid_for(total)), dim3(256), 0, stream, p, (long)bs, chw, total);
+        return aide_launch_status();
+    }
     const long total4 = (long)N * chw / 4;
     hipLaunchKernelGGL(fill_zero_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, p, (long)bs, chw / 4,
                        total4);

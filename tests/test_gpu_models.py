@@ -21,6 +21,8 @@ RTOL = 1e-3
 
 
 def rel(a, b):
+    if isinstance(b, torch.Tensor):
+        b = b.detach().cpu().numpy()
     a, b = a.detach().cpu().double(), torch.as_tensor(np.asarray(b)).double()
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
@@ -142,10 +144,16 @@ def test_golden_forward_backward_adam(dev, kind, learned, gold):
     # Adam(amsgrad) step on the live parameters, BN running statistics, eval-mode forward
     torch.optim.Adam(ref.parameters(), lr=1e-4, amsgrad=True).step()
     Adam(net.parameters(), lr=1e-4, amsgrad=True).step()
+    # (the first amsgrad step is lr * g / (|g| + eps): elements whose gradient is comparable to
+    # eps = 1e-8 move by an ill-conditioned fraction of lr in ANY fp32 implementation -> masked out)
+    ref_grads = {k: q.grad.clone() for k, q in ref.named_parameters()}
     for (k, p), (_, q), gabs in zip(net.named_parameters(), ref.named_parameters(), fx['grad_absmax']):
         if float(gabs) < 1e-6 or id(p) in taint:
             continue                                   # dead biases random-walk in the reference too
-        assert (p.detach().cpu() - q.detach()).abs().max().item() < 2e-5, k      # lr = 1e-4 sized steps
+        well = ref_grads[k].abs() > 1e-5
+        d = (p.detach().cpu() - q.detach()).abs()
+        assert d[well].max().item() < 2e-6, k          # lr = 1e-4 sized steps
+        assert d.max().item() <= 2.1e-4, k
     for (k, b), (_, c) in zip(net.named_buffers(), ref.named_buffers()):
         if 'num_batches_tracked' in k:
             assert int(b) == int(c) == 1
@@ -171,7 +179,7 @@ def test_reference_checkpoint_roundtrip(dev):
                 m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
     net.load_state_dict(ref.state_dict())
     g = torch.Generator().manual_seed(0)
-    x1, x2 = torch.randn(1, 3, 48, 32, generator=g), torch.randn(1, 3, 48, 32, generator=g)
+    x1, x2 = torch.randn(1, 3, 48, 32, generator=g), torch.randn(1, 3, 48, 32, generator=g)   # 3x2 at the bottom
     net.eval(); ref.eval()
     with torch.no_grad():
         assert rel(net(x1.to(dev), x2.to(dev)), ref(x1, x2)) < RTOL
