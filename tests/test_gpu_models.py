@@ -1,12 +1,13 @@
 """-m gpu: whole-network parity through the drop-in nn.Modules (C-ABI underneath).
 
-Forward quantities (logits, loss, BN running statistics, eval-mode logits) are compared tightly.
-Gradients are compared with a ReLU-flip-aware rule: fp32 differences of ~1e-6 between two correct
-implementations can put a pre-activation on opposite sides of zero; such a flip changes the
-gradient of that layer and of every layer feeding it by O(1/pixels) — much more than 1e-3 on a
-32x32 test problem, while being irrelevant at 256x256.  The test therefore detects flips by comparing
-our post-ReLU masks with the oracle's, marks the affected ("tainted") layers through the engine
-graph, holds all untainted parameters to 1e-3 and the tainted ones to a loose sanity bound."""
+Forward quantities (logits, loss, BN running statistics, eval-mode logits) are compared tightly with
+the golden vectors of the real reference.  Gradients: two correct fp32 implementations differ by
+~1e-6 in a pre-activation, which occasionally puts it on the other side of zero; one such ReLU-mask
+flip changes the gradients of that layer and of everything upstream by O(1/pixels) — far above 1e-3 on
+a 32x32 problem, irrelevant at 256x256 (see test_config2_digest_256).  The gradient check is therefore
+made flip-free BY CONSTRUCTION: the oracle's backward is evaluated with the ReLU masks of our forward
+(F.relu temporarily replaced by `x * mask`, a <= 1e-5 perturbation of its forward), and then every
+parameter gradient is held to 1e-3.  The number of flipped mask elements is asserted to be tiny."""
 import os
 
 import numpy as np
@@ -45,49 +46,38 @@ def build_pair(kind, learned, dev):
     return net, ref
 
 
-def relu_flips(net, ref, plan):
-    """-> {op index: number of flipped mask elements} comparing our post-ReLU buffers with the oracle."""
-    ref_mods = dict(ref.named_modules())
-    name_of = {id(m): n for n, m in net.named_modules()}
-    flips = {}
-    for i, st in enumerate(plan.steps):
-        if st['kind'] not in ('conv', 'convT'):
-            continue
-        bn_out = ref_mods[name_of[id(st['bn'])]]._captured
-        ours = plan.view(st['dst']).detach().cpu()
-        n = int(((ours > 0) != (bn_out > 0)).sum())
-        if n:
-            flips[i] = n
-    return flips
+class forced_relu_masks(object):
+    """Context manager: torch.nn.functional.relu := x * (our post-ReLU mask of the BN that ran last)."""
 
+    def __init__(self, net, ref, plan):
+        name_of = {id(m): n for n, m in net.named_modules()}
+        self.masks = {}
+        for st in plan.steps:
+            if st['kind'] in ('conv', 'convT'):
+                self.masks[name_of[id(st['bn'])]] = (plan.view(st['dst']).detach().cpu() > 0).float()
+        self.ref, self.cur, self.flips, self.hooks = ref, [None], {}, []
 
-def tainted_params(plan, flipped_ops):
-    """Parameters whose gradient a mask flip at `flipped_ops` can reach: the flipped op itself and,
-    transitively, every producer of its input (backward data flow through the engine graph)."""
-    steps = plan.steps
+    def __enter__(self):
+        import torch.nn.functional as F
+        names = {id(m): n for n, m in self.ref.named_modules()}
 
-    def overlaps(a, b):
-        return a.root is b.root and a.c0 < b.c0 + b.C and b.c0 < a.c0 + a.C
-    tainted, work = set(flipped_ops), list(flipped_ops)
-    while work:
-        j = work.pop()
-        for i, st in enumerate(steps[:j]):
-            if i not in tainted and 'dst' in st and overlaps(st['dst'], steps[j]['src']):
-                tainted.add(i)
-                work.append(i)
-    out = set()
-    for i in tainted:
-        for key in ('conv', 'bn'):
-            m = steps[i].get(key)
-            if m is not None:
-                out |= {id(p) for p in m.parameters()}
-    return out
+        def hook(mod, inp, out):
+            self.cur[0] = names[id(mod)]
+            n = int(((out.detach() > 0).float() != self.masks[self.cur[0]]).sum())
+            if n:
+                self.flips[self.cur[0]] = n
+        for m in self.ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                self.hooks.append(m.register_forward_hook(hook))
+        self.orig = F.relu
+        F.relu = lambda x, inplace=False: x * self.masks[self.cur[0]]
+        return self
 
-
-def is_dead_bias(name):
-    """conv / convT biases feeding a BatchNorm have a mathematically zero gradient."""
-    return name.endswith('.bias') and 'last_conv1' not in name and '.bn' not in name and \
-        not name.endswith(('bilinear_up.2.bias', )) and not (name.split('.')[-2] == '1' and 'bilinear_up' in name and False)
+    def __exit__(self, *a):
+        import torch.nn.functional as F
+        F.relu = self.orig
+        for h in self.hooks:
+            h.remove()
 
 
 CASES = [('fuseunet', False, 'g1_fuseunet.npz'), ('fuseunet', True, 'g1_fuseunet_learned.npz'),
@@ -104,14 +94,9 @@ def test_golden_forward_backward_adam(dev, kind, learned, gold):
     xs = [torch.from_numpy(fx['x%d' % i]) for i in range(nin)]
     t = torch.from_numpy(fx['targets'])
     w = torch.tensor([1.0, 1.0])
-    for m in ref.modules():
-        if isinstance(m, torch.nn.BatchNorm2d):
-            m.register_forward_hook(lambda mod, i, o: setattr(mod, '_captured', o.detach()))
     net.train(); ref.train()
-    out_r = ref(*xs)
-    oracle.CEMDiceLoss(w, w, w)(out_r, t).backward()
     out = net(*[x.to(dev) for x in xs])
-    assert rel(out, fx['logits']) < RTOL and rel(out, out_r) < RTOL
+    assert rel(out, fx['logits']) < RTOL
     crit = U.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
     loss = crit(out, t.to(dev))
     assert abs(loss.item() - float(fx['loss'])) < RTOL * float(fx['loss'])
@@ -119,26 +104,25 @@ def test_golden_forward_backward_adam(dev, kind, learned, gold):
     assert rel(per, fx['per_image_loss']) < RTOL
     loss.backward()
     plan = list(net.engine.plans.values())[0]
-    flips = relu_flips(net, ref, plan)
-    taint = tainted_params(plan, list(flips))
+    with forced_relu_masks(net, ref, plan) as fm:
+        out_r = ref(*xs)
+        oracle.CEMDiceLoss(w, w, w)(out_r, t).backward()
+    flips = fm.flips
+    assert sum(flips.values()) <= 8, 'implausibly many ReLU mask flips: %s' % flips
+    assert rel(out, out_r) < RTOL
     names = [str(n) for n in fx['param_names']]
     assert names == [k for k, _ in net.named_parameters()]
-    n_tight = 0
     for (k, p), (_, q), gabs in zip(net.named_parameters(), ref.named_parameters(), fx['grad_absmax']):
         err = (p.grad.cpu().double() - q.grad.double()).abs().max().item()
-        dead = k.endswith('.bias') and float(gabs) < 1e-6
-        if dead:
-            assert err < 1e-5, 'dead bias %s: abs err %.2e' % (k, err)
-        elif id(p) in taint:
-            assert err <= 0.25 * float(gabs), 'tainted %s: err %.2e scale %.2e' % (k, err, float(gabs))
+        if k.endswith('.bias') and float(gabs) < 1e-6:
+            assert err < 1e-5, 'dead conv bias %s: abs err %.2e' % (k, err)     # mathematically zero
         else:
-            n_tight += 1
-            assert err <= RTOL * float(gabs), '%s: grad err %.2e scale %.2e (flips %s)' % (k, err, float(gabs), flips)
-    assert sum(flips.values()) <= 8, 'implausibly many ReLU mask flips: %s' % flips
-    assert n_tight >= 10
-    if not flips:
+            scale = q.grad.abs().max().item()
+            assert err <= RTOL * scale, '%s: grad err %.2e scale %.2e (flips %s)' % (k, err, scale, flips)
+    taint = set()
+    if not flips:                      # then the reference's own gradients (golden) must match as well
         for k in fx.files:
-            if k.startswith('grad/') and not is_dead_bias(k[5:]):
+            if k.startswith('grad/') and float(fx['grad_absmax'][names.index(k[5:])]) >= 1e-6:
                 p = dict(net.named_parameters())[k[5:]]
                 assert rel(torch.from_numpy(sub(p.grad)), fx[k]) < RTOL, k
     # Adam(amsgrad) step on the live parameters, BN running statistics, eval-mode forward
@@ -152,7 +136,7 @@ def test_golden_forward_backward_adam(dev, kind, learned, gold):
             continue                                   # dead biases random-walk in the reference too
         well = ref_grads[k].abs() > 1e-5
         d = (p.detach().cpu() - q.detach()).abs()
-        assert d[well].max().item() < 2e-6, k          # lr = 1e-4 sized steps
+        assert (not well.any()) or d[well].max().item() < 2e-6, k          # lr = 1e-4 sized steps
         assert d.max().item() <= 2.1e-4, k
     for (k, b), (_, c) in zip(net.named_buffers(), ref.named_buffers()):
         if 'num_batches_tracked' in k:
@@ -162,8 +146,9 @@ def test_golden_forward_backward_adam(dev, kind, learned, gold):
     net.eval(); ref.eval()
     with torch.no_grad():
         ev, ev_r = net(*[x.to(dev) for x in xs]), ref(*xs)
-    if not taint:
-        assert rel(ev, ev_r) < 5e-3 and rel(ev, fx['eval_logits']) < 5e-3
+    assert rel(ev, ev_r) < 5e-3
+    if not flips:
+        assert rel(ev, fx['eval_logits']) < 5e-3
     with pytest.raises(RuntimeError):
         net(*[x.to(dev).requires_grad_(False) for x in xs]).sum().backward()     # eval-mode backward
 
