@@ -34,23 +34,31 @@ struct ConvArgs {
     int tiles_w, tiles_h, n_co_tiles, splitk, chunks_total, accumulate;
 };
 
-template <int TCO, int WAVES_M, int WM, int WN, int PT_W, int CK>
+template <int TCO, int WAVES_M, int WM, int WN, int PT_W, int CK, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int RPT = 32 / PT_W;                 // image rows covered by one 32-pixel MFMA tile
     constexpr int PT_H = WAVES_N * WN * RPT;
-    constexpr int RS = PT_W + 2;                   // LDS row stride of the halo tile
+    // Halo tile rows are laid out [3 pad][col -1][cols 0..PT_W-1][col PT_W][3 pad] so that the
+    // interior is 16-byte aligned: it is fetched with 16-byte buffer loads and stored with
+    // ds_write_b128; only the two edge columns move as dwords.  (The dword-per-element version of
+    // this staging cost 21 % of the kernel: VMEM instruction count, not bytes, was the limiter.)
+    constexpr int RS = PT_W + 8;                   // LDS row stride
     constexpr int CS = (PT_H + 2) * RS;            // LDS channel stride
-    constexpr int XL = ((CK * CS + 3) / 4) * 4;    // halo tile floats (16-B aligned end)
+    constexpr int XL = CK * CS;                    // halo tile floats
     constexpr int WL = CK * 9 * TCO;               // filter block floats
-    constexpr int EX = (CK * CS + 255) / 256;      // halo elements per thread
+    constexpr int UB = CK * (PT_H + 2) * (PT_W / 4);   // interior float4 units per chunk
+    constexpr int UC = CK * (PT_H + 2) * 2;            // edge dword units per chunk
+    constexpr int NB = (UB + 255) / 256, NC = (UC + 255) / 256;
     constexpr int WV = (WL / 4 + 255) / 256;       // filter float4 per thread
     static_assert(TCO == WAVES_M * WM * 32, "tile mismatch");
-    static_assert(CK % 2 == 0, "channel pairs");
+    static_assert(CK % 2 == 0 && XL % 4 == 0, "channel pairs / alignment");
 
-    __shared__ __attribute__((aligned(16))) float lds[XL + WL];
-    float* xl = lds;
-    float* wl = lds + XL;
+    // Two stage buffers: the MFMAs read buffer `cur` while the next channel chunk is fetched to
+    // registers (first half of the k-steps) and stored to the other buffer (second half), one staging
+    // op per k-step, so no wave ever sits in a load/store burst with the matrix pipe drained.
+    constexpr int BUF = XL + WL;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int half = lane >> 5, j = lane & 31;
@@ -70,17 +78,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     const int c_end = min(c_begin + cps, a.chunks_total);
 
     // ---- per-thread staging descriptors (identical for every chunk) ----
-    // Descriptor base sits (W+1) floats before the block's first pixel so that all halo offsets are
-    // non-negative; out-of-image elements carry the BUF_OOB offset and read as 0.0f in hardware.
-    unsigned goff[EX];
+    // Descriptor base sits at (row h0-1, col w0-1) so that every unit offset is non-negative; units
+    // outside the image carry the BUF_OOB offset and read as 0.0f in hardware (zero padding).
+    unsigned offB[NB], ldsB[NB], offC[NC], ldsC[NC], mskB[NB];
 #pragma unroll
-    for (int e = 0; e < EX; ++e) {
-        const int idx = tid + e * 256;
-        const int c = idx / CS, rem = idx - c * CS;
-        const int r = rem / RS, col = rem - r * RS;
-        const int ih = h0 - 1 + r, iw = w0 - 1 + col;
-        const bool ok = (idx < CK * CS) && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        goff[e] = ok ? (unsigned)(c * HW + r * a.W + col) * 4u : BUF_OOB;
+    for (int e = 0; e < NB; ++e) {
+        const int q = tid + e * 256;
+        const int c = q / ((PT_H + 2) * (PT_W / 4)), rem = q - c * ((PT_H + 2) * (PT_W / 4));
+        const int r = rem / (PT_W / 4), s4 = rem - r * (PT_W / 4);
+        const int ih = h0 - 1 + r, iw = w0 + 4 * s4;
+        const bool rowok = q < UB && ih >= 0 && ih < a.H;
+        offB[e] = (rowok && (VEC ? iw < a.W : true)) ? (unsigned)(c * HW + r * a.W + 1 + 4 * s4) * 4u : BUF_OOB;
+        ldsB[e] = q < UB ? (unsigned)(c * CS + r * RS + 4 + 4 * s4) : 0xffffffffu;
+        mskB[e] = 0;
+        if (!VEC) {           // widths that are not a multiple of 4: per-element column validity
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mskB[e] |= (rowok && iw + i < a.W) ? (1u << i) : 0u;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NC; ++e) {
+        const int q = tid + e * 256;
+        const int c = q / ((PT_H + 2) * 2), rem = q - c * ((PT_H + 2) * 2);
+        const int r = rem / 2, side = rem - r * 2;
+        const int ih = h0 - 1 + r, iw = side ? w0 + PT_W : w0 - 1;
+        const bool ok = q < UC && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        offC[e] = ok ? (unsigned)(c * HW + r * a.W + (side ? PT_W + 1 : 0)) * 4u : BUF_OOB;
+        ldsC[e] = q < UC ? (unsigned)(c * CS + r * RS + (side ? 4 + PT_W : 3)) : 0xffffffffu;
     }
     const __amdgpu_buffer_rsrc_t xrs =
         make_rsrc(a.x + (long)n * a.x_bs + (long)h0 * a.W + w0 - (a.W + 1));
@@ -94,31 +118,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     }
     const bool ragged_c = (a.Cin % CK) != 0;   // only the 3-channel stems
 
-    float xr[EX];
+    f32x4 xb[NB];
+    float xc[NC];
     f32x4 wr[WV];
-    auto load_chunk = [&](int chunk) {
-        const int ci0 = chunk * CK;
-        const unsigned xs = (unsigned)ci0 * (unsigned)HW * 4u;
-#pragma unroll
-        for (int e = 0; e < EX; ++e) {
-            unsigned off = goff[e];
-            if (ragged_c && (ci0 + (tid + e * 256) / CS) >= a.Cin) off = BUF_OOB;
-            xr[e] = buf_load_f32(xrs, off, xs);
-        }
-        const unsigned wsoff = (unsigned)ci0 * 9u * (unsigned)a.ldw * 4u;
-#pragma unroll
-        for (int v = 0; v < WV; ++v) wr[v] = buf_load_f32x4(wrs, woff[v], wsoff);
+    constexpr int NL = NB + NC + WV;           // staging ops per thread per chunk (loads == stores)
+    unsigned xs = 0, wsoff = 0;
+    bool has_chunk = false;
+    int ci0 = 0;
+    auto set_chunk = [&](int chunk) {
+        has_chunk = chunk < c_end;
+        ci0 = chunk * CK;
+        xs = (unsigned)ci0 * (unsigned)HW * 4u;
+        wsoff = (unsigned)ci0 * 9u * (unsigned)a.ldw * 4u;
     };
-    auto store_chunk = [&]() {
+    auto fetch = [&](int l) {                  // l is a compile-time op index
+        if (l < NB) {
+            const int e = l;
+            unsigned off = has_chunk ? offB[e] : BUF_OOB;
+            if (ragged_c && (ci0 + (tid + e * 256) / ((PT_H + 2) * (PT_W / 4))) >= a.Cin) off = BUF_OOB;
+            if (VEC) {
+                xb[e] = buf_load_f32x4(xrs, off, xs);
+            } else {
 #pragma unroll
-        for (int e = 0; e < EX; ++e) {
-            const int idx = tid + e * 256;
-            if (idx < CK * CS) xl[idx] = xr[e];
+                for (int i = 0; i < 4; ++i)
+                    xb[e][i] = buf_load_f32(xrs, ((mskB[e] >> i) & 1u) && off != BUF_OOB ? off + 4u * i : BUF_OOB, xs);
+            }
+        } else if (l < NB + NC) {
+            const int e = l - NB;
+            unsigned off = has_chunk ? offC[e] : BUF_OOB;
+            if (ragged_c && (ci0 + (tid + e * 256) / ((PT_H + 2) * 2)) >= a.Cin) off = BUF_OOB;
+            xc[e] = buf_load_f32(xrs, off, xs);
+        } else {
+            const int v = l - NB - NC;
+            wr[v] = buf_load_f32x4(wrs, has_chunk ? woff[v] : BUF_OOB, wsoff);
         }
-#pragma unroll
-        for (int v = 0; v < WV; ++v) {
-            const int f = tid + v * 256;
-            if (f < WL / 4) *reinterpret_cast<f32x4*>(wl + f * 4) = wr[v];
+    };
+    auto put = [&](int l, float* buf) {
+        if (l < NB) {
+            if (ldsB[l] != 0xffffffffu) *reinterpret_cast<f32x4*>(buf + ldsB[l]) = xb[l];
+        } else if (l < NB + NC) {
+            const int e = l - NB;
+            if (ldsC[e] != 0xffffffffu) buf[ldsC[e]] = xc[e];
+        } else {
+            const int v = l - NB - NC, f = tid + v * 256;
+            if (f < WL / 4) *reinterpret_cast<f32x4*>(buf + XL + f * 4) = wr[v];
         }
     };
 
@@ -130,42 +173,67 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.0f;
 
-    // lane bases of the MFMA operand fragments
-    const float* la = wl + half * 9 * TCO + wave_m * WM * 32 + j;
-    const float* lb = xl + half * CS + (wave_n * WN * RPT + j / PT_W) * RS + (j % PT_W);
+    // lane offsets of the MFMA operand fragments (pixel column c lives at row index 4 + c)
+    const int la_off = XL + half * 9 * TCO + wave_m * WM * 32 + j;
+    const int lb_off = half * CS + (wave_n * WN * RPT + j / PT_W) * RS + 3 + (j % PT_W);
 
-    if (c_begin < c_end) load_chunk(c_begin);
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        __syncthreads();                       // previous chunk's fragments fully consumed
-        store_chunk();
-        __syncthreads();
-        if (chunk + 1 < c_end) load_chunk(chunk + 1);   // in flight during the MFMAs below
-        {
-            // explicit one-step-ahead fragment pipeline over the CK/2 * 9 (channel pair, tap) steps
-            constexpr int STEPS = (CK / 2) * 9;
-            float af[2][WM], bf[2][WN];
-            auto frag = [&](int s, int buf) {
-                const int q = s / 9, t = s % 9;          // compile-time after unrolling
-                const int kh = t / 3, kw = t % 3;
+    constexpr int STEPS = (CK / 2) * 9;        // (channel pair, tap) k-steps per chunk
+    constexpr int HALF = STEPS / 2;
+    constexpr int PER = (NL + HALF - 1) / HALF;
+    static_assert(PER * HALF >= NL, "staging schedule");
+
+    // prologue: first chunk straight into buffer 0
+    set_chunk(c_begin);
 #pragma unroll
-                for (int m = 0; m < WM; ++m) af[buf][m] = la[(2 * q * 9 + t) * TCO + m * 32];
+    for (int l = 0; l < NL; ++l) fetch(l);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) put(l, lds);
+    __syncthreads();
+
+    int cur = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const float* la = lds + cur * BUF + la_off;
+        const float* lb = lds + cur * BUF + lb_off;
+        float* nxt = lds + (cur ^ 1) * BUF;
+        set_chunk(chunk + 1);                  // past the end: every fetch carries BUF_OOB
+        // two separately named fragment sets (an array indexed by s&1 can be demoted to memory)
+        float afA[WM], bfA[WN], afB[WM], bfB[WN];
+        auto frag = [&](int st, float (&af)[WM], float (&bf)[WN]) {
+            const int q = st / 9, t = st % 9;            // compile-time after unrolling
+            const int kh = t / 3, kw = t % 3;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) af[m] = la[(2 * q * 9 + t) * TCO + m * 32];
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) bf[nt] = lb[2 * q * CS + (kh + nt * RPT) * RS + kw];
+        };
+        auto kstep = [&](int st, float (&afc)[WM], float (&bfc)[WN], float (&afn)[WM], float (&bfn)[WN]) {
+            if (st + 1 < STEPS) frag(st + 1, afn, bfn);
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
 #pragma unroll
                 for (int nt = 0; nt < WN; ++nt)
-                    bf[buf][nt] = lb[2 * q * CS + (kh + nt * RPT) * RS + kw];
-            };
-            frag(0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afc[m], bfc[nt], acc[m][nt], 0, 0, 0);
+#ifndef AIDE_PROBE_NOSTAGE
+            if (st < HALF) {
 #pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                if (s + 1 < STEPS) frag(s + 1, (s + 1) & 1);
+                for (int k = 0; k < PER; ++k)
+                    if (st * PER + k < NL) fetch(st * PER + k);
+            } else {
 #pragma unroll
-                for (int m = 0; m < WM; ++m)
-#pragma unroll
-                    for (int nt = 0; nt < WN; ++nt)
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][m], bf[s & 1][nt],
-                                                                          acc[m][nt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < PER; ++k)
+                    if ((st - HALF) * PER + k < NL) put((st - HALF) * PER + k, nxt);
             }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        frag(0, afA, bfA);
+#pragma unroll
+        for (int st = 0; st < STEPS; st += 2) {
+            kstep(st, afA, bfA, afB, bfB);
+            kstep(st + 1, afB, bfB, afA, bfA);
         }
+        __syncthreads();
+        cur ^= 1;
     }
 
     // ---- epilogue: D layout row i = (r&3) + 8*(r>>2) + 4*half, col j ----
@@ -234,6 +302,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 
 template <int TCO, int WAVES_M, int WM, int WN, int PT_W, int CK>
 int launch_cfg(ConvArgs a, hipStream_t stream) {
+    constexpr bool CAN_SCALAR = PT_W == 8;      // widths not divisible by 4 are routed to PT_W = 8
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int PT_H = WAVES_N * WN * (32 / PT_W);
     a.tiles_w = (a.W + PT_W - 1) / PT_W;
@@ -241,8 +310,17 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
     a.n_co_tiles = (a.Cout + TCO - 1) / TCO;
     a.chunks_total = (a.Cin + CK - 1) / CK;
     const long nb = (long)a.tiles_w * a.tiles_h * a.N * a.n_co_tiles * a.splitk;
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<TCO, WAVES_M, WM, WN, PT_W, CK>), dim3((unsigned)nb),
-                       dim3(256), 0, stream, a);
+    const bool vec = (a.W % 4 == 0) && (a.x_bs % 4 == 0);
+    if (vec) {
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<TCO, WAVES_M, WM, WN, PT_W, CK, true>), dim3((unsigned)nb),
+                           dim3(256), 0, stream, a);
+    } else {
+        if constexpr (CAN_SCALAR)
+            hipLaunchKernelGGL((conv3x3_mfma_kernel<TCO, WAVES_M, WM, WN, PT_W, CK, false>), dim3((unsigned)nb),
+                               dim3(256), 0, stream, a);
+        else
+            return AIDE_ERR_ARG;
+    }
     return aide_launch_status();
 }
 
@@ -269,6 +347,7 @@ int launch_ptw(int variant, int ck, const ConvArgs& a, hipStream_t s) {
 }
 
 int pick_ptw(int W) {
+    if (W % 4 != 0) return 8;                   // only PT_W = 8 carries the per-element (non-16-byte) loader
     int best = 32, waste = ((W + 31) / 32) * 32;
     for (int p : {16, 8}) {
         const int cover = ((W + p - 1) / p) * p;
