@@ -56,34 +56,61 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ partials, int splits, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float eps, float momentum, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, long long* __restrict__ nbt,
-                                   float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < splits; ++k) {
-        s += partials[((long)c * splits + k) * 2 + 0];
-        ss += partials[((long)c * splits + k) * 2 + 1];
+// Training forward, second pass: every block re-derives its channel's (scale, shift) from the fp64
+// partials (one wave, <= 64 splits) and applies a = relu(z*scale + shift); the (x == 0, n == 0) block
+// of each channel also publishes mean / rstd / scale / shift and updates the running statistics.
+// (Folding the finalize step in here removes one ~5 us launch per BatchNorm.)
+template <int V>
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(
+    const float* __restrict__ z, long z_bs, float* __restrict__ a, long a_bs, int C, int HW,
+    const double* __restrict__ partials, int splits, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
+    float* __restrict__ running_var, long long* __restrict__ nbt, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out, int relu) {
+    __shared__ float coef[2];
+    const int plane = blockIdx.y;                 // n*C + c
+    const int n = plane / C, c = plane - n * C;
+    if (threadIdx.x < 64) {
+        double s = 0.0, ss = 0.0;
+        if ((int)threadIdx.x < splits) {
+            s = partials[((long)c * splits + threadIdx.x) * 2 + 0];
+            ss = partials[((long)c * splits + threadIdx.x) * 2 + 1];
+        }
+        s = wave_sum_d(s);
+        ss = wave_sum_d(ss);
+        if (threadIdx.x == 0) {
+            const double mean = s / count;
+            double var = ss / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float g = gamma ? gamma[c] : 1.0f, bb = beta ? beta[c] : 0.0f;
+            const float sc = g * rstd, sh = bb - (float)mean * sc;
+            coef[0] = sc; coef[1] = sh;
+            if (blockIdx.x == 0 && n == 0) {
+                mean_out[c] = (float)mean; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh;
+                if (running_mean) {
+                    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+                    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+                }
+                if (c == 0 && nbt) *nbt += 1;
+            }
+        }
     }
-    const double mean = s / count;
-    double var = ss / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
-    mean_out[c] = (float)mean;
-    rstd_out[c] = rstd;
-    const float sc = g * rstd;
-    scale_out[c] = sc;
-    shift_out[c] = b - (float)mean * sc;
-    if (running_mean) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
-        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    __syncthreads();
+    const float sc = coef[0], sh = coef[1];
+    const float* zp = z + (long)n * z_bs + (long)c * HW;
+    float* ap = a + (long)n * a_bs + (long)c * HW;
+    const int hw4 = HW / V;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw4; i += gridDim.x * 256) {
+        float v[V];
+        ldv<V>(zp + i * V, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float y = fmaf(v[k], sc, sh);
+            v[k] = relu ? fmaxf(y, 0.0f) : y;
+        }
+        stv<V>(ap + i * V, v);
     }
 }
 
@@ -124,7 +151,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------- backward reductions
-// partials[c][s] = { sum dy, sum dy*xhat } with dy = dA * (z*scale+shift > 0)
+// partials[c][s] = { sum dy, sum dy*xhat, sum xhat } with dy = dA * (z*scale+shift > 0)
 template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dA, long d_bs,
                                                             const float* __restrict__ z, long z_bs, int N,
@@ -134,14 +161,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu,
                                                             double* __restrict__ partials) {
-    __shared__ double sm[2 * 4];
+    __shared__ double sm[3 * 4];
     const int c = blockIdx.x % C, s = blockIdx.x / C;
     const long total4 = (long)N * HW / V;
     const long per = (total4 + splits - 1) / splits;
     const long beg = s * per, end = min(beg + per, total4);
     const int hw4 = HW / V;
     const float mu = mean[c], rs = rstd[c], sc = scale[c], sh = shift[c];
-    double acc[2] = {0.0, 0.0};
+    double acc[3] = {0.0, 0.0, 0.0};
     for (long i = beg + threadIdx.x; i < end; i += 256) {
         const long n = i / hw4, p = i - n * hw4;
         float zv[V], dv[V];
@@ -154,51 +181,61 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             const float xh = (zv[k] - mu) * rs;
             acc[0] += (double)dy;
             acc[1] += (double)dy * (double)xh;
+            acc[2] += (double)xh;
         }
     }
-    block_sum_d<2>(acc, sm);
+    block_sum_d<3>(acc, sm);
     if (threadIdx.x == 0) {
-        partials[((long)c * splits + s) * 2 + 0] = acc[0];
-        partials[((long)c * splits + s) * 2 + 1] = acc[1];
+        partials[((long)c * splits + s) * 3 + 0] = acc[0];
+        partials[((long)c * splits + s) * 3 + 1] = acc[1];
+        partials[((long)c * splits + s) * 3 + 2] = acc[2];
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int splits, int C, double count,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ coef /* [2][C]: dbeta/n, dgamma/n */) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, sx = 0.0;
-    for (int k = 0; k < splits; ++k) {
-        s += partials[((long)c * splits + k) * 2 + 0];
-        sx += partials[((long)c * splits + k) * 2 + 1];
-    }
-    if (dbeta) dbeta[c] = (float)s;
-    if (dgamma) dgamma[c] = (float)sx;
-    coef[c] = (float)(s / count);
-    coef[C + c] = (float)(sx / count);
-}
-
-// dz = scale*(dy - c0 - xhat*c1); also per-(channel,split) partial of sum dz (conv bias gradient)
+// dz = scale*(dy - c0 - xhat*c1) with c0 = sum(dy)/n, c1 = sum(dy*xhat)/n re-derived per block from the
+// fp64 partials; the split-0 block of each channel also writes dgamma, dbeta and the conv-bias gradient.
+// The latter is sum(dz), which is zero in exact arithmetic; it is evaluated from the same sums,
+//   sum dz = scale * ((sum dy - n c0) - c1 sum xhat),
+// i.e. as the rounding residue it is (the reference's autograd value is the same kind of ~1e-8 noise).
 template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dA, long d_bs,
                                                            const float* __restrict__ z, long z_bs,
                                                            float* __restrict__ dz, long dz_bs, int N, int C,
-                                                           int HW, int splits, const float* __restrict__ mean,
+                                                           int HW, int splits, double count,
+                                                           const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int relu,
-                                                           const float* __restrict__ coef,
-                                                           double* __restrict__ dzsum_partials) {
-    __shared__ double sm[4];
+                                                           const double* __restrict__ partials,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ dbias) {
+    __shared__ float coef[2];
     const int c = blockIdx.x % C, s = blockIdx.x / C;
+    const float mu = mean[c], rs = rstd[c], sc = scale[c], sh = shift[c];
+    if (threadIdx.x < 64) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        if ((int)threadIdx.x < splits) {
+            a0 = partials[((long)c * splits + threadIdx.x) * 3 + 0];
+            a1 = partials[((long)c * splits + threadIdx.x) * 3 + 1];
+            a2 = partials[((long)c * splits + threadIdx.x) * 3 + 2];
+        }
+        a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2);
+        if (threadIdx.x == 0) {
+            const float c0f = (float)(a0 / count), c1f = (float)(a1 / count);
+            coef[0] = c0f; coef[1] = c1f;
+            if (s == 0) {
+                if (dbeta) dbeta[c] = (float)a0;
+                if (dgamma) dgamma[c] = (float)a1;
+                if (dbias) dbias[c] = (float)((double)sc * ((a0 - count * (double)c0f) - (double)c1f * a2));
+            }
+        }
+    }
+    __syncthreads();
+    const float c0 = coef[0], c1 = coef[1];
     const long total4 = (long)N * HW / V;
     const long per = (total4 + splits - 1) / splits;
     const long beg = s * per, end = min(beg + per, total4);
     const int hw4 = HW / V;
-    const float mu = mean[c], rs = rstd[c], sc = scale[c], sh = shift[c];
-    const float c0 = coef[c], c1 = coef[C + c];
-    double acc[1] = {0.0};
     for (long i = beg + threadIdx.x; i < end; i += 256) {
         const long n = i / hw4, p = i - n * hw4;
         float zv[V], dv[V], o[V];
@@ -210,21 +247,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const float dy = on ? dv[k] : 0.0f;
             const float xh = (zv[k] - mu) * rs;
             o[k] = sc * (dy - c0 - xh * c1);
-            acc[0] += (double)o[k];
         }
         stv<V>(dz + n * dz_bs + (long)c * HW + p * V, o);
     }
-    block_sum_d<1>(acc, sm);
-    if (threadIdx.x == 0 && dzsum_partials) dzsum_partials[(long)c * splits + s] = acc[0];
-}
-
-__global__ void channel_partials_finalize_kernel(const double* __restrict__ partials, int splits, int C,
-                                                 float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int k = 0; k < splits; ++k) s += partials[(long)c * splits + k];
-    out[c] = (float)s;
 }
 
 int pick_splits(int N, int C, int HW) {
@@ -242,23 +267,32 @@ int pick_splits(int N, int C, int HW) {
 extern "C" {
 
 // workspace doubles needed by the BN kernels for a C-channel tensor
-size_t aide_bn_ws_bytes(int C) { return (size_t)C * 64 * 2 * sizeof(double) + (size_t)2 * C * sizeof(float); }
+size_t aide_bn_ws_bytes(int C) { return (size_t)C * 64 * 3 * sizeof(double); }
 
-// Batch statistics + running-stat update + (scale, shift) for the apply kernel.
-int aide_bn_train_stats(const float* z, int64_t z_bs, int N, int C, int H, int W, const float* gamma,
-                        const float* beta, float eps, float momentum, float* running_mean,
-                        float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
-                        float* scale, float* shift, void* ws, hipStream_t stream) {
+// Training-mode forward of relu(bn(z)): batch statistics (pass 1), then finalize + apply (pass 2).
+// Outputs mean/rstd/scale/shift [C] are kept by the caller for the backward.
+int aide_bn_train_fwd(const float* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
+                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                      float* scale, float* shift, int relu, void* ws, hipStream_t stream) {
     const int HW = H * W;
-    if (!z || !ws) return AIDE_ERR_ARG;
-    const bool v4 = HW % 4 == 0 && z_bs % 4 == 0;
+    if (!z || !a || !ws) return AIDE_ERR_ARG;
+    const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && a_bs % 4 == 0;
     const int splits = pick_splits(N, C, HW);
     double* partials = (double*)ws;
-    if (v4) hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
-    else hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, partials, splits, C,
-                       (double)N * HW, gamma, beta, eps, momentum, running_mean, running_var,
-                       num_batches_tracked, mean, rstd, scale, shift);
+    const double count = (double)N * HW;
+    const int gx = max(1, min((HW / (v4 ? 4 : 1) + 255) / 256, 16));
+    if (v4) {
+        hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
+        hipLaunchKernelGGL(bn_train_apply_kernel<4>, dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+                           partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
+                           num_batches_tracked, mean, rstd, scale, shift, relu);
+    } else {
+        hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
+        hipLaunchKernelGGL(bn_train_apply_kernel<1>, dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+                           partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
+                           num_batches_tracked, mean, rstd, scale, shift, relu);
+    }
     return aide_launch_status();
 }
 
@@ -289,16 +323,14 @@ int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs
     const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && d_bs % 4 == 0 && dz_bs % 4 == 0;
     const int splits = pick_splits(N, C, HW);
     double* partials = (double*)ws;
-    float* coef = (float*)((char*)ws + (size_t)C * 64 * 2 * sizeof(double));
-    if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, partials, splits, C,
-                       (double)N * HW, dgamma, dbeta, coef);
-    if (v4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, coef, dbias ? partials : (double*)nullptr);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, coef, dbias ? partials : (double*)nullptr);
-    if (dbias)
-        hipLaunchKernelGGL(channel_partials_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream,
-                           partials, splits, C, dbias);
+    const double count = (double)N * HW;
+    if (v4) {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
+    }
     return aide_launch_status();
 }
 

@@ -315,6 +315,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// few splits (the large-filter layers): one thread per element streams its <= 8 slab values
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ slabs, int splits,
+                                                                 int Co, int Ci, float* __restrict__ dw) {
+    const long cc = (long)Co * Ci, total = 9 * cc;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        float v = slabs[e];
+        for (int s = 1; s < splits; ++s) v += slabs[(long)s * total + e];
+        const long t = e / cc, rem = e - t * cc;
+        dw[rem * 9 + t] = v;
+    }
+}
+
 template <int WAVES_CO, int WAVES_CI, int WAVES_PX>
 int launch_wgrad(WgradArgs g, hipStream_t stream) {
     g.n_co_tiles = (g.Co + WAVES_CO * 32 - 1) / (WAVES_CO * 32);
@@ -385,8 +397,12 @@ int aide_conv3x3_wgrad(const float* dz, int64_t dz_bs, const float* a, int64_t a
     }
     if (rc != 0) return rc;
     const long total = 9L * Co * Ci;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, ws,
-                       g.splits, Co, Ci, dw);
+    if (g.splits <= 8)
+        hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0,
+                           stream, ws, g.splits, Co, Ci, dw);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, ws,
+                           g.splits, Co, Ci, dw);
     return aide_launch_status();
 }
 

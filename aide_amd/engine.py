@@ -219,13 +219,13 @@ class Plan(object):
 
     def _bn_apply(self, st, bn):
         if self.training:
-            ops.bn_train_stats(st['z'], bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
-                               bn.running_var, bn.num_batches_tracked, st['mean'], st['rstd'],
-                               st['scale'], st['shift'], self.bn_ws)
+            ops.bn_train_fwd(st['z'], self.view(st['dst']), bn.weight, bn.bias, bn.eps, bn.momentum,
+                             bn.running_mean, bn.running_var, bn.num_batches_tracked, st['mean'],
+                             st['rstd'], st['scale'], st['shift'], self.bn_ws, True)
         else:
             ops.bn_eval_coeff(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, st['scale'],
                               st['shift'])
-        ops.bn_relu_apply(st['z'], self.view(st['dst']), st['scale'], st['shift'], True)
+            ops.bn_relu_apply(st['z'], self.view(st['dst']), st['scale'], st['shift'], True)
 
     # ------------------------------------------------------------------ backward
     def backward(self, inputs, dlogits, flat, offsets, after_op=None):

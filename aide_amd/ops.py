@@ -142,13 +142,16 @@ def bn_ws(c, device):
     return torch.empty(lib.aide_bn_ws_bytes(c) // 8, device=device, dtype=torch.float64)
 
 
-def bn_train_stats(z, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, rstd, scale,
-                   shift, ws):
+def bn_train_fwd(z, a, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, rstd, scale, shift,
+                 ws, relu=True):
+    """a = relu(bn_train(z)); updates running stats / num_batches_tracked; saves mean/rstd/scale/shift."""
     zp, zbs = planes(z)
+    ap, abs_ = planes(a)
     n, c, h, w = z.shape
-    check(lib.aide_bn_train_stats(zp, zbs, n, c, h, w, ptr(gamma), ptr(beta), eps, momentum,
-                                  ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd),
-                                  ptr(scale), ptr(shift), ptr(ws), stream_ptr()), 'bn_train_stats')
+    check(lib.aide_bn_train_fwd(zp, zbs, ap, abs_, n, c, h, w, ptr(gamma), ptr(beta), eps, momentum,
+                                ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd),
+                                ptr(scale), ptr(shift), int(relu), ptr(ws), stream_ptr()), 'bn_train_fwd')
+    return a
 
 
 def bn_eval_coeff(gamma, beta, running_mean, running_var, eps, scale, shift):

@@ -52,10 +52,10 @@ int aide_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t d
 /* ---- BatchNorm2d (+ReLU) -----------------------------------------------------------------------
  * replaces nn.BatchNorm2d + nn.ReLU: netblocks.py:25,27,28,18 ; UNet.py:20,22,23,13 */
 size_t aide_bn_ws_bytes(int C);
-int aide_bn_train_stats(const float* z, int64_t z_bs, int N, int C, int H, int W, const float* gamma,
-                        const float* beta, float eps, float momentum, float* running_mean,
-                        float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
-                        float* scale, float* shift, void* ws, aide_stream_t stream);
+int aide_bn_train_fwd(const float* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
+                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                      float* scale, float* shift, int relu, void* ws, aide_stream_t stream);
 int aide_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift,
                        aide_stream_t stream);

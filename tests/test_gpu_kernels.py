@@ -105,9 +105,11 @@ def test_bn_relu_fwd_bwd(dev, shape):
     nbt = torch.zeros((), dtype=torch.int64, device=dev)
     mean, rstd, scale, shift = (torch.empty(c, device=dev) for _ in range(4))
     ws = ops.bn_ws(c, dev)
-    ops.bn_train_stats(zd, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rm, rv, nbt, mean, rstd, scale, shift, ws)
     a = torch.empty_like(zd)
-    ops.bn_relu_apply(zd, a, scale, shift, True)
+    ops.bn_train_fwd(zd, a, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rm, rv, nbt, mean, rstd, scale, shift, ws, True)
+    a2 = torch.empty_like(zd)
+    ops.bn_relu_apply(zd, a2, scale, shift, True)          # eval-path apply kernel with the same coefficients
+    assert torch.equal(a, a2)
     _close(a, ar, what='bn+relu fwd')
     _close(rm, bn.running_mean, what='running_mean')
     _close(rv, bn.running_var, what='running_var')
