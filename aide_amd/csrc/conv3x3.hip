@@ -300,6 +300,38 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
+// all filters of a network in ONE launch: a descriptor table (device memory) plus a prefix of
+// 256-element blocks per tensor, located by binary search (same scheme as the fused Adam)
+struct PackDesc {
+    const float* w; float* wf; float* wd;
+    int Co, Ci, ci_pad, co_pad;
+    long block_start;
+};
+
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackDesc* __restrict__ descs, int n) {
+    const long blk = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_start <= blk) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc d = descs[lo];
+    const long nf = (long)d.ci_pad * 9 * d.Co, nd = d.wd ? (long)d.co_pad * 9 * d.Ci : 0;
+    const long i = (blk - d.block_start) * 256 + threadIdx.x;
+    if (i < nf) {
+        const int co = (int)(i % d.Co);
+        const long r = i / d.Co;
+        const int t = (int)(r % 9), ci = (int)(r / 9);
+        d.wf[i] = (ci < d.Ci) ? d.w[((long)co * d.Ci + ci) * 9 + t] : 0.0f;
+    } else if (i < nf + nd) {
+        const long k = i - nf;
+        const int ci = (int)(k % d.Ci);
+        const long r = k / d.Ci;
+        const int t = (int)(r % 9), co = (int)(r / 9);
+        d.wd[k] = (co < d.Co) ? d.w[((long)co * d.Ci + ci) * 9 + (8 - t)] : 0.0f;
+    }
+}
+
 template <int TCO, int WAVES_M, int WM, int WN, int PT_W, int CK>
 int launch_cfg(ConvArgs a, hipStream_t stream) {
     constexpr bool CAN_SCALAR = PT_W == 8;      // widths not divisible by 4 are routed to PT_W = 8
@@ -369,6 +401,16 @@ int aide_conv3x3_pack_weights(const float* w, float* wf, float* wd, int Co, int 
     const int blocks = (int)min((total + 255) / 256, (long)4096);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, w, wf, wd, Co, Ci,
                        ci_pad, co_pad);
+    return aide_launch_status();
+}
+
+// descs: DEVICE array of n records {w, wf, wd (or 0), Co, Ci, ci_pad, co_pad, block_start} laid out as
+// 3 pointers, 4 int32, 1 int64 (40 bytes); total_blocks = sum over tensors of ceil(elems/256).
+int aide_conv3x3_pack_weights_multi(const void* descs, int n, int64_t total_blocks, hipStream_t stream) {
+    if (!descs || n <= 0 || total_blocks <= 0) return AIDE_ERR_ARG;
+    static_assert(sizeof(PackDesc) == 48, "descriptor layout");
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream,
+                       (const PackDesc*)descs, n);
     return aide_launch_status();
 }
 

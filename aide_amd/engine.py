@@ -15,7 +15,7 @@ All arithmetic is in libaide_hip.so (see include/aide_hip.h); torch only owns me
 import torch
 
 from . import ops
-from ._lib import lib
+from ._lib import lib, check as _check
 
 # bumped by aide_amd.optim.Adam (which updates parameters through raw pointers, invisible to
 # tensor._version) so that cached packed filters are refreshed
@@ -151,6 +151,7 @@ class Plan(object):
         self.wg_ws = None
         self._bwd_ready = False
         self.profiler = None             # set by Engine (bench.py's per-kernel HIP-event timing)
+        self._pack_key, self._pack_tab = None, None
 
     # ------------------------------------------------------------------ helpers
     def view(self, t, inputs=None):
@@ -185,16 +186,38 @@ class Plan(object):
         self._bwd_ready = True
 
     # ------------------------------------------------------------------ forward
+    def _pack_filters(self):
+        """Refresh the packed forward/dgrad filters of every conv in ONE launch when any master weight
+        changed (tensor._version for torch optimizers, PARAM_EPOCH for the fused Adam)."""
+        convs = [st for st in self.steps if st['kind'] == 'conv']
+        key = (PARAM_EPOCH[0],) + tuple((st['conv'].weight.data_ptr(), st['conv'].weight._version) for st in convs)
+        if key == self._pack_key:
+            return
+        ptrs = tuple(k[0] for k in key[1:])
+        if self._pack_tab is None or self._pack_tab[0] != ptrs:
+            import struct
+            rec, start = b'', 0
+            for st in convs:
+                w, wf, wd = st['conv'].weight, st['wf'], st['wd']
+                co, ci = w.shape[0], w.shape[1]
+                elems = wf.numel() + (wd.numel() if wd is not None else 0)
+                rec += struct.pack('<QQQiiiiq', w.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else 0,
+                                   co, ci, wf.shape[0], wd.shape[0] if wd is not None else 0, start)
+                start += (elems + 255) // 256
+            tab = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(self.dev)
+            self._pack_tab = (ptrs, tab, len(convs), start)
+        _, tab, n, blocks = self._pack_tab
+        ops.check(lib.aide_conv3x3_pack_weights_multi(ops.ptr(tab), n, blocks, ops.stream_ptr()),
+                  'conv3x3_pack_weights_multi')
+        self._pack_key = key
+
     def forward(self, inputs, out):
         n = self.N
+        self._pack_filters()
         for st in self.steps:
             kind = st['kind']
             if kind == 'conv':
                 conv, bn = st['conv'], st['bn']
-                key = (conv.weight.data_ptr(), conv.weight._version, PARAM_EPOCH[0])
-                if st['pack_key'] != key:
-                    ops.pack_weights_into(conv.weight, st['wf'], st['wd'])
-                    st['pack_key'] = key
                 x = self.view(st['src'], inputs)
                 prof = self.profiler
                 if prof is not None:

@@ -28,6 +28,9 @@ int aide_conv3x3_chunk(int Cin);                                  /* channel pad
 int aide_conv3x3_pack_weights(const float* w /*[Co][Ci][3][3]*/, float* wf /*[ci_pad][9][Co]*/,
                               float* wd /*[co_pad][9][Ci] or NULL*/, int Co, int Ci, int ci_pad,
                               int co_pad, aide_stream_t stream);
+/* all filters of a network in one launch; descs = DEVICE array of n 48-byte records
+ * {const float* w; float* wf; float* wd; int32 Co, Ci, ci_pad, co_pad; int64 block_start} */
+int aide_conv3x3_pack_weights_multi(const void* descs, int n, int64_t total_blocks, aide_stream_t stream);
 int aide_conv3x3_plan(int N, int Cin, int H, int W, int Cout);    /* variant | splitk<<8 */
 size_t aide_conv3x3_ws_bytes(int N, int H, int W, int Cout, int splitk);
 int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, const float* bias,
