@@ -100,6 +100,35 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
     }
 }
 
+// 4 consecutive outputs per thread, one 16-byte store (the scalar form ran at 1.1 TB/s)
+__global__ __launch_bounds__(256) void upsample2x_fwd_vec_kernel(const float* __restrict__ x, long x_bs,
+                                                                 float* __restrict__ y, long y_bs, int C, int H,
+                                                                 int W, long total4) {
+    const int Ho = 2 * H, Wo = 2 * W, Wo4 = Wo / 4;
+    const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int ow4 = (int)(i % Wo4);
+        long r = i / Wo4;
+        const int oh = (int)(r % Ho); r /= Ho;
+        const int c = (int)(r % C);
+        const long n = r / C;
+        int h0, h1; float lh;
+        src_index(oh, sh, H, h0, h1, lh);
+        const float* p0 = x + n * x_bs + (long)c * H * W + (long)h0 * W;
+        const float* p1 = x + n * x_bs + (long)c * H * W + (long)h1 * W;
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int w0, w1; float lw;
+            src_index(4 * ow4 + k, sw, W, w0, w1, lw);
+            const float top = (1.f - lw) * p0[w0] + lw * p0[w1], bot = (1.f - lw) * p1[w0] + lw * p1[w1];
+            o[k] = (1.f - lh) * top + lh * bot;
+        }
+        *reinterpret_cast<f32x4*>(y + n * y_bs + (long)c * Ho * Wo + (long)oh * Wo + 4 * ow4) = o;
+    }
+}
+
 // gather form of the transpose: each source pixel sums the destination pixels that referenced it
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, long dy_bs,
                                                              float* __restrict__ dx, long dx_bs, int C, int H,
@@ -245,6 +274,11 @@ int aide_maxpool2x2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t d
 int aide_upsample2x_bilinear_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int N, int C, int H,
                                  int W, hipStream_t stream) {
     const long total = (long)N * C * 4 * H * W;
+    if ((2 * W) % 4 == 0 && y_bs % 4 == 0) {
+        hipLaunchKernelGGL(upsample2x_fwd_vec_kernel, dim3(grid_for(total / 4)), dim3(256), 0, stream, x,
+                           (long)x_bs, y, (long)y_bs, C, H, W, total / 4);
+        return aide_launch_status();
+    }
     hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
                        (long)y_bs, C, H, W, total);
     return aide_launch_status();

@@ -103,8 +103,15 @@ class GradAllReduce(object):
         if view.is_cuda:
             ev = torch.cuda.Event()
             ev.record()                                    # all kernels writing this bucket are enqueued
+            side = getattr(self.engine, 'side_stream', None)
+            ev2 = None
+            if side is not None:                           # ... the weight gradients on the side stream
+                ev2 = torch.cuda.Event()
+                ev2.record(side)
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                if ev2 is not None:
+                    self.comm_stream.wait_event(ev2)
                 # RCCL averages in the collective itself: no extra elementwise pass over the arena
                 self.works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
         else:

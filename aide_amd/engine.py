@@ -147,11 +147,11 @@ class Plan(object):
         self.bn_ws = ops.bn_ws(max(max_bnc, 1), device)
         self.sk_ws = torch.empty(max(max_sk // 4, 1), **f32)
         self._max_dz, self._max_wg = max_dz, max_wg
-        self.dz = None
         self.wg_ws = None
         self._bwd_ready = False
         self.profiler = None             # set by Engine (bench.py's per-kernel HIP-event timing)
         self._pack_key, self._pack_tab = None, None
+        self.overlap = True              # weight gradients on a side stream (see backward)
 
     # ------------------------------------------------------------------ helpers
     def view(self, t, inputs=None):
@@ -171,8 +171,14 @@ class Plan(object):
         n, h, w = self.N, self.H, self.W
         for t in self.g.roots:
             self.grad[id(t)] = torch.empty(n, t.C, h >> t.level, w >> t.level, **f32)
-        self.dz = torch.empty(max(self._max_dz, 1), **f32)
+        # one dz buffer per conv: the weight-gradient kernels run on a side stream and may still be
+        # reading dz of layer L while the main stream already produces dz of layer L-1
+        for st in self.steps:
+            if st['kind'] in ('conv', 'convT'):
+                st['dz'] = torch.empty_like(st['z'])
         self.wg_ws = torch.empty(max(self._max_wg // 4, 1), **f32)
+        self.head_ws = torch.empty(max(self._max_wg // 4, 1), **f32)
+        self.side = torch.cuda.Stream(device=self.dev)
         cover = {id(t): _Cover() for t in self.g.roots}
         for st in reversed(self.steps):
             src = st['src']
@@ -260,6 +266,14 @@ class Plan(object):
             i = self.pindex[id(p)]
             return flat[offsets[i]:offsets[i] + p.numel()].view(p.shape)
 
+        # Two streams: the main stream carries the dependent chain (BN backward -> dgrad -> pool /
+        # up-sampling backward); every weight-gradient kernel (MFMA-bound, off the critical path) goes to
+        # a side stream as soon as its dz exists, so the HBM-bound kernels of the next layer run in
+        # its shadow instead of between two MFMA kernels.
+        main = torch.cuda.current_stream()
+        side = self.side if (self.overlap and self.profiler is None) else None
+        if side is not None:
+            side.wait_stream(main)
         for st in reversed(self.steps):
             kind = st['kind']
             sg = st.get('src_grad')
@@ -271,23 +285,30 @@ class Plan(object):
                 k = conv.out_channels
                 ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1),
                                 self.gview(st['src']) if sg is not None else None,
-                                gslot(conv.weight).view(k, -1), gslot(conv.bias), ws=self.wg_ws)
+                                gslot(conv.weight).view(k, -1), gslot(conv.bias), ws=self.head_ws)
                 assert sg is None or not sg['accumulate']
             elif kind in ('conv', 'convT'):
                 conv, bn = st['conv'], st['bn']
                 z = st['z']
-                dz = self.dz[:z.numel()].view(z.shape)
+                dz = st['dz']
                 ops.bn_relu_bwd(self.gview(st['dst']), z, dz, st['mean'], st['rstd'], st['scale'],
                                 st['shift'], gslot(bn.weight), gslot(bn.bias), gslot(conv.bias),
                                 self.bn_ws, True)
                 x = self.view(st['src'], inputs)
                 if kind == 'conv':
                     prof = self.profiler
-                    if prof is not None:
-                        prof.begin('conv3x3_wgrad', st['flops'])
-                    ops.conv3x3_wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
-                    if prof is not None:
-                        prof.end()
+                    if side is not None:
+                        ev = torch.cuda.Event()
+                        ev.record(main)
+                        with torch.cuda.stream(side):
+                            side.wait_event(ev)
+                            ops.conv3x3_wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
+                    else:
+                        if prof is not None:
+                            prof.begin('conv3x3_wgrad', st['flops'])
+                        ops.conv3x3_wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
+                        if prof is not None:
+                            prof.end()
                     if sg is not None:
                         if prof is not None:
                             prof.begin('conv3x3_igemm', st['flops'])
@@ -296,7 +317,14 @@ class Plan(object):
                         if prof is not None:
                             prof.end()
                 else:
-                    ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=self.wg_ws)
+                    if side is not None:
+                        ev = torch.cuda.Event()
+                        ev.record(main)
+                        with torch.cuda.stream(side):      # shares the slab workspace with conv wgrad
+                            side.wait_event(ev)
+                            ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=self.wg_ws)
+                    else:
+                        ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=self.wg_ws)
                     if sg is not None:
                         ops.convT2x2_dgrad(dz, conv.weight, self.gview(st['src']))
             elif kind == 'pool':
@@ -309,6 +337,8 @@ class Plan(object):
                                        accumulate=sg['accumulate'])
             if after_op is not None:
                 after_op(st)
+        if side is not None:
+            main.wait_stream(side)
 
 
 class _NetFunction(torch.autograd.Function):
@@ -337,6 +367,10 @@ class _NetFunction(torch.autograd.Function):
             raise RuntimeError('aide_amd: backward through an eval-mode forward is not supported')
         dlogits = dlogits.contiguous()
         flat = torch.empty(eng.flat_numel, device=dlogits.device, dtype=torch.float32)
+        eng.side_stream = plan.side if (plan._bwd_ready and plan.overlap) else None
+        if not plan._bwd_ready:
+            plan._prepare_backward()
+            eng.side_stream = plan.side if plan.overlap else None
         if eng.before_backward is not None:
             eng.before_backward(flat)
         plan.backward(ctx.inputs, dlogits, flat, eng.offsets, eng.after_backward_op)
@@ -358,6 +392,7 @@ class Engine(object):
         self.after_backward_op = None    # callable(step) e.g. bucketed all-reduce overlap
         self.profiler = None             # object with begin(tag, flops) / end(): per-kernel HIP events
         self.before_backward = None      # callable(flat_grad) at the start of every backward
+        self.side_stream = None          # stream carrying the weight-gradient kernels of the running backward
         self.graph = None
 
     def _refresh_params(self):

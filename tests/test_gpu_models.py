@@ -56,6 +56,7 @@ class forced_relu_masks(object):
             if st['kind'] in ('conv', 'convT'):
                 self.masks[name_of[id(st['bn'])]] = (plan.view(st['dst']).detach().cpu() > 0).float()
         self.ref, self.cur, self.flips, self.hooks = ref, [None], {}, []
+        self.total = sum(m.numel() for m in self.masks.values())
 
     def __enter__(self):
         import torch.nn.functional as F
@@ -108,7 +109,7 @@ def test_golden_forward_backward_adam(dev, kind, learned, gold):
         out_r = ref(*xs)
         oracle.CEMDiceLoss(w, w, w)(out_r, t).backward()
     flips = fm.flips
-    assert sum(flips.values()) <= 8, 'implausibly many ReLU mask flips: %s' % flips
+    assert sum(flips.values()) <= 4 + 2e-5 * fm.total, 'implausibly many ReLU mask flips: %s' % flips
     assert rel(out, out_r) < RTOL
     names = [str(n) for n in fx['param_names']]
     assert names == [k for k, _ in net.named_parameters()]
@@ -214,3 +215,53 @@ def test_backward_after_newer_forward_is_refused(dev):
         a.sum().backward()
     with pytest.raises(RuntimeError, match='multiples of 16'):
         net(torch.randn(1, 3, 40, 40, device=dev), torch.randn(1, 3, 40, 40, device=dev))
+
+
+def test_side_stream_wgrad_is_bit_identical(dev):
+    """Weight gradients run on a side stream; serial and overlapped schedules must agree bit for bit
+    (same kernels, fixed-order reductions) — also a race detector for the shared slab workspace."""
+    from aide_amd import utils as U
+    for kind, learned in (('fuseunet', False), ('unet', True)):
+        net, _ = build_pair(kind, learned, dev)
+        g = torch.Generator().manual_seed(5)
+        xs = [torch.randn(2, 3, 64, 64, generator=g).to(dev) for _ in range(2 if kind == 'fuseunet' else 1)]
+        t = (torch.rand(2, 64, 64, generator=g) > 0.8).long().to(dev)
+        w = torch.tensor([1.0, 1.0])
+        grads = []
+        for overlap in (True, False, True):
+            net.zero_grad()
+            out = net(*xs)
+            list(net.engine.plans.values())[0].overlap = overlap
+            U.CEMDiceLoss(w, w, w)(out, t).backward()
+            grads.append([p.grad.clone() for p in net.parameters()])
+        for a, b, c in zip(*grads):
+            assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_unet_ragged_sizes(dev):
+    """UNet at 160x176 (levels 160x176 ... 10x11): exercises the PT_W = 16 / 8 tiles, widths that are
+    not multiples of 4 (dword loaders), ragged wgrad tiles and the scalar BN / pool kernels."""
+    from aide_amd import utils as U
+    net, ref = build_pair('unet', False, dev)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 3, 160, 176, generator=g)
+    t = (torch.rand(1, 160, 176, generator=g) > 0.8).long()
+    w = torch.tensor([1.0, 1.0])
+    net.train(); ref.train()
+    out = net(x.to(dev))
+    loss = U.CEMDiceLoss(w, w, w)(out, t.to(dev))
+    loss.backward()
+    plan = list(net.engine.plans.values())[0]
+    with forced_relu_masks(net, ref, plan) as fm:
+        out_r = ref(x)
+        loss_r = oracle.CEMDiceLoss(w, w, w)(out_r, t)
+        loss_r.backward()
+    assert rel(out, out_r) < RTOL and abs(loss.item() - loss_r.item()) < RTOL * loss_r.item()
+    assert sum(fm.flips.values()) <= 4 + 2e-5 * fm.total, 'implausibly many ReLU mask flips: %s' % fm.flips
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        scale = q.grad.abs().max().item()
+        err = (p.grad.cpu() - q.grad).abs().max().item()
+        if k.endswith('.bias') and scale < 1e-6:
+            assert err < 1e-5, k
+        else:
+            assert err <= RTOL * scale, '%s: err %.2e scale %.2e' % (k, err, scale)
