@@ -234,6 +234,57 @@ __global__ __launch_bounds__(256) void fill_zero_kernel(float* __restrict__ p, l
     }
 }
 
+// Inverse augmentation of logit planes (train_files/trainchaos_proposed_30cases1labeled.py:81-95):
+// optional horizontal flip, then PIL Image.rotate(angle, BILINEAR) on mode 'F' images.  PIL semantics
+// (Image.rotate + Geometry.c affine_transform / bilinear_filter32F): inverse affine map about the
+// centre (w/2, h/2) evaluated at pixel centres in double precision, samples outside the source are 0,
+// neighbours are clamped in x, the y+1 row falls back to the y row at the bottom edge; multiples of
+// 90 degrees take PIL's exact transpose paths.  par[n] = {a, b, c, d, e, f, flip, mode}.
+__global__ __launch_bounds__(256) void reverse_aug_kernel(const float* __restrict__ x, long x_bs,
+                                                          float* __restrict__ y, long y_bs,
+                                                          const double* __restrict__ par, int C, int H, int W,
+                                                          long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ox = (int)(i % W);
+        long r = i / W;
+        const int oy = (int)(r % H); r /= H;
+        const int c = (int)(r % C);
+        const long n = r / C;
+        const double* m = par + n * 8;
+        const bool flip = m[6] != 0.0;
+        const int mode = (int)m[7];
+        const float* src = x + n * x_bs + (long)c * H * W;
+        auto at = [&](int yy, int xx) { return src[(long)yy * W + (flip ? W - 1 - xx : xx)]; };
+        float v;
+        if (mode == 1) v = at(oy, ox);
+        else if (mode == 2) v = at(H - 1 - oy, W - 1 - ox);
+        else if (mode == 3) v = at(ox, W - 1 - oy);            // ROTATE_90 (square images only)
+        else if (mode == 4) v = at(H - 1 - ox, oy);            // ROTATE_270
+        else {
+            const double xin = m[0] * (ox + 0.5) + m[1] * (oy + 0.5) + m[2];
+            const double yin = m[3] * (ox + 0.5) + m[4] * (oy + 0.5) + m[5];
+            if (xin < 0.0 || xin >= (double)W || yin < 0.0 || yin >= (double)H) {
+                v = 0.f;
+            } else {
+                const double xi = xin - 0.5, yi = yin - 0.5;
+                const double fx = floor(xi), fy = floor(yi);
+                const double dx = xi - fx, dy = yi - fy;
+                const int x0 = (int)fx, y0 = (int)fy;
+                const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
+                const int yc0 = min(max(y0, 0), H - 1);
+                const double p00 = at(yc0, xc0), p01 = at(yc0, xc1);
+                double v1 = p00 + (p01 - p00) * dx, v2 = v1;
+                if (y0 + 1 >= 0 && y0 + 1 < H) {
+                    const double p10 = at(y0 + 1, xc0), p11 = at(y0 + 1, xc1);
+                    v2 = p10 + (p11 - p10) * dx;
+                }
+                v = (float)(v1 + (v2 - v1) * dy);
+            }
+        }
+        y[n * y_bs + (long)c * H * W + (long)oy * W + ox] = v;
+    }
+}
+
 int grid_for(long total) { return (int)max(1L, min((total + 255) / 256, 8192L)); }
 
 }  // namespace
@@ -290,6 +341,17 @@ int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int6
     const long total = (long)N * C * H * W;
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, (long)dy_bs,
                        dx, (long)dx_bs, C, H, W, accumulate, total);
+    return aide_launch_status();
+}
+
+// x, y: [N][C][H][W] (y must not alias x); par: DEVICE array [N][8] doubles {a,b,c,d,e,f,flip,mode},
+// mode 0 = affine bilinear, 1 = copy, 2 = rotate 180, 3 = rotate 90, 4 = rotate 270 (3/4: H == W).
+int aide_reverse_aug(const float* x, int64_t x_bs, float* y, int64_t y_bs, const double* par, int N, int C,
+                     int H, int W, hipStream_t stream) {
+    if (!x || !y || !par || x == y) return AIDE_ERR_ARG;
+    const long total = (long)N * C * H * W;
+    hipLaunchKernelGGL(reverse_aug_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
+                       (long)y_bs, par, C, H, W, total);
     return aide_launch_status();
 }
 

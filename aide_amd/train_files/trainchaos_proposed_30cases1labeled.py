@@ -47,13 +47,17 @@ def parse_args(argv=None):
 
 
 def coteach_step(net1, net2, opt1, opt2, loss_op, inphase, outphase, aug_pairs, targets1, targets2, rate,
-                 temperature=1.0):
-    """One step of trainchaos_proposed_30cases1labeled.py:260-325 on device tensors."""
-    from aide_amd.utils import pseudo_label_ensemble
+                 temperature=1.0, augset=None):
+    """One step of trainchaos_proposed_30cases1labeled.py:260-325 on device tensors. `augset` (the
+    loader's dict with 'augno', 'hflip{k}', 'degree{k}') triggers the on-device reverseaug (:271-272)."""
+    from aide_amd.utils import pseudo_label_ensemble, reverseaug
     a1, a2 = [], []
     for xin, xout in aug_pairs:                                   # :265-269
         a1.append(net1(xin, xout).detach())
         a2.append(net2(xin, xout).detach())
+    if augset is not None:
+        a1 = reverseaug(augset, a1, 2)                            # :271-272, no host round trip
+        a2 = reverseaug(augset, a2, 2)
     pl1, wm1 = pseudo_label_ensemble(a1, temperature)             # :274-292
     pl2, wm2 = pseudo_label_ensemble(a2, temperature)
     opt1.zero_grad()

@@ -4,3 +4,4 @@ from .loss2d import (CrossEntropyLoss2d, DiceLoss, CEMDiceLoss, MulticlassDiceLo
 from .metrics2d import Dice_fn  # noqa: F401
 from .coteach_loss import (Coteachingloss_dropimage, Coteachingloss_weightimage, CoTeachingProposedLoss,  # noqa: F401
                            pseudo_label_ensemble)
+from .augment import reverseaug, reverse_aug_tensor  # noqa: F401

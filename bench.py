@@ -26,6 +26,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md ch
 WORKLOADS = {
     # name: (model, per-GPU batch, image size, fwd+bwd algorithmic GFLOP / image)
     'c2': ('fuseunet', 4, 256, 348.40),
+    # AIDE proposed co-teaching step: two FuseUNets, per net 4 augmented forwards + 1 forward + 1 backward
+    'c3': ('coteach', 4, 256, 1626.5),
     'c4': ('UNet', 4, 320, 612.32),
     'c2-512': ('fuseunet', 4, 512, 1393.58),
     'tiny': ('fuseunet', 2, 64, 348.40 / 16),
@@ -85,6 +87,48 @@ def cpu_baseline(model_name, batch, size, steps, max_threads):
                 sec_per_step=dt)
 
 
+def main_coteach(args, rank, world, device, batch, size, gflop_img):
+    """BASELINE config 3 (not the headline): the AIDE proposed step on one GPU."""
+    from aide_amd.optim import Adam
+    from aide_amd.synthetic import chaos_batch
+    from aide_amd.utils import CoTeachingProposedLoss
+    from aide_amd.train_files.trainchaos_proposed_30cases1labeled import coteach_step
+    n1, n2 = build('fuseunet', device), build('fuseunet', device)
+    n1.train(); n2.train()
+    o1, o2 = Adam(n1.parameters(), lr=1e-4, amsgrad=True), Adam(n2.parameters(), lr=1e-4, amsgrad=True)
+    op = CoTeachingProposedLoss(cediceweight=[1.0, 1.0], ceclassweight=[1.0, 1.0], segcor_weight=[1.0, 10.0])
+    xin, xout, t = chaos_batch(batch, size, seed=1234 + rank)
+    xin, xout, t = xin.to(device), xout.to(device), t.to(device)
+    augs = [((xin * (1 + 0.05 * k)), (xout * (1 - 0.05 * k))) for k in range(4)]
+    augset = {'augno': [4] * batch}
+    for k in range(4):
+        augset['hflip%d' % (k + 1)] = [(k + b) % 2 for b in range(batch)]
+        augset['degree%d' % (k + 1)] = [15.0 * (k + 1) - 7.0 * b for b in range(batch)]
+
+    def step():
+        return coteach_step(n1, n2, o1, o2, op, xin, xout, augs, t, t, 0.25, augset=augset)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    value = batch * args.steps / el
+    print(json.dumps(dict(metric='training images/sec AIDE co-teaching (2x FuseUNet) %dx%dx2 bs=%d/GPU' % (size, size, batch),
+                          value=round(value, 2), unit='images/sec', n_gpus=1, steps=args.steps, warmup=args.warmup,
+                          ms_per_step=round(el / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
+                          vs_baseline=None, dtype='f32', data='synthetic',
+                          config=dict(workload='c3 two fuseunet co-teaching step (4 aug fwd + fwd + bwd + Adam per net, '
+                                               'on-device reverseaug, fused selection), %dx%d, bs=%d, fp32' % (size, size, batch),
+                                      alg_gflop_per_image=gflop_img),
+                          step_tflops=round(value * gflop_img / 1e3, 2),
+                          step_mfma_frac=round(value * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+                          final_loss=[round(float(r['loss1']), 6), round(float(r['loss2']), 6)],
+                          roofline=None, cpu_baseline=None)))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -109,6 +153,8 @@ def main():
     model_name, batch, size, gflop_img = WORKLOADS[args.workload]
     if args.batch_size:
         batch = args.batch_size
+    if model_name == 'coteach':
+        return main_coteach(args, rank, world, device, batch, size, gflop_img)
     net = build(model_name, device)
     net.train()
     if world > 1:

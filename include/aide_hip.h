@@ -80,6 +80,11 @@ int aide_upsample2x_bilinear_fwd(const float* x, int64_t x_bs, float* y, int64_t
                                  int W, aide_stream_t stream);
 int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int N, int C,
                                  int H, int W, int accumulate, aide_stream_t stream);
+/* inverse augmentation of logit planes (flip + PIL-exact bilinear rotation); replaces the D2H -> PIL ->
+ * H2D round trip of reverseaug(): train_files/trainchaos_proposed_30cases1labeled.py:81-95.
+ * par: DEVICE [N][8] doubles {a,b,c,d,e,f (PIL inverse affine), flip, mode (0 affine,1 copy,2 r180,3 r90,4 r270)} */
+int aide_reverse_aug(const float* x, int64_t x_bs, float* y, int64_t y_bs, const double* par, int N, int C,
+                     int H, int W, aide_stream_t stream);
 int aide_fill_zero(float* p, int64_t bs, int N, int C, int H, int W, aide_stream_t stream);
 
 /* ---- 1x1 head convolution -----------------------------------------------------------------------

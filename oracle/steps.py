@@ -25,6 +25,25 @@ def comparison_step(net, criterion, optimizer, inphase, outphase, targets):
     return outputs.detach(), loss.detach()
 
 
+def reverseaug(augset, augoutput, classno):
+    """trainchaos_proposed_30cases1labeled.py:81-95, restated: per (batch, aug, class) plane -> PIL 'F'
+    image -> optional FLIP_LEFT_RIGHT -> rotate(0 - degree, BILINEAR) -> back.  PIL (pillow, unpinned in
+    requirements.txt:3) is the third-party arithmetic here; this oracle calls it directly."""
+    import numpy as np
+    from PIL import Image
+    for b in range(len(augset['augno'])):
+        for k in range(int(augset['augno'][b])):
+            flip = augset['hflip%d' % (k + 1)][b]
+            rot = 0 - float(augset['degree%d' % (k + 1)][b])
+            for c in range(classno):
+                m = Image.fromarray(augoutput[k][b, c].cpu().numpy(), mode='F')
+                if flip:
+                    m = m.transpose(Image.FLIP_LEFT_RIGHT)
+                m = m.rotate(rot, Image.BILINEAR)
+                augoutput[k][b, c] = torch.from_numpy(np.array(m))
+    return augoutput
+
+
 def pseudo_labels(aug_logits, temperature):
     """trainchaos_proposed_30cases1labeled.py:274-292 — mean softmax over the (already
     reverse-augmented) passes, sharpen, weightmap = 1 - 4 p0 p1."""

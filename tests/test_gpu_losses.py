@@ -164,3 +164,28 @@ def test_full_size_properties(dev):
     close(U.CEMDiceLossImage(w, w, w)(z + 3.0, t), per, rtol=1e-5)
     # ... and two runs are bit-identical (no atomics)
     assert torch.equal(U.CEMDiceLossImage(w, w, w)(z, t), per)
+
+
+def test_reverseaug_matches_pil(dev):
+    """GPU reverseaug vs the PIL round trip of the reference (oracle.steps.reverseaug), incl. PIL's exact
+    fast paths (0/90/180/270 degrees) and non-square planes."""
+    import warnings
+    from aide_amd import utils as U
+    from oracle import steps
+    g = torch.Generator().manual_seed(21)
+    for (h, w) in ((32, 32), (48, 64)):
+        nb = 4
+        outs = [torch.randn(nb, 2, h, w, generator=g) for _ in range(4)]
+        augset = {'augno': [4, 4, 4, 3],
+                  'hflip1': [0, 1, 0, 1], 'degree1': [0.0, 37.5, -60.0, 12.25],
+                  'hflip2': [1, 0, 1, 0], 'degree2': [90.0, 180.0, 270.0, -90.0],
+                  'hflip3': [0, 0, 1, 1], 'degree3': [59.99, -0.5, 360.0, 45.0],
+                  'hflip4': [1, 1, 0, 0], 'degree4': [-33.0, 5.0, 120.0, 77.0]}
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            ref = steps.reverseaug(augset, [o.clone() for o in outs], 2)
+        got = U.reverseaug(augset, [o.to(dev) for o in outs], 2)
+        for k in range(4):
+            assert (got[k].cpu() - ref[k]).abs().max().item() < 2e-6, (h, w, k)
+        # element 3 has augno == 3: its 4th output is left untouched by the reference
+        assert torch.equal(got[3][3].cpu(), outs[3][3])
