@@ -214,17 +214,23 @@ def main():
             if agg:
                 dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
                 a = dom[1]
+                traffic = None
+                tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+                if args.workload == 'c2' and os.path.exists(tpath):
+                    # PMC counters cannot be read from inside this process: the per-launch HBM bytes of
+                    # this kernel family come from the committed rocprofv3 --pmc passes (profiles/)
+                    traffic = json.load(open(tpath)).get(dom[0], {}).get('hbm_bytes_per_launch')
                 roof = dict(bound='mfma', kernel=dom[0], achieved=round(a['tflops'], 2),
                             peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                            frac=round(a['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                            frac=round(a['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                             launches_per_step=a['launches'] // ev_steps,
                             avg_launch_ms=round(a['avg_ms'], 5),
                             alg_gflop_per_launch=round(a['flops'] / a['launches'] / 1e9, 3))
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(model_name, batch, size, args.cpu_steps, args.cpu_threads)
-        line = dict(metric='training images/sec %s %dx%dx2 bs=%d/GPU' % (
-                        'FuseUNet' if model_name == 'fuseunet' else 'UNet', size, size, batch),
+        line = dict(metric='training images/sec %s bs=%d/GPU' % (
+                        ('FuseUNet %dx%dx2' if model_name == 'fuseunet' else 'UNet %dx%d') % (size, size), batch),
                     value=round(value, 2), unit='images/sec', n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True,
                     scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
