@@ -81,3 +81,36 @@ def test_cli_smoke(dev):
     assert hist['train_loss'][-1] < hist['train_loss'][0]
     with pytest.raises(ValueError, match='Model not implemented'):
         build_model('resnet', 2)
+
+
+def test_rccl_gradient_allreduce_single_rank(dev):
+    """The bucketed RCCL all-reduce path of bench.py --gpus N, exercised on a 1-rank NCCL(=RCCL) group:
+    side streams, events and ReduceOp.AVG must run and leave the gradients bit-identical."""
+    import os
+    import torch.distributed as dist
+    from aide_amd import utils as U
+    from aide_amd.distributed import GradAllReduce, broadcast_module
+    from aide_amd.models_twomodalinputs import fuseunet
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(2)
+        net = fuseunet(2).to(dev)
+        net.train()
+        broadcast_module(net)
+        g = torch.Generator().manual_seed(1)
+        x1, x2 = torch.randn(2, 3, 64, 64, generator=g).to(dev), torch.randn(2, 3, 64, 64, generator=g).to(dev)
+        t = (torch.rand(2, 64, 64, generator=g) > 0.8).long().to(dev)
+        w = torch.tensor([1.0, 1.0])
+        U.CEMDiceLoss(w, w, w)(net(x1, x2), t).backward()
+        ref = [p.grad.clone() for p in net.parameters()]
+        net.zero_grad()
+        red = GradAllReduce(net, bucket_mb=8.0, force=True)
+        U.CEMDiceLoss(w, w, w)(net(x1, x2), t).backward()
+        torch.cuda.synchronize()
+        assert len(red.sched.buckets) >= 5 and all(p == 0 for p in red.sched.pending)
+        for a, p in zip(ref, net.parameters()):
+            assert torch.equal(a, p.grad)
+    finally:
+        dist.destroy_process_group()
