@@ -150,7 +150,7 @@ class Plan(object):
         self.wg_ws = None
         self._bwd_ready = False
         self.profiler = None             # set by Engine (bench.py's per-kernel HIP-event timing)
-        self._pack_key, self._pack_tab = None, None
+        self._pack_key, self._pack_tab, self.side_fwd = None, None, None
         self.overlap = True              # weight gradients on a side stream (see backward)
 
     # ------------------------------------------------------------------ helpers
@@ -193,37 +193,56 @@ class Plan(object):
 
     # ------------------------------------------------------------------ forward
     def _pack_filters(self):
-        """Refresh the packed forward/dgrad filters of every conv in ONE launch when any master weight
-        changed (tensor._version for torch optimizers, PARAM_EPOCH for the fused Adam)."""
+        """Refresh the packed forward/dgrad filters when any master weight changed (tensor._version for
+        torch optimizers, PARAM_EPOCH for the fused Adam).  Two launches: the first few (tiny, stage-1)
+        filters on the main stream, all the others on the side stream so that the 0.25 ms re-layout runs
+        under the first convolutions; returns the index of the first conv that must wait for it."""
         convs = [st for st in self.steps if st['kind'] == 'conv']
         key = (PARAM_EPOCH[0],) + tuple((st['conv'].weight.data_ptr(), st['conv'].weight._version) for st in convs)
         if key == self._pack_key:
-            return
+            return None
         ptrs = tuple(k[0] for k in key[1:])
         if self._pack_tab is None or self._pack_tab[0] != ptrs:
             import struct
-            rec, start = b'', 0
-            for st in convs:
-                w, wf, wd = st['conv'].weight, st['wf'], st['wd']
-                co, ci = w.shape[0], w.shape[1]
-                elems = wf.numel() + (wd.numel() if wd is not None else 0)
-                rec += struct.pack('<QQQiiiiq', w.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else 0,
-                                   co, ci, wf.shape[0], wd.shape[0] if wd is not None else 0, start)
-                start += (elems + 255) // 256
-            tab = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(self.dev)
-            self._pack_tab = (ptrs, tab, len(convs), start)
-        _, tab, n, blocks = self._pack_tab
-        ops.check(lib.aide_conv3x3_pack_weights_multi(ops.ptr(tab), n, blocks, ops.stream_ptr()),
+            split = min(4, len(convs))
+
+            def table(group):
+                rec, start = b'', 0
+                for st in group:
+                    w, wf, wd = st['conv'].weight, st['wf'], st['wd']
+                    co, ci = w.shape[0], w.shape[1]
+                    elems = wf.numel() + (wd.numel() if wd is not None else 0)
+                    rec += struct.pack('<QQQiiiiq', w.data_ptr(), wf.data_ptr(),
+                                       wd.data_ptr() if wd is not None else 0, co, ci, wf.shape[0],
+                                       wd.shape[0] if wd is not None else 0, start)
+                    start += (elems + 255) // 256
+                return torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(self.dev), len(group), start
+            self._pack_tab = (ptrs, table(convs[:split]), table(convs[split:]) if len(convs) > split else None,
+                              convs[split] if len(convs) > split else None)
+        _, first, rest, gate = self._pack_tab
+        ops.check(lib.aide_conv3x3_pack_weights_multi(ops.ptr(first[0]), first[1], first[2], ops.stream_ptr()),
                   'conv3x3_pack_weights_multi')
         self._pack_key = key
+        if rest is None:
+            return None
+        if self.side_fwd is None:
+            self.side_fwd = torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream()
+        self.side_fwd.wait_stream(main)
+        with torch.cuda.stream(self.side_fwd):
+            ops.check(lib.aide_conv3x3_pack_weights_multi(ops.ptr(rest[0]), rest[1], rest[2], ops.stream_ptr()),
+                      'conv3x3_pack_weights_multi')
+        return gate
 
     def forward(self, inputs, out):
         n = self.N
-        self._pack_filters()
+        gate = self._pack_filters()
         for st in self.steps:
             kind = st['kind']
             if kind == 'conv':
                 conv, bn = st['conv'], st['bn']
+                if st is gate:                 # the remaining filters were re-packed on the side stream
+                    torch.cuda.current_stream().wait_stream(self.side_fwd)
                 x = self.view(st['src'], inputs)
                 prof = self.profiler
                 if prof is not None:
