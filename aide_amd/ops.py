@@ -247,3 +247,47 @@ def head1x1_bwd(dy, x, w, dx, dw, db, ws=None):
         ws = torch.empty(lib.aide_head1x1_ws_bytes(c, k) // 8, device=x.device, dtype=torch.float64)
     check(lib.aide_head1x1_bwd(gp, gbs, xp, xbs, ptr(w), dp, dbs, ptr(dw), ptr(db), n, c, k, h, wd,
                                ptr(ws), stream_ptr()), 'head1x1_bwd')
+
+
+# ------------------------------------------------------------------------------- Winograd F(2x2,3x3)
+def wino_supported(cin, h, w, cout):
+    return bool(lib.aide_conv3x3_wino_supported(cin, h, w, cout))
+
+
+def wino_pack_table(entries, device):
+    """entries: list of (w, uf, ud|None). -> (device table, n, total_blocks) for aide_conv3x3_wino_pack_multi."""
+    import struct
+    rec, start = b'', 0
+    for w, uf, ud in entries:
+        co, ci = w.shape[0], w.shape[1]
+        elems = uf.shape[0] * co + (ud.shape[0] * ci if ud is not None else 0)
+        rec += struct.pack('<QQQiiiiq', w.data_ptr(), uf.data_ptr(), ud.data_ptr() if ud is not None else 0,
+                           co, ci, uf.shape[0], ud.shape[0] if ud is not None else 0, start)
+        start += (elems + 255) // 256
+    return torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(device), len(entries), start
+
+
+def wino_pack(w, need_dgrad=True):
+    """w [Co,Ci,3,3] -> (uf [ci_pad,16,Co], ud [co_pad,16,Ci] | None): G g G^T of the (rotated) filters."""
+    _req(w)
+    co, ci = w.shape[0], w.shape[1]
+    uf = torch.empty(pad_to(ci, 8), 16, co, device=w.device, dtype=torch.float32)
+    ud = torch.empty(pad_to(co, 8), 16, ci, device=w.device, dtype=torch.float32) if need_dgrad else None
+    tab, n, blocks = wino_pack_table([(w, uf, ud)], w.device)
+    check(lib.aide_conv3x3_wino_pack_multi(ptr(tab), n, blocks, stream_ptr()), 'conv3x3_wino_pack_multi')
+    return uf, ud
+
+
+def conv3x3_wino(x, u, bias, y, accumulate=False, splitk=-1, ws=None):
+    xp, xbs = planes(x)
+    yp, ybs = planes(y)
+    n, cin, h, w = x.shape
+    cout = y.shape[1]
+    assert u.shape[1] == 16 and u.shape[2] == cout and u.shape[0] >= cin
+    if splitk < 0:
+        splitk = lib.aide_conv3x3_wino_splitk(n, cin, h, w, cout)
+    if splitk > 1 and ws is None:
+        ws = torch.empty(lib.aide_conv3x3_ws_bytes(n, h, w, cout, splitk) // 4, device=x.device, dtype=torch.float32)
+    check(lib.aide_conv3x3_wino(xp, xbs, ptr(u), ptr(bias), yp, ybs, n, cin, h, w, cout, int(accumulate), splitk,
+                                ptr(ws), stream_ptr()), 'conv3x3_wino')
+    return y

@@ -36,6 +36,14 @@ size_t aide_conv3x3_ws_bytes(int N, int H, int W, int Cout, int splitk);
 int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, const float* bias,
                        float* y, int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate,
                        int plan, float* ws, aide_stream_t stream);   /* forward and dgrad */
+/* Winograd F(2x2,3x3) variant of the same convolution (forward / dgrad) for even H, W % 4 == 0,
+ * Cout % 64 == 0, Cin % 8 == 0.  Filters are pre-transformed: uf [ci_pad][16][Co], ud [co_pad][16][Ci]. */
+int aide_conv3x3_wino_supported(int Cin, int H, int W, int Cout);
+int aide_conv3x3_wino_splitk(int N, int Cin, int H, int W, int Cout);
+int aide_conv3x3_wino_pack_multi(const void* descs, int n, int64_t total_blocks, aide_stream_t stream);
+int aide_conv3x3_wino(const float* x, int64_t x_bs, const float* u, const float* bias, float* y,
+                      int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,
+                      float* ws, aide_stream_t stream);
 int aide_conv3x3_wgrad_splits(int N, int Co, int Ci, int H, int W);
 size_t aide_conv3x3_wgrad_ws_bytes(int N, int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs,

@@ -206,3 +206,37 @@ def test_head1x1(dev):
     _close(dx, xr.grad, what='head dgrad')
     _close(dw, wr.grad.view(2, 64), what='head wgrad')
     _close(db, br.grad, what='head dbias')
+
+
+WINO_CASES = [(2, 64, 64, 32, 32), (1, 128, 64, 64, 64), (2, 64, 128, 16, 16), (1, 256, 256, 16, 16),
+              (1, 64, 128, 80, 80), (4, 512, 512, 16, 16), (1, 32, 64, 40, 24), (2, 8, 64, 6, 12)]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_conv3x3_winograd_fwd_dgrad(dev, case):
+    """Winograd F(2x2,3x3) forward / dgrad vs aten: same 2e-5 bound as the direct kernels."""
+    from aide_amd import ops
+    n, ci, co, h, w = case
+    assert ops.wino_supported(ci, h, w, co)
+    g = torch.Generator().manual_seed(ci * 7 + co)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) * (1.0 / (3.0 * ci ** 0.5))
+    b = torch.randn(co, generator=g)
+    dy = torch.randn(n, co, h, w, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wt, b, padding=1)
+    yr.backward(dy)
+    uf, ud = ops.wino_pack(wt.to(dev), need_dgrad=(ci % 64 == 0))
+    for splitk in (1, 2):
+        if splitk > ci // 8:
+            continue
+        y = torch.full((n, co, h, w), 3.0, device=dev)
+        ops.conv3x3_wino(x.to(dev), uf, b.to(dev), y, splitk=splitk)
+        _close(y, yr, what='wino fwd splitk %d %s' % (splitk, case))
+    y = torch.empty(n, co, h, w, device=dev)
+    ops.conv3x3_wino(x.to(dev), uf, b.to(dev), y)                 # auto split-K
+    _close(y, yr, what='wino fwd auto %s' % (case,))
+    if ud is not None:
+        dx = torch.ones(n, ci, h, w, device=dev)
+        ops.conv3x3_wino(dy.to(dev), ud, None, dx, accumulate=True)
+        _close(dx, xr.grad + 1.0, what='wino dgrad accumulate %s' % (case,))

@@ -66,6 +66,18 @@ def main():
             t = timeit(lambda: ops.conv3x3_igemm(dy, wd, None, dx, plan=plan, ws=ws))
             line += ' dgrad v%d/s%d %7.3f ms %6.1f TF |' % (plan & 255, plan >> 8, t, gf / t)
             tot['dgrad'] += t * cnt; totf['dgrad'] += gf * cnt
+        if mode in ('wino', 'all') and ops.wino_supported(ci, h, h, co):
+            uf, ud = ops.wino_pack(w, need_dgrad=ci % 64 == 0)
+            wsw = torch.empty(1 << 26, device=dev)
+            sk = lib.aide_conv3x3_wino_splitk(N, ci, h, h, co)
+            t = timeit(lambda: ops.conv3x3_wino(x, uf, b, y, splitk=sk, ws=wsw))
+            line += ' WINO fwd s%d %7.3f ms %6.1f TF |' % (sk, t, gf / t)
+            tot.setdefault('wino', 0.0); totf.setdefault('wino', 0.0)
+            tot['wino'] += t * cnt; totf['wino'] += gf * cnt
+            if ud is not None:
+                sk = lib.aide_conv3x3_wino_splitk(N, co, h, h, ci)
+                t = timeit(lambda: ops.conv3x3_wino(dy, ud, None, dx, splitk=sk, ws=wsw))
+                line += ' WINO dgrad s%d %7.3f ms %6.1f TF |' % (sk, t, gf / t)
         if mode in ('wgrad', 'all'):
             ws = torch.empty(lib.aide_conv3x3_wgrad_ws_bytes(N, co, ci, h, h) // 4, device=dev)
             t = timeit(lambda: ops.conv3x3_wgrad(dy, x, dw, ws=ws))
