@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackDesc*
         if (descs[mid].block_start <= blk) lo = mid; else hi = mid - 1;
     }
     const PackDesc d = descs[lo];
-    const long nf = (long)d.ci_pad * 9 * d.Co, nd = d.wd ? (long)d.co_pad * 9 * d.Ci : 0;
+    const long nf = d.wf ? (long)d.ci_pad * 9 * d.Co : 0, nd = d.wd ? (long)d.co_pad * 9 * d.Ci : 0;
     const long i = (blk - d.block_start) * 256 + threadIdx.x;
     if (i < nf) {
         const int co = (int)(i % d.Co);

@@ -121,33 +121,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     };
     auto put_u = [&](int v, float* ubuf) { *reinterpret_cast<f32x4*>(ubuf + (tid + v * 256) * 4) = ru[v]; };
 
-    // input transform of item e (two items per thread and chunk): one (ci, tile) 4x4 patch -> 16 values
-    float td[2][16];
-    auto xf_load = [&](int e, const float* raw) {
+    // Input transform of item e (two items per thread and chunk): one (ci, tile) 4x4 patch -> 16 values.
+    // Split into single-instruction pieces so that the main loop can issue ONE piece per MFMA slot:
+    //   xf_read(e, i)  : td[e][i]  <- raw patch element i            (16 LDS reads)
+    //   xf_col(e, c)   : column c of B^T d                           (4 adds)
+    //   xf_out(e, o)   : output o = row r, column k of (B^T d) B     (1 add + 1 LDS store)
+    float td[2][16], tt[2][16];
+    auto xf_read = [&](int e, int i, const float* raw) {
         const int item = tid + e * 256, ci = item >> 6, tile = item & 63, ti = tile >> 3, tj = tile & 7;
-        const float* p = raw + ci * RROWS * RRS + (2 * ti) * RRS + 3 + 2 * tj;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) td[e][r * 4 + c] = p[r * RRS + c];
+        td[e][i] = raw[ci * RROWS * RRS + (2 * ti + i / 4) * RRS + 3 + 2 * tj + (i % 4)];
     };
-    auto xf_store = [&](int e, float* vbuf) {
+    auto xf_col = [&](int e, int c) {
+        const float d0 = td[e][c], d1 = td[e][4 + c], d2 = td[e][8 + c], d3 = td[e][12 + c];
+        tt[e][c] = d0 - d2; tt[e][4 + c] = d1 + d2; tt[e][8 + c] = d2 - d1; tt[e][12 + c] = d1 - d3;
+    };
+    auto xf_out = [&](int e, int o, float* vbuf) {
         const int item = tid + e * 256, ci = item >> 6, tile = item & 63;
-        float t[16];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {                      // B^T d
-            const float d0 = td[e][c], d1 = td[e][4 + c], d2 = td[e][8 + c], d3 = td[e][12 + c];
-            t[c] = d0 - d2; t[4 + c] = d1 + d2; t[8 + c] = d2 - d1; t[12 + c] = d1 - d3;
-        }
-        float* q = vbuf + ci * 64 + tile;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                      // (B^T d) B
-            const float t0 = t[r * 4], t1 = t[r * 4 + 1], t2 = t[r * 4 + 2], t3 = t[r * 4 + 3];
-            q[(r * 4 + 0) * WCK * 64] = t0 - t2;
-            q[(r * 4 + 1) * WCK * 64] = t1 + t2;
-            q[(r * 4 + 2) * WCK * 64] = t2 - t1;
-            q[(r * 4 + 3) * WCK * 64] = t1 - t3;
-        }
+        const int r = o / 4, k = o % 4;
+        const float t0 = tt[e][r * 4], t1 = tt[e][r * 4 + 1], t2 = tt[e][r * 4 + 2], t3 = tt[e][r * 4 + 3];
+        const float v = k == 0 ? t0 - t2 : k == 1 ? t1 + t2 : k == 2 ? t2 - t1 : t1 - t3;
+        vbuf[o * WCK * 64 + ci * 64 + tile] = v;
     };
 
     f32x16 acc[16];
@@ -171,7 +164,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     for (int l = 0; l < NRB + NRC; ++l) fetch_raw(l, c_begin + 1);
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 2; ++e) { xf_load(e, set0); xf_store(e, set0 + RAWL); }
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xf_read(e, i, set0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xf_col(e, c);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) xf_out(e, o, set0 + RAWL);
+    }
 #pragma unroll
     for (int l = 0; l < NRB + NRC; ++l) put_raw(l, set1);
     __syncthreads();
@@ -198,16 +198,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
             if (st + 1 < STEPS) frag(st + 1, afn, bfn);
             const int p = st / (WCK / 2);
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(afc, bfc, acc[p], 0, 0, 0);
-            // staging schedule (compile-time): slots 0..12 issue the global fetches of U[chunk+1] and
-            // raw[chunk+2]; 14,15 / 30,31 read the two 4x4 patches; 16..47 store V; 48..60 store U, raw
+            // staging schedule (compile-time, at most ~4 light instructions per 64-cycle MFMA slot):
+            //   slots  0..12 : global fetches of U[chunk+1] (8) and raw[chunk+2] (5)
+            //   item e at base S = 30 e : S..S+15 patch reads, S+16..S+19 column transforms,
+            //                             S+20..S+27 two outputs (add + LDS store) per slot
+            //   slots 48..55 : LDS stores of U[chunk+1];  56..60 : LDS stores of raw[chunk+2]
             if (st < NU) fetch_u(st, chunk + 1);
             else if (st < NU + NRB + NRC) fetch_raw(st - NU, chunk + 2);
-            if (st == 14) xf_load(0, sn);
-            if (st == 20) xf_store(0, sn + RAWL);
-            if (st == 26) xf_load(1, sn);
-            if (st == 32) xf_store(1, sn + RAWL);
-            if (st >= 40 && st < 40 + NU) put_u(st - 40, sn + RAWL + VL);
-            if (st >= 50 && st < 50 + NRB + NRC) put_raw(st - 50, sc);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int rel = st - 30 * e;
+                if (rel >= 0 && rel < 16) xf_read(e, rel, sn);
+                else if (rel >= 16 && rel < 20) xf_col(e, rel - 16);
+                else if (rel >= 20 && rel < 28) { xf_out(e, 2 * (rel - 20), sn + RAWL); xf_out(e, 2 * (rel - 20) + 1, sn + RAWL); }
+            }
+            if (st >= 48 && st < 48 + NU) put_u(st - 48, sn + RAWL + VL);
+            if (st >= 56 && st < 56 + NRB + NRC) put_raw(st - 56, sc);
             __builtin_amdgcn_sched_barrier(0);
         };
         frag(0, afA, bfA);
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(256) void wino_pack_multi_kernel(const WinoPackDesc
     }
     const WinoPackDesc d = descs[lo];
     // one thread per (padded ci, co) pair of the forward pack, then per (padded co, ci) of the dgrad pack
-    const long nf = (long)d.ci_pad * d.Co, nd = d.ud ? (long)d.co_pad * d.Ci : 0;
+    const long nf = d.uf ? (long)d.ci_pad * d.Co : 0, nd = d.ud ? (long)d.co_pad * d.Ci : 0;
     const long i = (blk - d.block_start) * 256 + threadIdx.x;
     float g[9], u[16];
     if (i < nf) {

@@ -68,6 +68,19 @@ class Graph(object):
         self.ops.append(dict(kind='head', src=src, conv=conv))
 
 
+USE_WINOGRAD = [True]          # global switch (tests / A-B runs)
+USE_WINOGRAD_DGRAD = [True]    # ... for the dgrad direction only
+
+
+def use_winograd(n, cin, h, w, cout):
+    """Static (deterministic) choice between the Winograd and the direct conv kernel, from the layer
+    sweep in profiles/: Winograd wins whenever it is supported except for the channel-expanding layers at
+    small resolutions, where its 64co x 64-tile workgroups leave too few workgroups / too much split-K."""
+    if not USE_WINOGRAD[0] or not lib.aide_conv3x3_wino_supported(cin, h, w, cout):
+        return False
+    return cin >= cout or h * w >= 128 * 128
+
+
 class _Cover(object):
     """Tracks which channel ranges of a gradient buffer have been written during the backward
     schedule: first writer overwrites, later writers accumulate, gaps are zero-filled once."""
@@ -127,10 +140,24 @@ class Plan(object):
                 if op['kind'] == 'conv':
                     cin = src.C
                     need_dg = not src.root.is_input
-                    st['wf'] = torch.empty(ops.pad_to(cin, ops.conv_chunk(cin)), 9, cout, **f32)
-                    st['wd'] = torch.empty(ops.pad_to(cout, ops.conv_chunk(cout)), 9, cin, **f32) if need_dg else None
-                    st['plan_f'] = lib.aide_conv3x3_plan(n, cin, hh, ww, cout)
-                    st['plan_d'] = lib.aide_conv3x3_plan(n, cout, hh, ww, cin) if need_dg else 0
+                    # Winograd F(2x2,3x3) where it is supported and measured faster (16 MFMA-multiplies
+                    # per output instead of 36); the direct implicit GEMM otherwise
+                    st['wino_f'] = use_winograd(n, cin, hh, ww, cout)
+                    st['wino_d'] = need_dg and USE_WINOGRAD_DGRAD[0] and use_winograd(n, cout, hh, ww, cin)
+                    st['wf'] = st['wd'] = st['uf'] = st['ud'] = None
+                    st['plan_f'] = st['plan_d'] = 0
+                    if st['wino_f']:
+                        st['uf'] = torch.empty(ops.pad_to(cin, 8), 16, cout, **f32)
+                        st['plan_f'] = lib.aide_conv3x3_wino_splitk(n, cin, hh, ww, cout) << 8
+                    else:
+                        st['wf'] = torch.empty(ops.pad_to(cin, ops.conv_chunk(cin)), 9, cout, **f32)
+                        st['plan_f'] = lib.aide_conv3x3_plan(n, cin, hh, ww, cout)
+                    if need_dg and st['wino_d']:
+                        st['ud'] = torch.empty(ops.pad_to(cout, 8), 16, cin, **f32)
+                        st['plan_d'] = lib.aide_conv3x3_wino_splitk(n, cout, hh, ww, cin) << 8
+                    elif need_dg:
+                        st['wd'] = torch.empty(ops.pad_to(cout, ops.conv_chunk(cout)), 9, cin, **f32)
+                        st['plan_d'] = lib.aide_conv3x3_plan(n, cout, hh, ww, cin)
                     max_sk = max(max_sk, lib.aide_conv3x3_ws_bytes(n, hh, ww, cout, st['plan_f'] >> 8),
                                  lib.aide_conv3x3_ws_bytes(n, hh, ww, cin, st['plan_d'] >> 8) if need_dg else 0)
                     max_wg = max(max_wg, lib.aide_conv3x3_wgrad_ws_bytes(n, cout, cin, hh, ww))
@@ -206,22 +233,26 @@ class Plan(object):
             import struct
             split = min(4, len(convs))
 
-            def table(group):
-                rec, start = b'', 0
-                for st in group:
-                    w, wf, wd = st['conv'].weight, st['wf'], st['wd']
-                    co, ci = w.shape[0], w.shape[1]
-                    elems = wf.numel() + (wd.numel() if wd is not None else 0)
-                    rec += struct.pack('<QQQiiiiq', w.data_ptr(), wf.data_ptr(),
-                                       wd.data_ptr() if wd is not None else 0, co, ci, wf.shape[0],
-                                       wd.shape[0] if wd is not None else 0, start)
-                    start += (elems + 255) // 256
-                return torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(self.dev), len(group), start
-            self._pack_tab = (ptrs, table(convs[:split]), table(convs[split:]) if len(convs) > split else None,
+            def tables(group):
+                direct = [(st['conv'].weight, st['wf'], st['wd']) for st in group
+                          if st['wf'] is not None or st['wd'] is not None]
+                wino = [(st['conv'].weight, st['uf'], st['ud']) for st in group
+                        if st['uf'] is not None or st['ud'] is not None]
+                return (ops.pack_table(direct, self.dev) if direct else None,
+                        ops.wino_pack_table(wino, self.dev) if wino else None)
+            self._pack_tab = (ptrs, tables(convs[:split]), tables(convs[split:]) if len(convs) > split else None,
                               convs[split] if len(convs) > split else None)
         _, first, rest, gate = self._pack_tab
-        ops.check(lib.aide_conv3x3_pack_weights_multi(ops.ptr(first[0]), first[1], first[2], ops.stream_ptr()),
-                  'conv3x3_pack_weights_multi')
+
+        def launch(tabs):
+            d, wn = tabs
+            if d is not None:
+                ops.check(lib.aide_conv3x3_pack_weights_multi(ops.ptr(d[0]), d[1], d[2], ops.stream_ptr()),
+                          'conv3x3_pack_weights_multi')
+            if wn is not None:
+                ops.check(lib.aide_conv3x3_wino_pack_multi(ops.ptr(wn[0]), wn[1], wn[2], ops.stream_ptr()),
+                          'conv3x3_wino_pack_multi')
+        launch(first)
         self._pack_key = key
         if rest is None:
             return None
@@ -230,8 +261,7 @@ class Plan(object):
         main = torch.cuda.current_stream()
         self.side_fwd.wait_stream(main)
         with torch.cuda.stream(self.side_fwd):
-            ops.check(lib.aide_conv3x3_pack_weights_multi(ops.ptr(rest[0]), rest[1], rest[2], ops.stream_ptr()),
-                      'conv3x3_pack_weights_multi')
+            launch(rest)
         return gate
 
     def forward(self, inputs, out):
@@ -247,7 +277,10 @@ class Plan(object):
                 prof = self.profiler
                 if prof is not None:
                     prof.begin('conv3x3_igemm', st['flops'])
-                ops.conv3x3_igemm(x, st['wf'], conv.bias, st['z'], plan=st['plan_f'], ws=self.sk_ws)
+                if st['wino_f']:
+                    ops.conv3x3_wino(x, st['uf'], conv.bias, st['z'], splitk=st['plan_f'] >> 8, ws=self.sk_ws)
+                else:
+                    ops.conv3x3_igemm(x, st['wf'], conv.bias, st['z'], plan=st['plan_f'], ws=self.sk_ws)
                 if prof is not None:
                     prof.end()
                 self._bn_apply(st, bn)
@@ -331,8 +364,12 @@ class Plan(object):
                     if sg is not None:
                         if prof is not None:
                             prof.begin('conv3x3_igemm', st['flops'])
-                        ops.conv3x3_igemm(dz, st['wd'], None, self.gview(st['src']),
-                                          accumulate=sg['accumulate'], plan=st['plan_d'], ws=self.sk_ws)
+                        if st['wino_d']:
+                            ops.conv3x3_wino(dz, st['ud'], None, self.gview(st['src']),
+                                             accumulate=sg['accumulate'], splitk=st['plan_d'] >> 8, ws=self.sk_ws)
+                        else:
+                            ops.conv3x3_igemm(dz, st['wd'], None, self.gview(st['src']),
+                                              accumulate=sg['accumulate'], plan=st['plan_d'], ws=self.sk_ws)
                         if prof is not None:
                             prof.end()
                 else:

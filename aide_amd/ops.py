@@ -64,6 +64,21 @@ def pack_weights(w, need_dgrad=True):
     return wf, wd
 
 
+def pack_table(entries, device):
+    """entries: list of (w, wf|None, wd|None) -> (device table, n, total_blocks) for
+    aide_conv3x3_pack_weights_multi (48-byte records, see include/aide_hip.h)."""
+    import struct
+    rec, start = b'', 0
+    for w, wf, wd in entries:
+        co, ci = w.shape[0], w.shape[1]
+        elems = (wf.numel() if wf is not None else 0) + (wd.numel() if wd is not None else 0)
+        rec += struct.pack('<QQQiiiiq', w.data_ptr(), wf.data_ptr() if wf is not None else 0,
+                           wd.data_ptr() if wd is not None else 0, co, ci,
+                           wf.shape[0] if wf is not None else 0, wd.shape[0] if wd is not None else 0, start)
+        start += (elems + 255) // 256
+    return torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(device), len(entries), start
+
+
 def pack_weights_into(w, wf, wd):
     co, ci = w.shape[0], w.shape[1]
     check(lib.aide_conv3x3_pack_weights(ptr(w), ptr(wf), ptr(wd), co, ci, wf.shape[0],
@@ -260,9 +275,10 @@ def wino_pack_table(entries, device):
     rec, start = b'', 0
     for w, uf, ud in entries:
         co, ci = w.shape[0], w.shape[1]
-        elems = uf.shape[0] * co + (ud.shape[0] * ci if ud is not None else 0)
-        rec += struct.pack('<QQQiiiiq', w.data_ptr(), uf.data_ptr(), ud.data_ptr() if ud is not None else 0,
-                           co, ci, uf.shape[0], ud.shape[0] if ud is not None else 0, start)
+        elems = (uf.shape[0] * co if uf is not None else 0) + (ud.shape[0] * ci if ud is not None else 0)
+        rec += struct.pack('<QQQiiiiq', w.data_ptr(), uf.data_ptr() if uf is not None else 0,
+                           ud.data_ptr() if ud is not None else 0, co, ci,
+                           uf.shape[0] if uf is not None else 0, ud.shape[0] if ud is not None else 0, start)
         start += (elems + 255) // 256
     return torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(device), len(entries), start
 

@@ -55,6 +55,15 @@ class forced_relu_masks(object):
         for st in plan.steps:
             if st['kind'] in ('conv', 'convT'):
                 self.masks[name_of[id(st['bn'])]] = (plan.view(st['dst']).detach().cpu() > 0).float()
+        # max-pool arg-max: near-ties (two window elements within the fp32 noise) are the same kind of
+        # discrete event; the oracle's pooling is evaluated with OUR window winners as well
+        self.pool_idx = {}
+        for st in plan.steps:
+            if st['kind'] == 'pool':
+                src = plan.view(st['src']).detach().cpu()
+                _, idx = torch.nn.functional.max_pool2d(src, 2, 2, return_indices=True)
+                self.pool_idx[tuple(src.shape[2:])] = idx
+        self.pool_flips = 0
         self.ref, self.cur, self.flips, self.hooks = ref, [None], {}, []
         self.total = sum(m.numel() for m in self.masks.values())
 
@@ -72,11 +81,22 @@ class forced_relu_masks(object):
                 self.hooks.append(m.register_forward_hook(hook))
         self.orig = F.relu
         F.relu = lambda x, inplace=False: x * self.masks[self.cur[0]]
+        self.orig_pool = F.max_pool2d
+
+        def forced_pool(x, kernel_size, stride=None, *a, **k):
+            idx = self.pool_idx[tuple(x.shape[2:])]
+            idx = idx[:, idx.shape[1] - x.shape[1]:]           # modal-2 pools the trailing channel slice
+            _, own = self.orig_pool(x.detach(), 2, 2, return_indices=True)
+            self.pool_flips += int((own != idx).sum())
+            n, c, h, w = x.shape
+            return x.reshape(n, c, h * w).gather(2, idx.reshape(n, c, -1)).reshape(n, c, h // 2, w // 2)
+        F.max_pool2d = forced_pool
         return self
 
     def __exit__(self, *a):
         import torch.nn.functional as F
         F.relu = self.orig
+        F.max_pool2d = self.orig_pool
         for h in self.hooks:
             h.remove()
 
