@@ -407,3 +407,311 @@ int aide_conv3x3_wgrad(const float* dz, int64_t dz_bs, const float* a, int64_t a
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// Winograd form of the weight gradient:  dW = G^T [ sum_tiles (A Z A^T) (.) (B^T D B) ] G
+// (the transposition of F(2x2,3x3): Z = 2x2 tile of dz, D = the 4x4 input patch, 16 multiplies per
+// (tile, co, ci) instead of 36).  Per transform position p the sum over tiles is a GEMM
+//   M[p][co][ci] += ZT[p][co][tile] * V[p][ci][tile]           (K = tiles, two per v_mfma_f32_32x32x2_f32)
+// Workgroup = 64 co x 64 ci, wave = 32 x 32 x 16 positions (256 accumulator registers, 1 wave/SIMD);
+// a chunk = 8 tiles of one tile row (2 x 16 output pixels).  Raw dz / input rows go global -> regs ->
+// LDS, every lane transforms (channel = lane, tile = wave-slot) patches into the double-buffered
+// ZT / V operands ([p][channel][8 tiles], XOR-swizzled so that fragment reads and transform writes are
+// conflict-free without padding), all in the shadow of the MFMAs.  The raw LDS area is single
+// buffered: a mid-chunk barrier separates its last transform read from the next chunk's store.
+namespace {
+
+struct WWArgs {
+    const float* dz;
+    const float* a;
+    float* slabs;
+    long dz_bs, a_bs;
+    int N, Co, Ci, H, W;
+    int rows_t, cols_c, n_co_tiles, n_ci_tiles, splits, chunks_total;
+};
+
+constexpr int WW_DSTR = 73, WW_ZSTR = 33;                 // odd raw channel strides (4x18 / 2x16 rows)
+constexpr int WW_OP = 16 * 64 * 8;                        // one operand buffer (floats)
+constexpr int WW_LDS = 4 * WW_OP + 64 * WW_DSTR + 64 * WW_ZSTR;   // 39552 floats = 154.5 KB
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(const WWArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ztb = lds;                       // ZT[2][16][512]
+    float* vb = lds + 2 * WW_OP;            // V [2][16][512]
+    float* rawD = lds + 4 * WW_OP;
+    float* rawZ = rawD + 64 * WW_DSTR;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    const int wave_co = wid >> 1, wave_ci = wid & 1;
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci_tile = b % g.n_ci_tiles; b /= g.n_ci_tiles;
+    const int co_tile = b % g.n_co_tiles;
+    const int split = b / g.n_co_tiles;
+    const int co0 = co_tile * 64, ci0 = ci_tile * 64;
+    const int HW = g.H * g.W;
+    const int cps = (g.chunks_total + g.splits - 1) / g.splits;
+    const int c_begin = split * cps, c_end = min(c_begin + cps, g.chunks_total);
+
+    const __amdgpu_buffer_rsrc_t drs = make_rsrc(g.dz + (long)co0 * HW);
+    const __amdgpu_buffer_rsrc_t ars = make_rsrc(g.a + (long)ci0 * HW - (g.W + 1));
+
+    // ---- tile-invariant unit descriptors ----
+    // D interior: 64 ci x 4 rows x 4 float4 (4 per thread); D edges: 64 x 4 x 2 dwords (2 per thread);
+    // Z: 64 co x 2 rows x 4 float4 (2 per thread)
+    unsigned offDi[4], ldsDi[4], rowDi[4], colDi[4], offDe[2], ldsDe[2], rowDe[2], sideDe[2], offZ[2], ldsZ[2], colZ[2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int q = tid + e * 256, c = q >> 4, r = (q >> 2) & 3, s4 = q & 3;
+        offDi[e] = (ci0 + c) < g.Ci ? (unsigned)(c * HW + r * g.W + 1 + 4 * s4) * 4u : BUF_OOB;
+        ldsDi[e] = (unsigned)(c * WW_DSTR + r * 18 + 1 + 4 * s4);
+        rowDi[e] = r; colDi[e] = 4 * s4;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int q = tid + e * 256, c = q >> 3, r = (q >> 1) & 3, side = q & 1;
+        offDe[e] = (ci0 + c) < g.Ci ? (unsigned)(c * HW + r * g.W + (side ? 17 : 0)) * 4u : BUF_OOB;
+        ldsDe[e] = (unsigned)(c * WW_DSTR + r * 18 + (side ? 17 : 0));
+        rowDe[e] = r; sideDe[e] = side;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int q = tid + e * 256, c = q >> 3, r = (q >> 2) & 1, s4 = q & 3;
+        offZ[e] = (co0 + c) < g.Co ? (unsigned)(c * HW + r * g.W + 4 * s4) * 4u : BUF_OOB;
+        ldsZ[e] = (unsigned)(c * WW_ZSTR + r * 16 + 4 * s4);
+        colZ[e] = 4 * s4;
+    }
+
+    int th0 = 0, tw0 = 0;
+    unsigned dso = 0, aso = 0;
+    auto set_chunk = [&](int c) {
+        c = min(c, c_end - 1);                 // past the end: refetch the last chunk (never consumed)
+        const int cc = c % g.cols_c;
+        const int r2 = c / g.cols_c;
+        const int tr = r2 % g.rows_t, n = r2 / g.rows_t;
+        th0 = 2 * tr; tw0 = 16 * cc;
+        dso = (unsigned)((long)n * g.dz_bs + th0 * g.W + tw0) * 4u;
+        aso = (unsigned)((long)n * g.a_bs + th0 * g.W + tw0) * 4u;
+    };
+    f32x4 rDi[4], rZ[2];
+    float rDe[2];
+    auto fetch = [&](int l) {                  // 8 global loads per thread and chunk
+        if (l < 4) {
+            const int ih = th0 - 1 + (int)rowDi[l];
+            const bool ok = ih >= 0 && ih < g.H && tw0 + (int)colDi[l] < g.W;
+            rDi[l] = buf_load_f32x4(ars, ok ? offDi[l] : BUF_OOB, aso);
+        } else if (l < 6) {
+            const int e = l - 4, ih = th0 - 1 + (int)rowDe[e], iw = sideDe[e] ? tw0 + 16 : tw0 - 1;
+            const bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+            rDe[e] = buf_load_f32(ars, ok ? offDe[e] : BUF_OOB, aso);
+        } else {
+            const int e = l - 6;
+            rZ[e] = buf_load_f32x4(drs, (tw0 + (int)colZ[e] < g.W) ? offZ[e] : BUF_OOB, dso);
+        }
+    };
+    auto put = [&](int w) {                    // 26 LDS stores per thread and chunk
+        if (w < 16) rawD[ldsDi[w >> 2] + (w & 3)] = rDi[w >> 2][w & 3];
+        else if (w < 18) rawD[ldsDe[w - 16]] = rDe[w - 16];
+        else rawZ[ldsZ[(w - 18) >> 2] + ((w - 18) & 3)] = rZ[(w - 18) >> 2][(w - 18) & 3];
+    };
+
+    // transforms: item e in {0,1} -> tile = wid + 4 e of the chunk, channel = lane
+    const int swz = (lane >> 2) & 7;
+    float td[2][16], tt[2][16], tz[2][4], tu[2][8];
+    auto d_read = [&](int e, int i) { td[e][i] = rawD[lane * WW_DSTR + (i >> 2) * 18 + 2 * (wid + 4 * e) + (i & 3)]; };
+    auto d_col = [&](int e, int c) {
+        const float d0 = td[e][c], d1 = td[e][4 + c], d2 = td[e][8 + c], d3 = td[e][12 + c];
+        tt[e][c] = d0 - d2; tt[e][4 + c] = d1 + d2; tt[e][8 + c] = d2 - d1; tt[e][12 + c] = d1 - d3;
+    };
+    auto d_out = [&](int e, int o, float* vbuf) {
+        const int r = o >> 2, k = o & 3;
+        const float t0 = tt[e][r * 4], t1 = tt[e][r * 4 + 1], t2 = tt[e][r * 4 + 2], t3 = tt[e][r * 4 + 3];
+        vbuf[o * 512 + lane * 8 + ((wid + 4 * e) ^ swz)] = k == 0 ? t0 - t2 : k == 1 ? t1 + t2 : k == 2 ? t2 - t1 : t1 - t3;
+    };
+    auto z_read = [&](int e, int i) { tz[e][i] = rawZ[lane * WW_ZSTR + (i >> 1) * 16 + 2 * (wid + 4 * e) + (i & 1)]; };
+    auto z_col = [&](int e) {                  // A Z : rows (z0, z0+z1, z0-z1, -z1) for both columns
+        const float a0 = tz[e][0], a1 = tz[e][1], b0 = tz[e][2], b1 = tz[e][3];
+        tu[e][0] = a0; tu[e][1] = a1; tu[e][2] = a0 + b0; tu[e][3] = a1 + b1;
+        tu[e][4] = a0 - b0; tu[e][5] = a1 - b1; tu[e][6] = -b0; tu[e][7] = -b1;
+    };
+    auto z_out = [&](int e, int o, float* zbuf) {
+        const int r = o >> 2, k = o & 3;
+        const float u0 = tu[e][2 * r], u1 = tu[e][2 * r + 1];
+        zbuf[o * 512 + lane * 8 + ((wid + 4 * e) ^ swz)] = k == 0 ? u0 : k == 1 ? u0 + u1 : k == 2 ? u0 - u1 : -u1;
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+
+    // fragment offsets: channel row + swizzled tile slot for the four tile pairs of a chunk
+    const int cho_a = (wave_co * 32 + j) * 8, sw_a = ((wave_co * 32 + j) >> 2) & 7;
+    const int cho_b = (wave_ci * 32 + j) * 8, sw_b = ((wave_ci * 32 + j) >> 2) & 7;
+    int fa[4], fb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { fa[s] = cho_a + ((2 * s + half) ^ sw_a); fb[s] = cho_b + ((2 * s + half) ^ sw_b); }
+
+    // ---- prologue ----
+    set_chunk(c_begin);
+#pragma unroll
+    for (int l = 0; l < 8; ++l) fetch(l);
+#pragma unroll
+    for (int w = 0; w < 26; ++w) put(w);
+    set_chunk(c_begin + 1);
+#pragma unroll
+    for (int l = 0; l < 8; ++l) fetch(l);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d_read(e, i);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d_col(e, c);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) d_out(e, o, vb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z_read(e, i);
+        z_col(e);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) z_out(e, o, ztb);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 26; ++w) put(w);
+    __syncthreads();
+
+    int cur = 0;
+    for (int c = c_begin; c < c_end; ++c) {
+        const float* za = ztb + cur * WW_OP;
+        const float* va = vb + cur * WW_OP;
+        float* zn = ztb + (cur ^ 1) * WW_OP;
+        float* vn = vb + (cur ^ 1) * WW_OP;
+        set_chunk(c + 2);
+        float afA, bfA, afB, bfB;
+        auto frag = [&](int st, float& af, float& bf) {
+            const int p = st >> 2, s = st & 3;
+            af = za[p * 512 + fa[s]];
+            bf = va[p * 512 + fb[s]];
+        };
+        auto slot = [&](int st, float& afc, float& bfc, float& afn, float& bfn) {
+            if (st + 1 < 64) frag(st + 1, afn, bfn);
+            acc[st >> 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(afc, bfc, acc[st >> 2], 0, 0, 0);
+            // schedule: 0..7 global fetches of raw[c+2]; D transform of item e at 20 e + {0..15 reads,
+            // 16..19 columns} and outputs two per slot; Z transform in the gaps; 46: raw LDS free
+            // (mid barrier) ; 47..59 raw[c+2] stores (two per slot)
+            if (st < 8) fetch(st);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int rel = st - 14 * e;
+                if (rel >= 0 && rel < 8) { d_read(e, 2 * rel); d_read(e, 2 * rel + 1); }
+                else if (rel >= 8 && rel < 10) { d_col(e, 2 * (rel - 8)); d_col(e, 2 * (rel - 8) + 1); }
+                else if (rel >= 10 && rel < 14) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d_out(e, 4 * (rel - 10) + k, vn);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int rel = st - 28 - 8 * e;
+                if (rel == 0) { z_read(e, 0); z_read(e, 1); z_read(e, 2); z_read(e, 3); }
+                else if (rel == 1) z_col(e);
+                else if (rel >= 2 && rel < 6) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) z_out(e, 4 * (rel - 2) + k, zn);
+                }
+            }
+            if (st == 46) __syncthreads();
+            if (st >= 47 && st < 60) { put(2 * (st - 47)); put(2 * (st - 47) + 1); }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        frag(0, afA, bfA);
+#pragma unroll
+        for (int st = 0; st < 64; st += 2) {
+            slot(st, afA, bfA, afB, bfB);
+            slot(st + 1, afB, bfB, afA, bfA);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- dW = G^T M G per lane (co = accumulator row, ci = lane column), write the split's slab ----
+    float* slab = g.slabs + (long)split * 9 * g.Co * g.Ci;
+    const int ci = ci0 + wave_ci * 32 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wave_co * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float t[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float m0 = acc[c][r], m1 = acc[4 + c][r], m2 = acc[8 + c][r], m3 = acc[12 + c][r];
+            const float hs = 0.5f * (m1 + m2), hd = 0.5f * (m1 - m2);
+            t[0][c] = m0 + hs; t[1][c] = hd; t[2][c] = hs + m3;
+        }
+        if (co < g.Co && ci < g.Ci) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float hs = 0.5f * (t[i][1] + t[i][2]), hd = 0.5f * (t[i][1] - t[i][2]);
+                slab[((long)(i * 3 + 0) * g.Co + co) * g.Ci + ci] = t[i][0] + hs;
+                slab[((long)(i * 3 + 1) * g.Co + co) * g.Ci + ci] = hd;
+                slab[((long)(i * 3 + 2) * g.Co + co) * g.Ci + ci] = hs + t[i][3];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int aide_conv3x3_wgrad_wino_supported(int Co, int Ci, int H, int W) {
+    return (H % 2 == 0 && W % 4 == 0 && Co >= 64 && Ci >= 64) ? 1 : 0;
+}
+
+int aide_conv3x3_wgrad_wino_splits(int N, int Co, int Ci, int H, int W) {
+    const long blocks = (long)((Co + 63) / 64) * ((Ci + 63) / 64);
+    const long chunks = (long)N * (H / 2) * ((W + 15) / 16);
+    long s = (256 + blocks - 1) / blocks;
+    if (s > chunks) s = chunks;
+    return (int)(s < 1 ? 1 : s);
+}
+
+size_t aide_conv3x3_wgrad_wino_ws_bytes(int N, int Co, int Ci, int H, int W) {
+    return (size_t)aide_conv3x3_wgrad_wino_splits(N, Co, Ci, H, W) * 9 * Co * Ci * sizeof(float);
+}
+
+// Same contract as aide_conv3x3_wgrad (dw [Co][Ci][3][3]); requires aide_conv3x3_wgrad_wino_supported.
+int aide_conv3x3_wgrad_wino(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
+                            int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
+    if (!dz || !a || !dw || !ws || !aide_conv3x3_wgrad_wino_supported(Co, Ci, H, W) || dz_bs % 4 || a_bs % 4)
+        return AIDE_ERR_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv3x3_wgrad_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            WW_LDS * (int)sizeof(float));
+        attr_set = true;
+    }
+    WWArgs g;
+    g.dz = dz; g.a = a; g.slabs = ws; g.dz_bs = dz_bs; g.a_bs = a_bs;
+    g.N = N; g.Co = Co; g.Ci = Ci; g.H = H; g.W = W;
+    g.rows_t = H / 2; g.cols_c = (W + 15) / 16;
+    g.n_co_tiles = (Co + 63) / 64; g.n_ci_tiles = (Ci + 63) / 64;
+    g.chunks_total = N * g.rows_t * g.cols_c;
+    g.splits = aide_conv3x3_wgrad_wino_splits(N, Co, Ci, H, W);
+    const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
+    hipLaunchKernelGGL(conv3x3_wgrad_wino_kernel, dim3((unsigned)nb), dim3(256), WW_LDS * sizeof(float), stream, g);
+    int rc = aide_launch_status();
+    if (rc != 0) return rc;
+    const long total = 9L * Co * Ci;
+    if (g.splits <= 8)
+        hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0,
+                           stream, ws, g.splits, Co, Ci, dw);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, ws,
+                           g.splits, Co, Ci, dw);
+    return aide_launch_status();
+}
+
+}  // extern "C"

@@ -160,7 +160,9 @@ class Plan(object):
                         st['plan_d'] = lib.aide_conv3x3_plan(n, cout, hh, ww, cin)
                     max_sk = max(max_sk, lib.aide_conv3x3_ws_bytes(n, hh, ww, cout, st['plan_f'] >> 8),
                                  lib.aide_conv3x3_ws_bytes(n, hh, ww, cin, st['plan_d'] >> 8) if need_dg else 0)
-                    max_wg = max(max_wg, lib.aide_conv3x3_wgrad_ws_bytes(n, cout, cin, hh, ww))
+                    st['wino_w'] = bool(USE_WINOGRAD[0] and lib.aide_conv3x3_wgrad_wino_supported(cout, cin, hh, ww))
+                    max_wg = max(max_wg, lib.aide_conv3x3_wgrad_wino_ws_bytes(n, cout, cin, hh, ww) if st['wino_w']
+                                 else lib.aide_conv3x3_wgrad_ws_bytes(n, cout, cin, hh, ww))
                     st['pack_key'] = None
                     st['flops'] = 2.0 * n * hh * ww * cout * cin * 9      # algorithmic, per launch
                 else:
@@ -349,16 +351,17 @@ class Plan(object):
                 x = self.view(st['src'], inputs)
                 if kind == 'conv':
                     prof = self.profiler
+                    wgrad = ops.conv3x3_wgrad_wino if st['wino_w'] else ops.conv3x3_wgrad
                     if side is not None:
                         ev = torch.cuda.Event()
                         ev.record(main)
                         with torch.cuda.stream(side):
                             side.wait_event(ev)
-                            ops.conv3x3_wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
+                            wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
                     else:
                         if prof is not None:
                             prof.begin('conv3x3_wgrad', st['flops'])
-                        ops.conv3x3_wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
+                        wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
                         if prof is not None:
                             prof.end()
                     if sg is not None:

@@ -307,3 +307,21 @@ def conv3x3_wino(x, u, bias, y, accumulate=False, splitk=-1, ws=None):
     check(lib.aide_conv3x3_wino(xp, xbs, ptr(u), ptr(bias), yp, ybs, n, cin, h, w, cout, int(accumulate), splitk,
                                 ptr(ws), stream_ptr()), 'conv3x3_wino')
     return y
+
+
+def wgrad_wino_supported(co, ci, h, w):
+    return bool(lib.aide_conv3x3_wgrad_wino_supported(co, ci, h, w))
+
+
+def conv3x3_wgrad_wino(dz, a, dw, ws=None):
+    dp, dbs = planes(dz)
+    ap, abs_ = planes(a)
+    n, co, h, w = dz.shape
+    ci = a.shape[1]
+    assert tuple(dw.shape) == (co, ci, 3, 3) and dw.is_contiguous()
+    if ws is None:
+        ws = torch.empty(lib.aide_conv3x3_wgrad_wino_ws_bytes(n, co, ci, h, w) // 4, device=dz.device,
+                         dtype=torch.float32)
+    check(lib.aide_conv3x3_wgrad_wino(dp, dbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), stream_ptr()),
+          'conv3x3_wgrad_wino')
+    return dw

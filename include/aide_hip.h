@@ -50,6 +50,14 @@ int aide_conv3x3_wgrad(const float* dz, int64_t dz_bs, const float* a, int64_t a
                        float* dw /*[Co][Ci][3][3]*/, int N, int Co, int Ci, int H, int W, float* ws,
                        aide_stream_t stream);
 
+/* Winograd form of the weight gradient (16 instead of 36 MFMA-multiplies per tile, co, ci);
+ * even H, W % 4 == 0, Co >= 64, Ci >= 64.  Same outputs as aide_conv3x3_wgrad. */
+int aide_conv3x3_wgrad_wino_supported(int Co, int Ci, int H, int W);
+int aide_conv3x3_wgrad_wino_splits(int N, int Co, int Ci, int H, int W);
+size_t aide_conv3x3_wgrad_wino_ws_bytes(int N, int Co, int Ci, int H, int W);
+int aide_conv3x3_wgrad_wino(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
+                            int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
+
 /* ---- ConvTranspose2d(k=2, s=2) (learned_bilinear=True up path) ---------------------------------
  * replaces nn.ConvTranspose2d: netblocks.py:12, UNet.py:7 */
 int aide_convT2x2_fwd(const float* x, int64_t x_bs, const float* w /*[Ci][Co][2][2]*/, const float* b,

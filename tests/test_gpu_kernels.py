@@ -240,3 +240,26 @@ def test_conv3x3_winograd_fwd_dgrad(dev, case):
         dx = torch.ones(n, ci, h, w, device=dev)
         ops.conv3x3_wino(dy.to(dev), ud, None, dx, accumulate=True)
         _close(dx, xr.grad + 1.0, what='wino dgrad accumulate %s' % (case,))
+
+
+@pytest.mark.parametrize('case', [(2, 64, 64, 32, 32), (1, 128, 64, 64, 64), (2, 64, 128, 16, 16), (1, 256, 256, 16, 16),
+                                  (1, 64, 128, 80, 80), (4, 512, 512, 16, 16), (1, 96, 160, 40, 24), (2, 64, 64, 6, 12)])
+def test_conv3x3_wgrad_winograd(dev, case):
+    """Winograd weight gradient (transposed F(2x2,3x3)) vs aten, incl. ragged widths and partial channel tiles."""
+    from aide_amd import ops
+    n, ci, co, h, w = case
+    assert ops.wgrad_wino_supported(co, ci, h, w)
+    g = torch.Generator().manual_seed(ci + 3 * co)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    dy = torch.randn(n, co, h, w, generator=g)
+    F.conv2d(x, wt, None, padding=1).backward(dy)
+    dw = torch.empty(co, ci, 3, 3, device=dev)
+    ops.conv3x3_wgrad_wino(dy.to(dev), x.to(dev), dw)
+    _close(dw, wt.grad, what='wino wgrad %s' % (case,))
+    # channel-slice operands (concatenation buffers)
+    big = torch.randn(n, ci + 32, h, w, generator=g)
+    wt2 = (torch.randn(co, ci, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    F.conv2d(big[:, 32:], wt2, None, padding=1).backward(dy)
+    ops.conv3x3_wgrad_wino(dy.to(dev), big.to(dev)[:, 32:], dw)
+    _close(dw, wt2.grad, what='wino wgrad slice %s' % (case,))

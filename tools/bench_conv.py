@@ -82,6 +82,12 @@ def main():
             ws = torch.empty(lib.aide_conv3x3_wgrad_ws_bytes(N, co, ci, h, h) // 4, device=dev)
             t = timeit(lambda: ops.conv3x3_wgrad(dy, x, dw, ws=ws))
             line += ' wgrad s%d %7.3f ms %6.1f TF' % (lib.aide_conv3x3_wgrad_splits(N, co, ci, h, h), t, gf / t)
+            if ops.wgrad_wino_supported(co, ci, h, h):
+                ws2 = torch.empty(lib.aide_conv3x3_wgrad_wino_ws_bytes(N, co, ci, h, h) // 4, device=dev)
+                t2 = timeit(lambda: ops.conv3x3_wgrad_wino(dy, x, dw, ws=ws2))
+                line += ' | WINO wgrad s%d %7.3f ms %6.1f TF' % (lib.aide_conv3x3_wgrad_wino_splits(N, co, ci, h, h), t2, gf / t2)
+                tot.setdefault('wino_wgrad', 0.0); totf.setdefault('wino_wgrad', 0.0)
+                tot['wino_wgrad'] += t2 * cnt; totf['wino_wgrad'] += gf * cnt
             tot['wgrad'] += t * cnt; totf['wgrad'] += gf * cnt
         print(line, flush=True)
     for k in tot:
