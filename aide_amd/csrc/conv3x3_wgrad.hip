@@ -590,14 +590,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(const WWArgs
         float* zn = ztb + (cur ^ 1) * WW_OP;
         float* vn = vb + (cur ^ 1) * WW_OP;
         set_chunk(c + 2);
-        float afA, bfA, afB, bfB;
+        // four rotating fragment sets, requested three slots before their MFMA (see conv3x3_winograd.hip)
+        float af0, bf0, af1, bf1, af2, bf2, af3, bf3;
         auto frag = [&](int st, float& af, float& bf) {
             const int p = st >> 2, s = st & 3;
             af = za[p * 512 + fa[s]];
             bf = va[p * 512 + fb[s]];
         };
         auto slot = [&](int st, float& afc, float& bfc, float& afn, float& bfn) {
-            if (st + 1 < 64) frag(st + 1, afn, bfn);
+            if (st + 3 < 64) frag(st + 3, afn, bfn);
             acc[st >> 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(afc, bfc, acc[st >> 2], 0, 0, 0);
             // schedule: 0..7 global fetches of raw[c+2]; D transform of item e at 20 e + {0..15 reads,
             // 16..19 columns} and outputs two per slot; Z transform in the gaps; 46: raw LDS free
@@ -627,11 +628,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(const WWArgs
             if (st >= 47 && st < 60) { put(2 * (st - 47)); put(2 * (st - 47) + 1); }
             __builtin_amdgcn_sched_barrier(0);
         };
-        frag(0, afA, bfA);
+        frag(0, af0, bf0); frag(1, af1, bf1); frag(2, af2, bf2);
 #pragma unroll
-        for (int st = 0; st < 64; st += 2) {
-            slot(st, afA, bfA, afB, bfB);
-            slot(st + 1, afB, bfB, afA, bfA);
+        for (int st = 0; st < 64; st += 4) {
+            slot(st, af0, bf0, af3, bf3);
+            slot(st + 1, af1, bf1, af0, bf0);
+            slot(st + 2, af2, bf2, af1, bf1);
+            slot(st + 3, af3, bf3, af2, bf2);
         }
         __syncthreads();
         cur ^= 1;

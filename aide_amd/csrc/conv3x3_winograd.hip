@@ -24,7 +24,7 @@ namespace {
 
 struct WinoArgs {
     const float* x;
-    const float* u;      // [Cin_pad][16][Cout]
+    const float* u;      // [Cin_pad/8][16][Cout][8]
     const float* bias;
     float* y;
     long x_bs, y_bs, split_stride;
@@ -35,10 +35,11 @@ struct WinoArgs {
 constexpr int WCK = 8;                    // input channels per stage
 constexpr int WTCO = 64;                  // output channels per workgroup
 constexpr int RROWS = 18, RRS = 24;       // raw halo tile: 18 rows, row = [3 pad][-1][0..15][16][3 pad]
-constexpr int RAWL = WCK * RROWS * RRS;   // 3456 floats
-constexpr int VL = 16 * WCK * 64;         // V[p][ci][tile]
-constexpr int UL = WCK * 16 * WTCO;       // U[ci][p][co]
-constexpr int WBUF = RAWL + VL + UL;      // one stage set (19840 floats = 79.4 KB)
+constexpr int RCS = RROWS * RRS + 8;      // raw channel stride 440 (= 24 mod 32: conflict-free patch reads)
+constexpr int RAWL = WCK * RCS;           // 3520 floats
+constexpr int VL = 16 * 64 * WCK;         // V[p][tile][ci]   (ci minor: one ds_read_b128 = 4 k-steps)
+constexpr int UL = 16 * WTCO * WCK;       // U[p][co][ci]
+constexpr int WBUF = RAWL + VL + UL;      // one stage set (19904 floats = 79.6 KB)
 
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];       // 2 * WBUF floats
@@ -65,82 +66,88 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     unsigned offB[NRB], ldsB[NRB], offC[NRC], ldsC[NRC], offU[NU];
 #pragma unroll
     for (int e = 0; e < NRB; ++e) {
-        const int q = tid + e * 256;
-        const int c = q / (RROWS * 4), rem = q - c * (RROWS * 4), r = rem / 4, s4 = rem - r * 4;
+        int q = tid + e * 256;
+        if (q >= WCK * RROWS * 4) q -= 256;                // spare lanes repeat a unit (same data, same slot):
+        const int c = q / (RROWS * 4), rem = q - c * (RROWS * 4), r = rem / 4, s4 = rem - r * 4;   // no predicate
         const int ih = h0 - 1 + r, iw = w0 + 4 * s4;
-        const bool ok = q < WCK * RROWS * 4 && ih >= 0 && ih < a.H && iw < a.W;
+        const bool ok = ih >= 0 && ih < a.H && iw < a.W;
         offB[e] = ok ? (unsigned)(c * HW + r * a.W + 1 + 4 * s4) * 4u : BUF_OOB;
-        ldsB[e] = q < WCK * RROWS * 4 ? (unsigned)(c * RROWS * RRS + r * RRS + 4 + 4 * s4) : 0xffffffffu;
+        ldsB[e] = (unsigned)(c * RCS + r * RRS + 4 + 4 * s4);
     }
 #pragma unroll
     for (int e = 0; e < NRC; ++e) {
-        const int q = tid + e * 256;
+        int q = tid + e * 256;
+        if (q >= WCK * RROWS * 2) q -= 256;
         const int c = q / (RROWS * 2), rem = q - c * (RROWS * 2), r = rem / 2, side = rem - r * 2;
         const int ih = h0 - 1 + r, iw = side ? w0 + 16 : w0 - 1;
-        const bool ok = q < WCK * RROWS * 2 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
         offC[e] = ok ? (unsigned)(c * HW + r * a.W + (side ? 17 : 0)) * 4u : BUF_OOB;
-        ldsC[e] = q < WCK * RROWS * 2 ? (unsigned)(c * RROWS * RRS + r * RRS + (side ? 20 : 3)) : 0xffffffffu;
+        ldsC[e] = (unsigned)(c * RCS + r * RRS + (side ? 20 : 3));
     }
 #pragma unroll
     for (int v = 0; v < NU; ++v) {
-        const int f = tid + v * 256;                       // float4 index inside the [CK*16][64] block
-        const int row = f / (WTCO / 4), c4 = f - row * (WTCO / 4);
-        offU[v] = (unsigned)(row * a.Cout + c4 * 4) * 4u;
+        const int f = tid + v * 256;                       // float4 index inside the [16][64 co][8 ci] block
+        const int pp = f / (WTCO * WCK / 4), w4 = f - pp * (WTCO * WCK / 4);
+        offU[v] = (unsigned)(pp * a.Cout * WCK + w4 * 4) * 4u;
     }
     const __amdgpu_buffer_rsrc_t xrs =
         make_rsrc(a.x + (long)n * a.x_bs + (long)h0 * a.W + w0 - (a.W + 1));
-    const __amdgpu_buffer_rsrc_t urs = make_rsrc(a.u + co0);
+    const __amdgpu_buffer_rsrc_t urs = make_rsrc(a.u + (long)co0 * WCK);
 
     f32x4 rb[NRB], ru[NU];
     float rc[NRC];
+    // Staging helpers carry NO vector-ALU work: the fp32 MFMA shares the VALU pipe, every v_* between
+    // two MFMAs costs ~5 cycles plus ~13 for the first one in a slot (tools/ubench/mfma_shadow.hip),
+    // whereas LDS, VMEM and scalar instructions issue in the MFMA's shadow.  Chunks past the end of
+    // this split re-read the last chunk (scalar min); their data is stored but never consumed.
     auto fetch_raw = [&](int l, int chunk) {               // l < NRB + NRC, compile-time
-        const bool has = chunk < c_end;
-        const unsigned xs = (unsigned)(chunk * WCK) * (unsigned)HW * 4u;
-        if (l < NRB) {
-            unsigned off = has ? offB[l] : BUF_OOB;
-            if (chunk * WCK + (tid + l * 256) / (RROWS * 4) >= a.Cin) off = BUF_OOB;
-            rb[l] = buf_load_f32x4(xrs, off, xs);
-        } else {
-            const int e = l - NRB;
-            unsigned off = has ? offC[e] : BUF_OOB;
-            if (chunk * WCK + (tid + e * 256) / (RROWS * 2) >= a.Cin) off = BUF_OOB;
-            rc[e] = buf_load_f32(xrs, off, xs);
-        }
+        const unsigned xs = (unsigned)(min(chunk, c_end - 1) * WCK) * (unsigned)HW * 4u;
+        if (l < NRB) rb[l] = buf_load_f32x4(xrs, offB[l], xs);
+        else rc[l - NRB] = buf_load_f32(xrs, offC[l - NRB], xs);
     };
     auto put_raw = [&](int l, float* raw) {
-        if (l < NRB) {
-            if (ldsB[l] != 0xffffffffu) *reinterpret_cast<f32x4*>(raw + ldsB[l]) = rb[l];
-        } else {
-            const int e = l - NRB;
-            if (ldsC[e] != 0xffffffffu) raw[ldsC[e]] = rc[e];
-        }
+        if (l < NRB) *reinterpret_cast<f32x4*>(raw + ldsB[l]) = rb[l];
+        else raw[ldsC[l - NRB]] = rc[l - NRB];
     };
     auto fetch_u = [&](int v, int chunk) {
-        const unsigned us = (unsigned)(chunk * WCK) * 16u * (unsigned)a.Cout * 4u;
-        ru[v] = buf_load_f32x4(urs, chunk < c_end ? offU[v] : BUF_OOB, us);
+        const unsigned us = (unsigned)min(chunk, c_end - 1) * 16u * (unsigned)a.Cout * (unsigned)WCK * 4u;
+        ru[v] = buf_load_f32x4(urs, offU[v], us);
     };
     auto put_u = [&](int v, float* ubuf) { *reinterpret_cast<f32x4*>(ubuf + (tid + v * 256) * 4) = ru[v]; };
 
-    // Input transform of item e (two items per thread and chunk): one (ci, tile) 4x4 patch -> 16 values.
-    // Split into single-instruction pieces so that the main loop can issue ONE piece per MFMA slot:
-    //   xf_read(e, i)  : td[e][i]  <- raw patch element i            (16 LDS reads)
-    //   xf_col(e, c)   : column c of B^T d                           (4 adds)
-    //   xf_out(e, o)   : output o = row r, column k of (B^T d) B     (1 add + 1 LDS store)
-    float td[2][16], tt[2][16];
-    auto xf_read = [&](int e, int i, const float* raw) {
-        const int item = tid + e * 256, ci = item >> 6, tile = item & 63, ti = tile >> 3, tj = tile & 7;
-        td[e][i] = raw[ci * RROWS * RRS + (2 * ti + i / 4) * RRS + 3 + 2 * tj + (i % 4)];
+    // Input transform B^T d B of the thread's two (ci, tile) items per chunk, 4x4 patch -> 16 values each.
+    // The two items live in the two halves of f32x2 registers, so every add is one v_pk_add_f32
+    // (32 VALU instructions per chunk instead of 64), and the adds are issued as ONE cluster:
+    //   xf_read(i)  : td[i] <- raw patch element i of both items        (2 LDS reads, no VALU)
+    //   xf_math()   : tt = B^T td ; to = tt B                           (32 packed adds)
+    //   xf_store(o) : V[o] <- to[o] for both items                      (2 LDS stores, no VALU)
+    // item e of this thread: input channel ci = lane & 7, tile (ti, tj) = (2 wid + e, lane >> 3): a wave
+    // writes 64 consecutive floats of V[p][tile][ci] per position (conflict-free) and reads raw patches
+    // at channel stride 440 (conflict-free)
+    f32x2 td[16], to[16];
+    const int xci = lane & 7, xtj = lane >> 3;
+    const int xr_off = xci * RCS + 4 * wid * RRS + 3 + 2 * xtj;           // item 0; item 1 is 2 rows down
+    const int xw_off = (2 * wid * 8 + xtj) * WCK + xci;                   // item 0; item 1 is 8 tiles on
+    auto xf_read = [&](int i, const float* raw) {
+        td[i].x = raw[xr_off + (i / 4) * RRS + (i % 4)];
+        td[i].y = raw[xr_off + (2 + i / 4) * RRS + (i % 4)];
     };
-    auto xf_col = [&](int e, int c) {
-        const float d0 = td[e][c], d1 = td[e][4 + c], d2 = td[e][8 + c], d3 = td[e][12 + c];
-        tt[e][c] = d0 - d2; tt[e][4 + c] = d1 + d2; tt[e][8 + c] = d2 - d1; tt[e][12 + c] = d1 - d3;
+    auto xf_math = [&]() {
+        f32x2 tt[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            tt[c] = td[c] - td[8 + c]; tt[4 + c] = td[4 + c] + td[8 + c];
+            tt[8 + c] = td[8 + c] - td[4 + c]; tt[12 + c] = td[4 + c] - td[12 + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            to[r * 4] = tt[r * 4] - tt[r * 4 + 2]; to[r * 4 + 1] = tt[r * 4 + 1] + tt[r * 4 + 2];
+            to[r * 4 + 2] = tt[r * 4 + 2] - tt[r * 4 + 1]; to[r * 4 + 3] = tt[r * 4 + 1] - tt[r * 4 + 3];
+        }
     };
-    auto xf_out = [&](int e, int o, float* vbuf) {
-        const int item = tid + e * 256, ci = item >> 6, tile = item & 63;
-        const int r = o / 4, k = o % 4;
-        const float t0 = tt[e][r * 4], t1 = tt[e][r * 4 + 1], t2 = tt[e][r * 4 + 2], t3 = tt[e][r * 4 + 3];
-        const float v = k == 0 ? t0 - t2 : k == 1 ? t1 + t2 : k == 2 ? t2 - t1 : t1 - t3;
-        vbuf[o * WCK * 64 + ci * 64 + tile] = v;
+    auto xf_store = [&](int o, float* vbuf) {
+        vbuf[o * 64 * WCK + xw_off] = to[o].x;
+        vbuf[o * 64 * WCK + xw_off + 8 * WCK] = to[o].y;
     };
 
     f32x16 acc[16];
@@ -164,14 +171,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     for (int l = 0; l < NRB + NRC; ++l) fetch_raw(l, c_begin + 1);
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int i = 0; i < 16; ++i) xf_read(i, set0);
+    xf_math();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) xf_read(e, i, set0);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) xf_col(e, c);
-#pragma unroll
-        for (int o = 0; o < 16; ++o) xf_out(e, o, set0 + RAWL);
-    }
+    for (int o = 0; o < 16; ++o) xf_store(o, set0 + RAWL);
 #pragma unroll
     for (int l = 0; l < NRB + NRC; ++l) put_raw(l, set1);
     __syncthreads();
@@ -185,44 +188,57 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         float* sc = cur ? set1 : set0;
         float* sn = cur ? set0 : set1;
-        const float* la = sc + RAWL + VL + half * 16 * WTCO + wave_m * 32 + j;     // U[ci][p][co]
-        const float* lb = sc + RAWL + half * 64 + wave_n * 32 + j;                 // V[p][ci][tile]
-        constexpr int STEPS = 16 * (WCK / 2);              // (position, channel pair) k-steps = 64
-        float afA, bfA, afB, bfB;
-        auto frag = [&](int st, float& af, float& bf) {
-            const int p = st / (WCK / 2), q = st % (WCK / 2);          // compile-time after unrolling
-            af = la[(2 * q) * 16 * WTCO + p * WTCO];
-            bf = lb[p * WCK * 64 + (2 * q) * 64];
+        const float* la = sc + RAWL + VL + (wave_m * 32 + j) * WCK + half * 4;     // U[p][co][ci]
+        const float* lb = sc + RAWL + (wave_n * 32 + j) * WCK + half * 4;          // V[p][tile][ci]
+        constexpr int STEPS = 16 * (WCK / 2);              // 16 positions x 4 channel pairs = 64 MFMAs
+        // K order inside a chunk: step q pairs channel q (lanes 0-31) with channel q+4 (lanes 32-63), so
+        // one ds_read_b128 per operand and position feeds four MFMAs (was: two ds_read_b32 per MFMA).
+        // Two rotating fragment sets: position p+1 is requested while the four MFMAs of p run.
+        // Consecutive MFMAs must not share an accumulator: with other instructions issued between
+        // them, two dependent v_mfma_f32_32x32x2_f32 cost +43 cycles per pair (MI355X_MICROARCH.md,
+        // "extra issue slot between two MFMAs on the SAME accumulator").  Positions are therefore
+        // processed in pairs (p, p+1 alternating), which puts 128 cycles between dependent MFMAs.
+        f32x4 a0A, b0A, a1A, b1A, a0B, b0B, a1B, b1B;
+        auto frag = [&](int p, f32x4& af, f32x4& bf) {
+            af = *reinterpret_cast<const f32x4*>(la + p * WTCO * WCK);
+            bf = *reinterpret_cast<const f32x4*>(lb + p * 64 * WCK);
         };
-        auto slot = [&](int st, float& afc, float& bfc, float& afn, float& bfn) {
-            if (st + 1 < STEPS) frag(st + 1, afn, bfn);
-            const int p = st / (WCK / 2);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(afc, bfc, acc[p], 0, 0, 0);
-            // staging schedule (compile-time, at most ~4 light instructions per 64-cycle MFMA slot):
+        auto slot = [&](int st, const f32x4& a0c, const f32x4& b0c, const f32x4& a1c, const f32x4& b1c,
+                        f32x4& a0n, f32x4& b0n, f32x4& a1n, f32x4& b1n) {
+            const int g2 = st >> 3, k = st & 7, q = k >> 1;
+            if (k == 0 && g2 + 1 < 8) { frag(2 * g2 + 2, a0n, b0n); frag(2 * g2 + 3, a1n, b1n); }
+            if (k & 1) acc[2 * g2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1c[q], b1c[q], acc[2 * g2 + 1], 0, 0, 0);
+            else acc[2 * g2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0c[q], b0c[q], acc[2 * g2], 0, 0, 0);
+            // staging schedule (compile-time): only slot 24 carries vector-ALU work
             //   slots  0..12 : global fetches of U[chunk+1] (8) and raw[chunk+2] (5)
-            //   item e at base S = 30 e : S..S+15 patch reads, S+16..S+19 column transforms,
-            //                             S+20..S+27 two outputs (add + LDS store) per slot
-            //   slots 48..55 : LDS stores of U[chunk+1];  56..60 : LDS stores of raw[chunk+2]
+            //   slots  4..19 : patch reads (2 LDS reads each);  slot 24 : the 32 packed transform adds
+            //   slots 26..41 : V stores (2 each);  44..51 : U[chunk+1] stores;  52..56 : raw[chunk+2] stores
+#ifndef AIDE_PROBE_WNOFETCH
             if (st < NU) fetch_u(st, chunk + 1);
             else if (st < NU + NRB + NRC) fetch_raw(st - NU, chunk + 2);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int rel = st - 30 * e;
-                if (rel >= 0 && rel < 16) xf_read(e, rel, sn);
-                else if (rel >= 16 && rel < 20) xf_col(e, rel - 16);
-                else if (rel >= 20 && rel < 28) { xf_out(e, 2 * (rel - 20), sn + RAWL); xf_out(e, 2 * (rel - 20) + 1, sn + RAWL); }
-            }
-            if (st >= 48 && st < 48 + NU) put_u(st - 48, sn + RAWL + VL);
-            if (st >= 56 && st < 56 + NRB + NRC) put_raw(st - 56, sc);
+#endif
+#ifndef AIDE_PROBE_WNOXF
+            if (st >= 4 && st < 20) xf_read(st - 4, sn);
+            if (st == 24) xf_math();
+            if (st >= 26 && st < 42) xf_store(st - 26, sn + RAWL);
+#endif
+#ifndef AIDE_PROBE_WNOFETCH
+            if (st >= 44 && st < 44 + NU) put_u(st - 44, sn + RAWL + VL);
+            if (st >= 52 && st < 52 + NRB + NRC) put_raw(st - 52, sc);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         };
-        frag(0, afA, bfA);
+        frag(0, a0A, b0A); frag(1, a1A, b1A);
 #pragma unroll
-        for (int st = 0; st < STEPS; st += 2) {
-            slot(st, afA, bfA, afB, bfB);
-            slot(st + 1, afB, bfB, afA, bfA);
+        for (int st = 0; st < STEPS; st += 16) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) slot(st + k, a0A, b0A, a1A, b1A, a0B, b0B, a1B, b1B);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) slot(st + 8 + k, a0B, b0B, a1B, b1B, a0A, b0A, a1A, b1A);
         }
+#ifndef AIDE_PROBE_WNOBAR
         __syncthreads();
+#endif
         cur ^= 1;
     }
 
@@ -274,7 +290,7 @@ __global__ void wino_splitk_reduce_kernel(const float* __restrict__ slabs, long 
     }
 }
 
-// w[Co][Ci][3][3] -> uf[Ci_pad][16][Co] = G g G^T (forward) and ud[Co_pad][16][Ci] for the rotated,
+// w[Co][Ci][3][3] -> uf[Ci_pad/8][16][Co][8] = G g G^T (forward) and ud[Co_pad/8][16][Ci][8] for the rotated,
 // channel-transposed filter (dgrad).  One launch for all layers (descriptor table, like Adam).
 struct WinoPackDesc {
     const float* w; float* uf; float* ud;
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(256) void wino_pack_multi_kernel(const WinoPackDesc
         for (int t = 0; t < 9; ++t) g[t] = (ci < d.Ci) ? d.w[((long)co * d.Ci + ci) * 9 + t] : 0.f;
         wino_g(g, u);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) d.uf[((long)ci * 16 + p) * d.Co + co] = u[p];
+        for (int p = 0; p < 16; ++p) d.uf[((((long)(ci >> 3) * 16 + p) * d.Co + co) << 3) + (ci & 7)] = u[p];
     } else if (i < nf + nd) {
         const long k = i - nf;
         const int ci = (int)(k % d.Ci), co = (int)(k / d.Ci);
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(256) void wino_pack_multi_kernel(const WinoPackDesc
         for (int t = 0; t < 9; ++t) g[t] = (co < d.Co) ? d.w[((long)co * d.Ci + ci) * 9 + (8 - t)] : 0.f;
         wino_g(g, u);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) d.ud[((long)co * 16 + p) * d.Ci + ci] = u[p];
+        for (int p = 0; p < 16; ++p) d.ud[((((long)(co >> 3) * 16 + p) * d.Ci + ci) << 3) + (co & 7)] = u[p];
     }
 }
 
