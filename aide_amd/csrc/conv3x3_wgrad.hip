@@ -494,21 +494,32 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(const WWArgs
         dso = (unsigned)((long)n * g.dz_bs + th0 * g.W + tw0) * 4u;
         aso = (unsigned)((long)n * g.a_bs + th0 * g.W + tw0) * 4u;
     };
+    // The fp32 MFMA shares the vector-ALU pipe (tools/ubench/mfma_shadow.hip): VALU instructions between
+    // MFMAs are never hidden (~5 cycles each + ~13 for the first in a slot) while LDS / VMEM / scalar
+    // instructions are.  So per chunk ALL vector-ALU work is issued in two clusters: the halo selects of
+    // the eight fetch offsets (prep) and the transform adds (xf_math, packed: the thread's two items sit
+    // in the halves of f32x2 registers -> v_pk_add_f32).
     f32x4 rDi[4], rZ[2];
     float rDe[2];
-    auto fetch = [&](int l) {                  // 8 global loads per thread and chunk
-        if (l < 4) {
+    unsigned vo[8];
+    auto prep = [&]() {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
             const int ih = th0 - 1 + (int)rowDi[l];
-            const bool ok = ih >= 0 && ih < g.H && tw0 + (int)colDi[l] < g.W;
-            rDi[l] = buf_load_f32x4(ars, ok ? offDi[l] : BUF_OOB, aso);
-        } else if (l < 6) {
-            const int e = l - 4, ih = th0 - 1 + (int)rowDe[e], iw = sideDe[e] ? tw0 + 16 : tw0 - 1;
-            const bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-            rDe[e] = buf_load_f32(ars, ok ? offDe[e] : BUF_OOB, aso);
-        } else {
-            const int e = l - 6;
-            rZ[e] = buf_load_f32x4(drs, (tw0 + (int)colZ[e] < g.W) ? offZ[e] : BUF_OOB, dso);
+            vo[l] = (ih >= 0 && ih < g.H && tw0 + (int)colDi[l] < g.W) ? offDi[l] : BUF_OOB;
         }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ih = th0 - 1 + (int)rowDe[e], iw = sideDe[e] ? tw0 + 16 : tw0 - 1;
+            vo[4 + e] = (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) ? offDe[e] : BUF_OOB;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) vo[6 + e] = (tw0 + (int)colZ[e] < g.W) ? offZ[e] : BUF_OOB;
+    };
+    auto fetch = [&](int l) {                  // 8 global loads per thread and chunk
+        if (l < 4) rDi[l] = buf_load_f32x4(ars, vo[l], aso);
+        else if (l < 6) rDe[l - 4] = buf_load_f32(ars, vo[l], aso);
+        else rZ[l - 6] = buf_load_f32x4(drs, vo[l], dso);
     };
     auto put = [&](int w) {                    // 26 LDS stores per thread and chunk
         if (w < 16) rawD[ldsDi[w >> 2] + (w & 3)] = rDi[w >> 2][w & 3];
@@ -516,30 +527,44 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(const WWArgs
         else rawZ[ldsZ[(w - 18) >> 2] + ((w - 18) & 3)] = rZ[(w - 18) >> 2][(w - 18) & 3];
     };
 
-    // transforms: item e in {0,1} -> tile = wid + 4 e of the chunk, channel = lane
+    // transforms: item e in {0,1} (register half) -> tile = wid + 4 e of the chunk, channel = lane.
+    // Z side: rows of A Z are (z0, z0+z1, z0-z1, -z1) and columns likewise; the two negations are NOT
+    // applied here - they flip the sign of whole positions (p >= 12, p % 4 == 3) and are folded into the
+    // output transform instead.
     const int swz = (lane >> 2) & 7;
-    float td[2][16], tt[2][16], tz[2][4], tu[2][8];
-    auto d_read = [&](int e, int i) { td[e][i] = rawD[lane * WW_DSTR + (i >> 2) * 18 + 2 * (wid + 4 * e) + (i & 3)]; };
-    auto d_col = [&](int e, int c) {
-        const float d0 = td[e][c], d1 = td[e][4 + c], d2 = td[e][8 + c], d3 = td[e][12 + c];
-        tt[e][c] = d0 - d2; tt[e][4 + c] = d1 + d2; tt[e][8 + c] = d2 - d1; tt[e][12 + c] = d1 - d3;
+    const int rd0 = lane * WW_DSTR + 2 * wid, rz0 = lane * WW_ZSTR + 2 * wid;
+    const int ws0 = lane * 8 + (wid ^ swz), ws1 = lane * 8 + ((wid + 4) ^ swz);
+    f32x2 td[16], to[16], tz[4], zo[16];
+    auto d_read = [&](int i) {
+        td[i].x = rawD[rd0 + (i >> 2) * 18 + (i & 3)];
+        td[i].y = rawD[rd0 + (i >> 2) * 18 + (i & 3) + 8];
     };
-    auto d_out = [&](int e, int o, float* vbuf) {
-        const int r = o >> 2, k = o & 3;
-        const float t0 = tt[e][r * 4], t1 = tt[e][r * 4 + 1], t2 = tt[e][r * 4 + 2], t3 = tt[e][r * 4 + 3];
-        vbuf[o * 512 + lane * 8 + ((wid + 4 * e) ^ swz)] = k == 0 ? t0 - t2 : k == 1 ? t1 + t2 : k == 2 ? t2 - t1 : t1 - t3;
+    auto z_read = [&](int i) {
+        tz[i].x = rawZ[rz0 + (i >> 1) * 16 + (i & 1)];
+        tz[i].y = rawZ[rz0 + (i >> 1) * 16 + (i & 1) + 8];
     };
-    auto z_read = [&](int e, int i) { tz[e][i] = rawZ[lane * WW_ZSTR + (i >> 1) * 16 + 2 * (wid + 4 * e) + (i & 1)]; };
-    auto z_col = [&](int e) {                  // A Z : rows (z0, z0+z1, z0-z1, -z1) for both columns
-        const float a0 = tz[e][0], a1 = tz[e][1], b0 = tz[e][2], b1 = tz[e][3];
-        tu[e][0] = a0; tu[e][1] = a1; tu[e][2] = a0 + b0; tu[e][3] = a1 + b1;
-        tu[e][4] = a0 - b0; tu[e][5] = a1 - b1; tu[e][6] = -b0; tu[e][7] = -b1;
+    auto xf_math = [&]() {
+        f32x2 tt[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            tt[c] = td[c] - td[8 + c]; tt[4 + c] = td[4 + c] + td[8 + c];
+            tt[8 + c] = td[8 + c] - td[4 + c]; tt[12 + c] = td[4 + c] - td[12 + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            to[r * 4] = tt[r * 4] - tt[r * 4 + 2]; to[r * 4 + 1] = tt[r * 4 + 1] + tt[r * 4 + 2];
+            to[r * 4 + 2] = tt[r * 4 + 2] - tt[r * 4 + 1]; to[r * 4 + 3] = tt[r * 4 + 1] - tt[r * 4 + 3];
+        }
+        // (z rows) u[0] = (a0, a1), u[1] = (a0 + b0, a1 + b1), u[2] = (a0 - b0, a1 - b1), u[3] = (b0, b1) [sign folded]
+        const f32x2 u0[4] = {tz[0], tz[0] + tz[2], tz[0] - tz[2], tz[2]};
+        const f32x2 u1[4] = {tz[1], tz[1] + tz[3], tz[1] - tz[3], tz[3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            zo[r * 4] = u0[r]; zo[r * 4 + 1] = u0[r] + u1[r]; zo[r * 4 + 2] = u0[r] - u1[r]; zo[r * 4 + 3] = u1[r];
+        }
     };
-    auto z_out = [&](int e, int o, float* zbuf) {
-        const int r = o >> 2, k = o & 3;
-        const float u0 = tu[e][2 * r], u1 = tu[e][2 * r + 1];
-        zbuf[o * 512 + lane * 8 + ((wid + 4 * e) ^ swz)] = k == 0 ? u0 : k == 1 ? u0 + u1 : k == 2 ? u0 - u1 : -u1;
-    };
+    auto d_store = [&](int o, float* vbuf) { vbuf[o * 512 + ws0] = to[o].x; vbuf[o * 512 + ws1] = to[o].y; };
+    auto z_store = [&](int o, float* zbuf) { zbuf[o * 512 + ws0] = zo[o].x; zbuf[o * 512 + ws1] = zo[o].y; };
 
     f32x16 acc[16];
 #pragma unroll
@@ -556,28 +581,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(const WWArgs
 
     // ---- prologue ----
     set_chunk(c_begin);
+    prep();
 #pragma unroll
     for (int l = 0; l < 8; ++l) fetch(l);
 #pragma unroll
     for (int w = 0; w < 26; ++w) put(w);
     set_chunk(c_begin + 1);
+    prep();
 #pragma unroll
     for (int l = 0; l < 8; ++l) fetch(l);
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int i = 0; i < 16; ++i) d_read(i);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) d_read(e, i);
+    for (int i = 0; i < 4; ++i) z_read(i);
+    xf_math();
 #pragma unroll
-        for (int c = 0; c < 4; ++c) d_col(e, c);
-#pragma unroll
-        for (int o = 0; o < 16; ++o) d_out(e, o, vb);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z_read(e, i);
-        z_col(e);
-#pragma unroll
-        for (int o = 0; o < 16; ++o) z_out(e, o, ztb);
-    }
+    for (int o = 0; o < 16; ++o) { d_store(o, vb); z_store(o, ztb); }
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < 26; ++w) put(w);
@@ -600,32 +620,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(const WWArgs
         auto slot = [&](int st, float& afc, float& bfc, float& afn, float& bfn) {
             if (st + 3 < 64) frag(st + 3, afn, bfn);
             acc[st >> 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(afc, bfc, acc[st >> 2], 0, 0, 0);
-            // schedule: 0..7 global fetches of raw[c+2]; D transform of item e at 20 e + {0..15 reads,
-            // 16..19 columns} and outputs two per slot; Z transform in the gaps; 46: raw LDS free
-            // (mid barrier) ; 47..59 raw[c+2] stores (two per slot)
+            // schedule (vector-ALU work only in slots 0 and 20):
+            //    0      halo selects of the fetch offsets;  0..7 global fetches of raw[c+2]
+            //    1..16  input patch reads, 17..18 dz tile reads (both items each)
+            //   20      all transform adds;   21 barrier: the raw LDS area is free
+            //   22..37  V stores, 38..53 ZT stores (both items each), 28..53 raw[c+2] stores
+            if (st == 0) prep();
             if (st < 8) fetch(st);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int rel = st - 14 * e;
-                if (rel >= 0 && rel < 8) { d_read(e, 2 * rel); d_read(e, 2 * rel + 1); }
-                else if (rel >= 8 && rel < 10) { d_col(e, 2 * (rel - 8)); d_col(e, 2 * (rel - 8) + 1); }
-                else if (rel >= 10 && rel < 14) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) d_out(e, 4 * (rel - 10) + k, vn);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int rel = st - 28 - 8 * e;
-                if (rel == 0) { z_read(e, 0); z_read(e, 1); z_read(e, 2); z_read(e, 3); }
-                else if (rel == 1) z_col(e);
-                else if (rel >= 2 && rel < 6) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) z_out(e, 4 * (rel - 2) + k, zn);
-                }
-            }
-            if (st == 46) __syncthreads();
-            if (st >= 47 && st < 60) { put(2 * (st - 47)); put(2 * (st - 47) + 1); }
+            if (st >= 1 && st < 17) d_read(st - 1);
+            if (st == 17 || st == 18) { z_read(2 * (st - 17)); z_read(2 * (st - 17) + 1); }
+            if (st == 20) xf_math();
+            if (st == 21) __syncthreads();
+            if (st >= 22 && st < 38) d_store(st - 22, vn);
+            if (st >= 38 && st < 54) z_store(st - 38, zn);
+            if (st >= 28 && st < 54) put(st - 28);
             __builtin_amdgcn_sched_barrier(0);
         };
         frag(0, af0, bf0); frag(1, af1, bf1); frag(2, af2, bf2);
@@ -649,7 +657,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(const WWArgs
         float t[3][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float m0 = acc[c][r], m1 = acc[4 + c][r], m2 = acc[8 + c][r], m3 = acc[12 + c][r];
+            // positions with p % 4 == 3 and p >= 12 carry a folded sign (see the Z transform above)
+            const float sg = c == 3 ? -1.0f : 1.0f;
+            const float m0 = sg * acc[c][r], m1 = sg * acc[4 + c][r], m2 = sg * acc[8 + c][r], m3 = -sg * acc[12 + c][r];
             const float hs = 0.5f * (m1 + m2), hd = 0.5f * (m1 - m2);
             t[0][c] = m0 + hs; t[1][c] = hd; t[2][c] = hs + m3;
         }

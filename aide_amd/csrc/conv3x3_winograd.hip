@@ -11,7 +11,7 @@
 // GEMM  M[p][co][tile] += U[p][ci][co] * V[p][ci][tile]  on v_mfma_f32_32x32x2_f32.
 //   * workgroup = 4 waves = 64 output channels x 64 tiles (8x8 tiles = 16x16 pixels); a wave owns
 //     32 co x 32 tiles x 16 positions = 16 accumulators (256 registers, one wave per SIMD);
-//   * filters arrive pre-transformed (aide_conv3x3_wino_pack: U[ci][16][co]); the input transform runs
+//   * filters arrive pre-transformed (aide_conv3x3_wino_pack_multi: U[ci/8][16][co][8 ci]); the input transform runs
 //     inside the kernel: raw halo tile -> LDS, each lane turns one (ci, tile) 4x4 patch into 16 values
 //     (32 adds) and scatters them to V[p][ci][tile]; the output transform (24 adds per 2x2) is
 //     per-lane on the accumulators, no cross-lane traffic;
@@ -312,7 +312,14 @@ __device__ __forceinline__ void wino_g(const float g[9], float u[16]) {
     }
 }
 
+// One workgroup transforms a 32 co x 32 ci filter tile.  The 9-tap filters are read as 32 contiguous
+// 1152-byte runs into LDS; every thread computes G g G^T for one (co, ci) pair per group and the 16
+// transformed values go back through LDS so that global stores are contiguous 1 KB runs of the packed
+// layouts  uf [ci/8][16][Co][8 ci]  and  ud [co/8][16][Ci][8 co]  (4 groups of 8 channels each).
+constexpr int WP_T = 32, WP_ROW = WP_T * 9 + 1;          // odd LDS row stride
 __global__ __launch_bounds__(256) void wino_pack_multi_kernel(const WinoPackDesc* __restrict__ descs, int n) {
+    __shared__ float wt[WP_T * WP_ROW];                  // [co][ci * 9 + tap]
+    __shared__ __attribute__((aligned(16))) float ot[16 * 256];   // [p][256 pairs]
     const long blk = blockIdx.x;
     int lo = 0, hi = n - 1;
     while (lo < hi) {
@@ -320,25 +327,48 @@ __global__ __launch_bounds__(256) void wino_pack_multi_kernel(const WinoPackDesc
         if (descs[mid].block_start <= blk) lo = mid; else hi = mid - 1;
     }
     const WinoPackDesc d = descs[lo];
-    // one thread per (padded ci, co) pair of the forward pack, then per (padded co, ci) of the dgrad pack
-    const long nf = d.uf ? (long)d.ci_pad * d.Co : 0, nd = d.ud ? (long)d.co_pad * d.Ci : 0;
-    const long i = (blk - d.block_start) * 256 + threadIdx.x;
+    const int tid = threadIdx.x;
+    const int tiles_ci = (d.Ci + WP_T - 1) / WP_T;
+    const int tb = (int)(blk - d.block_start);
+    const int co0 = (tb / tiles_ci) * WP_T, ci0 = (tb % tiles_ci) * WP_T;
+    const int nci = min(WP_T, d.Ci - ci0);               // valid input channels of this tile
+    // ---- filters -> LDS (zero outside [Co] x [Ci]) ----
+    for (int e = tid; e < WP_T * WP_T * 9; e += 256) {
+        const int co = e / (WP_T * 9), r = e - co * (WP_T * 9);
+        float v = 0.f;
+        if (co0 + co < d.Co && r < nci * 9) v = d.w[((long)(co0 + co) * d.Ci + ci0) * 9 + r];
+        wt[co * WP_ROW + r] = v;
+    }
+    __syncthreads();
     float g[9], u[16];
-    if (i < nf) {
-        const int co = (int)(i % d.Co), ci = (int)(i / d.Co);
+    const int lo3 = tid & 7, hi5 = tid >> 3;
+    for (int grp = 0; grp < 8; ++grp) {
+        const bool fwd = grp < 4;
+        const int q = grp & 3;
+        float* dst = fwd ? d.uf : d.ud;
+        if (dst == nullptr) continue;                    // uniform
+        // forward: 8 ci (group q) x 32 co, pair = (co = hi5, ci = 8q + lo3); dgrad: 8 co x 32 ci
+        const int co = fwd ? hi5 : 8 * q + lo3, ci = fwd ? 8 * q + lo3 : hi5;
+        const bool live = fwd ? (ci0 + 8 * q < d.ci_pad) : (co0 + 8 * q < d.co_pad);   // uniform
+        if (!live) continue;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) g[t] = (ci < d.Ci) ? d.w[((long)co * d.Ci + ci) * 9 + t] : 0.f;
+        for (int t = 0; t < 9; ++t) g[t] = wt[co * WP_ROW + ci * 9 + (fwd ? t : 8 - t)];
         wino_g(g, u);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) d.uf[((((long)(ci >> 3) * 16 + p) * d.Co + co) << 3) + (ci & 7)] = u[p];
-    } else if (i < nf + nd) {
-        const long k = i - nf;
-        const int ci = (int)(k % d.Ci), co = (int)(k / d.Ci);
+        for (int p = 0; p < 16; ++p) ot[p * 256 + tid] = u[p];
+        __syncthreads();
+        // 16 runs of 256 floats: run p starts at ((group * 16 + p) * C + c0) * 8, C = Co (fwd) / Ci (dgrad)
+        const int C = fwd ? d.Co : d.Ci, c0 = fwd ? co0 : ci0;
+        const long gbase = (long)((fwd ? ci0 : co0) / 8 + q) * 16;
+        const int nrun = min(WP_T, C - c0) * 8;          // floats per run that exist (multiple of 8)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) g[t] = (co < d.Co) ? d.w[((long)co * d.Ci + ci) * 9 + (8 - t)] : 0.f;
-        wino_g(g, u);
-#pragma unroll
-        for (int p = 0; p < 16; ++p) d.ud[((((long)(co >> 3) * 16 + p) * d.Ci + ci) << 3) + (co & 7)] = u[p];
+        for (int k = 0; k < 4; ++k) {
+            const int f = tid + k * 256, p = f >> 6, x4 = (f & 63) * 4;
+            if (x4 < nrun)
+                *reinterpret_cast<f32x4*>(dst + ((gbase + p) * C + c0) * 8 + x4) =
+                    *reinterpret_cast<const f32x4*>(ot + p * 256 + x4);
+        }
+        __syncthreads();
     }
 }
 
@@ -362,6 +392,10 @@ int aide_conv3x3_wino_splitk(int N, int Cin, int H, int W, int Cout) {
 
 // descs: DEVICE array of n 48-byte records {w, uf, ud (or 0), int32 Co, Ci, ci_pad, co_pad, int64
 // block_start}; blocks per tensor = ceil((ci_pad*Co + co_pad*Ci) / 256).
+int aide_conv3x3_wino_pack_blocks(int Co, int Ci) {
+    return ((Co + WP_T - 1) / WP_T) * ((Ci + WP_T - 1) / WP_T);
+}
+
 int aide_conv3x3_wino_pack_multi(const void* descs, int n, int64_t total_blocks, hipStream_t stream) {
     if (!descs || n <= 0 || total_blocks <= 0) return AIDE_ERR_ARG;
     static_assert(sizeof(WinoPackDesc) == 48, "descriptor layout");
@@ -370,7 +404,7 @@ int aide_conv3x3_wino_pack_multi(const void* descs, int n, int64_t total_blocks,
     return aide_launch_status();
 }
 
-// y (+)= conv3x3(x) with Winograd-packed filters u [Cin_pad][16][Cout] (forward pack, or the dgrad pack
+// y (+)= conv3x3(x) with Winograd-packed filters u [Cin_pad/8][16][Cout][8] (forward pack, or the dgrad pack
 // with Cin/Cout swapped by the caller).  splitk from aide_conv3x3_wino_splitk (or 1); ws: split-K slabs.
 int aide_conv3x3_wino(const float* x, int64_t x_bs, const float* u, const float* bias, float* y,
                       int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,

@@ -73,12 +73,10 @@ USE_WINOGRAD_DGRAD = [True]    # ... for the dgrad direction only
 
 
 def use_winograd(n, cin, h, w, cout):
-    """Static (deterministic) choice between the Winograd and the direct conv kernel, from the layer
-    sweep in profiles/: Winograd wins whenever it is supported except for the channel-expanding layers at
-    small resolutions, where its 64co x 64-tile workgroups leave too few workgroups / too much split-K."""
-    if not USE_WINOGRAD[0] or not lib.aide_conv3x3_wino_supported(cin, h, w, cout):
-        return False
-    return cin >= cout or h * w >= 128 * 128
+    """Static (deterministic) choice between the Winograd and the direct conv kernel: the layer sweep
+    (tools/bench_conv.py all) has Winograd ahead on every layer shape it supports (1.2x-1.9x; the one
+    exception, 64->128 @64x64 forward, loses 4 us), so it is used wherever it is supported."""
+    return bool(USE_WINOGRAD[0] and lib.aide_conv3x3_wino_supported(cin, h, w, cout))
 
 
 class _Cover(object):

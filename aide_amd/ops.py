@@ -275,11 +275,10 @@ def wino_pack_table(entries, device):
     rec, start = b'', 0
     for w, uf, ud in entries:
         co, ci = w.shape[0], w.shape[1]
-        elems = (uf.shape[0] * co if uf is not None else 0) + (ud.shape[0] * ci if ud is not None else 0)
         rec += struct.pack('<QQQiiiiq', w.data_ptr(), uf.data_ptr() if uf is not None else 0,
                            ud.data_ptr() if ud is not None else 0, co, ci,
                            uf.shape[0] if uf is not None else 0, ud.shape[0] if ud is not None else 0, start)
-        start += (elems + 255) // 256
+        start += lib.aide_conv3x3_wino_pack_blocks(co, ci)
     return torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(device), len(entries), start
 
 

@@ -37,9 +37,12 @@ int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, c
                        float* y, int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate,
                        int plan, float* ws, aide_stream_t stream);   /* forward and dgrad */
 /* Winograd F(2x2,3x3) variant of the same convolution (forward / dgrad) for even H, W % 4 == 0,
- * Cout % 64 == 0, Cin % 8 == 0.  Filters are pre-transformed: uf [ci_pad][16][Co], ud [co_pad][16][Ci]. */
+ * Cout % 64 == 0, Cin % 8 == 0.  Filters are pre-transformed (G g G^T), channel-blocked by 8:
+ * uf [ci_pad/8][16][Co][8 ci], ud [co_pad/8][16][Ci][8 co] (the tensors are allocated as [pad][16][C]). */
 int aide_conv3x3_wino_supported(int Cin, int H, int W, int Cout);
 int aide_conv3x3_wino_splitk(int N, int Cin, int H, int W, int Cout);
+/* descs as above with {w, uf, ud}; an entry occupies aide_conv3x3_wino_pack_blocks(Co, Ci) workgroups */
+int aide_conv3x3_wino_pack_blocks(int Co, int Ci);
 int aide_conv3x3_wino_pack_multi(const void* descs, int n, int64_t total_blocks, aide_stream_t stream);
 int aide_conv3x3_wino(const float* x, int64_t x_bs, const float* u, const float* bias, float* y,
                       int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,

@@ -31,7 +31,12 @@ def test_comparison_three_steps(dev):
         loss.backward()
         opt.step()
         losses.append(loss.item())
-    assert np.max(np.abs(np.array(losses) - fx['losses']) / fx['losses']) < 1e-3, (losses, fx['losses'])
+    # Tolerance per step: this 2x3x32x32 fixture normalises over as few as 8 values per channel at the
+    # bottom level and Adam's first steps are ~lr*sign(g), so rounding differences are amplified step by
+    # step.  tests/test_oracle_golden.py::test_trajectory_noise_floor measures it on the oracle itself:
+    # one-ulp (1e-7 relative) weight noise moves its losses by up to 2e-4 at step 2 and 1.5e-3 at step 3.
+    rel = np.abs(np.array(losses) - fx['losses']) / fx['losses']
+    assert rel[0] < 1e-5 and rel[1] < 5e-4 and rel[2] < 3e-3, (losses, fx['losses'])
     assert losses[0] > losses[1] > losses[2]
     hw = net.last_conv1.weight.detach().cpu().numpy()
     assert np.abs(hw - fx['step3/last_conv1.weight']).max() < 1e-4     # three lr=1e-4 steps

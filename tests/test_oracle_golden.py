@@ -140,3 +140,38 @@ def test_g2_config2_digest():
     w = torch.tensor([1.0, 1.0])
     close(oracle.CEMDiceLoss(w, w, w)(out, t), fx['loss'], rtol=1e-4)
     close(oracle.CEMDiceLossImage(w, w, w)(out, t), fx['per_image_loss'], rtol=1e-4)
+
+
+def test_trajectory_noise_floor():
+    """How much of the 3-step loss trajectory (g5_adam.npz) is determined at fp32?  The oracle is re-run with
+    one-ulp multiplicative noise (1e-7 relative) on the weights before each step; the deviation from its
+    own unperturbed trajectory is the floor below which a trajectory comparison carries no information
+    (measured here: ~1e-7 at step 1, <= 2e-4 at step 2, up to 1.5e-3 at step 3).  The GPU trajectory
+    test's per-step tolerances (tests/test_gpu_steps.py) are set just above this floor."""
+    from oracle import nets, losses, steps
+    g1 = np.load(os.path.join(GOLD, 'g1_fuseunet.npz'))
+    fx = np.load(os.path.join(GOLD, 'g5_adam.npz'))
+    x1, x2, t = (torch.from_numpy(g1[k]) for k in ('x0', 'x1', 'targets'))
+
+    def run(eps, seed):
+        torch.manual_seed(2)
+        net = nets.fuseunet(2)
+        net.train()
+        w = torch.tensor([1.0, 1.0])
+        crit = losses.CEMDiceLoss(w, w, w)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, amsgrad=True)
+        gen = torch.Generator().manual_seed(seed)
+        out = []
+        for _ in range(3):
+            if eps > 0:
+                with torch.no_grad():
+                    for p in net.parameters():
+                        p.mul_(1 + eps * torch.randn(p.shape, generator=gen))
+            out.append(steps.comparison_step(net, crit, opt, x1, x2, t)[1].item())
+        return np.array(out)
+
+    base = run(0.0, 0)
+    assert np.max(np.abs(base - fx['losses']) / fx['losses']) < 1e-6          # the pinned trajectory
+    dev = np.max([np.abs(run(1e-7, s) - base) / base for s in range(2)], axis=0)
+    assert dev[0] < 1e-6 and dev[1] < 5e-4 and dev[2] < 3e-3, dev             # inside the GPU test's bounds
+    assert dev[2] > 1e-5, dev                                                 # ... and genuinely amplified
