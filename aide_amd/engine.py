@@ -72,6 +72,9 @@ USE_WINOGRAD = [True]          # global switch (tests / A-B runs)
 USE_WINOGRAD_DGRAD = [True]    # ... for the dgrad direction only
 
 
+WINO_EXEC = 16.0 / 36.0     # multiplies a Winograd F(2x2,3x3) launch executes per algorithmic multiply
+
+
 def use_winograd(n, cin, h, w, cout):
     """Static (deterministic) choice between the Winograd and the direct conv kernel: the layer sweep
     (tools/bench_conv.py all) has Winograd ahead on every layer shape it supports (1.2x-1.9x; the one
@@ -276,7 +279,7 @@ class Plan(object):
                 x = self.view(st['src'], inputs)
                 prof = self.profiler
                 if prof is not None:
-                    prof.begin('conv3x3_igemm', st['flops'])
+                    prof.begin('conv3x3_igemm', st['flops'], st['flops'] * (WINO_EXEC if st['wino_f'] else 1.0))
                 if st['wino_f']:
                     ops.conv3x3_wino(x, st['uf'], conv.bias, st['z'], splitk=st['plan_f'] >> 8, ws=self.sk_ws)
                 else:
@@ -358,13 +361,13 @@ class Plan(object):
                             wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
                     else:
                         if prof is not None:
-                            prof.begin('conv3x3_wgrad', st['flops'])
+                            prof.begin('conv3x3_wgrad', st['flops'], st['flops'] * (WINO_EXEC if st['wino_w'] else 1.0))
                         wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
                         if prof is not None:
                             prof.end()
                     if sg is not None:
                         if prof is not None:
-                            prof.begin('conv3x3_igemm', st['flops'])
+                            prof.begin('conv3x3_igemm', st['flops'], st['flops'] * (WINO_EXEC if st['wino_d'] else 1.0))
                         if st['wino_d']:
                             ops.conv3x3_wino(dz, st['ud'], None, self.gview(st['src']),
                                              accumulate=sg['accumulate'], splitk=st['plan_d'] >> 8, ws=self.sk_ws)
