@@ -346,6 +346,18 @@ __global__ __launch_bounds__(256) void pseudo_label_kernel(const PseudoArgs a) {
     }
 }
 
+// label map of the per-case inference loop: argmax(softmax(z), dim=1) for two classes.  The softmax is
+// monotonic, but its rounding merges logits closer than ~2^-25 into equal probabilities, and argmax then
+// returns the FIRST index: label 1 needs z1 > z0 *and* exp(z0 - z1) < 1 in fp32.
+__global__ __launch_bounds__(256) void label_map_kernel(const float* __restrict__ logits, long l_bs, int HW,
+                                                        long long* __restrict__ labels, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / HW, p = i - n * HW;
+        const float z0 = logits[n * l_bs + p], z1 = logits[n * l_bs + HW + p];
+        labels[i] = (z1 > z0 && expf(z0 - z1) < 1.0f) ? 1 : 0;
+    }
+}
+
 int bpi_for(int HW) { return max(1, min((HW + 2047) / 2048, 64)); }
 
 }  // namespace
@@ -415,6 +427,14 @@ int aide_mse_map(const float* logits, int64_t l_bs, const float* target, int64_t
                  float* out, const float* gout, float* dlogits, int64_t d_bs, hipStream_t stream) {
     hipLaunchKernelGGL(mse_map_kernel, dim3(bpi_for(HW) * 4, N), dim3(256), 0, stream, logits, (long)l_bs,
                        target, (long)q_bs, HW, out, gout, dlogits, (long)d_bs);
+    return aide_launch_status();
+}
+
+int aide_label_map(const float* logits, int64_t l_bs, int N, int HW, long long* labels, hipStream_t stream) {
+    if (!logits || !labels || N <= 0 || HW <= 0) return AIDE_ERR_ARG;
+    const long total = (long)N * HW;
+    hipLaunchKernelGGL(label_map_kernel, dim3((unsigned)min((total + 255) / 256, 8192L)), dim3(256), 0, stream,
+                       logits, (long)l_bs, HW, labels, total);
     return aide_launch_status();
 }
 

@@ -1,0 +1,66 @@
+"""Per-case inference of the training scripts, on device and batched.
+
+Reference (train_files/trainchaos_comparison_1case.py:233-273, :275-314; the same loop in
+trainchaos_proposed_30cases1labeled.py:373-493 and evalchaos_comparison_1cases.py:143-243): for every
+slice of a case, bs=1: `argmax(softmax(net(inphase, outphase), dim=1), dim=1)` under `net.eval()` +
+`no_grad`, `.cpu().numpy()` per slice, `np.stack(..., axis=-1)`, then skimage's largest connected
+component (CPU, out of scope here) and `Dice3d_fn`.
+
+Here the slices of a case go through the eval-mode kernels in batches (eval BatchNorm uses the running
+statistics, so slices are independent and batching changes nothing but the launch count), the label
+map is one kernel (`aide_label_map`) and the volume leaves the device once.
+"""
+import numpy as np
+import torch
+
+from ._lib import lib, check
+from .ops import ptr, stream_ptr
+
+
+def label_map(logits):
+    """[N,2,H,W] fp32 logits -> [N,H,W] int64 labels = torch.argmax(F.softmax(logits, 1), 1)."""
+    if logits.dim() != 4 or logits.shape[1] != 2 or logits.dtype != torch.float32 or not logits.is_cuda:
+        raise RuntimeError('label_map expects a [N,2,H,W] fp32 HIP tensor')
+    logits = logits.detach()
+    if not logits.is_contiguous():
+        logits = logits.contiguous()
+    n, _, h, w = logits.shape
+    out = torch.empty(n, h, w, device=logits.device, dtype=torch.int64)
+    check(lib.aide_label_map(ptr(logits), 2 * h * w, n, h * w, ptr(out), stream_ptr()), 'label_map')
+    return out
+
+
+def predict_labels(net, *modal_inputs, **kw):
+    """Labels [S,H,W] (int64, on device) for S slices; `modal_inputs` = (inphase[, outphase]) each
+    [S,3,H,W].  The network must be in eval mode, as in the reference loop (:210 `net.eval()`)."""
+    batch_size = kw.pop('batch_size', 16)
+    if kw:
+        raise TypeError('unexpected arguments %r' % sorted(kw))
+    if net.training:
+        raise RuntimeError('predict_labels needs net.eval(): train-mode BatchNorm at bs=1 is not what the '
+                           'reference loop runs')
+    s = modal_inputs[0].shape[0]
+    dev = next(net.parameters()).device
+    out = []
+    with torch.no_grad():
+        for i in range(0, s, batch_size):
+            xs = [m[i:i + batch_size].to(dev, non_blocking=True) for m in modal_inputs]
+            out.append(label_map(net(*xs)))
+    return torch.cat(out, 0) if len(out) > 1 else out[0]
+
+
+def predict_case(net, *modal_inputs, **kw):
+    """The reference's `generatedtarget`: numpy int64 [H,W,S] (slices stacked on the last axis, :267)."""
+    return predict_labels(net, *modal_inputs, **kw).permute(1, 2, 0).contiguous().cpu().numpy()
+
+
+def Dice3d_fn(inputs, targets):
+    """trainchaos_comparison_1case.py:88-95 for label volumes (numpy arrays or tensors): 2·Σ(i·t)/(Σi+Σt).
+    Integer sums, one float64 division — identical to the numpy original (0/0 -> nan like numpy)."""
+    if isinstance(inputs, np.ndarray) and isinstance(targets, np.ndarray):
+        i, t = inputs.reshape(-1), targets.reshape(-1)
+        return 2 * np.sum(i * t) / (np.sum(i) + np.sum(t))
+    i = torch.as_tensor(inputs).reshape(-1).to(torch.int64)
+    t = torch.as_tensor(targets).reshape(-1).to(i.device, torch.int64)
+    inter, union = 2 * int((i * t).sum().item()), int(i.sum().item()) + int(t.sum().item())
+    return np.float64(inter) / np.float64(union) if union else np.float64('nan')

@@ -144,6 +144,10 @@ int aide_pseudo_label(const float* const* logits /* HOST array of K device point
                       int64_t l_bs, int N, int HW, float temperature, float* pl, float* wm,
                       aide_stream_t stream);
 
+/* per-case inference (trainchaos_comparison_1case.py:262-264): labels[n][p] = argmax(softmax(logits[n][:,p]))
+ * for two classes, int64 like torch.argmax; ties (also those created by the softmax rounding) -> 0 */
+int aide_label_map(const float* logits, int64_t l_bs, int N, int HW, long long* labels, aide_stream_t stream);
+
 /* ---- Adam(amsgrad), one launch for all parameter tensors ----------------------------------------
  * replaces torch.optim.Adam(net.parameters(), lr, amsgrad=True): trainchaos_comparison_1case.py:170 */
 int aide_adam_amsgrad_multi(float* const* p, const float* const* g, float* const* m, float* const* v,

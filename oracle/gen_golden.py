@@ -329,8 +329,57 @@ def g2_config(ref_f, ref_utils):
     print('g2 loss', float(loss), 'per-image', per.tolist())
 
 
+def g6_inference(ref_f, ref_u, ref_utils):
+    """Per-case inference (trainchaos_comparison_1case.py:233-273): two training steps move the BN running
+    statistics, then eval-mode bs=1 slices -> softmax -> argmax -> [H,W,S] volume and Dice3d_fn."""
+    import oracle
+    from oracle import steps
+    fx = {}
+    w = torch.tensor([1.0, 1.0])
+    for name, two_modal, mods in (('fuseunet', True, (ref_f, oracle)), ('unet', False, (ref_u, oracle))):
+        xs, t = tiny_inputs(two_modal)
+        g = torch.Generator().manual_seed(77)
+        sl = [torch.randn(6, 3, 48, 32, generator=g) for _ in range(2 if two_modal else 1)]
+        tgt = (torch.rand(48, 32, 6, generator=g) > 0.6).numpy().astype(np.int64)
+        res = []
+        for m in mods:
+            torch.manual_seed(2)
+            net = m.fuseunet(2) if two_modal else m.UNet(2)
+            net.train()
+            crit = (ref_utils if m is not oracle else oracle).CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
+            opt = torch.optim.Adam(net.parameters(), lr=1e-4, amsgrad=True)
+            for _ in range(2):
+                steps.comparison_step(net, crit, opt, xs[0], xs[1] if two_modal else None, t)
+            net.eval()
+            vol, lg = steps.predict_case(net, sl[0], sl[1] if two_modal else None)
+            # an untrained net predicts one class everywhere: move the head bias to the median margin so
+            # that the label volume is a real mixture (same state for reference and oracle; recorded)
+            if not res:
+                shift = float((lg[:, 1] - lg[:, 0]).median())
+            with torch.no_grad():
+                net.last_conv1.bias[1] -= shift
+            vol, lg = steps.predict_case(net, sl[0], sl[1] if two_modal else None)
+            res.append((vol, lg, steps.Dice3d_fn(vol, tgt)))
+        assert np.array_equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), name
+        vol, lg, dice = res[0]
+        for i, x in enumerate(sl):
+            fx['%s/slices%d' % (name, i)] = _np(x)
+        fx[name + '/labels'] = vol.astype(np.uint8)                 # [H,W,S]
+        fx[name + '/margin'] = _np(lg[:, 1] - lg[:, 0])             # [S,H,W]
+        fx[name + '/targets'] = tgt.astype(np.uint8)
+        fx[name + '/dice3d'] = np.array(dice)
+        fx[name + '/head_bias1_shift'] = np.array(shift, dtype=np.float64)
+        print('g6', name, 'foreground fraction %.3f' % vol.mean(), 'dice3d %.6f' % dice,
+              'min |margin| %.2e' % float((lg[:, 1] - lg[:, 0]).abs().min()))
+    np.savez_compressed(os.path.join(OUT, 'g6_inference.npz'), **fx)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['g6']:
+        torch.set_num_threads(8)
+        ref_f, ref_u, ref_utils = _import_reference()
+        return g6_inference(ref_f, ref_u, ref_utils)
     torch.set_num_threads(8)
     ref_f, ref_u, ref_utils = _import_reference()
     import oracle
@@ -342,6 +391,7 @@ def main():
     g4_proposed(ref_f, ref_utils)
     g5_adam(ref_f, ref_utils)
     g2_config(ref_f, ref_utils)
+    g6_inference(ref_f, ref_u, ref_utils)
     print('all golden fixtures written to', OUT)
 
 

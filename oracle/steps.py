@@ -102,3 +102,29 @@ def proposed_step(net1, net2, criterion, corr, opt1, opt2, inphase, outphase, au
     opt2.step()
     return dict(outputs1=o1.detach(), outputs2=o2.detach(), loss1=loss1.detach(),
                 loss2=loss2.detach(), indx1=indx1, indx2=indx2, loss1_pre=l1pre, loss2_pre=l2pre)
+
+
+def predict_case(net, inphase, outphase=None):
+    """trainchaos_comparison_1case.py:257-267 — per slice, bs=1, eval mode: softmax -> argmax -> numpy,
+    slices stacked on the last axis.  Returns (generatedtarget int64 [H,W,S], logits [S,2,H,W])."""
+    import numpy as np
+    gen, lg = [], []
+    for i in range(inphase.shape[0]):
+        with torch.no_grad():
+            a = torch.unsqueeze(inphase[i], 0)
+            output = net(a, torch.unsqueeze(outphase[i], 0)) if outphase is not None else net(a)
+            lg.append(output[0].clone())
+            output = F.softmax(output, dim=1)
+            output = torch.argmax(output, dim=1)
+            gen.append(output.squeeze().cpu().numpy())
+    return np.stack(gen, axis=-1), torch.stack(lg, 0)
+
+
+def Dice3d_fn(inputs, targets):
+    """trainchaos_comparison_1case.py:88-95."""
+    import numpy as np
+    iflat = inputs.reshape(-1)
+    tflat = targets.reshape(-1)
+    intersection = 2 * np.sum(iflat * tflat)
+    union = np.sum(iflat) + np.sum(tflat)
+    return intersection / union

@@ -175,3 +175,35 @@ def test_trajectory_noise_floor():
     dev = np.max([np.abs(run(1e-7, s) - base) / base for s in range(2)], axis=0)
     assert dev[0] < 1e-6 and dev[1] < 5e-4 and dev[2] < 3e-3, dev             # inside the GPU test's bounds
     assert dev[2] > 1e-5, dev                                                 # ... and genuinely amplified
+
+
+@pytest.mark.parametrize('name', ['fuseunet', 'unet'])
+def test_inference_path_g6(name):
+    """Per-case inference loop (trainchaos_comparison_1case.py:233-273) restated in oracle/steps.py vs the
+    label volume the real reference produced (g6_inference.npz)."""
+    from oracle import nets, losses
+    fx = load('g6_inference.npz')
+    two = name == 'fuseunet'
+    g = torch.Generator().manual_seed(1234)
+    xs = [torch.randn(2, 3, 32, 32, generator=g) for _ in range(2 if two else 1)]
+    t = (torch.rand(2, 32, 32, generator=g) > 0.7).long()
+    torch.manual_seed(2)
+    net = nets.fuseunet(2) if two else nets.UNet(2)
+    net.train()
+    w = torch.tensor([1.0, 1.0])
+    crit = losses.CEMDiceLoss(w, w, w)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, amsgrad=True)
+    for _ in range(2):
+        steps.comparison_step(net, crit, opt, xs[0], xs[1] if two else None, t)
+    net.eval()
+    with torch.no_grad():
+        net.last_conv1.bias[1] -= float(fx[name + '/head_bias1_shift'])
+    sl = [torch.from_numpy(fx['%s/slices%d' % (name, i)]) for i in range(2 if two else 1)]
+    vol, lg = steps.predict_case(net, sl[0], sl[1] if two else None)
+    assert vol.shape == (48, 32, 6) and vol.dtype == np.int64
+    margin = np.transpose(fx[name + '/margin'], (1, 2, 0))
+    bad = vol != fx[name + '/labels']
+    assert not np.any(bad & (np.abs(margin) > 1e-5))          # only fp32 near-ties may differ across hosts
+    assert bad.sum() <= 4
+    d = steps.Dice3d_fn(vol, fx[name + '/targets'].astype(np.int64))
+    assert abs(d - float(fx[name + '/dice3d'])) < 1e-3
