@@ -1,0 +1,485 @@
+// 3x3 / pad 1 convolution, Winograd F(4x4, 3x3) on fp32 MFMA (gfx950).  Forward and dgrad of the
+// large layers (nn.Conv2d(ci, co, 3, padding=1): models_twomodalinputs/netblocks.py:17,24,26).
+//
+//   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A      d: 6x6 input patch, g: 3x3 filter, Y: 4x4 outputs
+//
+// 36 multiplies per 16 outputs (2.25 per output; F(2x2,3x3) needs 4, the direct form 9).  Per transform
+// position p (36 of them) the contraction over input channels is a GEMM
+//   M[p][co][tile] += U[p][co][ci] * V[p][tile][ci]        on v_mfma_f32_32x32x2_f32.
+// 36 positions x 16 accumulator registers do not fit one wave, so a (32 co x 32 tiles) block is shared by
+// TWO waves that own the transform rows 0-2 / 3-5 (18 positions = 288 accumulator registers each):
+//   * workgroup = 4 waves = 64 co x 32 tiles (8 x 4 tiles = 32 x 16 pixels) x 36 positions;
+//   * stage = 4 input channels: raw halo tile [4][18][40], U[36][64][4], V[36][32][4], all double
+//     buffered in LDS (131 KB); fragments are ds_read_b64 (channel q pairs with q+2 in the two K slots);
+//   * the input transform is split the same way as the positions: a thread produces the 18 values of
+//     rows 0-2 (or 3-5) of B^T d B for one (ci, tile) — no exchange, both halves read the 6x6 patch;
+//   * the fp32 MFMA shares the vector-ALU pipe (tools/ubench/mfma_shadow.hip), so the loop carries no
+//     address arithmetic or selects and the transform's FMAs are issued as one cluster per stage;
+//   * output transform: each wave reduces its 18 positions to partial 4x4 outputs, the two partner waves
+//     swap halves through LDS (the staging buffers are free by then) and store 16-byte rows.
+// Forward error: the transform matrices have entries up to 8 (A) and 5 (B); measured <= 2e-5 relative to
+// the output scale on the network's layers (parity tests hold it to 1e-4; the north-star bound is 1e-3).
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+template <int V> using ic = std::integral_constant<int, V>;
+
+struct W4Args {
+    const float* x;
+    const float* u;      // [Cin/4][36][Cout][4]
+    const float* bias;
+    float* y;
+    long x_bs, y_bs, split_stride;
+    int N, Cin, H, W, Cout;
+    int blocks_w, blocks_h, n_co_tiles, splitk, stages_total, accumulate;
+};
+
+constexpr int F4_NAGPR = 16;               // accumulators (of 18) kept in the AGPR file; the rest are pinned to VGPRs
+constexpr int F4_RRS = 40;                 // raw row: [3 pad][-1][0..31][32][3 pad]
+constexpr int F4_RCS = 721;                // raw channel stride, odd: conflict-free patch reads over (ci, tile)
+constexpr int F4_RAW = 4 * F4_RCS;         // 2884 floats
+constexpr int F4_V = 36 * 32 * 4;          // V[p][tile][4 ci]
+constexpr int F4_U = 36 * 64 * 4;          // U[p][co][4 ci]
+constexpr int F4_SET = F4_RAW + F4_V + F4_U;   // 16708 floats = 66832 B; two sets = 130.5 KB
+constexpr int F4_LDS = 2 * F4_SET > 4 * 128 * 64 ? 2 * F4_SET : 4 * 128 * 64;   // epilogue swap needs 32768
+
+// 1-D input transform B^T (F(4,3), points 0, +-1, +-2, inf), all six outputs
+__device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, float d4, float d5, float* o, int st) {
+    const float a = __builtin_fmaf(-4.f, d2, d4), b = __builtin_fmaf(4.f, d1, -d3);
+    const float c = d4 - d2, e = d3 - d1;
+    o[0] = __builtin_fmaf(-5.f, d2, __builtin_fmaf(4.f, d0, d4));
+    o[st] = a - b;
+    o[2 * st] = a + b;
+    o[3 * st] = __builtin_fmaf(2.f, e, c);
+    o[4 * st] = __builtin_fmaf(-2.f, e, c);
+    o[5 * st] = __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5));
+}
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform (scalar) roles
+    const int half = lane >> 5, j = lane & 31;
+    const int ph = wid & 1, cb = wid >> 1;                 // position half (transform rows 3ph..3ph+2), co block
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int co_tile = b % a.n_co_tiles; b /= a.n_co_tiles;
+    const int split = b % a.splitk;       b /= a.splitk;
+    const int tw = b % a.blocks_w;        b /= a.blocks_w;
+    const int th = b % a.blocks_h;
+    const int n = b / a.blocks_h;
+    const int h0 = th * 16, w0 = tw * 32, co0 = co_tile * 64;
+    const int HW = a.H * a.W;
+
+    const int sps = a.stages_total / a.splitk;             // even, and splitk divides stages_total (host)
+    const int s_begin = split * sps;
+    const int s_end = min(s_begin + sps, a.stages_total);
+
+    // ---- staging descriptors (stage-invariant) ----
+    // raw interior: 4 ci x 18 rows x 8 float4 = 576 units (3 rounds, spare lanes repeat unit q - 256);
+    // raw edges: 4 x 18 x 2 dwords = 144 units (1 round); U: 2304 float4 (9 rounds)
+    unsigned offB[3], ldsB[3], offC, ldsC, offU[9];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        int q = tid + e * 256;
+        if (q >= 576) q -= 256;
+        const int c = q / 144, rem = q - c * 144, r = rem >> 3, s4 = rem & 7;
+        const int ih = h0 - 1 + r, iw = w0 + 4 * s4;
+        const bool ok = ih >= 0 && ih < a.H && iw < a.W;
+        offB[e] = ok ? (unsigned)(c * HW + r * a.W + 1 + 4 * s4) * 4u : BUF_OOB;
+        ldsB[e] = (unsigned)(c * F4_RCS + r * F4_RRS + 4 + 4 * s4);
+    }
+    {
+        int q = tid;
+        if (q >= 144) q -= 144;
+        const int c = q / 36, rem = q - c * 36, r = rem >> 1, side = rem & 1;
+        const int ih = h0 - 1 + r, iw = side ? w0 + 32 : w0 - 1;
+        const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        offC = ok ? (unsigned)(c * HW + r * a.W + (side ? 33 : 0)) * 4u : BUF_OOB;
+        ldsC = (unsigned)(c * F4_RCS + r * F4_RRS + (side ? 36 : 3));
+    }
+#pragma unroll
+    for (int v = 0; v < 9; ++v) {
+        const int f = tid + v * 256;                       // float4 index inside the [36][64 co][4 ci] block
+        offU[v] = (unsigned)((f >> 6) * a.Cout * 4 + (f & 63) * 4) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t xrs =
+        make_rsrc(a.x + (long)n * a.x_bs + (long)h0 * a.W + w0 - (a.W + 1));
+    const __amdgpu_buffer_rsrc_t urs = make_rsrc(a.u + (long)co0 * 4);
+
+    f32x4 rb[3], ru[9];
+    float rc;
+    auto fetch = [&](int l, int stage) {                   // l < 13: 9 U loads then 4 raw loads
+        if (l < 9) {
+            const unsigned us = (unsigned)min(stage, s_end - 1) * 36u * (unsigned)a.Cout * 16u;
+            ru[l] = buf_load_f32x4(urs, offU[l], us);
+        } else {
+            const unsigned xs = (unsigned)(min(stage, s_end - 1) * 4) * (unsigned)HW * 4u;
+            if (l < 12) rb[l - 9] = buf_load_f32x4(xrs, offB[l - 9], xs);
+            else rc = buf_load_f32(xrs, offC, xs);
+        }
+    };
+    auto put_u = [&](int v, float* ubuf) { *reinterpret_cast<f32x4*>(ubuf + (tid + v * 256) * 4) = ru[v]; };
+    auto put_raw = [&](int w, float* raw) {                // 13 dword stores (odd channel stride)
+        if (w < 12) raw[ldsB[w >> 2] + (w & 3)] = rb[w >> 2][w & 3];
+        else raw[ldsC] = rc;
+    };
+
+    // ---- input transform: thread = (half hs, ci, tile) ----
+    const int item = tid & 127, hs = wid >> 1;             // hs is wave-uniform
+    const int xr_off = (item & 3) * F4_RCS + (item >> 5) * 4 * F4_RRS + 3 + 4 * ((item >> 2) & 7);
+    float td[36], to[18];
+    auto xf_read = [&](int i, const float* raw) { td[i] = raw[xr_off + (i / 6) * F4_RRS + (i % 6)]; };
+    auto xf_half = [&](auto HS) {
+        // column pass: rows 3hs..3hs+2 of B^T d for each of the six columns, then full B^T along the rows
+        constexpr int khs = decltype(HS)::value;
+        float t[18];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const float d0 = td[c], d1 = td[6 + c], d2 = td[12 + c], d3 = td[18 + c], d4 = td[24 + c], d5 = td[30 + c];
+            if (khs == 0) {
+                const float aa = __builtin_fmaf(-4.f, d2, d4), bb = __builtin_fmaf(4.f, d1, -d3);
+                t[c] = __builtin_fmaf(-5.f, d2, __builtin_fmaf(4.f, d0, d4));
+                t[6 + c] = aa - bb;
+                t[12 + c] = aa + bb;
+            } else {
+                const float cc = d4 - d2, ee = d3 - d1;
+                t[c] = __builtin_fmaf(2.f, ee, cc);
+                t[6 + c] = __builtin_fmaf(-2.f, ee, cc);
+                t[12 + c] = __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            bt6(t[6 * i], t[6 * i + 1], t[6 * i + 2], t[6 * i + 3], t[6 * i + 4], t[6 * i + 5], to + 6 * i, 1);
+    };
+    auto xf_math = [&]() {
+        if (hs == 0) xf_half(ic<0>{}); else xf_half(ic<1>{});
+    };
+    auto xf_store = [&](int o, float* vbuf) { vbuf[(18 * hs + o) * 128 + item] = to[o]; };
+
+    f32x16 acc[18];
+#pragma unroll
+    for (int p = 0; p < 18; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+
+    float* const set0 = lds;
+    float* const set1 = lds + F4_SET;
+    // ---- prologue: raw[s0] + U[s0] -> set0, transform -> set0.V; raw[s0+1] -> set1.raw ----
+#pragma unroll
+    for (int l = 0; l < 13; ++l) fetch(l, s_begin);
+#pragma unroll
+    for (int w = 0; w < 13; ++w) put_raw(w, set0);
+#pragma unroll
+    for (int v = 0; v < 9; ++v) put_u(v, set0 + F4_RAW + F4_V);
+#pragma unroll
+    for (int l = 9; l < 13; ++l) fetch(l, s_begin + 1);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 36; ++i) xf_read(i, set0);
+    xf_math();
+#pragma unroll
+    for (int o = 0; o < 18; ++o) xf_store(o, set0 + F4_RAW);
+#pragma unroll
+    for (int w = 0; w < 13; ++w) put_raw(w, set1);
+    __syncthreads();
+
+    // ---- main loop.  While the MFMAs consume (V, U) of set `sc` (stage s):
+    //   U[s+1] is fetched and stored into `sn`; raw[s+1] (already in sn.raw) is transformed into sn.V;
+    //   raw[s+2] is fetched and stored into sc.raw (consumed by the previous stage's transform).
+    auto stage = [&](int s, float* sc, float* sn) {
+        const float* la = sc + F4_RAW + F4_V + ((18 * ph) * 64 + cb * 32 + j) * 4 + half * 2;   // U[p][co][ci]
+        const float* lb = sc + F4_RAW + ((18 * ph) * 32 + j) * 4 + half * 2;                    // V[p][tile][ci]
+        // three rotating fragment sets, position pairs: (A0,B0,A1,B1) requested 4 slots ahead
+        f32x2 fa[6], fb[6];
+        auto frag = [&](int pi, int slot2) {
+            fa[slot2] = *reinterpret_cast<const f32x2*>(la + pi * 256);
+            fb[slot2] = *reinterpret_cast<const f32x2*>(lb + pi * 128);
+        };
+        frag(0, 0); frag(1, 1); frag(2, 2); frag(3, 3);
+#pragma unroll
+        for (int st = 0; st < 36; ++st) {
+            // slot order inside a position pair g: (2g,k0) (2g+1,k0) (2g,k1) (2g+1,k1)
+            const int g = st >> 2, w = st & 3, pi = 2 * g + (w & 1), k = w >> 1;
+            const int fs = pi % 6;
+            if (w == 0 && pi + 4 < 18) { frag(pi + 4, (pi + 4) % 6); frag(pi + 5, (pi + 5) % 6); }
+            // 18 x 16 accumulator registers exceed the 256 AGPRs: positions 16 and 17 are pinned to VGPRs
+            // (hipcc otherwise shuffles whole accumulators between the two files every stage)
+            // (register classes are spelled out: 16 accumulators fill the AGPR file, fragments stay in VGPRs)
+            if (pi < F4_NAGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pi]) : "v"(fa[fs][k]), "v"(fb[fs][k]));
+            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[pi]) : "v"(fa[fs][k]), "v"(fb[fs][k]));
+            // staging schedule: only slot 20 carries vector-ALU work
+            //   0..12 global fetches (U[s+1] x9, raw[s+2] x4);  0..17 patch reads (2 per slot)
+            //   20 transform;  21..29 V stores (2 per slot);  24..32 U stores;  31..35 raw stores (3 per slot)
+            if (st < 9) fetch(st, s + 1);
+            else if (st < 13) fetch(st, s + 2);
+            if (st < 18) { xf_read(2 * st, sn); xf_read(2 * st + 1, sn); }
+            if (st == 20) xf_math();
+            if (st >= 21 && st < 30) { xf_store(2 * (st - 21), sn + F4_RAW); xf_store(2 * (st - 21) + 1, sn + F4_RAW); }
+            if (st >= 24 && st < 33) put_u(st - 24, sn + F4_RAW + F4_V);
+            if (st >= 31) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (3 * (st - 31) + q < 13) put_raw(3 * (st - 31) + q, sc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    // two stages per iteration, unconditionally (the host makes the stage count of a split even): with a
+    // conditional second stage hipcc reconciles the accumulator registers of the two paths by copying them
+    for (int s = s_begin; s < s_end; s += 2) {
+        stage(s, set0, set1);
+        stage(s + 1, set1, set0);
+    }
+
+    // ---- output transform.  Partial over this wave's rows i = 3ph..3ph+2:
+    //   T[i][b] = sum_c M[i][c] A[c][b];   Yp[a][b] = sum_i A^T[a][i] T[i][b]
+    // The wave with ph = 0 finishes accumulator rows r < 8, its partner r >= 8; the other half of the
+    // partials travels through LDS ([wave][128][64 lanes]).
+    float* xbuf = lds;
+    float* yn = a.y + (long)split * a.split_stride + (long)n * a.y_bs;
+    const bool add_bias = (a.bias != nullptr) && (split == 0);
+    const int oh = h0 + 4 * (j >> 3), ow = w0 + 4 * (j & 7);
+    const bool pok = oh < a.H && ow < a.W;                 // H, W multiples of 4: a tile is in or out
+    auto epilogue = [&](auto PH) {
+        constexpr int kph = decltype(PH)::value;
+        auto partial = [&](int r, float* yp) {             // r is a compile-time constant after unrolling
+            float T[3][4];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float m0 = acc[6 * i][r], m1 = acc[6 * i + 1][r], m2 = acc[6 * i + 2][r],
+                            m3 = acc[6 * i + 3][r], m4 = acc[6 * i + 4][r], m5 = acc[6 * i + 5][r];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                T[i][0] = m0 + s12 + s34;
+                T[i][1] = __builtin_fmaf(2.f, d34, d12);
+                T[i][2] = __builtin_fmaf(4.f, s34, s12);
+                T[i][3] = __builtin_fmaf(8.f, d34, d12) + m5;
+            }
+#pragma unroll
+            for (int bq = 0; bq < 4; ++bq) {
+                if (kph == 0) {                             // A^T columns 0,1,2: (1,0,0,0) (1,1,1,1) (1,-1,1,-1)
+                    const float sm = T[1][bq] + T[2][bq], df = T[1][bq] - T[2][bq];
+                    yp[bq] = T[0][bq] + sm; yp[4 + bq] = df; yp[8 + bq] = sm; yp[12 + bq] = df;
+                } else {                                    // columns 3,4,5: (1,2,4,8) (1,-2,4,-8) (0,0,0,1)
+                    const float sm = T[0][bq] + T[1][bq], df = T[0][bq] - T[1][bq];
+                    yp[bq] = sm; yp[4 + bq] = 2.f * df; yp[8 + bq] = 4.f * sm;
+                    yp[12 + bq] = __builtin_fmaf(8.f, df, T[2][bq]);
+                }
+            }
+        };
+        // (the main loop ended with a barrier: the staging buffers are free)
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            float yp[16];
+            partial(rr + 8 * (1 - kph), yp);               // the partner's rows
+#pragma unroll
+            for (int o = 0; o < 16; ++o) xbuf[((wid * 128) + rr * 16 + o) * 64 + lane] = yp[o];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            constexpr int dummy = 0; (void)dummy;
+            const int r = rr + 8 * kph;
+            float yp[16];
+            partial(r, yp);
+#pragma unroll
+            for (int o = 0; o < 16; ++o) yp[o] += xbuf[(((wid ^ 1) * 128) + rr * 16 + o) * 64 + lane];
+            const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (pok) {
+                const float bv = add_bias ? a.bias[co] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 o = {yp[4 * i] + bv, yp[4 * i + 1] + bv, yp[4 * i + 2] + bv, yp[4 * i + 3] + bv};
+                    f32x4* p = reinterpret_cast<f32x4*>(yn + (long)co * HW + (long)(oh + i) * a.W + ow);
+                    if (a.accumulate) { const f32x4 old = *p; o += old; }
+                    *p = o;
+                }
+            }
+        }
+    };
+    if (ph == 0) epilogue(ic<0>{}); else epilogue(ic<1>{});
+}
+
+// y[n][c][p] (+)= bias[c] + sum_s slab[s][n][c][p], 16 bytes per thread, fixed summation order
+__global__ __launch_bounds__(256) void w4_splitk_reduce_kernel(const float* __restrict__ slabs, long split_stride,
+                                                               int splitk, float* __restrict__ y, long y_bs, int C,
+                                                               int HW, const float* __restrict__ bias, int accumulate,
+                                                               long total4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long e = i * 4, chw = (long)C * HW;
+        const long n = e / chw, rem = e - n * chw;
+        f32x4 v = *reinterpret_cast<const f32x4*>(slabs + e);
+        for (int s = 1; s < splitk; ++s) v += *reinterpret_cast<const f32x4*>(slabs + (long)s * split_stride + e);
+        if (bias) { const float bv = bias[rem / HW]; v += f32x4{bv, bv, bv, bv}; }
+        f32x4* p = reinterpret_cast<f32x4*>(y + n * y_bs + rem);
+        if (accumulate) v += *p;
+        *p = v;
+    }
+}
+
+// G g G^T for F(4x4,3x3): 6x6 values per (co, ci) filter
+__device__ __forceinline__ void wino4_g(const float g[9], float u[36]) {
+    float t[18];                                           // G g : 6x3
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g0 = g[c], g1 = g[3 + c], g2 = g[6 + c];
+        const float s = g0 + g2;
+        t[c] = 0.25f * g0;
+        t[3 + c] = (-1.f / 6.f) * (s + g1);
+        t[6 + c] = (-1.f / 6.f) * (s - g1);
+        const float q = __builtin_fmaf(4.f, g2, g0);       // g0 + 4 g2
+        t[9 + c] = (1.f / 24.f) * (q + 2.f * g1);
+        t[12 + c] = (1.f / 24.f) * (q - 2.f * g1);
+        t[15 + c] = g2;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {                          // (G g) G^T : 6x6
+        const float a0 = t[r * 3], a1 = t[r * 3 + 1], a2 = t[r * 3 + 2];
+        const float s = a0 + a2, q = __builtin_fmaf(4.f, a2, a0);
+        u[r * 6] = 0.25f * a0;
+        u[r * 6 + 1] = (-1.f / 6.f) * (s + a1);
+        u[r * 6 + 2] = (-1.f / 6.f) * (s - a1);
+        u[r * 6 + 3] = (1.f / 24.f) * (q + 2.f * a1);
+        u[r * 6 + 4] = (1.f / 24.f) * (q - 2.f * a1);
+        u[r * 6 + 5] = a2;
+    }
+}
+
+struct W4PackDesc {
+    const float* w; float* uf; float* ud;
+    int Co, Ci, pad0, pad1;
+    long block_start;
+};
+
+// One workgroup transforms a 32 co x 32 ci filter tile (see wino_pack_multi_kernel): filters -> LDS, one
+// (co, ci) pair per thread and group, 36 runs of 128 floats per group of 4 channels:
+//   uf [ci/4][36][Co][4 ci]   ud [co/4][36][Ci][4 co] (taps reversed)
+constexpr int P4_T = 32, P4_ROW = P4_T * 9 + 1;
+__global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc* __restrict__ descs, int n) {
+    __shared__ float wt[P4_T * P4_ROW];
+    __shared__ __attribute__((aligned(16))) float ot[36 * 128];
+    const long blk = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_start <= blk) lo = mid; else hi = mid - 1;
+    }
+    const W4PackDesc d = descs[lo];
+    const int tid = threadIdx.x;
+    const int tiles_ci = (d.Ci + P4_T - 1) / P4_T;
+    const int tb = (int)(blk - d.block_start);
+    const int co0 = (tb / tiles_ci) * P4_T, ci0 = (tb % tiles_ci) * P4_T;
+    const int nci = min(P4_T, d.Ci - ci0);
+    for (int e = tid; e < P4_T * P4_T * 9; e += 128) {
+        const int co = e / (P4_T * 9), r = e - co * (P4_T * 9);
+        float v = 0.f;
+        if (co0 + co < d.Co && r < nci * 9) v = d.w[((long)(co0 + co) * d.Ci + ci0) * 9 + r];
+        wt[co * P4_ROW + r] = v;
+    }
+    __syncthreads();
+    float g[9], u[36];
+    const int lo2 = tid & 3, hi5 = tid >> 2;
+    for (int grp = 0; grp < 16; ++grp) {                   // 8 forward groups of 4 ci, 8 dgrad groups of 4 co
+        const bool fwd = grp < 8;
+        const int q = grp & 7;
+        float* dst = fwd ? d.uf : d.ud;
+        if (dst == nullptr) continue;
+        const int co = fwd ? hi5 : 4 * q + lo2, ci = fwd ? 4 * q + lo2 : hi5;
+        const bool live = fwd ? (ci0 + 4 * q < d.Ci) : (co0 + 4 * q < d.Co);
+        if (!live) continue;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) g[t] = wt[co * P4_ROW + ci * 9 + (fwd ? t : 8 - t)];
+        wino4_g(g, u);
+#pragma unroll
+        for (int p = 0; p < 36; ++p) ot[p * 128 + tid] = u[p];
+        __syncthreads();
+        const int C = fwd ? d.Co : d.Ci, c0 = fwd ? co0 : ci0;
+        const long gbase = (long)((fwd ? ci0 : co0) / 4 + q) * 36;
+        const int nrun = min(P4_T, C - c0) * 4;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int f = tid + k * 128, p = f >> 5, x4 = (f & 31) * 4;
+            if (x4 < nrun)
+                *reinterpret_cast<f32x4*>(dst + ((gbase + p) * C + c0) * 4 + x4) =
+                    *reinterpret_cast<const f32x4*>(ot + p * 128 + x4);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int aide_conv3x3_wino4_supported(int Cin, int H, int W, int Cout) {
+    return (H % 4 == 0 && W % 4 == 0 && H >= 16 && W >= 32 && Cout % 64 == 0 && Cin % 8 == 0) ? 1 : 0;
+}
+
+int aide_conv3x3_wino4_splitk(int N, int Cin, int H, int W, int Cout) {
+    const long nb = (long)((H + 15) / 16) * ((W + 31) / 32) * N * (Cout / 64);
+    const int pairs = Cin / 8;                             // a split gets a whole number of stage pairs
+    int s = 1;
+    while (nb * s < 200 && pairs % (s * 2) == 0 && s * 2 <= pairs / 4) s *= 2;
+    return s;
+}
+
+int aide_conv3x3_wino4_pack_blocks(int Co, int Ci) {
+    return ((Co + P4_T - 1) / P4_T) * ((Ci + P4_T - 1) / P4_T);
+}
+
+// descs: DEVICE array of n 48-byte records {w, uf (or 0), ud (or 0), int32 Co, Ci, 0, 0, int64 block_start}
+int aide_conv3x3_wino4_pack_multi(const void* descs, int n, int64_t total_blocks, hipStream_t stream) {
+    if (!descs || n <= 0 || total_blocks <= 0) return AIDE_ERR_ARG;
+    static_assert(sizeof(W4PackDesc) == 48, "descriptor layout");
+    hipLaunchKernelGGL(wino4_pack_multi_kernel, dim3((unsigned)total_blocks), dim3(128), 0, stream,
+                       (const W4PackDesc*)descs, n);
+    return aide_launch_status();
+}
+
+// y (+)= conv3x3(x) with F(4x4,3x3)-packed filters u [Cin/4][36][Cout][4] (forward pack, or the dgrad pack
+// with Cin/Cout swapped by the caller).  splitk from aide_conv3x3_wino4_splitk (or 1); ws: split-K slabs
+// of aide_conv3x3_ws_bytes(N, H, W, Cout, splitk) bytes.
+int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float* bias, float* y,
+                       int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,
+                       float* ws, hipStream_t stream) {
+    if (!x || !u || !y || !aide_conv3x3_wino4_supported(Cin, H, W, Cout) || x_bs % 4 || y_bs % 4)
+        return AIDE_ERR_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv3x3_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            F4_LDS * (int)sizeof(float));
+        attr_set = true;
+    }
+    W4Args a;
+    a.x = x; a.u = u; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
+    a.blocks_w = (W + 31) / 32; a.blocks_h = (H + 15) / 16; a.n_co_tiles = Cout / 64;
+    a.stages_total = Cin / 4;
+    if (splitk < 1) splitk = 1;
+    if ((Cin / 8) % splitk != 0) return AIDE_ERR_ARG;
+    if (splitk > 1 && !ws) return AIDE_ERR_ARG;
+    a.splitk = splitk;
+    if (splitk > 1) {
+        a.y = ws; a.y_bs = (long)Cout * H * W; a.split_stride = (long)N * Cout * H * W;
+        a.bias = nullptr; a.accumulate = 0;
+    } else {
+        a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = accumulate;
+    }
+    const long nb = (long)a.blocks_w * a.blocks_h * N * a.n_co_tiles * splitk;
+    hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)nb), dim3(256), F4_LDS * sizeof(float), stream, a);
+    int rc = aide_launch_status();
+    if (rc != 0) return rc;
+    if (splitk > 1) {
+        const long total4 = (long)N * Cout * H * W / 4;
+        hipLaunchKernelGGL(w4_splitk_reduce_kernel, dim3((unsigned)min((total4 + 255) / 256, 4096L)), dim3(256), 0,
+                           stream, ws, (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias, accumulate,
+                           total4);
+        rc = aide_launch_status();
+    }
+    return rc;
+}
+
+}  // extern "C"

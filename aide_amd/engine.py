@@ -72,7 +72,21 @@ USE_WINOGRAD = [True]          # global switch (tests / A-B runs)
 USE_WINOGRAD_DGRAD = [True]    # ... for the dgrad direction only
 
 
-WINO_EXEC = 16.0 / 36.0     # multiplies a Winograd F(2x2,3x3) launch executes per algorithmic multiply
+# multiplies a launch executes per algorithmic (direct-convolution) multiply, by conv mode
+WINO_EXEC = 16.0 / 36.0
+EXEC_FRAC = {0: 1.0, 2: 16.0 / 36.0, 4: 36.0 / 144.0}
+USE_WINOGRAD4 = [True]
+
+
+def conv_mode(n, cin, h, w, cout):
+    """0 = direct implicit GEMM, 2 = Winograd F(2x2,3x3), 4 = Winograd F(4x4,3x3).  Static rule from the layer
+    sweep (tools/bench_conv.py wino): F(4x4) wins on every layer of >= 8 GFLOP and on the >= 128x128-channel
+    layers (1.3-1.5x over F(2x2) on the 19 / 39 GFLOP decoder layers); F(2x2) elsewhere; direct where neither
+    is supported."""
+    if USE_WINOGRAD[0] and USE_WINOGRAD4[0] and lib.aide_conv3x3_wino4_supported(cin, h, w, cout):
+        if 2.0 * n * h * w * cin * cout * 9 >= 8e9 or cin * cout >= 128 * 128:
+            return 4
+    return 2 if use_winograd(n, cin, h, w, cout) else 0
 
 
 def use_winograd(n, cin, h, w, cout):
@@ -143,17 +157,23 @@ class Plan(object):
                     need_dg = not src.root.is_input
                     # Winograd F(2x2,3x3) where it is supported and measured faster (16 MFMA-multiplies
                     # per output instead of 36); the direct implicit GEMM otherwise
-                    st['wino_f'] = use_winograd(n, cin, hh, ww, cout)
-                    st['wino_d'] = need_dg and USE_WINOGRAD_DGRAD[0] and use_winograd(n, cout, hh, ww, cin)
+                    st['wino_f'] = conv_mode(n, cin, hh, ww, cout)
+                    st['wino_d'] = conv_mode(n, cout, hh, ww, cin) if (need_dg and USE_WINOGRAD_DGRAD[0]) else 0
                     st['wf'] = st['wd'] = st['uf'] = st['ud'] = None
                     st['plan_f'] = st['plan_d'] = 0
-                    if st['wino_f']:
+                    if st['wino_f'] == 4:
+                        st['uf'] = torch.empty(cin, 36, cout, **f32)
+                        st['plan_f'] = lib.aide_conv3x3_wino4_splitk(n, cin, hh, ww, cout) << 8
+                    elif st['wino_f']:
                         st['uf'] = torch.empty(ops.pad_to(cin, 8), 16, cout, **f32)
                         st['plan_f'] = lib.aide_conv3x3_wino_splitk(n, cin, hh, ww, cout) << 8
                     else:
                         st['wf'] = torch.empty(ops.pad_to(cin, ops.conv_chunk(cin)), 9, cout, **f32)
                         st['plan_f'] = lib.aide_conv3x3_plan(n, cin, hh, ww, cout)
-                    if need_dg and st['wino_d']:
+                    if need_dg and st['wino_d'] == 4:
+                        st['ud'] = torch.empty(cout, 36, cin, **f32)
+                        st['plan_d'] = lib.aide_conv3x3_wino4_splitk(n, cout, hh, ww, cin) << 8
+                    elif need_dg and st['wino_d']:
                         st['ud'] = torch.empty(ops.pad_to(cout, 8), 16, cin, **f32)
                         st['plan_d'] = lib.aide_conv3x3_wino_splitk(n, cout, hh, ww, cin) << 8
                     elif need_dg:
@@ -239,16 +259,25 @@ class Plan(object):
             def tables(group):
                 direct = [(st['conv'].weight, st['wf'], st['wd']) for st in group
                           if st['wf'] is not None or st['wd'] is not None]
-                wino = [(st['conv'].weight, st['uf'], st['ud']) for st in group
-                        if st['uf'] is not None or st['ud'] is not None]
+                # a conv may use different modes forward and backward: each table gets only its own packs
+                wino = [(st['conv'].weight, st['uf'] if st['wino_f'] == 2 else None,
+                         st['ud'] if st['wino_d'] == 2 else None) for st in group
+                        if (st['uf'] is not None and st['wino_f'] == 2) or (st['ud'] is not None and st['wino_d'] == 2)]
+                wino4 = [(st['conv'].weight, st['uf'] if st['wino_f'] == 4 else None,
+                          st['ud'] if st['wino_d'] == 4 else None) for st in group
+                         if (st['uf'] is not None and st['wino_f'] == 4) or (st['ud'] is not None and st['wino_d'] == 4)]
                 return (ops.pack_table(direct, self.dev) if direct else None,
-                        ops.wino_pack_table(wino, self.dev) if wino else None)
+                        ops.wino_pack_table(wino, self.dev) if wino else None,
+                        ops.wino4_pack_table(wino4, self.dev) if wino4 else None)
             self._pack_tab = (ptrs, tables(convs[:split]), tables(convs[split:]) if len(convs) > split else None,
                               convs[split] if len(convs) > split else None)
         _, first, rest, gate = self._pack_tab
 
         def launch(tabs):
-            d, wn = tabs
+            d, wn, w4 = tabs
+            if w4 is not None:
+                ops.check(lib.aide_conv3x3_wino4_pack_multi(ops.ptr(w4[0]), w4[1], w4[2], ops.stream_ptr()),
+                          'conv3x3_wino4_pack_multi')
             if d is not None:
                 ops.check(lib.aide_conv3x3_pack_weights_multi(ops.ptr(d[0]), d[1], d[2], ops.stream_ptr()),
                           'conv3x3_pack_weights_multi')
@@ -279,8 +308,10 @@ class Plan(object):
                 x = self.view(st['src'], inputs)
                 prof = self.profiler
                 if prof is not None:
-                    prof.begin('conv3x3_igemm', st['flops'], st['flops'] * (WINO_EXEC if st['wino_f'] else 1.0))
-                if st['wino_f']:
+                    prof.begin('conv3x3_igemm', st['flops'], st['flops'] * EXEC_FRAC[st['wino_f']])
+                if st['wino_f'] == 4:
+                    ops.conv3x3_wino4(x, st['uf'], conv.bias, st['z'], splitk=st['plan_f'] >> 8, ws=self.sk_ws)
+                elif st['wino_f']:
                     ops.conv3x3_wino(x, st['uf'], conv.bias, st['z'], splitk=st['plan_f'] >> 8, ws=self.sk_ws)
                 else:
                     ops.conv3x3_igemm(x, st['wf'], conv.bias, st['z'], plan=st['plan_f'], ws=self.sk_ws)
@@ -367,8 +398,11 @@ class Plan(object):
                             prof.end()
                     if sg is not None:
                         if prof is not None:
-                            prof.begin('conv3x3_igemm', st['flops'], st['flops'] * (WINO_EXEC if st['wino_d'] else 1.0))
-                        if st['wino_d']:
+                            prof.begin('conv3x3_igemm', st['flops'], st['flops'] * EXEC_FRAC[st['wino_d']])
+                        if st['wino_d'] == 4:
+                            ops.conv3x3_wino4(dz, st['ud'], None, self.gview(st['src']),
+                                              accumulate=sg['accumulate'], splitk=st['plan_d'] >> 8, ws=self.sk_ws)
+                        elif st['wino_d']:
                             ops.conv3x3_wino(dz, st['ud'], None, self.gview(st['src']),
                                              accumulate=sg['accumulate'], splitk=st['plan_d'] >> 8, ws=self.sk_ws)
                         else:

@@ -308,6 +308,49 @@ def conv3x3_wino(x, u, bias, y, accumulate=False, splitk=-1, ws=None):
     return y
 
 
+# ---- Winograd F(4x4,3x3) (large layers) -------------------------------------------------------------
+def wino4_supported(cin, h, w, cout):
+    return bool(lib.aide_conv3x3_wino4_supported(cin, h, w, cout))
+
+
+def wino4_pack_table(entries, device):
+    """entries: list of (w, uf|None, ud|None). -> (device table, n, total_blocks) for aide_conv3x3_wino4_pack_multi."""
+    import struct
+    rec, start = b'', 0
+    for w, uf, ud in entries:
+        co, ci = w.shape[0], w.shape[1]
+        rec += struct.pack('<QQQiiiiq', w.data_ptr(), uf.data_ptr() if uf is not None else 0,
+                           ud.data_ptr() if ud is not None else 0, co, ci, 0, 0, start)
+        start += lib.aide_conv3x3_wino4_pack_blocks(co, ci)
+    return torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(device), len(entries), start
+
+
+def wino4_pack(w, need_dgrad=True):
+    """w [Co,Ci,3,3] -> (uf [Ci,36,Co], ud [Co,36,Ci] | None): 6x6 G g G^T of the (rotated) filters, channel-blocked by 4."""
+    _req(w)
+    co, ci = w.shape[0], w.shape[1]
+    uf = torch.empty(ci, 36, co, device=w.device, dtype=torch.float32)
+    ud = torch.empty(co, 36, ci, device=w.device, dtype=torch.float32) if need_dgrad else None
+    tab, n, blocks = wino4_pack_table([(w, uf, ud)], w.device)
+    check(lib.aide_conv3x3_wino4_pack_multi(ptr(tab), n, blocks, stream_ptr()), 'conv3x3_wino4_pack_multi')
+    return uf, ud
+
+
+def conv3x3_wino4(x, u, bias, y, accumulate=False, splitk=-1, ws=None):
+    xp, xbs = planes(x)
+    yp, ybs = planes(y)
+    n, cin, h, w = x.shape
+    cout = y.shape[1]
+    assert u.shape[1] == 36 and u.shape[2] == cout and u.shape[0] == cin
+    if splitk < 0:
+        splitk = lib.aide_conv3x3_wino4_splitk(n, cin, h, w, cout)
+    if splitk > 1 and ws is None:
+        ws = torch.empty(lib.aide_conv3x3_ws_bytes(n, h, w, cout, splitk) // 4, device=x.device, dtype=torch.float32)
+    check(lib.aide_conv3x3_wino4(xp, xbs, ptr(u), ptr(bias), yp, ybs, n, cin, h, w, cout, int(accumulate), splitk,
+                                 ptr(ws), stream_ptr()), 'conv3x3_wino4')
+    return y
+
+
 def wgrad_wino_supported(co, ci, h, w):
     return bool(lib.aide_conv3x3_wgrad_wino_supported(co, ci, h, w))
 

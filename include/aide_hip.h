@@ -41,6 +41,17 @@ int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, c
  * uf [ci_pad/8][16][Co][8 ci], ud [co_pad/8][16][Ci][8 co] (the tensors are allocated as [pad][16][C]). */
 int aide_conv3x3_wino_supported(int Cin, int H, int W, int Cout);
 int aide_conv3x3_wino_splitk(int N, int Cin, int H, int W, int Cout);
+/* Winograd F(4x4,3x3) variant for the large layers (36 multiplies per 16 outputs): H % 4 == 0, W % 4 == 0,
+ * H >= 16, W >= 32, Cout % 64 == 0, Cin % 8 == 0.  Filters: uf [Ci/4][36][Co][4 ci], ud [Co/4][36][Ci][4 co]
+ * (allocated as [C][36][C']); pack descriptors as above with {w, uf|0, ud|0, Co, Ci, 0, 0, block_start}.
+ * splitk must divide Cin / 8. */
+int aide_conv3x3_wino4_supported(int Cin, int H, int W, int Cout);
+int aide_conv3x3_wino4_splitk(int N, int Cin, int H, int W, int Cout);
+int aide_conv3x3_wino4_pack_blocks(int Co, int Ci);
+int aide_conv3x3_wino4_pack_multi(const void* descs, int n, int64_t total_blocks, aide_stream_t stream);
+int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float* bias, float* y, int64_t y_bs,
+                       int N, int Cin, int H, int W, int Cout, int accumulate, int splitk, float* ws,
+                       aide_stream_t stream);
 /* descs as above with {w, uf, ud}; an entry occupies aide_conv3x3_wino_pack_blocks(Co, Ci) workgroups */
 int aide_conv3x3_wino_pack_blocks(int Co, int Ci);
 int aide_conv3x3_wino_pack_multi(const void* descs, int n, int64_t total_blocks, aide_stream_t stream);

@@ -242,6 +242,38 @@ def test_conv3x3_winograd_fwd_dgrad(dev, case):
         _close(dx, xr.grad + 1.0, what='wino dgrad accumulate %s' % (case,))
 
 
+@pytest.mark.parametrize('case', [(2, 64, 64, 32, 32), (1, 128, 64, 64, 64), (2, 16, 128, 16, 32), (1, 256, 256, 32, 32),
+                                  (1, 64, 128, 80, 80), (1, 8, 64, 20, 44), (1, 96, 192, 40, 48), (2, 40, 64, 48, 36)])
+def test_conv3x3_winograd4_fwd_dgrad(dev, case):
+    """Winograd F(4x4,3x3) forward / dgrad vs aten, incl. ragged block edges (H % 16, W % 32 != 0), split-K,
+    accumulate.  F(4x4) transform constants reach 8: the bound is 1e-4 of the output scale (north star: 1e-3)."""
+    from aide_amd import ops
+    n, ci, co, h, w = case
+    assert ops.wino4_supported(ci, h, w, co)
+    g = torch.Generator().manual_seed(ci * 7 + co)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) * (1.0 / (3.0 * ci ** 0.5))
+    b = torch.randn(co, generator=g)
+    dy = torch.randn(n, co, h, w, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wt, b, padding=1)
+    yr.backward(dy)
+    uf, ud = ops.wino4_pack(wt.to(dev), need_dgrad=(ci % 64 == 0))
+    for splitk in (1, 2, 4):
+        if (ci // 8) % splitk:
+            continue
+        y = torch.full((n, co, h, w), 3.0, device=dev)
+        ops.conv3x3_wino4(x.to(dev), uf, b.to(dev), y, splitk=splitk)
+        _close(y, yr, rtol=1e-4, what='wino4 fwd splitk %d %s' % (splitk, case))
+    y = torch.empty(n, co, h, w, device=dev)
+    ops.conv3x3_wino4(x.to(dev), uf, b.to(dev), y)                # auto split-K
+    _close(y, yr, rtol=1e-4, what='wino4 fwd auto %s' % (case,))
+    if ud is not None:
+        dx = torch.ones(n, ci, h, w, device=dev)
+        ops.conv3x3_wino4(dy.to(dev), ud, None, dx, accumulate=True)
+        _close(dx, xr.grad + 1.0, rtol=1e-4, what='wino4 dgrad accumulate %s' % (case,))
+
+
 @pytest.mark.parametrize('case', [(2, 64, 64, 32, 32), (1, 128, 64, 64, 64), (2, 64, 128, 16, 16), (1, 256, 256, 16, 16),
                                   (1, 64, 128, 80, 80), (4, 512, 512, 16, 16), (1, 96, 160, 40, 24), (2, 64, 64, 6, 12)])
 def test_conv3x3_wgrad_winograd(dev, case):

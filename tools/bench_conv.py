@@ -78,6 +78,20 @@ def main():
                 sk = lib.aide_conv3x3_wino_splitk(N, co, h, h, ci)
                 t = timeit(lambda: ops.conv3x3_wino(dy, ud, None, dx, splitk=sk, ws=wsw))
                 line += ' WINO dgrad s%d %7.3f ms %6.1f TF |' % (sk, t, gf / t)
+        if mode in ('wino4', 'wino', 'all') and ops.wino4_supported(ci, h, h, co):
+            uf4, ud4 = ops.wino4_pack(w, need_dgrad=ci % 64 == 0)
+            wsw = torch.empty(1 << 26, device=dev)
+            for sk in sorted(set([lib.aide_conv3x3_wino4_splitk(N, ci, h, h, co)] + ([1, 2, 4, 8] if sweep else []))):
+                if (ci // 8) % sk:
+                    continue
+                t = timeit(lambda: ops.conv3x3_wino4(x, uf4, b, y, splitk=sk, ws=wsw))
+                line += ' F4 fwd s%d %7.3f ms %6.1f TF |' % (sk, t, gf / t)
+            tot.setdefault('wino4', 0.0); totf.setdefault('wino4', 0.0)
+            tot['wino4'] += t * cnt; totf['wino4'] += gf * cnt
+            if ud4 is not None:
+                sk = lib.aide_conv3x3_wino4_splitk(N, co, h, h, ci)
+                t = timeit(lambda: ops.conv3x3_wino4(dy, ud4, None, dx, splitk=sk, ws=wsw))
+                line += ' F4 dgrad s%d %7.3f ms %6.1f TF |' % (sk, t, gf / t)
         if mode in ('wgrad', 'all'):
             ws = torch.empty(lib.aide_conv3x3_wgrad_ws_bytes(N, co, ci, h, h) // 4, device=dev)
             t = timeit(lambda: ops.conv3x3_wgrad(dy, x, dw, ws=ws))
