@@ -292,40 +292,54 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs g
     }
 }
 
-// dW[co][ci][t] = sum_s slab[s][t][co][ci].  Block = 64 elements x 4 split-slices: every thread sums
-// a contiguous quarter of the splits (coalesced along ci), the four partial sums are combined in a
-// fixed order through LDS (deterministic).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, int Co,
-                                                           int Ci, float* __restrict__ dw) {
-    __shared__ float sm[4][64];
+// dW[co][ci][t] = sum_s slab[s][t][co][ci].  Block = 64 consecutive (co, ci) pairs x 9 taps x YG split
+// groups: thread (x, y) sums splits y, y + YG, ... for its 9 taps (nine independent coalesced 256-byte
+// row loads in flight per iteration), the YG partial sums are combined in a fixed order through LDS
+// (deterministic), and the 576 results leave as one contiguous run of the [co][ci][9] layout.
+template <int YG>
+__global__ __launch_bounds__(64 * YG) void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, int Co,
+                                                               int Ci, float* __restrict__ dw) {
+    __shared__ float sm[YG][9][64];
     const long cc = (long)Co * Ci, total = 9 * cc;
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
-    const long e = (long)blockIdx.x * 64 + x;                 // e = (t*Co + co)*Ci + ci
-    const int per = (splits + 3) / 4;
-    const int s0 = y * per, s1 = min(s0 + per, splits);
-    float v = 0.f;
-    if (e < total)
-        for (int s = s0; s < s1; ++s) v += slabs[(long)s * total + e];
-    sm[y][x] = v;
+    const long rem0 = (long)blockIdx.x * 64;
+    const bool ok = rem0 + x < cc;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    if (ok) {
+        const float* p = slabs + rem0 + x;
+#pragma unroll 2
+        for (int s = y; s < splits; s += YG) {
+            const float* q = p + (long)s * total;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] += q[t * cc];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sm[y][t][x] = acc[t];
     __syncthreads();
-    if (y == 0 && e < total) {
-        const float r = ((sm[0][x] + sm[1][x]) + sm[2][x]) + sm[3][x];
-        const long t = e / cc, rem = e - t * cc;              // rem = co*Ci + ci
-        dw[rem * 9 + t] = r;
+    const int n_out = (int)min(64L, cc - rem0) * 9;
+    for (int e = threadIdx.x; e < n_out; e += 64 * YG) {
+        const int xx = e / 9, t = e - xx * 9;
+        float r = sm[0][t][xx];
+#pragma unroll
+        for (int g = 1; g < YG; ++g) r += sm[g][t][xx];
+        dw[rem0 * 9 + e] = r;
     }
 }
 
-// few splits (the large-filter layers): one thread per element streams its <= 8 slab values
-__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ slabs, int splits,
-                                                                 int Co, int Ci, float* __restrict__ dw) {
-    const long cc = (long)Co * Ci, total = 9 * cc;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        float v = slabs[e];
-        for (int s = 1; s < splits; ++s) v += slabs[(long)s * total + e];
-        const long t = e / cc, rem = e - t * cc;
-        dw[rem * 9 + t] = v;
-    }
+static int launch_wgrad_reduce(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream) {
+    const unsigned nb = (unsigned)(((long)Co * Ci + 63) / 64);
+    if (splits >= 32)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(nb), dim3(1024), 0, stream, ws, splits, Co, Ci, dw);
+    else if (splits >= 3)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(nb), dim3(256), 0, stream, ws, splits, Co, Ci, dw);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(nb), dim3(64), 0, stream, ws, splits, Co, Ci, dw);
+    return aide_launch_status();
 }
+
 
 template <int WAVES_CO, int WAVES_CI, int WAVES_PX>
 int launch_wgrad(WgradArgs g, hipStream_t stream) {
@@ -396,14 +410,7 @@ int aide_conv3x3_wgrad(const float* dz, int64_t dz_bs, const float* a, int64_t a
         default: rc = launch_wgrad<1, 1, 4>(g, stream); break;
     }
     if (rc != 0) return rc;
-    const long total = 9L * Co * Ci;
-    if (g.splits <= 8)
-        hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0,
-                           stream, ws, g.splits, Co, Ci, dw);
-    else
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, ws,
-                           g.splits, Co, Ci, dw);
-    return aide_launch_status();
+    return launch_wgrad_reduce(ws, g.splits, Co, Ci, dw, stream);
 }
 
 }  // extern "C"
@@ -717,14 +724,7 @@ int aide_conv3x3_wgrad_wino(const float* dz, int64_t dz_bs, const float* a, int6
     hipLaunchKernelGGL(conv3x3_wgrad_wino_kernel, dim3((unsigned)nb), dim3(256), WW_LDS * sizeof(float), stream, g);
     int rc = aide_launch_status();
     if (rc != 0) return rc;
-    const long total = 9L * Co * Ci;
-    if (g.splits <= 8)
-        hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0,
-                           stream, ws, g.splits, Co, Ci, dw);
-    else
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, ws,
-                           g.splits, Co, Ci, dw);
-    return aide_launch_status();
+    return launch_wgrad_reduce(ws, g.splits, Co, Ci, dw, stream);
 }
 
 }  // extern "C"

@@ -62,56 +62,76 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
 }
 
 // partial[b][k][c] = sum over this block's pixels of dy[k] * x[c];  partial[b][K*C + k] = sum dy[k]
+// Channels are walked in groups of 8 ("channel" -1 = the bias: x == 1): eight 16-byte x loads in flight
+// per pixel quad and ONE block reduction (two barriers) per group instead of per channel.
 template <int K>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dy, long dy_bs,
                                                          const float* __restrict__ x, long x_bs, int C, int HW,
                                                          long total4, double* __restrict__ partials) {
-    __shared__ double sm[4][K + 1];
+    constexpr int G = 8;
+    __shared__ double sm[4][G * K];
     const int hw4 = HW / 4;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    // each thread keeps dy of its pixels; channels are walked in the outer loop so that the block
-    // reduction cost (K shuffles-trees per channel) is amortised over all of the block's pixels
     const int stride = gridDim.x * 256;
-    double bsum[K];
+    for (int c0 = -1; c0 < C; c0 += G) {
+        double acc[G][K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) bsum[k] = 0.0;
-    for (int c = -1; c < C; ++c) {
-        double acc[K];
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = 0.0;
+            for (int k = 0; k < K; ++k) acc[g][k] = 0.0;
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
             const long n = i / hw4, p = i - n * hw4;
-            f32x4 v = {1.f, 1.f, 1.f, 1.f};
-            if (c >= 0) v = *reinterpret_cast<const f32x4*>(x + n * x_bs + (long)c * HW + p * 4);
+            f32x4 gk[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const f32x4 g = *reinterpret_cast<const f32x4*>(dy + n * dy_bs + (long)k * HW + p * 4);
-                acc[k] += (double)(g[0] * v[0]) + (double)(g[1] * v[1]) + (double)(g[2] * v[2]) + (double)(g[3] * v[3]);
+            for (int k = 0; k < K; ++k) gk[k] = *reinterpret_cast<const f32x4*>(dy + n * dy_bs + (long)k * HW + p * 4);
+            f32x4 v[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int c = c0 + g;
+                v[g] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (c >= 0 && c < C) v[g] = *reinterpret_cast<const f32x4*>(x + n * x_bs + (long)c * HW + p * 4);
             }
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    acc[g][k] += (double)(gk[k][0] * v[g][0]) + (double)(gk[k][1] * v[g][1]) +
+                                 (double)(gk[k][2] * v[g][2]) + (double)(gk[k][3] * v[g][3]);
         }
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = wave_sum_d(acc[k]);
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[g][k] = wave_sum_d(acc[g][k]);
         __syncthreads();
         if (lane == 0)
 #pragma unroll
-            for (int k = 0; k < K; ++k) sm[wid][k] = acc[k];
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int k = 0; k < K; ++k) sm[wid][g * K + k] = acc[g][k];
         __syncthreads();
-        if (threadIdx.x < K) {
-            const double s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
-            const int slot = (c >= 0) ? threadIdx.x * C + c : K * C + threadIdx.x;
-            partials[(long)blockIdx.x * (K * C + K) + slot] = s;
+        if (threadIdx.x < G * K) {
+            const int g = threadIdx.x / K, k = threadIdx.x - g * K, c = c0 + g;
+            if (c < C) {
+                const double t = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+                const int slot = (c >= 0) ? k * C + c : K * C + k;
+                partials[(long)blockIdx.x * (K * C + K) + slot] = t;
+            }
         }
     }
 }
 
-__global__ void head_wgrad_finalize_kernel(const double* __restrict__ partials, int nblocks, int KC, int K,
-                                           float* __restrict__ dw, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= KC + K) return;
+// one wave per output: lanes stride over the per-block partials, fixed-order shuffle tree
+__global__ __launch_bounds__(64) void head_wgrad_finalize_kernel(const double* __restrict__ partials, int nblocks,
+                                                                 int KC, int K, float* __restrict__ dw,
+                                                                 float* __restrict__ db) {
+    const int i = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partials[(long)b * (KC + K) + i];
-    if (i < KC) dw[i] = (float)s;
-    else if (db) db[i - KC] = (float)s;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(long)b * (KC + K) + i];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) {
+        if (i < KC) dw[i] = (float)s;
+        else if (db) db[i - KC] = (float)s;
+    }
 }
 
 // ---------------------------------------------------------------- Adam (amsgrad), multi-tensor
@@ -206,7 +226,7 @@ int aide_head1x1_bwd(const float* dy, int64_t dy_bs, const float* x, int64_t x_b
         default: rc = head_wgrad_launch<4>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream);
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(head_wgrad_finalize_kernel, dim3((K * C + K + 63) / 64), dim3(64), 0, stream,
+    hipLaunchKernelGGL(head_wgrad_finalize_kernel, dim3(K * C + K), dim3(64), 0, stream,
                        (const double*)ws, nblocks, K * C, K, dw, db);
     return aide_launch_status();
 }
