@@ -292,17 +292,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(const WgradArgs g
     }
 }
 
-// dW[co][ci][t] = sum_s slab[s][t][co][ci].  Block = 64 consecutive (co, ci) pairs x 9 taps x YG split
-// groups: thread (x, y) sums splits y, y + YG, ... for its 9 taps (nine independent coalesced 256-byte
-// row loads in flight per iteration), the YG partial sums are combined in a fixed order through LDS
+// dW[co][ci][t] = sum_s slab[s][t][co][ci].  Block = R consecutive (co, ci) pairs x 9 taps x YG split
+// groups: thread (x, y) sums splits y, y + YG, ... for its 9 taps (nine independent coalesced row loads
+// in flight per iteration), the YG partial sums are combined in a fixed order through LDS
 // (deterministic), and the 576 results leave as one contiguous run of the [co][ci][9] layout.
-template <int YG>
-__global__ __launch_bounds__(64 * YG) void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, int Co,
-                                                               int Ci, float* __restrict__ dw) {
-    __shared__ float sm[YG][9][64];
+template <int R, int YG>
+__global__ __launch_bounds__(R * YG) void wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, int Co,
+                                                              int Ci, float* __restrict__ dw) {
+    __shared__ float sm[YG][9][R];
     const long cc = (long)Co * Ci, total = 9 * cc;
-    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
-    const long rem0 = (long)blockIdx.x * 64;
+    const int x = threadIdx.x % R, y = threadIdx.x / R;
+    const long rem0 = (long)blockIdx.x * R;
     const bool ok = rem0 + x < cc;
     float acc[9];
 #pragma unroll
@@ -319,24 +319,29 @@ __global__ __launch_bounds__(64 * YG) void wgrad_reduce_kernel(const float* __re
 #pragma unroll
     for (int t = 0; t < 9; ++t) sm[y][t][x] = acc[t];
     __syncthreads();
-    const int n_out = (int)min(64L, cc - rem0) * 9;
-    for (int e = threadIdx.x; e < n_out; e += 64 * YG) {
+    const int n_out = (int)min((long)R, cc - rem0) * 9;
+    for (int e = threadIdx.x; e < n_out; e += R * YG) {
         const int xx = e / 9, t = e - xx * 9;
         float r = sm[0][t][xx];
-#pragma unroll
+#pragma unroll 8
         for (int g = 1; g < YG; ++g) r += sm[g][t][xx];
         dw[rem0 * 9 + e] = r;
     }
 }
 
+// R (co, ci) pairs per block: 64 when that still gives >= 256 blocks, else 16 with more split groups
 static int launch_wgrad_reduce(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream) {
-    const unsigned nb = (unsigned)(((long)Co * Ci + 63) / 64);
-    if (splits >= 32)
-        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(nb), dim3(1024), 0, stream, ws, splits, Co, Ci, dw);
+    const long cc = (long)Co * Ci;
+    const bool narrow = cc / 64 < 256 && splits >= 16;
+    const unsigned nb = (unsigned)((cc + (narrow ? 15 : 63)) / (narrow ? 16 : 64));
+    if (narrow)
+        hipLaunchKernelGGL((wgrad_reduce_kernel<16, 64>), dim3(nb), dim3(1024), 0, stream, ws, splits, Co, Ci, dw);
+    else if (splits >= 32)
+        hipLaunchKernelGGL((wgrad_reduce_kernel<64, 16>), dim3(nb), dim3(1024), 0, stream, ws, splits, Co, Ci, dw);
     else if (splits >= 3)
-        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(nb), dim3(256), 0, stream, ws, splits, Co, Ci, dw);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<64, 4>), dim3(nb), dim3(256), 0, stream, ws, splits, Co, Ci, dw);
     else
-        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(nb), dim3(64), 0, stream, ws, splits, Co, Ci, dw);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<64, 1>), dim3(nb), dim3(64), 0, stream, ws, splits, Co, Ci, dw);
     return aide_launch_status();
 }
 

@@ -37,12 +37,12 @@ struct W4Args {
 };
 
 constexpr int F4_NAGPR = 16;               // accumulators (of 18) kept in the AGPR file; the rest are pinned to VGPRs
-constexpr int F4_RRS = 40;                 // raw row: [3 pad][-1][0..31][32][3 pad]
-constexpr int F4_RCS = 721;                // raw channel stride, odd: conflict-free patch reads over (ci, tile)
-constexpr int F4_RAW = 4 * F4_RCS;         // 2884 floats
+constexpr int F4_RRS = 41;                 // raw row: [3 pad][-1][0..31][32][4 pad]; odd: conflict-free raw stores
+constexpr int F4_RCS = 775;                // raw channel stride: (41, 775) makes patch reads AND raw stores conflict-free
+constexpr int F4_RAW = 4 * F4_RCS;         // 3100 floats
 constexpr int F4_V = 36 * 32 * 4;          // V[p][tile][4 ci]
 constexpr int F4_U = 36 * 64 * 4;          // U[p][co][4 ci]
-constexpr int F4_SET = F4_RAW + F4_V + F4_U;   // 16708 floats = 66832 B; two sets = 130.5 KB
+constexpr int F4_SET = F4_RAW + F4_V + F4_U;   // 16924 floats = 67696 B; two sets = 132.2 KB
 constexpr int F4_LDS = 2 * F4_SET > 4 * 128 * 64 ? 2 * F4_SET : 4 * 128 * 64;   // epilogue swap needs 32768
 
 // 1-D input transform B^T (F(4,3), points 0, +-1, +-2, inf), all six outputs
@@ -130,35 +130,50 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     // ---- input transform: thread = (half hs, ci, tile) ----
     const int item = tid & 127, hs = wid >> 1;             // hs is wave-uniform
     const int xr_off = (item & 3) * F4_RCS + (item >> 5) * 4 * F4_RRS + 3 + 4 * ((item >> 2) & 7);
-    float td[36], to[18];
-    auto xf_read = [&](int i, const float* raw) { td[i] = raw[xr_off + (i / 6) * F4_RRS + (i % 6)]; };
+    // patch rows as pairs of columns: the column pass is element-wise over columns -> v_pk_fma_f32 / v_pk_add_f32
+    f32x2 tp[6][3];
+    float to[18];
+    auto xf_read = [&](int i, const float* raw) {
+        const float v = raw[xr_off + (i / 6) * F4_RRS + (i % 6)];
+        if ((i % 6) & 1) tp[i / 6][(i % 6) >> 1].y = v; else tp[i / 6][(i % 6) >> 1].x = v;
+    };
     auto xf_half = [&](auto HS) {
-        // column pass: rows 3hs..3hs+2 of B^T d for each of the six columns, then full B^T along the rows
+        // column pass: rows 3hs..3hs+2 of B^T d for each pair of columns, then the full B^T along the rows
         constexpr int khs = decltype(HS)::value;
-        float t[18];
+        f32x2 T[3][3];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const float d0 = td[c], d1 = td[6 + c], d2 = td[12 + c], d3 = td[18 + c], d4 = td[24 + c], d5 = td[30 + c];
+        for (int cp = 0; cp < 3; ++cp) {
+            const f32x2 d0 = tp[0][cp], d1 = tp[1][cp], d2 = tp[2][cp], d3 = tp[3][cp], d4 = tp[4][cp], d5 = tp[5][cp];
             if (khs == 0) {
-                const float aa = __builtin_fmaf(-4.f, d2, d4), bb = __builtin_fmaf(4.f, d1, -d3);
-                t[c] = __builtin_fmaf(-5.f, d2, __builtin_fmaf(4.f, d0, d4));
-                t[6 + c] = aa - bb;
-                t[12 + c] = aa + bb;
+                const f32x2 aa = d4 - 4.f * d2, bb = 4.f * d1 - d3;
+                T[0][cp] = (4.f * d0 + d4) - 5.f * d2;
+                T[1][cp] = aa - bb;
+                T[2][cp] = aa + bb;
             } else {
-                const float cc = d4 - d2, ee = d3 - d1;
-                t[c] = __builtin_fmaf(2.f, ee, cc);
-                t[6 + c] = __builtin_fmaf(-2.f, ee, cc);
-                t[12 + c] = __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5));
+                const f32x2 cc = d4 - d2, ee = d3 - d1;
+                T[0][cp] = cc + 2.f * ee;
+                T[1][cp] = cc - 2.f * ee;
+                T[2][cp] = (4.f * d1 + d5) - 5.f * d3;
             }
         }
+        // row pass, six packed ops per row: (a, c) (b, e) (o1, o2) (o3, o4) (4 t0 + t4, 4 t1 + t5) (o0, o5)
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            bt6(t[6 * i], t[6 * i + 1], t[6 * i + 2], t[6 * i + 3], t[6 * i + 4], t[6 * i + 5], to + 6 * i, 1);
+        for (int i = 0; i < 3; ++i) {
+            const f32x2 t01 = T[i][0], t23 = T[i][1], t45 = T[i][2];
+            const f32x2 ac = f32x2{t23.x, t23.x} * f32x2{-4.f, -1.f} + f32x2{t45.x, t45.x};
+            const f32x2 be = f32x2{t01.y, t01.y} * f32x2{4.f, -1.f} + f32x2{-t23.y, t23.y};
+            const f32x2 o12 = f32x2{ac.x, ac.x} + f32x2{-be.x, be.x};
+            const f32x2 o34 = f32x2{be.y, be.y} * f32x2{2.f, -2.f} + f32x2{ac.y, ac.y};
+            const f32x2 o05 = t23 * f32x2{-5.f, -5.f} + (t01 * f32x2{4.f, 4.f} + t45);
+            to[6 * i] = o05.x; to[6 * i + 1] = o12.x; to[6 * i + 2] = o12.y;
+            to[6 * i + 3] = o34.x; to[6 * i + 4] = o34.y; to[6 * i + 5] = o05.y;
+        }
     };
     auto xf_math = [&]() {
         if (hs == 0) xf_half(ic<0>{}); else xf_half(ic<1>{});
     };
-    auto xf_store = [&](int o, float* vbuf) { vbuf[(18 * hs + o) * 128 + item] = to[o]; };
+    const int vitem = item ^ ((item >> 5) & 2);            // tiles 16-31: channel pairs swapped (fragment swizzle)
+    auto xf_store = [&](int o, float* vbuf) { vbuf[(18 * hs + o) * 128 + vitem] = to[o]; };
 
     f32x16 acc[18];
 #pragma unroll
@@ -191,8 +206,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     //   U[s+1] is fetched and stored into `sn`; raw[s+1] (already in sn.raw) is transformed into sn.V;
     //   raw[s+2] is fetched and stored into sc.raw (consumed by the previous stage's transform).
     auto stage = [&](int s, float* sc, float* sn) {
-        const float* la = sc + F4_RAW + F4_V + ((18 * ph) * 64 + cb * 32 + j) * 4 + half * 2;   // U[p][co][ci]
-        const float* lb = sc + F4_RAW + ((18 * ph) * 32 + j) * 4 + half * 2;                    // V[p][tile][ci]
+        // ds_read_b64 is serviced in lane groups {0-31} {32-63} over 64 banks: rows j and j + 16 of a
+        // [row][4] layout would share a bank pair, so rows with bit 4 set keep their two channel pairs swapped
+        const int fsw = (half ^ (j >> 4)) * 2;
+        const float* la = sc + F4_RAW + F4_V + ((18 * ph) * 64 + cb * 32 + j) * 4 + fsw;        // U[p][co][ci]
+        const float* lb = sc + F4_RAW + ((18 * ph) * 32 + j) * 4 + fsw;                         // V[p][tile][ci]
         // three rotating fragment sets, position pairs: (A0,B0,A1,B1) requested 4 slots ahead
         f32x2 fa[6], fb[6];
         auto frag = [&](int pi, int slot2) {
@@ -214,20 +232,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             // staging schedule: only slot 20 carries vector-ALU work
             //   0..12 global fetches (U[s+1] x9, raw[s+2] x4);  0..17 patch reads (2 per slot)
             //   20 transform;  21..29 V stores (2 per slot);  24..32 U stores;  31..35 raw stores (3 per slot)
+#ifndef AIDE_PROBE_4NOFETCH
             if (st < 9) fetch(st, s + 1);
             else if (st < 13) fetch(st, s + 2);
+#endif
+#ifndef AIDE_PROBE_4NOXF
             if (st < 18) { xf_read(2 * st, sn); xf_read(2 * st + 1, sn); }
             if (st == 20) xf_math();
             if (st >= 21 && st < 30) { xf_store(2 * (st - 21), sn + F4_RAW); xf_store(2 * (st - 21) + 1, sn + F4_RAW); }
+#endif
+#ifndef AIDE_PROBE_4NOFETCH
             if (st >= 24 && st < 33) put_u(st - 24, sn + F4_RAW + F4_V);
             if (st >= 31) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
                     if (3 * (st - 31) + q < 13) put_raw(3 * (st - 31) + q, sc);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifndef AIDE_PROBE_4NOBAR
         __syncthreads();
+#endif
     };
     // two stages per iteration, unconditionally (the host makes the stage count of a split even): with a
     // conditional second stage hipcc reconciles the accumulator registers of the two paths by copying them
@@ -357,7 +383,8 @@ struct W4PackDesc {
 
 // One workgroup transforms a 32 co x 32 ci filter tile (see wino_pack_multi_kernel): filters -> LDS, one
 // (co, ci) pair per thread and group, 36 runs of 128 floats per group of 4 channels:
-//   uf [ci/4][36][Co][4 ci]   ud [co/4][36][Ci][4 co] (taps reversed)
+//   uf [ci/4][36][Co][4 ci]   ud [co/4][36][Ci][4 co] (taps reversed); rows (co resp. ci) with bit 4 set
+//   hold their channels in the order 2,3,0,1
 constexpr int P4_T = 32, P4_ROW = P4_T * 9 + 1;
 __global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc* __restrict__ descs, int n) {
     __shared__ float wt[P4_T * P4_ROW];
@@ -394,8 +421,10 @@ __global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc*
 #pragma unroll
         for (int t = 0; t < 9; ++t) g[t] = wt[co * P4_ROW + ci * 9 + (fwd ? t : 8 - t)];
         wino4_g(g, u);
+        // rows with bit 4 set store their two channel pairs swapped (the kernel's ds_read_b64 bank swizzle)
+        const int otid = tid ^ ((hi5 >> 3) & 2);
 #pragma unroll
-        for (int p = 0; p < 36; ++p) ot[p * 128 + tid] = u[p];
+        for (int p = 0; p < 36; ++p) ot[p * 128 + otid] = u[p];
         __syncthreads();
         const int C = fwd ? d.Co : d.Ci, c0 = fwd ? co0 : ci0;
         const long gbase = (long)((fwd ? ci0 : co0) / 4 + q) * 36;

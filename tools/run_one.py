@@ -1,5 +1,5 @@
 """Run ONE conv kernel family on one shape a few times (target for rocprofv3 --pmc).
-usage: run_one.py {fwd|dgrad|wgrad|wino|wino_wgrad} Ci Co H [iters]"""
+usage: run_one.py {fwd|dgrad|wgrad|wino|wino4|wino_wgrad} Ci Co H [iters]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,11 +13,13 @@ dy = torch.randn(N, co, h, h, device=dev); y = torch.empty(N, co, h, h, device=d
 dx = torch.empty(N, ci, h, h, device=dev); dw = torch.empty(co, ci, 3, 3, device=dev)
 wf, wd = ops.pack_weights(w)
 uf, ud = ops.wino_pack(w)
+uf4, ud4 = ops.wino4_pack(w) if ops.wino4_supported(ci, h, h, co) else (None, None)
 ws = torch.empty(1 << 26, device=dev)
 for _ in range(iters):
     if mode == 'fwd': ops.conv3x3_igemm(x, wf, None, y, ws=ws)
     elif mode == 'dgrad': ops.conv3x3_igemm(dy, wd, None, dx, ws=ws)
     elif mode == 'wino': ops.conv3x3_wino(x, uf, None, y, ws=ws)
+    elif mode == 'wino4': ops.conv3x3_wino4(x, uf4, None, y, ws=ws)
     elif mode == 'wino_wgrad': ops.conv3x3_wgrad_wino(dy, x, dw, ws=ws)
     else: ops.conv3x3_wgrad(dy, x, dw, ws=ws)
 torch.cuda.synchronize()
