@@ -9,8 +9,10 @@
 // 36 positions x 16 accumulator registers do not fit one wave, so a (32 co x 32 tiles) block is shared by
 // TWO waves that own the transform rows 0-2 / 3-5 (18 positions = 288 accumulator registers each):
 //   * workgroup = 4 waves = 64 co x 32 tiles (8 x 4 tiles = 32 x 16 pixels) x 36 positions;
-//   * stage = 4 input channels: raw halo tile [4][18][40], U[36][64][4], V[36][32][4], all double
-//     buffered in LDS (131 KB); fragments are ds_read_b64 (channel q pairs with q+2 in the two K slots);
+//   * stage = 4 input channels: raw halo tile [4][18][41] and V[36][32][4] double buffered in LDS; the
+//     filter fragments are loaded global -> registers one stage ahead (each wave is the only consumer of its
+//     (positions, co) slice, so LDS staging would only add store traffic: ablation, -12 %); B fragments are
+//     ds_read_b64 (channel q pairs with q+2 in the two K slots);
 //   * the input transform is split the same way as the positions: a thread produces the 18 values of
 //     rows 0-2 (or 3-5) of B^T d B for one (ci, tile) — no exchange, both halves read the 6x6 patch;
 //   * the fp32 MFMA shares the vector-ALU pipe (tools/ubench/mfma_shadow.hip), so the loop carries no
@@ -28,7 +30,7 @@ template <int V> using ic = std::integral_constant<int, V>;
 
 struct W4Args {
     const float* x;
-    const float* u;      // [Cin/4][36][Cout][4]
+    const float* u;      // [Cin/4][36][2][Cout][2]  (stage, position, channel pair, co, channel of the pair)
     const float* bias;
     float* y;
     long x_bs, y_bs, split_stride;
@@ -41,8 +43,7 @@ constexpr int F4_RRS = 41;                 // raw row: [3 pad][-1][0..31][32][4 
 constexpr int F4_RCS = 775;                // raw channel stride: (41, 775) makes patch reads AND raw stores conflict-free
 constexpr int F4_RAW = 4 * F4_RCS;         // 3100 floats
 constexpr int F4_V = 36 * 32 * 4;          // V[p][tile][4 ci]
-constexpr int F4_U = 36 * 64 * 4;          // U[p][co][4 ci]
-constexpr int F4_SET = F4_RAW + F4_V + F4_U;   // 16924 floats = 67696 B; two sets = 132.2 KB
+constexpr int F4_SET = F4_RAW + F4_V;      // 7708 floats = 30832 B; two sets = 60.2 KB (filters never touch LDS)
 constexpr int F4_LDS = 2 * F4_SET > 4 * 128 * 64 ? 2 * F4_SET : 4 * 128 * 64;   // epilogue swap needs 32768
 
 // 1-D input transform B^T (F(4,3), points 0, +-1, +-2, inf), all six outputs
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     // ---- staging descriptors (stage-invariant) ----
     // raw interior: 4 ci x 18 rows x 8 float4 = 576 units (3 rounds, spare lanes repeat unit q - 256);
     // raw edges: 4 x 18 x 2 dwords = 144 units (1 round); U: 2304 float4 (9 rounds)
-    unsigned offB[3], ldsB[3], offC, ldsC, offU[9];
+    unsigned offB[3], ldsB[3], offC, ldsC;
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
         int q = tid + e * 256;
@@ -100,28 +101,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
         offC = ok ? (unsigned)(c * HW + r * a.W + (side ? 33 : 0)) * 4u : BUF_OOB;
         ldsC = (unsigned)(c * F4_RCS + r * F4_RRS + (side ? 36 : 3));
     }
-#pragma unroll
-    for (int v = 0; v < 9; ++v) {
-        const int f = tid + v * 256;                       // float4 index inside the [36][64 co][4 ci] block
-        offU[v] = (unsigned)((f >> 6) * a.Cout * 4 + (f & 63) * 4) * 4u;
-    }
     const __amdgpu_buffer_rsrc_t xrs =
         make_rsrc(a.x + (long)n * a.x_bs + (long)h0 * a.W + w0 - (a.W + 1));
-    const __amdgpu_buffer_rsrc_t urs = make_rsrc(a.u + (long)co0 * 4);
+    // Filter fragments go global -> registers, never through LDS: wave (cb, ph) is the only consumer of
+    // U[p in its half][co in its block], and the packed layout [stage][p][pair][Co][2] makes one position a
+    // contiguous 512-byte dwordx2 load in exactly the MFMA A-operand lane order (lane = pair * 32 + co).
+    const __amdgpu_buffer_rsrc_t urs = make_rsrc(a.u + ((long)18 * ph * 2 * a.Cout + co0 + cb * 32) * 2);
+    const unsigned uoff = (unsigned)(half * a.Cout + j) * 8u;
+    const unsigned upos = (unsigned)a.Cout * 16u;          // bytes per position
 
-    f32x4 rb[3], ru[9];
+    f32x4 rb[3];
     float rc;
-    auto fetch = [&](int l, int stage) {                   // l < 13: 9 U loads then 4 raw loads
-        if (l < 9) {
-            const unsigned us = (unsigned)min(stage, s_end - 1) * 36u * (unsigned)a.Cout * 16u;
-            ru[l] = buf_load_f32x4(urs, offU[l], us);
-        } else {
-            const unsigned xs = (unsigned)(min(stage, s_end - 1) * 4) * (unsigned)HW * 4u;
-            if (l < 12) rb[l - 9] = buf_load_f32x4(xrs, offB[l - 9], xs);
-            else rc = buf_load_f32(xrs, offC, xs);
-        }
+    f32x2 ua[2][18];                                       // A fragments of the current / next stage
+    auto fetch_u = [&](int pi, int stage, f32x2* dst) {
+        const unsigned us = ((unsigned)min(stage, s_end - 1) * 36u + (unsigned)pi) * upos;
+        dst[pi] = buf_load_f32x2(urs, uoff, us);
     };
-    auto put_u = [&](int v, float* ubuf) { *reinterpret_cast<f32x4*>(ubuf + (tid + v * 256) * 4) = ru[v]; };
+    auto fetch = [&](int l, int stage) {                   // 4 raw loads
+        const unsigned xs = (unsigned)(min(stage, s_end - 1) * 4) * (unsigned)HW * 4u;
+        if (l < 3) rb[l] = buf_load_f32x4(xrs, offB[l], xs);
+        else rc = buf_load_f32(xrs, offC, xs);
+    };
     auto put_raw = [&](int w, float* raw) {                // 13 dword stores (odd channel stride)
         if (w < 12) raw[ldsB[w >> 2] + (w & 3)] = rb[w >> 2][w & 3];
         else raw[ldsC] = rc;
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     // patch rows as pairs of columns: the column pass is element-wise over columns -> v_pk_fma_f32 / v_pk_add_f32
     f32x2 tp[6][3];
     float to[18];
-    auto xf_read = [&](int i, const float* raw) {
-        const float v = raw[xr_off + (i / 6) * F4_RRS + (i % 6)];
+    auto xf_read = [&](int i, int xo) {                    // xo = patch origin of this thread in a set
+        const float v = lds[xo + (i / 6) * F4_RRS + (i % 6)];
         if ((i % 6) & 1) tp[i / 6][(i % 6) >> 1].y = v; else tp[i / 6][(i % 6) >> 1].x = v;
     };
     auto xf_half = [&](auto HS) {
@@ -169,9 +169,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             to[6 * i + 3] = o34.x; to[6 * i + 4] = o34.y; to[6 * i + 5] = o05.y;
         }
     };
-    auto xf_math = [&]() {
-        if (hs == 0) xf_half(ic<0>{}); else xf_half(ic<1>{});
-    };
+    // The transform half is wave-uniform.  Everything from here on is instantiated once per half and
+    // selected by ONE branch: a branch inside the stage makes hipcc drain vmcnt to 0 at the join, i.e.
+    // wait for the filter fragments it has just requested.
+    auto run = [&](auto HS) {
+    auto xf_math = [&]() { xf_half(HS); };
     const int vitem = item ^ ((item >> 5) & 2);            // tiles 16-31: channel pairs swapped (fragment swizzle)
     auto xf_store = [&](int o, float* vbuf) { vbuf[(18 * hs + o) * 128 + vitem] = to[o]; };
 
@@ -183,18 +185,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
 
     float* const set0 = lds;
     float* const set1 = lds + F4_SET;
-    // ---- prologue: raw[s0] + U[s0] -> set0, transform -> set0.V; raw[s0+1] -> set1.raw ----
+    // per-set patch origins as live registers: with one base + a 30 KB constant hipcc pairs the reads into
+    // ds_read2_b32 (8-bit offsets) and re-derives the base with a v_add in every MFMA slot
+    int xr0 = xr_off, xr1 = F4_SET + xr_off;
+    asm volatile("" : "+v"(xr0), "+v"(xr1));
+    // ---- prologue: raw[s0] -> set0, U[s0] -> registers, transform -> set0.V; raw[s0+1] -> set1.raw ----
 #pragma unroll
-    for (int l = 0; l < 13; ++l) fetch(l, s_begin);
+    for (int l = 0; l < 4; ++l) fetch(l, s_begin);
+#pragma unroll
+    for (int pi = 0; pi < 18; ++pi) fetch_u(pi, s_begin, ua[0]);
 #pragma unroll
     for (int w = 0; w < 13; ++w) put_raw(w, set0);
 #pragma unroll
-    for (int v = 0; v < 9; ++v) put_u(v, set0 + F4_RAW + F4_V);
-#pragma unroll
-    for (int l = 9; l < 13; ++l) fetch(l, s_begin + 1);
+    for (int l = 0; l < 4; ++l) fetch(l, s_begin + 1);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 36; ++i) xf_read(i, set0);
+    for (int i = 0; i < 36; ++i) xf_read(i, xr0);
     xf_math();
 #pragma unroll
     for (int o = 0; o < 18; ++o) xf_store(o, set0 + F4_RAW);
@@ -202,21 +208,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     for (int w = 0; w < 13; ++w) put_raw(w, set1);
     __syncthreads();
 
-    // ---- main loop.  While the MFMAs consume (V, U) of set `sc` (stage s):
-    //   U[s+1] is fetched and stored into `sn`; raw[s+1] (already in sn.raw) is transformed into sn.V;
+    // ---- main loop.  While the MFMAs consume V of set `sc` and the A fragments ua[CUR] (stage s):
+    //   U[s+1] is fetched into ua[1 - CUR]; raw[s+1] (already in sn.raw) is transformed into sn.V;
     //   raw[s+2] is fetched and stored into sc.raw (consumed by the previous stage's transform).
-    auto stage = [&](int s, float* sc, float* sn) {
-        // ds_read_b64 is serviced in lane groups {0-31} {32-63} over 64 banks: rows j and j + 16 of a
-        // [row][4] layout would share a bank pair, so rows with bit 4 set keep their two channel pairs swapped
-        const int fsw = (half ^ (j >> 4)) * 2;
-        const float* la = sc + F4_RAW + F4_V + ((18 * ph) * 64 + cb * 32 + j) * 4 + fsw;        // U[p][co][ci]
-        const float* lb = sc + F4_RAW + ((18 * ph) * 32 + j) * 4 + fsw;                         // V[p][tile][ci]
-        // three rotating fragment sets, position pairs: (A0,B0,A1,B1) requested 4 slots ahead
-        f32x2 fa[6], fb[6];
-        auto frag = [&](int pi, int slot2) {
-            fa[slot2] = *reinterpret_cast<const f32x2*>(la + pi * 256);
-            fb[slot2] = *reinterpret_cast<const f32x2*>(lb + pi * 128);
-        };
+    auto stage = [&](int s, float* sc, float* sn, auto CUR) {
+        constexpr int kcur = decltype(CUR)::value;
+        // ds_read_b64 is serviced in lane groups {0-31} {32-63} over 64 banks: rows j and j + 16 of the
+        // [tile][4] layout would share a bank pair, so tiles 16-31 keep their two channel pairs swapped
+        const float* lb = sc + F4_RAW + ((18 * ph) * 32 + j) * 4 + (half ^ (j >> 4)) * 2;       // V[p][tile][ci]
+        f32x2 fb[6];                                       // B fragments, requested 4 slots ahead
+        auto frag = [&](int pi, int slot2) { fb[slot2] = *reinterpret_cast<const f32x2*>(lb + pi * 128); };
         frag(0, 0); frag(1, 1); frag(2, 2); frag(3, 3);
 #pragma unroll
         for (int st = 0; st < 36; ++st) {
@@ -224,25 +225,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             const int g = st >> 2, w = st & 3, pi = 2 * g + (w & 1), k = w >> 1;
             const int fs = pi % 6;
             if (w == 0 && pi + 4 < 18) { frag(pi + 4, (pi + 4) % 6); frag(pi + 5, (pi + 5) % 6); }
-            // 18 x 16 accumulator registers exceed the 256 AGPRs: positions 16 and 17 are pinned to VGPRs
-            // (hipcc otherwise shuffles whole accumulators between the two files every stage)
-            // (register classes are spelled out: 16 accumulators fill the AGPR file, fragments stay in VGPRs)
-            if (pi < F4_NAGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pi]) : "v"(fa[fs][k]), "v"(fb[fs][k]));
-            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[pi]) : "v"(fa[fs][k]), "v"(fb[fs][k]));
+            // 18 x 16 accumulator registers exceed the 256 AGPRs: positions 16 and 17 are pinned to VGPRs,
+            // and the register classes are spelled out (hipcc otherwise shuffles whole accumulators
+            // between the two files every stage)
+            if (pi < F4_NAGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pi]) : "v"(ua[kcur][pi][k]), "v"(fb[fs][k]));
+            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[pi]) : "v"(ua[kcur][pi][k]), "v"(fb[fs][k]));
             // staging schedule: only slot 20 carries vector-ALU work
-            //   0..12 global fetches (U[s+1] x9, raw[s+2] x4);  0..17 patch reads (2 per slot)
-            //   20 transform;  21..29 V stores (2 per slot);  24..32 U stores;  31..35 raw stores (3 per slot)
+            //   0..3 raw[s+2] global fetches, 4..21 U[s+1] fragment fetches;  0..17 patch reads (2 per slot)
+            //   20 transform;  21..29 V stores (2 per slot);  31..35 raw stores (3 per slot)
 #ifndef AIDE_PROBE_4NOFETCH
-            if (st < 9) fetch(st, s + 1);
-            else if (st < 13) fetch(st, s + 2);
+            if (st < 4) fetch(st, s + 2);
+            else if (st < 22) fetch_u(st - 4, s + 1, ua[1 - kcur]);
 #endif
 #ifndef AIDE_PROBE_4NOXF
-            if (st < 18) { xf_read(2 * st, sn); xf_read(2 * st + 1, sn); }
+            if (st < 18) { xf_read(2 * st, kcur ? xr0 : xr1); xf_read(2 * st + 1, kcur ? xr0 : xr1); }
             if (st == 20) xf_math();
             if (st >= 21 && st < 30) { xf_store(2 * (st - 21), sn + F4_RAW); xf_store(2 * (st - 21) + 1, sn + F4_RAW); }
 #endif
 #ifndef AIDE_PROBE_4NOFETCH
-            if (st >= 24 && st < 33) put_u(st - 24, sn + F4_RAW + F4_V);
             if (st >= 31) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     // two stages per iteration, unconditionally (the host makes the stage count of a split even): with a
     // conditional second stage hipcc reconciles the accumulator registers of the two paths by copying them
     for (int s = s_begin; s < s_end; s += 2) {
-        stage(s, set0, set1);
-        stage(s + 1, set1, set0);
+        stage(s, set0, set1, ic<0>{});
+        stage(s + 1, set1, set0, ic<1>{});
     }
 
     // ---- output transform.  Partial over this wave's rows i = 3ph..3ph+2:
@@ -328,6 +328,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
         }
     };
     if (ph == 0) epilogue(ic<0>{}); else epilogue(ic<1>{});
+    };   // run
+    if (hs == 0) run(ic<0>{}); else run(ic<1>{});
 }
 
 // y[n][c][p] (+)= bias[c] + sum_s slab[s][n][c][p], 16 bytes per thread, fixed summation order
@@ -383,8 +385,8 @@ struct W4PackDesc {
 
 // One workgroup transforms a 32 co x 32 ci filter tile (see wino_pack_multi_kernel): filters -> LDS, one
 // (co, ci) pair per thread and group, 36 runs of 128 floats per group of 4 channels:
-//   uf [ci/4][36][Co][4 ci]   ud [co/4][36][Ci][4 co] (taps reversed); rows (co resp. ci) with bit 4 set
-//   hold their channels in the order 2,3,0,1
+//   uf [ci/4][36][2][Co][2]   ud [co/4][36][2][Ci][2] (taps reversed): per (channel group, position) the two
+//   channel pairs as separate [row][2] runs = the A-operand lane order of the kernel's direct fragment loads
 constexpr int P4_T = 32, P4_ROW = P4_T * 9 + 1;
 __global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc* __restrict__ descs, int n) {
     __shared__ float wt[P4_T * P4_ROW];
@@ -421,20 +423,20 @@ __global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc*
 #pragma unroll
         for (int t = 0; t < 9; ++t) g[t] = wt[co * P4_ROW + ci * 9 + (fwd ? t : 8 - t)];
         wino4_g(g, u);
-        // rows with bit 4 set store their two channel pairs swapped (the kernel's ds_read_b64 bank swizzle)
-        const int otid = tid ^ ((hi5 >> 3) & 2);
+        // per position two runs (channel pair 0 / 1) of [row][2]: row = co (forward) resp. ci (dgrad)
+        const int otid = (lo2 >> 1) * 64 + hi5 * 2 + (lo2 & 1);
 #pragma unroll
         for (int p = 0; p < 36; ++p) ot[p * 128 + otid] = u[p];
         __syncthreads();
         const int C = fwd ? d.Co : d.Ci, c0 = fwd ? co0 : ci0;
         const long gbase = (long)((fwd ? ci0 : co0) / 4 + q) * 36;
-        const int nrun = min(P4_T, C - c0) * 4;
+        const int nrun = min(P4_T, C - c0) * 2;            // floats per run that exist
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int f = tid + k * 128, p = f >> 5, x4 = (f & 31) * 4;
+            const int f = tid + k * 128, p = f >> 5, hh = (f >> 4) & 1, x4 = (f & 15) * 4;
             if (x4 < nrun)
-                *reinterpret_cast<f32x4*>(dst + ((gbase + p) * C + c0) * 4 + x4) =
-                    *reinterpret_cast<const f32x4*>(ot + p * 128 + x4);
+                *reinterpret_cast<f32x4*>(dst + (((gbase + p) * 2 + hh) * C + c0) * 2 + x4) =
+                    *reinterpret_cast<const f32x4*>(ot + p * 128 + hh * 64 + x4);
         }
         __syncthreads();
     }
