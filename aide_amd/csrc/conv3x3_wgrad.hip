@@ -376,6 +376,12 @@ void wgrad_tiles(int variant, int Co, int Ci, int* nco, int* nci) {
 
 }  // namespace
 
+// shared with conv3x3_wgrad4.hip
+int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream) {
+    return launch_wgrad_reduce(ws, splits, Co, Ci, dw, stream);
+}
+
+
 extern "C" {
 
 // Number of pixel-range splits (= slabs) used for this problem.

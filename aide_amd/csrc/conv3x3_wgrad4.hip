@@ -1,0 +1,418 @@
+// 3x3 convolution weight gradient, transposed Winograd F(4x4,3x3) on fp32 MFMA (gfx950), for the large layers
+// (autograd of nn.Conv2d(ci, co, 3, padding=1): models_twomodalinputs/netblocks.py:17,24,26).
+//
+//   dW = G^T [ sum_tiles (A Z A^T) (.) (B^T D B) ] G      Z: 4x4 tile of dz, D: the 6x6 input patch around it
+//
+// 36 multiplies per (tile, co, ci) for 16 output pixels (direct: 144, F(2x2): 64).  Per transform position the sum
+// over tiles is a GEMM  M[p][co][ci] += ZT[p][co][tile] * V[p][ci][tile]  (K = tiles, two per MFMA).
+//   * workgroup = 64 co x 32 ci x 36 positions; as in conv3x3_wino4.hip a (32 x 32) block belongs to two partner
+//     waves that own transform rows 0-2 / 3-5 (18 accumulators: 16 in AGPRs, 2 pinned to VGPRs);
+//   * chunk = 4 horizontally adjacent tiles (4 rows x 16 pixels).  dz tiles go global -> registers (a thread
+//     owns one (co, tile) and produces all 36 values of A Z A^T); input patches go through a double-buffered raw
+//     LDS tile and are transformed by (ci, tile, row-half) threads; ZT[36][64][4] and V[36][32][4] are double
+//     buffered, fragments are swizzled ds_read_b64;
+//   * vector-ALU work (it shares the pipe with the fp32 MFMA) sits in three clusters per chunk, the
+//     wave-uniform role branch is hoisted around the whole loop;
+//   * output: each wave reduces its 18 positions to a partial 3x3 (G^T M G is linear in the rows of M), partner
+//     waves swap halves through LDS, the split's slab [9][Co][Ci] is written coalesced along ci and reduced by
+//     the fixed-order slab reduce (launch_wgrad_reduce, conv3x3_wgrad.hip).
+#include "common.h"
+#include <type_traits>
+
+int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream);
+
+namespace {
+
+template <int V> using ic = std::integral_constant<int, V>;
+
+struct G4Args {
+    const float* dz;
+    const float* a;
+    float* slabs;
+    long dz_bs, a_bs;
+    int N, Co, Ci, H, W;
+    int rows_t, cols_c, n_co_tiles, n_ci_tiles, splits, chunks_total;
+};
+
+constexpr int G4_NAGPR = 16;
+constexpr int G4_RS = 20;                  // raw input row: [-1][0..15][16][2 pad]: patch of tile t starts at 4 t (16-byte aligned)
+constexpr int G4_DS = 144;                 // raw channel stride (= 16 mod 64: conflict-free b128 patch reads)
+constexpr int G4_RAW = 32 * G4_DS;         // 4608 floats
+constexpr int G4_ZT = 36 * 64 * 4;         // ZT[p][co][4 tiles]
+constexpr int G4_V = 36 * 32 * 4;          // V[p][ci][4 tiles]
+constexpr int G4_SET = G4_ZT + G4_V;       // 13824 floats
+constexpr int G4_LDS = 2 * G4_SET + 2 * G4_RAW;   // 36864 floats = 144 KB (epilogue swap needs 4 x 72 x 64 = 18432)
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, j = lane & 31;
+    const int ph = wid & 1, cb = wid >> 1;                 // position half, co block of the MFMA role
+    const int hs = wid >> 1, vt_hi = wid & 1;              // input-transform role: row half, tile pair
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci_tile = b % g.n_ci_tiles; b /= g.n_ci_tiles;
+    const int co_tile = b % g.n_co_tiles;
+    const int split = b / g.n_co_tiles;
+    const int co0 = co_tile * 64, ci0 = ci_tile * 32;
+    const int HW = g.H * g.W;
+    const int cps = (g.chunks_total + g.splits - 1) / g.splits;
+    const int c_begin = split * cps, c_end = min(c_begin + cps, g.chunks_total);
+    const int c_stop = c_begin + ((max(c_end - c_begin, 0) + 1) & ~1);     // chunks are processed in pairs
+
+    const __amdgpu_buffer_rsrc_t drs = make_rsrc(g.dz + (long)co0 * HW);
+    const __amdgpu_buffer_rsrc_t ars = make_rsrc(g.a + (long)ci0 * HW - (g.W + 1));
+    const __amdgpu_buffer_rsrc_t nul = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dz), 0, 0, 0x00020000);
+
+    // ---- dz tiles: thread = (co_l, tile), four 16-byte row loads straight into registers ----
+    const int zco = 16 * wid + (lane >> 2), zt = lane & 3;
+    const unsigned offZ = (unsigned)(zco * HW + 4 * zt) * 4u;
+    // ---- raw input units: interior 32 ci x 6 rows x 4 float4 (3 rounds), edges 32 x 6 x 2 dwords (2 rounds) ----
+    // Which lanes must read zeros depends on the chunk (top / bottom image row, first / last column block) but
+    // the lane sets are fixed: they are kept as 64-bit lane masks in scalar registers, the per-chunk halo
+    // logic is scalar, and each of the 6 load offsets costs ONE v_cndmask per chunk.
+    typedef unsigned long long u64;
+    const int w_last = g.W - 16 * (g.cols_c - 1);          // valid pixels in the last column block (4..16)
+    unsigned offDi[3], ldsDi[3], offDe[2], ldsDe[2];
+    u64 mTopI[3], mBotI[3], mColI[3], mTopE[2], mBotE[2], mLeft[2], mRight[2];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int q = tid + e * 256, c = q / 24, rem = q - c * 24, r = rem >> 2, s4 = rem & 3;
+        offDi[e] = (unsigned)(c * HW + r * g.W + 1 + 4 * s4) * 4u;
+        ldsDi[e] = (unsigned)(c * G4_DS + r * G4_RS + 1 + 4 * s4);
+        mTopI[e] = __builtin_amdgcn_ballot_w64(r == 0);
+        mBotI[e] = __builtin_amdgcn_ballot_w64(r == 5);
+        mColI[e] = __builtin_amdgcn_ballot_w64(4 * s4 >= w_last);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        int q = tid + e * 256;
+        if (q >= 384) q -= 256;                            // spare lanes repeat a unit
+        const int c = q / 12, rem = q - c * 12, r = rem >> 1, side = rem & 1;
+        offDe[e] = (unsigned)(c * HW + r * g.W + (side ? 17 : 0)) * 4u;
+        ldsDe[e] = (unsigned)(c * G4_DS + r * G4_RS + (side ? 17 : 0));
+        mTopE[e] = __builtin_amdgcn_ballot_w64(r == 0);
+        mBotE[e] = __builtin_amdgcn_ballot_w64(r == 5);
+        mLeft[e] = __builtin_amdgcn_ballot_w64(side == 0);
+        mRight[e] = __builtin_amdgcn_ballot_w64(side == 1);
+    }
+    const u64 mColZ = __builtin_amdgcn_ballot_w64(4 * zt >= w_last);
+
+    // chunk cursors (scalar, advanced incrementally: no divisions in the loop): Z runs one chunk ahead of the
+    // MFMAs, D two chunks ahead
+    struct Cur { int c, cc, tr, n; };
+    auto cur_init = [&](int c) {
+        Cur k; k.c = c;
+        const int cl = min(c, g.chunks_total - 1);
+        k.cc = cl % g.cols_c; const int r2 = cl / g.cols_c; k.tr = r2 % g.rows_t; k.n = r2 / g.rows_t;
+        return k;
+    };
+    auto cur_next = [&](Cur& k) {
+        ++k.c;
+        if (++k.cc == g.cols_c) { k.cc = 0; if (++k.tr == g.rows_t) { k.tr = 0; ++k.n; } }
+    };
+    auto sel = [&](unsigned off, u64 bad) {                // off where the lane's bit in `bad` is clear, else OOB
+        unsigned r;
+        asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(off), "v"(BUF_OOB), "s"(bad));
+        return r;
+    };
+    f32x4 rz[4], rDi[3];
+    float rDe[2];
+    unsigned voZ, voD[5], dso = 0, aso = 0;
+    int liveZ = 0, liveD = 0;
+    // chunks past the end of the split (odd tail of the pair loop) read through an empty descriptor: zeros
+    auto prep_z = [&](const Cur& k) {
+        liveZ = k.c < c_end;
+        dso = (unsigned)((long)k.n * g.dz_bs + 4 * k.tr * g.W + 16 * k.cc) * 4u;
+        voZ = sel(offZ, k.cc == g.cols_c - 1 ? mColZ : 0ull);
+    };
+    auto prep_d = [&](const Cur& k) {
+        liveD = k.c < c_end;
+        aso = (unsigned)((long)k.n * g.a_bs + 4 * k.tr * g.W + 16 * k.cc) * 4u;
+        const bool top = k.tr == 0, bot = k.tr == g.rows_t - 1, first = k.cc == 0, last = k.cc == g.cols_c - 1;
+        const bool rbad = 16 * k.cc + 16 >= g.W;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+            voD[l] = sel(offDi[l], (top ? mTopI[l] : 0ull) | (bot ? mBotI[l] : 0ull) | (last ? mColI[l] : 0ull));
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            voD[3 + e] = sel(offDe[e], (top ? mTopE[e] : 0ull) | (bot ? mBotE[e] : 0ull) | (first ? mLeft[e] : 0ull) |
+                                           (rbad ? mRight[e] : 0ull));
+    };
+    auto fetch_z = [&](int r) { rz[r] = buf_load_f32x4(liveZ ? drs : nul, voZ, dso + (unsigned)(r * g.W) * 4u); };
+    auto fetch_d = [&](int l) {
+        if (l < 3) rDi[l] = buf_load_f32x4(liveD ? ars : nul, voD[l], aso);
+        else rDe[l - 3] = buf_load_f32(liveD ? ars : nul, voD[l], aso);
+    };
+    auto put_d = [&](int w, float* raw) {                  // 14 dword stores
+        if (w < 12) raw[ldsDi[w >> 2] + (w & 3)] = rDi[w >> 2][w & 3];
+        else raw[ldsDe[w - 12]] = rDe[w - 12];
+    };
+
+    // ---- input transform (B^T D B), thread = (row half hs, ci, tile) ----
+    const int vtile = lane & 3, vci = (lane >> 2) + 16 * vt_hi;
+    int xr0 = 2 * G4_SET + vci * G4_DS + 4 * vtile, xr1 = xr0 + G4_RAW;
+    asm volatile("" : "+v"(xr0), "+v"(xr1));
+    f32x2 tp[6][3];
+    float to[18];
+    auto v_read = [&](int r, int xo) {                     // one 16-byte + one 8-byte read per patch row
+        const f32x4 q = *reinterpret_cast<const f32x4*>(lds + xo + r * G4_RS);
+        const f32x2 e = *reinterpret_cast<const f32x2*>(lds + xo + r * G4_RS + 4);
+        tp[r][0] = f32x2{q[0], q[1]}; tp[r][1] = f32x2{q[2], q[3]}; tp[r][2] = e;
+    };
+    auto v_math = [&](auto HS) {
+        constexpr int khs = decltype(HS)::value;
+        f32x2 T[3][3];
+#pragma unroll
+        for (int cp = 0; cp < 3; ++cp) {
+            const f32x2 d0 = tp[0][cp], d1 = tp[1][cp], d2 = tp[2][cp], d3 = tp[3][cp], d4 = tp[4][cp], d5 = tp[5][cp];
+            if (khs == 0) {
+                const f32x2 aa = d4 - 4.f * d2, bb = 4.f * d1 - d3;
+                T[0][cp] = (4.f * d0 + d4) - 5.f * d2;
+                T[1][cp] = aa - bb;
+                T[2][cp] = aa + bb;
+            } else {
+                const f32x2 cc = d4 - d2, ee = d3 - d1;
+                T[0][cp] = cc + 2.f * ee;
+                T[1][cp] = cc - 2.f * ee;
+                T[2][cp] = (4.f * d1 + d5) - 5.f * d3;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x2 t01 = T[i][0], t23 = T[i][1], t45 = T[i][2];
+            const f32x2 ac = f32x2{t23.x, t23.x} * f32x2{-4.f, -1.f} + f32x2{t45.x, t45.x};
+            const f32x2 be = f32x2{t01.y, t01.y} * f32x2{4.f, -1.f} + f32x2{-t23.y, t23.y};
+            const f32x2 o12 = f32x2{ac.x, ac.x} + f32x2{-be.x, be.x};
+            const f32x2 o34 = f32x2{be.y, be.y} * f32x2{2.f, -2.f} + f32x2{ac.y, ac.y};
+            const f32x2 o05 = t23 * f32x2{-5.f, -5.f} + (t01 * f32x2{4.f, 4.f} + t45);
+            to[6 * i] = o05.x; to[6 * i + 1] = o12.x; to[6 * i + 2] = o12.y;
+            to[6 * i + 3] = o34.x; to[6 * i + 4] = o34.y; to[6 * i + 5] = o05.y;
+        }
+    };
+    // operand rows are [channel][4 tiles]; rows with bit 4 set keep their two tile pairs swapped (ds_read_b64 banks)
+    const int vpos = vci * 4 + (((vtile >> 1) ^ ((vci >> 4) & 1)) * 2 + (vtile & 1));
+    auto v_store = [&](int o, float* vbuf) { vbuf[(18 * hs + o) * 128 + vpos] = to[o]; };
+
+    // ---- dz transform (A Z A^T), thread = (co_l, tile), all 36 values ----
+    float zo[36];
+    auto z_math = [&]() {
+        // column pass over column pairs: y0 = z0, y1/y2 = (z0 + z2) +- (z1 + z3), y3/y4 = (z0 + 4 z2) +- 2 (z1 + 4 z3), y5 = z3
+        f32x2 Y[6][2];
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            const f32x2 z0 = f32x2{rz[0][2 * cp], rz[0][2 * cp + 1]}, z1 = f32x2{rz[1][2 * cp], rz[1][2 * cp + 1]},
+                        z2 = f32x2{rz[2][2 * cp], rz[2][2 * cp + 1]}, z3 = f32x2{rz[3][2 * cp], rz[3][2 * cp + 1]};
+            const f32x2 s02 = z0 + z2, s13 = z1 + z3, aa = z0 + 4.f * z2, bb = z1 + 4.f * z3;
+            Y[0][cp] = z0; Y[1][cp] = s02 + s13; Y[2][cp] = s02 - s13;
+            Y[3][cp] = aa + 2.f * bb; Y[4][cp] = aa - 2.f * bb; Y[5][cp] = z3;
+        }
+        // row pass, four packed ops per row: (s02, a) (s13, b) (o1, o2) (o3, o4); o0 = t0, o5 = t3
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const f32x2 t01 = Y[i][0], t23 = Y[i][1];
+            const f32x2 sa = f32x2{t23.x, t23.x} * f32x2{1.f, 4.f} + f32x2{t01.x, t01.x};
+            const f32x2 sb = f32x2{t23.y, t23.y} * f32x2{1.f, 4.f} + f32x2{t01.y, t01.y};
+            const f32x2 o12 = f32x2{sa.x, sa.x} + f32x2{sb.x, -sb.x};
+            const f32x2 o34 = f32x2{sb.y, sb.y} * f32x2{2.f, -2.f} + f32x2{sa.y, sa.y};
+            zo[6 * i] = t01.x; zo[6 * i + 1] = o12.x; zo[6 * i + 2] = o12.y;
+            zo[6 * i + 3] = o34.x; zo[6 * i + 4] = o34.y; zo[6 * i + 5] = t23.y;
+        }
+    };
+    const int zpos = zco * 4 + (((zt >> 1) ^ ((zco >> 4) & 1)) * 2 + (zt & 1));
+    auto z_store = [&](int o, float* zbuf) { zbuf[o * 256 + zpos] = zo[o]; };
+
+    float* const set0 = lds;
+    float* const set1 = lds + G4_SET;
+    float* const raw0 = lds + 2 * G4_SET;
+    float* const raw1 = raw0 + G4_RAW;
+
+    auto run = [&](auto HS) {
+    f32x16 acc[18];
+#pragma unroll
+    for (int p = 0; p < 18; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+
+    // ---- prologue: chunk c0 -> set0 (ZT, V); raw input of c0 + 1 -> raw1; dz of c0 + 1 is fetched in the loop ----
+    Cur kz = cur_init(c_begin), kd = cur_init(c_begin);
+    prep_z(kz); prep_d(kd);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fetch_z(r);
+#pragma unroll
+    for (int l = 0; l < 5; ++l) fetch_d(l);
+#pragma unroll
+    for (int w = 0; w < 14; ++w) put_d(w, raw0);
+    cur_next(kd);
+    prep_d(kd);
+#pragma unroll
+    for (int l = 0; l < 5; ++l) fetch_d(l);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 6; ++r) v_read(r, xr0);
+    v_math(HS);
+#pragma unroll
+    for (int o = 0; o < 18; ++o) v_store(o, set0 + G4_ZT);
+    z_math();
+#pragma unroll
+    for (int o = 0; o < 36; ++o) z_store(o, set0);
+#pragma unroll
+    for (int w = 0; w < 14; ++w) put_d(w, raw1);
+    __syncthreads();
+
+    // ---- main loop.  While the MFMAs consume set `sc` (chunk c):
+    //   dz tiles of c + 1 are fetched into registers, transformed and stored to sn.ZT;
+    //   the raw input of c + 1 (in rawn) is transformed into sn.V;
+    //   the raw input of c + 2 is fetched and stored into rawc (consumed by the previous chunk's transform).
+    auto chunk = [&](int c, float* sc, float* sn, float* rawc, auto CUR) {
+        constexpr int kcur = decltype(CUR)::value;
+        const float* la = sc + ((18 * ph) * 64 + cb * 32 + j) * 4 + (half ^ (j >> 4)) * 2;       // ZT[p][co][tiles]
+        const float* lb = sc + G4_ZT + ((18 * ph) * 32 + j) * 4 + (half ^ (j >> 4)) * 2;        // V[p][ci][tiles]
+        f32x2 fa[6], fb[6];
+        auto frag = [&](int pi, int s2) {
+            fa[s2] = *reinterpret_cast<const f32x2*>(la + pi * 256);
+            fb[s2] = *reinterpret_cast<const f32x2*>(lb + pi * 128);
+        };
+        frag(0, 0); frag(1, 1); frag(2, 2); frag(3, 3);
+#pragma unroll
+        for (int st = 0; st < 36; ++st) {
+            const int gq = st >> 2, w = st & 3, pi = 2 * gq + (w & 1), k = w >> 1;
+            const int fs = pi % 6;
+            if (w == 0 && pi + 4 < 18) { frag(pi + 4, (pi + 4) % 6); frag(pi + 5, (pi + 5) % 6); }
+            if (pi < G4_NAGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pi]) : "v"(fa[fs][k]), "v"(fb[fs][k]));
+            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[pi]) : "v"(fa[fs][k]), "v"(fb[fs][k]));
+            // schedule (vector-ALU work only in slots 0, 14 and 20):
+            //   0 offsets;  0..3 dz[c+1] loads, 4..8 raw[c+2] loads;  1..6 patch reads
+            //   14 input transform, 15..23 V stores;  20 dz transform, 21..32 ZT stores (3 per slot)
+            //   31..35 raw[c+2] stores (3 per slot)
+            if (st == 0) { cur_next(kz); prep_z(kz); }
+            if (st < 4) fetch_z(st);
+            if (st == 3) { cur_next(kd); prep_d(kd); }
+            if (st >= 4 && st < 9) fetch_d(st - 4);
+            if (st >= 1 && st < 7) v_read(st - 1, kcur ? xr0 : xr1);
+            if (st == 14) v_math(HS);
+            if (st >= 15 && st < 24) { v_store(2 * (st - 15), sn + G4_ZT); v_store(2 * (st - 15) + 1, sn + G4_ZT); }
+            if (st == 20) z_math();
+            if (st >= 21 && st < 33) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) z_store(3 * (st - 21) + q, sn);
+            }
+            if (st >= 31) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (3 * (st - 31) + q < 14) put_d(3 * (st - 31) + q, rawc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    for (int c = c_begin; c < c_stop; c += 2) {
+        chunk(c, set0, set1, raw0, ic<0>{});
+        chunk(c + 1, set1, set0, raw1, ic<1>{});
+    }
+
+    // ---- dW = G^T M G.  Partial over this wave's rows i = 3ph..3ph+2:
+    //   T[i][b] = sum_c M[i][c] G[c][b];   dWp[a][b] = sum_i G[i][a] T[i][b]
+    float* xbuf = lds;
+    float* slab = g.slabs + (long)split * 9 * g.Co * g.Ci;
+    const int ci = ci0 + j;
+    auto epilogue = [&](auto PH) {
+        constexpr int kph = decltype(PH)::value;
+        auto partial = [&](int r, float* wp) {
+            float T[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float m0 = acc[6 * i][r], m1 = acc[6 * i + 1][r], m2 = acc[6 * i + 2][r],
+                            m3 = acc[6 * i + 3][r], m4 = acc[6 * i + 4][r], m5 = acc[6 * i + 5][r];
+                const float s12 = m1 + m2, d21 = m2 - m1, s34 = m3 + m4, d34 = m3 - m4;
+                T[i][0] = 0.25f * m0 - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+                T[i][1] = (1.f / 6.f) * d21 + (1.f / 12.f) * d34;
+                T[i][2] = (1.f / 6.f) * (s34 - s12) + m5;
+            }
+#pragma unroll
+            for (int bq = 0; bq < 3; ++bq) {
+                if (kph == 0) {                             // G rows 0,1,2: (1/4,0,0) (-1/6,-1/6,-1/6) (-1/6,1/6,-1/6)
+                    const float sm = T[1][bq] + T[2][bq];
+                    wp[bq] = 0.25f * T[0][bq] - (1.f / 6.f) * sm;
+                    wp[3 + bq] = (1.f / 6.f) * (T[2][bq] - T[1][bq]);
+                    wp[6 + bq] = -(1.f / 6.f) * sm;
+                } else {                                    // G rows 3,4,5: (1/24,1/12,1/6) (1/24,-1/12,1/6) (0,0,1)
+                    const float sm = T[0][bq] + T[1][bq];
+                    wp[bq] = (1.f / 24.f) * sm;
+                    wp[3 + bq] = (1.f / 12.f) * (T[0][bq] - T[1][bq]);
+                    wp[6 + bq] = (1.f / 6.f) * sm + T[2][bq];
+                }
+            }
+        };
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            float wp[9];
+            partial(rr + 8 * (1 - kph), wp);               // the partner's rows
+#pragma unroll
+            for (int o = 0; o < 9; ++o) xbuf[((wid * 72) + rr * 9 + o) * 64 + lane] = wp[o];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = rr + 8 * kph;
+            float wp[9];
+            partial(r, wp);
+            const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+            for (int o = 0; o < 9; ++o)
+                slab[((long)o * g.Co + co) * g.Ci + ci] = wp[o] + xbuf[(((wid ^ 1) * 72) + rr * 9 + o) * 64 + lane];
+        }
+    };
+    if (ph == 0) epilogue(ic<0>{}); else epilogue(ic<1>{});
+    };   // run
+    if (hs == 0) run(ic<0>{}); else run(ic<1>{});
+}
+
+}  // namespace
+
+extern "C" {
+
+int aide_conv3x3_wgrad_wino4_supported(int Co, int Ci, int H, int W) {
+    return (H % 4 == 0 && W % 4 == 0 && H >= 8 && W >= 16 && Co % 64 == 0 && Ci % 32 == 0) ? 1 : 0;
+}
+
+int aide_conv3x3_wgrad_wino4_splits(int N, int Co, int Ci, int H, int W) {
+    const long blocks = (long)(Co / 64) * (Ci / 32);
+    const long chunks = (long)N * (H / 4) * ((W + 15) / 16);
+    long s = (256 + blocks - 1) / blocks;
+    if (s > chunks / 2) s = chunks / 2;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+size_t aide_conv3x3_wgrad_wino4_ws_bytes(int N, int Co, int Ci, int H, int W) {
+    return (size_t)aide_conv3x3_wgrad_wino4_splits(N, Co, Ci, H, W) * 9 * Co * Ci * sizeof(float);
+}
+
+// dw [Co][Ci][3][3] = sum over images and pixels of dz (x) shifted input; ws: aide_conv3x3_wgrad_wino4_ws_bytes()
+int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
+                             int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
+    if (!dz || !a || !dw || !ws || N <= 0 || !aide_conv3x3_wgrad_wino4_supported(Co, Ci, H, W) || dz_bs % 4 || a_bs % 4)
+        return AIDE_ERR_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  G4_LDS * (int)sizeof(float));
+        attr_set = true;
+    }
+    G4Args g;
+    g.dz = dz; g.a = a; g.slabs = ws; g.dz_bs = dz_bs; g.a_bs = a_bs;
+    g.N = N; g.Co = Co; g.Ci = Ci; g.H = H; g.W = W;
+    g.rows_t = H / 4; g.cols_c = (W + 15) / 16;
+    g.n_co_tiles = Co / 64; g.n_ci_tiles = Ci / 32;
+    g.chunks_total = N * g.rows_t * g.cols_c;
+    g.splits = aide_conv3x3_wgrad_wino4_splits(N, Co, Ci, H, W);
+    const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
+    hipLaunchKernelGGL(conv3x3_wgrad4_kernel, dim3((unsigned)nb), dim3(256), G4_LDS * sizeof(float), stream, g);
+    const int rc = aide_launch_status();
+    if (rc != 0) return rc;
+    return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, stream);
+}
+
+}  // extern "C"

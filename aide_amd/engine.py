@@ -181,9 +181,17 @@ class Plan(object):
                         st['plan_d'] = lib.aide_conv3x3_plan(n, cout, hh, ww, cin)
                     max_sk = max(max_sk, lib.aide_conv3x3_ws_bytes(n, hh, ww, cout, st['plan_f'] >> 8),
                                  lib.aide_conv3x3_ws_bytes(n, hh, ww, cin, st['plan_d'] >> 8) if need_dg else 0)
-                    st['wino_w'] = bool(USE_WINOGRAD[0] and lib.aide_conv3x3_wgrad_wino_supported(cout, cin, hh, ww))
-                    max_wg = max(max_wg, lib.aide_conv3x3_wgrad_wino_ws_bytes(n, cout, cin, hh, ww) if st['wino_w']
-                                 else lib.aide_conv3x3_wgrad_ws_bytes(n, cout, cin, hh, ww))
+                    # weight gradient: transposed F(4x4,3x3) wherever supported (ahead on every layer of the sweep),
+                    # else transposed F(2x2,3x3), else the direct kernel
+                    if USE_WINOGRAD[0] and USE_WINOGRAD4[0] and lib.aide_conv3x3_wgrad_wino4_supported(cout, cin, hh, ww):
+                        st['wino_w'] = 4
+                        max_wg = max(max_wg, lib.aide_conv3x3_wgrad_wino4_ws_bytes(n, cout, cin, hh, ww))
+                    elif USE_WINOGRAD[0] and lib.aide_conv3x3_wgrad_wino_supported(cout, cin, hh, ww):
+                        st['wino_w'] = 2
+                        max_wg = max(max_wg, lib.aide_conv3x3_wgrad_wino_ws_bytes(n, cout, cin, hh, ww))
+                    else:
+                        st['wino_w'] = 0
+                        max_wg = max(max_wg, lib.aide_conv3x3_wgrad_ws_bytes(n, cout, cin, hh, ww))
                     st['pack_key'] = None
                     st['flops'] = 2.0 * n * hh * ww * cout * cin * 9      # algorithmic, per launch
                 else:
@@ -383,7 +391,8 @@ class Plan(object):
                 x = self.view(st['src'], inputs)
                 if kind == 'conv':
                     prof = self.profiler
-                    wgrad = ops.conv3x3_wgrad_wino if st['wino_w'] else ops.conv3x3_wgrad
+                    wgrad = (ops.conv3x3_wgrad_wino4 if st['wino_w'] == 4 else
+                             ops.conv3x3_wgrad_wino if st['wino_w'] else ops.conv3x3_wgrad)
                     if side is not None:
                         ev = torch.cuda.Event()
                         ev.record(main)
@@ -392,7 +401,7 @@ class Plan(object):
                             wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
                     else:
                         if prof is not None:
-                            prof.begin('conv3x3_wgrad', st['flops'], st['flops'] * (WINO_EXEC if st['wino_w'] else 1.0))
+                            prof.begin('conv3x3_wgrad', st['flops'], st['flops'] * EXEC_FRAC[st['wino_w']])
                         wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
                         if prof is not None:
                             prof.end()

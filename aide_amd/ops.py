@@ -351,6 +351,23 @@ def conv3x3_wino4(x, u, bias, y, accumulate=False, splitk=-1, ws=None):
     return y
 
 
+def wgrad_wino4_supported(co, ci, h, w):
+    return bool(lib.aide_conv3x3_wgrad_wino4_supported(co, ci, h, w))
+
+
+def conv3x3_wgrad_wino4(dz, a, dw, ws=None):
+    """dw [Co,Ci,3,3] <- weight gradient via the transposed Winograd F(4x4,3x3) kernel."""
+    dzp, dzbs = planes(dz)
+    ap, abs_ = planes(a)
+    n, co, h, w = dz.shape
+    ci = a.shape[1]
+    if ws is None:
+        ws = torch.empty(lib.aide_conv3x3_wgrad_wino4_ws_bytes(n, co, ci, h, w) // 4, device=dz.device, dtype=torch.float32)
+    check(lib.aide_conv3x3_wgrad_wino4(dzp, dzbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), stream_ptr()),
+          'conv3x3_wgrad_wino4')
+    return dw
+
+
 def wgrad_wino_supported(co, ci, h, w):
     return bool(lib.aide_conv3x3_wgrad_wino_supported(co, ci, h, w))
 

@@ -71,6 +71,12 @@ int aide_conv3x3_wgrad_wino_splits(int N, int Co, int Ci, int H, int W);
 size_t aide_conv3x3_wgrad_wino_ws_bytes(int N, int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_wino(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
                             int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
+/* transposed F(4x4,3x3) for the large layers: H % 4 == 0, W % 4 == 0, H >= 8, W >= 16, Co % 64 == 0, Ci % 32 == 0 */
+int aide_conv3x3_wgrad_wino4_supported(int Co, int Ci, int H, int W);
+int aide_conv3x3_wgrad_wino4_splits(int N, int Co, int Ci, int H, int W);
+size_t aide_conv3x3_wgrad_wino4_ws_bytes(int N, int Co, int Ci, int H, int W);
+int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
+                             int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
 
 /* ---- ConvTranspose2d(k=2, s=2) (learned_bilinear=True up path) ---------------------------------
  * replaces nn.ConvTranspose2d: netblocks.py:12, UNet.py:7 */

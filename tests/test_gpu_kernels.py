@@ -295,3 +295,26 @@ def test_conv3x3_wgrad_winograd(dev, case):
     F.conv2d(big[:, 32:], wt2, None, padding=1).backward(dy)
     ops.conv3x3_wgrad_wino(dy.to(dev), big.to(dev)[:, 32:], dw)
     _close(dw, wt2.grad, what='wino wgrad slice %s' % (case,))
+
+
+@pytest.mark.parametrize('case', [(2, 64, 64, 32, 32), (1, 128, 64, 64, 64), (2, 32, 128, 16, 16), (1, 256, 256, 32, 32),
+                                  (1, 64, 128, 80, 80), (3, 32, 64, 8, 16), (1, 96, 192, 40, 24), (2, 64, 64, 12, 36)])
+def test_conv3x3_wgrad_winograd4(dev, case):
+    """Weight gradient via the transposed Winograd F(4x4,3x3) vs aten, incl. ragged column blocks (W % 16 != 0),
+    odd chunk counts per split and channel-slice operands.  Bound 1e-4 of the gradient scale (north star: 1e-3)."""
+    from aide_amd import ops
+    n, ci, co, h, w = case
+    assert ops.wgrad_wino4_supported(co, ci, h, w)
+    g = torch.Generator().manual_seed(ci + 3 * co)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    dy = torch.randn(n, co, h, w, generator=g)
+    F.conv2d(x, wt, None, padding=1).backward(dy)
+    dw = torch.empty(co, ci, 3, 3, device=dev)
+    ops.conv3x3_wgrad_wino4(dy.to(dev), x.to(dev), dw)
+    _close(dw, wt.grad, rtol=1e-4, what='wino4 wgrad %s' % (case,))
+    big = torch.randn(n, ci + 32, h, w, generator=g)
+    wt2 = (torch.randn(co, ci, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    F.conv2d(big[:, 32:], wt2, None, padding=1).backward(dy)
+    ops.conv3x3_wgrad_wino4(dy.to(dev), big.to(dev)[:, 32:], dw)
+    _close(dw, wt2.grad, rtol=1e-4, what='wino4 wgrad slice %s' % (case,))

@@ -12,6 +12,8 @@ if mode == 'wino4':
     u, _ = ops.wino4_pack(w); f = lambda: ops.conv3x3_wino4(x, u, None, y, ws=ws)
 elif mode == 'wino':
     u, _ = ops.wino_pack(w); f = lambda: ops.conv3x3_wino(x, u, None, y, ws=ws)
+elif mode == 'wgrad4':
+    f = lambda: ops.conv3x3_wgrad_wino4(dy, x, dw, ws=ws)
 else:
     f = lambda: ops.conv3x3_wgrad_wino(dy, x, dw, ws=ws)
 for _ in range(5): f()

@@ -102,6 +102,12 @@ def main():
                 line += ' | WINO wgrad s%d %7.3f ms %6.1f TF' % (lib.aide_conv3x3_wgrad_wino_splits(N, co, ci, h, h), t2, gf / t2)
                 tot.setdefault('wino_wgrad', 0.0); totf.setdefault('wino_wgrad', 0.0)
                 tot['wino_wgrad'] += t2 * cnt; totf['wino_wgrad'] += gf * cnt
+            if ops.wgrad_wino4_supported(co, ci, h, h):
+                ws4 = torch.empty(lib.aide_conv3x3_wgrad_wino4_ws_bytes(N, co, ci, h, h) // 4, device=dev)
+                t4 = timeit(lambda: ops.conv3x3_wgrad_wino4(dy, x, dw, ws=ws4))
+                line += ' | F4 wgrad s%d %7.3f ms %6.1f TF' % (lib.aide_conv3x3_wgrad_wino4_splits(N, co, ci, h, h), t4, gf / t4)
+                tot.setdefault('wgrad4', 0.0); totf.setdefault('wgrad4', 0.0)
+                tot['wgrad4'] += t4 * cnt; totf['wgrad4'] += gf * cnt
             tot['wgrad'] += t * cnt; totf['wgrad'] += gf * cnt
         print(line, flush=True)
     for k in tot:
