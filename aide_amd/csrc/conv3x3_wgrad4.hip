@@ -286,26 +286,36 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
             //   0 offsets;  0..3 dz[c+1] loads, 4..8 raw[c+2] loads;  1..6 patch reads
             //   14 input transform, 15..23 V stores;  20 dz transform, 21..32 ZT stores (3 per slot)
             //   31..35 raw[c+2] stores (3 per slot)
+#ifndef AIDE_PROBE_GNOFETCH
             if (st == 0) { cur_next(kz); prep_z(kz); }
             if (st < 4) fetch_z(st);
             if (st == 3) { cur_next(kd); prep_d(kd); }
             if (st >= 4 && st < 9) fetch_d(st - 4);
+#endif
+#ifndef AIDE_PROBE_GNOV
             if (st >= 1 && st < 7) v_read(st - 1, kcur ? xr0 : xr1);
             if (st == 14) v_math(HS);
             if (st >= 15 && st < 24) { v_store(2 * (st - 15), sn + G4_ZT); v_store(2 * (st - 15) + 1, sn + G4_ZT); }
+#endif
+#ifndef AIDE_PROBE_GNOZ
             if (st == 20) z_math();
             if (st >= 21 && st < 33) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) z_store(3 * (st - 21) + q, sn);
             }
+#endif
+#ifndef AIDE_PROBE_GNOFETCH
             if (st >= 31) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
                     if (3 * (st - 31) + q < 14) put_d(3 * (st - 31) + q, rawc);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifndef AIDE_PROBE_GNOBAR
         __syncthreads();
+#endif
     };
     for (int c = c_begin; c < c_stop; c += 2) {
         chunk(c, set0, set1, raw0, ic<0>{});

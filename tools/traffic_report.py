@@ -1,0 +1,48 @@
+"""HBM traffic per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
+usage: traffic_report.py <fetch counter_collection.csv> <write counter_collection.csv> <steps run> <out.md> <out.json>
+Units: counters are KB; FETCH_SIZE is x2-corrected for 16 B/lane reads (MI355X_MICROARCH.md, HBM section; calibrated
+on adam_kernel below)."""
+import csv, sys, re, json, collections
+fetch_csv, write_csv, steps, out_md, out_json = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4], sys.argv[5]
+
+
+def load(path, counter):
+    agg = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter:
+            continue
+        n = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name']).replace('void ', '')
+        n = re.sub(r'\((?:[^()]|\([^()]*\))*\)$', '', n)[:70]
+        a = agg.setdefault(n, [0, 0.0])
+        a[0] += 1; a[1] += float(r['Counter_Value'])
+    return agg
+
+
+F, W = load(fetch_csv, 'FETCH_SIZE'), load(write_csv, 'WRITE_SIZE')
+fam = {'conv3x3_igemm': ('conv3x3_mfma_kernel', 'conv3x3_wino_kernel', 'conv3x3_wino4_kernel', 'splitk_reduce_kernel'),
+       'conv3x3_wgrad': ('conv3x3_wgrad', 'wgrad_reduce_kernel')}
+ops_per_step = {'conv3x3_igemm': 62.0, 'conv3x3_wgrad': 32.0}     # conv operator calls per C2 step (fwd + dgrad / wgrad)
+lines = ['# HBM traffic per kernel, FuseUNet C2 step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)', '',
+         'Raw counter units are KB. FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads on gfx950',
+         '(MI355X_MICROARCH.md, HBM section): the x2 column applies that correction; adam_kernel (20 B/param read, 16 B/param',
+         'written, 26.68 M params = 533.5 / 426.8 MB) is the calibration row.', '',
+         '| kernel | launches/step | FETCH raw MB/launch | x2 corrected | WRITE MB/launch |', '|---|---|---|---|---|']
+tf = tw = 0.0
+famtot = {k: [0.0, 0.0] for k in fam}
+for n, (cnt, kb) in F.items():
+    wkb = W.get(n, [cnt, 0.0])[1]
+    lines.append('| `%s` | %.1f | %.2f | %.2f | %.2f |' % (n, cnt / steps, kb / cnt / 1e3, 2 * kb / cnt / 1e3, wkb / max(W.get(n, [cnt])[0], 1) / 1e3))
+    tf += kb; tw += wkb
+    for k, pats in fam.items():
+        if any(p in n for p in pats):
+            famtot[k][0] += 2 * kb * 1e3 / steps; famtot[k][1] += wkb * 1e3 / steps
+lines += ['', 'Whole step: FETCH raw %.2f GB (<= %.2f GB corrected), WRITE %.2f GB per step.' % (tf / steps / 1e6, 2 * tf / steps / 1e6, tw / steps / 1e6)]
+open(out_md, 'w').write('\n'.join(lines) + '\n')
+js = {}
+for k, (fb, wb) in famtot.items():
+    js[k] = dict(launches_per_step=ops_per_step[k], fetch_bytes_per_launch_corrected=fb / ops_per_step[k],
+                 write_bytes_per_launch=wb / ops_per_step[k], hbm_bytes_per_launch=(fb + wb) / ops_per_step[k],
+                 source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py, FETCH x2 per MI355X_MICROARCH.md; '
+                        'per conv operator call = main kernel + its split reduce')
+json.dump(js, open(out_json, 'w'), indent=1)
+print('\n'.join(lines[-3:])); print(json.dumps(js, indent=1))
