@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('AIDE_HIP_LIB', os.path.join(HERE, 'libaide_hip.so')) 
 
 _SCALARS = {
     'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float, 'size_t': ctypes.c_size_t,
-    'aide_stream_t': ctypes.c_void_p,
+    'aide_stream_t': ctypes.c_void_p, 'double': ctypes.c_double,
 }
 
 

@@ -2,6 +2,7 @@
 from .loss2d import (CrossEntropyLoss2d, DiceLoss, CEMDiceLoss, MulticlassDiceLoss, MulticlassMSELoss,  # noqa: F401
                      CEMDiceLossImage)
 from .metrics2d import Dice_fn  # noqa: F401
-from .coteach_loss import (Coteachingloss_dropimage, Coteachingloss_weightimage, CoTeachingProposedLoss,  # noqa: F401
+from .coteach_loss import (Coteachingloss_dropimage, Coteachingloss_weightimage, Coteachingloss_dropregionce,  # noqa: F401
+                           Coteachingloss_dropimagedroppixel, KLbidirection, CoTeachingProposedLoss,
                            pseudo_label_ensemble)
 from .augment import reverseaug, reverse_aug_tensor  # noqa: F401

@@ -46,6 +46,149 @@ class Coteachingloss_weightimage(_CoteachBase):
     variant = 2
 
 
+# ---- remaining operators of utils/coteach_loss.py -------------------------------------
+class _KLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z1, z2):
+        n, _, h, w = z1.shape
+        out = torch.empty(n, h, w, device=z1.device, dtype=torch.float32)
+        check(lib.aide_kl_map(ptr(z1), 2 * h * w, ptr(z2), 2 * h * w, n, h * w, ptr(out), None, None, 0, None, 0,
+                              stream_ptr()), 'kl_map')
+        ctx.save_for_backward(z1, z2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z1, z2 = ctx.saved_tensors
+        n, _, h, w = z1.shape
+        g = g.contiguous().float()
+        g1, g2 = torch.empty_like(z1), torch.empty_like(z2)
+        check(lib.aide_kl_map(ptr(z1), 2 * h * w, ptr(z2), 2 * h * w, n, h * w, None, ptr(g), ptr(g1), 2 * h * w,
+                              ptr(g2), 2 * h * w, stream_ptr()), 'kl_map bwd')
+        return g1, g2
+
+
+def KLbidirection(inputs1, inputs2):
+    """utils/coteach_loss.py:85-92: per-pixel KL(p1||p2) + KL(p2||p1) of the two softmax maps -> [N,H,W]."""
+    return _KLFn.apply(_seg._logits(inputs1), _seg._logits(inputs2))
+
+
+def _select(sel_vals, sum_vals, nseg, m, k_host=-1, rr=-1.0, k_in=None, only_positive=False):
+    dev = sel_vals.device
+    mask = torch.empty(nseg * m, device=dev, dtype=torch.uint8)
+    sums = torch.empty(nseg, device=dev, dtype=torch.float64)
+    ks = torch.empty(nseg, device=dev, dtype=torch.int64)
+    check(lib.aide_select_smallest(ptr(sel_vals), ptr(sum_vals), m, nseg, m, int(k_host), float(rr), ptr(k_in),
+                                   int(only_positive), ptr(mask), ptr(sums), ptr(ks), stream_ptr()), 'select_smallest')
+    return mask, sums, ks
+
+
+class _RegionCEFn(torch.autograd.Function):
+    """mean over images and kept regions of the region CE of `z`, the kept set chosen by the OTHER net's losses."""
+
+    @staticmethod
+    def forward(ctx, z, aux, loss_self, loss_other, keep):
+        n, _, h, w = z.shape
+        p = (h // 2) * (w // 2)
+        mask, sums, _ = _select(loss_other, loss_self, n, p, k_host=keep)
+        ctx.save_for_backward(z, aux, mask)
+        ctx.denom = float(n * keep)
+        return (sums.sum() / ctx.denom).float() if keep > 0 else sums.sum().float() * float('nan')
+
+    @staticmethod
+    def backward(ctx, g):
+        z, aux, mask = ctx.saved_tensors
+        n, _, h, w = z.shape
+        coeff = (g.reshape(1).float() / ctx.denom).contiguous()
+        dz = torch.empty_like(z)
+        check(lib.aide_region_ce_bwd(ptr(z), 2 * h * w, ptr(aux), ptr(mask), ptr(coeff), n, h, w, ptr(dz), 2 * h * w,
+                                     stream_ptr()), 'region_ce_bwd')
+        return dz, None, None, None, None
+
+
+class Coteachingloss_dropregionce(nn.Module):
+    """utils/coteach_loss.py:163-196.  Cross entropy on 2x2 max-pooled regions (logits per class, targets); per image
+    the `int((1 - forget_rate) * P)` regions with the smallest loss of the other net are kept; mean over all kept."""
+
+    def __init__(self, scale=0.5, reduction='none'):
+        super(Coteachingloss_dropregionce, self).__init__()
+        if scale != 0.5:
+            raise NotImplementedError('aide_amd.Coteachingloss_dropregionce implements the reference default scale=0.5')
+        if reduction != 'none':
+            raise RuntimeError("Coteachingloss_dropregionce needs reduction='none' (the reference's .view(N, -1), "
+                               "utils/coteach_loss.py:178, fails on a reduced loss)")
+        self.scale = scale
+
+    def forward(self, inputs1, inputs2, targets, forget_rate):
+        z1, z2 = _seg._logits(inputs1), _seg._logits(inputs2)
+        tg, t_bs = _seg._targets(targets, z1)
+        n, _, h, w = z1.shape
+        if h % 2 or w % 2:
+            raise RuntimeError('Coteachingloss_dropregionce: H and W must be even')
+        p = (h // 2) * (w // 2)
+        keep = int((1 - forget_rate) * p)
+        dev = z1.device
+        with torch.no_grad():
+            l1, l2 = torch.empty(n * p, device=dev), torch.empty(n * p, device=dev)
+            a1, a2 = torch.empty(n * p, device=dev, dtype=torch.uint8), torch.empty(n * p, device=dev, dtype=torch.uint8)
+            for z, l, a in ((z1, l1, a1), (z2, l2, a2)):
+                check(lib.aide_region_ce_fwd(ptr(z), 2 * h * w, ptr(tg), t_bs, n, h, w, 255, ptr(l), ptr(a),
+                                             stream_ptr()), 'region_ce_fwd')
+        return _RegionCEFn.apply(z1, a1, l1, l2, keep), _RegionCEFn.apply(z2, a2, l2, l1, keep)
+
+
+class _DropPixelFn(torch.autograd.Function):
+    """mean of the `keep2` smallest positive values of target * (KL(z1, z2) + CE(z_which, target)) over the dropped
+    images idx (device int64); keep2 = int(rr * #positive) or the count handed over from the other branch."""
+
+    @staticmethod
+    def forward(ctx, z1, z2, tg, t_bs, idx, which, rr, k_in):
+        n, _, h, w = z1.shape
+        hw, nd = h * w, idx.numel()
+        v = torch.empty(nd * hw, device=z1.device, dtype=torch.float32)
+        check(lib.aide_droppixel_map(ptr(z1), 2 * hw, ptr(z2), 2 * hw, ptr(tg), t_bs, ptr(idx), nd, hw, which, ptr(v),
+                                     stream_ptr()), 'droppixel_map')
+        mask, sums, ks = _select(v, v, 1, nd * hw, rr=(-1.0 if k_in is not None else rr), k_in=k_in,
+                                 k_host=0, only_positive=True)
+        ctx.save_for_backward(z1, z2, tg, idx, mask, ks)
+        ctx.t_bs, ctx.which = t_bs, which
+        ctx.mark_non_differentiable(ks)
+        return (sums[0] / ks[0].double()).float(), ks          # 0 / 0 -> nan like torch.mean of an empty tensor
+
+    @staticmethod
+    def backward(ctx, g, _gk):
+        z1, z2, tg, idx, mask, ks = ctx.saved_tensors
+        n, _, h, w = z1.shape
+        hw, nd = h * w, idx.numel()
+        coeff = (g.reshape(1).double() / ks[0].double()).float().contiguous()
+        g1, g2 = torch.zeros_like(z1), torch.zeros_like(z2)
+        check(lib.aide_droppixel_bwd(ptr(z1), 2 * hw, ptr(z2), 2 * hw, ptr(tg), ctx.t_bs, ptr(idx), nd, hw, ctx.which,
+                                     ptr(mask), ptr(coeff), ptr(g1), ptr(g2), stream_ptr()), 'droppixel_bwd')
+        return g1, g2, None, None, None, None, None, None
+
+
+class Coteachingloss_dropimagedroppixel(_CoteachBase):
+    """utils/coteach_loss.py:198-254: Coteachingloss_dropimage plus 0.25 x the pixel-level term on the dropped
+    images.  Reference quirks kept: branch 2 keeps as many pixels as branch 1 (`num_remember2`, :249); a dropped
+    set without positive foreground values gives nan (torch.mean of an empty tensor)."""
+    variant = 1
+
+    def forward(self, inputs1, inputs2, targets, forget_rate):
+        l1, l2 = super(Coteachingloss_dropimagedroppixel, self).forward(inputs1, inputs2, targets, forget_rate)
+        n = inputs1.shape[0]
+        keep = _keep_count(forget_rate, n)
+        if keep >= n:                                       # nothing dropped: both extra terms are 0.0
+            return l1, l2
+        z1, z2 = _seg._logits(inputs1), _seg._logits(inputs2)
+        tg, t_bs = _seg._targets(targets, z1)
+        rr = 1 - forget_rate
+        d1 = self.last['argsort1'][keep:].contiguous()      # images dropped by net 1's ranking
+        d2 = self.last['argsort2'][keep:].contiguous()
+        drop1, k2 = _DropPixelFn.apply(z1, z2, tg, t_bs, d2, 0, rr, None)
+        drop2, _ = _DropPixelFn.apply(z1, z2, tg, t_bs, d1, 1, rr, k2)
+        return l1 + 0.25 * drop1, l2 + 0.25 * drop2
+
+
 def pseudo_label_ensemble(aug_logits, temperature=1.0):
     """mean softmax over the (reverse-augmented) passes -> sharpen -> weightmap
     (trainchaos_proposed_30cases1labeled.py:274-292). Returns (pseudo_label [N,2,H,W], weightmap [N,1,H,W])."""

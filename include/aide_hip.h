@@ -161,6 +161,31 @@ int aide_pseudo_label(const float* const* logits /* HOST array of K device point
                       int64_t l_bs, int N, int HW, float temperature, float* pl, float* wm,
                       aide_stream_t stream);
 
+/* ---- remaining co-teaching operators (utils/coteach_loss.py:85-92, 163-196, 198-254), two classes ----
+ * aide_kl_map: KLbidirection, out[n][p] = KL(p1||p2) + KL(p2||p1); with gout (per-pixel upstream gradient) also
+ *   the gradients w.r.t. both logit tensors.
+ * aide_region_ce_fwd/_bwd: cross entropy on 2x2 max-pooled logits (per class) and targets (:171-179); aux keeps
+ *   the arg-max window positions and the pooled target; bwd scatters coeff[0] * mask * dCE to those positions.
+ * aide_select_smallest: per segment of M values the k smallest candidates (all values, or only those > 0), ties
+ *   by lower index (stable argsort, :180-186 / :228-232); k = *k_in | (int64)(rr * candidates) if rr >= 0 | k_host;
+ *   mask[M] marks the selection, sums[seg] = fp64 sum of sum_vals over it, ks[seg] = k.
+ * aide_droppixel_map/_bwd: v = target * (KL(z1, z2) + CE(z_which, target)) on the images idx[0..ndrop) (:221-227,
+ *   :240-246) and its gradient w.r.t. both logit tensors for the selected pixels (g1, g2 pre-zeroed). */
+int aide_kl_map(const float* z1, int64_t b1, const float* z2, int64_t b2, int N, int HW, float* out,
+                const float* gout, float* g1, int64_t gb1, float* g2, int64_t gb2, aide_stream_t stream);
+int aide_region_ce_fwd(const float* z, int64_t zb, const long long* t, int64_t tb, int N, int H, int W,
+                       int ignore_index, float* loss, unsigned char* aux, aide_stream_t stream);
+int aide_region_ce_bwd(const float* z, int64_t zb, const unsigned char* aux, const unsigned char* mask,
+                       const float* coeff, int N, int H, int W, float* dz, int64_t db, aide_stream_t stream);
+int aide_select_smallest(const float* sel_vals, const float* sum_vals, int64_t seg_stride, int nseg, int M,
+                         int64_t k_host, double rr, const long long* k_in, int only_positive, unsigned char* mask,
+                         double* sums, long long* ks, aide_stream_t stream);
+int aide_droppixel_map(const float* z1, int64_t b1, const float* z2, int64_t b2, const long long* t, int64_t tb,
+                       const long long* idx, int ndrop, int HW, int which, float* v, aide_stream_t stream);
+int aide_droppixel_bwd(const float* z1, int64_t b1, const float* z2, int64_t b2, const long long* t, int64_t tb,
+                       const long long* idx, int ndrop, int HW, int which, const unsigned char* mask,
+                       const float* coeff, float* g1, float* g2, aide_stream_t stream);
+
 /* per-case inference (trainchaos_comparison_1case.py:262-264): labels[n][p] = argmax(softmax(logits[n][:,p]))
  * for two classes, int64 like torch.argmax; ties (also those created by the softmax rounding) -> 0 */
 int aide_label_map(const float* logits, int64_t l_bs, int N, int HW, long long* labels, aide_stream_t stream);

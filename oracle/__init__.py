@@ -14,6 +14,7 @@ from .nets import fuseunet, UNet  # noqa: F401
 from .losses import (  # noqa: F401
     CrossEntropyLoss2d, DiceLoss, MulticlassDiceLoss, MulticlassMSELoss,
     CEMDiceLoss, CEMDiceLossImage, Coteachingloss_dropimage,
-    Coteachingloss_weightimage, Dice_fn, sharpen,
+    Coteachingloss_weightimage, Coteachingloss_dropregionce, Coteachingloss_dropimagedroppixel,
+    KLbidirection, Dice_fn, sharpen,
 )
 from .steps import comparison_step, proposed_step  # noqa: F401

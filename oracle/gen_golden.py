@@ -374,8 +374,53 @@ def g6_inference(ref_f, ref_u, ref_utils):
     np.savez_compressed(os.path.join(OUT, 'g6_inference.npz'), **fx)
 
 
+def g7_coteach_ext(ref_utils):
+    """a17: KLbidirection, Coteachingloss_dropregionce, Coteachingloss_dropimagedroppixel on the g3 logits."""
+    import importlib
+    import oracle
+    ref_ct = importlib.import_module('utils.coteach_loss')
+    g3 = np.load(os.path.join(OUT, 'g3_losses.npz'))
+    z1, z2, t = torch.from_numpy(g3['z1']), torch.from_numpy(g3['z2']), torch.from_numpy(g3['targets'])
+    fx = {}
+    vals = {}
+    for tag, fn in (('ref', ref_ct.KLbidirection), ('ora', oracle.KLbidirection)):
+        a1, a2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+        v = fn(a1, a2)
+        gw = torch.linspace(0.5, 1.5, v.numel()).view_as(v)
+        (v * gw).sum().backward()
+        vals[tag] = (v.detach(), a1.grad.clone(), a2.grad.clone())
+    for i in range(3):
+        _same(vals['ref'][i], vals['ora'][i], 'KLbidirection #%d' % i)
+    fx['KL/map'], fx['KL/grad1'], fx['KL/grad2'] = (_np(x) for x in vals['ref'])
+    for cname, kw in (('Coteachingloss_dropregionce', dict(scale=0.5, reduction='none')),
+                      ('Coteachingloss_dropimagedroppixel', dict(weight=1.0, reduction='none'))):
+        for fr in (0.0, 0.25, 0.5):
+            vals = {}
+            for tag, mod in (('ref', ref_utils), ('ora', oracle)):
+                out = []
+                for which in (0, 1):                    # the two losses are back-propagated separately
+                    a1, a2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+                    ls = getattr(mod, cname)(**kw)(a1, a2, t, fr)
+                    ls[which].backward()
+                    out += [ls[which].detach(), a1.grad.clone() if a1.grad is not None else torch.zeros_like(z1),
+                            a2.grad.clone() if a2.grad is not None else torch.zeros_like(z2)]
+                vals[tag] = out
+            for i in range(6):
+                _same(vals['ref'][i], vals['ora'][i], '%s fr=%g #%d' % (cname, fr, i))
+            key = '%s/fr%g' % (cname, fr)
+            r = vals['ref']
+            fx[key + '/loss1'], fx[key + '/l1_grad1'], fx[key + '/l1_grad2'] = _np(r[0]), _np(r[1]), _np(r[2])
+            fx[key + '/loss2'], fx[key + '/l2_grad1'], fx[key + '/l2_grad2'] = _np(r[3]), _np(r[4]), _np(r[5])
+            print('g7', key, float(r[0]), float(r[3]), 'cross-grad norms', float(r[2].norm()), float(r[4].norm()))
+    np.savez_compressed(os.path.join(OUT, 'g7_coteach_ext.npz'), **fx)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['g7']:
+        torch.set_num_threads(8)
+        ref_f, ref_u, ref_utils = _import_reference()
+        return g7_coteach_ext(ref_utils)
     if sys.argv[1:] == ['g6']:
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()
@@ -392,6 +437,7 @@ def main():
     g5_adam(ref_f, ref_utils)
     g2_config(ref_f, ref_utils)
     g6_inference(ref_f, ref_u, ref_utils)
+    g7_coteach_ext(ref_utils)
     print('all golden fixtures written to', OUT)
 
 

@@ -10,6 +10,9 @@ Reference:
   utils/loss2d.py:137-154  CEMDiceLossImage
   utils/coteach_loss.py:94-119   Coteachingloss_dropimage
   utils/coteach_loss.py:121-161  Coteachingloss_weightimage
+  utils/coteach_loss.py:85-92    KLbidirection
+  utils/coteach_loss.py:163-196  Coteachingloss_dropregionce
+  utils/coteach_loss.py:198-254  Coteachingloss_dropimagedroppixel
   utils/metrics2d.py:8-29  Dice_fn
   train_files/trainchaos_proposed_30cases1labeled.py:97-101 sharpen
 """
@@ -184,6 +187,81 @@ class Coteachingloss_weightimage(nn.Module):
         if len(d2) > 0:
             u2 = u2 + 0.1 * _ct_image_loss(self.weight, inputs2[d1], targets[d1])
         return u1.mean(dim=0), u2.mean(dim=0)
+
+
+def KLbidirection(inputs1, inputs2):
+    """coteach_loss.py:85-92: per-pixel KL(p1||p2) + KL(p2||p1) of the two softmax maps -> [N,H,W]."""
+    p1 = F.softmax(inputs1, dim=1)
+    p2 = F.softmax(inputs2, dim=1)
+    kl12 = torch.sum(p1 * torch.log(p1 / p2), dim=1)
+    kl21 = torch.sum(p2 * torch.log(p2 / p1), dim=1)
+    return kl12 + kl21
+
+
+class Coteachingloss_dropregionce(nn.Module):
+    """coteach_loss.py:163-196: CE on max-pooled regions (logits pooled per class, targets pooled), per image the
+    `num_remember` regions with the smallest loss of the OTHER net are kept; mean over all kept regions."""
+
+    def __init__(self, scale=0.5, reduction='none'):
+        super().__init__()
+        self.scale = scale
+        self.reduction = reduction
+
+    def forward(self, inputs1, inputs2, targets, forget_rate):
+        total_w, total_h = inputs1.shape[2], inputs1.shape[3]
+        patch_w, patch_h = int(total_w * self.scale), int(total_h * self.scale)
+        kernel = (int(total_w / patch_w), int(total_h / patch_h))
+        pool = lambda x: F.max_pool2d(x, kernel_size=kernel, stride=kernel, padding=0, ceil_mode=True)
+        z1, z2 = pool(inputs1), pool(inputs2)
+        tp = pool(targets.float()).long()
+        n = z1.shape[0]
+        loss1 = F.nll_loss(F.log_softmax(z1, dim=1), tp, reduction=self.reduction, ignore_index=255).view(n, -1)
+        loss2 = F.nll_loss(F.log_softmax(z2, dim=1), tp, reduction=self.reduction, ignore_index=255).view(n, -1)
+        i1 = torch.from_numpy(np.argsort(loss1.detach().cpu().numpy(), axis=-1, kind='stable'))
+        i2 = torch.from_numpy(np.argsort(loss2.detach().cpu().numpy(), axis=-1, kind='stable'))
+        keep = int((1 - forget_rate) * loss1.shape[1])
+        u1 = torch.cat([loss1[i, i2[i, :keep]] for i in range(n)], dim=0)      # :186-194
+        u2 = torch.cat([loss2[i, i1[i, :keep]] for i in range(n)], dim=0)
+        return torch.mean(u1), torch.mean(u2)
+
+
+class Coteachingloss_dropimagedroppixel(nn.Module):
+    """coteach_loss.py:198-254: image-level small-loss selection as dropimage, plus 0.25 x a pixel-level term on
+    the dropped images: (KL + CE) on foreground pixels, the smallest remember_rate fraction kept.  Quirks kept:
+    branch 2 reuses num_remember2 of branch 1 (:249) and tests len(ind_2_drop) (:240)."""
+
+    def __init__(self, weight=1.0, reduction='mean'):
+        super().__init__()
+        if reduction != 'none':
+            raise IndexError("Coteachingloss_* require reduction='none' (reference behaviour)")
+        self.weight = weight
+
+    def forward(self, inputs1, inputs2, targets, forget_rate):
+        ce = lambda z, t: F.nll_loss(F.log_softmax(z, dim=1), t, reduction='none', ignore_index=255)
+        l1 = _ct_image_loss(self.weight, inputs1, targets)
+        l2 = _ct_image_loss(self.weight, inputs2, targets)
+        i1, i2 = _argsort_host(l1), _argsort_host(l2)
+        rr = 1 - forget_rate
+        keep = int(rr * l1.shape[0])
+        k1, d1, k2, d2 = i1[:keep], i1[keep:], i2[:keep], i2[keep:]
+        u1 = _ct_image_loss(self.weight, inputs1[k2], targets[k2])
+        u2 = _ct_image_loss(self.weight, inputs2[k1], targets[k1])
+        drop1 = drop2 = 0.0
+        keep2 = None
+        if len(d1) > 0:
+            t1 = targets[d2]
+            v = (KLbidirection(inputs1[d2], inputs2[d2]) + ce(inputs1[d2], t1)).view(-1) * t1.view(-1).float()
+            fore = v[v > 0]
+            order = torch.from_numpy(np.argsort(fore.detach().cpu().numpy(), kind='stable'))
+            keep2 = int(rr * len(order))
+            drop1 = torch.mean(fore[order[:keep2]])
+        if len(d2) > 0:
+            t2 = targets[d1]
+            v = (KLbidirection(inputs1[d1], inputs2[d1]) + ce(inputs2[d1], t2)).view(-1) * t2.view(-1).float()
+            fore = v[v > 0]
+            order = torch.from_numpy(np.argsort(fore.detach().cpu().numpy(), kind='stable'))
+            drop2 = torch.mean(fore[order[:keep2]])          # :249 num_remember2 of branch 1
+        return u1.mean(dim=0) + 0.25 * drop1, u2.mean(dim=0) + 0.25 * drop2
 
 
 def Dice_fn(inputs, targets, threshold=0.5):

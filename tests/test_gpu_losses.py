@@ -189,3 +189,72 @@ def test_reverseaug_matches_pil(dev):
             assert (got[k].cpu() - ref[k]).abs().max().item() < 2e-6, (h, w, k)
         # element 3 has augno == 3: its 4th output is left untouched by the reference
         assert torch.equal(got[3][3].cpu(), outs[3][3])
+
+
+def test_kl_bidirection_g7(dev):
+    """utils/coteach_loss.py:85-92 vs the reference's map and both gradients (g7_coteach_ext.npz)."""
+    from aide_amd import utils as U
+    g3, fx = np.load(os.path.join(GOLD, 'g3_losses.npz')), np.load(os.path.join(GOLD, 'g7_coteach_ext.npz'))
+    a1 = torch.from_numpy(g3['z1']).to(dev).requires_grad_(True)
+    a2 = torch.from_numpy(g3['z2']).to(dev).requires_grad_(True)
+    v = U.KLbidirection(a1, a2)
+    ref = fx['KL/map']
+    assert np.abs(v.detach().cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+    gw = torch.linspace(0.5, 1.5, v.numel()).view_as(v).to(dev)
+    (v * gw).sum().backward()
+    for g, key in ((a1.grad, 'KL/grad1'), (a2.grad, 'KL/grad2')):
+        assert np.abs(g.cpu().numpy() - fx[key]).max() < 2e-5 * np.abs(fx[key]).max()
+
+
+@pytest.mark.parametrize('cname', ['Coteachingloss_dropregionce', 'Coteachingloss_dropimagedroppixel'])
+def test_coteach_ext_g7(dev, cname):
+    """Coteachingloss_dropregionce (:163-196) / _dropimagedroppixel (:198-254) vs the real reference: both losses
+    and, back-propagated separately, their gradients w.r.t. BOTH logit tensors (the KL term of the pixel branch
+    reaches the other net), forget rates 0 / 0.25 / 0.5."""
+    from aide_amd import utils as U
+    g3, fx = np.load(os.path.join(GOLD, 'g3_losses.npz')), np.load(os.path.join(GOLD, 'g7_coteach_ext.npz'))
+    z1, z2, t = (torch.from_numpy(g3[k]).to(dev) for k in ('z1', 'z2', 'targets'))
+    kw = dict(scale=0.5, reduction='none') if 'region' in cname else dict(weight=1.0, reduction='none')
+    for fr in (0.0, 0.25, 0.5):
+        key = '%s/fr%g' % (cname, fr)
+        for which in (0, 1):
+            a1, a2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+            ls = getattr(U, cname)(**kw)(a1, a2, t, fr)
+            ref = float(fx[key + '/loss%d' % (which + 1)])
+            assert abs(ls[which].item() - ref) < 1e-5 * abs(ref), (key, which, ls[which].item(), ref)
+            ls[which].backward()
+            for g, gk in ((a1.grad, '/l%d_grad1' % (which + 1)), (a2.grad, '/l%d_grad2' % (which + 1))):
+                gr = fx[key + gk]
+                got = np.zeros_like(gr) if g is None else g.cpu().numpy()
+                # selections may differ from the reference only between values closer than fp32 noise
+                bad = np.abs(got - gr) > 1e-4 * np.abs(gr).max() + 1e-12
+                assert bad.mean() < 2e-4, (key, gk, bad.sum(), np.abs(got - gr).max(), np.abs(gr).max())
+    with pytest.raises((RuntimeError, IndexError)):
+        getattr(U, cname)(reduction='mean')
+
+
+def test_select_smallest_ties_and_edges(dev):
+    """aide_select_smallest: stable ties (lower index first), the > 0 candidate filter, k = int(rr * count),
+    k handed over on the device, and the empty selection (-> nan mean like torch.mean of an empty tensor)."""
+    from aide_amd.utils.coteach_loss import _select
+    g = torch.Generator().manual_seed(3)
+    v = torch.rand(5000, generator=g)
+    v[100:140] = 0.25                                           # 40 tied values
+    v[::7] = 0.0                                                # non-candidates for the positive filter
+    v[3] = -1.0
+    vd = v.to(dev)
+    for only_pos, k in ((False, 1300), (True, 1300), (True, 0), (False, 5000)):
+        cand = (v > 0) if only_pos else torch.ones_like(v, dtype=torch.bool)
+        order = torch.from_numpy(np.argsort(np.where(cand.numpy(), v.numpy(), np.inf), kind='stable'))
+        kk = min(k, int(cand.sum()))
+        ref = torch.zeros(5000, dtype=torch.uint8); ref[order[:kk]] = 1
+        mask, sums, ks = _select(vd, vd, 1, 5000, k_host=k, only_positive=only_pos)
+        assert int(ks[0]) == kk and torch.equal(mask.cpu(), ref)
+        assert abs(float(sums[0]) - float(v.double()[ref.bool()].sum())) < 1e-9
+    mask, sums, ks = _select(vd, vd, 1, 5000, rr=0.75, only_positive=True)
+    assert int(ks[0]) == int(0.75 * int((v > 0).sum()))
+    mask2, _, ks2 = _select(vd, vd, 1, 5000, k_in=ks, only_positive=True)
+    assert torch.equal(mask, mask2) and int(ks2[0]) == int(ks[0])
+    z = torch.zeros(64, device=dev)
+    _, s0, k0 = _select(z, z, 1, 64, rr=0.5, only_positive=True)
+    assert int(k0[0]) == 0 and torch.isnan(s0[0] / k0[0].double())
