@@ -216,7 +216,7 @@ def test_coteach_ext_g7():
     z1, z2, t = (torch.from_numpy(g3[k]) for k in ('z1', 'z2', 'targets'))
     a1, a2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
     v = oracle.KLbidirection(a1, a2)
-    close(v, fx['KL/map'], what='KL map')
+    close(v.detach(), fx['KL/map'], what='KL map')
     (v * torch.linspace(0.5, 1.5, v.numel()).view_as(v)).sum().backward()
     close(a1.grad, fx['KL/grad1'], what='KL grad1'); close(a2.grad, fx['KL/grad2'], what='KL grad2')
     for cname, kw in (('Coteachingloss_dropregionce', dict(scale=0.5, reduction='none')),
@@ -226,7 +226,7 @@ def test_coteach_ext_g7():
             for which in (0, 1):
                 a1, a2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
                 ls = getattr(oracle, cname)(**kw)(a1, a2, t, fr)
-                close(ls[which], fx[key + '/loss%d' % (which + 1)], what=key)
+                close(ls[which].detach(), fx[key + '/loss%d' % (which + 1)], what=key)
                 ls[which].backward()
                 for g, gk in ((a1.grad, '/l%d_grad1' % (which + 1)), (a2.grad, '/l%d_grad2' % (which + 1))):
                     close(torch.zeros_like(z1) if g is None else g, fx[key + gk], what=key + gk)
