@@ -232,7 +232,7 @@ def main():
                             avg_launch_ms=round(a['avg_ms'], 5),
                             alg_gflop_per_launch=round(a['flops'] / a['launches'] / 1e9, 3))
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.cpu_steps > 0:
             cpu = cpu_baseline(model_name, batch, size, args.cpu_steps, args.cpu_threads)
         line = dict(metric='training images/sec %s bs=%d/GPU' % (
                         ('FuseUNet %dx%dx2' if model_name == 'fuseunet' else 'UNet %dx%d') % (size, size), batch),
