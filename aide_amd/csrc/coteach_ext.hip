@@ -254,6 +254,64 @@ __global__ __launch_bounds__(256) void droppixel_bwd_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------- Pixelcoreg_Focalloss (utils/reg_loss.py:58-193)
+// focal(gamma = 2) cross entropy of a logit difference d = z1 - z0: t = 1: (1 - s)^2 softplus(-d), t = 0: s^2 softplus(d)
+__device__ __forceinline__ float focal2(float d, int t) {
+    const float s = sigmoidf_(d), q = t ? 1.0f - s : s;
+    return q * q * ce2(d, t);
+}
+__device__ __forceinline__ float focal2_grad(float d, int t) {
+    const float s = sigmoidf_(d);
+    if (t) { const float q = 1.0f - s; return -q * q * (2.0f * s * ce2(d, 1) + q); }
+    return s * s * (2.0f * (1.0f - s) * ce2(d, 0) + s);
+}
+
+// key = (1 - kd) * (focal1 + focal2 [+ focal3]) + kd * KL(1, 2); val = focal3 (three nets) or key (two nets)
+__global__ __launch_bounds__(256) void pixelcoreg_map_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
+                                                             const float* __restrict__ z3,
+                                                             const long long* __restrict__ t, long tb, int HW,
+                                                             float kd, long total, float* __restrict__ key,
+                                                             float* __restrict__ val, float* __restrict__ tf) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / HW, p = i - n * HW;
+        const int tg = t[n * tb + p] != 0;
+        const float d1 = z1[(n * 2 + 1) * HW + p] - z1[n * 2 * HW + p], d2 = z2[(n * 2 + 1) * HW + p] - z2[n * 2 * HW + p];
+        float f = focal2(d1, tg) + focal2(d2, tg), f3 = 0.0f;
+        if (z3) { f3 = focal2(z3[(n * 2 + 1) * HW + p] - z3[n * 2 * HW + p], tg); f += f3; }
+        const float k = (1.0f - kd) * f + kd * kl2(d1, d2);
+        key[i] = k;
+        if (z3) val[i] = f3;
+        tf[i] = (float)tg;
+    }
+}
+
+// gradients of coeff * sum over the selection: two nets -> g1, g2 from the key itself; three nets -> g3 from focal3
+__global__ __launch_bounds__(256) void pixelcoreg_bwd_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
+                                                             const float* __restrict__ z3,
+                                                             const long long* __restrict__ t, long tb, int HW,
+                                                             float kd, long total, const unsigned char* __restrict__ mask,
+                                                             const float* __restrict__ coeff, float* __restrict__ g1,
+                                                             float* __restrict__ g2, float* __restrict__ g3) {
+    const float cf = coeff[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / HW, p = i - n * HW;
+        const int tg = t[n * tb + p] != 0;
+        const float m = mask[i] ? cf : 0.0f;
+        if (z3) {
+            const float a = m * focal2_grad(z3[(n * 2 + 1) * HW + p] - z3[n * 2 * HW + p], tg);
+            g3[n * 2 * HW + p] = -a; g3[(n * 2 + 1) * HW + p] = a;
+        } else {
+            const float d1 = z1[(n * 2 + 1) * HW + p] - z1[n * 2 * HW + p], d2 = z2[(n * 2 + 1) * HW + p] - z2[n * 2 * HW + p];
+            float a, b;
+            kl2_grad(d1, d2, a, b);
+            a = m * ((1.0f - kd) * focal2_grad(d1, tg) + kd * a);
+            b = m * ((1.0f - kd) * focal2_grad(d2, tg) + kd * b);
+            g1[n * 2 * HW + p] = -a; g1[(n * 2 + 1) * HW + p] = a;
+            g2[n * 2 * HW + p] = -b; g2[(n * 2 + 1) * HW + p] = b;
+        }
+    }
+}
+
 int grid1(long total) { return (int)max(1L, min((total + 255) / 256, 4096L)); }
 
 }  // namespace
@@ -293,6 +351,26 @@ int aide_select_smallest(const float* sel_vals, const float* sum_vals, int64_t s
     if (!sel_vals || !sum_vals || !mask || !sums || !ks || nseg <= 0 || M <= 0) return AIDE_ERR_ARG;
     hipLaunchKernelGGL(select_smallest_kernel, dim3(nseg), dim3(1024), 0, stream, sel_vals, sum_vals, (long)seg_stride,
                        M, (long)k_host, rr, k_in, only_positive, mask, sums, ks);
+    return aide_launch_status();
+}
+
+// z1, z2 (, z3 or NULL): contiguous [N][2][HW] logits.  key/val/tf: [N][HW]; val is written only with three nets
+int aide_pixelcoreg_map(const float* z1, const float* z2, const float* z3, const long long* t, int64_t tb, int N,
+                        int HW, float kd, float* key, float* val, float* tf, hipStream_t stream) {
+    if (!z1 || !z2 || !t || !key || !tf || (z3 && !val) || N <= 0 || HW <= 0) return AIDE_ERR_ARG;
+    const long total = (long)N * HW;
+    hipLaunchKernelGGL(pixelcoreg_map_kernel, dim3(grid1(total)), dim3(256), 0, stream, z1, z2, z3, t, (long)tb, HW, kd,
+                       total, key, val, tf);
+    return aide_launch_status();
+}
+
+int aide_pixelcoreg_bwd(const float* z1, const float* z2, const float* z3, const long long* t, int64_t tb, int N,
+                        int HW, float kd, const unsigned char* mask, const float* coeff, float* g1, float* g2,
+                        float* g3, hipStream_t stream) {
+    if (!z1 || !z2 || !t || !mask || !coeff || N <= 0 || HW <= 0 || (z3 ? !g3 : (!g1 || !g2))) return AIDE_ERR_ARG;
+    const long total = (long)N * HW;
+    hipLaunchKernelGGL(pixelcoreg_bwd_kernel, dim3(grid1(total)), dim3(256), 0, stream, z1, z2, z3, t, (long)tb, HW, kd,
+                       total, mask, coeff, g1, g2, g3);
     return aide_launch_status();
 }
 

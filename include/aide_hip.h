@@ -186,6 +186,16 @@ int aide_droppixel_bwd(const float* z1, int64_t b1, const float* z2, int64_t b2,
                        const long long* idx, int ndrop, int HW, int which, const unsigned char* mask,
                        const float* coeff, float* g1, float* g2, aide_stream_t stream);
 
+/* Pixelcoreg_Focalloss / _twomodel (utils/reg_loss.py:58-193): per pixel key = (1-kd)(focal1 + focal2 [+ focal3]) +
+ * kd KL(1,2) (focal: gamma 2, lossweight 1), val = focal3 with three nets (z3 != NULL), tf = target as float; the
+ * per-image "k smallest keys" selection is aide_select_smallest; bwd: coeff[0] * mask * d val / d logits (two nets:
+ * g1, g2 of the key; three nets: g3 only, as in the reference where the ranking is not differentiated). */
+int aide_pixelcoreg_map(const float* z1, const float* z2, const float* z3, const long long* t, int64_t tb, int N,
+                        int HW, float kd, float* key, float* val, float* tf, aide_stream_t stream);
+int aide_pixelcoreg_bwd(const float* z1, const float* z2, const float* z3, const long long* t, int64_t tb, int N,
+                        int HW, float kd, const unsigned char* mask, const float* coeff, float* g1, float* g2,
+                        float* g3, aide_stream_t stream);
+
 /* per-case inference (trainchaos_comparison_1case.py:262-264): labels[n][p] = argmax(softmax(logits[n][:,p]))
  * for two classes, int64 like torch.argmax; ties (also those created by the softmax rounding) -> 0 */
 int aide_label_map(const float* logits, int64_t l_bs, int N, int HW, long long* labels, aide_stream_t stream);

@@ -15,6 +15,6 @@ from .losses import (  # noqa: F401
     CrossEntropyLoss2d, DiceLoss, MulticlassDiceLoss, MulticlassMSELoss,
     CEMDiceLoss, CEMDiceLossImage, Coteachingloss_dropimage,
     Coteachingloss_weightimage, Coteachingloss_dropregionce, Coteachingloss_dropimagedroppixel,
-    KLbidirection, Dice_fn, sharpen,
+    KLbidirection, Pixelcoreg_Focalloss, Pixelcoreg_Focalloss_twomodel, Dice_fn, sharpen,
 )
 from .steps import comparison_step, proposed_step  # noqa: F401

@@ -415,8 +415,38 @@ def g7_coteach_ext(ref_utils):
     np.savez_compressed(os.path.join(OUT, 'g7_coteach_ext.npz'), **fx)
 
 
+def g8_pixelcoreg(ref_utils):
+    """Pixelcoreg_Focalloss / _twomodel (utils/reg_loss.py:58-193) on the g3 logits."""
+    import oracle
+    g3 = np.load(os.path.join(OUT, 'g3_losses.npz'))
+    z1, z2, t = torch.from_numpy(g3['z1']), torch.from_numpy(g3['z2']), torch.from_numpy(g3['targets'])
+    z3 = torch.randn(z1.shape, generator=torch.Generator().manual_seed(99)) * 2.0
+    fx = {'z3': _np(z3)}
+    for cname, three in (('Pixelcoreg_Focalloss', True), ('Pixelcoreg_Focalloss_twomodel', False)):
+        for fr, kd, red in ((0.0, 0.3, 'mean'), (0.25, 0.3, 'mean'), (0.5, 0.7, 'sum')):
+            vals = {}
+            for tag, mod in (('ref', ref_utils), ('ora', oracle)):
+                a = [z.clone().requires_grad_(True) for z in ((z1, z2, z3) if three else (z1, z2))]
+                loss, frac = getattr(mod, cname)(reduction=red)(*a, t, fr, kd, torch.device('cpu'))
+                loss.backward()
+                vals[tag] = [loss.detach(), torch.as_tensor(frac).detach().float()] + \
+                    [x.grad.clone() if x.grad is not None else torch.zeros_like(z1) for x in a]
+            for i in range(len(vals['ref'])):
+                _same(vals['ref'][i], vals['ora'][i], '%s fr=%g #%d' % (cname, fr, i))
+            key = '%s/fr%g_kd%g_%s' % (cname, fr, kd, red)
+            fx[key + '/loss'], fx[key + '/frac'] = _np(vals['ref'][0]), _np(vals['ref'][1])
+            for i, g in enumerate(vals['ref'][2:]):
+                fx[key + '/grad%d' % (i + 1)] = _np(g)
+            print('g8', key, float(vals['ref'][0]), float(vals['ref'][1]))
+    np.savez_compressed(os.path.join(OUT, 'g8_pixelcoreg.npz'), **fx)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['g8']:
+        torch.set_num_threads(8)
+        ref_f, ref_u, ref_utils = _import_reference()
+        return g8_pixelcoreg(ref_utils)
     if sys.argv[1:] == ['g7']:
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()
@@ -438,6 +468,7 @@ def main():
     g2_config(ref_f, ref_utils)
     g6_inference(ref_f, ref_u, ref_utils)
     g7_coteach_ext(ref_utils)
+    g8_pixelcoreg(ref_utils)
     print('all golden fixtures written to', OUT)
 
 

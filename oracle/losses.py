@@ -13,6 +13,7 @@ Reference:
   utils/coteach_loss.py:85-92    KLbidirection
   utils/coteach_loss.py:163-196  Coteachingloss_dropregionce
   utils/coteach_loss.py:198-254  Coteachingloss_dropimagedroppixel
+  utils/reg_loss.py:58-193       Pixelcoreg_Focalloss, Pixelcoreg_Focalloss_twomodel
   utils/metrics2d.py:8-29  Dice_fn
   train_files/trainchaos_proposed_30cases1labeled.py:97-101 sharpen
 """
@@ -262,6 +263,66 @@ class Coteachingloss_dropimagedroppixel(nn.Module):
             order = torch.from_numpy(np.argsort(fore.detach().cpu().numpy(), kind='stable'))
             drop2 = torch.mean(fore[order[:keep2]])          # :249 num_remember2 of branch 1
         return u1.mean(dim=0) + 0.25 * drop1, u2.mean(dim=0) + 0.25 * drop2
+
+
+def _focal_kd_maps(targets, *inputs):
+    """reg_loss.py:69-97: one log_softmax / softmax per net, shared by the focal(gamma=2) terms (lossweight is
+    overwritten with 1, :67) and by KL(p1||p2) + KL(p2||p1) of nets 1 and 2 — same expression order as the
+    reference, so the autograd accumulation order (and with it the last bits of the gradients) is the same."""
+    n = targets.shape[0]
+    ls = [F.log_softmax(z, dim=1) for z in inputs]
+    sm = [F.softmax(z, dim=1) for z in inputs]
+    focal = [(-targets.float() * torch.pow(1 - q[:, 1, :, :], 2) * l[:, 1, :, :]
+              - 1 * (1 - targets).float() * torch.pow(1 - q[:, 0, :, :], 2) * l[:, 0, :, :]).view(n, -1)
+             for l, q in zip(ls, sm)]
+    p1, p2 = sm[0], sm[1]
+    k12 = (p1[:, 0, :, :] * torch.log(p1[:, 0, :, :] / p2[:, 0, :, :]) +
+           p1[:, 1, :, :] * torch.log(p1[:, 1, :, :] / p2[:, 1, :, :])).view(n, -1)
+    k21 = (p2[:, 0, :, :] * torch.log(p2[:, 0, :, :] / p1[:, 0, :, :]) +
+           p2[:, 1, :, :] * torch.log(p2[:, 1, :, :] / p1[:, 1, :, :])).view(n, -1)
+    return focal, k12, k21
+
+
+def _pixel_select(key, value, targets, forget_rate, reduction):
+    # reg_loss.py:101-129: per image the int((1 - forget_rate) * HW) pixels with the smallest key
+    n = key.shape[0]
+    order = torch.from_numpy(np.argsort(key.detach().cpu().numpy(), axis=-1, kind='stable'))
+    keep = int((1 - forget_rate) * key.shape[1])
+    upd = torch.cat([value[i, order[i, :keep]] for i in range(n)], dim=0).view(n, -1)
+    if reduction == 'mean':
+        upd = torch.mean(upd)
+    elif reduction == 'sum':
+        upd = torch.sum(upd)
+    ts = targets.view(n, -1)
+    tsel = torch.cat([ts[i, order[i, :keep]] for i in range(n)], dim=0)
+    return upd, tsel.sum() / targets.sum()
+
+
+class Pixelcoreg_Focalloss(nn.Module):
+    """reg_loss.py:58-131: three nets; pixels ranked by (1-kd)(focal1+focal2+focal3) + kd KL(1,2); the loss is the
+    mean of net 3's focal loss over the kept pixels; second output = kept foreground fraction."""
+
+    def __init__(self, smooth=1.0, reduction='mean'):
+        super().__init__()
+        self.reduction = reduction
+
+    def forward(self, inputs1, inputs2, inputs3, targets, forget_rate, kdweight, device=None):
+        (l1, l2, l3), k12, k21 = _focal_kd_maps(targets, inputs1, inputs2, inputs3)
+        key = (1 - kdweight) * (l1 + l2 + l3) + kdweight * (k12 + k21)
+        return _pixel_select(key, l3, targets, forget_rate, self.reduction)
+
+
+class Pixelcoreg_Focalloss_twomodel(nn.Module):
+    """reg_loss.py:133-193: two nets; the combined map is both the ranking key and the value that is averaged."""
+
+    def __init__(self, smooth=1.0, reduction='mean'):
+        super().__init__()
+        self.reduction = reduction
+
+    def forward(self, inputs1, inputs2, targets, forget_rate, kdweight, device=None):
+        (l1, l2), k12, k21 = _focal_kd_maps(targets, inputs1, inputs2)
+        key = (1 - kdweight) * (l1 + l2) + kdweight * (k12 + k21)
+        return _pixel_select(key, key, targets, forget_rate, self.reduction)
 
 
 def Dice_fn(inputs, targets, threshold=0.5):

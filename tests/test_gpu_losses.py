@@ -258,3 +258,28 @@ def test_select_smallest_ties_and_edges(dev):
     z = torch.zeros(64, device=dev)
     _, s0, k0 = _select(z, z, 1, 64, rr=0.5, only_positive=True)
     assert int(k0[0]) == 0 and torch.isnan(s0[0] / k0[0].double())
+
+
+@pytest.mark.parametrize('cname', ['Pixelcoreg_Focalloss', 'Pixelcoreg_Focalloss_twomodel'])
+def test_pixelcoreg_g8(dev, cname):
+    """utils/reg_loss.py:58-193 vs the real reference (g8_pixelcoreg.npz): loss, kept foreground fraction and the
+    gradients of every input (the three-net form differentiates net 3 only)."""
+    from aide_amd import utils as U
+    g3, fx = np.load(os.path.join(GOLD, 'g3_losses.npz')), np.load(os.path.join(GOLD, 'g8_pixelcoreg.npz'))
+    three = cname == 'Pixelcoreg_Focalloss'
+    zs = [torch.from_numpy(g3['z1']), torch.from_numpy(g3['z2'])] + ([torch.from_numpy(fx['z3'])] if three else [])
+    t = torch.from_numpy(g3['targets']).to(dev)
+    for fr, kd, red in ((0.0, 0.3, 'mean'), (0.25, 0.3, 'mean'), (0.5, 0.7, 'sum')):
+        key = '%s/fr%g_kd%g_%s' % (cname, fr, kd, red)
+        a = [z.clone().to(dev).requires_grad_(True) for z in zs]
+        loss, frac = getattr(U, cname)(reduction=red)(*a, t, fr, kd, dev)
+        assert abs(loss.item() - float(fx[key + '/loss'])) < 2e-5 * abs(float(fx[key + '/loss'])), (key, loss.item())
+        assert abs(frac.item() - float(fx[key + '/frac'])) < 2e-3
+        loss.backward()
+        for i, x in enumerate(a):
+            gr = fx[key + '/grad%d' % (i + 1)]
+            got = np.zeros_like(gr) if x.grad is None else x.grad.cpu().numpy()
+            bad = np.abs(got - gr) > 1e-4 * max(np.abs(gr).max(), 1e-30) + 1e-12
+            assert bad.mean() < 2e-4, (key, i, bad.sum())
+    with pytest.raises(NotImplementedError):
+        getattr(U, cname)(reduction='none')

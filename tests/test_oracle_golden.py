@@ -230,3 +230,21 @@ def test_coteach_ext_g7():
                 ls[which].backward()
                 for g, gk in ((a1.grad, '/l%d_grad1' % (which + 1)), (a2.grad, '/l%d_grad2' % (which + 1))):
                     close(torch.zeros_like(z1) if g is None else g, fx[key + gk], what=key + gk)
+
+
+@pytest.mark.parametrize('cname', ['Pixelcoreg_Focalloss', 'Pixelcoreg_Focalloss_twomodel'])
+def test_pixelcoreg_g8(cname):
+    """utils/reg_loss.py:58-193 restated in oracle/losses.py vs the reference's values (g8_pixelcoreg.npz)."""
+    g3, fx = load('g3_losses.npz'), load('g8_pixelcoreg.npz')
+    three = cname == 'Pixelcoreg_Focalloss'
+    zs = [torch.from_numpy(g3['z1']), torch.from_numpy(g3['z2'])] + ([torch.from_numpy(fx['z3'])] if three else [])
+    t = torch.from_numpy(g3['targets'])
+    for fr, kd, red in ((0.0, 0.3, 'mean'), (0.25, 0.3, 'mean'), (0.5, 0.7, 'sum')):
+        key = '%s/fr%g_kd%g_%s' % (cname, fr, kd, red)
+        a = [z.clone().requires_grad_(True) for z in zs]
+        loss, frac = getattr(oracle, cname)(reduction=red)(*a, t, fr, kd, torch.device('cpu'))
+        close(loss.detach(), fx[key + '/loss'], what=key)
+        close(torch.as_tensor(frac).float(), fx[key + '/frac'], what=key + ' frac')
+        loss.backward()
+        for i, x in enumerate(a):
+            close(torch.zeros_like(zs[0]) if x.grad is None else x.grad, fx[key + '/grad%d' % (i + 1)], what=key)
