@@ -10,7 +10,7 @@
 //   * chunk = 4 horizontally adjacent tiles (4 rows x 16 pixels).  dz tiles go global -> registers (a thread
 //     owns one (co, tile) and produces all 36 values of A Z A^T); input patches go through a double-buffered raw
 //     LDS tile and are transformed by (ci, tile, row-half) threads; ZT[36][64][4] and V[36][32][4] are double
-//     buffered, fragments are swizzled ds_read_b64;
+//     buffered as [p][tile pair][channel][2], so every ds_read_b64 fragment is 512 contiguous bytes;
 //   * vector-ALU work (it shares the pipe with the fp32 MFMA) sits in three clusters per chunk, the
 //     wave-uniform role branch is hoisted around the whole loop;
 //   * output: each wave reduces its 18 positions to a partial 3x3 (G^T M G is linear in the rows of M), partner
@@ -38,8 +38,8 @@ constexpr int G4_NAGPR = 16;
 constexpr int G4_RS = 20;                  // raw input row: [-1][0..15][16][2 pad]: patch of tile t starts at 4 t (16-byte aligned)
 constexpr int G4_DS = 144;                 // raw channel stride (= 16 mod 64: conflict-free b128 patch reads)
 constexpr int G4_RAW = 32 * G4_DS;         // 4608 floats
-constexpr int G4_ZT = 36 * 64 * 4;         // ZT[p][co][4 tiles]
-constexpr int G4_V = 36 * 32 * 4;          // V[p][ci][4 tiles]
+constexpr int G4_ZT = 36 * 64 * 4;         // ZT[p][2 tile pairs][64 co][2]
+constexpr int G4_V = 36 * 32 * 4;          // V[p][2 tile pairs][32 ci][2]
 constexpr int G4_SET = G4_ZT + G4_V;       // 13824 floats
 constexpr int G4_LDS = 2 * G4_SET + 2 * G4_RAW;   // 36864 floats = 144 KB (epilogue swap needs 4 x 72 x 64 = 18432)
 
@@ -191,8 +191,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
             to[6 * i + 3] = o34.x; to[6 * i + 4] = o34.y; to[6 * i + 5] = o05.y;
         }
     };
-    // operand rows are [channel][4 tiles]; rows with bit 4 set keep their two tile pairs swapped (ds_read_b64 banks)
-    const int vpos = vci * 4 + (((vtile >> 1) ^ ((vci >> 4) & 1)) * 2 + (vtile & 1));
+    const int vpos = (vtile >> 1) * 64 + vci * 2 + (vtile & 1);       // V[p][tile pair][ci][2]
     auto v_store = [&](int o, float* vbuf) { vbuf[(18 * hs + o) * 128 + vpos] = to[o]; };
 
     // ---- dz transform (A Z A^T), thread = (co_l, tile), all 36 values ----
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
             zo[6 * i + 3] = o34.x; zo[6 * i + 4] = o34.y; zo[6 * i + 5] = t23.y;
         }
     };
-    const int zpos = zco * 4 + (((zt >> 1) ^ ((zco >> 4) & 1)) * 2 + (zt & 1));
+    const int zpos = (zt >> 1) * 128 + zco * 2 + (zt & 1);            // ZT[p][tile pair][co][2]
     auto z_store = [&](int o, float* zbuf) { zbuf[o * 256 + zpos] = zo[o]; };
 
     float* const set0 = lds;
@@ -267,8 +266,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
     //   the raw input of c + 2 is fetched and stored into rawc (consumed by the previous chunk's transform).
     auto chunk = [&](int c, float* sc, float* sn, float* rawc, auto CUR) {
         constexpr int kcur = decltype(CUR)::value;
-        const float* la = sc + ((18 * ph) * 64 + cb * 32 + j) * 4 + (half ^ (j >> 4)) * 2;       // ZT[p][co][tiles]
-        const float* lb = sc + G4_ZT + ((18 * ph) * 32 + j) * 4 + (half ^ (j >> 4)) * 2;        // V[p][ci][tiles]
+        // operands are stored [p][tile pair][channel][2]: a wave's ds_read_b64 covers 512 contiguous bytes
+        const float* la = sc + (18 * ph) * 256 + half * 128 + (cb * 32 + j) * 2;                // ZT[p][pair][co 64][2]
+        const float* lb = sc + G4_ZT + (18 * ph) * 128 + half * 64 + j * 2;                     // V[p][pair][ci 32][2]
         f32x2 fa[6], fb[6];
         auto frag = [&](int pi, int s2) {
             fa[s2] = *reinterpret_cast<const f32x2*>(la + pi * 256);

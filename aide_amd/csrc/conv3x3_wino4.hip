@@ -42,7 +42,7 @@ constexpr int F4_NAGPR = 16;               // accumulators (of 18) kept in the A
 constexpr int F4_RRS = 41;                 // raw row: [3 pad][-1][0..31][32][4 pad]; odd: conflict-free raw stores
 constexpr int F4_RCS = 775;                // raw channel stride: (41, 775) makes patch reads AND raw stores conflict-free
 constexpr int F4_RAW = 4 * F4_RCS;         // 3100 floats
-constexpr int F4_V = 36 * 32 * 4;          // V[p][tile][4 ci]
+constexpr int F4_V = 36 * 32 * 4;          // V[p][2 channel pairs][32 tiles][2]
 constexpr int F4_SET = F4_RAW + F4_V;      // 7708 floats = 30832 B; two sets = 60.2 KB (filters never touch LDS)
 constexpr int F4_LDS = 2 * F4_SET > 4 * 128 * 64 ? 2 * F4_SET : 4 * 128 * 64;   // epilogue swap needs 32768
 
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     // wait for the filter fragments it has just requested.
     auto run = [&](auto HS) {
     auto xf_math = [&]() { xf_half(HS); };
-    const int vitem = item ^ ((item >> 5) & 2);            // tiles 16-31: channel pairs swapped (fragment swizzle)
+    const int vitem = ((item >> 1) & 1) * 64 + (item >> 2) * 2 + (item & 1);      // [pair][tile][2]
     auto xf_store = [&](int o, float* vbuf) { vbuf[(18 * hs + o) * 128 + vitem] = to[o]; };
 
     f32x16 acc[18];
@@ -213,9 +213,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     //   raw[s+2] is fetched and stored into sc.raw (consumed by the previous stage's transform).
     auto stage = [&](int s, float* sc, float* sn, auto CUR) {
         constexpr int kcur = decltype(CUR)::value;
-        // ds_read_b64 is serviced in lane groups {0-31} {32-63} over 64 banks: rows j and j + 16 of the
-        // [tile][4] layout would share a bank pair, so tiles 16-31 keep their two channel pairs swapped
-        const float* lb = sc + F4_RAW + ((18 * ph) * 32 + j) * 4 + (half ^ (j >> 4)) * 2;       // V[p][tile][ci]
+        // V[p][channel pair][tile][2]: a wave's ds_read_b64 covers 512 contiguous bytes in lane order (a
+        // [tile][4] row layout measured 2-way bank conflicts on every fragment read, with or without swizzle)
+        const float* lb = sc + F4_RAW + (18 * ph) * 128 + half * 64 + j * 2;
         f32x2 fb[6];                                       // B fragments, requested 4 slots ahead
         auto frag = [&](int pi, int slot2) { fb[slot2] = *reinterpret_cast<const f32x2*>(lb + pi * 128); };
         frag(0, 0); frag(1, 1); frag(2, 2); frag(3, 3);
