@@ -75,6 +75,9 @@ USE_WINOGRAD_DGRAD = [True]    # ... for the dgrad direction only
 # multiplies a launch executes per algorithmic (direct-convolution) multiply, by conv mode
 WINO_EXEC = 16.0 / 36.0
 EXEC_FRAC = {0: 1.0, 2: 16.0 / 36.0, 4: 36.0 / 144.0}
+# profiler tags = the kernel that does the work of one conv operator call (its split reduce rides along)
+FWD_TAG = {0: 'conv3x3_mfma_kernel', 2: 'conv3x3_wino_kernel', 4: 'conv3x3_wino4_kernel'}
+WGRAD_TAG = {0: 'conv3x3_wgrad_kernel', 2: 'conv3x3_wgrad_wino_kernel', 4: 'conv3x3_wgrad4_kernel'}
 USE_WINOGRAD4 = [True]
 
 
@@ -316,7 +319,7 @@ class Plan(object):
                 x = self.view(st['src'], inputs)
                 prof = self.profiler
                 if prof is not None:
-                    prof.begin('conv3x3_igemm', st['flops'], st['flops'] * EXEC_FRAC[st['wino_f']])
+                    prof.begin(FWD_TAG[st['wino_f']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_f']])
                 if st['wino_f'] == 4:
                     ops.conv3x3_wino4(x, st['uf'], conv.bias, st['z'], splitk=st['plan_f'] >> 8, ws=self.sk_ws)
                 elif st['wino_f']:
@@ -401,13 +404,13 @@ class Plan(object):
                             wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
                     else:
                         if prof is not None:
-                            prof.begin('conv3x3_wgrad', st['flops'], st['flops'] * EXEC_FRAC[st['wino_w']])
+                            prof.begin(WGRAD_TAG[st['wino_w']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_w']])
                         wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
                         if prof is not None:
                             prof.end()
                     if sg is not None:
                         if prof is not None:
-                            prof.begin('conv3x3_igemm', st['flops'], st['flops'] * EXEC_FRAC[st['wino_d']])
+                            prof.begin(FWD_TAG[st['wino_d']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_d']])
                         if st['wino_d'] == 4:
                             ops.conv3x3_wino4(dz, st['ud'], None, self.gview(st['src']),
                                               accumulate=sg['accumulate'], splitk=st['plan_d'] >> 8, ws=self.sk_ws)

@@ -19,9 +19,12 @@ def load(path, counter):
 
 
 F, W = load(fetch_csv, 'FETCH_SIZE'), load(write_csv, 'WRITE_SIZE')
-fam = {'conv3x3_igemm': ('conv3x3_mfma_kernel', 'conv3x3_wino_kernel', 'conv3x3_wino4_kernel', 'splitk_reduce_kernel'),
-       'conv3x3_wgrad': ('conv3x3_wgrad', 'wgrad_reduce_kernel')}
-ops_per_step = {'conv3x3_igemm': 62.0, 'conv3x3_wgrad': 32.0}     # conv operator calls per C2 step (fwd + dgrad / wgrad)
+# operator families as bench.py tags them: the main kernel (+ its split reduce on split layers)
+fam = {'conv3x3_wino4_kernel': ('conv3x3_wino4_kernel', 'w4_splitk_reduce_kernel'),
+       'conv3x3_wino_kernel': ('conv3x3_wino_kernel', 'wino_splitk_reduce_kernel'),
+       'conv3x3_mfma_kernel': ('conv3x3_mfma_kernel', '`splitk_reduce_kernel'),
+       'conv3x3_wgrad4_kernel': ('conv3x3_wgrad4_kernel',)}
+main = {k: v[0] for k, v in fam.items()}
 lines = ['# HBM traffic per kernel, FuseUNet C2 step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)', '',
          'Raw counter units are KB. FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads on gfx950',
          '(MI355X_MICROARCH.md, HBM section): the x2 column applies that correction; adam_kernel (20 B/param read, 16 B/param',
@@ -34,14 +37,17 @@ for n, (cnt, kb) in F.items():
     lines.append('| `%s` | %.1f | %.2f | %.2f | %.2f |' % (n, cnt / steps, kb / cnt / 1e3, 2 * kb / cnt / 1e3, wkb / max(W.get(n, [cnt])[0], 1) / 1e3))
     tf += kb; tw += wkb
     for k, pats in fam.items():
-        if any(p in n for p in pats):
+        if any(p.lstrip('`') in n and not (p.startswith('`') and not n.startswith(p[1:])) for p in pats):
             famtot[k][0] += 2 * kb * 1e3 / steps; famtot[k][1] += wkb * 1e3 / steps
 lines += ['', 'Whole step: FETCH raw %.2f GB (<= %.2f GB corrected), WRITE %.2f GB per step.' % (tf / steps / 1e6, 2 * tf / steps / 1e6, tw / steps / 1e6)]
 open(out_md, 'w').write('\n'.join(lines) + '\n')
 js = {}
 for k, (fb, wb) in famtot.items():
-    js[k] = dict(launches_per_step=ops_per_step[k], fetch_bytes_per_launch_corrected=fb / ops_per_step[k],
-                 write_bytes_per_launch=wb / ops_per_step[k], hbm_bytes_per_launch=(fb + wb) / ops_per_step[k],
+    calls = sum(c for n, (c, _) in F.items() if main[k] in n) / steps      # operator calls per step = main-kernel launches
+    if calls == 0:
+        continue
+    js[k] = dict(launches_per_step=calls, fetch_bytes_per_launch_corrected=fb / calls,
+                 write_bytes_per_launch=wb / calls, hbm_bytes_per_launch=(fb + wb) / calls,
                  source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py, FETCH x2 per MI355X_MICROARCH.md; '
                         'per conv operator call = main kernel + its split reduce')
 json.dump(js, open(out_json, 'w'), indent=1)
