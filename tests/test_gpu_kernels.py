@@ -318,3 +318,46 @@ def test_conv3x3_wgrad_winograd4(dev, case):
     F.conv2d(big[:, 32:], wt2, None, padding=1).backward(dy)
     ops.conv3x3_wgrad_wino4(dy.to(dev), big.to(dev)[:, 32:], dw)
     _close(dw, wt2.grad, rtol=1e-4, what='wino4 wgrad slice %s' % (case,))
+
+
+FULL_LAYERS = [(1024, 512, 32), (512, 256, 64), (256, 128, 128), (128, 64, 256), (64, 64, 256)]   # Ci, Co, H (= W), N = 4
+
+
+@pytest.mark.parametrize('layer', FULL_LAYERS)
+def test_full_size_layers_winograd_vs_direct(dev, layer):
+    """BASELINE config 2 layer sizes (N = 4), too large for the CPU oracle in a unit test: the three independent
+    implementations of the same operator — F(4x4,3x3), F(2x2,3x3) and the direct implicit GEMM — must agree
+    (forward, dgrad, wgrad; 1e-4 of the result scale), and the F(4x4) kernels must be linear in their input."""
+    from aide_amd import ops
+    ci, co, h = layer
+    n = 4
+    g = torch.Generator(device='cpu').manual_seed(ci + h)
+    x = torch.randn(n, ci, h, h, generator=g).to(dev)
+    w = (torch.randn(co, ci, 3, 3, generator=g) * (1.0 / (3.0 * ci ** 0.5))).to(dev)
+    b = torch.randn(co, generator=g).to(dev)
+    dy = torch.randn(n, co, h, h, generator=g).to(dev)
+    wf, wd = ops.pack_weights(w)
+    u2f, u2d = ops.wino_pack(w)
+    u4f, u4d = ops.wino4_pack(w)
+    y0 = ops.conv3x3_igemm(x, wf, b, torch.empty(n, co, h, h, device=dev))
+    y2 = ops.conv3x3_wino(x, u2f, b, torch.empty_like(y0))
+    y4 = ops.conv3x3_wino4(x, u4f, b, torch.empty_like(y0))
+    _close(y2, y0, rtol=1e-4, what='F2 vs direct fwd %s' % (layer,))
+    _close(y4, y0, rtol=1e-4, what='F4 vs direct fwd %s' % (layer,))
+    # linearity: conv(2 x1 - x2) == 2 conv(x1) - conv(x2) (no bias)
+    x2 = torch.randn(n, ci, h, h, generator=g).to(dev)
+    ya = ops.conv3x3_wino4(x, u4f, None, torch.empty_like(y0))
+    yb = ops.conv3x3_wino4(x2, u4f, None, torch.empty_like(y0))
+    yc = ops.conv3x3_wino4(2 * x - x2, u4f, None, torch.empty_like(y0))
+    _close(yc, 2 * ya - yb, rtol=1e-4, what='F4 linearity %s' % (layer,))
+    d0 = ops.conv3x3_igemm(dy, wd, None, torch.empty(n, ci, h, h, device=dev))
+    d4 = ops.conv3x3_wino4(dy, u4d, None, torch.empty_like(d0))
+    _close(d4, d0, rtol=1e-4, what='F4 vs direct dgrad %s' % (layer,))
+    g0 = ops.conv3x3_wgrad(dy, x, torch.empty_like(w))
+    g2 = ops.conv3x3_wgrad_wino(dy, x, torch.empty_like(w))
+    g4 = ops.conv3x3_wgrad_wino4(dy, x, torch.empty_like(w))
+    _close(g2, g0, rtol=1e-4, what='F2 vs direct wgrad %s' % (layer,))
+    _close(g4, g0, rtol=1e-4, what='F4 vs direct wgrad %s' % (layer,))
+    # determinism: a second launch is bit-identical (fixed-order split reductions, no atomics)
+    assert torch.equal(ops.conv3x3_wgrad_wino4(dy, x, torch.empty_like(w)), g4)
+    assert torch.equal(ops.conv3x3_wino4(x, u4f, b, torch.empty_like(y0)), y4)
