@@ -106,7 +106,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     // Filter fragments go global -> registers, never through LDS: wave (cb, ph) is the only consumer of
     // U[p in its half][co in its block], and the packed layout [stage][p][pair][Co][2] makes one position a
     // contiguous 512-byte dwordx2 load in exactly the MFMA A-operand lane order (lane = pair * 32 + co).
-    const __amdgpu_buffer_rsrc_t urs = make_rsrc(a.u + ((long)18 * ph * 2 * a.Cout + co0 + cb * 32) * 2);
+    // (Cout % 64 == 32: the upper co block of the last workgroup reads past its rows - into the next run, or past the
+    // tensor, where the exact-size descriptor returns zeros; those accumulator rows are never stored)
+    const long ubase = ((long)18 * ph * 2 * a.Cout + co0 + cb * 32) * 2;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.u + ubase), 0, (int)(((long)a.Cin * 36 * a.Cout - ubase) * 4), 0x00020000);
     const unsigned uoff = (unsigned)(half * a.Cout + j) * 8u;
     const unsigned upos = (unsigned)a.Cout * 16u;          // bytes per position
 
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
 #pragma unroll
             for (int o = 0; o < 16; ++o) yp[o] += xbuf[(((wid ^ 1) * 128) + rr * 16 + o) * 64 + lane];
             const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (pok) {
+            if (pok && co < a.Cout) {
                 const float bv = add_bias ? a.bias[co] : 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -447,11 +451,11 @@ __global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc*
 extern "C" {
 
 int aide_conv3x3_wino4_supported(int Cin, int H, int W, int Cout) {
-    return (H % 4 == 0 && W % 4 == 0 && H >= 16 && W >= 32 && Cout % 64 == 0 && Cin % 8 == 0) ? 1 : 0;
+    return (H % 4 == 0 && W % 4 == 0 && H >= 16 && W >= 32 && Cout % 32 == 0 && Cin % 8 == 0) ? 1 : 0;
 }
 
 int aide_conv3x3_wino4_splitk(int N, int Cin, int H, int W, int Cout) {
-    const long nb = (long)((H + 15) / 16) * ((W + 31) / 32) * N * (Cout / 64);
+    const long nb = (long)((H + 15) / 16) * ((W + 31) / 32) * N * ((Cout + 63) / 64);
     const int pairs = Cin / 8;                             // a split gets a whole number of stage pairs
     int s = 1;
     while (nb * s < 200 && pairs % (s * 2) == 0 && s * 2 <= pairs / 4) s *= 2;
@@ -487,7 +491,7 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
     }
     W4Args a;
     a.x = x; a.u = u; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
-    a.blocks_w = (W + 31) / 32; a.blocks_h = (H + 15) / 16; a.n_co_tiles = Cout / 64;
+    a.blocks_w = (W + 31) / 32; a.blocks_h = (H + 15) / 16; a.n_co_tiles = (Cout + 63) / 64;
     a.stages_total = Cin / 4;
     if (splitk < 1) splitk = 1;
     if ((Cin / 8) % splitk != 0) return AIDE_ERR_ARG;

@@ -87,7 +87,10 @@ def conv_mode(n, cin, h, w, cout):
     layers (1.3-1.5x over F(2x2) on the 19 / 39 GFLOP decoder layers); F(2x2) elsewhere; direct where neither
     is supported."""
     if USE_WINOGRAD[0] and USE_WINOGRAD4[0] and lib.aide_conv3x3_wino4_supported(cin, h, w, cout):
-        if 2.0 * n * h * w * cin * cout * 9 >= 8e9 or cin * cout >= 128 * 128:
+        flops = 2.0 * n * h * w * cin * cout * 9
+        if cout % 64:                       # trailing half block computed and dropped: 42 vs 52 us on 32->32 @256x256,
+            return 0                        # but the 4x larger filter pack eats the gain in the whole step
+        if flops >= 8e9 or cin * cout >= 128 * 128:
             return 4
     return 2 if use_winograd(n, cin, h, w, cout) else 0
 
