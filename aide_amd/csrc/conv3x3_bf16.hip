@@ -1,0 +1,650 @@
+// bf16-MFMA mode of the 3x3 / stride 1 / pad 1 convolution (BASELINE config 5):
+// bf16 operands in LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 tensors in HBM, fp32 master
+// weights / bias / BatchNorm statistics / loss.  Replaces (reference) nn.Conv2d(ci, co, 3, padding=1) forward and
+// autograd's convolution_backward at models_twomodalinputs/netblocks.py:17,24,26 and
+// models_singlemodalinput/UNet.py:12,19,21 when the engine runs with precision='bf16'.
+//
+// Numerics contract: every operand (activation, gradient, filter) is rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when it
+// is staged; products are exact in fp32 and the sums are fp32 fma chains, so the result equals an fp32 convolution
+// of the bf16-rounded operands up to summation order (tests/test_gpu_bf16.py checks exactly that, <= 2e-5).
+//
+// Forward / dgrad (conv3x3_bf16_kernel): implicit GEMM  D[co][pix] = sum_{ci,tap} W[co][ci,tap] X[ci][pix+tap].
+//   * one MFMA consumes 16 input channels at ONE tap: lanes 0-31 hold channels 0-7, lanes 32-63 channels 8-15 of
+//     their row (A: output channel) / column (B: pixel) -- 8 bf16 = one 16-byte LDS slot per lane per operand;
+//   * LDS image of the input halo tile is pixel-major: slot[g][row][col] = the 8 channels of group g at one pixel,
+//     so the B fragment of any tap is 32 consecutive slots (512 contiguous bytes per half wave: conflict free) and
+//     a tap shift is an immediate offset.  Staging converts NCHW fp32 -> that image in registers: a thread owns a
+//     pixel PAIR x 8 channels (eight coalesced 8-byte loads, eight v_cvt_pk, two ds_write_b128);
+//   * filters are pre-packed once per optimizer step to bf16 [Ci/16][tap][g][Co][8] = the A-fragment slot order, so
+//     a filter block moves global -> LDS as plain 16-byte pieces;
+//   * a workgroup (4 waves, one per SIMD) owns TCO x (TH rows x 32 pixels); the pipeline is two deep in registers:
+//     while chunk c is multiplied out of LDS buffer `cur`, the registers holding chunk c+1 (fetched one whole stage
+//     earlier) are converted and stored into the other buffer, and each freed register set immediately re-issues
+//     its loads for chunk c+2 -- one staging op per tap, so HBM latency has a full stage (~1 us) to land;
+//   * dgrad = the same kernel on the rotated, channel-transposed pack with an accumulate epilogue; split-K over
+//     channel chunks into slabs with a fixed-order reduce for the deep layers.
+//
+// Weight gradient (conv3x3_wgrad_bf16_kernel): dW[co][ci][tap] = sum_pix dz[co][pix] x[ci][pix+tap], K = pixels.
+//   * an MFMA consumes 16 consecutive pixels of one image row: NCHW rows are already K-contiguous, so both LDS
+//     images stay channel-major (dz [co][4 rows][32 px], x [ci][6 rows][-1..38 px], bf16);
+//   * the +-1 column shift of the x operand would need 2-byte-misaligned 16-byte reads; instead the x rows are
+//     stored starting at column -1, one aligned 32-byte window per (row, k-step) is read and the three shifted
+//     fragments are formed in registers (kw=0: the window itself, kw=1: four v_alignbit, kw=2: a register slice);
+//   * workgroup = 64 co x 64 ci x 9 taps (a wave owns 32 x 32 x 9 = 144 accumulators), stage = 4 image rows x 32
+//     columns, pixel range split over workgroups into slabs [split][tap][co][ci] reduced in fixed order
+//     (aide_wgrad_reduce_launch, shared with the fp32 kernels) -> bit-reproducible.
+#include "common.h"
+#include <stdlib.h>
+
+int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream);
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ u32x4 buf_load_u32x4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+
+// ------------------------------------------------------------------------------------------ forward / dgrad
+struct BfArgs {
+    const float* x;
+    const uint16_t* wp;
+    const float* bias;
+    float* y;
+    long x_bs, y_bs, split_stride;
+    int N, Cin, H, W, Cout;
+    int tiles_w, tiles_h, n_co_tiles, splitk, chunks_total, accumulate;
+};
+
+constexpr int BF_PITCH = 36;          // slots per halo-tile row: columns -2 .. 33 (18 pixel pairs)
+
+template <int WM, int WAVES_M, int WN, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) {
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int TCO = 32 * WM * WAVES_M;
+    constexpr int TH = WAVES_N * WN;               // image rows per tile (32 columns wide)
+    constexpr int PLANE = (TH + 2) * BF_PITCH;     // slots per channel group
+    constexpr int XS = 2 * PLANE;                  // halo-tile slots (2 groups of 8 channels)
+    constexpr int AS = 18 * TCO;                   // filter-block slots: [tap][g][TCO]
+    constexpr int BUF = XS + AS;
+    constexpr int UX = 2 * (TH + 2) * 18;          // pixel-pair units per stage
+    constexpr int NUX = (UX + 255) / 256;
+    constexpr int NUA = (AS + 255) / 256;
+    constexpr int NOPA0 = (9 - NUX) < NUA ? (9 - NUX) : NUA;
+    constexpr int APG = (NUA + NOPA0 - 1) / NOPA0;      // filter pieces per staging op
+    constexpr int NOPA = (NUA + APG - 1) / APG;
+    constexpr int NOPS = NUX + NOPA;                    // one staging op per tap
+    static_assert(NOPS <= 9, "staging schedule");
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * BUF slots
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    const int wave_m = wid / WAVES_N, wave_n = wid % WAVES_N;
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int co_tile = b % a.n_co_tiles; b /= a.n_co_tiles;
+    const int split = b % a.splitk;       b /= a.splitk;
+    const int tw = b % a.tiles_w;         b /= a.tiles_w;
+    const int th = b % a.tiles_h;
+    const int n = b / a.tiles_h;
+    const int h0 = th * TH, w0 = tw * 32, co0 = co_tile * TCO;
+    const int HW = a.H * a.W;
+
+    const int cps = (a.chunks_total + a.splitk - 1) / a.splitk;
+    const int c_begin = split * cps;
+    const int c_end = min(c_begin + cps, a.chunks_total);
+
+    // ---- per-thread staging descriptors (the same for every chunk) ----
+    unsigned offX[NUX], ldsX[NUX], chX[NUX];
+#pragma unroll
+    for (int e = 0; e < NUX; ++e) {
+        const int u = tid + e * 256;
+        const int g = u / ((TH + 2) * 18), rem = u - g * ((TH + 2) * 18);
+        const int row = rem / 18, pr = rem - row * 18;
+        const int ih = h0 - 1 + row, iw = w0 - 2 + 2 * pr;
+        const bool ok = u < UX && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        offX[e] = ok ? (unsigned)(g * 8 * HW + row * a.W + 2 * pr) * 4u : BUF_OOB;
+        ldsX[e] = u < UX ? (unsigned)(g * PLANE + row * BF_PITCH + 2 * pr) : 0xffffffffu;
+        chX[e] = (unsigned)(g * 8);
+    }
+    unsigned offA[NUA];
+#pragma unroll
+    for (int v = 0; v < NUA; ++v) {
+        const int p = tid + v * 256;
+        offA[v] = p < AS ? (unsigned)((p / TCO) * a.Cout + (p % TCO)) * 16u : BUF_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t xrs =
+        make_rsrc(a.x + (long)n * a.x_bs + (long)(h0 - 1) * a.W + (w0 - 2));
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.wp + (long)co0 * 8);
+    const bool ragged_c = (a.Cin & 15) != 0;
+
+    f32x2 xr[NUX][8];
+    u32x4 wr[NUA];
+    auto fetch = [&](int op, int chunk) {          // op is a compile-time index
+        const bool has = chunk < c_end;
+        const int ci0 = chunk * 16;
+        if (op < NUX) {
+            const int e = op;
+            const unsigned xs = (unsigned)ci0 * (unsigned)HW * 4u;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                unsigned off = has ? offX[e] : BUF_OOB;
+                if (ragged_c && ci0 + (int)chX[e] + c >= a.Cin) off = BUF_OOB;
+                xr[e][c] = buf_load_f32x2(xrs, off, xs + (unsigned)c * (unsigned)HW * 4u);
+            }
+        } else {
+            const unsigned ws = (unsigned)chunk * 18u * (unsigned)a.Cout * 16u;
+#pragma unroll
+            for (int k = 0; k < APG; ++k) {
+                const int v = (op - NUX) * APG + k;
+                if (v < NUA) wr[v] = buf_load_u32x4(wrs, has ? offA[v] : BUF_OOB, ws);
+            }
+        }
+    };
+    auto put = [&](int op, u32x4* buf) {
+        if (op < NUX) {
+            const int e = op;
+            if (ldsX[e] != 0xffffffffu) {
+                u32x4 s0, s1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s0[q] = pk_bf16(xr[e][2 * q].x, xr[e][2 * q + 1].x);
+                    s1[q] = pk_bf16(xr[e][2 * q].y, xr[e][2 * q + 1].y);
+                }
+                buf[ldsX[e]] = s0;
+                buf[ldsX[e] + 1] = s1;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < APG; ++k) {
+                const int v = (op - NUX) * APG + k;
+                if (v < NUA && tid + v * 256 < AS) buf[XS + tid + v * 256] = wr[v];
+            }
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.0f;
+
+    // lane slots of the operand fragments: pixel column c sits at slot c + 2 of its tile row
+    const int la = XS + half * TCO + wave_m * WM * 32 + j;
+    const int lb = half * PLANE + wave_n * WN * BF_PITCH + j + 1;
+
+    // prologue: chunk c_begin -> buffer 0, chunk c_begin + 1 stays in registers
+#pragma unroll
+    for (int op = 0; op < NOPS; ++op) fetch(op, c_begin);
+#pragma unroll
+    for (int op = 0; op < NOPS; ++op) put(op, lds);
+#pragma unroll
+    for (int op = 0; op < NOPS; ++op) fetch(op, c_begin + 1);
+    __syncthreads();
+
+    int cur = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const u32x4* pa = lds + cur * BUF + la;
+        const u32x4* pb = lds + cur * BUF + lb;
+        u32x4* nxt = lds + (cur ^ 1) * BUF;
+        bf16x8 afA[WM], bfA[WN], afB[WM], bfB[WN];
+        auto frag = [&](int t, bf16x8 (&af)[WM], bf16x8 (&bf)[WN]) {
+            const int kh = t / 3, kw = t % 3;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) af[m] = __builtin_bit_cast(bf16x8, pa[t * 2 * TCO + m * 32]);
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) bf[nt] = __builtin_bit_cast(bf16x8, pb[(nt + kh) * BF_PITCH + kw]);
+        };
+        auto kstep = [&](int t, bf16x8 (&afc)[WM], bf16x8 (&bfc)[WN], bf16x8 (&afn)[WM], bf16x8 (&bfn)[WN]) {
+            if (t + 1 < 9) frag(t + 1, afn, bfn);
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[m], bfc[nt], acc[m][nt], 0, 0, 0);
+            if (t < NOPS) {
+                put(t, nxt);               // chunk + 1 (fetched one stage ago) -> the other buffer
+                fetch(t, chunk + 2);       // its registers re-issue their loads at once
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        frag(0, afA, bfA);
+        kstep(0, afA, bfA, afB, bfB);
+        kstep(1, afB, bfB, afA, bfA);
+        kstep(2, afA, bfA, afB, bfB);
+        kstep(3, afB, bfB, afA, bfA);
+        kstep(4, afA, bfA, afB, bfB);
+        kstep(5, afB, bfB, afA, bfA);
+        kstep(6, afA, bfA, afB, bfB);
+        kstep(7, afB, bfB, afA, bfA);
+        kstep(8, afA, bfA, afB, bfB);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: D row i = (r&3) + 8*(r>>2) + 4*half (output channel), column j (pixel) ----
+    float* yn = a.y + (long)split * a.split_stride + (long)n * a.y_bs;
+    const bool add_bias = (a.bias != nullptr) && (split == 0);
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+        const int oh = h0 + wave_n * WN + nt;
+        const int ow = w0 + j;
+        const bool pok = oh < a.H;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (pok) {
+                    float v = acc[m][nt][r];
+                    if (add_bias) v += a.bias[co];
+                    float* p = yn + (long)co * HW + oh * a.W + ow;
+                    if (a.accumulate) v += *p;
+                    *p = v;
+                }
+            }
+        }
+    }
+}
+
+// y[n][c][p] (+)= bias[c] + sum_s slab[s][n][c][p]   (fixed summation order, 4 pixels per thread)
+__global__ void bf16_splitk_reduce_kernel(const float* __restrict__ slabs, long split_stride, int splitk,
+                                          float* __restrict__ y, long y_bs, int C, int HW,
+                                          const float* __restrict__ bias, int accumulate, long total4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long e = i * 4, chw = (long)C * HW;
+        const long n = e / chw, rem = e - n * chw;
+        f32x4 v = *reinterpret_cast<const f32x4*>(slabs + e);
+        for (int s = 1; s < splitk; ++s) v += *reinterpret_cast<const f32x4*>(slabs + (long)s * split_stride + e);
+        if (bias) v += bias[rem / HW];
+        f32x4* p = reinterpret_cast<f32x4*>(y + n * y_bs + rem);
+        if (accumulate) v += *p;
+        *p = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ filter pack
+// w[Co][Ci][9] fp32 -> uf[ceil(Ci/16)][9][2][Co][8] bf16 (forward) and ud[ceil(Co/16)][9 reversed][2][Ci][8]
+// (dgrad: 180-degree rotation + channel transpose).  One thread per 16-byte slot; padding channels are zero.
+struct BfPackDesc {
+    const float* w; uint16_t* uf; uint16_t* ud;
+    int Co, Ci, r0, r1;
+    long block_start;
+};
+
+__global__ __launch_bounds__(256) void bf16_pack_multi_kernel(const BfPackDesc* __restrict__ descs, int n) {
+    const long blk = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_start <= blk) lo = mid; else hi = mid - 1;
+    }
+    const BfPackDesc d = descs[lo];
+    const long nf = d.uf ? (long)((d.Ci + 15) / 16) * 18 * d.Co : 0;
+    const long nd = d.ud ? (long)((d.Co + 15) / 16) * 18 * d.Ci : 0;
+    const long i = (blk - d.block_start) * 256 + threadIdx.x;
+    float v[8];
+    if (i < nf) {
+        const int co = (int)(i % d.Co);
+        long r = i / d.Co;
+        const int g = (int)(r & 1); r >>= 1;
+        const int t = (int)(r % 9), chunk = (int)(r / 9);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int ci = chunk * 16 + g * 8 + c;
+            v[c] = ci < d.Ci ? d.w[((long)co * d.Ci + ci) * 9 + t] : 0.0f;
+        }
+    } else if (i < nf + nd) {
+        const long k = i - nf;
+        const int ci = (int)(k % d.Ci);
+        long r = k / d.Ci;
+        const int g = (int)(r & 1); r >>= 1;
+        const int t = (int)(r % 9), chunk = (int)(r / 9);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int co = chunk * 16 + g * 8 + c;
+            v[c] = co < d.Co ? d.w[((long)co * d.Ci + ci) * 9 + (8 - t)] : 0.0f;
+        }
+    } else {
+        return;
+    }
+    u32x4 s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] = pk_bf16(v[2 * q], v[2 * q + 1]);
+    u32x4* dst = reinterpret_cast<u32x4*>(i < nf ? d.uf : d.ud) + (i < nf ? i : i - nf);
+    *dst = s;
+}
+
+template <int WM, int WAVES_M, int WN, int OCC>
+int launch_bf16(BfArgs a, hipStream_t stream) {
+    constexpr int WAVES_N = 4 / WAVES_M, TCO = 32 * WM * WAVES_M, TH = WAVES_N * WN;
+    constexpr int BUF = 2 * (TH + 2) * BF_PITCH + 18 * TCO;
+    constexpr int LDS_BYTES = 2 * BUF * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    a.tiles_w = a.W / 32;
+    a.tiles_h = (a.H + TH - 1) / TH;
+    a.n_co_tiles = a.Cout / TCO;
+    const long nb = (long)a.tiles_w * a.tiles_h * a.N * a.n_co_tiles * a.splitk;
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC>), dim3((unsigned)nb), dim3(256), LDS_BYTES, stream, a);
+    return aide_launch_status();
+}
+
+// variant: 0 = 32 co x 16 rows, 1 = 64 co x 16 rows, 2 = 128 co x 8 rows (x 32 columns)
+int bf16_variant(int Cout) { return Cout % 128 == 0 ? 2 : (Cout % 64 == 0 ? 1 : 0); }
+long bf16_blocks(int variant, int N, int H, int W, int Cout) {
+    const int th = variant == 2 ? 8 : 16, tco = variant == 2 ? 128 : (variant == 1 ? 64 : 32);
+    return (long)(W / 32) * ((H + th - 1) / th) * N * (Cout / tco);
+}
+
+// ------------------------------------------------------------------------------------------ weight gradient
+struct BgArgs {
+    const float* dz;
+    const float* x;
+    float* slabs;
+    long dz_bs, x_bs;
+    int N, Co, Ci, H, W;
+    int n_co_tiles, n_ci_tiles, splits, chunks_total, segs_w, bands_h;
+};
+
+constexpr int G_R = 4;                       // dz rows per stage
+constexpr int G_DZP = G_R * 4 + 1;           // slots per dz channel (odd: conflict-free b128 across channels)
+constexpr int G_XP = (G_R + 2) * 5 + 1;      // slots per x channel: 6 rows x 5 slots (columns -1 .. 38)
+constexpr int G_DZS = 64 * G_DZP;
+constexpr int G_BUF = G_DZS + 64 * G_XP;     // slots per stage buffer
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs g) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * G_BUF slots
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    const int wco = wid >> 1, wci = wid & 1;
+
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci_tile = b % g.n_ci_tiles;    b /= g.n_ci_tiles;   // tiles of one pixel range are neighbours: they
+    const int co_tile = b % g.n_co_tiles;                         // share its dz / x rows in the XCD's L2
+    const int split = b / g.n_co_tiles;
+    const int co0 = co_tile * 64, ci0 = ci_tile * 64;
+    const int HW = g.H * g.W;
+    const int cps = (g.chunks_total + g.splits - 1) / g.splits;
+    const int c_begin = split * cps;
+    const int c_end = min(c_begin + cps, g.chunks_total);
+
+    // ---- staging descriptors ----
+    // dz: unit = (co, row, 8-pixel block): two 16-byte loads -> one slot
+    unsigned offD[4], ldsD[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int u = tid + e * 256;
+        const int blk = u & 3, row = (u >> 2) & 3, co = u >> 4;
+        offD[e] = (co0 + co < g.Co) ? (unsigned)(co * HW + row * g.W + blk * 8) * 4u : BUF_OOB;
+        ldsD[e] = (unsigned)(co * G_DZP + row * 4 + blk);
+    }
+    // x main: unit = (ci, tile row, slot s): columns 8s-1 .. 8s+6 of the segment -> one slot
+    unsigned offM[6], ldsM[6], rowM[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        const int u = tid + e * 256;
+        const int s = u & 3, rr = u >> 2;
+        const int row = rr % 6, ci = rr / 6;
+        offM[e] = (ci0 + ci < g.Ci) ? (unsigned)(ci * HW + row * g.W + s * 8 + 1) * 4u : BUF_OOB;   // base = column -1
+        ldsM[e] = (unsigned)(G_DZS + ci * G_XP + row * 5 + s);
+        rowM[e] = (unsigned)row | (s == 0 ? 8u : 0u);
+    }
+    // x edge: unit = (ci, tile row): columns 31, 32 -> first dword of slot 4
+    unsigned offE[2], ldsE[2], rowE[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int u = tid + e * 256;
+        const int row = u % 6, ci = u / 6;
+        const bool ok = u < 64 * 6 && ci0 + ci < g.Ci;
+        offE[e] = ok ? (unsigned)(ci * HW + row * g.W + 32) * 4u : BUF_OOB;
+        ldsE[e] = u < 64 * 6 ? (unsigned)(G_DZS + ci * G_XP + row * 5 + 4) : 0xffffffffu;
+        rowE[e] = (unsigned)row;
+    }
+
+    f32x4 dr[4][2];
+    float me[6];
+    f32x4 mr[6][2];
+    float er[2][2];
+    // ops 0..3 = dz units, 4..9 = x main units, 10..11 = x edge units
+    auto fetch = [&](int op, int chunk) {
+        const bool has = chunk < c_end;
+        const int seg = chunk % g.segs_w;
+        const int t2 = chunk / g.segs_w;
+        const int band = t2 % g.bands_h, n = t2 / g.bands_h;
+        const int h0 = band * G_R, w0 = seg * 32;
+        if (op < 4) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(g.dz + (long)n * g.dz_bs + (long)co0 * HW + (long)h0 * g.W + w0);
+            const unsigned off = has ? offD[op] : BUF_OOB;
+            dr[op][0] = buf_load_f32x4(rs, off, 0);
+            dr[op][1] = buf_load_f32x4(rs, off, 16);
+        } else if (op < 10) {
+            const int e = op - 4;
+            const __amdgpu_buffer_rsrc_t rs =
+                make_rsrc(g.x + (long)n * g.x_bs + (long)ci0 * HW + (long)(h0 - 1) * g.W + w0 - 1);
+            const int ih = h0 - 1 + (int)(rowM[e] & 7u);
+            const bool rowok = has && ih >= 0 && ih < g.H;
+            const unsigned off = rowok ? offM[e] : BUF_OOB;
+            const bool leftok = !(rowM[e] & 8u) || w0 > 0;        // column -1 of the image is zero padding
+            me[e] = buf_load_f32(rs, (leftok && off != BUF_OOB) ? off - 4u : BUF_OOB, 0);
+            mr[e][0] = buf_load_f32x4(rs, off, 0);
+            mr[e][1] = buf_load_f32x4(rs, off, 16);
+        } else {
+            const int e = op - 10;
+            const __amdgpu_buffer_rsrc_t rs =
+                make_rsrc(g.x + (long)n * g.x_bs + (long)ci0 * HW + (long)(h0 - 1) * g.W + w0 - 1);
+            const int ih = h0 - 1 + (int)rowE[e];
+            const bool rowok = has && ih >= 0 && ih < g.H;
+            const unsigned off = rowok ? offE[e] : BUF_OOB;
+            er[e][0] = buf_load_f32(rs, off, 0);
+            er[e][1] = buf_load_f32(rs, (off != BUF_OOB && w0 + 32 < g.W) ? off + 4u : BUF_OOB, 0);
+        }
+    };
+    auto put = [&](int op, u32x4* buf) {
+        if (op < 4) {
+            u32x4 s;
+            s[0] = pk_bf16(dr[op][0].x, dr[op][0].y); s[1] = pk_bf16(dr[op][0].z, dr[op][0].w);
+            s[2] = pk_bf16(dr[op][1].x, dr[op][1].y); s[3] = pk_bf16(dr[op][1].z, dr[op][1].w);
+            buf[ldsD[op]] = s;
+        } else if (op < 10) {
+            const int e = op - 4;
+            u32x4 s;
+            s[0] = pk_bf16(me[e], mr[e][0].x);        s[1] = pk_bf16(mr[e][0].y, mr[e][0].z);
+            s[2] = pk_bf16(mr[e][0].w, mr[e][1].x);   s[3] = pk_bf16(mr[e][1].y, mr[e][1].z);
+            buf[ldsM[e]] = s;
+        } else {
+            const int e = op - 10;
+            if (ldsE[e] != 0xffffffffu)
+                reinterpret_cast<unsigned*>(buf + ldsE[e])[0] = pk_bf16(er[e][0], er[e][1]);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    const int la = (wco * 32 + j) * G_DZP + half;
+    const int lb = G_DZS + (wci * 32 + j) * G_XP + half;
+
+#pragma unroll
+    for (int op = 0; op < 12; ++op) fetch(op, c_begin);
+#pragma unroll
+    for (int op = 0; op < 12; ++op) put(op, lds);
+#pragma unroll
+    for (int op = 0; op < 12; ++op) fetch(op, c_begin + 1);
+    __syncthreads();
+
+    int cur = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const u32x4* pa = lds + cur * G_BUF + la;
+        const u32x4* pb = lds + cur * G_BUF + lb;
+        u32x4* nxt = lds + (cur ^ 1) * G_BUF;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {              // k-step = (dz row r, 16-pixel half segment hs)
+            const int r = ks >> 1, hs = ks & 1;
+            const bf16x8 af = __builtin_bit_cast(bf16x8, pa[r * 4 + hs * 2]);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const u32x4 w0v = pb[(r + kh) * 5 + hs * 2];
+                const u32x4 w1v = pb[(r + kh) * 5 + hs * 2 + 1];
+                u32x4 s1, s2;
+                s1[0] = __builtin_amdgcn_alignbit(w0v[1], w0v[0], 16);
+                s1[1] = __builtin_amdgcn_alignbit(w0v[2], w0v[1], 16);
+                s1[2] = __builtin_amdgcn_alignbit(w0v[3], w0v[2], 16);
+                s1[3] = __builtin_amdgcn_alignbit(w1v[0], w0v[3], 16);
+                s2[0] = w0v[1]; s2[1] = w0v[2]; s2[2] = w0v[3]; s2[3] = w1v[0];
+                acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, w0v), acc[kh * 3 + 0], 0, 0, 0);
+                acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, s1), acc[kh * 3 + 1], 0, 0, 0);
+                acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, s2), acc[kh * 3 + 2], 0, 0, 0);
+            }
+            // staging: chunk + 1 registers -> the other buffer, then re-issue their loads for chunk + 2
+            if (ks < 6) {
+                put(2 * ks, nxt);     fetch(2 * ks, chunk + 2);
+                put(2 * ks + 1, nxt); fetch(2 * ks + 1, chunk + 2);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float* slab = g.slabs + (long)split * 9 * g.Co * g.Ci;
+    const int ci = ci0 + wci * 32 + j;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < g.Co && ci < g.Ci) slab[((long)t * g.Co + co) * g.Ci + ci] = acc[t][r];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// bf16 mode covers every layer whose width is a multiple of 32 and whose output channels are a multiple of 32
+// (all FuseUNet / UNet layers at 512x512 and the >= 32-wide levels of smaller inputs); the engine keeps the fp32
+// kernels for the rest.
+int aide_conv3x3_bf16_supported(int Cin, int H, int W, int Cout) {
+    return Cin >= 1 && H >= 1 && W >= 32 && W % 32 == 0 && Cout % 32 == 0;
+}
+
+// split factor over 16-channel chunks for layers that cannot fill 256 CUs with pixel x channel tiles
+int aide_conv3x3_bf16_splitk(int N, int Cin, int H, int W, int Cout) {
+    if (!aide_conv3x3_bf16_supported(Cin, H, W, Cout)) return 1;
+    const long nb = bf16_blocks(bf16_variant(Cout), N, H, W, Cout);
+    const int chunks = (Cin + 15) / 16;
+    int s = 1;
+    while (nb * s < 256 && s * 2 <= chunks / 4) s *= 2;
+    return s;
+}
+
+size_t aide_conv3x3_bf16_pack_elems(int Cout, int Cin) {    // bf16 elements of one direction's pack
+    return (size_t)((Cin + 15) / 16) * 18 * Cout * 8;
+}
+
+// descs: DEVICE array of n 48-byte records {const float* w; uint16* uf; uint16* ud (or 0); int32 Co, Ci, 0, 0;
+// int64 block_start}; an entry occupies ceil((slots_f + slots_d) / 256) workgroups, slots = pack_elems / 8.
+int aide_conv3x3_bf16_pack_multi(const void* descs, int n, int64_t total_blocks, hipStream_t stream) {
+    if (!descs || n <= 0 || total_blocks <= 0) return AIDE_ERR_ARG;
+    static_assert(sizeof(BfPackDesc) == 48, "descriptor layout");
+    hipLaunchKernelGGL(bf16_pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream,
+                       (const BfPackDesc*)descs, n);
+    return aide_launch_status();
+}
+
+// y (+)= conv3x3(x) with bf16-packed filters u (forward pack, or the dgrad pack with Cin/Cout swapped by the
+// caller).  x, y: fp32 NCHW with batch strides (elements); ws: split-K slabs (splitk * N*Cout*H*W floats).
+int aide_conv3x3_bf16(const float* x, int64_t x_bs, const uint16_t* u, const float* bias, float* y, int64_t y_bs,
+                      int N, int Cin, int H, int W, int Cout, int accumulate, int splitk, float* ws,
+                      hipStream_t stream) {
+    if (!x || !u || !y || N <= 0 || !aide_conv3x3_bf16_supported(Cin, H, W, Cout)) return AIDE_ERR_ARG;
+    BfArgs a;
+    a.x = x; a.wp = u; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
+    a.chunks_total = (Cin + 15) / 16;
+    if (splitk < 1) splitk = 1;
+    if (splitk > a.chunks_total) splitk = a.chunks_total;
+    if (splitk > 1 && (!ws || (y_bs % 4) != 0)) return AIDE_ERR_ARG;
+    a.splitk = splitk;
+    if (splitk > 1) {
+        a.y = ws; a.y_bs = (long)Cout * H * W; a.split_stride = (long)N * Cout * H * W;
+        a.bias = nullptr; a.accumulate = 0;
+    } else {
+        a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = accumulate;
+    }
+    int rc;
+    static const bool occ2 = !(getenv("AIDE_BF16_OCC") && atoi(getenv("AIDE_BF16_OCC")) == 1);   // probe switch
+    switch (bf16_variant(Cout)) {
+        case 2: rc = launch_bf16<2, 2, 4, 1>(a, stream); break;
+        case 1: rc = occ2 ? launch_bf16<2, 1, 4, 2>(a, stream) : launch_bf16<2, 1, 4, 1>(a, stream); break;
+        default: rc = launch_bf16<1, 1, 4, 2>(a, stream); break;
+    }
+    if (rc != 0) return rc;
+    if (splitk > 1) {
+        const long total4 = (long)N * Cout * H * W / 4;
+        const int blocks = (int)min((total4 + 255) / 256, (long)2048);
+        hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws,
+                           (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias, accumulate, total4);
+        rc = aide_launch_status();
+    }
+    return rc;
+}
+
+int aide_conv3x3_wgrad_bf16_supported(int Co, int Ci, int H, int W) {
+    return Co % 32 == 0 && Ci % 32 == 0 && W % 32 == 0 && H % G_R == 0;
+}
+
+int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W) {
+    const long tiles = (long)((Co + 63) / 64) * ((Ci + 63) / 64);
+    const long chunks = (long)N * (H / G_R) * (W / 32);
+    long s = (512 + tiles - 1) / tiles;          // two rounds of workgroups
+    if (s > chunks / 2) s = chunks / 2;          // at least two stages per workgroup
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+size_t aide_conv3x3_wgrad_bf16_ws_bytes(int N, int Co, int Ci, int H, int W) {
+    return (size_t)aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W) * 9 * Co * Ci * sizeof(float);
+}
+
+//   dz : [N][Co][H][W] (batch stride dz_bs)   a : [N][Ci][H][W] (batch stride a_bs)   dw : [Co][Ci][3][3] fp32
+int aide_conv3x3_wgrad_bf16(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N, int Co,
+                            int Ci, int H, int W, float* ws, hipStream_t stream) {
+    if (!dz || !a || !dw || !ws || N <= 0 || !aide_conv3x3_wgrad_bf16_supported(Co, Ci, H, W)) return AIDE_ERR_ARG;
+    if ((dz_bs % 4) || (a_bs % 4)) return AIDE_ERR_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * G_BUF * 16);
+        attr_set = true;
+    }
+    BgArgs g;
+    g.dz = dz; g.x = a; g.slabs = ws; g.dz_bs = dz_bs; g.x_bs = a_bs;
+    g.N = N; g.Co = Co; g.Ci = Ci; g.H = H; g.W = W;
+    g.n_co_tiles = (Co + 63) / 64; g.n_ci_tiles = (Ci + 63) / 64;
+    g.segs_w = W / 32; g.bands_h = H / G_R;
+    g.chunks_total = N * g.segs_w * g.bands_h;
+    g.splits = aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W);
+    const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
+    hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel, dim3((unsigned)nb), dim3(256), 2 * G_BUF * 16, stream, g);
+    const int rc = aide_launch_status();
+    if (rc != 0) return rc;
+    return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, stream);
+}
+
+}  // extern "C"

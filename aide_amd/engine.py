@@ -74,10 +74,13 @@ USE_WINOGRAD_DGRAD = [True]    # ... for the dgrad direction only
 
 # multiplies a launch executes per algorithmic (direct-convolution) multiply, by conv mode
 WINO_EXEC = 16.0 / 36.0
-EXEC_FRAC = {0: 1.0, 2: 16.0 / 36.0, 4: 36.0 / 144.0}
+BF16 = 16                      # conv mode id of the bf16-MFMA kernels (conv3x3_bf16.hip)
+EXEC_FRAC = {0: 1.0, 2: 16.0 / 36.0, 4: 36.0 / 144.0, BF16: 1.0}
 # profiler tags = the kernel that does the work of one conv operator call (its split reduce rides along)
-FWD_TAG = {0: 'conv3x3_mfma_kernel', 2: 'conv3x3_wino_kernel', 4: 'conv3x3_wino4_kernel'}
-WGRAD_TAG = {0: 'conv3x3_wgrad_kernel', 2: 'conv3x3_wgrad_wino_kernel', 4: 'conv3x3_wgrad4_kernel'}
+FWD_TAG = {0: 'conv3x3_mfma_kernel', 2: 'conv3x3_wino_kernel', 4: 'conv3x3_wino4_kernel', BF16: 'conv3x3_bf16_kernel'}
+WGRAD_TAG = {0: 'conv3x3_wgrad_kernel', 2: 'conv3x3_wgrad_wino_kernel', 4: 'conv3x3_wgrad4_kernel',
+             BF16: 'conv3x3_wgrad_bf16_kernel'}
+PRECISIONS = ('fp32', 'bf16')
 USE_WINOGRAD4 = [True]
 
 
@@ -137,8 +140,10 @@ class _Cover(object):
 
 
 class Plan(object):
-    def __init__(self, graph, params, n, h, w, device, training):
+    def __init__(self, graph, params, n, h, w, device, training, precision='fp32'):
         self.g, self.N, self.H, self.W, self.dev, self.training = graph, n, h, w, device, training
+        self.precision = precision
+        bf16 = precision == 'bf16'
         self.pindex = {id(p): i for i, p in enumerate(params)}
         f32 = dict(device=device, dtype=torch.float32)
         self.act = {}
@@ -165,9 +170,18 @@ class Plan(object):
                     # per output instead of 36); the direct implicit GEMM otherwise
                     st['wino_f'] = conv_mode(n, cin, hh, ww, cout)
                     st['wino_d'] = conv_mode(n, cout, hh, ww, cin) if (need_dg and USE_WINOGRAD_DGRAD[0]) else 0
+                    # precision='bf16': bf16 operands / fp32 accumulation wherever the bf16 kernels cover the
+                    # layer shape, the fp32 kernels elsewhere (narrow deep levels of small inputs, 3-channel wgrad)
+                    if bf16 and lib.aide_conv3x3_bf16_supported(cin, hh, ww, cout):
+                        st['wino_f'] = BF16
+                    if bf16 and need_dg and lib.aide_conv3x3_bf16_supported(cout, hh, ww, cin):
+                        st['wino_d'] = BF16
                     st['wf'] = st['wd'] = st['uf'] = st['ud'] = None
                     st['plan_f'] = st['plan_d'] = 0
-                    if st['wino_f'] == 4:
+                    if st['wino_f'] == BF16:
+                        st['uf'] = ops.bf16_pack_alloc(cout, cin, device)
+                        st['plan_f'] = lib.aide_conv3x3_bf16_splitk(n, cin, hh, ww, cout) << 8
+                    elif st['wino_f'] == 4:
                         st['uf'] = torch.empty(cin, 36, cout, **f32)
                         st['plan_f'] = lib.aide_conv3x3_wino4_splitk(n, cin, hh, ww, cout) << 8
                     elif st['wino_f']:
@@ -176,7 +190,10 @@ class Plan(object):
                     else:
                         st['wf'] = torch.empty(ops.pad_to(cin, ops.conv_chunk(cin)), 9, cout, **f32)
                         st['plan_f'] = lib.aide_conv3x3_plan(n, cin, hh, ww, cout)
-                    if need_dg and st['wino_d'] == 4:
+                    if need_dg and st['wino_d'] == BF16:
+                        st['ud'] = ops.bf16_pack_alloc(cin, cout, device)
+                        st['plan_d'] = lib.aide_conv3x3_bf16_splitk(n, cout, hh, ww, cin) << 8
+                    elif need_dg and st['wino_d'] == 4:
                         st['ud'] = torch.empty(cout, 36, cin, **f32)
                         st['plan_d'] = lib.aide_conv3x3_wino4_splitk(n, cout, hh, ww, cin) << 8
                     elif need_dg and st['wino_d']:
@@ -189,7 +206,10 @@ class Plan(object):
                                  lib.aide_conv3x3_ws_bytes(n, hh, ww, cin, st['plan_d'] >> 8) if need_dg else 0)
                     # weight gradient: transposed F(4x4,3x3) wherever supported (ahead on every layer of the sweep),
                     # else transposed F(2x2,3x3), else the direct kernel
-                    if USE_WINOGRAD[0] and USE_WINOGRAD4[0] and lib.aide_conv3x3_wgrad_wino4_supported(cout, cin, hh, ww):
+                    if bf16 and lib.aide_conv3x3_wgrad_bf16_supported(cout, cin, hh, ww):
+                        st['wino_w'] = BF16
+                        max_wg = max(max_wg, lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, cout, cin, hh, ww))
+                    elif USE_WINOGRAD[0] and USE_WINOGRAD4[0] and lib.aide_conv3x3_wgrad_wino4_supported(cout, cin, hh, ww):
                         st['wino_w'] = 4
                         max_wg = max(max_wg, lib.aide_conv3x3_wgrad_wino4_ws_bytes(n, cout, cin, hh, ww))
                     elif USE_WINOGRAD[0] and lib.aide_conv3x3_wgrad_wino_supported(cout, cin, hh, ww):
@@ -280,15 +300,22 @@ class Plan(object):
                 wino4 = [(st['conv'].weight, st['uf'] if st['wino_f'] == 4 else None,
                           st['ud'] if st['wino_d'] == 4 else None) for st in group
                          if (st['uf'] is not None and st['wino_f'] == 4) or (st['ud'] is not None and st['wino_d'] == 4)]
+                b16 = [(st['conv'].weight, st['uf'] if st['wino_f'] == BF16 else None,
+                        st['ud'] if st['wino_d'] == BF16 else None) for st in group
+                       if (st['uf'] is not None and st['wino_f'] == BF16) or (st['ud'] is not None and st['wino_d'] == BF16)]
                 return (ops.pack_table(direct, self.dev) if direct else None,
                         ops.wino_pack_table(wino, self.dev) if wino else None,
-                        ops.wino4_pack_table(wino4, self.dev) if wino4 else None)
+                        ops.wino4_pack_table(wino4, self.dev) if wino4 else None,
+                        ops.bf16_pack_table(b16, self.dev) if b16 else None)
             self._pack_tab = (ptrs, tables(convs[:split]), tables(convs[split:]) if len(convs) > split else None,
                               convs[split] if len(convs) > split else None)
         _, first, rest, gate = self._pack_tab
 
         def launch(tabs):
-            d, wn, w4 = tabs
+            d, wn, w4, b16 = tabs
+            if b16 is not None:
+                ops.check(lib.aide_conv3x3_bf16_pack_multi(ops.ptr(b16[0]), b16[1], b16[2], ops.stream_ptr()),
+                          'conv3x3_bf16_pack_multi')
             if w4 is not None:
                 ops.check(lib.aide_conv3x3_wino4_pack_multi(ops.ptr(w4[0]), w4[1], w4[2], ops.stream_ptr()),
                           'conv3x3_wino4_pack_multi')
@@ -323,7 +350,9 @@ class Plan(object):
                 prof = self.profiler
                 if prof is not None:
                     prof.begin(FWD_TAG[st['wino_f']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_f']])
-                if st['wino_f'] == 4:
+                if st['wino_f'] == BF16:
+                    ops.conv3x3_bf16(x, st['uf'], conv.bias, st['z'], splitk=st['plan_f'] >> 8, ws=self.sk_ws)
+                elif st['wino_f'] == 4:
                     ops.conv3x3_wino4(x, st['uf'], conv.bias, st['z'], splitk=st['plan_f'] >> 8, ws=self.sk_ws)
                 elif st['wino_f']:
                     ops.conv3x3_wino(x, st['uf'], conv.bias, st['z'], splitk=st['plan_f'] >> 8, ws=self.sk_ws)
@@ -397,7 +426,8 @@ class Plan(object):
                 x = self.view(st['src'], inputs)
                 if kind == 'conv':
                     prof = self.profiler
-                    wgrad = (ops.conv3x3_wgrad_wino4 if st['wino_w'] == 4 else
+                    wgrad = (ops.conv3x3_wgrad_bf16 if st['wino_w'] == BF16 else
+                             ops.conv3x3_wgrad_wino4 if st['wino_w'] == 4 else
                              ops.conv3x3_wgrad_wino if st['wino_w'] else ops.conv3x3_wgrad)
                     if side is not None:
                         ev = torch.cuda.Event()
@@ -414,7 +444,10 @@ class Plan(object):
                     if sg is not None:
                         if prof is not None:
                             prof.begin(FWD_TAG[st['wino_d']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_d']])
-                        if st['wino_d'] == 4:
+                        if st['wino_d'] == BF16:
+                            ops.conv3x3_bf16(dz, st['ud'], None, self.gview(st['src']),
+                                             accumulate=sg['accumulate'], splitk=st['plan_d'] >> 8, ws=self.sk_ws)
+                        elif st['wino_d'] == 4:
                             ops.conv3x3_wino4(dz, st['ud'], None, self.gview(st['src']),
                                               accumulate=sg['accumulate'], splitk=st['plan_d'] >> 8, ws=self.sk_ws)
                         elif st['wino_d']:
@@ -503,6 +536,21 @@ class Engine(object):
         self.before_backward = None      # callable(flat_grad) at the start of every backward
         self.side_stream = None          # stream carrying the weight-gradient kernels of the running backward
         self.graph = None
+        self._precision = 'fp32'
+
+    @property
+    def precision(self):
+        """'fp32' (default: exact-fp32 MFMA / Winograd kernels, the reference's arithmetic) or 'bf16' (BASELINE
+        config 5: bf16 conv operands, fp32 accumulation, fp32 everything else)."""
+        return self._precision
+
+    @precision.setter
+    def precision(self, value):
+        if value not in PRECISIONS:
+            raise ValueError('aide_amd: precision must be one of %s (got %r)' % (PRECISIONS, value))
+        if value != self._precision:
+            self._precision = value
+            self.plans = {}
 
     def _refresh_params(self):
         params = list(self.module.parameters())
@@ -523,10 +571,10 @@ class Engine(object):
         n, _, h, w = x.shape
         if h % 16 or w % 16:
             raise RuntimeError('aide_amd: H and W must be multiples of 16 (got %dx%d)' % (h, w))
-        key = (n, h, w, x.device.index, bool(self.module.training))
+        key = (n, h, w, x.device.index, bool(self.module.training), self._precision)
         plan = self.plans.get(key)
         if plan is None:
-            plan = Plan(self.graph, self.params, n, h, w, x.device, bool(self.module.training))
+            plan = Plan(self.graph, self.params, n, h, w, x.device, bool(self.module.training), self._precision)
             self.plans[key] = plan
         return plan
 

@@ -351,6 +351,75 @@ def conv3x3_wino4(x, u, bias, y, accumulate=False, splitk=-1, ws=None):
     return y
 
 
+# ------------------------------------------------------------------------------- bf16-MFMA conv mode
+def bf16_supported(cin, h, w, cout):
+    return bool(lib.aide_conv3x3_bf16_supported(cin, h, w, cout))
+
+
+def bf16_pack_alloc(cout, cin, device):
+    """Uninitialised bf16 pack of one direction: [ceil(cin/16)][9][2][cout][8] (as int16 storage)."""
+    return torch.empty(lib.aide_conv3x3_bf16_pack_elems(cout, cin), device=device, dtype=torch.int16)
+
+
+def bf16_pack_table(entries, device):
+    """entries: list of (w, uf|None, ud|None) -> (device table, n, total_blocks) for aide_conv3x3_bf16_pack_multi."""
+    import struct
+    rec, start = b'', 0
+    for w, uf, ud in entries:
+        co, ci = w.shape[0], w.shape[1]
+        rec += struct.pack('<QQQiiiiq', w.data_ptr(), uf.data_ptr() if uf is not None else 0,
+                           ud.data_ptr() if ud is not None else 0, co, ci, 0, 0, start)
+        slots = ((uf.numel() if uf is not None else 0) + (ud.numel() if ud is not None else 0)) // 8
+        start += (slots + 255) // 256
+    return torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(device), len(entries), start
+
+
+def bf16_pack(w, need_dgrad=True):
+    """w [Co,Ci,3,3] fp32 -> (uf, ud | None) bf16 packs (RNE)."""
+    _req(w)
+    co, ci = w.shape[0], w.shape[1]
+    uf = bf16_pack_alloc(co, ci, w.device)
+    ud = bf16_pack_alloc(ci, co, w.device) if need_dgrad else None
+    tab, n, blocks = bf16_pack_table([(w, uf, ud)], w.device)
+    check(lib.aide_conv3x3_bf16_pack_multi(ptr(tab), n, blocks, stream_ptr()), 'conv3x3_bf16_pack_multi')
+    return uf, ud
+
+
+def conv3x3_bf16(x, u, bias, y, accumulate=False, splitk=-1, ws=None):
+    """y (+)= conv3x3(x) on the bf16 MFMA path (fp32 tensors, bf16 operands, fp32 accumulation)."""
+    xp, xbs = planes(x)
+    yp, ybs = planes(y)
+    n, cin, h, w = x.shape
+    cout = y.shape[1]
+    assert u.dtype == torch.int16 and u.numel() == lib.aide_conv3x3_bf16_pack_elems(cout, cin)
+    if splitk < 0:
+        splitk = lib.aide_conv3x3_bf16_splitk(n, cin, h, w, cout)
+    if splitk > 1 and ws is None:
+        ws = torch.empty(lib.aide_conv3x3_ws_bytes(n, h, w, cout, splitk) // 4, device=x.device, dtype=torch.float32)
+    check(lib.aide_conv3x3_bf16(xp, xbs, ptr(u), ptr(bias), yp, ybs, n, cin, h, w, cout, int(accumulate), splitk,
+                                ptr(ws), stream_ptr()), 'conv3x3_bf16')
+    return y
+
+
+def wgrad_bf16_supported(co, ci, h, w):
+    return bool(lib.aide_conv3x3_wgrad_bf16_supported(co, ci, h, w))
+
+
+def conv3x3_wgrad_bf16(dz, a, dw, ws=None):
+    """dw [Co,Ci,3,3] fp32 <- weight gradient on the bf16 MFMA path."""
+    dzp, dzbs = planes(dz)
+    ap, abs_ = planes(a)
+    n, co, h, w = dz.shape
+    ci = a.shape[1]
+    assert tuple(dw.shape) == (co, ci, 3, 3) and dw.is_contiguous()
+    if ws is None:
+        ws = torch.empty(lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, co, ci, h, w) // 4, device=dz.device,
+                         dtype=torch.float32)
+    check(lib.aide_conv3x3_wgrad_bf16(dzp, dzbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), stream_ptr()),
+          'conv3x3_wgrad_bf16')
+    return dw
+
+
 def wgrad_wino4_supported(co, ci, h, w):
     return bool(lib.aide_conv3x3_wgrad_wino4_supported(co, ci, h, w))
 

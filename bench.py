@@ -23,6 +23,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md chip table
+BF16_MFMA_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak, same table
+WORKLOAD_PRECISION = {'c5': 'bf16'}
 WORKLOADS = {
     # name: (model, per-GPU batch, image size, fwd+bwd algorithmic GFLOP / image)
     'c2': ('fuseunet', 4, 256, 348.40),
@@ -30,6 +32,9 @@ WORKLOADS = {
     'c3': ('coteach', 4, 256, 1626.5),
     'c4': ('UNet', 4, 320, 612.32),
     'c2-512': ('fuseunet', 4, 512, 1393.58),
+    # BASELINE config 5: FuseUNet bf16 MFMA path, 512x512 2-modal, bs=8/GPU (bf16 conv operands, fp32 accumulate,
+    # fp32 master weights / BatchNorm statistics / loss / Adam)
+    'c5': ('fuseunet', 8, 512, 1393.58),
     'tiny': ('fuseunet', 2, 64, 348.40 / 16),
 }
 
@@ -41,6 +46,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--batch_size', type=int, default=None, help='per-GPU batch (default: workload)')
+    ap.add_argument('--precision', default=None, choices=('fp32', 'bf16'),
+                    help='conv arithmetic (default: fp32, bf16 for workload c5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--no-kernel-events', action='store_true',
@@ -157,6 +164,9 @@ def main():
         return main_coteach(args, rank, world, device, batch, size, gflop_img)
     net = build(model_name, device)
     net.train()
+    precision = args.precision or WORKLOAD_PRECISION.get(args.workload, 'fp32')
+    net.engine.precision = precision
+    peak = BF16_MFMA_PEAK_TFLOPS if precision == 'bf16' else FP32_MFMA_PEAK_TFLOPS
     if world > 1:
         broadcast_module(net)
     reducer = GradAllReduce(net) if world > 1 else None
@@ -221,13 +231,13 @@ def main():
                     # this kernel family come from the committed rocprofv3 --pmc passes (profiles/)
                     traffic = json.load(open(tpath)).get(dom[0], {}).get('hbm_bytes_per_launch')
                 roof = dict(bound='mfma', kernel=dom[0], achieved=round(a['tflops'], 2),
-                            peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                            frac=round(a['tflops'] / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                            peak=peak, unit='TFLOP/s',
+                            frac=round(a['tflops'] / peak, 4), traffic=traffic,
                             # Winograd launches execute 16/36 of the algorithmic multiplies: `achieved`
                             # (algorithmic, as the contract defines it) may exceed the MFMA peak,
                             # `executed` is what the MFMA pipe really sustains
                             executed=round(a['executed_tflops'], 2),
-                            executed_frac=round(a['executed_tflops'] / FP32_MFMA_PEAK_TFLOPS, 4),
+                            executed_frac=round(a['executed_tflops'] / peak, 4),
                             launches_per_step=a['launches'] // ev_steps,
                             avg_launch_ms=round(a['avg_ms'], 5),
                             alg_gflop_per_launch=round(a['flops'] / a['launches'] / 1e9, 3))
@@ -238,14 +248,17 @@ def main():
                         ('FuseUNet %dx%dx2' if model_name == 'fuseunet' else 'UNet %dx%d') % (size, size), batch),
                     value=round(value, 2), unit='images/sec', n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True,
-                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                    config=dict(workload='%s %s fwd+loss+bwd+Adam(amsgrad), %dx%d %s, bs=%d/GPU, fp32'
+                    scaling='weak', vs_baseline=None, dtype='f32' if precision == 'fp32' else 'bf16',
+                    data='synthetic',
+                    config=dict(workload='%s %s fwd+loss+bwd+Adam(amsgrad), %dx%d %s, bs=%d/GPU, %s'
                                          % (args.workload, model_name, size, size,
-                                            '2-modal' if model_name == 'fuseunet' else '1-modal', batch),
+                                            '2-modal' if model_name == 'fuseunet' else '1-modal', batch,
+                                            'fp32' if precision == 'fp32' else
+                                            'bf16 conv operands / fp32 accumulate, fp32 BN+loss+Adam'),
                                 global_batch=batch * world, parallelism='dp%d' % world,
                                 alg_gflop_per_image=gflop_img),
                     step_tflops=round(value * gflop_img / 1e3, 2),
-                    step_mfma_frac=round(value * gflop_img / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+                    step_mfma_frac=round(value * gflop_img / 1e3 / world / peak, 4),
                     final_loss=round(final_loss, 6), roofline=roof, kernels=kernels, cpu_baseline=cpu)
         print(json.dumps(line))
     if world > 1:

@@ -78,6 +78,28 @@ size_t aide_conv3x3_wgrad_wino4_ws_bytes(int N, int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
                              int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
 
+/* ---- bf16-MFMA mode of the same convolution (BASELINE config 5: "FuseUNet bf16 MFMA path") -------------------
+ * replaces the same nn.Conv2d call sites (netblocks.py:17,24,26; UNet.py:12,19,21) when the engine runs with
+ * precision='bf16': operands are rounded to bf16 (RNE) while they are staged into LDS, products accumulate in fp32
+ * (v_mfma_f32_32x32x16_bf16); tensors in HBM, master weights, bias, BatchNorm statistics and the loss stay fp32.
+ * Filters are pre-packed to bf16: uf [ceil(Ci/16)][9][2][Co][8], ud [ceil(Co/16)][9 reversed][2][Ci][8].
+ * Supported: W % 32 == 0, Cout % 32 == 0 (forward / dgrad); Co % 32 == 0, Ci % 32 == 0, W % 32 == 0, H % 4 == 0
+ * (weight gradient).  The engine keeps the fp32 kernels for every other layer. */
+int aide_conv3x3_bf16_supported(int Cin, int H, int W, int Cout);
+int aide_conv3x3_bf16_splitk(int N, int Cin, int H, int W, int Cout);
+size_t aide_conv3x3_bf16_pack_elems(int Cout, int Cin);          /* bf16 elements of one direction's pack */
+/* descs = DEVICE array of n 48-byte records {const float* w; uint16_t* uf; uint16_t* ud (or 0); int32 Co, Ci, 0, 0;
+ * int64 block_start}; an entry occupies ceil((elems_f + elems_d) / 8 / 256) workgroups */
+int aide_conv3x3_bf16_pack_multi(const void* descs, int n, int64_t total_blocks, aide_stream_t stream);
+int aide_conv3x3_bf16(const float* x, int64_t x_bs, const uint16_t* u, const float* bias, float* y, int64_t y_bs,
+                      int N, int Cin, int H, int W, int Cout, int accumulate, int splitk, float* ws,
+                      aide_stream_t stream);                     /* forward and dgrad */
+int aide_conv3x3_wgrad_bf16_supported(int Co, int Ci, int H, int W);
+int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W);
+size_t aide_conv3x3_wgrad_bf16_ws_bytes(int N, int Co, int Ci, int H, int W);
+int aide_conv3x3_wgrad_bf16(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
+                            int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
+
 /* ---- ConvTranspose2d(k=2, s=2) (learned_bilinear=True up path) ---------------------------------
  * replaces nn.ConvTranspose2d: netblocks.py:12, UNet.py:7 */
 int aide_convT2x2_fwd(const float* x, int64_t x_bs, const float* w /*[Ci][Co][2][2]*/, const float* b,

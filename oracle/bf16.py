@@ -1,0 +1,64 @@
+"""bf16-operand emulation of the 3x3 convolutions of an oracle network (TEST INFRASTRUCTURE ONLY).
+
+BASELINE config 5 asks for a bf16 MFMA path.  The product's contract (aide_amd/csrc/conv3x3_bf16.hip) is:
+conv operands -- activations, incoming gradients, filters -- are rounded to bf16 (round-to-nearest-even) where
+they enter a convolution, products are accumulated in fp32, and everything else (bias, BatchNorm, pooling,
+up-sampling, head, loss, Adam) is the fp32 arithmetic of the reference.  `emulate_bf16(net)` rewires the
+nn.Conv2d(.., 3, padding=1) layers of an oracle network (oracle/nets.py, which follows
+models_twomodalinputs/netblocks.py:24-27 and models_singlemodalinput/UNet.py:19-22) to exactly that arithmetic with
+stock aten CPU ops, for the layers / directions the product runs in bf16 (same shape predicates as
+include/aide_hip.h: aide_conv3x3_bf16_supported / aide_conv3x3_wgrad_bf16_supported, restated here in Python so
+the oracle never calls into the HIP library)."""
+import types
+
+import torch
+import torch.nn.functional as F
+
+
+def rb(t):
+    """fp32 -> bf16 (RNE) -> fp32"""
+    return t.bfloat16().float()
+
+
+def conv_bf16_supported(cin, h, w, cout):
+    return w >= 32 and w % 32 == 0 and cout % 32 == 0
+
+
+def wgrad_bf16_supported(co, ci, h, w):
+    return co % 32 == 0 and ci % 32 == 0 and w % 32 == 0 and h % 4 == 0
+
+
+class _ConvBf16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        n, ci, h, wd = x.shape
+        co = w.shape[0]
+        if conv_bf16_supported(ci, h, wd, co):
+            return F.conv2d(rb(x), rb(w), b, padding=1)
+        return F.conv2d(x, w, b, padding=1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        n, ci, h, wd = x.shape
+        co = w.shape[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if conv_bf16_supported(co, h, wd, ci):           # dgrad = the same kernel with the channel roles swapped
+                dx = F.conv_transpose2d(rb(dy), rb(w), padding=1)
+            else:
+                dx = F.conv_transpose2d(dy, w, padding=1)
+        if wgrad_bf16_supported(co, ci, h, wd):
+            dw = torch.nn.grad.conv2d_weight(rb(x), w.shape, rb(dy), padding=1)
+        else:
+            dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1)
+        return dx, dw, dy.sum((0, 2, 3))
+
+
+def emulate_bf16(net):
+    """Rewire every 3x3/pad-1 nn.Conv2d of `net` (in place; parameters and state_dict keys unchanged)."""
+    for m in net.modules():
+        if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.padding == (1, 1):
+            m.forward = types.MethodType(lambda self, x: _ConvBf16.apply(x, self.weight, self.bias), m)
+    return net

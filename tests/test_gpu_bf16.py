@@ -1,0 +1,229 @@
+"""bf16-MFMA conv mode (-m gpu; BASELINE config 5).  Contract (aide_amd/csrc/conv3x3_bf16.hip): operands are rounded
+to bf16 (RNE) when staged, products accumulate in fp32.  The check is therefore two-sided:
+  * tight: against the aten fp32 convolution of the bf16-ROUNDED operands (what the kernel computes, up to fp32
+    summation order) -- tolerance 3e-5 of the output scale;
+  * loose: against the plain fp32 convolution of the unrounded operands -- the bf16 input-rounding bound
+    (2^-8 relative per operand, random signs): 1e-2 of the output scale.
+The packed filters are compared bit-exactly with torch's RNE bf16 conversion."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rb(t):
+    return t.bfloat16().float()
+
+
+def _close(got, ref, rtol, what=''):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, '%s: max abs err %.3e > %.3e (ref scale %.3e)' % (what, err, rtol * scale, scale)
+
+
+def test_bf16_pack_bit_exact(dev):
+    from aide_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for co, ci in ((32, 3), (64, 40), (128, 64)):
+        w = torch.randn(co, ci, 3, 3, generator=g)
+        uf, ud = ops.bf16_pack(w.to(dev))
+        torch.cuda.synchronize()
+        cf, cd = (ci + 15) // 16, (co + 15) // 16
+        wb = w.bfloat16().view(torch.int16)                      # [co][ci][3][3] bit patterns
+        ref_f = torch.zeros(cf * 16, 9, co, dtype=torch.int16)
+        ref_f[:ci] = wb.reshape(co, ci, 9).permute(1, 2, 0)
+        ref_f = ref_f.view(cf, 2, 8, 9, co).permute(0, 3, 1, 4, 2).contiguous()      # [chunk][tap][g][co][8]
+        assert torch.equal(uf.cpu().view(cf, 9, 2, co, 8), ref_f), 'forward pack %dx%d' % (co, ci)
+        ref_d = torch.zeros(cd * 16, 9, ci, dtype=torch.int16)
+        ref_d[:co] = wb.reshape(co, ci, 9).flip(2).permute(0, 2, 1)
+        ref_d = ref_d.view(cd, 2, 8, 9, ci).permute(0, 3, 1, 4, 2).contiguous()
+        assert torch.equal(ud.cpu().view(cd, 9, 2, ci, 8), ref_d), 'dgrad pack %dx%d' % (co, ci)
+
+
+BF16_CASES = [
+    # N, Cin, Cout, H, W
+    (2, 3, 32, 32, 32), (1, 32, 32, 64, 64), (2, 64, 64, 32, 32), (1, 128, 64, 64, 64), (2, 64, 128, 16, 32),
+    (1, 256, 256, 32, 32), (1, 40, 96, 24, 64), (2, 512, 512, 32, 32), (1, 32, 64, 20, 96),
+]
+
+
+@pytest.mark.parametrize('case', BF16_CASES)
+def test_conv3x3_bf16_fwd_dgrad(dev, case):
+    from aide_amd import ops
+    n, ci, co, h, w = case
+    assert ops.bf16_supported(ci, h, w, co)
+    g = torch.Generator().manual_seed(ci * 131 + co)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) * (1.0 / (3.0 * ci ** 0.5))
+    b = torch.randn(co, generator=g)
+    dy = torch.randn(n, co, h, w, generator=g)
+    y_exact = F.conv2d(_rb(x), _rb(wt), b, padding=1)
+    y_fp32 = F.conv2d(x, wt, b, padding=1)
+    dx_exact = F.conv_transpose2d(_rb(dy), _rb(wt), padding=1)
+    dx_fp32 = F.conv_transpose2d(dy, wt, padding=1)
+
+    xd, wd_, bd, dyd = x.to(dev), wt.to(dev), b.to(dev), dy.to(dev)
+    uf, ud = ops.bf16_pack(wd_, need_dgrad=(ci % 32 == 0))
+    for splitk in (1, 2, 4):
+        if splitk > (ci + 15) // 16:
+            continue
+        y = torch.full((n, co, h, w), float('nan'), device=dev)
+        ops.conv3x3_bf16(xd, uf, bd, y, splitk=splitk)
+        _close(y, y_exact, 3e-5, 'fwd exact splitk %d %s' % (splitk, case))
+        _close(y, y_fp32, 1e-2, 'fwd vs fp32 splitk %d %s' % (splitk, case))
+    if ud is not None:
+        for splitk in (1, 2):
+            base = torch.randn(n, ci, h, w, generator=g)
+            dx = base.to(dev)
+            ops.conv3x3_bf16(dyd, ud, None, dx, accumulate=True, splitk=splitk)       # skip-connection form
+            _close(dx, dx_exact + base, 3e-5, 'dgrad exact splitk %d %s' % (splitk, case))
+            _close(dx, dx_fp32 + base, 1e-2, 'dgrad vs fp32 %s' % (case,))
+
+
+def test_conv3x3_bf16_channel_slices(dev):
+    """inputs / outputs that are channel slices of concatenation buffers (explicit batch stride)."""
+    from aide_amd import ops
+    g = torch.Generator().manual_seed(9)
+    n, ci, co, h, w = 2, 32, 64, 32, 32
+    xbuf = torch.randn(n, ci + 16, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) * 0.05
+    ybuf = torch.zeros(n, co + 32, h, w)
+    yr = F.conv2d(_rb(xbuf[:, 16:]), _rb(wt), None, padding=1)
+    xd, yd = xbuf.to(dev), ybuf.to(dev)
+    uf, _ = ops.bf16_pack(wt.to(dev), need_dgrad=False)
+    ops.conv3x3_bf16(xd[:, 16:], uf, None, yd[:, 32:])
+    _close(yd[:, 32:], yr, 3e-5, 'slice fwd')
+    assert float(yd[:, :32].abs().max()) == 0.0
+
+
+WGRAD_CASES = [
+    # N, Co, Ci, H, W
+    (2, 32, 32, 32, 32), (1, 64, 64, 64, 64), (2, 64, 128, 16, 32), (1, 128, 64, 32, 96), (2, 256, 256, 32, 32),
+    (1, 96, 32, 8, 64), (3, 64, 64, 4, 32),
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_CASES)
+def test_conv3x3_wgrad_bf16(dev, case):
+    from aide_amd import ops
+    n, co, ci, h, w = case
+    assert ops.wgrad_bf16_supported(co, ci, h, w)
+    g = torch.Generator().manual_seed(co * 17 + ci)
+    x = torch.randn(n, ci, h, w, generator=g)
+    dy = torch.randn(n, co, h, w, generator=g)
+
+    def wgrad_ref(xx, dd):
+        wt = torch.zeros(co, ci, 3, 3, requires_grad=True)
+        F.conv2d(xx, wt, None, padding=1).backward(dd)
+        return wt.grad
+    dw_exact = wgrad_ref(_rb(x), _rb(dy))
+    dw_fp32 = wgrad_ref(x, dy)
+    dw = torch.full((co, ci, 3, 3), float('nan'), device=dev)
+    ops.conv3x3_wgrad_bf16(dy.to(dev), x.to(dev), dw)
+    _close(dw, dw_exact, 5e-5, 'wgrad exact %s' % (case,))
+    _close(dw, dw_fp32, 1e-2, 'wgrad vs fp32 %s' % (case,))
+    dw2 = torch.empty_like(dw)
+    ops.conv3x3_wgrad_bf16(dy.to(dev), x.to(dev), dw2)
+    assert torch.equal(dw, dw2), 'wgrad must be bit-reproducible'
+
+
+# ------------------------------------------------------------------------------------------ whole network
+def _pair(dev, kind='fuseunet'):
+    import oracle
+    from oracle.bf16 import emulate_bf16
+    from aide_amd.models_twomodalinputs import fuseunet
+    from aide_amd.models_singlemodalinput import UNet
+    ours_c, ref_c = (fuseunet, oracle.fuseunet) if kind == 'fuseunet' else (UNet, oracle.UNet)
+    torch.manual_seed(2)
+    ref = emulate_bf16(ref_c(2))
+    torch.manual_seed(2)
+    net = ours_c(2).to(dev)
+    net.engine.precision = 'bf16'
+    return net, ref
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize('kind', ['fuseunet', 'UNet'])
+def test_bf16_network_vs_bf16_oracle(dev, kind):
+    """precision='bf16' against the oracle whose 3x3 convolutions use bf16-rounded operands (oracle/bf16.py) for the
+    same layers: logits, loss and every parameter gradient.  A bf16 rounding point is a discontinuity like a ReLU
+    mask (an fp32-noise difference before the rounding moves one operand by a bf16 ulp: ~3e-4 of all operands flip
+    between two fp32 implementations), and this random-init, 2-image, 64x64 network amplifies perturbations (the
+    full bf16 rounding moves its logits by 10 %), so the bounds are 1e-2 of the tensor scale for logits, 5e-3 for the
+    loss and 5e-2 for gradients; the kernels themselves are held to 3e-5 above."""
+    import oracle
+    from aide_amd import utils as U
+    from aide_amd.engine import BF16
+    net, ref = _pair(dev, kind)
+    g = torch.Generator().manual_seed(1234)
+    n, s = 2, 64
+    xs = [torch.randn(n, 3, s, s, generator=g) for _ in range(2 if kind == 'fuseunet' else 1)]
+    t = (torch.rand(n, s, s, generator=g) > 0.7).long()
+    w = torch.tensor([1.0, 1.0])
+    ref.train(); net.train()
+    out = net(*[x.to(dev) for x in xs])
+    loss = U.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)(out, t.to(dev))
+    loss.backward()
+    plan = list(net.engine.plans.values())[0]
+    # the oracle's backward runs on OUR ReLU masks / pooling winners (tests/test_gpu_models.py: a mask element that
+    # flips because the two forwards differ in the last digits is a property of the arithmetic, not of either side)
+    from test_gpu_models import forced_relu_masks
+    with forced_relu_masks(net, ref, plan) as fm:
+        out_r = ref(*xs)
+        loss_r = oracle.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)(out_r, t)
+        loss_r.backward()
+    assert sum(fm.flips.values()) <= 2e-3 * fm.total, 'implausibly many ReLU mask flips: %s' % fm.flips
+    modes = [(st['wino_f'], st['wino_d'], st['wino_w']) for st in plan.steps if st['kind'] == 'conv']
+    assert sum(m[0] == BF16 for m in modes) >= 8 and sum(m[2] == BF16 for m in modes) >= 6, modes
+    assert _rel(out, out_r) < 1e-2, 'logits %g' % _rel(out, out_r)
+    assert abs(loss.item() - loss_r.item()) < 5e-3 * abs(loss_r.item())
+    worst = 0.0
+    for (name, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        if name.endswith('conv1.bias') or name.endswith('conv2.bias') or '.bilinear_up.' in name and name.endswith('.1.bias'):
+            continue                                   # biases feeding a BatchNorm: zero true gradient
+        scale = q.grad.abs().max().item()
+        if scale < 1e-7:
+            continue
+        worst = max(worst, (p.grad.cpu() - q.grad).abs().max().item() / scale)
+    assert worst < 5e-2, 'worst parameter-gradient error %g' % worst
+
+
+def test_bf16_mode_close_to_fp32_mode(dev):
+    """The bf16 mode is a bounded perturbation of the fp32 mode (this small random-init network amplifies the 2^-9
+    operand rounding to ~10 % of the logit scale: bound 0.3) and training still reduces the loss."""
+    from aide_amd import utils as U
+    from aide_amd.optim import Adam
+    from aide_amd.models_twomodalinputs import fuseunet
+    g = torch.Generator().manual_seed(7)
+    x1 = torch.randn(2, 3, 64, 64, generator=g).to(dev)
+    x2 = torch.randn(2, 3, 64, 64, generator=g).to(dev)
+    t = (torch.rand(2, 64, 64, generator=g) > 0.7).long().to(dev)
+    w = torch.tensor([1.0, 1.0])
+    crit = U.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
+    outs = {}
+    for prec in ('fp32', 'bf16'):
+        torch.manual_seed(2)
+        net = fuseunet(2).to(dev)
+        net.engine.precision = prec
+        assert net.engine.precision == prec
+        net.train()
+        outs[prec] = net(x1, x2).detach().clone()
+        if prec == 'bf16':
+            opt = Adam(net.parameters(), lr=1e-3, amsgrad=True)
+            losses = []
+            for _ in range(6):
+                opt.zero_grad()
+                loss = crit(net(x1, x2), t)
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+            assert losses[-1] < losses[0], losses
+    assert _rel(outs['bf16'], outs['fp32']) < 0.3
+    with pytest.raises(ValueError):
+        net.engine.precision = 'fp16'
