@@ -64,7 +64,7 @@ struct BfArgs {
 
 constexpr int BF_PITCH = 36;          // slots per halo-tile row: columns -2 .. 33 (18 pixel pairs)
 
-template <int WM, int WAVES_M, int WN, int OCC>
+template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED>
 __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int TCO = 32 * WM * WAVES_M;
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
     constexpr int PLANE = (TH + 2) * BF_PITCH;     // slots per channel group
     constexpr int XS = 2 * PLANE;                  // halo-tile slots (2 groups of 8 channels)
     constexpr int AS = 18 * TCO;                   // filter-block slots: [tap][g][TCO]
-    constexpr int BUF = XS + AS;
+    constexpr int BUF = XS + AS + 2;               // + 2 dump slots: idle staging lanes store there (no branches)
+    constexpr int DUMP = XS + AS;
     constexpr int UX = 2 * (TH + 2) * 18;          // pixel-pair units per stage
     constexpr int NUX = (UX + 255) / 256;
     constexpr int NUA = (AS + 255) / 256;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
     const int c_end = min(c_begin + cps, a.chunks_total);
 
     // ---- per-thread staging descriptors (the same for every chunk) ----
-    unsigned offX[NUX], ldsX[NUX], chX[NUX];
+    unsigned offX[NUX], ldsX[NUX];
 #pragma unroll
     for (int e = 0; e < NUX; ++e) {
         const int u = tid + e * 256;
@@ -110,61 +111,65 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
         const int ih = h0 - 1 + row, iw = w0 - 2 + 2 * pr;
         const bool ok = u < UX && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
         offX[e] = ok ? (unsigned)(g * 8 * HW + row * a.W + 2 * pr) * 4u : BUF_OOB;
-        ldsX[e] = u < UX ? (unsigned)(g * PLANE + row * BF_PITCH + 2 * pr) : 0xffffffffu;
-        chX[e] = (unsigned)(g * 8);
+        ldsX[e] = u < UX ? (unsigned)(g * PLANE + row * BF_PITCH + 2 * pr) : (unsigned)DUMP;
     }
-    unsigned offA[NUA];
-#pragma unroll
-    for (int v = 0; v < NUA; ++v) {
-        const int p = tid + v * 256;
-        offA[v] = p < AS ? (unsigned)((p / TCO) * a.Cout + (p % TCO)) * 16u : BUF_OOB;
-    }
-    const __amdgpu_buffer_rsrc_t xrs =
-        make_rsrc(a.x + (long)n * a.x_bs + (long)(h0 - 1) * a.W + (w0 - 2));
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.wp + (long)co0 * 8);
-    const bool ragged_c = (a.Cin & 15) != 0;
+    // filter pieces: piece v of a thread is 256 slots after piece v-1 = (256 / TCO) [tap][g] rows further on, a
+    // wave-uniform distance that rides in the scalar offset; only the last (partial) piece needs its own mask
+    static_assert(256 % TCO == 0 || TCO == 256, "filter piece stride");
+    const unsigned offA0 = (unsigned)((tid / TCO) * a.Cout + (tid % TCO)) * 16u;
+    const unsigned strideA = (unsigned)(256 / TCO) * (unsigned)a.Cout * 16u;
+    constexpr bool A_TAIL = (AS % 256) != 0;
+    const unsigned offAt = (tid + (NUA - 1) * 256 < AS) ? offA0 : BUF_OOB;
+    const unsigned ldsAt = (tid + (NUA - 1) * 256 < AS) ? (unsigned)(XS + tid + (NUA - 1) * 256) : (unsigned)DUMP;
+    // chunks past the end of this split read through an empty descriptor (every load returns 0, no per-load select)
+    const float* xbase = a.x + (long)n * a.x_bs + (long)(h0 - 1) * a.W + (w0 - 2);
+    const uint16_t* wbase = a.wp + (long)co0 * 8;
 
     f32x2 xr[NUX][8];
     u32x4 wr[NUA];
     auto fetch = [&](int op, int chunk) {          // op is a compile-time index
-        const bool has = chunk < c_end;
+        const unsigned nrec = chunk < c_end ? BUF_OOB : 0u;
         const int ci0 = chunk * 16;
         if (op < NUX) {
             const int e = op;
+            const __amdgpu_buffer_rsrc_t xrs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase), 0, nrec, 0x00020000);
             const unsigned xs = (unsigned)ci0 * (unsigned)HW * 4u;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                unsigned off = has ? offX[e] : BUF_OOB;
-                if (ragged_c && ci0 + (int)chX[e] + c >= a.Cin) off = BUF_OOB;
+                unsigned off = offX[e];
+                if (RAGGED && ci0 + (ldsX[e] >= (unsigned)PLANE && ldsX[e] < (unsigned)XS ? 8 : 0) + c >= a.Cin)
+                    off = BUF_OOB;
                 xr[e][c] = buf_load_f32x2(xrs, off, xs + (unsigned)c * (unsigned)HW * 4u);
             }
         } else {
+            const __amdgpu_buffer_rsrc_t wrs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wbase), 0, nrec, 0x00020000);
             const unsigned ws = (unsigned)chunk * 18u * (unsigned)a.Cout * 16u;
 #pragma unroll
             for (int k = 0; k < APG; ++k) {
                 const int v = (op - NUX) * APG + k;
-                if (v < NUA) wr[v] = buf_load_u32x4(wrs, has ? offA[v] : BUF_OOB, ws);
+                if (v < NUA)
+                    wr[v] = buf_load_u32x4(wrs, (A_TAIL && v == NUA - 1) ? offAt : offA0, ws + (unsigned)v * strideA);
             }
         }
     };
     auto put = [&](int op, u32x4* buf) {
         if (op < NUX) {
             const int e = op;
-            if (ldsX[e] != 0xffffffffu) {
-                u32x4 s0, s1;
+            u32x4 s0, s1;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    s0[q] = pk_bf16(xr[e][2 * q].x, xr[e][2 * q + 1].x);
-                    s1[q] = pk_bf16(xr[e][2 * q].y, xr[e][2 * q + 1].y);
-                }
-                buf[ldsX[e]] = s0;
-                buf[ldsX[e] + 1] = s1;
+            for (int q = 0; q < 4; ++q) {
+                s0[q] = pk_bf16(xr[e][2 * q].x, xr[e][2 * q + 1].x);
+                s1[q] = pk_bf16(xr[e][2 * q].y, xr[e][2 * q + 1].y);
             }
+            buf[ldsX[e]] = s0;
+            buf[ldsX[e] + 1] = s1;
         } else {
 #pragma unroll
             for (int k = 0; k < APG; ++k) {
                 const int v = (op - NUX) * APG + k;
-                if (v < NUA && tid + v * 256 < AS) buf[XS + tid + v * 256] = wr[v];
+                if (v < NUA) buf[(A_TAIL && v == NUA - 1) ? ldsAt : (unsigned)(XS + tid + v * 256)] = wr[v];
             }
         }
     };
@@ -213,6 +218,17 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
             if (t < NOPS) {
                 put(t, nxt);               // chunk + 1 (fetched one stage ago) -> the other buffer
                 fetch(t, chunk + 2);       // its registers re-issue their loads at once
+            }
+            // a wave issues in order: left alone, the staging instructions queue up behind the last MFMA and the
+            // matrix pipe drains.  Interleave: after each MFMA one fragment read, two conversions, one LDS store,
+            // one global load (groups without a matching instruction are skipped).
+#pragma unroll
+            for (int i = 0; i < WM * WN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -323,14 +339,14 @@ __global__ __launch_bounds__(256) void bf16_pack_multi_kernel(const BfPackDesc* 
     *dst = s;
 }
 
-template <int WM, int WAVES_M, int WN, int OCC>
-int launch_bf16(BfArgs a, hipStream_t stream) {
+template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED>
+int launch_bf16_r(BfArgs a, hipStream_t stream) {
     constexpr int WAVES_N = 4 / WAVES_M, TCO = 32 * WM * WAVES_M, TH = WAVES_N * WN;
-    constexpr int BUF = 2 * (TH + 2) * BF_PITCH + 18 * TCO;
+    constexpr int BUF = 2 * (TH + 2) * BF_PITCH + 18 * TCO + 2;
     constexpr int LDS_BYTES = 2 * BUF * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC>,
+        hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
@@ -338,8 +354,14 @@ int launch_bf16(BfArgs a, hipStream_t stream) {
     a.tiles_h = (a.H + TH - 1) / TH;
     a.n_co_tiles = a.Cout / TCO;
     const long nb = (long)a.tiles_w * a.tiles_h * a.N * a.n_co_tiles * a.splitk;
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC>), dim3((unsigned)nb), dim3(256), LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED>), dim3((unsigned)nb), dim3(256), LDS_BYTES, stream, a);
     return aide_launch_status();
+}
+
+template <int WM, int WAVES_M, int WN, int OCC>
+int launch_bf16(const BfArgs& a, hipStream_t stream) {
+    return (a.Cin & 15) ? launch_bf16_r<WM, WAVES_M, WN, OCC, true>(a, stream)
+                        : launch_bf16_r<WM, WAVES_M, WN, OCC, false>(a, stream);
 }
 
 // variant: 0 = 32 co x 16 rows, 1 = 64 co x 16 rows, 2 = 128 co x 8 rows (x 32 columns)
@@ -363,7 +385,7 @@ constexpr int G_R = 4;                       // dz rows per stage
 constexpr int G_DZP = G_R * 4 + 1;           // slots per dz channel (odd: conflict-free b128 across channels)
 constexpr int G_XP = (G_R + 2) * 5 + 1;      // slots per x channel: 6 rows x 5 slots (columns -1 .. 38)
 constexpr int G_DZS = 64 * G_DZP;
-constexpr int G_BUF = G_DZS + 64 * G_XP;     // slots per stage buffer
+constexpr int G_BUF = G_DZS + 64 * G_XP + 1;   // slots per stage buffer (+ 1 dump slot for idle staging lanes)
 
 __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs g) {
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * G_BUF slots
@@ -410,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs
         const int row = u % 6, ci = u / 6;
         const bool ok = u < 64 * 6 && ci0 + ci < g.Ci;
         offE[e] = ok ? (unsigned)(ci * HW + row * g.W + 32) * 4u : BUF_OOB;
-        ldsE[e] = u < 64 * 6 ? (unsigned)(G_DZS + ci * G_XP + row * 5 + 4) : 0xffffffffu;
+        ldsE[e] = u < 64 * 6 ? (unsigned)(G_DZS + ci * G_XP + row * 5 + 4) : (unsigned)(G_BUF - 1);   // dump slot
         rowE[e] = (unsigned)row;
     }
 
@@ -466,8 +488,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs
             buf[ldsM[e]] = s;
         } else {
             const int e = op - 10;
-            if (ldsE[e] != 0xffffffffu)
-                reinterpret_cast<unsigned*>(buf + ldsE[e])[0] = pk_bf16(er[e][0], er[e][1]);
+            reinterpret_cast<unsigned*>(buf + ldsE[e])[0] = pk_bf16(er[e][0], er[e][1]);
         }
     };
 
@@ -516,6 +537,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs
                 put(2 * ks, nxt);     fetch(2 * ks, chunk + 2);
                 put(2 * ks + 1, nxt); fetch(2 * ks + 1, chunk + 2);
             }
+            // in-order issue: spread the window reads, shifts and staging between the nine MFMAs of the k-step
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // VALU
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         cur ^= 1;
