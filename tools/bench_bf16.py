@@ -34,7 +34,9 @@ def main():
     dev = torch.device('cuda:0')
     tot = {'fwd': [0.0, 0.0], 'dgrad': [0.0, 0.0], 'wgrad': [0.0, 0.0]}
     print('%-22s %10s %10s %10s   (ms, TFLOP/s algorithmic)' % ('layer', 'fwd', 'dgrad', 'wgrad'))
-    for ci, co, lv in LAYERS:
+    only = os.environ.get('AIDE_ONLY')          # e.g. AIDE_ONLY=128,64,0 -> one layer (PMC runs)
+    layers = [tuple(int(v) for v in only.split(','))] if only else LAYERS
+    for ci, co, lv in layers:
         h = w = size >> lv
         if not ops.bf16_supported(ci, h, w, co):
             print('%4d->%4d @%3d  unsupported' % (ci, co, h))
