@@ -121,7 +121,7 @@ class GradAllReduce(object):
 
     def _after_op(self, st):
         idxs = []
-        for key in ('conv', 'bn'):
+        for key in ('conv', 'bn', 'mod'):
             m = st.get(key)
             if m is not None:
                 idxs += [self._pidx[id(p)] for p in m.parameters()]

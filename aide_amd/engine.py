@@ -67,6 +67,10 @@ class Graph(object):
     def head(self, src, conv):
         self.ops.append(dict(kind='head', src=src, conv=conv))
 
+    def spatial_attention(self, src, dst, mod):
+        """dst = mod(src) * src  (Spatial_Attention, netblocks.py:68-89 + fuseunet.py:139-141)"""
+        self.ops.append(dict(kind='sa', src=src, dst=dst, mod=mod))
+
 
 USE_WINOGRAD = [True]          # global switch (tests / A-B runs)
 USE_WINOGRAD_DGRAD = [True]    # ... for the dgrad direction only
@@ -227,6 +231,15 @@ class Plan(object):
                 src = op['src']
                 k = op['conv'].out_channels
                 max_wg = max(max_wg, lib.aide_head1x1_ws_bytes(src.C, k))
+            elif op['kind'] == 'sa':
+                src, mod = op['src'], op['mod']
+                hh, ww = h >> src.level, w >> src.level
+                r = mod.conv1.out_channels
+                for k in ('t1', 't2', 't3'):
+                    st[k] = torch.empty(n, r, hh, ww, **f32)
+                st['t4'] = torch.empty(n, 1, hh, ww, **f32)
+                st['gate'] = torch.empty(n, hh, ww, **f32)
+                st['stat'] = torch.empty(2, **f32)
             self.steps.append(st)
         self.bn_ws = ops.bn_ws(max(max_bnc, 1), device)
         self.sk_ws = torch.empty(max(max_sk // 4, 1), **f32)
@@ -262,6 +275,11 @@ class Plan(object):
                 st['dz'] = torch.empty_like(st['z'])
         self.wg_ws = torch.empty(max(self._max_wg // 4, 1), **f32)
         self.head_ws = torch.empty(max(self._max_wg // 4, 1), **f32)
+        sa = [st for st in self.steps if st['kind'] == 'sa']
+        if sa:                      # small-channel gradient ping-pong buffers + the gate-backward workspace
+            big = max(st['t1'].numel() for st in sa)
+            self.sa_da, self.sa_db = torch.empty(big, **f32), torch.empty(big, **f32)
+            self.sa_ws = torch.empty(max(st['gate'].numel() for st in sa) * 2 + 8, **f32)
         self.side = torch.cuda.Stream(device=self.dev)
         cover = {id(t): _Cover() for t in self.g.roots}
         for st in reversed(self.steps):
@@ -373,6 +391,16 @@ class Plan(object):
                 conv = st['conv']
                 ops.head1x1_fwd(self.view(st['src'], inputs), conv.weight.view(conv.out_channels, -1),
                                 conv.bias, out)
+            elif kind == 'sa':
+                m = st['mod']
+                y = self.view(st['src'], inputs)
+                dil = m.conv2.dilation[0]
+                ops.pwconv_fwd(y, m.conv1.weight, m.conv1.bias, st['t1'])
+                ops.dconv_small(st['t1'], m.conv2.weight, m.conv2.bias, st['t2'], dil)
+                ops.dconv_small(st['t2'], m.conv3.weight, m.conv3.bias, st['t3'], dil)
+                ops.pwconv_fwd(st['t3'], m.conv4.weight, m.conv4.bias, st['t4'])
+                ops.sa_gate_fwd(st['t4'], m.bn, self.training, st['stat'], st['gate'])
+                ops.sa_mul(st['gate'], y, self.view(st['dst']))
         return out
 
     def _bn_apply(self, st, bn):
@@ -469,6 +497,26 @@ class Plan(object):
                         ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=self.wg_ws)
                     if sg is not None:
                         ops.convT2x2_dgrad(dz, conv.weight, self.gview(st['src']))
+            elif kind == 'sa':
+                m = st['mod']
+                y, dout = self.view(st['src'], inputs), self.gview(st['dst'])
+                dil = m.conv2.dilation[0]
+                shp = st['t1'].shape
+                da, db = self.sa_da[:st['t1'].numel()].view(shp), self.sa_db[:st['t1'].numel()].view(shp)
+                mnum = st['gate'].numel()
+                dt4 = self.sa_ws[mnum + 8:mnum + 8 + mnum].view(st['t4'].shape)
+                ops.sa_gate_bwd(dout, y, st['gate'], st['t4'], st['stat'], m.bn.weight, gslot(m.bn.weight),
+                                gslot(m.bn.bias), dt4, self.sa_ws[:mnum + 4])
+                ops.pwconv_wgrad(dt4, st['t3'], gslot(m.conv4.weight), gslot(m.conv4.bias))
+                ops.pwconv_dgrad(dt4, m.conv4.weight, da)                                  # da = d t3
+                ops.dconv_small_wgrad(da, st['t2'], gslot(m.conv3.weight), gslot(m.conv3.bias), dil)
+                ops.dconv_small(da, m.conv3.weight, None, db, dil, transposed=True)       # db = d t2
+                ops.dconv_small_wgrad(db, st['t1'], gslot(m.conv2.weight), gslot(m.conv2.bias), dil)
+                ops.dconv_small(db, m.conv2.weight, None, da, dil, transposed=True)       # da = d t1
+                ops.pwconv_wgrad(da, y, gslot(m.conv1.weight), gslot(m.conv1.bias))
+                # d y = gate * dout (the multiply) + conv1^T d t1, in one pass over the C channels
+                ops.pwconv_dgrad(da, m.conv1.weight, self.gview(st['src']), gate=st['gate'], dout=dout,
+                                 accumulate=sg['accumulate'])
             elif kind == 'pool':
                 if sg is not None:
                     ops.maxpool2x2_bwd(self.view(st['src'], inputs), self.gview(st['dst']),

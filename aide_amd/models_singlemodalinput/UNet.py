@@ -4,19 +4,23 @@ forward/backward run as HIP kernels through aide_amd.engine."""
 import torch.nn as nn
 
 from ..engine import Engine, Graph
-from ..models_twomodalinputs.netblocks import UNet_basic_down_block, UNet_basic_up_block, add_decoder
+from ..models_twomodalinputs.netblocks import (UNet_basic_down_block, UNet_basic_up_block, Spatial_Attention,
+                                                add_decoder)
 
 
 class UNet(nn.Module):
+    _ATTENTION = False
     _ENC = ((3, 64), (64, 128), (128, 256), (256, 512), (512, 1024))             # UNet.py:139-143
     _UP = ((1024, 512, 512), (512, 256, 256), (256, 128, 128), (128, 64, 64))    # UNet.py:145-148
 
     def __init__(self, num_classes=2, learned_bilinear=False):
-        super(UNet, self).__init__()
+        nn.Module.__init__(self)
         for i, (a, b) in enumerate(self._ENC, 1):
             blk = UNet_basic_down_block(a, b, i > 1)
             blk.max_pool = nn.MaxPool2d(2, 2)          # parameter-free; kept for module-tree parity
             setattr(self, 'down_block%d' % i, blk)
+            if self._ATTENTION:                        # UNetsa: UNet.py:172-181
+                setattr(self, 'sa%d' % i, Spatial_Attention(b, reduction=16, dilation=4))
         for i, (a, p, o) in enumerate(self._UP, 1):
             setattr(self, 'up_block%d' % i, UNet_basic_up_block(a, p, o, learned_bilinear))
         self.last_conv1 = nn.Conv2d(64, num_classes, 1, padding=0)
@@ -40,7 +44,12 @@ class UNet(nn.Module):
             blk = getattr(self, 'down_block%d' % s).block
             t = g.tensor('enc_s%d_mid' % s, enc_c[s - 1], s - 1)
             g.conv_bn_relu(src, t, blk.conv1, blk.bn1)
-            g.conv_bn_relu(t, dst, blk.conv2, blk.bn2)
+            if self._ATTENTION:                        # x_s = sa_s(x_s) * x_s  (UNet.py:191-200)
+                pre = g.tensor('enc_s%d_pre' % s, enc_c[s - 1], s - 1)
+                g.conv_bn_relu(t, pre, blk.conv2, blk.bn2)
+                g.spatial_attention(pre, dst, getattr(self, 'sa%d' % s))
+            else:
+                g.conv_bn_relu(t, dst, blk.conv2, blk.bn2)
             if s < 5:
                 p = g.tensor('pool_s%d' % s, dst.C, s)
                 g.pool(dst, p)
@@ -51,3 +60,8 @@ class UNet(nn.Module):
 
     def forward(self, x):
         return self.engine.run(x)
+
+
+class UNetsa(UNet):
+    """models_singlemodalinput/UNet.py:168-208: UNet with a Spatial_Attention gate after every down block."""
+    _ATTENTION = True

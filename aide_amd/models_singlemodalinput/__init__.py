@@ -1,1 +1,1 @@
-from .UNet import UNet  # noqa: F401  (reference: models_singlemodalinput/__init__.py:1)
+from .UNet import UNet, UNetsa  # noqa: F401  (reference: models_singlemodalinput/__init__.py:1)

@@ -5,25 +5,27 @@ through aide_amd.engine."""
 import torch.nn as nn
 
 from ..engine import Engine, Graph
-from .netblocks import UNet_basic_down_block, UNet_basic_up_block, add_decoder
+from .netblocks import UNet_basic_down_block, UNet_basic_up_block, Spatial_Attention, add_decoder
 
 
 class fuseunet(nn.Module):
+    _ATTENTION = False
     _M1 = ((3, 32), (64, 64), (128, 128), (256, 256), (512, 512))      # fuseunet.py:12-20
     _M2 = ((3, 32), (32, 64), (64, 128), (128, 256), (256, 512))       # fuseunet.py:24-32
     _UP = ((1024, 512, 512), (512, 256, 256), (256, 128, 128), (128, 64, 64))   # fuseunet.py:36-39
 
     def __init__(self, num_classes=2, reduction=16, dilation=4, learned_bilinear=False):
-        super(fuseunet, self).__init__()
-        # `reduction` / `dilation` are accepted and ignored, as in the reference (fuseunet.py:7)
-        for i, (a, b) in enumerate(self._M1, 1):
-            setattr(self, 'modal1_downblock%d' % i, UNet_basic_down_block(a, b))
-            if i < 5:
-                setattr(self, 'modal1_maxpool%d' % i, nn.MaxPool2d(kernel_size=2, stride=2))
-        for i, (a, b) in enumerate(self._M2, 1):
-            setattr(self, 'modal2_downblock%d' % i, UNet_basic_down_block(a, b))
-            if i < 5:
-                setattr(self, 'modal2_maxpool%d' % i, nn.MaxPool2d(kernel_size=2, stride=2))
+        nn.Module.__init__(self)
+        # fuseunet: `reduction` / `dilation` are accepted and ignored, as in the reference (fuseunet.py:7);
+        # fuseunetsa (fuseunet.py:93-136) registers a Spatial_Attention after every down block
+        for m, widths in (('modal1', self._M1), ('modal2', self._M2)):
+            for i, (a, b) in enumerate(widths, 1):
+                setattr(self, '%s_downblock%d' % (m, i), UNet_basic_down_block(a, b))
+                if self._ATTENTION:
+                    setattr(self, '%s_sa%d' % (m, i), Spatial_Attention(input_channel=b, reduction=reduction,
+                                                                         dilation=dilation))
+                if i < 5:
+                    setattr(self, '%s_maxpool%d' % (m, i), nn.MaxPool2d(kernel_size=2, stride=2))
         for i, (a, p, o) in enumerate(self._UP, 1):
             setattr(self, 'up_block%d' % i, UNet_basic_up_block(a, p, o, learned_bilinear))
         self.last_conv1 = nn.Conv2d(64, num_classes, 1, padding=0)
@@ -60,14 +62,16 @@ class fuseunet(nn.Module):
             lvl = s - 1
             # modal-2 first: in the backward schedule modal-1 (which reads all channels of the pooled
             # tensor) then writes the gradient first and modal-2 accumulates into its slice
-            b2 = getattr(self, 'modal2_downblock%d' % s).block
-            t2 = g.tensor('m2_s%d_mid' % s, c2[s - 1], lvl)
-            g.conv_bn_relu(src2, t2, b2.conv1, b2.bn1)
-            g.conv_bn_relu(t2, d2, b2.conv2, b2.bn2)
-            b1 = getattr(self, 'modal1_downblock%d' % s).block
-            t1 = g.tensor('m1_s%d_mid' % s, c1[s - 1], lvl)
-            g.conv_bn_relu(src1, t1, b1.conv1, b1.bn1)
-            g.conv_bn_relu(t1, d1, b1.conv2, b1.bn2)
+            for m, src, d, cw in (('modal2', src2, d2, c2[s - 1]), ('modal1', src1, d1, c1[s - 1])):
+                blk = getattr(self, '%s_downblock%d' % (m, s)).block
+                t = g.tensor('%s_s%d_mid' % (m, s), cw, lvl)
+                g.conv_bn_relu(src, t, blk.conv1, blk.bn1)
+                if self._ATTENTION:            # y = sa(y) * y  (fuseunet.py:139-141): the gated tensor is the skip
+                    pre = g.tensor('%s_s%d_pre' % (m, s), cw, lvl)
+                    g.conv_bn_relu(t, pre, blk.conv2, blk.bn2)
+                    g.spatial_attention(pre, d, getattr(self, '%s_sa%d' % (m, s)))
+                else:
+                    g.conv_bn_relu(t, d, blk.conv2, blk.bn2)
             if s < 5:
                 p = g.tensor('pool_s%d' % s, skip.C, s)
                 g.pool(skip, p)
@@ -78,3 +82,9 @@ class fuseunet(nn.Module):
 
     def forward(self, modal1_inputs, modal2_inputs):
         return self.engine.run(modal1_inputs, modal2_inputs)
+
+
+class fuseunetsa(fuseunet):
+    """models_twomodalinputs/fuseunet.py:93-221: fuseunet with a Spatial_Attention gate after every down block of both
+    modalities (same constructor, forward signature, registration order and state_dict keys)."""
+    _ATTENTION = True

@@ -37,6 +37,22 @@ class basic_block(nn.Module):
         self.relu = nn.ReLU()
 
 
+class Spatial_Attention(nn.Module):
+    # netblocks.py:68-89 (dup UNet.py:85-107): conv1 (1x1, C -> C/r), conv2, conv3 (3x3, dilation = padding),
+    # conv4 (1x1 -> 1), bn(1), sigmoid.  Runs as aide_amd/csrc/attention.hip through the engine's `sa` op.
+    forward = _no_forward
+
+    def __init__(self, input_channel, reduction=16, dilation=4):
+        super(Spatial_Attention, self).__init__()
+        r = input_channel // reduction
+        self.conv1 = nn.Conv2d(input_channel, r, kernel_size=1, stride=1, padding=0)
+        self.conv2 = nn.Conv2d(r, r, kernel_size=3, dilation=dilation, stride=1, padding=dilation)
+        self.conv3 = nn.Conv2d(r, r, kernel_size=3, dilation=dilation, stride=1, padding=dilation)
+        self.conv4 = nn.Conv2d(r, 1, kernel_size=1, stride=1, padding=0)
+        self.bn = nn.BatchNorm2d(1)
+        self.sigmoid = nn.Sigmoid()
+
+
 class UNet_basic_down_block(nn.Module):
     # netblocks.py:128-135 ; the single-modal flavour (UNet.py:110-121) adds `down_size`
     forward = _no_forward

@@ -453,3 +453,83 @@ def conv3x3_wgrad_wino(dz, a, dw, ws=None):
     check(lib.aide_conv3x3_wgrad_wino(dp, dbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), stream_ptr()),
           'conv3x3_wgrad_wino')
     return dw
+
+
+# ------------------------------------------------------------------------------- Spatial_Attention branch
+def _dense(t):
+    _req(t)
+    if not t.is_contiguous():
+        raise RuntimeError('aide_amd: dense contiguous tensor expected')
+    return ptr(t)
+
+
+def pwconv_fwd(x, w, b, y):
+    """y [N,R,H,W] = conv1x1(x [N,C,H,W]; w [R,C], b [R])."""
+    xp, xbs = planes(x)
+    yp, ybs = planes(y)
+    n, c, h, wd = x.shape
+    r = y.shape[1]
+    assert w.numel() == r * c
+    check(lib.aide_pwconv_fwd(xp, xbs, ptr(w), ptr(b), yp, ybs, n, c, r, h * wd, stream_ptr()), 'pwconv_fwd')
+    return y
+
+
+def pwconv_dgrad(dt, w, dx, gate=None, dout=None, accumulate=False):
+    """dx [N,C,H,W] (+)= gate * dout + w^T dt   (dt [N,R,H,W], w [R,C])."""
+    tp, tbs = planes(dt)
+    xp, xbs = planes(dx)
+    n, c, h, wd = dx.shape
+    r = dt.shape[1]
+    assert w.numel() == r * c
+    dp, dbs = planes(dout) if dout is not None else (ctypes.c_void_p(0), 0)
+    check(lib.aide_pwconv_dgrad(tp, tbs, ptr(w), ptr(gate), dp, dbs, xp, xbs, n, c, r, h * wd, int(accumulate),
+                                stream_ptr()), 'pwconv_dgrad')
+    return dx
+
+
+def pwconv_wgrad(dt, x, dw, db):
+    tp, tbs = planes(dt)
+    xp, xbs = planes(x)
+    n, c, h, wd = x.shape
+    r = dt.shape[1]
+    assert dw.numel() == r * c
+    check(lib.aide_pwconv_wgrad(tp, tbs, xp, xbs, ptr(dw), ptr(db), n, c, r, h * wd, stream_ptr()), 'pwconv_wgrad')
+
+
+def dconv_small(x, w, b, y, dilation, transposed=False):
+    """Dilated 3x3 conv (padding = dilation) on dense small-channel tensors; transposed=True is its dgrad."""
+    n, cx, h, wd = x.shape
+    cout, cin = w.shape[0], w.shape[1]
+    assert (cx, y.shape[1]) == ((cout, cin) if transposed else (cin, cout))
+    check(lib.aide_dconv3x3_small(_dense(x), _dense(w), ptr(b), _dense(y), n, cin, cout, h, wd, dilation,
+                                  int(transposed), stream_ptr()), 'dconv3x3_small')
+    return y
+
+
+def dconv_small_wgrad(dy, x, dw, db, dilation):
+    n, cout, h, wd = dy.shape
+    cin = x.shape[1]
+    check(lib.aide_dconv3x3_small_wgrad(_dense(dy), _dense(x), ptr(dw), ptr(db), n, cout, cin, h, wd, dilation,
+                                        stream_ptr()), 'dconv3x3_small_wgrad')
+
+
+def sa_gate_fwd(t4, bn, training, stat, gate):
+    check(lib.aide_sa_gate_fwd(_dense(t4), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+                               ptr(bn.num_batches_tracked), float(bn.eps), float(bn.momentum), int(training),
+                               ptr(stat), _dense(gate), t4.numel(), stream_ptr()), 'sa_gate_fwd')
+
+
+def sa_mul(gate, y, out):
+    yp, ybs = planes(y)
+    op_, obs = planes(out)
+    n, c, h, wd = y.shape
+    check(lib.aide_sa_mul(_dense(gate), yp, ybs, op_, obs, n, c, h * wd, stream_ptr()), 'sa_mul')
+
+
+def sa_gate_bwd(dout, y, gate, t4, stat, gamma, dgamma, dbeta, dt4, ws):
+    dp, dbs = planes(dout)
+    yp, ybs = planes(y)
+    n, c, h, wd = y.shape
+    assert ws.numel() >= n * h * wd + 4
+    check(lib.aide_sa_gate_bwd(dp, dbs, yp, ybs, _dense(gate), _dense(t4), ptr(stat), ptr(gamma), ptr(dgamma),
+                               ptr(dbeta), _dense(dt4), n, c, h * wd, ptr(ws), stream_ptr()), 'sa_gate_bwd')

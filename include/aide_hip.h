@@ -145,6 +145,36 @@ int aide_reverse_aug(const float* x, int64_t x_bs, float* y, int64_t y_bs, const
                      int H, int W, aide_stream_t stream);
 int aide_fill_zero(float* p, int64_t bs, int N, int C, int H, int W, aide_stream_t stream);
 
+/* ---- Spatial_Attention branch of the attention variants (fuseunetsa / UNetsa) -----------------------------------
+ * replaces Spatial_Attention.forward (models_twomodalinputs/netblocks.py:68-89, models_singlemodalinput/UNet.py:85-107)
+ * and `y = sa(y) * y` (fuseunet.py:139-141, UNet.py:191-200) with their autograd backward:
+ *   t1 = conv1x1(y; C -> R)   t2, t3 = dilated conv3x3 (R -> R, dilation = padding)   t4 = conv1x1(t3; R -> 1)
+ *   gate = sigmoid(BatchNorm2d(1)(t4))   out[c] = gate * y[c]
+ * Small-channel tensors (t1..t4, gate) are dense; C-channel tensors carry a batch stride (concat slices). */
+int aide_pwconv_fwd(const float* x, int64_t x_bs, const float* w /*[R][C]*/, const float* b, float* y, int64_t y_bs,
+                    int N, int C, int R, int HW, aide_stream_t stream);
+/* dx (+)= gate * dout + W^T dt; gate [N][HW] and dout are both NULL for a plain 1x1 dgrad */
+int aide_pwconv_dgrad(const float* dt, int64_t dt_bs, const float* w, const float* gate, const float* dout,
+                      int64_t dout_bs, float* dx, int64_t dx_bs, int N, int C, int R, int HW, int accumulate,
+                      aide_stream_t stream);
+int aide_pwconv_wgrad(const float* dt, int64_t dt_bs, const float* x, int64_t x_bs, float* dw /*[R][C]*/,
+                      float* db /*[R] or NULL*/, int N, int C, int R, int HW, aide_stream_t stream);
+/* dilated 3x3 (padding = dilation), dense [N][C][H][W]; transposed != 0 computes the dgrad (x = dy, y = dx, b NULL) */
+int aide_dconv3x3_small(const float* x, const float* w /*[Cout][Cin][3][3]*/, const float* b, float* y, int N, int Cin,
+                        int Cout, int H, int W, int dilation, int transposed, aide_stream_t stream);
+int aide_dconv3x3_small_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cout, int Cin, int H,
+                              int W, int dilation, aide_stream_t stream);
+/* gate = sigmoid(bn(t4)) over M = N*H*W values of the single channel; stat[2] <- {mean, rstd} */
+int aide_sa_gate_fwd(const float* t4, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, float eps, float momentum, int training, float* stat, float* gate,
+                     int64_t M, aide_stream_t stream);
+int aide_sa_mul(const float* gate, const float* y, int64_t y_bs, float* out, int64_t out_bs, int N, int C, int HW,
+                aide_stream_t stream);
+/* dt4, dgamma, dbeta from dout (gradient of out) ; ws: N*HW floats + 16 bytes */
+int aide_sa_gate_bwd(const float* dout, int64_t dout_bs, const float* y, int64_t y_bs, const float* gate,
+                     const float* t4, const float* stat, const float* gamma, float* dgamma, float* dbeta, float* dt4,
+                     int N, int C, int HW, float* ws, aide_stream_t stream);
+
 /* ---- 1x1 head convolution -----------------------------------------------------------------------
  * replaces last_conv1 = nn.Conv2d(64, num_classes, 1): fuseunet.py:41,89 ; UNet.py:150,164 */
 int aide_head1x1_fwd(const float* x, int64_t x_bs, const float* w, const float* b, float* y, int64_t y_bs,

@@ -10,7 +10,7 @@ It is pinned by ``tests/golden/*.npz`` which were produced by importing the
 real reference (``oracle/gen_golden.py``, run in the build container where
 ``/root/reference`` exists); see DESIGN.md "Oracle pinning".
 """
-from .nets import fuseunet, UNet  # noqa: F401
+from .nets import fuseunet, UNet, fuseunetsa, UNetsa, Spatial_Attention  # noqa: F401
 from .losses import (  # noqa: F401
     CrossEntropyLoss2d, DiceLoss, MulticlassDiceLoss, MulticlassMSELoss,
     CEMDiceLoss, CEMDiceLossImage, Coteachingloss_dropimage,

@@ -451,6 +451,12 @@ def main():
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()
         return g7_coteach_ext(ref_utils)
+    if sys.argv[1:] == ['g9']:           # attention variants only
+        torch.set_num_threads(8)
+        ref_f, ref_u, ref_utils = _import_reference()
+        import oracle
+        g1_model('fuseunetsa', ref_f.fuseunetsa, oracle.fuseunetsa, {}, True, ref_utils)
+        return g1_model('unetsa', ref_u.UNetsa, oracle.UNetsa, {}, False, ref_utils)
     if sys.argv[1:] == ['g6']:
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()
@@ -462,6 +468,8 @@ def main():
     g1_model('fuseunet_learned', ref_f.fuseunet, oracle.fuseunet, dict(learned_bilinear=True), True, ref_utils)
     g1_model('unet', ref_u.UNet, oracle.UNet, {}, False, ref_utils)
     g1_model('unet_learned', ref_u.UNet, oracle.UNet, dict(learned_bilinear=True), False, ref_utils)
+    g1_model('fuseunetsa', ref_f.fuseunetsa, oracle.fuseunetsa, {}, True, ref_utils)
+    g1_model('unetsa', ref_u.UNetsa, oracle.UNetsa, {}, False, ref_utils)
     g3_losses(ref_utils)
     g4_proposed(ref_f, ref_utils)
     g5_adam(ref_f, ref_utils)

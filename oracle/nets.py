@@ -11,6 +11,8 @@ Reference:
   models_twomodalinputs/netblocks.py:128-147 down / up blocks
   models_twomodalinputs/fuseunet.py:6-91    fuseunet
   models_singlemodalinput/UNet.py:110-165   UNet (pool inside the down block)
+  models_twomodalinputs/netblocks.py:68-89  Spatial_Attention (dup UNet.py:85-107)
+  models_twomodalinputs/fuseunet.py:93-221  fuseunetsa ; models_singlemodalinput/UNet.py:168-208 UNetsa
 """
 import torch
 import torch.nn as nn
@@ -65,18 +67,37 @@ class _Up(nn.Module):
         return self.block(torch.cat((self.bilinear_up(x), skip), dim=1))
 
 
+class Spatial_Attention(nn.Module):
+    # netblocks.py:68-89: conv1 1x1 (C -> C/r), conv2 / conv3 3x3 dilated (padding = dilation), conv4 1x1 -> 1,
+    # BatchNorm2d(1), sigmoid; the caller multiplies the gate onto its input
+    def __init__(self, input_channel, reduction=16, dilation=4):
+        super().__init__()
+        r = input_channel // reduction
+        self.conv1 = nn.Conv2d(input_channel, r, kernel_size=1, stride=1, padding=0)
+        self.conv2 = nn.Conv2d(r, r, kernel_size=3, dilation=dilation, stride=1, padding=dilation)
+        self.conv3 = nn.Conv2d(r, r, kernel_size=3, dilation=dilation, stride=1, padding=dilation)
+        self.conv4 = nn.Conv2d(r, 1, kernel_size=1, stride=1, padding=0)
+        self.bn = nn.BatchNorm2d(1)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        return self.sigmoid(self.bn(self.conv4(self.conv3(self.conv2(self.conv1(x))))))
+
+
 class fuseunet(nn.Module):
     """fuseunet.py:6-91. ``reduction``/``dilation`` accepted and ignored (fuseunet.py:7)."""
+    ATTENTION = False
     M1 = [(3, 32), (64, 64), (128, 128), (256, 256), (512, 512)]     # fuseunet.py:12-20
     M2 = [(3, 32), (32, 64), (64, 128), (128, 256), (256, 512)]      # fuseunet.py:24-32
     UP = [(1024, 512, 512), (512, 256, 256), (256, 128, 128), (128, 64, 64)]  # :36-39
 
     def __init__(self, num_classes=2, reduction=16, dilation=4, learned_bilinear=False):
         super().__init__()
-        for i, (a, b) in enumerate(self.M1, 1):
-            setattr(self, 'modal1_downblock%d' % i, _Down(a, b))
-        for i, (a, b) in enumerate(self.M2, 1):
-            setattr(self, 'modal2_downblock%d' % i, _Down(a, b))
+        for m, widths in (('modal1', self.M1), ('modal2', self.M2)):
+            for i, (a, b) in enumerate(widths, 1):
+                setattr(self, '%s_downblock%d' % (m, i), _Down(a, b))
+                if self.ATTENTION:                                    # fuseunet.py:99-127 registration order
+                    setattr(self, '%s_sa%d' % (m, i), Spatial_Attention(b, reduction=reduction, dilation=dilation))
         for i, (a, p, o) in enumerate(self.UP, 1):
             setattr(self, 'up_block%d' % i, _Up(a, p, o, learned_bilinear))
         self.last_conv1 = nn.Conv2d(64, num_classes, 1, padding=0)
@@ -90,6 +111,9 @@ class fuseunet(nn.Module):
                 x = F.max_pool2d(x, 2, 2)
             y = getattr(self, 'modal1_downblock%d' % i)(y)
             x = getattr(self, 'modal2_downblock%d' % i)(x)
+            if self.ATTENTION:                                        # fuseunet.py:139-145: y = sa(y) * y
+                y = getattr(self, 'modal1_sa%d' % i)(y) * y
+                x = getattr(self, 'modal2_sa%d' % i)(x) * x
             skips.append(torch.cat((y, x), dim=1))  # (modal1, modal2)
         y = skips[4]
         for i in range(1, 5):                                         # fuseunet.py:85-88
@@ -97,14 +121,22 @@ class fuseunet(nn.Module):
         return self.last_conv1(y)                                     # fuseunet.py:89
 
 
+class fuseunetsa(fuseunet):
+    """fuseunet.py:93-221."""
+    ATTENTION = True
+
+
 class UNet(nn.Module):
     """UNet.py:135-165."""
+    ATTENTION = False
     ENC = [(3, 64), (64, 128), (128, 256), (256, 512), (512, 1024)]  # UNet.py:139-143
 
     def __init__(self, num_classes=2, learned_bilinear=False):
         super().__init__()
         for i, (a, b) in enumerate(self.ENC, 1):
             setattr(self, 'down_block%d' % i, _Down(a, b, pool=(i > 1)))
+            if self.ATTENTION:                                        # UNet.py:172-181
+                setattr(self, 'sa%d' % i, Spatial_Attention(b, reduction=16, dilation=4))
         for i, (a, p, o) in enumerate(fuseunet.UP, 1):
             setattr(self, 'up_block%d' % i, _Up(a, p, o, learned_bilinear))
         self.last_conv1 = nn.Conv2d(64, num_classes, 1, padding=0)
@@ -113,7 +145,14 @@ class UNet(nn.Module):
         feats = []
         for i in range(1, 6):
             x = getattr(self, 'down_block%d' % i)(x)
+            if self.ATTENTION:                                        # UNet.py:191-200
+                x = getattr(self, 'sa%d' % i)(x) * x
             feats.append(x)
         for i in range(1, 5):
             x = getattr(self, 'up_block%d' % i)(feats[4 - i], x)
         return self.last_conv1(x)
+
+
+class UNetsa(UNet):
+    """UNet.py:168-208."""
+    ATTENTION = True

@@ -33,7 +33,8 @@ def sub(a, limit=8192):
 
 
 MODELS = [('fuseunet', oracle.fuseunet, {}, 2), ('fuseunet_learned', oracle.fuseunet, dict(learned_bilinear=True), 2),
-          ('unet', oracle.UNet, {}, 1), ('unet_learned', oracle.UNet, dict(learned_bilinear=True), 1)]
+          ('unet', oracle.UNet, {}, 1), ('unet_learned', oracle.UNet, dict(learned_bilinear=True), 1),
+          ('fuseunetsa', oracle.fuseunetsa, {}, 2), ('unetsa', oracle.UNetsa, {}, 1)]      # attention variants (§8 f4)
 
 
 @pytest.mark.parametrize('name,ctor,kw,nin', MODELS)
