@@ -26,10 +26,29 @@ template <int V> __device__ __forceinline__ void stv(float* p, const float (&o)[
     if constexpr (V == 4) { *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]}; }
     else { p[0] = o[0]; }
 }
+// bf16 storage (precision='bf16': conv outputs z and their gradients dz live in HBM as bf16, the arithmetic
+// here stays fp32/fp64): widening is exact, narrowing is round-to-nearest-even (v_cvt_pk_bf16_f32)
+typedef uint16_t bf16_t;
+template <int V> __device__ __forceinline__ void ldv(const bf16_t* p, float (&o)[V]) {
+    if constexpr (V == 4) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+        o[0] = __builtin_bit_cast(float, v[0] << 16); o[1] = __builtin_bit_cast(float, v[0] & 0xffff0000u);
+        o[2] = __builtin_bit_cast(float, v[1] << 16); o[3] = __builtin_bit_cast(float, v[1] & 0xffff0000u);
+    } else { o[0] = __builtin_bit_cast(float, (unsigned)p[0] << 16); }
+}
+__device__ __forceinline__ unsigned bn_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+template <int V> __device__ __forceinline__ void stv(bf16_t* p, const float (&o)[V]) {
+    if constexpr (V == 4) { *reinterpret_cast<u32x2*>(p) = u32x2{bn_pk_bf16(o[0], o[1]), bn_pk_bf16(o[2], o[3])}; }
+    else { p[0] = (bf16_t)(bn_pk_bf16(o[0], 0.f) & 0xffffu); }
+}
 
 // ---------------------------------------------------------------- statistics (sum, sum of squares)
-template <int V>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, long z_bs, int N, int C,
+template <int V, typename ZT>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const ZT* __restrict__ z, long z_bs, int N, int C,
                                                        int HW, int splits, double* __restrict__ partials) {
     __shared__ double sm[2 * 4];
     const int c = blockIdx.x % C, s = blockIdx.x / C;
@@ -60,9 +79,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 // partials (one wave, <= 64 splits) and applies a = relu(z*scale + shift); the (x == 0, n == 0) block
 // of each channel also publishes mean / rstd / scale / shift and updates the running statistics.
 // (Folding the finalize step in here removes one ~5 us launch per BatchNorm.)
-template <int V>
+template <int V, typename ZT>
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(
-    const float* __restrict__ z, long z_bs, float* __restrict__ a, long a_bs, int C, int HW,
+    const ZT* __restrict__ z, long z_bs, float* __restrict__ a, long a_bs, int C, int HW,
     const double* __restrict__ partials, int splits, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
     float* __restrict__ running_var, long long* __restrict__ nbt, float* __restrict__ mean_out,
@@ -99,7 +118,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(
     }
     __syncthreads();
     const float sc = coef[0], sh = coef[1];
-    const float* zp = z + (long)n * z_bs + (long)c * HW;
+    const ZT* zp = z + (long)n * z_bs + (long)c * HW;
     float* ap = a + (long)n * a_bs + (long)c * HW;
     const int hw4 = HW / V;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < hw4; i += gridDim.x * 256) {
@@ -127,15 +146,15 @@ __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, con
 }
 
 // ---------------------------------------------------------------- a = relu(z*scale + shift)
-template <int V>
-__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ z, long z_bs,
+template <int V, typename ZT>
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ZT* __restrict__ z, long z_bs,
                                                             float* __restrict__ a, long a_bs, int C, int HW,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu) {
     const int plane = blockIdx.y;                 // n*C + c
     const int n = plane / C, c = plane - n * C;
     const float sc = scale[c], sh = shift[c];
-    const float* zp = z + (long)n * z_bs + (long)c * HW;
+    const ZT* zp = z + (long)n * z_bs + (long)c * HW;
     float* ap = a + (long)n * a_bs + (long)c * HW;
     const int hw4 = HW / V;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < hw4; i += gridDim.x * 256) {
@@ -152,9 +171,9 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
 
 // ---------------------------------------------------------------- backward reductions
 // partials[c][s] = { sum dy, sum dy*xhat, sum xhat } with dy = dA * (z*scale+shift > 0)
-template <int V>
+template <int V, typename ZT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dA, long d_bs,
-                                                            const float* __restrict__ z, long z_bs, int N,
+                                                            const ZT* __restrict__ z, long z_bs, int N,
                                                             int C, int HW, int splits,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
@@ -197,10 +216,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 // The latter is sum(dz), which is zero in exact arithmetic; it is evaluated from the same sums,
 //   sum dz = scale * ((sum dy - n c0) - c1 sum xhat),
 // i.e. as the rounding residue it is (the reference's autograd value is the same kind of ~1e-8 noise).
-template <int V>
+template <int V, typename ZT, typename DT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dA, long d_bs,
-                                                           const float* __restrict__ z, long z_bs,
-                                                           float* __restrict__ dz, long dz_bs, int N, int C,
+                                                           const ZT* __restrict__ z, long z_bs,
+                                                           DT* __restrict__ dz, long dz_bs, int N, int C,
                                                            int HW, int splits, double count,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
@@ -257,8 +276,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // the values are read ONCE into registers (<= 16 float4 per thread), reduced in fp64 in a fixed order, and
 // normalised from the registers.  Saves a launch (~4.5 us) and one pass over the tensor per BatchNorm and direction.
 constexpr int BN_FQ = 16;
+template <typename ZT>
 __global__ __launch_bounds__(256) void bn_train_fused_kernel(
-    const float* __restrict__ z, long z_bs, float* __restrict__ a, long a_bs, int N, int HW, double count,
+    const ZT* __restrict__ z, long z_bs, float* __restrict__ a, long a_bs, int N, int HW, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ scale_out,
@@ -274,7 +294,9 @@ __global__ __launch_bounds__(256) void bn_train_fused_kernel(
         v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (i < total4) {
             const int n = i / hw4, p = i - n * hw4;
-            v[k] = *reinterpret_cast<const f32x4*>(z + (long)n * z_bs + (long)c * HW + p * 4);
+            float t4[4];
+            ldv<4>(z + (long)n * z_bs + (long)c * HW + p * 4, t4);
+            v[k] = f32x4{t4[0], t4[1], t4[2], t4[3]};
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const double d = (double)v[k][e]; acc[0] += d; acc[1] += d * d; }
         }
@@ -311,8 +333,9 @@ __global__ __launch_bounds__(256) void bn_train_fused_kernel(
     }
 }
 
+template <typename ZT, typename DT>
 __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(
-    const float* __restrict__ dA, long d_bs, const float* __restrict__ z, long z_bs, float* __restrict__ dz,
+    const float* __restrict__ dA, long d_bs, const ZT* __restrict__ z, long z_bs, DT* __restrict__ dz,
     long dz_bs, int N, int HW, double count, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ scale, const float* __restrict__ shift, int relu, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ dbias) {
@@ -328,7 +351,8 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(
         dy[k] = f32x4{0.f, 0.f, 0.f, 0.f}; xh[k] = dy[k];
         if (i < total4) {
             const int n = i / hw4, p = i - n * hw4;
-            const f32x4 zv = *reinterpret_cast<const f32x4*>(z + (long)n * z_bs + (long)c * HW + p * 4);
+            float zv[4];
+            ldv<4>(z + (long)n * z_bs + (long)c * HW + p * 4, zv);
             const f32x4 dv = *reinterpret_cast<const f32x4*>(dA + (long)n * d_bs + (long)c * HW + p * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -356,10 +380,10 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(
         const int i = threadIdx.x + k * 256;
         if (i < total4) {
             const int n = i / hw4, p = i - n * hw4;
-            f32x4 o;
+            float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = sc * (dy[k][e] - c0 - xh[k][e] * c1);
-            *reinterpret_cast<f32x4*>(dz + (long)n * dz_bs + (long)c * HW + p * 4) = o;
+            stv<4>(dz + (long)n * dz_bs + (long)c * HW + p * 4, o);
         }
     }
 }
@@ -383,12 +407,15 @@ extern "C" {
 // workspace doubles needed by the BN kernels for a C-channel tensor
 size_t aide_bn_ws_bytes(int C) { return (size_t)C * 64 * 3 * sizeof(double); }
 
-// Training-mode forward of relu(bn(z)): batch statistics (pass 1), then finalize + apply (pass 2).
-// Outputs mean/rstd/scale/shift [C] are kept by the caller for the backward.
-int aide_bn_train_fwd(const float* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
-                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                      float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
-                      float* scale, float* shift, int relu, void* ws, hipStream_t stream) {
+}  // extern "C"
+
+namespace {
+
+template <typename ZT>
+int bn_train_fwd_t(const ZT* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
+                   const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                   float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                   float* scale, float* shift, int relu, void* ws, hipStream_t stream) {
     const int HW = H * W;
     if (!z || !a || !ws) return AIDE_ERR_ARG;
     const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && a_bs % 4 == 0;
@@ -397,23 +424,104 @@ int aide_bn_train_fwd(const float* z, int64_t z_bs, float* a, int64_t a_bs, int 
     const double count = (double)N * HW;
     const int gx = max(1, min((HW / (v4 ? 4 : 1) + 255) / 256, 16));
     if (v4 && bn_fused_ok(N, C, HW)) {
-        hipLaunchKernelGGL(bn_train_fused_kernel, dim3(C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, N, HW, count,
+        hipLaunchKernelGGL(bn_train_fused_kernel<ZT>, dim3(C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, N, HW, count,
                            gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd,
                            scale, shift, relu);
         return aide_launch_status();
     }
     if (v4) {
-        hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
-        hipLaunchKernelGGL(bn_train_apply_kernel<4>, dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+        hipLaunchKernelGGL((bn_stats_kernel<4, ZT>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
+        hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
                            num_batches_tracked, mean, rstd, scale, shift, relu);
     } else {
-        hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
-        hipLaunchKernelGGL(bn_train_apply_kernel<1>, dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+        hipLaunchKernelGGL((bn_stats_kernel<1, ZT>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
+        hipLaunchKernelGGL((bn_train_apply_kernel<1, ZT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
                            num_batches_tracked, mean, rstd, scale, shift, relu);
     }
     return aide_launch_status();
+}
+
+template <typename ZT>
+int bn_relu_apply_t(const ZT* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
+                    const float* scale, const float* shift, int relu, hipStream_t stream) {
+    const int HW = H * W;
+    const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && a_bs % 4 == 0;
+    const int gx = max(1, min((HW / (v4 ? 4 : 1) + 255) / 256, 16));
+    if (v4) hipLaunchKernelGGL((bn_relu_apply_kernel<4, ZT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
+    else hipLaunchKernelGGL((bn_relu_apply_kernel<1, ZT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
+    return aide_launch_status();
+}
+
+template <typename ZT, typename DT>
+int bn_relu_bwd_t(const float* dA, int64_t d_bs, const ZT* z, int64_t z_bs, DT* dz, int64_t dz_bs,
+                  int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
+                  const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws,
+                  hipStream_t stream) {
+    const int HW = H * W;
+    if (!ws) return AIDE_ERR_ARG;
+    const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && d_bs % 4 == 0 && dz_bs % 4 == 0;
+    const int splits = pick_splits(N, C, HW);
+    double* partials = (double*)ws;
+    const double count = (double)N * HW;
+    if (v4 && bn_fused_ok(N, C, HW)) {
+        hipLaunchKernelGGL((bn_bwd_fused_kernel<ZT, DT>), dim3(C), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs,
+                           N, HW, count, mean, rstd, scale, shift, relu, dgamma, dbeta, dbias);
+        return aide_launch_status();
+    }
+    if (v4) {
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, ZT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4, ZT, DT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
+    } else {
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, ZT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1, ZT, DT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
+    }
+    return aide_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+// Training-mode forward of relu(bn(z)): batch statistics (pass 1), then finalize + apply (pass 2).
+// Outputs mean/rstd/scale/shift [C] are kept by the caller for the backward.
+int aide_bn_train_fwd(const float* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
+                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                      float* scale, float* shift, int relu, void* ws, hipStream_t stream) {
+    return bn_train_fwd_t<float>(z, z_bs, a, a_bs, N, C, H, W, gamma, beta, eps, momentum, running_mean, running_var,
+                                 num_batches_tracked, mean, rstd, scale, shift, relu, ws, stream);
+}
+
+// the same operators on bf16-stored conv outputs / conv-output gradients (precision='bf16'); z_bf16 / dz_bf16 select
+// the storage type of the untyped pointers, everything else is unchanged
+int aide_bn_train_fwd_mixed(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
+                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                            float* scale, float* shift, int relu, void* ws, hipStream_t stream) {
+    if (z_bf16)
+        return bn_train_fwd_t<bf16_t>((const bf16_t*)z, z_bs, a, a_bs, N, C, H, W, gamma, beta, eps, momentum, running_mean,
+                                      running_var, num_batches_tracked, mean, rstd, scale, shift, relu, ws, stream);
+    return bn_train_fwd_t<float>((const float*)z, z_bs, a, a_bs, N, C, H, W, gamma, beta, eps, momentum, running_mean,
+                                 running_var, num_batches_tracked, mean, rstd, scale, shift, relu, ws, stream);
+}
+
+int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
+                             const float* scale, const float* shift, int relu, hipStream_t stream) {
+    if (z_bf16) return bn_relu_apply_t<bf16_t>((const bf16_t*)z, z_bs, a, a_bs, N, C, H, W, scale, shift, relu, stream);
+    return bn_relu_apply_t<float>((const float*)z, z_bs, a, a_bs, N, C, H, W, scale, shift, relu, stream);
+}
+
+int aide_bn_relu_bwd_mixed(const float* dA, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz, int dz_bf16,
+                           int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
+                           const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
+                           void* ws, hipStream_t stream) {
+#define AIDE_BN_BWD(ZT, DT) bn_relu_bwd_t<ZT, DT>(dA, d_bs, (const ZT*)z, z_bs, (DT*)dz, dz_bs, N, C, H, W, mean, rstd, \
+                                                  scale, shift, relu, dgamma, dbeta, dbias, ws, stream)
+    if (z_bf16) return dz_bf16 ? AIDE_BN_BWD(bf16_t, bf16_t) : AIDE_BN_BWD(bf16_t, float);
+    return dz_bf16 ? AIDE_BN_BWD(float, bf16_t) : AIDE_BN_BWD(float, float);
+#undef AIDE_BN_BWD
 }
 
 int aide_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean,
@@ -425,12 +533,7 @@ int aide_bn_eval_coeff(int C, const float* gamma, const float* beta, const float
 
 int aide_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
                        const float* scale, const float* shift, int relu, hipStream_t stream) {
-    const int HW = H * W;
-    const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && a_bs % 4 == 0;
-    const int gx = max(1, min((HW / (v4 ? 4 : 1) + 255) / 256, 16));
-    if (v4) hipLaunchKernelGGL(bn_relu_apply_kernel<4>, dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
-    else hipLaunchKernelGGL(bn_relu_apply_kernel<1>, dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
-    return aide_launch_status();
+    return bn_relu_apply_t<float>(z, z_bs, a, a_bs, N, C, H, W, scale, shift, relu, stream);
 }
 
 // Backward of relu(bn(z)): dA -> dz, dgamma, dbeta, and the (mathematically zero) conv-bias grad.
@@ -438,25 +541,8 @@ int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs
                      int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
                      const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws,
                      hipStream_t stream) {
-    const int HW = H * W;
-    if (!ws) return AIDE_ERR_ARG;
-    const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && d_bs % 4 == 0 && dz_bs % 4 == 0;
-    const int splits = pick_splits(N, C, HW);
-    double* partials = (double*)ws;
-    const double count = (double)N * HW;
-    if (v4 && bn_fused_ok(N, C, HW)) {
-        hipLaunchKernelGGL(bn_bwd_fused_kernel, dim3(C), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs,
-                           N, HW, count, mean, rstd, scale, shift, relu, dgamma, dbeta, dbias);
-        return aide_launch_status();
-    }
-    if (v4) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
-    } else {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
-    }
-    return aide_launch_status();
+    return bn_relu_bwd_t<float, float>(dA, d_bs, z, z_bs, dz, dz_bs, N, C, H, W, mean, rstd, scale, shift, relu, dgamma,
+                                       dbeta, dbias, ws, stream);
 }
 
 }  // extern "C"

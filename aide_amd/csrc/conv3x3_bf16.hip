@@ -53,10 +53,10 @@ __device__ __forceinline__ u32x4 buf_load_u32x4(__amdgpu_buffer_rsrc_t r, unsign
 
 // ------------------------------------------------------------------------------------------ forward / dgrad
 struct BfArgs {
-    const float* x;
+    const void* x;            // fp32, or bf16 when IN_BF16 (dgrad reading a bf16-stored dz)
     const uint16_t* wp;
     const float* bias;
-    float* y;
+    void* y;                  // fp32, or bf16 when OUT_BF16 (forward writing a bf16-stored z)
     long x_bs, y_bs, split_stride;
     int N, Cin, H, W, Cout;
     int tiles_w, tiles_h, n_co_tiles, splitk, chunks_total, accumulate;
@@ -64,8 +64,9 @@ struct BfArgs {
 
 constexpr int BF_PITCH = 36;          // slots per halo-tile row: columns -2 .. 33 (18 pixel pairs)
 
-template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED>
+template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16>
 __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) {
+    constexpr unsigned ES = IN_BF16 ? 2u : 4u;     // bytes per input element
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int TCO = 32 * WM * WAVES_M;
     constexpr int TH = WAVES_N * WN;               // image rows per tile (32 columns wide)
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
         const int row = rem / 18, pr = rem - row * 18;
         const int ih = h0 - 1 + row, iw = w0 - 2 + 2 * pr;
         const bool ok = u < UX && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        offX[e] = ok ? (unsigned)(g * 8 * HW + row * a.W + 2 * pr) * 4u : BUF_OOB;
+        offX[e] = ok ? (unsigned)(g * 8 * HW + row * a.W + 2 * pr) * ES : BUF_OOB;
         ldsX[e] = u < UX ? (unsigned)(g * PLANE + row * BF_PITCH + 2 * pr) : (unsigned)DUMP;
     }
     // filter pieces: piece v of a thread is 256 slots after piece v-1 = (256 / TCO) [tap][g] rows further on, a
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
     const unsigned offAt = (tid + (NUA - 1) * 256 < AS) ? offA0 : BUF_OOB;
     const unsigned ldsAt = (tid + (NUA - 1) * 256 < AS) ? (unsigned)(XS + tid + (NUA - 1) * 256) : (unsigned)DUMP;
     // chunks past the end of this split read through an empty descriptor (every load returns 0, no per-load select)
-    const float* xbase = a.x + (long)n * a.x_bs + (long)(h0 - 1) * a.W + (w0 - 2);
+    const char* xbase = (const char*)a.x + ((long)n * a.x_bs + (long)(h0 - 1) * a.W + (w0 - 2)) * (long)ES;
     const uint16_t* wbase = a.wp + (long)co0 * 8;
 
     f32x2 xr[NUX][8];
@@ -133,14 +134,15 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
         if (op < NUX) {
             const int e = op;
             const __amdgpu_buffer_rsrc_t xrs =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase), 0, nrec, 0x00020000);
-            const unsigned xs = (unsigned)ci0 * (unsigned)HW * 4u;
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, nrec, 0x00020000);
+            const unsigned xs = (unsigned)ci0 * (unsigned)HW * ES;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 unsigned off = offX[e];
                 if (RAGGED && ci0 + (ldsX[e] >= (unsigned)PLANE && ldsX[e] < (unsigned)XS ? 8 : 0) + c >= a.Cin)
                     off = BUF_OOB;
-                xr[e][c] = buf_load_f32x2(xrs, off, xs + (unsigned)c * (unsigned)HW * 4u);
+                if constexpr (IN_BF16) xr[e][c].x = buf_load_f32(xrs, off, xs + (unsigned)c * (unsigned)HW * ES);   // 2 pixels
+                else xr[e][c] = buf_load_f32x2(xrs, off, xs + (unsigned)c * (unsigned)HW * ES);
             }
         } else {
             const __amdgpu_buffer_rsrc_t wrs =
@@ -160,8 +162,15 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
             u32x4 s0, s1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                s0[q] = pk_bf16(xr[e][2 * q].x, xr[e][2 * q + 1].x);
-                s1[q] = pk_bf16(xr[e][2 * q].y, xr[e][2 * q + 1].y);
+                if constexpr (IN_BF16) {       // dword = (pixel 0, pixel 1) of one channel -> (channel 2q, 2q+1) of one pixel
+                    const unsigned lo = __builtin_bit_cast(unsigned, xr[e][2 * q].x);
+                    const unsigned hi = __builtin_bit_cast(unsigned, xr[e][2 * q + 1].x);
+                    s0[q] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+                    s1[q] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+                } else {
+                    s0[q] = pk_bf16(xr[e][2 * q].x, xr[e][2 * q + 1].x);
+                    s1[q] = pk_bf16(xr[e][2 * q].y, xr[e][2 * q + 1].y);
+                }
             }
             buf[ldsX[e]] = s0;
             buf[ldsX[e] + 1] = s1;
@@ -247,33 +256,60 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
     }
 
     // ---- epilogue: D row i = (r&3) + 8*(r>>2) + 4*half (output channel), column j (pixel) ----
-    float* yn = a.y + (long)split * a.split_stride + (long)n * a.y_bs;
     const bool add_bias = (a.bias != nullptr) && (split == 0);
+    if constexpr (OUT_BF16) {
+        // bf16 z: registers r, r+1 are channels i, i+1 at pixel j.  Neighbouring lanes swap one value (DPP) so that an
+        // even lane owns channel i at pixels (j, j+1) and an odd lane channel i+1 at (j-1, j): one packed dword each.
+        uint16_t* yn = (uint16_t*)a.y + (long)n * a.y_bs;
+        const int odd = j & 1;
 #pragma unroll
-    for (int nt = 0; nt < WN; ++nt) {
-        const int oh = h0 + wave_n * WN + nt;
-        const int ow = w0 + j;
-        const bool pok = oh < a.H;
+        for (int nt = 0; nt < WN; ++nt) {
+            const int oh = h0 + wave_n * WN + nt;
+            const int ow = w0 + (j & ~1);
+            const bool pok = oh < a.H;
 #pragma unroll
-        for (int m = 0; m < WM; ++m) {
+            for (int m = 0; m < WM; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (pok) {
-                    float v = acc[m][nt][r];
-                    if (add_bias) v += a.bias[co];
-                    float* p = yn + (long)co * HW + oh * a.W + ow;
-                    if (a.accumulate) v += *p;
-                    *p = v;
+                for (int r = 0; r < 16; r += 2) {
+                    const float own0 = acc[m][nt][r], own1 = acc[m][nt][r + 1];
+                    const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own0), 0xB1, 0xf, 0xf, true));
+                    const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own1), 0xB1, 0xf, 0xf, true));
+                    const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
+                    float lo = odd ? t1 : own0, hi = odd ? own1 : t0;
+                    if (add_bias) { const float b = a.bias[co]; lo += b; hi += b; }
+                    if (pok) *reinterpret_cast<unsigned*>(yn + (long)co * HW + oh * a.W + ow) = pk_bf16(lo, hi);
+                }
+            }
+        }
+    } else {
+        float* yn = (float*)a.y + (long)split * a.split_stride + (long)n * a.y_bs;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+            const int oh = h0 + wave_n * WN + nt;
+            const int ow = w0 + j;
+            const bool pok = oh < a.H;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (pok) {
+                        float v = acc[m][nt][r];
+                        if (add_bias) v += a.bias[co];
+                        float* p = yn + (long)co * HW + oh * a.W + ow;
+                        if (a.accumulate) v += *p;
+                        *p = v;
+                    }
                 }
             }
         }
     }
 }
 
-// y[n][c][p] (+)= bias[c] + sum_s slab[s][n][c][p]   (fixed summation order, 4 pixels per thread)
+// y[n][c][p] (+)= bias[c] + sum_s slab[s][n][c][p]   (fixed summation order, 4 pixels per thread; y fp32 or bf16)
+template <bool OUT_BF16>
 __global__ void bf16_splitk_reduce_kernel(const float* __restrict__ slabs, long split_stride, int splitk,
-                                          float* __restrict__ y, long y_bs, int C, int HW,
+                                          void* __restrict__ yv, long y_bs, int C, int HW,
                                           const float* __restrict__ bias, int accumulate, long total4) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const long e = i * 4, chw = (long)C * HW;
@@ -281,9 +317,13 @@ __global__ void bf16_splitk_reduce_kernel(const float* __restrict__ slabs, long 
         f32x4 v = *reinterpret_cast<const f32x4*>(slabs + e);
         for (int s = 1; s < splitk; ++s) v += *reinterpret_cast<const f32x4*>(slabs + (long)s * split_stride + e);
         if (bias) v += bias[rem / HW];
-        f32x4* p = reinterpret_cast<f32x4*>(y + n * y_bs + rem);
-        if (accumulate) v += *p;
-        *p = v;
+        if constexpr (OUT_BF16) {
+            *reinterpret_cast<u32x2*>((uint16_t*)yv + n * y_bs + rem) = u32x2{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])};
+        } else {
+            f32x4* p = reinterpret_cast<f32x4*>((float*)yv + n * y_bs + rem);
+            if (accumulate) v += *p;
+            *p = v;
+        }
     }
 }
 
@@ -339,41 +379,53 @@ __global__ __launch_bounds__(256) void bf16_pack_multi_kernel(const BfPackDesc* 
     *dst = s;
 }
 
-template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED>
+template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16>
 int launch_bf16_r(BfArgs a, hipStream_t stream) {
     constexpr int WAVES_N = 4 / WAVES_M, TCO = 32 * WM * WAVES_M, TH = WAVES_N * WN;
     constexpr int BUF = 2 * (TH + 2) * BF_PITCH + 18 * TCO + 2;
     constexpr int LDS_BYTES = 2 * BUF * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
     a.tiles_w = a.W / 32;
     a.tiles_h = (a.H + TH - 1) / TH;
     a.n_co_tiles = a.Cout / TCO;
     const long nb = (long)a.tiles_w * a.tiles_h * a.N * a.n_co_tiles * a.splitk;
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED>), dim3((unsigned)nb), dim3(256), LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16>), dim3((unsigned)nb), dim3(256),
+                       LDS_BYTES, stream, a);
     return aide_launch_status();
 }
 
+// storage combinations: fp32 -> fp32 (stand-alone operator), fp32 -> bf16 (forward into a bf16 z), bf16 -> fp32
+// (dgrad from a bf16 dz); ragged channel counts only occur on the fp32 network inputs
 template <int WM, int WAVES_M, int WN, int OCC>
-int launch_bf16(const BfArgs& a, hipStream_t stream) {
-    return (a.Cin & 15) ? launch_bf16_r<WM, WAVES_M, WN, OCC, true>(a, stream)
-                        : launch_bf16_r<WM, WAVES_M, WN, OCC, false>(a, stream);
+int launch_bf16(const BfArgs& a, int in_bf16, int out_bf16, hipStream_t stream) {
+    if (in_bf16) {
+        if (out_bf16 || (a.Cin & 15)) return AIDE_ERR_ARG;
+        return launch_bf16_r<WM, WAVES_M, WN, OCC, false, true, false>(a, stream);
+    }
+    if (out_bf16)
+        return (a.Cin & 15) ? launch_bf16_r<WM, WAVES_M, WN, OCC, true, false, true>(a, stream)
+                            : launch_bf16_r<WM, WAVES_M, WN, OCC, false, false, true>(a, stream);
+    return (a.Cin & 15) ? launch_bf16_r<WM, WAVES_M, WN, OCC, true, false, false>(a, stream)
+                        : launch_bf16_r<WM, WAVES_M, WN, OCC, false, false, false>(a, stream);
 }
 
-// variant: 0 = 32 co x 16 rows, 1 = 64 co x 16 rows, 2 = 128 co x 8 rows (x 32 columns)
-int bf16_variant(int Cout) { return Cout % 128 == 0 ? 2 : (Cout % 64 == 0 ? 1 : 0); }
+// variant: 0 = 32 co x 16 rows x 32 columns, 1 = 64 co x 16 rows x 32 columns; both run two workgroups per CU.
+// (A 128 co x 8 rows tile, one workgroup per CU, lost to variant 1 on every layer of the 512x512 sweep -- 1.0-1.3x --
+// and is not instantiated.)
+int bf16_variant(int Cout) { return Cout % 64 == 0 ? 1 : 0; }
 long bf16_blocks(int variant, int N, int H, int W, int Cout) {
-    const int th = variant == 2 ? 8 : 16, tco = variant == 2 ? 128 : (variant == 1 ? 64 : 32);
+    const int th = 16, tco = variant == 1 ? 64 : 32;
     return (long)(W / 32) * ((H + th - 1) / th) * N * (Cout / tco);
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient
 struct BgArgs {
-    const float* dz;
+    const void* dz;           // fp32, or bf16 when DZ_BF16
     const float* x;
     float* slabs;
     long dz_bs, x_bs;
@@ -387,6 +439,7 @@ constexpr int G_XP = (G_R + 2) * 5 + 1;      // slots per x channel: 6 rows x 5 
 constexpr int G_DZS = 64 * G_DZP;
 constexpr int G_BUF = G_DZS + 64 * G_XP + 1;   // slots per stage buffer (+ 1 dump slot for idle staging lanes)
 
+template <bool DZ_BF16>
 __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs g) {
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * G_BUF slots
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -410,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs
     for (int e = 0; e < 4; ++e) {
         const int u = tid + e * 256;
         const int blk = u & 3, row = (u >> 2) & 3, co = u >> 4;
-        offD[e] = (co0 + co < g.Co) ? (unsigned)(co * HW + row * g.W + blk * 8) * 4u : BUF_OOB;
+        offD[e] = (co0 + co < g.Co) ? (unsigned)(co * HW + row * g.W + blk * 8) * (DZ_BF16 ? 2u : 4u) : BUF_OOB;
         ldsD[e] = (unsigned)(co * G_DZP + row * 4 + blk);
     }
     // x main: unit = (ci, tile row, slot s): columns 8s-1 .. 8s+6 of the segment -> one slot
@@ -448,10 +501,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs
         const int band = t2 % g.bands_h, n = t2 / g.bands_h;
         const int h0 = band * G_R, w0 = seg * 32;
         if (op < 4) {
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc(g.dz + (long)n * g.dz_bs + (long)co0 * HW + (long)h0 * g.W + w0);
+            const long eoff = (long)n * g.dz_bs + (long)co0 * HW + (long)h0 * g.W + w0;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc((const char*)g.dz + eoff * (DZ_BF16 ? 2 : 4));
             const unsigned off = has ? offD[op] : BUF_OOB;
-            dr[op][0] = buf_load_f32x4(rs, off, 0);
-            dr[op][1] = buf_load_f32x4(rs, off, 16);
+            dr[op][0] = buf_load_f32x4(rs, off, 0);                       // bf16: the 8 pixels of the slot as stored
+            if constexpr (!DZ_BF16) dr[op][1] = buf_load_f32x4(rs, off, 16);
         } else if (op < 10) {
             const int e = op - 4;
             const __amdgpu_buffer_rsrc_t rs =
@@ -477,8 +531,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs
     auto put = [&](int op, u32x4* buf) {
         if (op < 4) {
             u32x4 s;
-            s[0] = pk_bf16(dr[op][0].x, dr[op][0].y); s[1] = pk_bf16(dr[op][0].z, dr[op][0].w);
-            s[2] = pk_bf16(dr[op][1].x, dr[op][1].y); s[3] = pk_bf16(dr[op][1].z, dr[op][1].w);
+            if constexpr (DZ_BF16) {
+                s = __builtin_bit_cast(u32x4, dr[op][0]);
+            } else {
+                s[0] = pk_bf16(dr[op][0].x, dr[op][0].y); s[1] = pk_bf16(dr[op][0].z, dr[op][0].w);
+                s[2] = pk_bf16(dr[op][1].x, dr[op][1].y); s[3] = pk_bf16(dr[op][1].z, dr[op][1].w);
+            }
             buf[ldsD[op]] = s;
         } else if (op < 10) {
             const int e = op - 4;
@@ -600,11 +658,15 @@ int aide_conv3x3_bf16_pack_multi(const void* descs, int n, int64_t total_blocks,
 }
 
 // y (+)= conv3x3(x) with bf16-packed filters u (forward pack, or the dgrad pack with Cin/Cout swapped by the
-// caller).  x, y: fp32 NCHW with batch strides (elements); ws: split-K slabs (splitk * N*Cout*H*W floats).
-int aide_conv3x3_bf16(const float* x, int64_t x_bs, const uint16_t* u, const float* bias, float* y, int64_t y_bs,
-                      int N, int Cin, int H, int W, int Cout, int accumulate, int splitk, float* ws,
-                      hipStream_t stream) {
+// caller).  x, y: NCHW with batch strides (elements), fp32 or -- x_bf16 / y_bf16 -- bf16 storage (the forward writing
+// a bf16 z, the dgrad reading a bf16 dz; bf16 -> bf16 and accumulation into a bf16 y are not provided).
+// ws: split-K slabs (splitk * N*Cout*H*W floats).
+int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint16_t* u, const float* bias, void* y,
+                            int y_bf16, int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,
+                            float* ws, hipStream_t stream) {
     if (!x || !u || !y || N <= 0 || !aide_conv3x3_bf16_supported(Cin, H, W, Cout)) return AIDE_ERR_ARG;
+    if (y_bf16 && (accumulate || x_bf16)) return AIDE_ERR_ARG;
+    if ((x_bf16 && (x_bs % 2)) || (y_bf16 && (y_bs % 2))) return AIDE_ERR_ARG;
     BfArgs a;
     a.x = x; a.wp = u; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.chunks_total = (Cin + 15) / 16;
@@ -612,28 +674,36 @@ int aide_conv3x3_bf16(const float* x, int64_t x_bs, const uint16_t* u, const flo
     if (splitk > a.chunks_total) splitk = a.chunks_total;
     if (splitk > 1 && (!ws || (y_bs % 4) != 0)) return AIDE_ERR_ARG;
     a.splitk = splitk;
+    int kernel_out_bf16 = y_bf16;
     if (splitk > 1) {
         a.y = ws; a.y_bs = (long)Cout * H * W; a.split_stride = (long)N * Cout * H * W;
         a.bias = nullptr; a.accumulate = 0;
+        kernel_out_bf16 = 0;                     // slabs are fp32; the reduce narrows
     } else {
         a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = accumulate;
     }
     int rc;
-    static const bool occ2 = !(getenv("AIDE_BF16_OCC") && atoi(getenv("AIDE_BF16_OCC")) == 1);   // probe switch
-    switch (bf16_variant(Cout)) {
-        case 2: rc = launch_bf16<2, 2, 4, 1>(a, stream); break;
-        case 1: rc = occ2 ? launch_bf16<2, 1, 4, 2>(a, stream) : launch_bf16<2, 1, 4, 1>(a, stream); break;
-        default: rc = launch_bf16<1, 1, 4, 2>(a, stream); break;
-    }
+    if (bf16_variant(Cout) == 1) rc = launch_bf16<2, 1, 4, 2>(a, x_bf16, kernel_out_bf16, stream);
+    else rc = launch_bf16<1, 1, 4, 2>(a, x_bf16, kernel_out_bf16, stream);
     if (rc != 0) return rc;
     if (splitk > 1) {
         const long total4 = (long)N * Cout * H * W / 4;
         const int blocks = (int)min((total4 + 255) / 256, (long)2048);
-        hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws,
-                           (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias, accumulate, total4);
+        if (y_bf16)
+            hipLaunchKernelGGL(bf16_splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, stream, ws,
+                               (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias, 0, total4);
+        else
+            hipLaunchKernelGGL(bf16_splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, stream, ws,
+                               (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias, accumulate, total4);
         rc = aide_launch_status();
     }
     return rc;
+}
+
+int aide_conv3x3_bf16(const float* x, int64_t x_bs, const uint16_t* u, const float* bias, float* y, int64_t y_bs,
+                      int N, int Cin, int H, int W, int Cout, int accumulate, int splitk, float* ws,
+                      hipStream_t stream) {
+    return aide_conv3x3_bf16_mixed(x, 0, x_bs, u, bias, y, 0, y_bs, N, Cin, H, W, Cout, accumulate, splitk, ws, stream);
 }
 
 int aide_conv3x3_wgrad_bf16_supported(int Co, int Ci, int H, int W) {
@@ -653,15 +723,18 @@ size_t aide_conv3x3_wgrad_bf16_ws_bytes(int N, int Co, int Ci, int H, int W) {
     return (size_t)aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W) * 9 * Co * Ci * sizeof(float);
 }
 
-//   dz : [N][Co][H][W] (batch stride dz_bs)   a : [N][Ci][H][W] (batch stride a_bs)   dw : [Co][Ci][3][3] fp32
-int aide_conv3x3_wgrad_bf16(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N, int Co,
-                            int Ci, int H, int W, float* ws, hipStream_t stream) {
+//   dz : [N][Co][H][W] (batch stride dz_bs; fp32, or bf16 storage when dz_bf16)   a : [N][Ci][H][W] fp32 (batch
+//   stride a_bs)   dw : [Co][Ci][3][3] fp32
+int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, const float* a, int64_t a_bs, float* dw,
+                                  int N, int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
     if (!dz || !a || !dw || !ws || N <= 0 || !aide_conv3x3_wgrad_bf16_supported(Co, Ci, H, W)) return AIDE_ERR_ARG;
-    if ((dz_bs % 4) || (a_bs % 4)) return AIDE_ERR_ARG;
+    if ((dz_bs % (dz_bf16 ? 8 : 4)) || (a_bs % 4)) return AIDE_ERR_ARG;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            2 * G_BUF * 16);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_BUF * 16);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_BUF * 16);
         attr_set = true;
     }
     BgArgs g;
@@ -672,10 +745,18 @@ int aide_conv3x3_wgrad_bf16(const float* dz, int64_t dz_bs, const float* a, int6
     g.chunks_total = N * g.segs_w * g.bands_h;
     g.splits = aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W);
     const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
-    hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel, dim3((unsigned)nb), dim3(256), 2 * G_BUF * 16, stream, g);
+    if (dz_bf16)
+        hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel<true>, dim3((unsigned)nb), dim3(256), 2 * G_BUF * 16, stream, g);
+    else
+        hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel<false>, dim3((unsigned)nb), dim3(256), 2 * G_BUF * 16, stream, g);
     const int rc = aide_launch_status();
     if (rc != 0) return rc;
     return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, stream);
+}
+
+int aide_conv3x3_wgrad_bf16(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N, int Co,
+                            int Ci, int H, int W, float* ws, hipStream_t stream) {
+    return aide_conv3x3_wgrad_bf16_mixed(dz, 0, dz_bs, a, a_bs, dw, N, Co, Ci, H, W, ws, stream);
 }
 
 }  // extern "C"

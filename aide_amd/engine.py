@@ -86,6 +86,7 @@ WGRAD_TAG = {0: 'conv3x3_wgrad_kernel', 2: 'conv3x3_wgrad_wino_kernel', 4: 'conv
              BF16: 'conv3x3_wgrad_bf16_kernel'}
 PRECISIONS = ('fp32', 'bf16')
 USE_WINOGRAD4 = [True]
+STORE_BF16 = [True]            # precision='bf16': z / dz stored as bf16 (A-B switch)
 
 
 def conv_mode(n, cin, h, w, cout):
@@ -224,6 +225,13 @@ class Plan(object):
                         max_wg = max(max_wg, lib.aide_conv3x3_wgrad_ws_bytes(n, cout, cin, hh, ww))
                     st['pack_key'] = None
                     st['flops'] = 2.0 * n * hh * ww * cout * cin * 9      # algorithmic, per launch
+                    # bf16 mode keeps the conv output z (read only by BatchNorm) and its gradient dz (read only by the
+                    # bf16 dgrad / wgrad kernels, which round it to bf16 anyway -- storing it narrow changes nothing
+                    # numerically) in HBM as bf16: half the bytes of the conv-output write, of four BatchNorm reads and
+                    # of the dz write + two reads
+                    st['dz_bf16'] = (st['wino_w'] == BF16 and (not need_dg or st['wino_d'] == BF16) and STORE_BF16[0])
+                    if st['wino_f'] == BF16 and STORE_BF16[0]:
+                        st['z'] = torch.empty(n, cout, hh, ww, device=device, dtype=torch.bfloat16)
                 else:
                     cin = src.C
                     max_wg = max(max_wg, lib.aide_convT2x2_wgrad_ws_bytes(n, cin, cout, h >> src.level, w >> src.level))
@@ -272,7 +280,8 @@ class Plan(object):
         # reading dz of layer L while the main stream already produces dz of layer L-1
         for st in self.steps:
             if st['kind'] in ('conv', 'convT'):
-                st['dz'] = torch.empty_like(st['z'])
+                st['dz'] = torch.empty(st['z'].shape, device=self.dev,
+                                       dtype=torch.bfloat16 if st.get('dz_bf16') else torch.float32)
         self.wg_ws = torch.empty(max(self._max_wg // 4, 1), **f32)
         self.head_ws = torch.empty(max(self._max_wg // 4, 1), **f32)
         sa = [st for st in self.steps if st['kind'] == 'sa']

@@ -24,10 +24,15 @@ def _req(t, dtype=torch.float32):
     return t
 
 
-def planes(t):
+def is_bf16(t):
+    return t.dtype == torch.bfloat16
+
+
+def planes(t, bf16_ok=False):
     """(data_ptr, batch_stride) of an NCHW fp32 tensor whose channel planes are dense
-    (a channel slice of a contiguous buffer qualifies)."""
-    _req(t)
+    (a channel slice of a contiguous buffer qualifies).  bf16_ok: the tensor may also be a bf16-stored conv output /
+    conv-output gradient of the precision='bf16' mode (strides are in elements either way)."""
+    _req(t, t.dtype if (bf16_ok and isinstance(t, torch.Tensor) and t.dtype == torch.bfloat16) else torch.float32)
     n, c, h, w = t.shape
     sn, sc, sh, sw = t.stride()
     ok = (sw == 1 or w == 1) and (sh == w or h == 1) and (sc == h * w or c == 1)
@@ -160,12 +165,12 @@ def bn_ws(c, device):
 def bn_train_fwd(z, a, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, rstd, scale, shift,
                  ws, relu=True):
     """a = relu(bn_train(z)); updates running stats / num_batches_tracked; saves mean/rstd/scale/shift."""
-    zp, zbs = planes(z)
+    zp, zbs = planes(z, bf16_ok=True)
     ap, abs_ = planes(a)
     n, c, h, w = z.shape
-    check(lib.aide_bn_train_fwd(zp, zbs, ap, abs_, n, c, h, w, ptr(gamma), ptr(beta), eps, momentum,
-                                ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd),
-                                ptr(scale), ptr(shift), int(relu), ptr(ws), stream_ptr()), 'bn_train_fwd')
+    check(lib.aide_bn_train_fwd_mixed(zp, int(is_bf16(z)), zbs, ap, abs_, n, c, h, w, ptr(gamma), ptr(beta), eps,
+                                      momentum, ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd),
+                                      ptr(scale), ptr(shift), int(relu), ptr(ws), stream_ptr()), 'bn_train_fwd')
     return a
 
 
@@ -176,22 +181,22 @@ def bn_eval_coeff(gamma, beta, running_mean, running_var, eps, scale, shift):
 
 
 def bn_relu_apply(z, a, scale, shift, relu=True):
-    zp, zbs = planes(z)
+    zp, zbs = planes(z, bf16_ok=True)
     ap, abs_ = planes(a)
     n, c, h, w = z.shape
-    check(lib.aide_bn_relu_apply(zp, zbs, ap, abs_, n, c, h, w, ptr(scale), ptr(shift), int(relu),
-                                 stream_ptr()), 'bn_relu_apply')
+    check(lib.aide_bn_relu_apply_mixed(zp, int(is_bf16(z)), zbs, ap, abs_, n, c, h, w, ptr(scale), ptr(shift),
+                                       int(relu), stream_ptr()), 'bn_relu_apply')
     return a
 
 
 def bn_relu_bwd(dA, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, relu=True):
     gp, gbs = planes(dA)
-    zp, zbs = planes(z)
-    dp, dbs = planes(dz)
+    zp, zbs = planes(z, bf16_ok=True)
+    dp, dbs = planes(dz, bf16_ok=True)
     n, c, h, w = z.shape
-    check(lib.aide_bn_relu_bwd(gp, gbs, zp, zbs, dp, dbs, n, c, h, w, ptr(mean), ptr(rstd), ptr(scale),
-                               ptr(shift), int(relu), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws),
-                               stream_ptr()), 'bn_relu_bwd')
+    check(lib.aide_bn_relu_bwd_mixed(gp, gbs, zp, int(is_bf16(z)), zbs, dp, int(is_bf16(dz)), dbs, n, c, h, w,
+                                     ptr(mean), ptr(rstd), ptr(scale), ptr(shift), int(relu), ptr(dgamma), ptr(dbeta),
+                                     ptr(dbias), ptr(ws), stream_ptr()), 'bn_relu_bwd')
     return dz
 
 
@@ -386,9 +391,10 @@ def bf16_pack(w, need_dgrad=True):
 
 
 def conv3x3_bf16(x, u, bias, y, accumulate=False, splitk=-1, ws=None):
-    """y (+)= conv3x3(x) on the bf16 MFMA path (fp32 tensors, bf16 operands, fp32 accumulation)."""
-    xp, xbs = planes(x)
-    yp, ybs = planes(y)
+    """y (+)= conv3x3(x) on the bf16 MFMA path (bf16 operands, fp32 accumulation).  x, y are fp32 tensors; y may be a
+    bf16-stored z (forward) or x a bf16-stored dz (dgrad)."""
+    xp, xbs = planes(x, bf16_ok=True)
+    yp, ybs = planes(y, bf16_ok=True)
     n, cin, h, w = x.shape
     cout = y.shape[1]
     assert u.dtype == torch.int16 and u.numel() == lib.aide_conv3x3_bf16_pack_elems(cout, cin)
@@ -396,8 +402,8 @@ def conv3x3_bf16(x, u, bias, y, accumulate=False, splitk=-1, ws=None):
         splitk = lib.aide_conv3x3_bf16_splitk(n, cin, h, w, cout)
     if splitk > 1 and ws is None:
         ws = torch.empty(lib.aide_conv3x3_ws_bytes(n, h, w, cout, splitk) // 4, device=x.device, dtype=torch.float32)
-    check(lib.aide_conv3x3_bf16(xp, xbs, ptr(u), ptr(bias), yp, ybs, n, cin, h, w, cout, int(accumulate), splitk,
-                                ptr(ws), stream_ptr()), 'conv3x3_bf16')
+    check(lib.aide_conv3x3_bf16_mixed(xp, int(is_bf16(x)), xbs, ptr(u), ptr(bias), yp, int(is_bf16(y)), ybs, n, cin, h,
+                                      w, cout, int(accumulate), splitk, ptr(ws), stream_ptr()), 'conv3x3_bf16')
     return y
 
 
@@ -406,8 +412,8 @@ def wgrad_bf16_supported(co, ci, h, w):
 
 
 def conv3x3_wgrad_bf16(dz, a, dw, ws=None):
-    """dw [Co,Ci,3,3] fp32 <- weight gradient on the bf16 MFMA path."""
-    dzp, dzbs = planes(dz)
+    """dw [Co,Ci,3,3] fp32 <- weight gradient on the bf16 MFMA path (dz fp32 or bf16-stored)."""
+    dzp, dzbs = planes(dz, bf16_ok=True)
     ap, abs_ = planes(a)
     n, co, h, w = dz.shape
     ci = a.shape[1]
@@ -415,8 +421,8 @@ def conv3x3_wgrad_bf16(dz, a, dw, ws=None):
     if ws is None:
         ws = torch.empty(lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, co, ci, h, w) // 4, device=dz.device,
                          dtype=torch.float32)
-    check(lib.aide_conv3x3_wgrad_bf16(dzp, dzbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), stream_ptr()),
-          'conv3x3_wgrad_bf16')
+    check(lib.aide_conv3x3_wgrad_bf16_mixed(dzp, int(is_bf16(dz)), dzbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws),
+                                            stream_ptr()), 'conv3x3_wgrad_bf16')
     return dw
 
 

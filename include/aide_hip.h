@@ -94,11 +94,18 @@ int aide_conv3x3_bf16_pack_multi(const void* descs, int n, int64_t total_blocks,
 int aide_conv3x3_bf16(const float* x, int64_t x_bs, const uint16_t* u, const float* bias, float* y, int64_t y_bs,
                       int N, int Cin, int H, int W, int Cout, int accumulate, int splitk, float* ws,
                       aide_stream_t stream);                     /* forward and dgrad */
+/* the same with bf16 STORAGE of the conv output z (forward: y_bf16) or of its gradient dz (dgrad: x_bf16) -- the
+ * engine's precision='bf16' mode keeps z and dz in HBM as bf16 (they are only read by BatchNorm / by these kernels) */
+int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint16_t* u, const float* bias, void* y,
+                            int y_bf16, int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,
+                            float* ws, aide_stream_t stream);
 int aide_conv3x3_wgrad_bf16_supported(int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W);
 size_t aide_conv3x3_wgrad_bf16_ws_bytes(int N, int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_bf16(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
                             int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
+int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, const float* a, int64_t a_bs, float* dw,
+                                  int N, int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
 
 /* ---- ConvTranspose2d(k=2, s=2) (learned_bilinear=True up path) ---------------------------------
  * replaces nn.ConvTranspose2d: netblocks.py:12, UNet.py:7 */
@@ -126,6 +133,18 @@ int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs
                      int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                      const float* scale, const float* shift, int relu, float* dgamma, float* dbeta,
                      float* dbias, void* ws, aide_stream_t stream);
+/* the same three operators on bf16-STORED z / dz (precision='bf16'): z_bf16 / dz_bf16 give the element type behind the
+ * untyped pointers; the arithmetic (fp32 per element, fp64 reductions) is unchanged, widening is exact, dz is narrowed RNE */
+int aide_bn_train_fwd_mixed(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
+                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                            float* scale, float* shift, int relu, void* ws, aide_stream_t stream);
+int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
+                             const float* scale, const float* shift, int relu, aide_stream_t stream);
+int aide_bn_relu_bwd_mixed(const float* dA, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz, int dz_bf16,
+                           int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
+                           const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
+                           void* ws, aide_stream_t stream);
 
 /* ---- MaxPool2d(2,2), bilinear x2 (align_corners=True) -------------------------------------------
  * replaces nn.MaxPool2d: fuseunet.py:13-31 (calls :51-78), UNet.py:114 ;

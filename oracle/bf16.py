@@ -2,8 +2,10 @@
 
 BASELINE config 5 asks for a bf16 MFMA path.  The product's contract (aide_amd/csrc/conv3x3_bf16.hip) is:
 conv operands -- activations, incoming gradients, filters -- are rounded to bf16 (round-to-nearest-even) where
-they enter a convolution, products are accumulated in fp32, and everything else (bias, BatchNorm, pooling,
-up-sampling, head, loss, Adam) is the fp32 arithmetic of the reference.  `emulate_bf16(net)` rewires the
+they enter a convolution, products are accumulated in fp32, the conv output z (= accumulators + bias) is stored as
+bf16 (what torch.autocast does as well; BatchNorm then reads the bf16 values in fp32), and everything else (BatchNorm,
+pooling, up-sampling, head, loss, Adam) is the fp32 arithmetic of the reference.  (The gradient dz is stored as bf16
+too, which is not a separate rounding: dz is only ever read as a conv operand.)  `emulate_bf16(net)` rewires the
 nn.Conv2d(.., 3, padding=1) layers of an oracle network (oracle/nets.py, which follows
 models_twomodalinputs/netblocks.py:24-27 and models_singlemodalinput/UNet.py:19-22) to exactly that arithmetic with
 stock aten CPU ops, for the layers / directions the product runs in bf16 (same shape predicates as
@@ -13,6 +15,9 @@ import types
 
 import torch
 import torch.nn.functional as F
+
+
+STORE_Z_BF16 = [True]       # False: emulate the A-B mode with an fp32-stored conv output (engine.STORE_BF16)
 
 
 def rb(t):
@@ -35,7 +40,8 @@ class _ConvBf16(torch.autograd.Function):
         n, ci, h, wd = x.shape
         co = w.shape[0]
         if conv_bf16_supported(ci, h, wd, co):
-            return F.conv2d(rb(x), rb(w), b, padding=1)
+            y = F.conv2d(rb(x), rb(w), b, padding=1)
+            return rb(y) if STORE_Z_BF16[0] else y
         return F.conv2d(x, w, b, padding=1)
 
     @staticmethod

@@ -82,6 +82,68 @@ def test_conv3x3_bf16_fwd_dgrad(dev, case):
             _close(dx, dx_fp32 + base, 1e-2, 'dgrad vs fp32 %s' % (case,))
 
 
+def test_bf16_storage_variants(dev):
+    """z stored as bf16 by the forward (= RNE of the fp32-output kernel's result, bit for bit), dz read as bf16 by the
+    dgrad / wgrad (= the fp32-input kernels on the widened values, bit for bit), with and without split-K."""
+    from aide_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for (n, ci, co, h, w) in ((2, 64, 64, 32, 32), (1, 3, 32, 20, 64), (1, 128, 96, 16, 32)):
+        x = torch.randn(n, ci, h, w, generator=g).to(dev)
+        wt = (torch.randn(co, ci, 3, 3, generator=g) * 0.1).to(dev)
+        b = torch.randn(co, generator=g).to(dev)
+        uf, ud = ops.bf16_pack(wt, need_dgrad=(ci % 32 == 0))
+        for splitk in (1, 2):
+            if splitk > (ci + 15) // 16:
+                continue
+            y32 = torch.empty(n, co, h, w, device=dev)
+            ops.conv3x3_bf16(x, uf, b, y32, splitk=splitk)
+            y16 = torch.empty(n, co, h, w, device=dev, dtype=torch.bfloat16)
+            ops.conv3x3_bf16(x, uf, b, y16, splitk=splitk)
+            assert torch.equal(y16, y32.bfloat16()), 'bf16 z, splitk %d, %s' % (splitk, (n, ci, co, h, w))
+        if ud is not None:
+            dz16 = torch.randn(n, co, h, w, generator=g).to(dev).bfloat16()
+            dx_a, dx_b = torch.empty(n, ci, h, w, device=dev), torch.empty(n, ci, h, w, device=dev)
+            ops.conv3x3_bf16(dz16, ud, None, dx_a)
+            ops.conv3x3_bf16(dz16.float(), ud, None, dx_b)
+            assert torch.equal(dx_a, dx_b), 'bf16 dz dgrad'
+            if ops.wgrad_bf16_supported(co, ci, h, w):
+                dw_a, dw_b = torch.empty_like(wt), torch.empty_like(wt)
+                ops.conv3x3_wgrad_bf16(dz16, x, dw_a)
+                ops.conv3x3_wgrad_bf16(dz16.float(), x, dw_b)
+                assert torch.equal(dw_a, dw_b), 'bf16 dz wgrad'
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 32, 32), (4, 64, 16, 16), (1, 8, 6, 5)])
+def test_bn_on_bf16_storage(dev, shape):
+    """BatchNorm forward / backward on a bf16-stored z and into a bf16-stored dz: bit-identical to the fp32-storage
+    kernels on the widened z, with dz narrowed RNE."""
+    from aide_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c)
+    z16 = torch.randn(n, c, h, w, generator=g).to(dev).bfloat16()
+    dA = torch.randn(n, c, h, w, generator=g).to(dev)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(dev), torch.randn(c, generator=g).to(dev)
+    res = []
+    for z in (z16, z16.float()):
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        nbt = torch.zeros((), dtype=torch.long, device=dev)
+        st = [torch.empty(c, device=dev) for _ in range(4)]
+        a = torch.empty(n, c, h, w, device=dev)
+        ws = ops.bn_ws(c, dev)
+        ops.bn_train_fwd(z, a, gamma, beta, 1e-5, 0.1, rm, rv, nbt, st[0], st[1], st[2], st[3], ws, True)
+        dz = torch.empty(n, c, h, w, device=dev, dtype=z.dtype)
+        dg, db, dbias = torch.empty(c, device=dev), torch.empty(c, device=dev), torch.empty(c, device=dev)
+        ops.bn_relu_bwd(dA, z, dz, st[0], st[1], st[2], st[3], dg, db, dbias, ws, True)
+        a_eval = torch.empty_like(a)
+        ops.bn_relu_apply(z, a_eval, st[2], st[3], True)
+        res.append((a, rm, rv, dz, dg, db, a_eval))
+    for t16, t32 in zip(res[0], res[1]):
+        if t16.dtype == torch.bfloat16:
+            assert torch.equal(t16, t32.bfloat16())
+        else:
+            assert torch.equal(t16, t32)
+
+
 def test_conv3x3_bf16_channel_slices(dev):
     """inputs / outputs that are channel slices of concatenation buffers (explicit batch stride)."""
     from aide_amd import ops
@@ -149,14 +211,28 @@ def _rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
 
-@pytest.mark.parametrize('kind', ['fuseunet', 'UNet'])
-def test_bf16_network_vs_bf16_oracle(dev, kind):
+@pytest.mark.parametrize('kind,store', [('fuseunet', True), ('UNet', True), ('fuseunet', False)])
+def test_bf16_network_vs_bf16_oracle(dev, kind, store):
     """precision='bf16' against the oracle whose 3x3 convolutions use bf16-rounded operands (oracle/bf16.py) for the
     same layers: logits, loss and every parameter gradient.  A bf16 rounding point is a discontinuity like a ReLU
-    mask (an fp32-noise difference before the rounding moves one operand by a bf16 ulp: ~3e-4 of all operands flip
-    between two fp32 implementations), and this random-init, 2-image, 64x64 network amplifies perturbations (the
-    full bf16 rounding moves its logits by 10 %), so the bounds are 1e-2 of the tensor scale for logits, 5e-3 for the
-    loss and 5e-2 for gradients; the kernels themselves are held to 3e-5 above."""
+    mask: an fp32-noise difference before the rounding moves the value by a whole bf16 ulp (2^-8 relative).  With the
+    conv output z stored as bf16 (`store`, the default) ~3e-4 of all z values land on the other side of a rounding
+    boundary in any two implementations that sum in a different order, and this random-init, 2-image, 64x64 network
+    amplifies perturbations (the full bf16 rounding moves its logits by 10 %).  Measured here: logits 1.8-3.2e-2 of
+    their scale, loss 7e-5, worst parameter gradient 3.5e-2, 0.3 % ReLU-mask flips; bounds 6e-2 / 2e-3 / 8e-2 (fp32-stored
+    z: 1e-2 / 5e-3 / 5e-2).  The kernels themselves are held to 3e-5 / bit-exactness above -- that is the parity
+    evidence; this test guards the wiring (which layers run where, storage types, gradient flow)."""
+    from aide_amd import engine as E
+    from oracle import bf16 as OB
+    LOGIT_TOL, LOSS_TOL, GRAD_TOL = (6e-2, 2e-3, 8e-2) if store else (1e-2, 5e-3, 5e-2)
+    E.STORE_BF16[0] = OB.STORE_Z_BF16[0] = store
+    try:
+        _network_vs_oracle(dev, kind, LOGIT_TOL, LOSS_TOL, GRAD_TOL)
+    finally:
+        E.STORE_BF16[0] = OB.STORE_Z_BF16[0] = True
+
+
+def _network_vs_oracle(dev, kind, LOGIT_TOL, LOSS_TOL, GRAD_TOL):
     import oracle
     from aide_amd import utils as U
     from aide_amd.engine import BF16
@@ -178,11 +254,16 @@ def test_bf16_network_vs_bf16_oracle(dev, kind):
         out_r = ref(*xs)
         loss_r = oracle.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)(out_r, t)
         loss_r.backward()
-    assert sum(fm.flips.values()) <= 2e-3 * fm.total, 'implausibly many ReLU mask flips: %s' % fm.flips
+    # (z is stored as bf16: an fp32-noise difference in an accumulator moves z by a whole bf16 ulp, so a BatchNorm output
+    # near zero changes sign far more often than between two fp32 implementations -- 0.3 % of the mask elements here)
+    assert sum(fm.flips.values()) <= 1e-2 * fm.total, 'implausibly many ReLU mask flips: %d of %d' % (
+        sum(fm.flips.values()), fm.total)
     modes = [(st['wino_f'], st['wino_d'], st['wino_w']) for st in plan.steps if st['kind'] == 'conv']
     assert sum(m[0] == BF16 for m in modes) >= 8 and sum(m[2] == BF16 for m in modes) >= 6, modes
-    assert _rel(out, out_r) < 1e-2, 'logits %g' % _rel(out, out_r)
-    assert abs(loss.item() - loss_r.item()) < 5e-3 * abs(loss_r.item())
+    print('bf16 network parity: logits %.3e loss %.3e flips %d/%d' % (
+        _rel(out, out_r), abs(loss.item() - loss_r.item()) / abs(loss_r.item()), sum(fm.flips.values()), fm.total))
+    assert _rel(out, out_r) < LOGIT_TOL, 'logits %g' % _rel(out, out_r)
+    assert abs(loss.item() - loss_r.item()) < LOSS_TOL * abs(loss_r.item())
     worst = 0.0
     for (name, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         if name.endswith('conv1.bias') or name.endswith('conv2.bias') or '.bilinear_up.' in name and name.endswith('.1.bias'):
@@ -191,7 +272,8 @@ def test_bf16_network_vs_bf16_oracle(dev, kind):
         if scale < 1e-7:
             continue
         worst = max(worst, (p.grad.cpu() - q.grad).abs().max().item() / scale)
-    assert worst < 5e-2, 'worst parameter-gradient error %g' % worst
+    print('worst parameter-gradient error %.3e' % worst)
+    assert worst < GRAD_TOL, 'worst parameter-gradient error %g' % worst
 
 
 def test_bf16_mode_close_to_fp32_mode(dev):
