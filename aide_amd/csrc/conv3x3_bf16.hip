@@ -62,20 +62,25 @@ struct BfArgs {
     int tiles_w, tiles_h, n_co_tiles, splitk, chunks_total, accumulate;
 };
 
-constexpr int BF_PITCH = 36;          // slots per halo-tile row: columns -2 .. 33 (18 pixel pairs)
 
-template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16>
+template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16, int TW>
 __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) {
     constexpr unsigned ES = IN_BF16 ? 2u : 4u;     // bytes per input element
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int TCO = 32 * WM * WAVES_M;
-    constexpr int TH = WAVES_N * WN;               // image rows per tile (32 columns wide)
+    // pixel tile = TH rows x TW columns (TW = 32 or 64): the WAVES_N * WN 32-pixel MFMA column blocks are laid out
+    // CB = TW / 32 per image row.  The wide form reads 272-byte and writes 128 / 256-byte row pieces (fp32 / bf16
+    // in, bf16 / fp32 out) instead of 144 and 64 / 128: fewer, fuller DRAM bursts on the HBM-bound big planes.
+    constexpr int CB = TW / 32;
+    constexpr int TH = WAVES_N * WN / CB;          // image rows per tile
+    constexpr int BF_PITCH = TW + 4;               // slots per halo-tile row: columns -2 .. TW + 1
+    constexpr int NPR = BF_PITCH / 2;              // pixel pairs per halo-tile row
     constexpr int PLANE = (TH + 2) * BF_PITCH;     // slots per channel group
     constexpr int XS = 2 * PLANE;                  // halo-tile slots (2 groups of 8 channels)
     constexpr int AS = 18 * TCO;                   // filter-block slots: [tap][g][TCO]
     constexpr int BUF = XS + AS + 2;               // + 2 dump slots: idle staging lanes store there (no branches)
     constexpr int DUMP = XS + AS;
-    constexpr int UX = 2 * (TH + 2) * 18;          // pixel-pair units per stage
+    constexpr int UX = 2 * (TH + 2) * NPR;         // pixel-pair units per stage
     constexpr int NUX = (UX + 255) / 256;
     constexpr int NUA = (AS + 255) / 256;
     constexpr int NOPA0 = (9 - NUX) < NUA ? (9 - NUX) : NUA;
@@ -83,6 +88,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
     constexpr int NOPA = (NUA + APG - 1) / APG;
     constexpr int NOPS = NUX + NOPA;                    // one staging op per tap
     static_assert(NOPS <= 9, "staging schedule");
+    static_assert(WN % CB == 0, "a wave's column blocks must cover whole tile rows");
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * BUF slots
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
     const int tw = b % a.tiles_w;         b /= a.tiles_w;
     const int th = b % a.tiles_h;
     const int n = b / a.tiles_h;
-    const int h0 = th * TH, w0 = tw * 32, co0 = co_tile * TCO;
+    const int h0 = th * TH, w0 = tw * TW, co0 = co_tile * TCO;
     const int HW = a.H * a.W;
 
     const int cps = (a.chunks_total + a.splitk - 1) / a.splitk;
@@ -107,8 +113,8 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
 #pragma unroll
     for (int e = 0; e < NUX; ++e) {
         const int u = tid + e * 256;
-        const int g = u / ((TH + 2) * 18), rem = u - g * ((TH + 2) * 18);
-        const int row = rem / 18, pr = rem - row * 18;
+        const int g = u / ((TH + 2) * NPR), rem = u - g * ((TH + 2) * NPR);
+        const int row = rem / NPR, pr = rem - row * NPR;
         const int ih = h0 - 1 + row, iw = w0 - 2 + 2 * pr;
         const bool ok = u < UX && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
         offX[e] = ok ? (unsigned)(g * 8 * HW + row * a.W + 2 * pr) * ES : BUF_OOB;
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
 
     // lane slots of the operand fragments: pixel column c sits at slot c + 2 of its tile row
     const int la = XS + half * TCO + wave_m * WM * 32 + j;
-    const int lb = half * PLANE + wave_n * WN * BF_PITCH + j + 1;
+    const int lb = half * PLANE + j + 1;
 
     // prologue: chunk c_begin -> buffer 0, chunk c_begin + 1 stays in registers
 #pragma unroll
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
     int cur = 0;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         const u32x4* pa = lds + cur * BUF + la;
-        const u32x4* pb = lds + cur * BUF + lb;
+        const u32x4* pb = lds + cur * BUF + lb + (wave_n * WN / CB) * BF_PITCH;
         u32x4* nxt = lds + (cur ^ 1) * BUF;
         bf16x8 afA[WM], bfA[WN], afB[WM], bfB[WN];
         auto frag = [&](int t, bf16x8 (&af)[WM], bf16x8 (&bf)[WN]) {
@@ -215,15 +221,22 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
 #pragma unroll
             for (int m = 0; m < WM; ++m) af[m] = __builtin_bit_cast(bf16x8, pa[t * 2 * TCO + m * 32]);
 #pragma unroll
-            for (int nt = 0; nt < WN; ++nt) bf[nt] = __builtin_bit_cast(bf16x8, pb[(nt + kh) * BF_PITCH + kw]);
+            for (int nt = 0; nt < WN; ++nt)
+                bf[nt] = __builtin_bit_cast(bf16x8, pb[((nt / CB) + kh) * BF_PITCH + (nt % CB) * 32 + kw]);
         };
         auto kstep = [&](int t, bf16x8 (&afc)[WM], bf16x8 (&bfc)[WN], bf16x8 (&afn)[WM], bf16x8 (&bfn)[WN]) {
             if (t + 1 < 9) frag(t + 1, afn, bfn);
+#ifdef AIDE_PROBE_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int m = 0; m < WM; ++m)
 #pragma unroll
                 for (int nt = 0; nt < WN; ++nt)
                     acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[m], bfc[nt], acc[m][nt], 0, 0, 0);
+#ifdef AIDE_PROBE_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if (t < NOPS) {
                 put(t, nxt);               // chunk + 1 (fetched one stage ago) -> the other buffer
                 fetch(t, chunk + 2);       // its registers re-issue their loads at once
@@ -239,7 +252,9 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
             }
+#ifndef AIDE_PROBE_NO_TAP_BARRIER
             __builtin_amdgcn_sched_barrier(0);
+#endif
         };
         frag(0, afA, bfA);
         kstep(0, afA, bfA, afB, bfB);
@@ -264,8 +279,8 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
         const int odd = j & 1;
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
-            const int oh = h0 + wave_n * WN + nt;
-            const int ow = w0 + (j & ~1);
+            const int oh = h0 + (wave_n * WN + nt) / CB;
+            const int ow = w0 + ((wave_n * WN + nt) % CB) * 32 + (j & ~1);
             const bool pok = oh < a.H;
 #pragma unroll
             for (int m = 0; m < WM; ++m) {
@@ -285,8 +300,8 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
         float* yn = (float*)a.y + (long)split * a.split_stride + (long)n * a.y_bs;
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
-            const int oh = h0 + wave_n * WN + nt;
-            const int ow = w0 + j;
+            const int oh = h0 + (wave_n * WN + nt) / CB;
+            const int ow = w0 + ((wave_n * WN + nt) % CB) * 32 + j;
             const bool pok = oh < a.H;
 #pragma unroll
             for (int m = 0; m < WM; ++m) {
@@ -379,24 +394,35 @@ __global__ __launch_bounds__(256) void bf16_pack_multi_kernel(const BfPackDesc* 
     *dst = s;
 }
 
-template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16>
-int launch_bf16_r(BfArgs a, hipStream_t stream) {
-    constexpr int WAVES_N = 4 / WAVES_M, TCO = 32 * WM * WAVES_M, TH = WAVES_N * WN;
-    constexpr int BUF = 2 * (TH + 2) * BF_PITCH + 18 * TCO + 2;
+// 64-column tiles wherever the width allows (ahead by 3-10 % on every layer of the sweep from W = 64 up)
+bool bf16_wide_tile(int W, int H) { return W >= 64 && W % 64 == 0; }
+
+template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16, int TW>
+int launch_bf16_t(BfArgs a, hipStream_t stream) {
+    constexpr int WAVES_N = 4 / WAVES_M, TCO = 32 * WM * WAVES_M, TH = WAVES_N * WN / (TW / 32);
+    constexpr int BUF = 2 * (TH + 2) * (TW + 4) + 18 * TCO + 2;
     constexpr int LDS_BYTES = 2 * BUF * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16>,
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, TW>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    a.tiles_w = a.W / 32;
+    a.tiles_w = a.W / TW;
     a.tiles_h = (a.H + TH - 1) / TH;
     a.n_co_tiles = a.Cout / TCO;
     const long nb = (long)a.tiles_w * a.tiles_h * a.N * a.n_co_tiles * a.splitk;
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16>), dim3((unsigned)nb), dim3(256),
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, TW>), dim3((unsigned)nb), dim3(256),
                        LDS_BYTES, stream, a);
     return aide_launch_status();
+}
+
+template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16>
+int launch_bf16_r(const BfArgs& a, hipStream_t stream) {
+    static const int force = getenv("AIDE_BF16_TW") ? atoi(getenv("AIDE_BF16_TW")) : 0;     // probe switch
+    const bool wide = force ? force == 64 : bf16_wide_tile(a.W, a.H);
+    if (wide && a.W % 64 == 0) return launch_bf16_t<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, 64>(a, stream);
+    return launch_bf16_t<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, 32>(a, stream);
 }
 
 // storage combinations: fp32 -> fp32 (stand-alone operator), fp32 -> bf16 (forward into a bf16 z), bf16 -> fp32
@@ -419,8 +445,9 @@ int launch_bf16(const BfArgs& a, int in_bf16, int out_bf16, hipStream_t stream) 
 // and is not instantiated.)
 int bf16_variant(int Cout) { return Cout % 64 == 0 ? 1 : 0; }
 long bf16_blocks(int variant, int N, int H, int W, int Cout) {
-    const int th = 16, tco = variant == 1 ? 64 : 32;
-    return (long)(W / 32) * ((H + th - 1) / th) * N * (Cout / tco);
+    const int tco = variant == 1 ? 64 : 32;
+    const int tw = (bf16_wide_tile(W, H) && W % 64 == 0) ? 64 : 32, th = 512 / tw;
+    return (long)(W / tw) * ((H + th - 1) / th) * N * (Cout / tco);
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient
@@ -572,14 +599,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs
         const u32x4* pa = lds + cur * G_BUF + la;
         const u32x4* pb = lds + cur * G_BUF + lb;
         u32x4* nxt = lds + (cur ^ 1) * G_BUF;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {              // k-step = (dz row r, 16-pixel half segment hs)
+        // operand registers of k-step ks + 1 are read from LDS while the MFMAs of k-step ks run (one wave per SIMD: an
+        // LDS round trip in front of every shift / MFMA group would otherwise be fully exposed)
+        bf16x8 afA, afB;
+        u32x4 wA[3][2], wB[3][2];
+        auto load_ops = [&](int ks, bf16x8& af, u32x4 (&wv)[3][2]) {
             const int r = ks >> 1, hs = ks & 1;
-            const bf16x8 af = __builtin_bit_cast(bf16x8, pa[r * 4 + hs * 2]);
+            af = __builtin_bit_cast(bf16x8, pa[r * 4 + hs * 2]);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                const u32x4 w0v = pb[(r + kh) * 5 + hs * 2];
-                const u32x4 w1v = pb[(r + kh) * 5 + hs * 2 + 1];
+                wv[kh][0] = pb[(r + kh) * 5 + hs * 2];
+                wv[kh][1] = pb[(r + kh) * 5 + hs * 2 + 1];
+            }
+        };
+        load_ops(0, afA, wA);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {              // k-step = (dz row r, 16-pixel half segment hs)
+            const bf16x8& af = (ks & 1) ? afB : afA;
+            u32x4 (&wv)[3][2] = (ks & 1) ? wB : wA;
+            if (ks + 1 < 8) { if (ks & 1) load_ops(ks + 1, afA, wA); else load_ops(ks + 1, afB, wB); }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const u32x4 w0v = wv[kh][0];
+                const u32x4 w1v = wv[kh][1];
                 u32x4 s1, s2;
                 s1[0] = __builtin_amdgcn_alignbit(w0v[1], w0v[0], 16);
                 s1[1] = __builtin_amdgcn_alignbit(w0v[2], w0v[1], 16);
@@ -713,7 +755,9 @@ int aide_conv3x3_wgrad_bf16_supported(int Co, int Ci, int H, int W) {
 int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W) {
     const long tiles = (long)((Co + 63) / 64) * ((Ci + 63) / 64);
     const long chunks = (long)N * (H / G_R) * (W / 32);
-    long s = (512 + tiles - 1) / tiles;          // two rounds of workgroups
+    static const long target = getenv("AIDE_BF16_WG_TARGET") ? atol(getenv("AIDE_BF16_WG_TARGET")) : 256;   // probe
+    long s = (target + tiles - 1) / tiles;       // one round of workgroups, one per CU (512 / 1024 measured 6 % / 16 % slower:
+                                                 // twice the slab bytes for the fixed-order reduce, twice the prologues)
     if (s > chunks / 2) s = chunks / 2;          // at least two stages per workgroup
     if (s < 1) s = 1;
     return (int)s;

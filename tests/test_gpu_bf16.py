@@ -46,6 +46,7 @@ BF16_CASES = [
     # N, Cin, Cout, H, W
     (2, 3, 32, 32, 32), (1, 32, 32, 64, 64), (2, 64, 64, 32, 32), (1, 128, 64, 64, 64), (2, 64, 128, 16, 32),
     (1, 256, 256, 32, 32), (1, 40, 96, 24, 64), (2, 512, 512, 32, 32), (1, 32, 64, 20, 96),
+    (1, 64, 64, 24, 128), (1, 3, 32, 12, 192),          # 64-column tiles (W >= 128), ragged bottom rows
 ]
 
 
@@ -87,7 +88,7 @@ def test_bf16_storage_variants(dev):
     dgrad / wgrad (= the fp32-input kernels on the widened values, bit for bit), with and without split-K."""
     from aide_amd import ops
     g = torch.Generator().manual_seed(21)
-    for (n, ci, co, h, w) in ((2, 64, 64, 32, 32), (1, 3, 32, 20, 64), (1, 128, 96, 16, 32)):
+    for (n, ci, co, h, w) in ((2, 64, 64, 32, 32), (1, 3, 32, 20, 64), (1, 128, 96, 16, 32), (1, 32, 64, 12, 128)):
         x = torch.randn(n, ci, h, w, generator=g).to(dev)
         wt = (torch.randn(co, ci, 3, 3, generator=g) * 0.1).to(dev)
         b = torch.randn(co, generator=g).to(dev)
