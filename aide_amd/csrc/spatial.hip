@@ -101,31 +101,46 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
 }
 
 // 4 consecutive outputs per thread, one 16-byte store (the scalar form ran at 1.1 TB/s)
+// One (n, c) plane per blockIdx.y, 32-bit index arithmetic (the flat 64-bit div/mod form of this kernel was VALU-bound
+// at 1.9 TB/s).  A thread produces four consecutive outputs of one row: their sources lie in the four columns
+// wl .. wl + 3 of two source rows (3 * scale < 1.5), read once each.
 __global__ __launch_bounds__(256) void upsample2x_fwd_vec_kernel(const float* __restrict__ x, long x_bs,
                                                                  float* __restrict__ y, long y_bs, int C, int H,
-                                                                 int W, long total4) {
+                                                                 int W, int per_plane4) {
     const int Ho = 2 * H, Wo = 2 * W, Wo4 = Wo / 4;
     const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
-        const int ow4 = (int)(i % Wo4);
-        long r = i / Wo4;
-        const int oh = (int)(r % Ho); r /= Ho;
-        const int c = (int)(r % C);
-        const long n = r / C;
+    const int plane = blockIdx.y, n = plane / C, c = plane - n * C;
+    const float* xp = x + (long)n * x_bs + (long)c * H * W;
+    float* yp = y + (long)n * y_bs + (long)c * Ho * Wo;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < per_plane4; e += gridDim.x * 256) {
+        const int oh = e / Wo4, ow4 = e - oh * Wo4;
         int h0, h1; float lh;
         src_index(oh, sh, H, h0, h1, lh);
-        const float* p0 = x + n * x_bs + (long)c * H * W + (long)h0 * W;
-        const float* p1 = x + n * x_bs + (long)c * H * W + (long)h1 * W;
+        const float* p0 = xp + h0 * W;
+        const float* p1 = xp + h1 * W;
+        int wl, wdummy; float ldummy;
+        src_index(4 * ow4, sw, W, wl, wdummy, ldummy);
+        float t[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int wc = min(wl + k, W - 1);
+            t[k] = p0[wc]; b[k] = p1[wc];
+        }
+        float v[4];                                   // rows blended first: v[k] = (1 - lh) t[k] + lh b[k]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (1.f - lh) * t[k] + lh * b[k];
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             int w0, w1; float lw;
             src_index(4 * ow4 + k, sw, W, w0, w1, lw);
-            const float top = (1.f - lw) * p0[w0] + lw * p0[w1], bot = (1.f - lw) * p1[w0] + lw * p1[w1];
-            o[k] = (1.f - lh) * top + lh * bot;
+            const int d0 = w0 - wl, d1 = w1 - wl;     // in 0 .. 3
+            const float a0 = d0 == 0 ? v[0] : d0 == 1 ? v[1] : d0 == 2 ? v[2] : v[3];
+            const float a1 = d1 == 0 ? v[0] : d1 == 1 ? v[1] : d1 == 2 ? v[2] : v[3];
+            o[k] = (1.f - lw) * a0 + lw * a1;
         }
-        *reinterpret_cast<f32x4*>(y + n * y_bs + (long)c * Ho * Wo + (long)oh * Wo + 4 * ow4) = o;
+        *reinterpret_cast<f32x4*>(yp + (long)oh * Wo + 4 * ow4) = o;
     }
 }
 
@@ -134,71 +149,68 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_vec_kernel(const float* __
 // loads), applies the column weights (<= 6 taps per source column, tables built once per workgroup), then the
 // row weights.  12 LDS reads + 12 FMAs per source pixel instead of 36 gathers + 12 index computations.
 constexpr int UB_TH = 16, UB_TW = 64, UB_RH = 2 * UB_TH + 4, UB_RW = 2 * UB_TW + 4;
+
+// weights of the (<= 6) destination candidates lo .. lo + 5 (lo = max(0, 2 i - 2)) of source index i
+__device__ __forceinline__ int up_bwd_weights(int i, int in_size, int out_size, float sc, float (&wt)[6]) {
+    const int lo = max(0, 2 * i - 2);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int a0, a1; float l;
+        wt[k] = 0.f;
+        if (i < in_size && lo + k < out_size) {
+            src_index(lo + k, sc, in_size, a0, a1, l);
+            if (a0 == i) wt[k] += 1.f - l;
+            if (a1 == i) wt[k] += l;
+        }
+    }
+    return lo;
+}
+
+// The window is stored de-interleaved (even / odd destination columns in separate arrays) so that both the 8-byte
+// global loads and the six-tap column pass touch consecutive LDS words per lane (the interleaved layout was 2-way
+// bank-conflicted on every access); the tap weights live in registers (a thread's source column, and its four source
+// rows, are fixed for the whole workgroup), not in LDS tables: 6 + 6 LDS reads per source pixel instead of 13 + 12.
 __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const float* __restrict__ dy, long dy_bs,
                                                                    float* __restrict__ dx, long dx_bs, int C, int H,
                                                                    int W, int tiles_w, int accumulate) {
-    __shared__ float tile[UB_RH][UB_RW + 1];
+    constexpr int HW2 = UB_RW / 2;                          // 66 column pairs
+    __shared__ float te[UB_RH][HW2 + 1], to[UB_RH][HW2 + 1];
     __shared__ float hp[UB_RH][UB_TW + 1];
-    __shared__ float whs[UB_TH][6], wws[UB_TW][6];
-    __shared__ int ohr[UB_TH], owr[UB_TW];
     const int Ho = 2 * H, Wo = 2 * W;
     const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     const int tid = threadIdx.x;
     const int h0 = (blockIdx.x / tiles_w) * UB_TH, w0 = (blockIdx.x % tiles_w) * UB_TW;
     const int plane = blockIdx.y, n = plane / C, c = plane - n * C;
-    const int R0 = 2 * h0 - 2, C0 = 2 * w0 - 2;            // destination window origin (may be -2)
-    // weight tables: destination candidates oh_lo .. oh_lo + 5 with floor(scale * dst) in {i - 1, i}
-    if (tid < UB_TH + UB_TW) {
-        const bool row = tid < UB_TH;
-        const int i = row ? h0 + tid : w0 + (tid - UB_TH);
-        const int in_size = row ? H : W, out_size = row ? Ho : Wo;
-        const float sc = row ? sh : sw;
-        const int lo = max(0, 2 * i - 2);
-        float wt[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            int a0, a1; float l;
-            wt[k] = 0.f;
-            if (i < in_size && lo + k < out_size) {
-                src_index(lo + k, sc, in_size, a0, a1, l);
-                if (a0 == i) wt[k] += 1.f - l;
-                if (a1 == i) wt[k] += l;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            if (row) whs[tid][k] = wt[k]; else wws[tid - UB_TH][k] = wt[k];
-        }
-        if (row) ohr[tid] = lo - R0; else owr[tid - UB_TH] = lo - C0;
-    }
-    // destination window -> LDS (zero outside the plane); window columns start even: float2 loads
+    const int R0 = 2 * h0 - 2, C0 = 2 * w0 - 2;            // destination window origin (may be -2, always even)
+    const int x = tid & 63, rq = tid >> 6;                  // this thread's source column / first source row
+    float wc[6];
+    const int oc = up_bwd_weights(w0 + x, W, Wo, sw, wc) - C0;      // first candidate column inside the window
+    // destination window -> LDS (zero outside the plane); 8-byte coalesced loads
     const float* g = dy + (long)n * dy_bs + (long)c * Ho * Wo;
-    for (int e = tid; e < UB_RH * (UB_RW / 2); e += 256) {
-        const int r = e / (UB_RW / 2), c2 = e - r * (UB_RW / 2);
+    for (int e = tid; e < UB_RH * HW2; e += 256) {
+        const int r = e / HW2, c2 = e - r * HW2;
         const int oh = R0 + r, ow = C0 + 2 * c2;
         float2 v = make_float2(0.f, 0.f);
         if (oh >= 0 && oh < Ho && ow >= 0 && ow < Wo) v = *reinterpret_cast<const float2*>(g + (long)oh * Wo + ow);
-        tile[r][2 * c2] = v.x; tile[r][2 * c2 + 1] = v.y;
+        te[r][c2] = v.x; to[r][c2] = v.y;
     }
     __syncthreads();
-    // column weights: hp[r][x] = sum_l ww[x][l] * tile[r][owr[x] + l]
-    for (int e = tid; e < UB_RH * UB_TW; e += 256) {
-        const int r = e >> 6, x = e & 63;
-        const int o = owr[x];
-        float a = 0.f;
+    // column pass: hp[r][x] = sum_l wc[l] * window[r][oc + l]; window column q lives in (q & 1 ? to : te)[r][q >> 1]
+    const int q0 = oc >> 1;                                 // oc is even: candidates start at max(0, 2 i - 2), C0 is even
+    for (int r = rq; r < UB_RH; r += 4)
+        hp[r][x] = wc[0] * te[r][q0] + wc[1] * to[r][q0] + wc[2] * te[r][q0 + 1] + wc[3] * to[r][q0 + 1] +
+                   wc[4] * te[r][q0 + 2] + wc[5] * to[r][q0 + 2];
+    __syncthreads();
 #pragma unroll
-        for (int l = 0; l < 6; ++l) a += wws[x][l] * tile[r][o + l];
-        hp[r][x] = a;
-    }
-    __syncthreads();
-    for (int e = tid; e < UB_TH * UB_TW; e += 256) {
-        const int r = e >> 6, x = e & 63;
+    for (int k4 = 0; k4 < UB_TH / 4; ++k4) {
+        const int r = rq + 4 * k4;
+        float wr[6];
+        const int o = up_bwd_weights(h0 + r, H, Ho, sh, wr) - R0;
         if (h0 + r < H && w0 + x < W) {
-            const int o = ohr[r];
             float a = 0.f;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) a += whs[r][k] * hp[o + k][x];
+            for (int k = 0; k < 6; ++k) a += wr[k] * hp[o + k][x];
             float* q = dx + (long)n * dx_bs + (long)c * H * W + (long)(h0 + r) * W + w0 + x;
             *q = accumulate ? (*q + a) : a;
         }
@@ -402,8 +414,10 @@ int aide_upsample2x_bilinear_fwd(const float* x, int64_t x_bs, float* y, int64_t
                                  int W, hipStream_t stream) {
     const long total = (long)N * C * 4 * H * W;
     if ((2 * W) % 4 == 0 && y_bs % 4 == 0) {
-        hipLaunchKernelGGL(upsample2x_fwd_vec_kernel, dim3(grid_for(total / 4)), dim3(256), 0, stream, x,
-                           (long)x_bs, y, (long)y_bs, C, H, W, total / 4);
+        const int per_plane4 = H * W;                       // (2H * 2W) / 4 float4 outputs per plane
+        const int gx = max(1, min((per_plane4 + 255) / 256, 64));
+        hipLaunchKernelGGL(upsample2x_fwd_vec_kernel, dim3(gx, N * C), dim3(256), 0, stream, x,
+                           (long)x_bs, y, (long)y_bs, C, H, W, per_plane4);
         return aide_launch_status();
     }
     hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
