@@ -63,10 +63,14 @@ struct BfArgs {
 };
 
 
-template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16, int TW>
-__global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) {
+// NW waves per workgroup: 4 (tile 32 / 64 co x 512 px, two workgroups per CU) or 8 (128 co x 512 px, one workgroup per
+// CU: the two co halves share ONE halo tile, which halves the input bytes through L1 and LDS per MFMA -- the fp32 input
+// stream, 59 B/clk/CU at full MFMA rate for the 64-co tile, is what bounds the deep layers)
+template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16, int TW, int NW>
+__global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs a) {
+    constexpr int NT = 64 * NW;                    // threads per workgroup
     constexpr unsigned ES = IN_BF16 ? 2u : 4u;     // bytes per input element
-    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WAVES_N = NW / WAVES_M;
     constexpr int TCO = 32 * WM * WAVES_M;
     // pixel tile = TH rows x TW columns (TW = 32 or 64): the WAVES_N * WN 32-pixel MFMA column blocks are laid out
     // CB = TW / 32 per image row.  The wide form reads 272-byte and writes 128 / 256-byte row pieces (fp32 / bf16
@@ -81,8 +85,8 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
     constexpr int BUF = XS + AS + 2;               // + 2 dump slots: idle staging lanes store there (no branches)
     constexpr int DUMP = XS + AS;
     constexpr int UX = 2 * (TH + 2) * NPR;         // pixel-pair units per stage
-    constexpr int NUX = (UX + 255) / 256;
-    constexpr int NUA = (AS + 255) / 256;
+    constexpr int NUX = (UX + NT - 1) / NT;
+    constexpr int NUA = (AS + NT - 1) / NT;
     constexpr int NOPA0 = (9 - NUX) < NUA ? (9 - NUX) : NUA;
     constexpr int APG = (NUA + NOPA0 - 1) / NOPA0;      // filter pieces per staging op
     constexpr int NOPA = (NUA + APG - 1) / APG;
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
     unsigned offX[NUX], ldsX[NUX];
 #pragma unroll
     for (int e = 0; e < NUX; ++e) {
-        const int u = tid + e * 256;
+        const int u = tid + e * NT;
         const int g = u / ((TH + 2) * NPR), rem = u - g * ((TH + 2) * NPR);
         const int row = rem / NPR, pr = rem - row * NPR;
         const int ih = h0 - 1 + row, iw = w0 - 2 + 2 * pr;
@@ -120,14 +124,14 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
         offX[e] = ok ? (unsigned)(g * 8 * HW + row * a.W + 2 * pr) * ES : BUF_OOB;
         ldsX[e] = u < UX ? (unsigned)(g * PLANE + row * BF_PITCH + 2 * pr) : (unsigned)DUMP;
     }
-    // filter pieces: piece v of a thread is 256 slots after piece v-1 = (256 / TCO) [tap][g] rows further on, a
+    // filter pieces: piece v of a thread is NT slots after piece v-1 = (NT / TCO) [tap][g] rows further on, a
     // wave-uniform distance that rides in the scalar offset; only the last (partial) piece needs its own mask
-    static_assert(256 % TCO == 0 || TCO == 256, "filter piece stride");
+    static_assert(NT % TCO == 0, "filter piece stride");
     const unsigned offA0 = (unsigned)((tid / TCO) * a.Cout + (tid % TCO)) * 16u;
-    const unsigned strideA = (unsigned)(256 / TCO) * (unsigned)a.Cout * 16u;
-    constexpr bool A_TAIL = (AS % 256) != 0;
-    const unsigned offAt = (tid + (NUA - 1) * 256 < AS) ? offA0 : BUF_OOB;
-    const unsigned ldsAt = (tid + (NUA - 1) * 256 < AS) ? (unsigned)(XS + tid + (NUA - 1) * 256) : (unsigned)DUMP;
+    const unsigned strideA = (unsigned)(NT / TCO) * (unsigned)a.Cout * 16u;
+    constexpr bool A_TAIL = (AS % NT) != 0;
+    const unsigned offAt = (tid + (NUA - 1) * NT < AS) ? offA0 : BUF_OOB;
+    const unsigned ldsAt = (tid + (NUA - 1) * NT < AS) ? (unsigned)(XS + tid + (NUA - 1) * NT) : (unsigned)DUMP;
     // chunks past the end of this split read through an empty descriptor (every load returns 0, no per-load select)
     const char* xbase = (const char*)a.x + ((long)n * a.x_bs + (long)(h0 - 1) * a.W + (w0 - 2)) * (long)ES;
     const uint16_t* wbase = a.wp + (long)co0 * 8;
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x3_bf16_kernel(const BfArgs a) 
 #pragma unroll
             for (int k = 0; k < APG; ++k) {
                 const int v = (op - NUX) * APG + k;
-                if (v < NUA) buf[(A_TAIL && v == NUA - 1) ? ldsAt : (unsigned)(XS + tid + v * 256)] = wr[v];
+                if (v < NUA) buf[(A_TAIL && v == NUA - 1) ? ldsAt : (unsigned)(XS + tid + v * NT)] = wr[v];
             }
         }
     };
@@ -397,14 +401,14 @@ __global__ __launch_bounds__(256) void bf16_pack_multi_kernel(const BfPackDesc* 
 // 64-column tiles wherever the width allows (ahead by 3-10 % on every layer of the sweep from W = 64 up)
 bool bf16_wide_tile(int W, int H) { return W >= 64 && W % 64 == 0; }
 
-template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16, int TW>
+template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16, int TW, int NW>
 int launch_bf16_t(BfArgs a, hipStream_t stream) {
-    constexpr int WAVES_N = 4 / WAVES_M, TCO = 32 * WM * WAVES_M, TH = WAVES_N * WN / (TW / 32);
+    constexpr int WAVES_N = NW / WAVES_M, TCO = 32 * WM * WAVES_M, TH = WAVES_N * WN / (TW / 32);
     constexpr int BUF = 2 * (TH + 2) * (TW + 4) + 18 * TCO + 2;
     constexpr int LDS_BYTES = 2 * BUF * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, TW>,
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, TW, NW>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
@@ -412,42 +416,49 @@ int launch_bf16_t(BfArgs a, hipStream_t stream) {
     a.tiles_h = (a.H + TH - 1) / TH;
     a.n_co_tiles = a.Cout / TCO;
     const long nb = (long)a.tiles_w * a.tiles_h * a.N * a.n_co_tiles * a.splitk;
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, TW>), dim3((unsigned)nb), dim3(256),
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, TW, NW>), dim3((unsigned)nb), dim3(64 * NW),
                        LDS_BYTES, stream, a);
     return aide_launch_status();
 }
 
-template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16>
+template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16, int NW>
 int launch_bf16_r(const BfArgs& a, hipStream_t stream) {
     static const int force = getenv("AIDE_BF16_TW") ? atoi(getenv("AIDE_BF16_TW")) : 0;     // probe switch
     const bool wide = force ? force == 64 : bf16_wide_tile(a.W, a.H);
-    if (wide && a.W % 64 == 0) return launch_bf16_t<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, 64>(a, stream);
-    return launch_bf16_t<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, 32>(a, stream);
+    if (wide && a.W % 64 == 0) return launch_bf16_t<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, 64, NW>(a, stream);
+    return launch_bf16_t<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, 32, NW>(a, stream);
 }
 
 // storage combinations: fp32 -> fp32 (stand-alone operator), fp32 -> bf16 (forward into a bf16 z), bf16 -> fp32
 // (dgrad from a bf16 dz); ragged channel counts only occur on the fp32 network inputs
-template <int WM, int WAVES_M, int WN, int OCC>
+template <int WM, int WAVES_M, int WN, int OCC, int NW>
 int launch_bf16(const BfArgs& a, int in_bf16, int out_bf16, hipStream_t stream) {
     if (in_bf16) {
         if (out_bf16 || (a.Cin & 15)) return AIDE_ERR_ARG;
-        return launch_bf16_r<WM, WAVES_M, WN, OCC, false, true, false>(a, stream);
+        return launch_bf16_r<WM, WAVES_M, WN, OCC, false, true, false, NW>(a, stream);
     }
     if (out_bf16)
-        return (a.Cin & 15) ? launch_bf16_r<WM, WAVES_M, WN, OCC, true, false, true>(a, stream)
-                            : launch_bf16_r<WM, WAVES_M, WN, OCC, false, false, true>(a, stream);
-    return (a.Cin & 15) ? launch_bf16_r<WM, WAVES_M, WN, OCC, true, false, false>(a, stream)
-                        : launch_bf16_r<WM, WAVES_M, WN, OCC, false, false, false>(a, stream);
+        return (a.Cin & 15) ? launch_bf16_r<WM, WAVES_M, WN, OCC, true, false, true, NW>(a, stream)
+                            : launch_bf16_r<WM, WAVES_M, WN, OCC, false, false, true, NW>(a, stream);
+    return (a.Cin & 15) ? launch_bf16_r<WM, WAVES_M, WN, OCC, true, false, false, NW>(a, stream)
+                        : launch_bf16_r<WM, WAVES_M, WN, OCC, false, false, false, NW>(a, stream);
 }
 
-// variant: 0 = 32 co x 16 rows x 32 columns, 1 = 64 co x 16 rows x 32 columns; both run two workgroups per CU.
-// (A 128 co x 8 rows tile, one workgroup per CU, lost to variant 1 on every layer of the 512x512 sweep -- 1.0-1.3x --
-// and is not instantiated.)
-int bf16_variant(int Cout) { return Cout % 64 == 0 ? 1 : 0; }
+// variant: 0 = 32 co, 1 = 64 co (4 waves, two workgroups per CU), 2 = 128 co (8 waves, one workgroup per CU, the two co
+// halves share the halo tile); pixel tile 512 = 16 rows x 32 or 8 rows x 64 columns.  (A 4-wave 128 co x 256 px tile at
+// one workgroup per CU lost 1.0-1.3x to variant 1 on every layer and was dropped.)
 long bf16_blocks(int variant, int N, int H, int W, int Cout) {
-    const int tco = variant == 1 ? 64 : 32;
+    const int tco = variant == 2 ? 128 : (variant == 1 ? 64 : 32);
     const int tw = (bf16_wide_tile(W, H) && W % 64 == 0) ? 64 : 32, th = 512 / tw;
     return (long)(W / tw) * ((H + th - 1) / th) * N * (Cout / tco);
+}
+// the 128-co tile needs one full round of workgroups (256) to pay: below that the 64-co tile has twice the blocks
+// (measured: 256->256 @64x64 x8 and smaller planes lose 5-10 % with the wide tile, everything above gains 4-10 %)
+int bf16_variant(int N, int H, int W, int Cout) {
+    static const int force = getenv("AIDE_BF16_V") ? atoi(getenv("AIDE_BF16_V")) : -1;     // probe switch
+    int v = Cout % 128 == 0 ? 2 : (Cout % 64 == 0 ? 1 : 0);
+    if (v == 2 && bf16_blocks(2, N, H, W, Cout) < 256) v = 1;
+    return (force >= 0 && force < v) ? force : v;
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient
@@ -460,15 +471,25 @@ struct BgArgs {
     int n_co_tiles, n_ci_tiles, splits, chunks_total, segs_w, bands_h;
 };
 
-constexpr int G_R = 4;                       // dz rows per stage
-constexpr int G_DZP = G_R * 4 + 1;           // slots per dz channel (odd: conflict-free b128 across channels)
-constexpr int G_XP = (G_R + 2) * 5 + 1;      // slots per x channel: 6 rows x 5 slots (columns -1 .. 38)
-constexpr int G_DZS = 64 * G_DZP;
-constexpr int G_BUF = G_DZS + 64 * G_XP + 1;   // slots per stage buffer (+ 1 dump slot for idle staging lanes)
+// R = image rows of dz per stage (4, or 2: half the staging registers -> two workgroups per CU)
+template <int R> struct GCfg {
+    static constexpr int DZP = R * 4 + 1;            // slots per dz channel (odd: conflict-free b128 across channels)
+    static constexpr int XP = (R + 2) * 5 + 1;       // slots per x channel: R + 2 rows x 5 slots (columns -1 .. 38)
+    static constexpr int DZS = 64 * DZP;
+    static constexpr int BUF = DZS + 64 * XP + 1;    // slots per stage buffer (+ 1 dump slot for idle staging lanes)
+    static constexpr int ND = R;                     // dz units per thread      (64 co x R rows x 4 blocks / 256)
+    static constexpr int NM = R + 2;                 // x main units per thread  (64 ci x (R + 2) rows x 4 slots / 256)
+    static constexpr int NE = (64 * (R + 2) + 255) / 256;      // x edge units per thread
+    static constexpr int NOPS = ND + NM + NE;
+    static constexpr int KS = 2 * R;                 // k-steps per stage
+};
+constexpr int G_RMIN = 2;
 
-template <bool DZ_BF16>
-__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs g) {
-    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * G_BUF slots
+template <int R, bool DZ_BF16>
+__global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel(const BgArgs g) {
+    using G = GCfg<R>;
+    constexpr int ND = G::ND, NM = G::NM, NE = G::NE, NOPS = G::NOPS, KS = G::KS;
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * G::BUF slots
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int half = lane >> 5, j = lane & 31;
     const int wco = wid >> 1, wci = wid & 1;
@@ -484,79 +505,84 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs
     const int c_end = min(c_begin + cps, g.chunks_total);
 
     // ---- staging descriptors ----
-    // dz: unit = (co, row, 8-pixel block): two 16-byte loads -> one slot
-    unsigned offD[4], ldsD[4];
+    // dz: unit = (co, row, 8-pixel block): 16 (bf16) or 2 x 16 (fp32) bytes -> one slot
+    unsigned offD[ND], ldsD[ND];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < ND; ++e) {
         const int u = tid + e * 256;
-        const int blk = u & 3, row = (u >> 2) & 3, co = u >> 4;
+        const int blk = u & 3, row = (u >> 2) % R, co = u / (4 * R);
         offD[e] = (co0 + co < g.Co) ? (unsigned)(co * HW + row * g.W + blk * 8) * (DZ_BF16 ? 2u : 4u) : BUF_OOB;
-        ldsD[e] = (unsigned)(co * G_DZP + row * 4 + blk);
+        ldsD[e] = (unsigned)(co * G::DZP + row * 4 + blk);
     }
-    // x main: unit = (ci, tile row, slot s): columns 8s-1 .. 8s+6 of the segment -> one slot
-    unsigned offM[6], ldsM[6], rowM[6];
+    // x main: unit = (ci, tile row, slot s): columns 8s-1 .. 8s+6 of the segment -> one slot.  flagM: bit 0 = top halo
+    // row, bit 1 = bottom halo row, bit 2 = the unit owns column -1 (zero padding when the segment starts the image row)
+    unsigned offM[NM], ldsM[NM], flagM[NM];
 #pragma unroll
-    for (int e = 0; e < 6; ++e) {
+    for (int e = 0; e < NM; ++e) {
         const int u = tid + e * 256;
         const int s = u & 3, rr = u >> 2;
-        const int row = rr % 6, ci = rr / 6;
+        const int row = rr % (R + 2), ci = rr / (R + 2);
         offM[e] = (ci0 + ci < g.Ci) ? (unsigned)(ci * HW + row * g.W + s * 8 + 1) * 4u : BUF_OOB;   // base = column -1
-        ldsM[e] = (unsigned)(G_DZS + ci * G_XP + row * 5 + s);
-        rowM[e] = (unsigned)row | (s == 0 ? 8u : 0u);
+        ldsM[e] = (unsigned)(G::DZS + ci * G::XP + row * 5 + s);
+        flagM[e] = (row == 0 ? 1u : 0u) | (row == R + 1 ? 2u : 0u) | (s == 0 ? 4u : 0u);
     }
     // x edge: unit = (ci, tile row): columns 31, 32 -> first dword of slot 4
-    unsigned offE[2], ldsE[2], rowE[2];
+    unsigned offE[NE], ldsE[NE], flagE[NE];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int u = tid + e * 256;
-        const int row = u % 6, ci = u / 6;
-        const bool ok = u < 64 * 6 && ci0 + ci < g.Ci;
+        const int row = u % (R + 2), ci = u / (R + 2);
+        const bool ok = u < 64 * (R + 2) && ci0 + ci < g.Ci;
         offE[e] = ok ? (unsigned)(ci * HW + row * g.W + 32) * 4u : BUF_OOB;
-        ldsE[e] = u < 64 * 6 ? (unsigned)(G_DZS + ci * G_XP + row * 5 + 4) : (unsigned)(G_BUF - 1);   // dump slot
-        rowE[e] = (unsigned)row;
+        ldsE[e] = u < 64 * (R + 2) ? (unsigned)(G::DZS + ci * G::XP + row * 5 + 4) : (unsigned)(G::BUF - 1);   // dump slot
+        flagE[e] = (row == 0 ? 1u : 0u) | (row == R + 1 ? 2u : 0u);
     }
 
-    f32x4 dr[4][2];
-    float me[6];
-    f32x4 mr[6][2];
-    float er[2][2];
-    // ops 0..3 = dz units, 4..9 = x main units, 10..11 = x edge units
-    auto fetch = [&](int op, int chunk) {
-        const bool has = chunk < c_end;
+    f32x4 dr[ND][2];
+    float me[NM];
+    f32x4 mr[NM][2];
+    float er[NE][2];
+    // Per-chunk scalars (descriptor bases, halo masks) are derived ONCE per stage -- the per-operation form of this
+    // (a scalar div/mod chain and a handful of selects in front of every load) made the kernel instruction-issue
+    // bound: 2.7 scalar + 4.1 vector instructions per MFMA (PMC), one wave per SIMD.  A chunk past the end of the
+    // split reads through empty descriptors; image-border rows / columns are one v_cndmask per unit.
+    __amdgpu_buffer_rsrc_t rsD, rsX;
+    unsigned edge_mask = 0;                      // bit 0: top row outside, 1: bottom row outside, 2: column -1 outside
+    bool right_ok = false;
+    auto set_chunk = [&](int chunk) {
+        const unsigned nrec = chunk < c_end ? BUF_OOB : 0u;
         const int seg = chunk % g.segs_w;
         const int t2 = chunk / g.segs_w;
         const int band = t2 % g.bands_h, n = t2 / g.bands_h;
-        const int h0 = band * G_R, w0 = seg * 32;
-        if (op < 4) {
-            const long eoff = (long)n * g.dz_bs + (long)co0 * HW + (long)h0 * g.W + w0;
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc((const char*)g.dz + eoff * (DZ_BF16 ? 2 : 4));
-            const unsigned off = has ? offD[op] : BUF_OOB;
-            dr[op][0] = buf_load_f32x4(rs, off, 0);                       // bf16: the 8 pixels of the slot as stored
-            if constexpr (!DZ_BF16) dr[op][1] = buf_load_f32x4(rs, off, 16);
-        } else if (op < 10) {
-            const int e = op - 4;
-            const __amdgpu_buffer_rsrc_t rs =
-                make_rsrc(g.x + (long)n * g.x_bs + (long)ci0 * HW + (long)(h0 - 1) * g.W + w0 - 1);
-            const int ih = h0 - 1 + (int)(rowM[e] & 7u);
-            const bool rowok = has && ih >= 0 && ih < g.H;
-            const unsigned off = rowok ? offM[e] : BUF_OOB;
-            const bool leftok = !(rowM[e] & 8u) || w0 > 0;        // column -1 of the image is zero padding
-            me[e] = buf_load_f32(rs, (leftok && off != BUF_OOB) ? off - 4u : BUF_OOB, 0);
-            mr[e][0] = buf_load_f32x4(rs, off, 0);
-            mr[e][1] = buf_load_f32x4(rs, off, 16);
+        const int h0 = band * R, w0 = seg * 32;
+        const long eoff = (long)n * g.dz_bs + (long)co0 * HW + (long)h0 * g.W + w0;
+        rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((const char*)g.dz + eoff * (DZ_BF16 ? 2 : 4)), 0, nrec,
+                                                0x00020000);
+        rsX = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(g.x + (long)n * g.x_bs + (long)ci0 * HW + (long)(h0 - 1) * g.W + w0 - 1), 0, nrec, 0x00020000);
+        edge_mask = (h0 == 0 ? 1u : 0u) | (h0 + R >= g.H ? 2u : 0u) | (w0 == 0 ? 4u : 0u);
+        right_ok = w0 + 32 < g.W;
+    };
+    // ops 0 .. ND-1 = dz units, then NM x main units, then NE x edge units
+    auto fetch = [&](int op) {
+        if (op < ND) {
+            dr[op][0] = buf_load_f32x4(rsD, offD[op], 0);                 // bf16: the 8 pixels of the slot as stored
+            if constexpr (!DZ_BF16) dr[op][1] = buf_load_f32x4(rsD, offD[op], 16);
+        } else if (op < ND + NM) {
+            const int e = op - ND;
+            const unsigned off = (flagM[e] & edge_mask & 3u) ? BUF_OOB : offM[e];
+            me[e] = buf_load_f32(rsX, ((flagM[e] & edge_mask & 4u) || off == BUF_OOB) ? BUF_OOB : off - 4u, 0);
+            mr[e][0] = buf_load_f32x4(rsX, off, 0);
+            mr[e][1] = buf_load_f32x4(rsX, off, 16);
         } else {
-            const int e = op - 10;
-            const __amdgpu_buffer_rsrc_t rs =
-                make_rsrc(g.x + (long)n * g.x_bs + (long)ci0 * HW + (long)(h0 - 1) * g.W + w0 - 1);
-            const int ih = h0 - 1 + (int)rowE[e];
-            const bool rowok = has && ih >= 0 && ih < g.H;
-            const unsigned off = rowok ? offE[e] : BUF_OOB;
-            er[e][0] = buf_load_f32(rs, off, 0);
-            er[e][1] = buf_load_f32(rs, (off != BUF_OOB && w0 + 32 < g.W) ? off + 4u : BUF_OOB, 0);
+            const int e = op - ND - NM;
+            const unsigned off = (flagE[e] & edge_mask) ? BUF_OOB : offE[e];
+            er[e][0] = buf_load_f32(rsX, off, 0);
+            er[e][1] = buf_load_f32(rsX, right_ok ? off + 4u : BUF_OOB, 0);
         }
     };
     auto put = [&](int op, u32x4* buf) {
-        if (op < 4) {
+        if (op < ND) {
             u32x4 s;
             if constexpr (DZ_BF16) {
                 s = __builtin_bit_cast(u32x4, dr[op][0]);
@@ -565,14 +591,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs
                 s[2] = pk_bf16(dr[op][1].x, dr[op][1].y); s[3] = pk_bf16(dr[op][1].z, dr[op][1].w);
             }
             buf[ldsD[op]] = s;
-        } else if (op < 10) {
-            const int e = op - 4;
+        } else if (op < ND + NM) {
+            const int e = op - ND;
             u32x4 s;
             s[0] = pk_bf16(me[e], mr[e][0].x);        s[1] = pk_bf16(mr[e][0].y, mr[e][0].z);
             s[2] = pk_bf16(mr[e][0].w, mr[e][1].x);   s[3] = pk_bf16(mr[e][1].y, mr[e][1].z);
             buf[ldsM[e]] = s;
         } else {
-            const int e = op - 10;
+            const int e = op - ND - NM;
             reinterpret_cast<unsigned*>(buf + ldsE[e])[0] = pk_bf16(er[e][0], er[e][1]);
         }
     };
@@ -583,45 +609,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    const int la = (wco * 32 + j) * G_DZP + half;
-    const int lb = G_DZS + (wci * 32 + j) * G_XP + half;
+    const int la = (wco * 32 + j) * G::DZP + half;
+    const int lb = G::DZS + (wci * 32 + j) * G::XP + half;
 
+    set_chunk(c_begin);
 #pragma unroll
-    for (int op = 0; op < 12; ++op) fetch(op, c_begin);
+    for (int op = 0; op < NOPS; ++op) fetch(op);
 #pragma unroll
-    for (int op = 0; op < 12; ++op) put(op, lds);
+    for (int op = 0; op < NOPS; ++op) put(op, lds);
+    set_chunk(c_begin + 1);
 #pragma unroll
-    for (int op = 0; op < 12; ++op) fetch(op, c_begin + 1);
+    for (int op = 0; op < NOPS; ++op) fetch(op);
     __syncthreads();
 
+    constexpr int OPK = (NOPS + KS - 1) / KS;        // staging ops per k-step
     int cur = 0;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        const u32x4* pa = lds + cur * G_BUF + la;
-        const u32x4* pb = lds + cur * G_BUF + lb;
-        u32x4* nxt = lds + (cur ^ 1) * G_BUF;
-        // operand registers of k-step ks + 1 are read from LDS while the MFMAs of k-step ks run (one wave per SIMD: an
-        // LDS round trip in front of every shift / MFMA group would otherwise be fully exposed)
-        bf16x8 afA, afB;
-        u32x4 wA[3][2], wB[3][2];
-        auto load_ops = [&](int ks, bf16x8& af, u32x4 (&wv)[3][2]) {
+        const u32x4* pa = lds + cur * G::BUF + la;
+        const u32x4* pb = lds + cur * G::BUF + lb;
+        u32x4* nxt = lds + (cur ^ 1) * G::BUF;
+        set_chunk(chunk + 2);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {             // k-step = (dz row r, 16-pixel half segment hs)
             const int r = ks >> 1, hs = ks & 1;
-            af = __builtin_bit_cast(bf16x8, pa[r * 4 + hs * 2]);
+            const bf16x8 af = __builtin_bit_cast(bf16x8, pa[r * 4 + hs * 2]);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                wv[kh][0] = pb[(r + kh) * 5 + hs * 2];
-                wv[kh][1] = pb[(r + kh) * 5 + hs * 2 + 1];
-            }
-        };
-        load_ops(0, afA, wA);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {              // k-step = (dz row r, 16-pixel half segment hs)
-            const bf16x8& af = (ks & 1) ? afB : afA;
-            u32x4 (&wv)[3][2] = (ks & 1) ? wB : wA;
-            if (ks + 1 < 8) { if (ks & 1) load_ops(ks + 1, afA, wA); else load_ops(ks + 1, afB, wB); }
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const u32x4 w0v = wv[kh][0];
-                const u32x4 w1v = wv[kh][1];
+                const u32x4 w0v = pb[(r + kh) * 5 + hs * 2];
+                const u32x4 w1v = pb[(r + kh) * 5 + hs * 2 + 1];
                 u32x4 s1, s2;
                 s1[0] = __builtin_amdgcn_alignbit(w0v[1], w0v[0], 16);
                 s1[1] = __builtin_amdgcn_alignbit(w0v[2], w0v[1], 16);
@@ -633,9 +648,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs
                 acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, s2), acc[kh * 3 + 2], 0, 0, 0);
             }
             // staging: chunk + 1 registers -> the other buffer, then re-issue their loads for chunk + 2
-            if (ks < 6) {
-                put(2 * ks, nxt);     fetch(2 * ks, chunk + 2);
-                put(2 * ks + 1, nxt); fetch(2 * ks + 1, chunk + 2);
+#pragma unroll
+            for (int k = 0; k < OPK; ++k) {
+                const int op = ks * OPK + k;
+                if (op < NOPS) { put(op, nxt); fetch(op); }
             }
             // in-order issue: spread the window reads, shifts and staging between the nine MFMAs of the k-step
 #pragma unroll
@@ -664,6 +680,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(const BgArgs
     }
 }
 
+template <int R, bool DZ_BF16>
+int launch_wgrad_bf16(BgArgs g, hipStream_t stream) {
+    constexpr int LDS_BYTES = 2 * GCfg<R>::BUF * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<R, DZ_BF16>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    g.bands_h = g.H / R;
+    g.chunks_total = g.N * g.segs_w * g.bands_h;
+    const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<R, DZ_BF16>), dim3((unsigned)nb), dim3(256), LDS_BYTES, stream, g);
+    return aide_launch_status();
+}
+
+// rows per stage: 2 = two workgroups per CU (probe switch AIDE_BF16_WG_R)
+int wgrad_bf16_rows() {
+    static const int r = getenv("AIDE_BF16_WG_R") ? atoi(getenv("AIDE_BF16_WG_R")) : 4;
+    return r == 2 ? 2 : 4;
+}
+
 }  // namespace
 
 extern "C" {
@@ -678,7 +716,7 @@ int aide_conv3x3_bf16_supported(int Cin, int H, int W, int Cout) {
 // split factor over 16-channel chunks for layers that cannot fill 256 CUs with pixel x channel tiles
 int aide_conv3x3_bf16_splitk(int N, int Cin, int H, int W, int Cout) {
     if (!aide_conv3x3_bf16_supported(Cin, H, W, Cout)) return 1;
-    const long nb = bf16_blocks(bf16_variant(Cout), N, H, W, Cout);
+    const long nb = bf16_blocks(bf16_variant(N, H, W, Cout), N, H, W, Cout);
     const int chunks = (Cin + 15) / 16;
     int s = 1;
     while (nb * s < 256 && s * 2 <= chunks / 4) s *= 2;
@@ -725,8 +763,11 @@ int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint1
         a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = accumulate;
     }
     int rc;
-    if (bf16_variant(Cout) == 1) rc = launch_bf16<2, 1, 4, 2>(a, x_bf16, kernel_out_bf16, stream);
-    else rc = launch_bf16<1, 1, 4, 2>(a, x_bf16, kernel_out_bf16, stream);
+    switch (bf16_variant(N, H, W, Cout)) {
+        case 2: rc = launch_bf16<2, 2, 4, 1, 8>(a, x_bf16, kernel_out_bf16, stream); break;
+        case 1: rc = launch_bf16<2, 1, 4, 2, 4>(a, x_bf16, kernel_out_bf16, stream); break;
+        default: rc = launch_bf16<1, 1, 4, 2, 4>(a, x_bf16, kernel_out_bf16, stream); break;
+    }
     if (rc != 0) return rc;
     if (splitk > 1) {
         const long total4 = (long)N * Cout * H * W / 4;
@@ -749,12 +790,12 @@ int aide_conv3x3_bf16(const float* x, int64_t x_bs, const uint16_t* u, const flo
 }
 
 int aide_conv3x3_wgrad_bf16_supported(int Co, int Ci, int H, int W) {
-    return Co % 32 == 0 && Ci % 32 == 0 && W % 32 == 0 && H % G_R == 0;
+    return Co % 32 == 0 && Ci % 32 == 0 && W % 32 == 0 && H % 4 == 0;
 }
 
 int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W) {
     const long tiles = (long)((Co + 63) / 64) * ((Ci + 63) / 64);
-    const long chunks = (long)N * (H / G_R) * (W / 32);
+    const long chunks = (long)N * (H / wgrad_bf16_rows()) * (W / 32);
     static const long target = getenv("AIDE_BF16_WG_TARGET") ? atol(getenv("AIDE_BF16_WG_TARGET")) : 256;   // probe
     long s = (target + tiles - 1) / tiles;       // one round of workgroups, one per CU (512 / 1024 measured 6 % / 16 % slower:
                                                  // twice the slab bytes for the fixed-order reduce, twice the prologues)
@@ -773,27 +814,15 @@ int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, co
                                   int N, int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
     if (!dz || !a || !dw || !ws || N <= 0 || !aide_conv3x3_wgrad_bf16_supported(Co, Ci, H, W)) return AIDE_ERR_ARG;
     if ((dz_bs % (dz_bf16 ? 8 : 4)) || (a_bs % 4)) return AIDE_ERR_ARG;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_BUF * 16);
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_BUF * 16);
-        attr_set = true;
-    }
     BgArgs g;
     g.dz = dz; g.x = a; g.slabs = ws; g.dz_bs = dz_bs; g.x_bs = a_bs;
     g.N = N; g.Co = Co; g.Ci = Ci; g.H = H; g.W = W;
     g.n_co_tiles = (Co + 63) / 64; g.n_ci_tiles = (Ci + 63) / 64;
-    g.segs_w = W / 32; g.bands_h = H / G_R;
-    g.chunks_total = N * g.segs_w * g.bands_h;
+    g.segs_w = W / 32;
     g.splits = aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W);
-    const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
-    if (dz_bf16)
-        hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel<true>, dim3((unsigned)nb), dim3(256), 2 * G_BUF * 16, stream, g);
-    else
-        hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel<false>, dim3((unsigned)nb), dim3(256), 2 * G_BUF * 16, stream, g);
-    const int rc = aide_launch_status();
+    int rc;
+    if (wgrad_bf16_rows() == 2) rc = dz_bf16 ? launch_wgrad_bf16<2, true>(g, stream) : launch_wgrad_bf16<2, false>(g, stream);
+    else rc = dz_bf16 ? launch_wgrad_bf16<4, true>(g, stream) : launch_wgrad_bf16<4, false>(g, stream);
     if (rc != 0) return rc;
     return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, stream);
 }

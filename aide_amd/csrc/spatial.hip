@@ -184,18 +184,46 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const float* 
     const int plane = blockIdx.y, n = plane / C, c = plane - n * C;
     const int R0 = 2 * h0 - 2, C0 = 2 * w0 - 2;            // destination window origin (may be -2, always even)
     const int x = tid & 63, rq = tid >> 6;                  // this thread's source column / first source row
-    float wc[6];
-    const int oc = up_bwd_weights(w0 + x, W, Wo, sw, wc) - C0;      // first candidate column inside the window
+    // tap-weight tables, built once per workgroup by 80 threads (every thread building its own cost more VALU time
+    // than the whole tile), then held in registers: a thread's column and its four rows never change
+    __shared__ float wtab[UB_TH + UB_TW][6];
+    __shared__ int otab[UB_TH + UB_TW];
+    if (tid < UB_TH + UB_TW) {
+        const bool row = tid < UB_TH;
+        float wt[6];
+        const int lo = row ? up_bwd_weights(h0 + tid, H, Ho, sh, wt) : up_bwd_weights(w0 + tid - UB_TH, W, Wo, sw, wt);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) wtab[tid][k] = wt[k];
+        otab[tid] = lo - (row ? R0 : C0);
+    }
     // destination window -> LDS (zero outside the plane); 8-byte coalesced loads
     const float* g = dy + (long)n * dy_bs + (long)c * Ho * Wo;
-    for (int e = tid; e < UB_RH * HW2; e += 256) {
+    // all ten loads of a thread are issued before the first LDS store (a load -> wait -> store loop exposed the full
+    // memory latency ten times per workgroup: 0.9 TB/s); out-of-plane elements read a clamped address and are zeroed
+    constexpr int NLD = (UB_RH * HW2 + 255) / 256;
+    float2 v[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = tid + k * 256;
         const int r = e / HW2, c2 = e - r * HW2;
         const int oh = R0 + r, ow = C0 + 2 * c2;
-        float2 v = make_float2(0.f, 0.f);
-        if (oh >= 0 && oh < Ho && ow >= 0 && ow < Wo) v = *reinterpret_cast<const float2*>(g + (long)oh * Wo + ow);
-        te[r][c2] = v.x; to[r][c2] = v.y;
+        const bool ok = e < UB_RH * HW2 && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
+        const float2 t = *reinterpret_cast<const float2*>(g + (ok ? (long)oh * Wo + ow : 0L));
+        v[k] = ok ? t : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = tid + k * 256;
+        if (e < UB_RH * HW2) {
+            const int r = e / HW2, c2 = e - r * HW2;
+            te[r][c2] = v[k].x; to[r][c2] = v[k].y;
+        }
     }
     __syncthreads();
+    float wc[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wc[k] = wtab[UB_TH + x][k];
+    const int oc = otab[UB_TH + x];                         // first candidate column inside the window
     // column pass: hp[r][x] = sum_l wc[l] * window[r][oc + l]; window column q lives in (q & 1 ? to : te)[r][q >> 1]
     const int q0 = oc >> 1;                                 // oc is even: candidates start at max(0, 2 i - 2), C0 is even
     for (int r = rq; r < UB_RH; r += 4)
@@ -206,7 +234,9 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const float* 
     for (int k4 = 0; k4 < UB_TH / 4; ++k4) {
         const int r = rq + 4 * k4;
         float wr[6];
-        const int o = up_bwd_weights(h0 + r, H, Ho, sh, wr) - R0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) wr[k] = wtab[r][k];     // wave-uniform: LDS broadcast
+        const int o = otab[r];
         if (h0 + r < H && w0 + x < W) {
             float a = 0.f;
 #pragma unroll
