@@ -145,9 +145,14 @@ class _Cover(object):
 
 
 class Plan(object):
-    def __init__(self, graph, params, n, h, w, device, training, precision='fp32'):
+    def __init__(self, graph, params, n, h, w, device, training, precision='fp32', groups=1):
         self.g, self.N, self.H, self.W, self.dev, self.training = graph, n, h, w, device, training
         self.precision = precision
+        # groups > 1: the batch is `groups` independent forwards of n / groups images stacked along N (forward only):
+        # convolutions / pooling / up-sampling run once over all of them, every BatchNorm takes its batch statistics
+        # and updates its running statistics per group, in order -- the semantics of `groups` sequential forwards
+        self.groups = groups
+        assert n % groups == 0
         bf16 = precision == 'bf16'
         self.pindex = {id(p): i for i, p in enumerate(params)}
         f32 = dict(device=device, dtype=torch.float32)
@@ -408,12 +413,25 @@ class Plan(object):
                 ops.dconv_small(st['t1'], m.conv2.weight, m.conv2.bias, st['t2'], dil)
                 ops.dconv_small(st['t2'], m.conv3.weight, m.conv3.bias, st['t3'], dil)
                 ops.pwconv_fwd(st['t3'], m.conv4.weight, m.conv4.bias, st['t4'])
-                ops.sa_gate_fwd(st['t4'], m.bn, self.training, st['stat'], st['gate'])
+                if self.training and self.groups > 1:
+                    mg = self.N // self.groups
+                    for gi in range(self.groups):
+                        ops.sa_gate_fwd(st['t4'][gi * mg:(gi + 1) * mg], m.bn, True, st['stat'],
+                                        st['gate'][gi * mg:(gi + 1) * mg])
+                else:
+                    ops.sa_gate_fwd(st['t4'], m.bn, self.training, st['stat'], st['gate'])
                 ops.sa_mul(st['gate'], y, self.view(st['dst']))
         return out
 
     def _bn_apply(self, st, bn):
-        if self.training:
+        if self.training and self.groups > 1:
+            m = self.N // self.groups
+            z, a = st['z'], self.view(st['dst'])
+            for gi in range(self.groups):
+                ops.bn_train_fwd(z[gi * m:(gi + 1) * m], a[gi * m:(gi + 1) * m], bn.weight, bn.bias, bn.eps, bn.momentum,
+                                 bn.running_mean, bn.running_var, bn.num_batches_tracked, st['mean'],
+                                 st['rstd'], st['scale'], st['shift'], self.bn_ws, True)
+        elif self.training:
             ops.bn_train_fwd(st['z'], self.view(st['dst']), bn.weight, bn.bias, bn.eps, bn.momentum,
                              bn.running_mean, bn.running_var, bn.num_batches_tracked, st['mean'],
                              st['rstd'], st['scale'], st['shift'], self.bn_ws, True)
@@ -425,6 +443,8 @@ class Plan(object):
     # ------------------------------------------------------------------ backward
     def backward(self, inputs, dlogits, flat, offsets, after_op=None):
         """flat: 1-D fp32 buffer receiving every parameter gradient at offsets[param index]."""
+        if self.groups > 1:
+            raise RuntimeError('aide_amd: a grouped forward is forward-only')
         if not self._bwd_ready:
             self._prepare_backward()
 
@@ -622,18 +642,45 @@ class Engine(object):
             self.graph = self.build_graph()
             self.plans = {}
 
-    def plan_for(self, inputs):
+    def plan_for(self, inputs, groups=1):
         self._refresh_params()
         x = inputs[0]
         n, _, h, w = x.shape
         if h % 16 or w % 16:
             raise RuntimeError('aide_amd: H and W must be multiples of 16 (got %dx%d)' % (h, w))
-        key = (n, h, w, x.device.index, bool(self.module.training), self._precision)
+        key = (n, h, w, x.device.index, bool(self.module.training), self._precision, groups)
         plan = self.plans.get(key)
         if plan is None:
-            plan = Plan(self.graph, self.params, n, h, w, x.device, bool(self.module.training), self._precision)
+            plan = Plan(self.graph, self.params, n, h, w, x.device, bool(self.module.training), self._precision,
+                        groups)
             self.plans[key] = plan
         return plan
+
+    def run_groups(self, input_groups):
+        """[net(*inputs).detach() for inputs in input_groups] in ONE pass: the groups are stacked along N, every
+        convolution / pooling / up-sampling kernel runs once over all of them (4x the pixels per launch: the deep
+        layers need no split-K and fill the chip), every BatchNorm normalises and updates its running statistics per
+        group, in order -- exactly what the sequential forwards of the co-teaching loop's augmentation passes do
+        (trainchaos_proposed_30cases1labeled.py:265-269).  Forward only (no autograd graph)."""
+        groups = len(input_groups)
+        nin = len(input_groups[0])
+        ins = []
+        for k in range(nin):
+            xs = [grp[k] for grp in input_groups]
+            for x in xs:
+                if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+                    raise RuntimeError('aide_amd: inputs must be fp32 NCHW tensors on a HIP device')
+                if x.shape != xs[0].shape:
+                    raise RuntimeError('aide_amd: grouped forward needs equal input shapes')
+            ins.append(torch.cat([x.detach() for x in xs], 0))
+        with torch.no_grad():
+            plan = self.plan_for(ins, groups)
+            plan.profiler = self.profiler
+            n, _, h, w = ins[0].shape
+            out = torch.empty(n, self.num_classes, h, w, device=ins[0].device, dtype=torch.float32)
+            plan.forward(ins, out)
+        m = n // groups
+        return [out[g * m:(g + 1) * m] for g in range(groups)]
 
     def run(self, *inputs):
         ins = []

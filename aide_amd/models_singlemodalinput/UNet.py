@@ -61,6 +61,11 @@ class UNet(nn.Module):
     def forward(self, x):
         return self.engine.run(x)
 
+    def forward_groups(self, input_groups):
+        """[self(*inputs).detach() for inputs in input_groups] in one pass over the stacked batch (BatchNorm statistics
+        per group, in order); see Engine.run_groups.  Extension for the co-teaching loop's augmentation forwards."""
+        return self.engine.run_groups([tuple(g) if isinstance(g, (tuple, list)) else (g,) for g in input_groups])
+
 
 class UNetsa(UNet):
     """models_singlemodalinput/UNet.py:168-208: UNet with a Spatial_Attention gate after every down block."""

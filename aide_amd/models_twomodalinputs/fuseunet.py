@@ -83,6 +83,11 @@ class fuseunet(nn.Module):
     def forward(self, modal1_inputs, modal2_inputs):
         return self.engine.run(modal1_inputs, modal2_inputs)
 
+    def forward_groups(self, input_groups):
+        """[self(*inputs).detach() for inputs in input_groups] in one pass over the stacked batch (BatchNorm statistics
+        per group, in order); see Engine.run_groups.  Extension for the co-teaching loop's augmentation forwards."""
+        return self.engine.run_groups([tuple(g) if isinstance(g, (tuple, list)) else (g,) for g in input_groups])
+
 
 class fuseunetsa(fuseunet):
     """models_twomodalinputs/fuseunet.py:93-221: fuseunet with a Spatial_Attention gate after every down block of both

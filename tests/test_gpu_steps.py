@@ -119,3 +119,33 @@ def test_rccl_gradient_allreduce_single_rank(dev):
             assert torch.equal(a, p.grad)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['fuseunet', 'unetsa'])
+def test_grouped_forward_equals_sequential(dev, kind):
+    """net.forward_groups([...]) (one stacked pass, per-group BatchNorm statistics) == the sequential train-mode forwards
+    of the augmentation loop (trainchaos_proposed_30cases1labeled.py:265-269): outputs, running statistics,
+    num_batches_tracked.  (Convolutions over 4x the pixels may pick another split-K plan: 2e-5, not bitwise.)"""
+    import copy
+    from aide_amd.models_twomodalinputs import fuseunet
+    from aide_amd.models_singlemodalinput import UNetsa
+    torch.manual_seed(2)
+    net = (fuseunet(2) if kind == 'fuseunet' else UNetsa(2)).to(dev)
+    ref = copy.deepcopy(net)
+    g = torch.Generator().manual_seed(5)
+    nin = 2 if kind == 'fuseunet' else 1
+    groups = [tuple(torch.randn(2, 3, 32, 48, generator=g).to(dev) for _ in range(nin)) for _ in range(4)]
+    net.train(); ref.train()
+    seq = [ref(*grp).detach() for grp in groups]
+    outs = net.forward_groups(groups)
+    assert len(outs) == 4
+    for a, b in zip(outs, seq):
+        assert not a.requires_grad
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    for (k, p), (_, q) in zip(net.named_buffers(), ref.named_buffers()):
+        if 'num_batches_tracked' in k:
+            assert int(p) == int(q) == 4
+        else:
+            assert (p - q).abs().max().item() <= 2e-5 * (q.abs().max().item() + 1e-6), k
+    with pytest.raises(RuntimeError):
+        net.forward_groups([groups[0], tuple(t[:1] for t in groups[1])])
