@@ -225,8 +225,9 @@ def main():
                 dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
                 a = dom[1]
                 traffic = None
-                tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-                if args.workload == 'c2' and os.path.exists(tpath):
+                tpath = os.path.join(ROOT, 'profiles', {'c2': 'r01_traffic.json', 'c5': 'r01_traffic_c5.json'}.get(
+                    args.workload, 'none'))
+                if os.path.exists(tpath):
                     # PMC counters cannot be read from inside this process: the per-launch HBM bytes of
                     # this kernel family come from the committed rocprofv3 --pmc passes (profiles/)
                     traffic = json.load(open(tpath)).get(dom[0], {}).get('hbm_bytes_per_launch')

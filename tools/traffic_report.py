@@ -1,5 +1,5 @@
 """HBM traffic per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
-usage: traffic_report.py <fetch counter_collection.csv> <write counter_collection.csv> <steps run> <out.md> <out.json>
+usage: traffic_report.py <fetch counter_collection.csv> <write counter_collection.csv> <steps run> <out.md> <out.json> [title]
 Units: counters are KB; FETCH_SIZE is x2-corrected for 16 B/lane reads (MI355X_MICROARCH.md, HBM section; calibrated
 on adam_kernel below)."""
 import csv, sys, re, json, collections
@@ -23,9 +23,12 @@ F, W = load(fetch_csv, 'FETCH_SIZE'), load(write_csv, 'WRITE_SIZE')
 fam = {'conv3x3_wino4_kernel': ('conv3x3_wino4_kernel', 'w4_splitk_reduce_kernel'),
        'conv3x3_wino_kernel': ('conv3x3_wino_kernel', 'wino_splitk_reduce_kernel'),
        'conv3x3_mfma_kernel': ('conv3x3_mfma_kernel', '`splitk_reduce_kernel'),
-       'conv3x3_wgrad4_kernel': ('conv3x3_wgrad4_kernel',)}
+       'conv3x3_wgrad4_kernel': ('conv3x3_wgrad4_kernel',),
+       'conv3x3_bf16_kernel': ('conv3x3_bf16_kernel', 'bf16_splitk_reduce_kernel'),
+       'conv3x3_wgrad_bf16_kernel': ('conv3x3_wgrad_bf16_kernel',)}
 main = {k: v[0] for k, v in fam.items()}
-lines = ['# HBM traffic per kernel, FuseUNet C2 step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)', '',
+title = sys.argv[6] if len(sys.argv) > 6 else 'FuseUNet C2 step'
+lines = ['# HBM traffic per kernel, ' + title + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)', '',
          'Raw counter units are KB. FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads on gfx950',
          '(MI355X_MICROARCH.md, HBM section): the x2 column applies that correction; adam_kernel (20 B/param read, 16 B/param',
          'written, 26.68 M params = 533.5 / 426.8 MB) is the calibration row.', '',
