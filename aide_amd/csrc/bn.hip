@@ -79,9 +79,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const ZT* __restrict__ z,
 // partials (one wave, <= 64 splits) and applies a = relu(z*scale + shift); the (x == 0, n == 0) block
 // of each channel also publishes mean / rstd / scale / shift and updates the running statistics.
 // (Folding the finalize step in here removes one ~5 us launch per BatchNorm.)
-template <int V, typename ZT>
+template <int V, typename ZT, typename AT>
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(
-    const ZT* __restrict__ z, long z_bs, float* __restrict__ a, long a_bs, int C, int HW,
+    const ZT* __restrict__ z, long z_bs, AT* __restrict__ a, long a_bs, int C, int HW,
     const double* __restrict__ partials, int splits, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
     float* __restrict__ running_var, long long* __restrict__ nbt, float* __restrict__ mean_out,
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(
     __syncthreads();
     const float sc = coef[0], sh = coef[1];
     const ZT* zp = z + (long)n * z_bs + (long)c * HW;
-    float* ap = a + (long)n * a_bs + (long)c * HW;
+    AT* ap = a + (long)n * a_bs + (long)c * HW;
     const int hw4 = HW / V;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < hw4; i += gridDim.x * 256) {
         float v[V];
@@ -146,16 +146,16 @@ __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, con
 }
 
 // ---------------------------------------------------------------- a = relu(z*scale + shift)
-template <int V, typename ZT>
+template <int V, typename ZT, typename AT>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ZT* __restrict__ z, long z_bs,
-                                                            float* __restrict__ a, long a_bs, int C, int HW,
+                                                            AT* __restrict__ a, long a_bs, int C, int HW,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu) {
     const int plane = blockIdx.y;                 // n*C + c
     const int n = plane / C, c = plane - n * C;
     const float sc = scale[c], sh = shift[c];
     const ZT* zp = z + (long)n * z_bs + (long)c * HW;
-    float* ap = a + (long)n * a_bs + (long)c * HW;
+    AT* ap = a + (long)n * a_bs + (long)c * HW;
     const int hw4 = HW / V;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < hw4; i += gridDim.x * 256) {
         float v[V];
@@ -276,9 +276,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // the values are read ONCE into registers (<= 16 float4 per thread), reduced in fp64 in a fixed order, and
 // normalised from the registers.  Saves a launch (~4.5 us) and one pass over the tensor per BatchNorm and direction.
 constexpr int BN_FQ = 16;
-template <typename ZT>
+template <typename ZT, typename AT>
 __global__ __launch_bounds__(256) void bn_train_fused_kernel(
-    const ZT* __restrict__ z, long z_bs, float* __restrict__ a, long a_bs, int N, int HW, double count,
+    const ZT* __restrict__ z, long z_bs, AT* __restrict__ a, long a_bs, int N, int HW, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ scale_out,
@@ -325,10 +325,10 @@ __global__ __launch_bounds__(256) void bn_train_fused_kernel(
         const int i = threadIdx.x + k * 256;
         if (i < total4) {
             const int n = i / hw4, p = i - n * hw4;
-            f32x4 o;
+            float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float y = fmaf(v[k][e], sc, sh); o[e] = relu ? fmaxf(y, 0.0f) : y; }
-            *reinterpret_cast<f32x4*>(a + (long)n * a_bs + (long)c * HW + p * 4) = o;
+            stv<4>(a + (long)n * a_bs + (long)c * HW + p * 4, o);
         }
     }
 }
@@ -411,8 +411,8 @@ size_t aide_bn_ws_bytes(int C) { return (size_t)C * 64 * 3 * sizeof(double); }
 
 namespace {
 
-template <typename ZT>
-int bn_train_fwd_t(const ZT* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
+template <typename ZT, typename AT>
+int bn_train_fwd_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C, int H, int W,
                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
                    float* scale, float* shift, int relu, void* ws, hipStream_t stream) {
@@ -424,33 +424,33 @@ int bn_train_fwd_t(const ZT* z, int64_t z_bs, float* a, int64_t a_bs, int N, int
     const double count = (double)N * HW;
     const int gx = max(1, min((HW / (v4 ? 4 : 1) + 255) / 256, 16));
     if (v4 && bn_fused_ok(N, C, HW)) {
-        hipLaunchKernelGGL(bn_train_fused_kernel<ZT>, dim3(C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, N, HW, count,
+        hipLaunchKernelGGL((bn_train_fused_kernel<ZT, AT>), dim3(C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, N, HW, count,
                            gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd,
                            scale, shift, relu);
         return aide_launch_status();
     }
     if (v4) {
         hipLaunchKernelGGL((bn_stats_kernel<4, ZT>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
-        hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+        hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
                            num_batches_tracked, mean, rstd, scale, shift, relu);
     } else {
         hipLaunchKernelGGL((bn_stats_kernel<1, ZT>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
-        hipLaunchKernelGGL((bn_train_apply_kernel<1, ZT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+        hipLaunchKernelGGL((bn_train_apply_kernel<1, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
                            num_batches_tracked, mean, rstd, scale, shift, relu);
     }
     return aide_launch_status();
 }
 
-template <typename ZT>
-int bn_relu_apply_t(const ZT* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
+template <typename ZT, typename AT>
+int bn_relu_apply_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C, int H, int W,
                     const float* scale, const float* shift, int relu, hipStream_t stream) {
     const int HW = H * W;
     const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && a_bs % 4 == 0;
     const int gx = max(1, min((HW / (v4 ? 4 : 1) + 255) / 256, 16));
-    if (v4) hipLaunchKernelGGL((bn_relu_apply_kernel<4, ZT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
-    else hipLaunchKernelGGL((bn_relu_apply_kernel<1, ZT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
+    if (v4) hipLaunchKernelGGL((bn_relu_apply_kernel<4, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
+    else hipLaunchKernelGGL((bn_relu_apply_kernel<1, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
     return aide_launch_status();
 }
 
@@ -490,27 +490,30 @@ int aide_bn_train_fwd(const float* z, int64_t z_bs, float* a, int64_t a_bs, int 
                       const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                       float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
                       float* scale, float* shift, int relu, void* ws, hipStream_t stream) {
-    return bn_train_fwd_t<float>(z, z_bs, a, a_bs, N, C, H, W, gamma, beta, eps, momentum, running_mean, running_var,
-                                 num_batches_tracked, mean, rstd, scale, shift, relu, ws, stream);
+    return bn_train_fwd_t<float, float>(z, z_bs, a, a_bs, N, C, H, W, gamma, beta, eps, momentum, running_mean,
+                                        running_var, num_batches_tracked, mean, rstd, scale, shift, relu, ws, stream);
 }
 
 // the same operators on bf16-stored conv outputs / conv-output gradients (precision='bf16'); z_bf16 / dz_bf16 select
 // the storage type of the untyped pointers, everything else is unchanged
-int aide_bn_train_fwd_mixed(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
-                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                            float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
-                            float* scale, float* shift, int relu, void* ws, hipStream_t stream) {
-    if (z_bf16)
-        return bn_train_fwd_t<bf16_t>((const bf16_t*)z, z_bs, a, a_bs, N, C, H, W, gamma, beta, eps, momentum, running_mean,
-                                      running_var, num_batches_tracked, mean, rstd, scale, shift, relu, ws, stream);
-    return bn_train_fwd_t<float>((const float*)z, z_bs, a, a_bs, N, C, H, W, gamma, beta, eps, momentum, running_mean,
-                                 running_var, num_batches_tracked, mean, rstd, scale, shift, relu, ws, stream);
+int aide_bn_train_fwd_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
+                            int H, int W, const float* gamma, const float* beta, float eps, float momentum,
+                            float* running_mean, float* running_var, long long* num_batches_tracked, float* mean,
+                            float* rstd, float* scale, float* shift, int relu, void* ws, hipStream_t stream) {
+#define AIDE_BN_FWD(ZT, AT) bn_train_fwd_t<ZT, AT>((const ZT*)z, z_bs, (AT*)a, a_bs, N, C, H, W, gamma, beta, eps, momentum, \
+                                                   running_mean, running_var, num_batches_tracked, mean, rstd, scale,      \
+                                                   shift, relu, ws, stream)
+    if (z_bf16) return a_bf16 ? AIDE_BN_FWD(bf16_t, bf16_t) : AIDE_BN_FWD(bf16_t, float);
+    return a_bf16 ? AIDE_BN_FWD(float, bf16_t) : AIDE_BN_FWD(float, float);
+#undef AIDE_BN_FWD
 }
 
-int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
-                             const float* scale, const float* shift, int relu, hipStream_t stream) {
-    if (z_bf16) return bn_relu_apply_t<bf16_t>((const bf16_t*)z, z_bs, a, a_bs, N, C, H, W, scale, shift, relu, stream);
-    return bn_relu_apply_t<float>((const float*)z, z_bs, a, a_bs, N, C, H, W, scale, shift, relu, stream);
+int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
+                             int H, int W, const float* scale, const float* shift, int relu, hipStream_t stream) {
+#define AIDE_BN_APPLY(ZT, AT) bn_relu_apply_t<ZT, AT>((const ZT*)z, z_bs, (AT*)a, a_bs, N, C, H, W, scale, shift, relu, stream)
+    if (z_bf16) return a_bf16 ? AIDE_BN_APPLY(bf16_t, bf16_t) : AIDE_BN_APPLY(bf16_t, float);
+    return a_bf16 ? AIDE_BN_APPLY(float, bf16_t) : AIDE_BN_APPLY(float, float);
+#undef AIDE_BN_APPLY
 }
 
 int aide_bn_relu_bwd_mixed(const float* dA, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz, int dz_bf16,
@@ -533,7 +536,7 @@ int aide_bn_eval_coeff(int C, const float* gamma, const float* beta, const float
 
 int aide_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
                        const float* scale, const float* shift, int relu, hipStream_t stream) {
-    return bn_relu_apply_t<float>(z, z_bs, a, a_bs, N, C, H, W, scale, shift, relu, stream);
+    return bn_relu_apply_t<float, float>(z, z_bs, a, a_bs, N, C, H, W, scale, shift, relu, stream);
 }
 
 // Backward of relu(bn(z)): dA -> dz, dgamma, dbeta, and the (mathematically zero) conv-bias grad.

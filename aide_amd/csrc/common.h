@@ -31,6 +31,37 @@ __device__ __forceinline__ f32x4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, unsign
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+// ---- bf16-stored activations (precision='bf16'): typed vector loads / stores.  Widening is exact, narrowing is
+// round-to-nearest-even (v_cvt_pk_bf16_f32).  T = float or bf16_store_t.
+typedef uint16_t bf16_store_t;
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float bf16_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const bf16_store_t* p) {
+    const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+    return f32x4{bf16_lo(v[0]), bf16_hi(v[0]), bf16_lo(v[1]), bf16_hi(v[1])};
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_store_t* p, f32x4 v) {
+    *reinterpret_cast<u32x2*>(p) = u32x2{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+}
+__device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+__device__ __forceinline__ f32x2 ld2(const bf16_store_t* p) {
+    const unsigned v = *reinterpret_cast<const unsigned*>(p);
+    return f32x2{bf16_lo(v), bf16_hi(v)};
+}
+__device__ __forceinline__ void st2(float* p, f32x2 v) { *reinterpret_cast<f32x2*>(p) = v; }
+__device__ __forceinline__ void st2(bf16_store_t* p, f32x2 v) { *reinterpret_cast<unsigned*>(p) = cvt_pk_bf16(v[0], v[1]); }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_store_t* p) { return __builtin_bit_cast(float, (unsigned)*p << 16); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_store_t* p, float v) { *p = (bf16_store_t)(cvt_pk_bf16(v, 0.f) & 0xffffu); }
+
 static inline int aide_launch_status() { return (int)hipGetLastError(); }
 
 // XCD-aware bijective remap of a 1-D block id: the hardware dispatches block b to XCD b % 8;

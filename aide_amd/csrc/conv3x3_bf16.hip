@@ -429,13 +429,15 @@ int launch_bf16_r(const BfArgs& a, hipStream_t stream) {
     return launch_bf16_t<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, 32, NW>(a, stream);
 }
 
-// storage combinations: fp32 -> fp32 (stand-alone operator), fp32 -> bf16 (forward into a bf16 z), bf16 -> fp32
-// (dgrad from a bf16 dz); ragged channel counts only occur on the fp32 network inputs
+// storage combinations: fp32 -> fp32 (stand-alone operator), fp32 -> bf16 (forward from an fp32 tensor into a bf16 z),
+// bf16 -> bf16 (forward from a bf16-stored activation), bf16 -> fp32 (dgrad from a bf16 dz); ragged channel counts
+// only occur on the fp32 network inputs
 template <int WM, int WAVES_M, int WN, int OCC, int NW>
 int launch_bf16(const BfArgs& a, int in_bf16, int out_bf16, hipStream_t stream) {
-    if (in_bf16) {
-        if (out_bf16 || (a.Cin & 15)) return AIDE_ERR_ARG;
-        return launch_bf16_r<WM, WAVES_M, WN, OCC, false, true, false, NW>(a, stream);
+    if (in_bf16) {                      // bf16-stored activations (forward) or conv-output gradients (dgrad)
+        if (a.Cin & 15) return AIDE_ERR_ARG;
+        return out_bf16 ? launch_bf16_r<WM, WAVES_M, WN, OCC, false, true, true, NW>(a, stream)
+                        : launch_bf16_r<WM, WAVES_M, WN, OCC, false, true, false, NW>(a, stream);
     }
     if (out_bf16)
         return (a.Cin & 15) ? launch_bf16_r<WM, WAVES_M, WN, OCC, true, false, true, NW>(a, stream)
@@ -464,7 +466,7 @@ int bf16_variant(int N, int H, int W, int Cout) {
 // ------------------------------------------------------------------------------------------ weight gradient
 struct BgArgs {
     const void* dz;           // fp32, or bf16 when DZ_BF16
-    const float* x;
+    const void* x;            // fp32, or bf16 when X_BF16 (bf16-stored activations)
     float* slabs;
     long dz_bs, x_bs;
     int N, Co, Ci, H, W;
@@ -485,8 +487,9 @@ template <int R> struct GCfg {
 };
 constexpr int G_RMIN = 2;
 
-template <int R, bool DZ_BF16>
+template <int R, bool DZ_BF16, bool X_BF16>
 __global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel(const BgArgs g) {
+    constexpr unsigned XE = X_BF16 ? 2u : 4u;        // bytes per x element
     using G = GCfg<R>;
     constexpr int ND = G::ND, NM = G::NM, NE = G::NE, NOPS = G::NOPS, KS = G::KS;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * G::BUF slots
@@ -522,7 +525,9 @@ __global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel
         const int u = tid + e * 256;
         const int s = u & 3, rr = u >> 2;
         const int row = rr % (R + 2), ci = rr / (R + 2);
-        offM[e] = (ci0 + ci < g.Ci) ? (unsigned)(ci * HW + row * g.W + s * 8 + 1) * 4u : BUF_OOB;   // base = column -1
+        // fp32: descriptor base = column -1, the unit's 16-byte loads start at column 8s; bf16: base = column -2 (the
+        // (8s-2, 8s-1) pair is one aligned dword), the unit's 16-byte load starts at column 8s
+        offM[e] = (ci0 + ci < g.Ci) ? (unsigned)(ci * HW + row * g.W + s * 8 + (X_BF16 ? 2 : 1)) * XE : BUF_OOB;
         ldsM[e] = (unsigned)(G::DZS + ci * G::XP + row * 5 + s);
         flagM[e] = (row == 0 ? 1u : 0u) | (row == R + 1 ? 2u : 0u) | (s == 0 ? 4u : 0u);
     }
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel
         const int u = tid + e * 256;
         const int row = u % (R + 2), ci = u / (R + 2);
         const bool ok = u < 64 * (R + 2) && ci0 + ci < g.Ci;
-        offE[e] = ok ? (unsigned)(ci * HW + row * g.W + 32) * 4u : BUF_OOB;
+        offE[e] = ok ? (unsigned)(ci * HW + row * g.W + 32) * XE : BUF_OOB;   // fp32: column 31 (base = column -1); bf16: pair (30, 31) (base = column -2)
         ldsE[e] = u < 64 * (R + 2) ? (unsigned)(G::DZS + ci * G::XP + row * 5 + 4) : (unsigned)(G::BUF - 1);   // dump slot
         flagE[e] = (row == 0 ? 1u : 0u) | (row == R + 1 ? 2u : 0u);
     }
@@ -558,8 +563,8 @@ __global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel
         const long eoff = (long)n * g.dz_bs + (long)co0 * HW + (long)h0 * g.W + w0;
         rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((const char*)g.dz + eoff * (DZ_BF16 ? 2 : 4)), 0, nrec,
                                                 0x00020000);
-        rsX = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(g.x + (long)n * g.x_bs + (long)ci0 * HW + (long)(h0 - 1) * g.W + w0 - 1), 0, nrec, 0x00020000);
+        const long xoff = (long)n * g.x_bs + (long)ci0 * HW + (long)(h0 - 1) * g.W + w0 - (X_BF16 ? 2 : 1);
+        rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((const char*)g.x + xoff * (long)XE), 0, nrec, 0x00020000);
         edge_mask = (h0 == 0 ? 1u : 0u) | (h0 + R >= g.H ? 2u : 0u) | (w0 == 0 ? 4u : 0u);
         right_ok = w0 + 32 < g.W;
     };
@@ -572,11 +577,12 @@ __global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel
             const int e = op - ND;
             const unsigned off = (flagM[e] & edge_mask & 3u) ? BUF_OOB : offM[e];
             me[e] = buf_load_f32(rsX, ((flagM[e] & edge_mask & 4u) || off == BUF_OOB) ? BUF_OOB : off - 4u, 0);
-            mr[e][0] = buf_load_f32x4(rsX, off, 0);
-            mr[e][1] = buf_load_f32x4(rsX, off, 16);
+            mr[e][0] = buf_load_f32x4(rsX, off, 0);              // bf16: columns 8s .. 8s+7 as stored, me = pair (8s-2, 8s-1)
+            if constexpr (!X_BF16) mr[e][1] = buf_load_f32x4(rsX, off, 16);
         } else {
             const int e = op - ND - NM;
             const unsigned off = (flagE[e] & edge_mask) ? BUF_OOB : offE[e];
+            // fp32: columns 31 and 32; bf16: the pairs (30, 31) and (32, 33)
             er[e][0] = buf_load_f32(rsX, off, 0);
             er[e][1] = buf_load_f32(rsX, right_ok ? off + 4u : BUF_OOB, 0);
         }
@@ -594,12 +600,23 @@ __global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel
         } else if (op < ND + NM) {
             const int e = op - ND;
             u32x4 s;
-            s[0] = pk_bf16(me[e], mr[e][0].x);        s[1] = pk_bf16(mr[e][0].y, mr[e][0].z);
-            s[2] = pk_bf16(mr[e][0].w, mr[e][1].x);   s[3] = pk_bf16(mr[e][1].y, mr[e][1].z);
+            if constexpr (X_BF16) {        // shift the stored pairs by one pixel: slot = columns 8s-1 .. 8s+6
+                const unsigned d = __builtin_bit_cast(unsigned, me[e]);
+                const u32x4 q = __builtin_bit_cast(u32x4, mr[e][0]);
+                s[0] = __builtin_amdgcn_alignbit(q[0], d, 16);    s[1] = __builtin_amdgcn_alignbit(q[1], q[0], 16);
+                s[2] = __builtin_amdgcn_alignbit(q[2], q[1], 16); s[3] = __builtin_amdgcn_alignbit(q[3], q[2], 16);
+            } else {
+                s[0] = pk_bf16(me[e], mr[e][0].x);        s[1] = pk_bf16(mr[e][0].y, mr[e][0].z);
+                s[2] = pk_bf16(mr[e][0].w, mr[e][1].x);   s[3] = pk_bf16(mr[e][1].y, mr[e][1].z);
+            }
             buf[ldsM[e]] = s;
         } else {
             const int e = op - ND - NM;
-            reinterpret_cast<unsigned*>(buf + ldsE[e])[0] = pk_bf16(er[e][0], er[e][1]);
+            if constexpr (X_BF16)          // (column 31 = high half of the first pair, column 32 = low half of the second)
+                reinterpret_cast<unsigned*>(buf + ldsE[e])[0] = __builtin_amdgcn_alignbit(
+                    __builtin_bit_cast(unsigned, er[e][1]), __builtin_bit_cast(unsigned, er[e][0]), 16);
+            else
+                reinterpret_cast<unsigned*>(buf + ldsE[e])[0] = pk_bf16(er[e][0], er[e][1]);
         }
     };
 
@@ -680,19 +697,19 @@ __global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel
     }
 }
 
-template <int R, bool DZ_BF16>
+template <int R, bool DZ_BF16, bool X_BF16>
 int launch_wgrad_bf16(BgArgs g, hipStream_t stream) {
     constexpr int LDS_BYTES = 2 * GCfg<R>::BUF * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<R, DZ_BF16>,
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<R, DZ_BF16, X_BF16>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
     g.bands_h = g.H / R;
     g.chunks_total = g.N * g.segs_w * g.bands_h;
     const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
-    hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<R, DZ_BF16>), dim3((unsigned)nb), dim3(256), LDS_BYTES, stream, g);
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<R, DZ_BF16, X_BF16>), dim3((unsigned)nb), dim3(256), LDS_BYTES, stream, g);
     return aide_launch_status();
 }
 
@@ -739,13 +756,13 @@ int aide_conv3x3_bf16_pack_multi(const void* descs, int n, int64_t total_blocks,
 
 // y (+)= conv3x3(x) with bf16-packed filters u (forward pack, or the dgrad pack with Cin/Cout swapped by the
 // caller).  x, y: NCHW with batch strides (elements), fp32 or -- x_bf16 / y_bf16 -- bf16 storage (the forward writing
-// a bf16 z, the dgrad reading a bf16 dz; bf16 -> bf16 and accumulation into a bf16 y are not provided).
+// a bf16 z from an fp32 or bf16-stored activation, the dgrad reading a bf16 dz; no accumulation into a bf16 y).
 // ws: split-K slabs (splitk * N*Cout*H*W floats).
 int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint16_t* u, const float* bias, void* y,
                             int y_bf16, int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,
                             float* ws, hipStream_t stream) {
     if (!x || !u || !y || N <= 0 || !aide_conv3x3_bf16_supported(Cin, H, W, Cout)) return AIDE_ERR_ARG;
-    if (y_bf16 && (accumulate || x_bf16)) return AIDE_ERR_ARG;
+    if (y_bf16 && accumulate) return AIDE_ERR_ARG;
     if ((x_bf16 && (x_bs % 2)) || (y_bf16 && (y_bs % 2))) return AIDE_ERR_ARG;
     BfArgs a;
     a.x = x; a.wp = u; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
@@ -808,12 +825,12 @@ size_t aide_conv3x3_wgrad_bf16_ws_bytes(int N, int Co, int Ci, int H, int W) {
     return (size_t)aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W) * 9 * Co * Ci * sizeof(float);
 }
 
-//   dz : [N][Co][H][W] (batch stride dz_bs; fp32, or bf16 storage when dz_bf16)   a : [N][Ci][H][W] fp32 (batch
-//   stride a_bs)   dw : [Co][Ci][3][3] fp32
-int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, const float* a, int64_t a_bs, float* dw,
-                                  int N, int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
+//   dz : [N][Co][H][W] (batch stride dz_bs; fp32, or bf16 storage when dz_bf16)   a : [N][Ci][H][W] (batch stride a_bs;
+//   fp32, or bf16 storage when a_bf16)   dw : [Co][Ci][3][3] fp32
+int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, const void* a, int a_bf16, int64_t a_bs,
+                                  float* dw, int N, int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
     if (!dz || !a || !dw || !ws || N <= 0 || !aide_conv3x3_wgrad_bf16_supported(Co, Ci, H, W)) return AIDE_ERR_ARG;
-    if ((dz_bs % (dz_bf16 ? 8 : 4)) || (a_bs % 4)) return AIDE_ERR_ARG;
+    if ((dz_bs % (dz_bf16 ? 8 : 4)) || (a_bs % (a_bf16 ? 8 : 4))) return AIDE_ERR_ARG;
     BgArgs g;
     g.dz = dz; g.x = a; g.slabs = ws; g.dz_bs = dz_bs; g.x_bs = a_bs;
     g.N = N; g.Co = Co; g.Ci = Ci; g.H = H; g.W = W;
@@ -821,15 +838,17 @@ int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, co
     g.segs_w = W / 32;
     g.splits = aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W);
     int rc;
-    if (wgrad_bf16_rows() == 2) rc = dz_bf16 ? launch_wgrad_bf16<2, true>(g, stream) : launch_wgrad_bf16<2, false>(g, stream);
-    else rc = dz_bf16 ? launch_wgrad_bf16<4, true>(g, stream) : launch_wgrad_bf16<4, false>(g, stream);
+#define AIDE_WG(RR) (dz_bf16 ? (a_bf16 ? launch_wgrad_bf16<RR, true, true>(g, stream) : launch_wgrad_bf16<RR, true, false>(g, stream)) \
+                             : (a_bf16 ? launch_wgrad_bf16<RR, false, true>(g, stream) : launch_wgrad_bf16<RR, false, false>(g, stream)))
+    if (wgrad_bf16_rows() == 2) rc = AIDE_WG(2); else rc = AIDE_WG(4);
+#undef AIDE_WG
     if (rc != 0) return rc;
     return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, stream);
 }
 
 int aide_conv3x3_wgrad_bf16(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N, int Co,
                             int Ci, int H, int W, float* ws, hipStream_t stream) {
-    return aide_conv3x3_wgrad_bf16_mixed(dz, 0, dz_bs, a, a_bs, dw, N, Co, Ci, H, W, ws, stream);
+    return aide_conv3x3_wgrad_bf16_mixed(dz, 0, dz_bs, a, 0, a_bs, dw, N, Co, Ci, H, W, ws, stream);
 }
 
 }  // extern "C"

@@ -12,8 +12,8 @@ namespace {
 
 constexpr int MAXK = 4;      // num_classes supported by the head kernels (reference uses 2)
 
-template <int K>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, long x_bs,
+template <int K, typename XT>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const XT* __restrict__ x, long x_bs,
                                                        const float* __restrict__ w, const float* __restrict__ b,
                                                        float* __restrict__ y, long y_bs, int C, int HW,
                                                        long total4) {
@@ -23,12 +23,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     const int hw4 = HW / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
         const long n = i / hw4, p = i - n * hw4;
-        const float* xp = x + n * x_bs + p * 4;
+        const XT* xp = x + n * x_bs + p * 4;
         f32x4 acc[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) { const float bk = b ? b[k] : 0.f; acc[k] = f32x4{bk, bk, bk, bk}; }
         for (int c = 0; c < C; ++c) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (long)c * HW);
+            const f32x4 v = ld4(xp + (long)c * HW);
 #pragma unroll
             for (int k = 0; k < K; ++k) acc[k] += ws[k * C + c] * v;
         }
@@ -64,9 +64,9 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
 // partial[b][k][c] = sum over this block's pixels of dy[k] * x[c];  partial[b][K*C + k] = sum dy[k]
 // Channels are walked in groups of 8 ("channel" -1 = the bias: x == 1): eight 16-byte x loads in flight
 // per pixel quad and ONE block reduction (two barriers) per group instead of per channel.
-template <int K>
+template <int K, typename XT>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dy, long dy_bs,
-                                                         const float* __restrict__ x, long x_bs, int C, int HW,
+                                                         const XT* __restrict__ x, long x_bs, int C, int HW,
                                                          long total4, double* __restrict__ partials) {
     constexpr int G = 8;
     __shared__ double sm[4][G * K];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
             for (int g = 0; g < G; ++g) {
                 const int c = c0 + g;
                 v[g] = f32x4{1.f, 1.f, 1.f, 1.f};
-                if (c >= 0 && c < C) v[g] = *reinterpret_cast<const f32x4*>(x + n * x_bs + (long)c * HW + p * 4);
+                if (c >= 0 && c < C) v[g] = ld4(x + n * x_bs + (long)c * HW + p * 4);
             }
 #pragma unroll
             for (int g = 0; g < G; ++g)
@@ -176,37 +176,31 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
 
 int grid_for(long total) { return (int)max(1L, min((total + 255) / 256, 4096L)); }
 
-template <int K>
-int head_wgrad_launch(const float* dy, long dy_bs, const float* x, long x_bs, int C, int HW, long total4,
+template <int K, typename XT>
+int head_wgrad_launch(const float* dy, long dy_bs, const XT* x, long x_bs, int C, int HW, long total4,
                       double* partials, int nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(head_wgrad_kernel<K>, dim3(nblocks), dim3(256), 0, s, dy, dy_bs, x, x_bs, C, HW,
+    hipLaunchKernelGGL((head_wgrad_kernel<K, XT>), dim3(nblocks), dim3(256), 0, s, dy, dy_bs, x, x_bs, C, HW,
                        total4, partials);
     return aide_launch_status();
 }
 
-}  // namespace
-
-extern "C" {
-
-int aide_head1x1_fwd(const float* x, int64_t x_bs, const float* w, const float* b, float* y, int64_t y_bs,
-                     int N, int C, int K, int H, int W, hipStream_t stream) {
+template <typename XT>
+int head_fwd_t(const XT* x, int64_t x_bs, const float* w, const float* b, float* y, int64_t y_bs, int N, int C, int K,
+               int H, int W, hipStream_t stream) {
     const int HW = H * W;
     if (K < 1 || K > MAXK || HW % 4 || x_bs % 4 || y_bs % 4) return AIDE_ERR_ARG;
     const long total4 = (long)N * HW / 4;
     const int grid = grid_for(total4);
     const size_t sh = (size_t)K * C * sizeof(float);
-#define AIDE_HEAD_FWD(KK) hipLaunchKernelGGL(head_fwd_kernel<KK>, dim3(grid), dim3(256), sh, stream, x, (long)x_bs, w, b, y, (long)y_bs, C, HW, total4)
+#define AIDE_HEAD_FWD(KK) hipLaunchKernelGGL((head_fwd_kernel<KK, XT>), dim3(grid), dim3(256), sh, stream, x, (long)x_bs, w, b, y, (long)y_bs, C, HW, total4)
     switch (K) { case 1: AIDE_HEAD_FWD(1); break; case 2: AIDE_HEAD_FWD(2); break; case 3: AIDE_HEAD_FWD(3); break; default: AIDE_HEAD_FWD(4); }
 #undef AIDE_HEAD_FWD
     return aide_launch_status();
 }
 
-size_t aide_head1x1_ws_bytes(int C, int K) { return (size_t)256 * (K * C + K) * sizeof(double); }
-
-// dy: [N][K][HW] -> dx [N][C][HW] (may be NULL), dw [K][C], db [K]
-int aide_head1x1_bwd(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, const float* w, float* dx,
-                     int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
-                     hipStream_t stream) {
+template <typename XT>
+int head_bwd_t(const float* dy, int64_t dy_bs, const XT* x, int64_t x_bs, const float* w, float* dx, int64_t dx_bs,
+               float* dw, float* db, int N, int C, int K, int H, int W, void* ws, hipStream_t stream) {
     const int HW = H * W;
     if (K < 1 || K > MAXK || HW % 4 || x_bs % 4 || dy_bs % 4 || (dx && dx_bs % 4) || !ws) return AIDE_ERR_ARG;
     const long total4 = (long)N * HW / 4;
@@ -229,6 +223,35 @@ int aide_head1x1_bwd(const float* dy, int64_t dy_bs, const float* x, int64_t x_b
     hipLaunchKernelGGL(head_wgrad_finalize_kernel, dim3(K * C + K), dim3(64), 0, stream,
                        (const double*)ws, nblocks, K * C, K, dw, db);
     return aide_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int aide_head1x1_fwd(const float* x, int64_t x_bs, const float* w, const float* b, float* y, int64_t y_bs,
+                     int N, int C, int K, int H, int W, hipStream_t stream) {
+    return head_fwd_t<float>(x, x_bs, w, b, y, y_bs, N, C, K, H, W, stream);
+}
+size_t aide_head1x1_ws_bytes(int C, int K) { return (size_t)256 * (K * C + K) * sizeof(double); }
+
+// dy: [N][K][HW] -> dx [N][C][HW] (may be NULL), dw [K][C], db [K]
+int aide_head1x1_bwd(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, const float* w, float* dx,
+                     int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
+                     hipStream_t stream) {
+    return head_bwd_t<float>(dy, dy_bs, x, x_bs, w, dx, dx_bs, dw, db, N, C, K, H, W, ws, stream);
+}
+// the head on a bf16-stored feature map (precision='bf16'); logits and every gradient stay fp32
+int aide_head1x1_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, const float* w, const float* b, float* y,
+                           int64_t y_bs, int N, int C, int K, int H, int W, hipStream_t stream) {
+    return x_bf16 ? head_fwd_t((const bf16_store_t*)x, x_bs, w, b, y, y_bs, N, C, K, H, W, stream)
+                  : head_fwd_t((const float*)x, x_bs, w, b, y, y_bs, N, C, K, H, W, stream);
+}
+int aide_head1x1_bwd_mixed(const float* dy, int64_t dy_bs, const void* x, int x_bf16, int64_t x_bs, const float* w,
+                           float* dx, int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
+                           hipStream_t stream) {
+    return x_bf16 ? head_bwd_t(dy, dy_bs, (const bf16_store_t*)x, x_bs, w, dx, dx_bs, dw, db, N, C, K, H, W, ws, stream)
+                  : head_bwd_t(dy, dy_bs, (const float*)x, x_bs, w, dx, dx_bs, dw, db, N, C, K, H, W, ws, stream);
 }
 
 // Pointer tables (device memory): p,g,m,v,vmax [ntensors]; sizes, block_start [ntensors] (int64).

@@ -11,8 +11,9 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void maxpool2x2_fwd_kernel(const float* __restrict__ x, long x_bs,
-                                                             float* __restrict__ y, long y_bs, int C, int H,
+template <typename XT, typename YT>
+__global__ __launch_bounds__(256) void maxpool2x2_fwd_kernel(const XT* __restrict__ x, long x_bs,
+                                                             YT* __restrict__ y, long y_bs, int C, int H,
                                                              int W, long total) {
     const int Ho = H / 2, Wo = W / 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -21,13 +22,13 @@ __global__ __launch_bounds__(256) void maxpool2x2_fwd_kernel(const float* __rest
         const int oh = (int)(r % Ho); r /= Ho;
         const int c = (int)(r % C);
         const long n = r / C;
-        const float* p = x + n * x_bs + (long)c * H * W + (long)(2 * oh) * W + 4 * ow2;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p + W);
-        float2 o;
-        o.x = fmaxf(fmaxf(a[0], a[1]), fmaxf(b[0], b[1]));
-        o.y = fmaxf(fmaxf(a[2], a[3]), fmaxf(b[2], b[3]));
-        *reinterpret_cast<float2*>(y + n * y_bs + (long)c * Ho * Wo + (long)oh * Wo + 2 * ow2) = o;
+        const XT* p = x + n * x_bs + (long)c * H * W + (long)(2 * oh) * W + 4 * ow2;
+        const f32x4 a = ld4(p);
+        const f32x4 b = ld4(p + W);
+        f32x2 o;
+        o[0] = fmaxf(fmaxf(a[0], a[1]), fmaxf(b[0], b[1]));
+        o[1] = fmaxf(fmaxf(a[2], a[3]), fmaxf(b[2], b[3]));
+        st2(y + n * y_bs + (long)c * Ho * Wo + (long)oh * Wo + 2 * ow2, o);     // max of bf16 values is exact in bf16
     }
 }
 
@@ -40,7 +41,8 @@ __device__ __forceinline__ int first_argmax4(float v0, float v1, float v2, float
 }
 
 // dx (+)= scatter of dy to the first arg-max of each window (windows do not overlap -> no atomics)
-__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const float* __restrict__ x, long x_bs,
+template <typename XT>
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const XT* __restrict__ x, long x_bs,
                                                              const float* __restrict__ dy, long dy_bs,
                                                              float* __restrict__ dx, long dx_bs, int C, int H,
                                                              int W, int accumulate, long total) {
@@ -52,9 +54,9 @@ __global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const float* __rest
         const int c = (int)(r % C);
         const long n = r / C;
         const long in_off = (long)c * H * W + (long)(2 * oh) * W + 4 * ow2;
-        const float* p = x + n * x_bs + in_off;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p + W);
+        const XT* p = x + n * x_bs + in_off;
+        const f32x4 a = ld4(p);
+        const f32x4 b = ld4(p + W);
         const float2 g = *reinterpret_cast<const float2*>(dy + n * dy_bs + (long)c * Ho * Wo + (long)oh * Wo + 2 * ow2);
         const int k0 = first_argmax4(a[0], a[1], b[0], b[1]);
         const int k1 = first_argmax4(a[2], a[3], b[2], b[3]);
@@ -104,28 +106,29 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
 // One (n, c) plane per blockIdx.y, 32-bit index arithmetic (the flat 64-bit div/mod form of this kernel was VALU-bound
 // at 1.9 TB/s).  A thread produces four consecutive outputs of one row: their sources lie in the four columns
 // wl .. wl + 3 of two source rows (3 * scale < 1.5), read once each.
-__global__ __launch_bounds__(256) void upsample2x_fwd_vec_kernel(const float* __restrict__ x, long x_bs,
-                                                                 float* __restrict__ y, long y_bs, int C, int H,
+template <typename XT, typename YT>
+__global__ __launch_bounds__(256) void upsample2x_fwd_vec_kernel(const XT* __restrict__ x, long x_bs,
+                                                                 YT* __restrict__ y, long y_bs, int C, int H,
                                                                  int W, int per_plane4) {
     const int Ho = 2 * H, Wo = 2 * W, Wo4 = Wo / 4;
     const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     const int plane = blockIdx.y, n = plane / C, c = plane - n * C;
-    const float* xp = x + (long)n * x_bs + (long)c * H * W;
-    float* yp = y + (long)n * y_bs + (long)c * Ho * Wo;
+    const XT* xp = x + (long)n * x_bs + (long)c * H * W;
+    YT* yp = y + (long)n * y_bs + (long)c * Ho * Wo;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < per_plane4; e += gridDim.x * 256) {
         const int oh = e / Wo4, ow4 = e - oh * Wo4;
         int h0, h1; float lh;
         src_index(oh, sh, H, h0, h1, lh);
-        const float* p0 = xp + h0 * W;
-        const float* p1 = xp + h1 * W;
+        const XT* p0 = xp + h0 * W;
+        const XT* p1 = xp + h1 * W;
         int wl, wdummy; float ldummy;
         src_index(4 * ow4, sw, W, wl, wdummy, ldummy);
         float t[4], b[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int wc = min(wl + k, W - 1);
-            t[k] = p0[wc]; b[k] = p1[wc];
+            t[k] = ld1(p0 + wc); b[k] = ld1(p1 + wc);
         }
         float v[4];                                   // rows blended first: v[k] = (1 - lh) t[k] + lh b[k]
 #pragma unroll
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_vec_kernel(const float* __
             const float a1 = d1 == 0 ? v[0] : d1 == 1 ? v[1] : d1 == 2 ? v[2] : v[3];
             o[k] = (1.f - lw) * a0 + lw * a1;
         }
-        *reinterpret_cast<f32x4*>(yp + (long)oh * Wo + 4 * ow4) = o;
+        st4(yp + (long)oh * Wo + 4 * ow4, o);
     }
 }
 
@@ -409,6 +412,36 @@ int grid_for(long total) { return (int)max(1L, min((total + 255) / 256, 8192L));
 
 extern "C" {
 
+}  // extern "C"
+
+namespace {
+template <typename XT, typename YT>
+int maxpool_fwd_t(const XT* x, int64_t x_bs, YT* y, int64_t y_bs, int N, int C, int H, int W, hipStream_t stream) {
+    const long total = (long)N * C * (H / 2) * (W / 4);
+    hipLaunchKernelGGL((maxpool2x2_fwd_kernel<XT, YT>), dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
+                       (long)y_bs, C, H, W, total);
+    return aide_launch_status();
+}
+template <typename XT>
+int maxpool_bwd_t(const XT* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int N, int C, int H,
+                  int W, int accumulate, hipStream_t stream) {
+    const long total = (long)N * C * (H / 2) * (W / 4);
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel<XT>, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, dy,
+                       (long)dy_bs, dx, (long)dx_bs, C, H, W, accumulate, total);
+    return aide_launch_status();
+}
+template <typename XT, typename YT>
+int upsample_fwd_t(const XT* x, int64_t x_bs, YT* y, int64_t y_bs, int N, int C, int H, int W, hipStream_t stream) {
+    const int per_plane4 = H * W;                       // (2H * 2W) / 4 four-pixel outputs per plane
+    const int gx = max(1, min((per_plane4 + 255) / 256, 64));
+    hipLaunchKernelGGL((upsample2x_fwd_vec_kernel<XT, YT>), dim3(gx, N * C), dim3(256), 0, stream, x, (long)x_bs, y,
+                       (long)y_bs, C, H, W, per_plane4);
+    return aide_launch_status();
+}
+}  // namespace
+
+extern "C" {
+
 int aide_maxpool2x2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int N, int C, int H, int W,
                         hipStream_t stream) {
     if (H % 2 || W % 2) return AIDE_ERR_ARG;
@@ -418,13 +451,19 @@ int aide_maxpool2x2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, in
                            (long)x_bs, y, (long)y_bs, C, H, W, total);
         return aide_launch_status();
     }
-    const long total = (long)N * C * (H / 2) * (W / 4);
-    hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
-                       (long)y_bs, C, H, W, total);
-    return aide_launch_status();
+    return maxpool_fwd_t<float, float>(x, x_bs, y, y_bs, N, C, H, W, stream);
 }
 
-// x: the pool INPUT (used to recompute the arg-max), dy: grad of the pooled output, dx: grad of x.
+// bf16-stored activations (precision='bf16'): x / y element types behind the untyped pointers; W % 4 == 0 required
+int aide_maxpool2x2_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, void* y, int y_bf16, int64_t y_bs, int N, int C,
+                              int H, int W, hipStream_t stream) {
+    if (H % 2 || W % 4 || x_bs % 4 || y_bs % 2) return AIDE_ERR_ARG;
+    if (x_bf16) return y_bf16 ? maxpool_fwd_t((const bf16_store_t*)x, x_bs, (bf16_store_t*)y, y_bs, N, C, H, W, stream)
+                              : maxpool_fwd_t((const bf16_store_t*)x, x_bs, (float*)y, y_bs, N, C, H, W, stream);
+    return y_bf16 ? maxpool_fwd_t((const float*)x, x_bs, (bf16_store_t*)y, y_bs, N, C, H, W, stream)
+                  : maxpool_fwd_t((const float*)x, x_bs, (float*)y, y_bs, N, C, H, W, stream);
+}
+
 int aide_maxpool2x2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx,
                         int64_t dx_bs, int N, int C, int H, int W, int accumulate, hipStream_t stream) {
     if (H % 2 || W % 2) return AIDE_ERR_ARG;
@@ -434,28 +473,35 @@ int aide_maxpool2x2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t d
                            (long)x_bs, dy, (long)dy_bs, dx, (long)dx_bs, C, H, W, accumulate, total);
         return aide_launch_status();
     }
-    const long total = (long)N * C * (H / 2) * (W / 4);
-    hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, dy,
-                       (long)dy_bs, dx, (long)dx_bs, C, H, W, accumulate, total);
-    return aide_launch_status();
+    return maxpool_bwd_t<float>(x, x_bs, dy, dy_bs, dx, dx_bs, N, C, H, W, accumulate, stream);
+}
+
+int aide_maxpool2x2_bwd_mixed(const void* x, int x_bf16, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx,
+                              int64_t dx_bs, int N, int C, int H, int W, int accumulate, hipStream_t stream) {
+    if (H % 2 || W % 4 || x_bs % 4 || dx_bs % 4 || dy_bs % 2) return AIDE_ERR_ARG;
+    return x_bf16 ? maxpool_bwd_t((const bf16_store_t*)x, x_bs, dy, dy_bs, dx, dx_bs, N, C, H, W, accumulate, stream)
+                  : maxpool_bwd_t((const float*)x, x_bs, dy, dy_bs, dx, dx_bs, N, C, H, W, accumulate, stream);
 }
 
 int aide_upsample2x_bilinear_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int N, int C, int H,
                                  int W, hipStream_t stream) {
     const long total = (long)N * C * 4 * H * W;
-    if ((2 * W) % 4 == 0 && y_bs % 4 == 0) {
-        const int per_plane4 = H * W;                       // (2H * 2W) / 4 float4 outputs per plane
-        const int gx = max(1, min((per_plane4 + 255) / 256, 64));
-        hipLaunchKernelGGL(upsample2x_fwd_vec_kernel, dim3(gx, N * C), dim3(256), 0, stream, x,
-                           (long)x_bs, y, (long)y_bs, C, H, W, per_plane4);
-        return aide_launch_status();
-    }
+    if ((2 * W) % 4 == 0 && y_bs % 4 == 0) return upsample_fwd_t<float, float>(x, x_bs, y, y_bs, N, C, H, W, stream);
     hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
                        (long)y_bs, C, H, W, total);
     return aide_launch_status();
 }
 
-// dy: [N][C][2H][2W]  ->  dx: [N][C][H][W]
+// interpolation in fp32 from fp32 / bf16-stored sources into an fp32 / bf16-stored destination (W % 2 == 0)
+int aide_upsample2x_bilinear_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, void* y, int y_bf16, int64_t y_bs, int N,
+                                       int C, int H, int W, hipStream_t stream) {
+    if ((2 * W) % 4 || y_bs % 4) return AIDE_ERR_ARG;
+    if (x_bf16) return y_bf16 ? upsample_fwd_t((const bf16_store_t*)x, x_bs, (bf16_store_t*)y, y_bs, N, C, H, W, stream)
+                              : upsample_fwd_t((const bf16_store_t*)x, x_bs, (float*)y, y_bs, N, C, H, W, stream);
+    return y_bf16 ? upsample_fwd_t((const float*)x, x_bs, (bf16_store_t*)y, y_bs, N, C, H, W, stream)
+                  : upsample_fwd_t((const float*)x, x_bs, (float*)y, y_bs, N, C, H, W, stream);
+}
+
 int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int N, int C,
                                  int H, int W, int accumulate, hipStream_t stream) {
     const long total = (long)N * C * H * W;

@@ -87,6 +87,7 @@ WGRAD_TAG = {0: 'conv3x3_wgrad_kernel', 2: 'conv3x3_wgrad_wino_kernel', 4: 'conv
 PRECISIONS = ('fp32', 'bf16')
 USE_WINOGRAD4 = [True]
 STORE_BF16 = [True]            # precision='bf16': z / dz stored as bf16 (A-B switch)
+STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 where every reader / writer allows it
 
 
 def conv_mode(n, cin, h, w, cout):
@@ -157,8 +158,6 @@ class Plan(object):
         self.pindex = {id(p): i for i, p in enumerate(params)}
         f32 = dict(device=device, dtype=torch.float32)
         self.act = {}
-        for t in graph.roots:
-            self.act[id(t)] = torch.empty(n, t.C, h >> t.level, w >> t.level, **f32)
         self.grad = {}
         self.steps = []
         max_dz = max_wg = max_bnc = max_sk = 0
@@ -254,6 +253,24 @@ class Plan(object):
                 st['gate'] = torch.empty(n, hh, ww, **f32)
                 st['stat'] = torch.empty(2, **f32)
             self.steps.append(st)
+        # activation buffers.  bf16 mode stores an activation buffer as bf16 when everything that touches it can: written by
+        # BatchNorm-apply / pooling / up-sampling, read by bf16 convolutions (forward AND weight gradient), pooling,
+        # up-sampling or the head.  For a conv operand that is numerically free (the kernels round it anyway), max-pooling
+        # commutes with the rounding; up-sampling and the head then see rounded inputs (what torch.autocast gives them).
+        # Gradients of activations stay fp32.
+        narrow = {id(t): bf16 and STORE_A_BF16[0] for t in graph.roots}
+        for st in self.steps:
+            kind = st['kind']
+            if kind == 'conv':
+                if not (st['wino_f'] == BF16 and st['wino_w'] == BF16):
+                    narrow[id(st['src'].root)] = False
+            elif kind in ('convT', 'sa'):
+                narrow[id(st['src'].root)] = False
+            if kind == 'sa':
+                narrow[id(st['dst'].root)] = False
+        for t in graph.roots:
+            dt = torch.bfloat16 if narrow.get(id(t)) else torch.float32
+            self.act[id(t)] = torch.empty(n, t.C, h >> t.level, w >> t.level, device=device, dtype=dt)
         self.bn_ws = ops.bn_ws(max(max_bnc, 1), device)
         self.sk_ws = torch.empty(max(max_sk // 4, 1), **f32)
         self._max_dz, self._max_wg = max_dz, max_wg

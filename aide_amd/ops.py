@@ -166,9 +166,9 @@ def bn_train_fwd(z, a, gamma, beta, eps, momentum, running_mean, running_var, nb
                  ws, relu=True):
     """a = relu(bn_train(z)); updates running stats / num_batches_tracked; saves mean/rstd/scale/shift."""
     zp, zbs = planes(z, bf16_ok=True)
-    ap, abs_ = planes(a)
+    ap, abs_ = planes(a, bf16_ok=True)
     n, c, h, w = z.shape
-    check(lib.aide_bn_train_fwd_mixed(zp, int(is_bf16(z)), zbs, ap, abs_, n, c, h, w, ptr(gamma), ptr(beta), eps,
+    check(lib.aide_bn_train_fwd_mixed(zp, int(is_bf16(z)), zbs, ap, int(is_bf16(a)), abs_, n, c, h, w, ptr(gamma), ptr(beta), eps,
                                       momentum, ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd),
                                       ptr(scale), ptr(shift), int(relu), ptr(ws), stream_ptr()), 'bn_train_fwd')
     return a
@@ -182,9 +182,9 @@ def bn_eval_coeff(gamma, beta, running_mean, running_var, eps, scale, shift):
 
 def bn_relu_apply(z, a, scale, shift, relu=True):
     zp, zbs = planes(z, bf16_ok=True)
-    ap, abs_ = planes(a)
+    ap, abs_ = planes(a, bf16_ok=True)
     n, c, h, w = z.shape
-    check(lib.aide_bn_relu_apply_mixed(zp, int(is_bf16(z)), zbs, ap, abs_, n, c, h, w, ptr(scale), ptr(shift),
+    check(lib.aide_bn_relu_apply_mixed(zp, int(is_bf16(z)), zbs, ap, int(is_bf16(a)), abs_, n, c, h, w, ptr(scale), ptr(shift),
                                        int(relu), stream_ptr()), 'bn_relu_apply')
     return a
 
@@ -202,28 +202,40 @@ def bn_relu_bwd(dA, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, r
 
 # ------------------------------------------------------------------------------- pool / upsample
 def maxpool2x2_fwd(x, y):
-    xp, xbs = planes(x)
-    yp, ybs = planes(y)
+    xp, xbs = planes(x, bf16_ok=True)
+    yp, ybs = planes(y, bf16_ok=True)
     n, c, h, w = x.shape
-    check(lib.aide_maxpool2x2_fwd(xp, xbs, yp, ybs, n, c, h, w, stream_ptr()), 'maxpool2x2_fwd')
+    if is_bf16(x) or is_bf16(y):       # bf16-stored activations (precision='bf16')
+        check(lib.aide_maxpool2x2_fwd_mixed(xp, int(is_bf16(x)), xbs, yp, int(is_bf16(y)), ybs, n, c, h, w, stream_ptr()),
+              'maxpool2x2_fwd')
+    else:
+        check(lib.aide_maxpool2x2_fwd(xp, xbs, yp, ybs, n, c, h, w, stream_ptr()), 'maxpool2x2_fwd')
     return y
 
 
 def maxpool2x2_bwd(x, dy, dx, accumulate=False):
-    xp, xbs = planes(x)
+    xp, xbs = planes(x, bf16_ok=True)
     gp, gbs = planes(dy)
     dp, dbs = planes(dx)
     n, c, h, w = x.shape
-    check(lib.aide_maxpool2x2_bwd(xp, xbs, gp, gbs, dp, dbs, n, c, h, w, int(accumulate), stream_ptr()),
-          'maxpool2x2_bwd')
+    if is_bf16(x):
+        check(lib.aide_maxpool2x2_bwd_mixed(xp, 1, xbs, gp, gbs, dp, dbs, n, c, h, w, int(accumulate), stream_ptr()),
+              'maxpool2x2_bwd')
+    else:
+        check(lib.aide_maxpool2x2_bwd(xp, xbs, gp, gbs, dp, dbs, n, c, h, w, int(accumulate), stream_ptr()),
+              'maxpool2x2_bwd')
     return dx
 
 
 def upsample2x_fwd(x, y):
-    xp, xbs = planes(x)
-    yp, ybs = planes(y)
+    xp, xbs = planes(x, bf16_ok=True)
+    yp, ybs = planes(y, bf16_ok=True)
     n, c, h, w = x.shape
-    check(lib.aide_upsample2x_bilinear_fwd(xp, xbs, yp, ybs, n, c, h, w, stream_ptr()), 'upsample2x_fwd')
+    if is_bf16(x) or is_bf16(y):
+        check(lib.aide_upsample2x_bilinear_fwd_mixed(xp, int(is_bf16(x)), xbs, yp, int(is_bf16(y)), ybs, n, c, h, w,
+                                                     stream_ptr()), 'upsample2x_fwd')
+    else:
+        check(lib.aide_upsample2x_bilinear_fwd(xp, xbs, yp, ybs, n, c, h, w, stream_ptr()), 'upsample2x_fwd')
     return y
 
 
@@ -245,18 +257,18 @@ def fill_zero(t):
 
 # ------------------------------------------------------------------------------- head 1x1
 def head1x1_fwd(x, w, b, y):
-    xp, xbs = planes(x)
+    xp, xbs = planes(x, bf16_ok=True)
     yp, ybs = planes(y)
     n, c, h, wd = x.shape
     k = w.shape[0]
-    check(lib.aide_head1x1_fwd(xp, xbs, ptr(w), ptr(b), yp, ybs, n, c, k, h, wd, stream_ptr()),
+    check(lib.aide_head1x1_fwd_mixed(xp, int(is_bf16(x)), xbs, ptr(w), ptr(b), yp, ybs, n, c, k, h, wd, stream_ptr()),
           'head1x1_fwd')
     return y
 
 
 def head1x1_bwd(dy, x, w, dx, dw, db, ws=None):
     gp, gbs = planes(dy)
-    xp, xbs = planes(x)
+    xp, xbs = planes(x, bf16_ok=True)
     n, c, h, wd = x.shape
     k = w.shape[0]
     if dx is not None:
@@ -265,8 +277,8 @@ def head1x1_bwd(dy, x, w, dx, dw, db, ws=None):
         dp, dbs = ctypes.c_void_p(0), 0
     if ws is None:
         ws = torch.empty(lib.aide_head1x1_ws_bytes(c, k) // 8, device=x.device, dtype=torch.float64)
-    check(lib.aide_head1x1_bwd(gp, gbs, xp, xbs, ptr(w), dp, dbs, ptr(dw), ptr(db), n, c, k, h, wd,
-                               ptr(ws), stream_ptr()), 'head1x1_bwd')
+    check(lib.aide_head1x1_bwd_mixed(gp, gbs, xp, int(is_bf16(x)), xbs, ptr(w), dp, dbs, ptr(dw), ptr(db), n, c, k, h,
+                                     wd, ptr(ws), stream_ptr()), 'head1x1_bwd')
 
 
 # ------------------------------------------------------------------------------- Winograd F(2x2,3x3)
@@ -414,15 +426,15 @@ def wgrad_bf16_supported(co, ci, h, w):
 def conv3x3_wgrad_bf16(dz, a, dw, ws=None):
     """dw [Co,Ci,3,3] fp32 <- weight gradient on the bf16 MFMA path (dz fp32 or bf16-stored)."""
     dzp, dzbs = planes(dz, bf16_ok=True)
-    ap, abs_ = planes(a)
+    ap, abs_ = planes(a, bf16_ok=True)
     n, co, h, w = dz.shape
     ci = a.shape[1]
     assert tuple(dw.shape) == (co, ci, 3, 3) and dw.is_contiguous()
     if ws is None:
         ws = torch.empty(lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, co, ci, h, w) // 4, device=dz.device,
                          dtype=torch.float32)
-    check(lib.aide_conv3x3_wgrad_bf16_mixed(dzp, int(is_bf16(dz)), dzbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws),
-                                            stream_ptr()), 'conv3x3_wgrad_bf16')
+    check(lib.aide_conv3x3_wgrad_bf16_mixed(dzp, int(is_bf16(dz)), dzbs, ap, int(is_bf16(a)), abs_, ptr(dw), n, co, ci,
+                                            h, w, ptr(ws), stream_ptr()), 'conv3x3_wgrad_bf16')
     return dw
 
 

@@ -104,8 +104,8 @@ int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W);
 size_t aide_conv3x3_wgrad_bf16_ws_bytes(int N, int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_bf16(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
                             int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
-int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, const float* a, int64_t a_bs, float* dw,
-                                  int N, int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
+int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, const void* a, int a_bf16, int64_t a_bs,
+                                  float* dw, int N, int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
 
 /* ---- ConvTranspose2d(k=2, s=2) (learned_bilinear=True up path) ---------------------------------
  * replaces nn.ConvTranspose2d: netblocks.py:12, UNet.py:7 */
@@ -133,14 +133,14 @@ int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs
                      int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                      const float* scale, const float* shift, int relu, float* dgamma, float* dbeta,
                      float* dbias, void* ws, aide_stream_t stream);
-/* the same three operators on bf16-STORED z / dz (precision='bf16'): z_bf16 / dz_bf16 give the element type behind the
+/* the same three operators on bf16-STORED z / a / dz (precision='bf16'): z_bf16 / a_bf16 / dz_bf16 give the element type behind the
  * untyped pointers; the arithmetic (fp32 per element, fp64 reductions) is unchanged, widening is exact, dz is narrowed RNE */
-int aide_bn_train_fwd_mixed(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
-                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                            float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
-                            float* scale, float* shift, int relu, void* ws, aide_stream_t stream);
-int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
-                             const float* scale, const float* shift, int relu, aide_stream_t stream);
+int aide_bn_train_fwd_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
+                            int H, int W, const float* gamma, const float* beta, float eps, float momentum,
+                            float* running_mean, float* running_var, long long* num_batches_tracked, float* mean,
+                            float* rstd, float* scale, float* shift, int relu, void* ws, aide_stream_t stream);
+int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
+                             int H, int W, const float* scale, const float* shift, int relu, aide_stream_t stream);
 int aide_bn_relu_bwd_mixed(const float* dA, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz, int dz_bf16,
                            int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                            const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
@@ -155,6 +155,13 @@ int aide_maxpool2x2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t d
                         int64_t dx_bs, int N, int C, int H, int W, int accumulate, aide_stream_t stream);
 int aide_upsample2x_bilinear_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int N, int C, int H,
                                  int W, aide_stream_t stream);
+/* the same on bf16-stored activations (precision='bf16'); gradients stay fp32 */
+int aide_maxpool2x2_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, void* y, int y_bf16, int64_t y_bs, int N, int C,
+                              int H, int W, aide_stream_t stream);
+int aide_maxpool2x2_bwd_mixed(const void* x, int x_bf16, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx,
+                              int64_t dx_bs, int N, int C, int H, int W, int accumulate, aide_stream_t stream);
+int aide_upsample2x_bilinear_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, void* y, int y_bf16, int64_t y_bs, int N,
+                                       int C, int H, int W, aide_stream_t stream);
 int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int N, int C,
                                  int H, int W, int accumulate, aide_stream_t stream);
 /* inverse augmentation of logit planes (flip + PIL-exact bilinear rotation); replaces the D2H -> PIL ->
@@ -199,6 +206,12 @@ int aide_sa_gate_bwd(const float* dout, int64_t dout_bs, const float* y, int64_t
 int aide_head1x1_fwd(const float* x, int64_t x_bs, const float* w, const float* b, float* y, int64_t y_bs,
                      int N, int C, int K, int H, int W, aide_stream_t stream);
 size_t aide_head1x1_ws_bytes(int C, int K);
+/* the head on a bf16-stored feature map (precision='bf16'); logits and every gradient stay fp32 */
+int aide_head1x1_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, const float* w, const float* b, float* y,
+                           int64_t y_bs, int N, int C, int K, int H, int W, aide_stream_t stream);
+int aide_head1x1_bwd_mixed(const float* dy, int64_t dy_bs, const void* x, int x_bf16, int64_t x_bs, const float* w,
+                           float* dx, int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
+                           aide_stream_t stream);
 int aide_head1x1_bwd(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, const float* w,
                      float* dx, int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W,
                      void* ws, aide_stream_t stream);

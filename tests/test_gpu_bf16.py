@@ -145,6 +145,91 @@ def test_bn_on_bf16_storage(dev, shape):
             assert torch.equal(t16, t32)
 
 
+def test_bf16_stored_activations(dev):
+    """Every operator that touches a bf16-stored activation: result == the fp32-storage operator on the widened input,
+    narrowed RNE where the output is bf16-stored (bit for bit; BatchNorm-apply, pooling, up-sampling, head, conv forward
+    and weight gradient)."""
+    from aide_amd import ops
+    g = torch.Generator().manual_seed(33)
+    n, c, h, w = 2, 64, 16, 64
+    a16 = torch.randn(n, c, h, w, generator=g).to(dev).bfloat16()
+    a32 = a16.float()
+    # BatchNorm apply into a bf16 activation (train and eval form), from fp32 and bf16 z
+    for z in (torch.randn(n, c, h, w, generator=g).to(dev), torch.randn(n, c, h, w, generator=g).to(dev).bfloat16()):
+        outs = []
+        for dt in (torch.bfloat16, torch.float32):
+            rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+            nbt = torch.zeros((), dtype=torch.long, device=dev)
+            st = [torch.empty(c, device=dev) for _ in range(4)]
+            gam, bet = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+            a = torch.empty(n, c, h, w, device=dev, dtype=dt)
+            ops.bn_train_fwd(z, a, gam, bet, 1e-5, 0.1, rm, rv, nbt, st[0], st[1], st[2], st[3], ops.bn_ws(c, dev), True)
+            e = torch.empty(n, c, h, w, device=dev, dtype=dt)
+            ops.bn_relu_apply(z, e, st[2], st[3], True)
+            outs.append((a, e))
+        assert torch.equal(outs[0][0], outs[1][0].bfloat16()) and torch.equal(outs[0][1], outs[1][1].bfloat16())
+    # max-pool forward (all four storage combinations) and backward (arg-max from the bf16 tensor)
+    ref = torch.empty(n, c, h // 2, w // 2, device=dev)
+    ops.maxpool2x2_fwd(a32, ref)
+    for dt in (torch.bfloat16, torch.float32):
+        y = torch.empty(n, c, h // 2, w // 2, device=dev, dtype=dt)
+        ops.maxpool2x2_fwd(a16, y)
+        assert torch.equal(y.float(), ref)                       # the maximum of bf16 values is a bf16 value
+    y16 = torch.empty(n, c, h // 2, w // 2, device=dev, dtype=torch.bfloat16)
+    ops.maxpool2x2_fwd(a32 * 1.001, y16)
+    ref2 = torch.empty_like(ref)
+    ops.maxpool2x2_fwd(a32 * 1.001, ref2)
+    assert torch.equal(y16, ref2.bfloat16())
+    dy = torch.randn(n, c, h // 2, w // 2, generator=g).to(dev)
+    dxa, dxb = torch.empty(n, c, h, w, device=dev), torch.empty(n, c, h, w, device=dev)
+    ops.maxpool2x2_bwd(a16, dy, dxa)
+    ops.maxpool2x2_bwd(a32, dy, dxb)
+    assert torch.equal(dxa, dxb)
+    # bilinear x2
+    up_ref = torch.empty(n, c, 2 * h, 2 * w, device=dev)
+    ops.upsample2x_fwd(a32, up_ref)
+    for dt in (torch.bfloat16, torch.float32):
+        u = torch.empty(n, c, 2 * h, 2 * w, device=dev, dtype=dt)
+        ops.upsample2x_fwd(a16, u)
+        # (the storage variants are separate template instantiations: the compiler may contract the interpolation
+        # FMAs differently, so fp32 results agree to an ulp and the narrowed ones to a bf16 ulp on rounding ties)
+        err = (u.float() - up_ref).abs()
+        assert float((err - (2.0 ** -8 if dt == torch.bfloat16 else 1e-6) * up_ref.abs()).max()) <= 1e-6
+    # head
+    wh, bh = torch.randn(2, c, generator=g).to(dev), torch.randn(2, generator=g).to(dev)
+    la, lb = torch.empty(n, 2, h, w, device=dev), torch.empty(n, 2, h, w, device=dev)
+    ops.head1x1_fwd(a16, wh, bh, la)
+    ops.head1x1_fwd(a32, wh, bh, lb)
+    assert torch.equal(la, lb)
+    dl = torch.randn(n, 2, h, w, generator=g).to(dev)
+    gr = []
+    for a in (a16, a32):
+        dx, dw, db = torch.empty(n, c, h, w, device=dev), torch.empty(2, c, device=dev), torch.empty(2, device=dev)
+        ops.head1x1_bwd(dl, a, wh, dx, dw, db)
+        gr.append((dx, dw, db))
+    assert all(torch.equal(p, q) for p, q in zip(*gr))
+    # conv forward from a bf16-stored activation (into fp32 and bf16 z) and weight gradient reading it
+    co = 64
+    wt = (torch.randn(co, c, 3, 3, generator=g) * 0.05).to(dev)
+    uf, _ = ops.bf16_pack(wt, need_dgrad=False)
+    for dt in (torch.float32, torch.bfloat16):
+        ya, yb = torch.empty(n, co, h, w, device=dev, dtype=dt), torch.empty(n, co, h, w, device=dev, dtype=dt)
+        ops.conv3x3_bf16(a16, uf, None, ya)
+        ops.conv3x3_bf16(a32, uf, None, yb)
+        assert torch.equal(ya, yb), 'conv forward from bf16 activation, out %s' % dt
+    for dz in (torch.randn(n, co, h, w, generator=g).to(dev), torch.randn(n, co, h, w, generator=g).to(dev).bfloat16()):
+        dwa, dwb = torch.empty_like(wt), torch.empty_like(wt)
+        ops.conv3x3_wgrad_bf16(dz, a16, dwa)
+        ops.conv3x3_wgrad_bf16(dz, a32, dwb)
+        assert torch.equal(dwa, dwb), 'wgrad from bf16 activation'
+    # ... through channel slices of a wider bf16 buffer (concat buffers)
+    big = torch.randn(n, c + 32, h, w, generator=g).to(dev).bfloat16()
+    ya, yb = torch.empty(n, co, h, w, device=dev), torch.empty(n, co, h, w, device=dev)
+    ops.conv3x3_bf16(big[:, 32:], uf, None, ya)
+    ops.conv3x3_bf16(big[:, 32:].float().contiguous(), uf, None, yb)
+    assert torch.equal(ya, yb)
+
+
 def test_conv3x3_bf16_channel_slices(dev):
     """inputs / outputs that are channel slices of concatenation buffers (explicit batch stride)."""
     from aide_amd import ops
@@ -227,10 +312,12 @@ def test_bf16_network_vs_bf16_oracle(dev, kind, store):
     from oracle import bf16 as OB
     LOGIT_TOL, LOSS_TOL, GRAD_TOL = (6e-2, 2e-3, 8e-2) if store else (1e-2, 5e-3, 5e-2)
     E.STORE_BF16[0] = OB.STORE_Z_BF16[0] = store
+    E.STORE_A_BF16[0] = OB.STORE_A_BF16[0] = store
     try:
         _network_vs_oracle(dev, kind, LOGIT_TOL, LOSS_TOL, GRAD_TOL)
     finally:
         E.STORE_BF16[0] = OB.STORE_Z_BF16[0] = True
+        E.STORE_A_BF16[0] = OB.STORE_A_BF16[0] = True
 
 
 def _network_vs_oracle(dev, kind, LOGIT_TOL, LOSS_TOL, GRAD_TOL):

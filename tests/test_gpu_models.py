@@ -67,7 +67,7 @@ class forced_relu_masks(object):
         self.pool_idx = {}
         for st in plan.steps:
             if st['kind'] == 'pool':
-                src = plan.view(st['src']).detach().cpu()
+                src = plan.view(st['src']).detach().cpu().float()        # (a bf16-stored buffer in the bf16 mode)
                 _, idx = torch.nn.functional.max_pool2d(src, 2, 2, return_indices=True)
                 self.pool_idx[tuple(src.shape[2:])] = idx
         self.pool_flips = 0
