@@ -180,7 +180,7 @@ class Plan(object):
                     st['wino_f'] = conv_mode(n, cin, hh, ww, cout)
                     st['wino_d'] = conv_mode(n, cout, hh, ww, cin) if (need_dg and USE_WINOGRAD_DGRAD[0]) else 0
                     # precision='bf16': bf16 operands / fp32 accumulation wherever the bf16 kernels cover the
-                    # layer shape, the fp32 kernels elsewhere (narrow deep levels of small inputs, 3-channel wgrad)
+                    # layer shape, the fp32 kernels elsewhere (narrow deep levels of small inputs)
                     if bf16 and lib.aide_conv3x3_bf16_supported(cin, hh, ww, cout):
                         st['wino_f'] = BF16
                     if bf16 and need_dg and lib.aide_conv3x3_bf16_supported(cout, hh, ww, cin):

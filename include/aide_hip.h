@@ -83,8 +83,8 @@ int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int
  * precision='bf16': operands are rounded to bf16 (RNE) while they are staged into LDS, products accumulate in fp32
  * (v_mfma_f32_32x32x16_bf16); tensors in HBM, master weights, bias, BatchNorm statistics and the loss stay fp32.
  * Filters are pre-packed to bf16: uf [ceil(Ci/16)][9][2][Co][8], ud [ceil(Co/16)][9 reversed][2][Ci][8].
- * Supported: W % 32 == 0, Cout % 32 == 0 (forward / dgrad); Co % 32 == 0, Ci % 32 == 0, W % 32 == 0, H % 4 == 0
- * (weight gradient).  The engine keeps the fp32 kernels for every other layer. */
+ * Supported: W % 32 == 0, Cout % 32 == 0 (forward / dgrad); Co % 32 == 0, W % 32 == 0, H % 4 == 0 (weight gradient;
+ * a bf16-stored x operand additionally needs Ci % 8 == 0).  The engine keeps the fp32 kernels for every other layer. */
 int aide_conv3x3_bf16_supported(int Cin, int H, int W, int Cout);
 int aide_conv3x3_bf16_splitk(int N, int Cin, int H, int W, int Cout);
 size_t aide_conv3x3_bf16_pack_elems(int Cout, int Cin);          /* bf16 elements of one direction's pack */

@@ -33,7 +33,7 @@ def conv_bf16_supported(cin, h, w, cout):
 
 
 def wgrad_bf16_supported(co, ci, h, w):
-    return co % 32 == 0 and ci % 32 == 0 and w % 32 == 0 and h % 4 == 0
+    return co % 32 == 0 and w % 32 == 0 and h % 4 == 0
 
 
 class _ConvBf16(torch.autograd.Function):

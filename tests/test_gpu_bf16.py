@@ -249,7 +249,7 @@ def test_conv3x3_bf16_channel_slices(dev):
 WGRAD_CASES = [
     # N, Co, Ci, H, W
     (2, 32, 32, 32, 32), (1, 64, 64, 64, 64), (2, 64, 128, 16, 32), (1, 128, 64, 32, 96), (2, 256, 256, 32, 32),
-    (1, 96, 32, 8, 64), (3, 64, 64, 4, 32),
+    (1, 96, 32, 8, 64), (3, 64, 64, 4, 32), (2, 32, 3, 16, 64), (1, 64, 40, 8, 32),     # ragged input channels
 ]
 
 
