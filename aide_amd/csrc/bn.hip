@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ZT* __restrict
 
 // ---------------------------------------------------------------- backward reductions
 // partials[c][s] = { sum dy, sum dy*xhat, sum xhat } with dy = dA * (z*scale+shift > 0)
-template <int V, typename ZT>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dA, long d_bs,
+template <int V, typename ZT, typename GT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const GT* __restrict__ dA, long d_bs,
                                                             const ZT* __restrict__ z, long z_bs, int N,
                                                             int C, int HW, int splits,
                                                             const float* __restrict__ mean,
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 // The latter is sum(dz), which is zero in exact arithmetic; it is evaluated from the same sums,
 //   sum dz = scale * ((sum dy - n c0) - c1 sum xhat),
 // i.e. as the rounding residue it is (the reference's autograd value is the same kind of ~1e-8 noise).
-template <int V, typename ZT, typename DT>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dA, long d_bs,
+template <int V, typename ZT, typename DT, typename GT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const GT* __restrict__ dA, long d_bs,
                                                            const ZT* __restrict__ z, long z_bs,
                                                            DT* __restrict__ dz, long dz_bs, int N, int C,
                                                            int HW, int splits, double count,
@@ -333,9 +333,9 @@ __global__ __launch_bounds__(256) void bn_train_fused_kernel(
     }
 }
 
-template <typename ZT, typename DT>
+template <typename ZT, typename DT, typename GT>
 __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(
-    const float* __restrict__ dA, long d_bs, const ZT* __restrict__ z, long z_bs, DT* __restrict__ dz,
+    const GT* __restrict__ dA, long d_bs, const ZT* __restrict__ z, long z_bs, DT* __restrict__ dz,
     long dz_bs, int N, int HW, double count, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ scale, const float* __restrict__ shift, int relu, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ dbias) {
@@ -353,7 +353,8 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(
             const int n = i / hw4, p = i - n * hw4;
             float zv[4];
             ldv<4>(z + (long)n * z_bs + (long)c * HW + p * 4, zv);
-            const f32x4 dv = *reinterpret_cast<const f32x4*>(dA + (long)n * d_bs + (long)c * HW + p * 4);
+            float dv[4];
+            ldv<4>(dA + (long)n * d_bs + (long)c * HW + p * 4, dv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bool on = !relu || fmaf(zv[e], sc, sh) > 0.0f;
@@ -454,8 +455,8 @@ int bn_relu_apply_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C
     return aide_launch_status();
 }
 
-template <typename ZT, typename DT>
-int bn_relu_bwd_t(const float* dA, int64_t d_bs, const ZT* z, int64_t z_bs, DT* dz, int64_t dz_bs,
+template <typename ZT, typename DT, typename GT>
+int bn_relu_bwd_t(const GT* dA, int64_t d_bs, const ZT* z, int64_t z_bs, DT* dz, int64_t dz_bs,
                   int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
                   const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws,
                   hipStream_t stream) {
@@ -466,16 +467,16 @@ int bn_relu_bwd_t(const float* dA, int64_t d_bs, const ZT* z, int64_t z_bs, DT* 
     double* partials = (double*)ws;
     const double count = (double)N * HW;
     if (v4 && bn_fused_ok(N, C, HW)) {
-        hipLaunchKernelGGL((bn_bwd_fused_kernel<ZT, DT>), dim3(C), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs,
+        hipLaunchKernelGGL((bn_bwd_fused_kernel<ZT, DT, GT>), dim3(C), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs,
                            N, HW, count, mean, rstd, scale, shift, relu, dgamma, dbeta, dbias);
         return aide_launch_status();
     }
     if (v4) {
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, ZT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<4, ZT, DT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, ZT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
     } else {
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, ZT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<1, ZT, DT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, ZT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
     }
     return aide_launch_status();
 }
@@ -516,14 +517,16 @@ int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, i
 #undef AIDE_BN_APPLY
 }
 
-int aide_bn_relu_bwd_mixed(const float* dA, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz, int dz_bf16,
-                           int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
+int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz,
+                           int dz_bf16, int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                            const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
                            void* ws, hipStream_t stream) {
-#define AIDE_BN_BWD(ZT, DT) bn_relu_bwd_t<ZT, DT>(dA, d_bs, (const ZT*)z, z_bs, (DT*)dz, dz_bs, N, C, H, W, mean, rstd, \
-                                                  scale, shift, relu, dgamma, dbeta, dbias, ws, stream)
-    if (z_bf16) return dz_bf16 ? AIDE_BN_BWD(bf16_t, bf16_t) : AIDE_BN_BWD(bf16_t, float);
-    return dz_bf16 ? AIDE_BN_BWD(float, bf16_t) : AIDE_BN_BWD(float, float);
+#define AIDE_BN_BWD(ZT, DT, GT) bn_relu_bwd_t<ZT, DT, GT>((const GT*)dA, d_bs, (const ZT*)z, z_bs, (DT*)dz, dz_bs, N, C, H, W, \
+                                                          mean, rstd, scale, shift, relu, dgamma, dbeta, dbias, ws, stream)
+#define AIDE_BN_BWD_G(ZT, DT) (dA_bf16 ? AIDE_BN_BWD(ZT, DT, bf16_t) : AIDE_BN_BWD(ZT, DT, float))
+    if (z_bf16) return dz_bf16 ? AIDE_BN_BWD_G(bf16_t, bf16_t) : AIDE_BN_BWD_G(bf16_t, float);
+    return dz_bf16 ? AIDE_BN_BWD_G(float, bf16_t) : AIDE_BN_BWD_G(float, float);
+#undef AIDE_BN_BWD_G
 #undef AIDE_BN_BWD
 }
 
@@ -544,7 +547,7 @@ int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs
                      int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
                      const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws,
                      hipStream_t stream) {
-    return bn_relu_bwd_t<float, float>(dA, d_bs, z, z_bs, dz, dz_bs, N, C, H, W, mean, rstd, scale, shift, relu, dgamma,
+    return bn_relu_bwd_t<float, float, float>(dA, d_bs, z, z_bs, dz, dz_bs, N, C, H, W, mean, rstd, scale, shift, relu, dgamma,
                                        dbeta, dbias, ws, stream);
 }
 

@@ -296,7 +296,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
                     const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
                     float lo = odd ? t1 : own0, hi = odd ? own1 : t0;
                     if (add_bias) { const float b = a.bias[co]; lo += b; hi += b; }
-                    if (pok) *reinterpret_cast<unsigned*>(yn + (long)co * HW + oh * a.W + ow) = pk_bf16(lo, hi);
+                    if (pok) {
+                        unsigned* q = reinterpret_cast<unsigned*>(yn + (long)co * HW + oh * a.W + ow);
+                        if (a.accumulate) {           // bf16-stored activation gradient with several writers (skip paths)
+                            const unsigned old = *q;
+                            lo += bf16_lo(old); hi += bf16_hi(old);
+                        }
+                        *q = pk_bf16(lo, hi);
+                    }
                 }
             }
         }
@@ -337,7 +344,12 @@ __global__ void bf16_splitk_reduce_kernel(const float* __restrict__ slabs, long 
         for (int s = 1; s < splitk; ++s) v += *reinterpret_cast<const f32x4*>(slabs + (long)s * split_stride + e);
         if (bias) v += bias[rem / HW];
         if constexpr (OUT_BF16) {
-            *reinterpret_cast<u32x2*>((uint16_t*)yv + n * y_bs + rem) = u32x2{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])};
+            u32x2* q = reinterpret_cast<u32x2*>((uint16_t*)yv + n * y_bs + rem);
+            if (accumulate) {
+                const u32x2 old = *q;
+                v[0] += bf16_lo(old[0]); v[1] += bf16_hi(old[0]); v[2] += bf16_lo(old[1]); v[3] += bf16_hi(old[1]);
+            }
+            *q = u32x2{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])};
         } else {
             f32x4* p = reinterpret_cast<f32x4*>((float*)yv + n * y_bs + rem);
             if (accumulate) v += *p;
@@ -756,13 +768,13 @@ int aide_conv3x3_bf16_pack_multi(const void* descs, int n, int64_t total_blocks,
 
 // y (+)= conv3x3(x) with bf16-packed filters u (forward pack, or the dgrad pack with Cin/Cout swapped by the
 // caller).  x, y: NCHW with batch strides (elements), fp32 or -- x_bf16 / y_bf16 -- bf16 storage (the forward writing
-// a bf16 z from an fp32 or bf16-stored activation, the dgrad reading a bf16 dz; no accumulation into a bf16 y).
+// a bf16 z from an fp32 or bf16-stored activation, the dgrad reading a bf16 dz and writing / accumulating a bf16-stored
+// activation gradient).
 // ws: split-K slabs (splitk * N*Cout*H*W floats).
 int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint16_t* u, const float* bias, void* y,
                             int y_bf16, int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,
                             float* ws, hipStream_t stream) {
     if (!x || !u || !y || N <= 0 || !aide_conv3x3_bf16_supported(Cin, H, W, Cout)) return AIDE_ERR_ARG;
-    if (y_bf16 && accumulate) return AIDE_ERR_ARG;
     if ((x_bf16 && (x_bs % 2)) || (y_bf16 && (y_bs % 2))) return AIDE_ERR_ARG;
     BfArgs a;
     a.x = x; a.wp = u; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
@@ -791,7 +803,7 @@ int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint1
         const int blocks = (int)min((total4 + 255) / 256, (long)2048);
         if (y_bf16)
             hipLaunchKernelGGL(bf16_splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, stream, ws,
-                               (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias, 0, total4);
+                               (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias, accumulate, total4);
         else
             hipLaunchKernelGGL(bf16_splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, stream, ws,
                                (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias, accumulate, total4);

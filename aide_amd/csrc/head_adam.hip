@@ -38,9 +38,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const XT* __restrict__ x,
 }
 
 // dx[n][c][p] = sum_k dy[n][k][p] w[k][c]
-template <int K>
+template <int K, typename DT>
 __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dy, long dy_bs,
-                                                         const float* __restrict__ w, float* __restrict__ dx,
+                                                         const float* __restrict__ w, DT* __restrict__ dx,
                                                          long dx_bs, int C, int HW, long total4) {
     extern __shared__ float ws[];
     for (int i = threadIdx.x; i < K * C; i += 256) ws[i] = w[i];
@@ -51,12 +51,12 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
         f32x4 g[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) g[k] = *reinterpret_cast<const f32x4*>(dy + n * dy_bs + (long)k * HW + p * 4);
-        float* xp = dx + n * dx_bs + p * 4;
+        DT* xp = dx + n * dx_bs + p * 4;
         for (int c = 0; c < C; ++c) {
             f32x4 v = ws[c] * g[0];
 #pragma unroll
             for (int k = 1; k < K; ++k) v += ws[k * C + c] * g[k];
-            *reinterpret_cast<f32x4*>(xp + (long)c * HW) = v;
+            st4(xp + (long)c * HW, v);
         }
     }
 }
@@ -198,8 +198,8 @@ int head_fwd_t(const XT* x, int64_t x_bs, const float* w, const float* b, float*
     return aide_launch_status();
 }
 
-template <typename XT>
-int head_bwd_t(const float* dy, int64_t dy_bs, const XT* x, int64_t x_bs, const float* w, float* dx, int64_t dx_bs,
+template <typename XT, typename DT>
+int head_bwd_t(const float* dy, int64_t dy_bs, const XT* x, int64_t x_bs, const float* w, DT* dx, int64_t dx_bs,
                float* dw, float* db, int N, int C, int K, int H, int W, void* ws, hipStream_t stream) {
     const int HW = H * W;
     if (K < 1 || K > MAXK || HW % 4 || x_bs % 4 || dy_bs % 4 || (dx && dx_bs % 4) || !ws) return AIDE_ERR_ARG;
@@ -207,7 +207,7 @@ int head_bwd_t(const float* dy, int64_t dy_bs, const XT* x, int64_t x_bs, const 
     const size_t sh = (size_t)K * C * sizeof(float);
     if (dx) {
         const int grid = grid_for(total4);
-#define AIDE_HEAD_DG(KK) hipLaunchKernelGGL(head_dgrad_kernel<KK>, dim3(grid), dim3(256), sh, stream, dy, (long)dy_bs, w, dx, (long)dx_bs, C, HW, total4)
+#define AIDE_HEAD_DG(KK) hipLaunchKernelGGL((head_dgrad_kernel<KK, DT>), dim3(grid), dim3(256), sh, stream, dy, (long)dy_bs, w, dx, (long)dx_bs, C, HW, total4)
         switch (K) { case 1: AIDE_HEAD_DG(1); break; case 2: AIDE_HEAD_DG(2); break; case 3: AIDE_HEAD_DG(3); break; default: AIDE_HEAD_DG(4); }
 #undef AIDE_HEAD_DG
     }
@@ -239,7 +239,7 @@ size_t aide_head1x1_ws_bytes(int C, int K) { return (size_t)256 * (K * C + K) * 
 int aide_head1x1_bwd(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, const float* w, float* dx,
                      int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
                      hipStream_t stream) {
-    return head_bwd_t<float>(dy, dy_bs, x, x_bs, w, dx, dx_bs, dw, db, N, C, K, H, W, ws, stream);
+    return head_bwd_t<float, float>(dy, dy_bs, x, x_bs, w, dx, dx_bs, dw, db, N, C, K, H, W, ws, stream);
 }
 // the head on a bf16-stored feature map (precision='bf16'); logits and every gradient stay fp32
 int aide_head1x1_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, const float* w, const float* b, float* y,
@@ -248,10 +248,12 @@ int aide_head1x1_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, const float*
                   : head_fwd_t((const float*)x, x_bs, w, b, y, y_bs, N, C, K, H, W, stream);
 }
 int aide_head1x1_bwd_mixed(const float* dy, int64_t dy_bs, const void* x, int x_bf16, int64_t x_bs, const float* w,
-                           float* dx, int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
-                           hipStream_t stream) {
-    return x_bf16 ? head_bwd_t(dy, dy_bs, (const bf16_store_t*)x, x_bs, w, dx, dx_bs, dw, db, N, C, K, H, W, ws, stream)
-                  : head_bwd_t(dy, dy_bs, (const float*)x, x_bs, w, dx, dx_bs, dw, db, N, C, K, H, W, ws, stream);
+                           void* dx, int dx_bf16, int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W,
+                           void* ws, hipStream_t stream) {
+#define AIDE_HB(XT, DT) head_bwd_t(dy, dy_bs, (const XT*)x, x_bs, w, (DT*)dx, dx_bs, dw, db, N, C, K, H, W, ws, stream)
+    if (x_bf16) return dx_bf16 ? AIDE_HB(bf16_store_t, bf16_store_t) : AIDE_HB(bf16_store_t, float);
+    return dx_bf16 ? AIDE_HB(float, bf16_store_t) : AIDE_HB(float, float);
+#undef AIDE_HB
 }
 
 // Pointer tables (device memory): p,g,m,v,vmax [ntensors]; sizes, block_start [ntensors] (int64).

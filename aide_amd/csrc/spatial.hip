@@ -41,10 +41,10 @@ __device__ __forceinline__ int first_argmax4(float v0, float v1, float v2, float
 }
 
 // dx (+)= scatter of dy to the first arg-max of each window (windows do not overlap -> no atomics)
-template <typename XT>
+template <typename XT, typename GT, typename DT>
 __global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const XT* __restrict__ x, long x_bs,
-                                                             const float* __restrict__ dy, long dy_bs,
-                                                             float* __restrict__ dx, long dx_bs, int C, int H,
+                                                             const GT* __restrict__ dy, long dy_bs,
+                                                             DT* __restrict__ dx, long dx_bs, int C, int H,
                                                              int W, int accumulate, long total) {
     const int Ho = H / 2, Wo = W / 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -57,18 +57,19 @@ __global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const XT* __restric
         const XT* p = x + n * x_bs + in_off;
         const f32x4 a = ld4(p);
         const f32x4 b = ld4(p + W);
-        const float2 g = *reinterpret_cast<const float2*>(dy + n * dy_bs + (long)c * Ho * Wo + (long)oh * Wo + 2 * ow2);
+        const f32x2 g2 = ld2(dy + n * dy_bs + (long)c * Ho * Wo + (long)oh * Wo + 2 * ow2);
+        const float2 g = make_float2(g2[0], g2[1]);
         const int k0 = first_argmax4(a[0], a[1], b[0], b[1]);
         const int k1 = first_argmax4(a[2], a[3], b[2], b[3]);
         f32x4 ta = {k0 == 0 ? g.x : 0.f, k0 == 1 ? g.x : 0.f, k1 == 0 ? g.y : 0.f, k1 == 1 ? g.y : 0.f};
         f32x4 tb = {k0 == 2 ? g.x : 0.f, k0 == 3 ? g.x : 0.f, k1 == 2 ? g.y : 0.f, k1 == 3 ? g.y : 0.f};
-        float* q = dx + n * dx_bs + in_off;
+        DT* q = dx + n * dx_bs + in_off;
         if (accumulate) {
-            ta += *reinterpret_cast<const f32x4*>(q);
-            tb += *reinterpret_cast<const f32x4*>(q + W);
+            ta += ld4(q);
+            tb += ld4(q + W);
         }
-        *reinterpret_cast<f32x4*>(q) = ta;
-        *reinterpret_cast<f32x4*>(q + W) = tb;
+        st4(q, ta);
+        st4(q + W, tb);
     }
 }
 
@@ -173,8 +174,9 @@ __device__ __forceinline__ int up_bwd_weights(int i, int in_size, int out_size, 
 // global loads and the six-tap column pass touch consecutive LDS words per lane (the interleaved layout was 2-way
 // bank-conflicted on every access); the tap weights live in registers (a thread's source column, and its four source
 // rows, are fixed for the whole workgroup), not in LDS tables: 6 + 6 LDS reads per source pixel instead of 13 + 12.
-__global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const float* __restrict__ dy, long dy_bs,
-                                                                   float* __restrict__ dx, long dx_bs, int C, int H,
+template <typename GT, typename DT>
+__global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const GT* __restrict__ dy, long dy_bs,
+                                                                   DT* __restrict__ dx, long dx_bs, int C, int H,
                                                                    int W, int tiles_w, int accumulate) {
     constexpr int HW2 = UB_RW / 2;                          // 66 column pairs
     __shared__ float te[UB_RH][HW2 + 1], to[UB_RH][HW2 + 1];
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const float* 
         otab[tid] = lo - (row ? R0 : C0);
     }
     // destination window -> LDS (zero outside the plane); 8-byte coalesced loads
-    const float* g = dy + (long)n * dy_bs + (long)c * Ho * Wo;
+    const GT* g = dy + (long)n * dy_bs + (long)c * Ho * Wo;
     // all ten loads of a thread are issued before the first LDS store (a load -> wait -> store loop exposed the full
     // memory latency ten times per workgroup: 0.9 TB/s); out-of-plane elements read a clamped address and are zeroed
     constexpr int NLD = (UB_RH * HW2 + 255) / 256;
@@ -211,8 +213,8 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const float* 
         const int r = e / HW2, c2 = e - r * HW2;
         const int oh = R0 + r, ow = C0 + 2 * c2;
         const bool ok = e < UB_RH * HW2 && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
-        const float2 t = *reinterpret_cast<const float2*>(g + (ok ? (long)oh * Wo + ow : 0L));
-        v[k] = ok ? t : make_float2(0.f, 0.f);
+        const f32x2 t = ld2(g + (ok ? (long)oh * Wo + ow : 0L));
+        v[k] = ok ? make_float2(t[0], t[1]) : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
@@ -244,8 +246,8 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const float* 
             float a = 0.f;
 #pragma unroll
             for (int k = 0; k < 6; ++k) a += wr[k] * hp[o + k][x];
-            float* q = dx + (long)n * dx_bs + (long)c * H * W + (long)(h0 + r) * W + w0 + x;
-            *q = accumulate ? (*q + a) : a;
+            DT* q = dx + (long)n * dx_bs + (long)c * H * W + (long)(h0 + r) * W + w0 + x;
+            st1(q, accumulate ? (ld1(q) + a) : a);
         }
     }
 }
@@ -422,11 +424,11 @@ int maxpool_fwd_t(const XT* x, int64_t x_bs, YT* y, int64_t y_bs, int N, int C, 
                        (long)y_bs, C, H, W, total);
     return aide_launch_status();
 }
-template <typename XT>
-int maxpool_bwd_t(const XT* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int N, int C, int H,
+template <typename XT, typename GT, typename DT>
+int maxpool_bwd_t(const XT* x, int64_t x_bs, const GT* dy, int64_t dy_bs, DT* dx, int64_t dx_bs, int N, int C, int H,
                   int W, int accumulate, hipStream_t stream) {
     const long total = (long)N * C * (H / 2) * (W / 4);
-    hipLaunchKernelGGL(maxpool2x2_bwd_kernel<XT>, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, dy,
+    hipLaunchKernelGGL((maxpool2x2_bwd_kernel<XT, GT, DT>), dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, dy,
                        (long)dy_bs, dx, (long)dx_bs, C, H, W, accumulate, total);
     return aide_launch_status();
 }
@@ -473,14 +475,18 @@ int aide_maxpool2x2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t d
                            (long)x_bs, dy, (long)dy_bs, dx, (long)dx_bs, C, H, W, accumulate, total);
         return aide_launch_status();
     }
-    return maxpool_bwd_t<float>(x, x_bs, dy, dy_bs, dx, dx_bs, N, C, H, W, accumulate, stream);
+    return maxpool_bwd_t<float, float, float>(x, x_bs, dy, dy_bs, dx, dx_bs, N, C, H, W, accumulate, stream);
 }
 
-int aide_maxpool2x2_bwd_mixed(const void* x, int x_bf16, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx,
-                              int64_t dx_bs, int N, int C, int H, int W, int accumulate, hipStream_t stream) {
+int aide_maxpool2x2_bwd_mixed(const void* x, int x_bf16, int64_t x_bs, const void* dy, int dy_bf16, int64_t dy_bs, void* dx,
+                              int dx_bf16, int64_t dx_bs, int N, int C, int H, int W, int accumulate, hipStream_t stream) {
     if (H % 2 || W % 4 || x_bs % 4 || dx_bs % 4 || dy_bs % 2) return AIDE_ERR_ARG;
-    return x_bf16 ? maxpool_bwd_t((const bf16_store_t*)x, x_bs, dy, dy_bs, dx, dx_bs, N, C, H, W, accumulate, stream)
-                  : maxpool_bwd_t((const float*)x, x_bs, dy, dy_bs, dx, dx_bs, N, C, H, W, accumulate, stream);
+#define AIDE_PB(XT, GT, DT) maxpool_bwd_t((const XT*)x, x_bs, (const GT*)dy, dy_bs, (DT*)dx, dx_bs, N, C, H, W, accumulate, stream)
+#define AIDE_PB_X(GT, DT) (x_bf16 ? AIDE_PB(bf16_store_t, GT, DT) : AIDE_PB(float, GT, DT))
+    if (dy_bf16) return dx_bf16 ? AIDE_PB_X(bf16_store_t, bf16_store_t) : AIDE_PB_X(bf16_store_t, float);
+    return dx_bf16 ? AIDE_PB_X(float, bf16_store_t) : AIDE_PB_X(float, float);
+#undef AIDE_PB_X
+#undef AIDE_PB
 }
 
 int aide_upsample2x_bilinear_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int N, int C, int H,
@@ -507,12 +513,25 @@ int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int6
     const long total = (long)N * C * H * W;
     if (dy_bs % 2 == 0 && (long)N * C <= 65535) {          // 8-byte loads of the destination rows
         const int tw = (W + UB_TW - 1) / UB_TW, th = (H + UB_TH - 1) / UB_TH;
-        hipLaunchKernelGGL(upsample2x_bwd_tiled_kernel, dim3(tw * th, N * C), dim3(256), 0, stream, dy, (long)dy_bs,
-                           dx, (long)dx_bs, C, H, W, tw, accumulate);
+        hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<float, float>), dim3(tw * th, N * C), dim3(256), 0, stream, dy,
+                           (long)dy_bs, dx, (long)dx_bs, C, H, W, tw, accumulate);
         return aide_launch_status();
     }
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, (long)dy_bs,
                        dx, (long)dx_bs, C, H, W, accumulate, total);
+    return aide_launch_status();
+}
+
+// the transpose on bf16-stored activation gradients (precision='bf16'); arithmetic in fp32
+int aide_upsample2x_bilinear_bwd_mixed(const void* dy, int dy_bf16, int64_t dy_bs, void* dx, int dx_bf16, int64_t dx_bs,
+                                       int N, int C, int H, int W, int accumulate, hipStream_t stream) {
+    if (dy_bs % 2 || (long)N * C > 65535) return AIDE_ERR_ARG;
+    const int tw = (W + UB_TW - 1) / UB_TW, th = (H + UB_TH - 1) / UB_TH;
+#define AIDE_UB(GT, DT) hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<GT, DT>), dim3(tw * th, N * C), dim3(256), 0, stream, \
+                                           (const GT*)dy, (long)dy_bs, (DT*)dx, (long)dx_bs, C, H, W, tw, accumulate)
+    if (dy_bf16) { if (dx_bf16) AIDE_UB(bf16_store_t, bf16_store_t); else AIDE_UB(bf16_store_t, float); }
+    else { if (dx_bf16) AIDE_UB(float, bf16_store_t); else AIDE_UB(float, float); }
+#undef AIDE_UB
     return aide_launch_status();
 }
 

@@ -88,6 +88,7 @@ PRECISIONS = ('fp32', 'bf16')
 USE_WINOGRAD4 = [True]
 STORE_BF16 = [True]            # precision='bf16': z / dz stored as bf16 (A-B switch)
 STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 where every reader / writer allows it
+STORE_G_BF16 = [True]          # ... and the gradients of those activations
 
 
 def conv_mode(n, cin, h, w, cout):
@@ -271,6 +272,14 @@ class Plan(object):
         for t in graph.roots:
             dt = torch.bfloat16 if narrow.get(id(t)) else torch.float32
             self.act[id(t)] = torch.empty(n, t.C, h >> t.level, w >> t.level, device=device, dtype=dt)
+        # the gradient of a bf16-stored activation buffer is stored as bf16 too when every conv that reads the buffer also
+        # runs its dgrad on the bf16 kernel (the other writers / readers -- pooling, up-sampling, head, BatchNorm backward --
+        # are storage-generic).  Writers after the first accumulate in fp32 and round once per write (torch.autocast's
+        # bf16 activation gradients accumulate the same way).
+        self.narrow_grad = {k: v and STORE_G_BF16[0] for k, v in narrow.items()}
+        for st in self.steps:
+            if st['kind'] == 'conv' and not st['src'].root.is_input and st['wino_d'] != BF16:
+                self.narrow_grad[id(st['src'].root)] = False
         self.bn_ws = ops.bn_ws(max(max_bnc, 1), device)
         self.sk_ws = torch.empty(max(max_sk // 4, 1), **f32)
         self._max_dz, self._max_wg = max_dz, max_wg
@@ -297,7 +306,8 @@ class Plan(object):
         f32 = dict(device=self.dev, dtype=torch.float32)
         n, h, w = self.N, self.H, self.W
         for t in self.g.roots:
-            self.grad[id(t)] = torch.empty(n, t.C, h >> t.level, w >> t.level, **f32)
+            dt = torch.bfloat16 if self.narrow_grad.get(id(t)) else torch.float32
+            self.grad[id(t)] = torch.empty(n, t.C, h >> t.level, w >> t.level, device=self.dev, dtype=dt)
         # one dz buffer per conv: the weight-gradient kernels run on a side stream and may still be
         # reading dz of layer L while the main stream already produces dz of layer L-1
         for st in self.steps:

@@ -190,11 +190,11 @@ def bn_relu_apply(z, a, scale, shift, relu=True):
 
 
 def bn_relu_bwd(dA, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, relu=True):
-    gp, gbs = planes(dA)
+    gp, gbs = planes(dA, bf16_ok=True)
     zp, zbs = planes(z, bf16_ok=True)
     dp, dbs = planes(dz, bf16_ok=True)
     n, c, h, w = z.shape
-    check(lib.aide_bn_relu_bwd_mixed(gp, gbs, zp, int(is_bf16(z)), zbs, dp, int(is_bf16(dz)), dbs, n, c, h, w,
+    check(lib.aide_bn_relu_bwd_mixed(gp, int(is_bf16(dA)), gbs, zp, int(is_bf16(z)), zbs, dp, int(is_bf16(dz)), dbs, n, c, h, w,
                                      ptr(mean), ptr(rstd), ptr(scale), ptr(shift), int(relu), ptr(dgamma), ptr(dbeta),
                                      ptr(dbias), ptr(ws), stream_ptr()), 'bn_relu_bwd')
     return dz
@@ -215,12 +215,12 @@ def maxpool2x2_fwd(x, y):
 
 def maxpool2x2_bwd(x, dy, dx, accumulate=False):
     xp, xbs = planes(x, bf16_ok=True)
-    gp, gbs = planes(dy)
-    dp, dbs = planes(dx)
+    gp, gbs = planes(dy, bf16_ok=True)
+    dp, dbs = planes(dx, bf16_ok=True)
     n, c, h, w = x.shape
-    if is_bf16(x):
-        check(lib.aide_maxpool2x2_bwd_mixed(xp, 1, xbs, gp, gbs, dp, dbs, n, c, h, w, int(accumulate), stream_ptr()),
-              'maxpool2x2_bwd')
+    if is_bf16(x) or is_bf16(dy) or is_bf16(dx):
+        check(lib.aide_maxpool2x2_bwd_mixed(xp, int(is_bf16(x)), xbs, gp, int(is_bf16(dy)), gbs, dp, int(is_bf16(dx)), dbs,
+                                            n, c, h, w, int(accumulate), stream_ptr()), 'maxpool2x2_bwd')
     else:
         check(lib.aide_maxpool2x2_bwd(xp, xbs, gp, gbs, dp, dbs, n, c, h, w, int(accumulate), stream_ptr()),
               'maxpool2x2_bwd')
@@ -240,18 +240,26 @@ def upsample2x_fwd(x, y):
 
 
 def upsample2x_bwd(dy, dx, accumulate=False):
-    gp, gbs = planes(dy)
-    dp, dbs = planes(dx)
+    gp, gbs = planes(dy, bf16_ok=True)
+    dp, dbs = planes(dx, bf16_ok=True)
     n, c, h, w = dx.shape
-    check(lib.aide_upsample2x_bilinear_bwd(gp, gbs, dp, dbs, n, c, h, w, int(accumulate), stream_ptr()),
-          'upsample2x_bwd')
+    if is_bf16(dy) or is_bf16(dx):
+        check(lib.aide_upsample2x_bilinear_bwd_mixed(gp, int(is_bf16(dy)), gbs, dp, int(is_bf16(dx)), dbs, n, c, h, w,
+                                                     int(accumulate), stream_ptr()), 'upsample2x_bwd')
+    else:
+        check(lib.aide_upsample2x_bilinear_bwd(gp, gbs, dp, dbs, n, c, h, w, int(accumulate), stream_ptr()),
+              'upsample2x_bwd')
     return dx
 
 
 def fill_zero(t):
-    p, bs = planes(t)
+    p, bs = planes(t, bf16_ok=True)
     n, c, h, w = t.shape
-    check(lib.aide_fill_zero(p, bs, n, c, h, w, stream_ptr()), 'fill_zero')
+    if is_bf16(t):                       # as pairs: zero is zero in either type
+        assert bs % 2 == 0 and (c * h * w) % 2 == 0
+        check(lib.aide_fill_zero(p, bs // 2, n, 1, 1, c * h * w // 2, stream_ptr()), 'fill_zero')
+    else:
+        check(lib.aide_fill_zero(p, bs, n, c, h, w, stream_ptr()), 'fill_zero')
     return t
 
 
@@ -272,13 +280,13 @@ def head1x1_bwd(dy, x, w, dx, dw, db, ws=None):
     n, c, h, wd = x.shape
     k = w.shape[0]
     if dx is not None:
-        dp, dbs = planes(dx)
+        dp, dbs = planes(dx, bf16_ok=True)
     else:
         dp, dbs = ctypes.c_void_p(0), 0
     if ws is None:
         ws = torch.empty(lib.aide_head1x1_ws_bytes(c, k) // 8, device=x.device, dtype=torch.float64)
-    check(lib.aide_head1x1_bwd_mixed(gp, gbs, xp, int(is_bf16(x)), xbs, ptr(w), dp, dbs, ptr(dw), ptr(db), n, c, k, h,
-                                     wd, ptr(ws), stream_ptr()), 'head1x1_bwd')
+    check(lib.aide_head1x1_bwd_mixed(gp, gbs, xp, int(is_bf16(x)), xbs, ptr(w), dp, int(dx is not None and is_bf16(dx)),
+                                     dbs, ptr(dw), ptr(db), n, c, k, h, wd, ptr(ws), stream_ptr()), 'head1x1_bwd')
 
 
 # ------------------------------------------------------------------------------- Winograd F(2x2,3x3)

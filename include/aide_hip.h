@@ -141,8 +141,8 @@ int aide_bn_train_fwd_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, in
                             float* rstd, float* scale, float* shift, int relu, void* ws, aide_stream_t stream);
 int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
                              int H, int W, const float* scale, const float* shift, int relu, aide_stream_t stream);
-int aide_bn_relu_bwd_mixed(const float* dA, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz, int dz_bf16,
-                           int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
+int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz,
+                           int dz_bf16, int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                            const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
                            void* ws, aide_stream_t stream);
 
@@ -155,11 +155,13 @@ int aide_maxpool2x2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t d
                         int64_t dx_bs, int N, int C, int H, int W, int accumulate, aide_stream_t stream);
 int aide_upsample2x_bilinear_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int N, int C, int H,
                                  int W, aide_stream_t stream);
-/* the same on bf16-stored activations (precision='bf16'); gradients stay fp32 */
+/* the same on bf16-stored activations and activation gradients (precision='bf16'); arithmetic in fp32 */
 int aide_maxpool2x2_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, void* y, int y_bf16, int64_t y_bs, int N, int C,
                               int H, int W, aide_stream_t stream);
-int aide_maxpool2x2_bwd_mixed(const void* x, int x_bf16, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx,
-                              int64_t dx_bs, int N, int C, int H, int W, int accumulate, aide_stream_t stream);
+int aide_maxpool2x2_bwd_mixed(const void* x, int x_bf16, int64_t x_bs, const void* dy, int dy_bf16, int64_t dy_bs, void* dx,
+                              int dx_bf16, int64_t dx_bs, int N, int C, int H, int W, int accumulate, aide_stream_t stream);
+int aide_upsample2x_bilinear_bwd_mixed(const void* dy, int dy_bf16, int64_t dy_bs, void* dx, int dx_bf16, int64_t dx_bs,
+                                       int N, int C, int H, int W, int accumulate, aide_stream_t stream);
 int aide_upsample2x_bilinear_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, void* y, int y_bf16, int64_t y_bs, int N,
                                        int C, int H, int W, aide_stream_t stream);
 int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int N, int C,
@@ -210,8 +212,8 @@ size_t aide_head1x1_ws_bytes(int C, int K);
 int aide_head1x1_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, const float* w, const float* b, float* y,
                            int64_t y_bs, int N, int C, int K, int H, int W, aide_stream_t stream);
 int aide_head1x1_bwd_mixed(const float* dy, int64_t dy_bs, const void* x, int x_bf16, int64_t x_bs, const float* w,
-                           float* dx, int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
-                           aide_stream_t stream);
+                           void* dx, int dx_bf16, int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W,
+                           void* ws, aide_stream_t stream);
 int aide_head1x1_bwd(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, const float* w,
                      float* dx, int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W,
                      void* ws, aide_stream_t stream);

@@ -65,9 +65,23 @@ class _ConvBf16(torch.autograd.Function):
         return dx, dw, dy.sum((0, 2, 3))
 
 
+STORE_G_BF16 = [True]       # gradients of the bf16-stored activations are stored as bf16 as well (engine.STORE_G_BF16)
+
+
+class _Store(torch.autograd.Function):
+    """A bf16-stored activation: the value is rounded on the way forward, its (summed) gradient on the way back."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return rb(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return rb(g) if STORE_G_BF16[0] else g
+
+
 def _round_st(t):
-    """bf16 rounding of a stored activation, straight-through for the gradient (gradients of activations stay fp32)."""
-    return t + (rb(t) - t).detach()
+    return _Store.apply(t)
 
 
 def _store_hook(mod, inp, out):

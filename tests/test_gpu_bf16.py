@@ -230,6 +230,69 @@ def test_bf16_stored_activations(dev):
     assert torch.equal(ya, yb)
 
 
+def test_bf16_stored_activation_gradients(dev):
+    """Operators that read / write / accumulate a bf16-stored activation gradient == the fp32-storage operators on the
+    widened input, the result narrowed RNE once per write."""
+    from aide_amd import ops
+    g = torch.Generator().manual_seed(44)
+    n, c, h, w = 2, 64, 16, 64
+    x = torch.randn(n, c, h, w, generator=g).to(dev)
+    # BatchNorm backward reading a bf16 dA
+    z = torch.randn(n, c, h, w, generator=g).to(dev).bfloat16()
+    dA16 = torch.randn(n, c, h, w, generator=g).to(dev).bfloat16()
+    st = [torch.empty(c, device=dev) for _ in range(4)]
+    gam, bet = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+    a = torch.empty(n, c, h, w, device=dev)
+    ops.bn_train_fwd(z, a, gam, bet, 1e-5, 0.1, torch.zeros(c, device=dev), torch.ones(c, device=dev),
+                     torch.zeros((), dtype=torch.long, device=dev), st[0], st[1], st[2], st[3], ops.bn_ws(c, dev), True)
+    res = []
+    for dA in (dA16, dA16.float()):
+        dz = torch.empty(n, c, h, w, device=dev, dtype=torch.bfloat16)
+        dg, db, dbias = (torch.empty(c, device=dev) for _ in range(3))
+        ops.bn_relu_bwd(dA, z, dz, st[0], st[1], st[2], st[3], dg, db, dbias, ops.bn_ws(c, dev), True)
+        res.append((dz, dg, db))
+    assert all(torch.equal(p, q) for p, q in zip(*res))
+    # max-pool backward: bf16 dy in, bf16 dx out, overwrite and accumulate
+    dy16 = torch.randn(n, c, h // 2, w // 2, generator=g).to(dev).bfloat16()
+    base16 = torch.randn(n, c, h, w, generator=g).to(dev).bfloat16()
+    for acc in (False, True):
+        d16, d32 = base16.clone(), base16.float()
+        ops.maxpool2x2_bwd(x, dy16, d16, accumulate=acc)
+        ops.maxpool2x2_bwd(x, dy16.float(), d32, accumulate=acc)
+        assert torch.equal(d16, d32.bfloat16()), 'pool bwd accumulate=%s' % acc
+    # up-sampling backward
+    du16 = torch.randn(n, c, 2 * h, 2 * w, generator=g).to(dev).bfloat16()
+    for acc in (False, True):
+        d16, d32 = base16.clone(), base16.float()
+        ops.upsample2x_bwd(du16, d16, accumulate=acc)
+        ops.upsample2x_bwd(du16.float(), d32, accumulate=acc)
+        err = (d16.float() - d32).abs() - 2.0 ** -8 * d32.abs()
+        assert float(err.max()) <= 1e-6, 'upsample bwd accumulate=%s' % acc
+    # head dgrad into a bf16 gradient buffer
+    wh = torch.randn(2, c, generator=g).to(dev)
+    dl = torch.randn(n, 2, h, w, generator=g).to(dev)
+    dx16, dx32 = torch.empty(n, c, h, w, device=dev, dtype=torch.bfloat16), torch.empty(n, c, h, w, device=dev)
+    dw, db = torch.empty(2, c, device=dev), torch.empty(2, device=dev)
+    ops.head1x1_bwd(dl, x, wh, dx16, dw, db)
+    ops.head1x1_bwd(dl, x, wh, dx32, dw, db)
+    assert torch.equal(dx16, dx32.bfloat16())
+    # conv dgrad: bf16 dz in, bf16 dA out, overwrite / accumulate, with and without split-K
+    ci, co = 64, 128
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * 0.05).to(dev)
+    _, ud = ops.bf16_pack(wt)
+    dz16 = torch.randn(n, co, h, w, generator=g).to(dev).bfloat16()
+    for splitk in (1, 2):
+        for acc in (False, True):
+            d16, d32 = base16.clone(), base16.float()
+            ops.conv3x3_bf16(dz16, ud, None, d16, accumulate=acc, splitk=splitk)
+            ops.conv3x3_bf16(dz16, ud, None, d32, accumulate=acc, splitk=splitk)
+            assert torch.equal(d16, d32.bfloat16()), 'dgrad splitk=%d accumulate=%s' % (splitk, acc)
+    # zero fill of a channel slice of a bf16 buffer
+    buf = torch.ones(n, c + 32, h, w, device=dev, dtype=torch.bfloat16)
+    ops.fill_zero(buf[:, 32:])
+    assert float(buf[:, 32:].float().abs().max()) == 0.0 and float(buf[:, :32].float().min()) == 1.0
+
+
 def test_conv3x3_bf16_channel_slices(dev):
     """inputs / outputs that are channel slices of concatenation buffers (explicit batch stride)."""
     from aide_amd import ops
@@ -313,11 +376,13 @@ def test_bf16_network_vs_bf16_oracle(dev, kind, store):
     LOGIT_TOL, LOSS_TOL, GRAD_TOL = (6e-2, 2e-3, 8e-2) if store else (1e-2, 5e-3, 5e-2)
     E.STORE_BF16[0] = OB.STORE_Z_BF16[0] = store
     E.STORE_A_BF16[0] = OB.STORE_A_BF16[0] = store
+    E.STORE_G_BF16[0] = OB.STORE_G_BF16[0] = store
     try:
         _network_vs_oracle(dev, kind, LOGIT_TOL, LOSS_TOL, GRAD_TOL)
     finally:
         E.STORE_BF16[0] = OB.STORE_Z_BF16[0] = True
         E.STORE_A_BF16[0] = OB.STORE_A_BF16[0] = True
+        E.STORE_G_BF16[0] = OB.STORE_G_BF16[0] = True
 
 
 def _network_vs_oracle(dev, kind, LOGIT_TOL, LOSS_TOL, GRAD_TOL):
