@@ -41,12 +41,14 @@ def main():
         if not ops.bf16_supported(ci, h, w, co):
             print('%4d->%4d @%3d  unsupported' % (ci, co, h))
             continue
-        x = torch.randn(n, ci, h, w, device=dev)
-        dy = torch.randn(n, co, h, w, device=dev)
+        store = os.environ.get('AIDE_SWEEP_STORE', '1') != '0' and ci % 16 == 0     # bf16-stored tensors (engine default)
+        sdt = torch.bfloat16 if store else torch.float32
+        x = torch.randn(n, ci, h, w, device=dev).to(sdt)
+        dy = torch.randn(n, co, h, w, device=dev).to(sdt)
         wt = torch.randn(co, ci, 3, 3, device=dev) * 0.05
         b = torch.zeros(co, device=dev)
-        y = torch.empty(n, co, h, w, device=dev)
-        dx = torch.empty(n, ci, h, w, device=dev)
+        y = torch.empty(n, co, h, w, device=dev, dtype=torch.bfloat16 if os.environ.get('AIDE_SWEEP_STORE', '1') != '0' else torch.float32)
+        dx = torch.empty(n, ci, h, w, device=dev, dtype=sdt)
         dw = torch.empty_like(wt)
         uf, ud = ops.bf16_pack(wt, need_dgrad=ci % 32 == 0)
         flops = 2.0 * n * h * w * ci * co * 9
