@@ -484,6 +484,8 @@ class Plan(object):
         # a side stream as soon as its dz exists, so the HBM-bound kernels of the next layer run in
         # its shadow instead of between two MFMA kernels.
         main = torch.cuda.current_stream()
+        # (with a profiler attached the step runs on ONE stream: an event pair then brackets exactly one kernel's own time,
+        # not its time under contention with the side stream -- bench.py instruments a single step for that reason)
         side = self.side if (self.overlap and self.profiler is None) else None
         if side is not None:
             side.wait_stream(main)
@@ -518,7 +520,11 @@ class Plan(object):
                         ev.record(main)
                         with torch.cuda.stream(side):
                             side.wait_event(ev)
+                            if prof is not None:
+                                prof.begin(WGRAD_TAG[st['wino_w']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_w']])
                             wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
+                            if prof is not None:
+                                prof.end()
                     else:
                         if prof is not None:
                             prof.begin(WGRAD_TAG[st['wino_w']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_w']])

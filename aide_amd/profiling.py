@@ -10,18 +10,28 @@ class KernelTimer(object):
     really multiplies (16/36 of it for a Winograd F(2x2,3x3) launch). Events are resolved after a device
     synchronise by summary()."""
 
-    def __init__(self):
+    def __init__(self, reserve=0):
         self.records = []
         self._open = None
+        # events are created up front: creating them inside the timed region costs far more than recording them
+        # (hundreds of hipEventCreate calls stalled the launch queue by ~14 ms per instrumented step)
+        self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reserve)]
+        for e in self._pool:             # first record of an event allocates its completion signal: do it out here too
+            e.record()
+        if self._pool:
+            torch.cuda.synchronize()
+
+    def _event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
 
     def begin(self, tag, flops, executed=None):
-        e0 = torch.cuda.Event(enable_timing=True)
+        e0 = self._event()
         e0.record()
         self._open = (tag, flops, flops if executed is None else executed, e0)
 
     def end(self):
         tag, flops, executed, e0 = self._open
-        e1 = torch.cuda.Event(enable_timing=True)
+        e1 = self._event()
         e1.record()
         self.records.append((tag, flops, executed, e0, e1))
         self._open = None
