@@ -233,17 +233,28 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
 #ifdef AIDE_PROBE_SETPRIO
             __builtin_amdgcn_s_setprio(1);
 #endif
+#ifndef AIDE_PROBE_NO_MFMA
 #pragma unroll
             for (int m = 0; m < WM; ++m)
 #pragma unroll
                 for (int nt = 0; nt < WN; ++nt)
                     acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[m], bfc[nt], acc[m][nt], 0, 0, 0);
+#else       // ablation probe: keep the fragments alive without the matrix pipe
+#pragma unroll
+            for (int m = 0; m < WM; ++m) acc[m][0][0] += __builtin_bit_cast(f32x4, afc[m])[0];
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) acc[0][nt][1] += __builtin_bit_cast(f32x4, bfc[nt])[0];
+#endif
 #ifdef AIDE_PROBE_SETPRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
             if (t < NOPS) {
+#ifndef AIDE_PROBE_NO_PUT
                 put(t, nxt);               // chunk + 1 (fetched one stage ago) -> the other buffer
+#endif
+#ifndef AIDE_PROBE_NO_FETCH
                 fetch(t, chunk + 2);       // its registers re-issue their loads at once
+#endif
             }
             // a wave issues in order: left alone, the staging instructions queue up behind the last MFMA and the
             // matrix pipe drains.  Interleave: after each MFMA one fragment read, two conversions, one LDS store,
@@ -275,37 +286,86 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
     }
 
     // ---- epilogue: D row i = (r&3) + 8*(r>>2) + 4*half (output channel), column j (pixel) ----
+#ifdef AIDE_PROBE_NO_STORE
+    if (a.N > 0) { if (acc[0][0][0] == 123.456f) ((float*)a.y)[0] = acc[WM - 1][WN - 1][15]; return; }
+#endif
     const bool add_bias = (a.bias != nullptr) && (split == 0);
     if constexpr (OUT_BF16) {
-        // bf16 z: registers r, r+1 are channels i, i+1 at pixel j.  Neighbouring lanes swap one value (DPP) so that an
-        // even lane owns channel i at pixels (j, j+1) and an odd lane channel i+1 at (j-1, j): one packed dword each.
+        // bf16 output through LDS.  Registers r, r+1 are channels i, i+1 at pixel j: neighbouring lanes swap one value
+        // (DPP) so that an even lane owns channel i at pixels (j, j+1) and an odd lane channel i+1 at (j-1, j), one
+        // packed dword each -- stored straight to HBM those dwords form 64-byte pieces (half cache lines), and the
+        // ablation (tools/ab_bf16_probes.sh) showed the stores, not the loads or the MFMAs, bounding the <= 128-channel
+        // layers (64->64 @512x512: 0.286 ms, 0.135 ms without the stores).  So the tile is first assembled in the (now
+        // idle) stage buffers as [co][row][pixel] and leaves as 16-byte pieces per lane: 128 / 64 contiguous bytes per
+        // (channel, row), eight such runs per instruction, a quarter of the store instructions.
+        constexpr int EP = TH * TW / 2 + 16;          // dwords per channel (+16: odd / even lanes hit disjoint banks)
+        static_assert(WM * 32 * EP * 4 <= 2 * BUF * 16, "epilogue tile must fit the stage buffers");
+        unsigned* ep = reinterpret_cast<unsigned*>(lds);
         uint16_t* yn = (uint16_t*)a.y + (long)n * a.y_bs;
         const int odd = j & 1;
+        if (a.accumulate) {
+            // a second / third writer of a bf16-stored gradient (skip paths): fp32 add to the stored value, ONE rounding
+            // -- straight from the accumulators (the LDS tile holds already-rounded values)
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) {
-            const int oh = h0 + (wave_n * WN + nt) / CB;
-            const int ow = w0 + ((wave_n * WN + nt) % CB) * 32 + (j & ~1);
-            const bool pok = oh < a.H;
+            for (int nt = 0; nt < WN; ++nt) {
+                const int oh = h0 + (wave_n * WN + nt) / CB;
+                const int ow = w0 + ((wave_n * WN + nt) % CB) * 32 + (j & ~1);
 #pragma unroll
-            for (int m = 0; m < WM; ++m) {
+                for (int m = 0; m < WM; ++m) {
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float own0 = acc[m][nt][r], own1 = acc[m][nt][r + 1];
-                    const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own0), 0xB1, 0xf, 0xf, true));
-                    const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own1), 0xB1, 0xf, 0xf, true));
-                    const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
-                    float lo = odd ? t1 : own0, hi = odd ? own1 : t0;
-                    if (add_bias) { const float b = a.bias[co]; lo += b; hi += b; }
-                    if (pok) {
-                        unsigned* q = reinterpret_cast<unsigned*>(yn + (long)co * HW + oh * a.W + ow);
-                        if (a.accumulate) {           // bf16-stored activation gradient with several writers (skip paths)
+                    for (int r = 0; r < 16; r += 2) {
+                        const float own0 = acc[m][nt][r], own1 = acc[m][nt][r + 1];
+                        const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own0), 0xB1, 0xf, 0xf, true));
+                        const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own1), 0xB1, 0xf, 0xf, true));
+                        const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
+                        float lo = odd ? t1 : own0, hi = odd ? own1 : t0;
+                        if (add_bias) { const float b = a.bias[co]; lo += b; hi += b; }
+                        if (oh < a.H) {
+                            unsigned* q = reinterpret_cast<unsigned*>(yn + (long)co * HW + oh * a.W + ow);
                             const unsigned old = *q;
-                            lo += bf16_lo(old); hi += bf16_hi(old);
+                            *q = pk_bf16(lo + bf16_lo(old), hi + bf16_hi(old));
                         }
-                        *q = pk_bf16(lo, hi);
                     }
                 }
             }
+            return;
+        }
+#pragma unroll
+        for (int pass = 0; pass < WAVES_M; ++pass) {   // 64 channels (one wave_m row of waves) per pass
+            if (wave_m == pass) {
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt) {
+                    const int row = (wave_n * WN + nt) / CB;
+                    const int colp = ((wave_n * WN + nt) % CB) * 16 + (j >> 1);
+#pragma unroll
+                    for (int m = 0; m < WM; ++m) {
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const float own0 = acc[m][nt][r], own1 = acc[m][nt][r + 1];
+                            const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own0), 0xB1, 0xf, 0xf, true));
+                            const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own1), 0xB1, 0xf, 0xf, true));
+                            const int cl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;      // channel within the pass
+                            float lo = odd ? t1 : own0, hi = odd ? own1 : t0;
+                            if (add_bias) { const float b = a.bias[co0 + pass * WM * 32 + cl]; lo += b; hi += b; }
+                            ep[cl * EP + row * (TW / 2) + colp] = pk_bf16(lo, hi);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            constexpr int SEG = TW / 8;                // 16-byte pieces per tile row
+            constexpr int NCH = WM * 32 * TH * SEG;    // pieces of this pass
+#pragma unroll
+            for (int k = 0; k < (NCH + NT - 1) / NT; ++k) {
+                const int q = tid + k * NT;
+                const int seg = q % SEG, row = (q / SEG) % TH, cl = q / (SEG * TH);
+                const int oh = h0 + row;
+                if (q < NCH && oh < a.H) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(ep + cl * EP + row * (TW / 2) + seg * 4);
+                    *reinterpret_cast<u32x4*>(yn + (long)(co0 + pass * WM * 32 + cl) * HW + (long)oh * a.W + w0 + seg * 8) = v;
+                }
+            }
+            if (pass + 1 < WAVES_M) __syncthreads();
         }
     } else {
         float* yn = (float*)a.y + (long)split * a.split_stride + (long)n * a.y_bs;
