@@ -718,35 +718,68 @@ __global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel
         const u32x4* pb = lds + cur * G::BUF + lb;
         u32x4* nxt = lds + (cur ^ 1) * G::BUF;
         set_chunk(chunk + 2);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {             // k-step = (dz row r, 16-pixel half segment hs)
+        // Operand registers are double buffered by hand: the LDS reads of k-step ks + 1 are ISSUED FIRST in k-step ks
+        // (one group, ahead of its MFMAs) and consumed a whole k-step later.  The ablation build without MFMAs ran at
+        // 88 % of the full kernel: every "read window -> s_waitcnt lgkmcnt(0) -> shift -> MFMA" group exposed the LDS
+        // round trip (~150 cycles, 40 times per stage) with one wave per SIMD to hide it.
+        bf16x8 afA, afB;
+        u32x4 wA[3][2], wB[3][2];
+        auto load_ops = [&](int ks, bf16x8& af, u32x4 (&wv)[3][2]) {
             const int r = ks >> 1, hs = ks & 1;
-            const bf16x8 af = __builtin_bit_cast(bf16x8, pa[r * 4 + hs * 2]);
+            af = __builtin_bit_cast(bf16x8, pa[r * 4 + hs * 2]);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                const u32x4 w0v = pb[(r + kh) * 5 + hs * 2];
-                const u32x4 w1v = pb[(r + kh) * 5 + hs * 2 + 1];
+                wv[kh][0] = pb[(r + kh) * 5 + hs * 2];
+                wv[kh][1] = pb[(r + kh) * 5 + hs * 2 + 1];
+            }
+        };
+        load_ops(0, afA, wA);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {             // k-step = (dz row r, 16-pixel half segment hs)
+            const bf16x8& af = (ks & 1) ? afB : afA;
+            u32x4 (&wv)[3][2] = (ks & 1) ? wB : wA;
+            if (ks + 1 < KS) { if (ks & 1) load_ops(ks + 1, afA, wA); else load_ops(ks + 1, afB, wB); }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const u32x4 w0v = wv[kh][0];
+                const u32x4 w1v = wv[kh][1];
                 u32x4 s1, s2;
+#ifndef AIDE_PROBE_WG_NO_SHIFT
                 s1[0] = __builtin_amdgcn_alignbit(w0v[1], w0v[0], 16);
                 s1[1] = __builtin_amdgcn_alignbit(w0v[2], w0v[1], 16);
                 s1[2] = __builtin_amdgcn_alignbit(w0v[3], w0v[2], 16);
                 s1[3] = __builtin_amdgcn_alignbit(w1v[0], w0v[3], 16);
                 s2[0] = w0v[1]; s2[1] = w0v[2]; s2[2] = w0v[3]; s2[3] = w1v[0];
+#else
+                s1 = w0v; s2 = w1v;
+#endif
+#ifndef AIDE_PROBE_WG_NO_MFMA
                 acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, w0v), acc[kh * 3 + 0], 0, 0, 0);
                 acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, s1), acc[kh * 3 + 1], 0, 0, 0);
                 acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, s2), acc[kh * 3 + 2], 0, 0, 0);
+#else
+                acc[kh * 3 + 0][0] += __builtin_bit_cast(f32x4, w0v)[0] + __builtin_bit_cast(f32x4, af)[0];
+                acc[kh * 3 + 1][0] += __builtin_bit_cast(f32x4, s1)[1];
+                acc[kh * 3 + 2][0] += __builtin_bit_cast(f32x4, s2)[2];
+#endif
             }
             // staging: chunk + 1 registers -> the other buffer, then re-issue their loads for chunk + 2
 #pragma unroll
             for (int k = 0; k < OPK; ++k) {
                 const int op = ks * OPK + k;
-                if (op < NOPS) { put(op, nxt); fetch(op); }
+#ifndef AIDE_PROBE_WG_NO_PUT
+                if (op < NOPS) put(op, nxt);
+#endif
+#ifndef AIDE_PROBE_WG_NO_FETCH
+                if (op < NOPS) fetch(op);
+#endif
             }
-            // in-order issue: spread the window reads, shifts and staging between the nine MFMAs of the k-step
+            // issue order: ALL operand reads of the next k-step first, then per MFMA three VALU (shifts / conversions),
+            // one LDS store, one global load
+            __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);       // DS reads (next k-step's operands)
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // VALU
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
