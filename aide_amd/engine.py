@@ -86,6 +86,8 @@ WGRAD_TAG = {0: 'conv3x3_wgrad_kernel', 2: 'conv3x3_wgrad_wino_kernel', 4: 'conv
              BF16: 'conv3x3_wgrad_bf16_kernel'}
 PRECISIONS = ('fp32', 'bf16')
 USE_WINOGRAD4 = [True]
+import os as _os
+PROBE_SKIP_WGRAD = [bool(_os.environ.get('AIDE_PROBE_SKIP_WGRAD'))]
 STORE_BF16 = [True]            # precision='bf16': z / dz stored as bf16 (A-B switch)
 STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 where every reader / writer allows it
 STORE_G_BF16 = [True]          # ... and the gradients of those activations
@@ -512,9 +514,12 @@ class Plan(object):
                 x = self.view(st['src'], inputs)
                 if kind == 'conv':
                     prof = self.profiler
-                    wgrad = (ops.conv3x3_wgrad_bf16 if st['wino_w'] == BF16 else
-                             ops.conv3x3_wgrad_wino4 if st['wino_w'] == 4 else
-                             ops.conv3x3_wgrad_wino if st['wino_w'] else ops.conv3x3_wgrad)
+                    if PROBE_SKIP_WGRAD[0]:            # ablation probe (results wrong): upper bound of what a faster wgrad buys
+                        wgrad = lambda *a, **k: None
+                    else:
+                        wgrad = (ops.conv3x3_wgrad_bf16 if st['wino_w'] == BF16 else
+                                 ops.conv3x3_wgrad_wino4 if st['wino_w'] == 4 else
+                                 ops.conv3x3_wgrad_wino if st['wino_w'] else ops.conv3x3_wgrad)
                     if side is not None:
                         ev = torch.cuda.Event()
                         ev.record(main)
