@@ -546,24 +546,30 @@ struct BgArgs {
 };
 
 // R = image rows of dz per stage (4, or 2: half the staging registers -> two workgroups per CU)
-template <int R> struct GCfg {
+// R = image rows of dz per stage (4, or 2: half the staging registers -> two workgroups per CU); NWCO = co blocks of 32
+// per workgroup: 2 (64 co x 64 ci, 4 waves) or 4 (128 co x 64 ci, 8 waves = two per SIMD: the four co blocks share one
+// x tile, halving the x bytes through L2 / L1 / LDS per MFMA, and a second wave per SIMD covers the other's stalls)
+template <int R, int NWCO> struct GCfg {
+    static constexpr int NT = 128 * NWCO;            // threads
+    static constexpr int TCO = 32 * NWCO;            // output channels per workgroup
     static constexpr int DZP = R * 4 + 1;            // slots per dz channel (odd: conflict-free b128 across channels)
     static constexpr int XP = (R + 2) * 5 + 1;       // slots per x channel: R + 2 rows x 5 slots (columns -1 .. 38)
-    static constexpr int DZS = 64 * DZP;
+    static constexpr int DZS = TCO * DZP;
     static constexpr int BUF = DZS + 64 * XP + 1;    // slots per stage buffer (+ 1 dump slot for idle staging lanes)
-    static constexpr int ND = R;                     // dz units per thread      (64 co x R rows x 4 blocks / 256)
-    static constexpr int NM = R + 2;                 // x main units per thread  (64 ci x (R + 2) rows x 4 slots / 256)
-    static constexpr int NE = (64 * (R + 2) + 255) / 256;      // x edge units per thread
+    static constexpr int ND = TCO * R * 4 / NT;                  // dz units per thread      (TCO co x R rows x 4 blocks)
+    static constexpr int NM = (64 * (R + 2) * 4 + NT - 1) / NT;  // x main units per thread  (64 ci x (R + 2) rows x 4 slots)
+    static constexpr int NE = (64 * (R + 2) + NT - 1) / NT;      // x edge units per thread
     static constexpr int NOPS = ND + NM + NE;
     static constexpr int KS = 2 * R;                 // k-steps per stage
+    static_assert(TCO * R * 4 % NT == 0 && 64 * (R + 2) * 4 % NT == 0, "staging units must divide evenly");
 };
 constexpr int G_RMIN = 2;
 
-template <int R, bool DZ_BF16, bool X_BF16>
-__global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel(const BgArgs g) {
+template <int R, bool DZ_BF16, bool X_BF16, int NWCO>
+__global__ __launch_bounds__(128 * NWCO, (R == 2 && NWCO == 2) ? 2 : 1) void conv3x3_wgrad_bf16_kernel(const BgArgs g) {
     constexpr unsigned XE = X_BF16 ? 2u : 4u;        // bytes per x element
-    using G = GCfg<R>;
-    constexpr int ND = G::ND, NM = G::NM, NE = G::NE, NOPS = G::NOPS, KS = G::KS;
+    using G = GCfg<R, NWCO>;
+    constexpr int ND = G::ND, NM = G::NM, NE = G::NE, NOPS = G::NOPS, KS = G::KS, NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * G::BUF slots
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int half = lane >> 5, j = lane & 31;
@@ -573,7 +579,7 @@ __global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel
     const int ci_tile = b % g.n_ci_tiles;    b /= g.n_ci_tiles;   // tiles of one pixel range are neighbours: they
     const int co_tile = b % g.n_co_tiles;                         // share its dz / x rows in the XCD's L2
     const int split = b / g.n_co_tiles;
-    const int co0 = co_tile * 64, ci0 = ci_tile * 64;
+    const int co0 = co_tile * G::TCO, ci0 = ci_tile * 64;
     const int HW = g.H * g.W;
     const int cps = (g.chunks_total + g.splits - 1) / g.splits;
     const int c_begin = split * cps;
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel
     unsigned offD[ND], ldsD[ND];
 #pragma unroll
     for (int e = 0; e < ND; ++e) {
-        const int u = tid + e * 256;
+        const int u = tid + e * NT;
         const int blk = u & 3, row = (u >> 2) % R, co = u / (4 * R);
         offD[e] = (co0 + co < g.Co) ? (unsigned)(co * HW + row * g.W + blk * 8) * (DZ_BF16 ? 2u : 4u) : BUF_OOB;
         ldsD[e] = (unsigned)(co * G::DZP + row * 4 + blk);
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel
     unsigned offM[NM], ldsM[NM], flagM[NM];
 #pragma unroll
     for (int e = 0; e < NM; ++e) {
-        const int u = tid + e * 256;
+        const int u = tid + e * NT;
         const int s = u & 3, rr = u >> 2;
         const int row = rr % (R + 2), ci = rr / (R + 2);
         // fp32: descriptor base = column -1, the unit's 16-byte loads start at column 8s; bf16: base = column -2 (the
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel
     unsigned offE[NE], ldsE[NE], flagE[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
-        const int u = tid + e * 256;
+        const int u = tid + e * NT;
         const int row = u % (R + 2), ci = u / (R + 2);
         const bool ok = u < 64 * (R + 2) && ci0 + ci < g.Ci;
         offE[e] = ok ? (unsigned)(ci * HW + row * g.W + 32) * XE : BUF_OOB;   // fp32: column 31 (base = column -1); bf16: pair (30, 31) (base = column -2)
@@ -802,19 +808,21 @@ __global__ __launch_bounds__(256, R == 2 ? 2 : 1) void conv3x3_wgrad_bf16_kernel
     }
 }
 
-template <int R, bool DZ_BF16, bool X_BF16>
+template <int R, bool DZ_BF16, bool X_BF16, int NWCO>
 int launch_wgrad_bf16(BgArgs g, hipStream_t stream) {
-    constexpr int LDS_BYTES = 2 * GCfg<R>::BUF * 16;
+    constexpr int LDS_BYTES = 2 * GCfg<R, NWCO>::BUF * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<R, DZ_BF16, X_BF16>,
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<R, DZ_BF16, X_BF16, NWCO>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
     g.bands_h = g.H / R;
     g.chunks_total = g.N * g.segs_w * g.bands_h;
+    g.n_co_tiles = (g.Co + 32 * NWCO - 1) / (32 * NWCO);
     const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
-    hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<R, DZ_BF16, X_BF16>), dim3((unsigned)nb), dim3(256), LDS_BYTES, stream, g);
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<R, DZ_BF16, X_BF16, NWCO>), dim3((unsigned)nb), dim3(128 * NWCO), LDS_BYTES,
+                       stream, g);
     return aide_launch_status();
 }
 
@@ -822,6 +830,14 @@ int launch_wgrad_bf16(BgArgs g, hipStream_t stream) {
 int wgrad_bf16_rows() {
     static const int r = getenv("AIDE_BF16_WG_R") ? atoi(getenv("AIDE_BF16_WG_R")) : 4;
     return r == 2 ? 2 : 4;
+}
+// co blocks per workgroup: the 128 x 64 tile (8 waves) pays on the large layers (>= 150 GFLOP: 1.06 vs 0.84 PFLOP/s on
+// 1024->512 @64x64 x8); below that it doubles the split count for nothing (probe switch AIDE_BF16_WG_NWCO: 2 = never)
+int wgrad_bf16_nwco(int N, int Co, int Ci, int H, int W) {
+    static const int f = getenv("AIDE_BF16_WG_NWCO") ? atoi(getenv("AIDE_BF16_WG_NWCO")) : 4;
+    const double flops = 18.0 * N * H * W * (double)Co * Ci;
+    const char* mf = getenv("AIDE_BF16_WG_NWCO_MINFLOPS");       // tests lower the threshold to reach the 8-wave kernel
+    return (f == 4 && Co % 128 == 0 && wgrad_bf16_rows() == 4 && flops >= (mf ? atof(mf) : 1.5e11)) ? 4 : 2;
 }
 
 }  // namespace
@@ -918,7 +934,8 @@ int aide_conv3x3_wgrad_bf16_supported(int Co, int Ci, int H, int W) {
 }
 
 int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W) {
-    const long tiles = (long)((Co + 63) / 64) * ((Ci + 63) / 64);
+    const int tco = 32 * wgrad_bf16_nwco(N, Co, Ci, H, W);
+    const long tiles = (long)((Co + tco - 1) / tco) * ((Ci + 63) / 64);
     const long chunks = (long)N * (H / wgrad_bf16_rows()) * (W / 32);
     static const long target = getenv("AIDE_BF16_WG_TARGET") ? atol(getenv("AIDE_BF16_WG_TARGET")) : 256;   // probe
     long s = (target + tiles - 1) / tiles;       // one round of workgroups, one per CU (512 / 1024 measured 6 % / 16 % slower:
@@ -945,9 +962,11 @@ int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, co
     g.segs_w = W / 32;
     g.splits = aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W);
     int rc;
-#define AIDE_WG(RR) (dz_bf16 ? (a_bf16 ? launch_wgrad_bf16<RR, true, true>(g, stream) : launch_wgrad_bf16<RR, true, false>(g, stream)) \
-                             : (a_bf16 ? launch_wgrad_bf16<RR, false, true>(g, stream) : launch_wgrad_bf16<RR, false, false>(g, stream)))
-    if (wgrad_bf16_rows() == 2) rc = AIDE_WG(2); else rc = AIDE_WG(4);
+#define AIDE_WG(RR, NW) (dz_bf16 ? (a_bf16 ? launch_wgrad_bf16<RR, true, true, NW>(g, stream) : launch_wgrad_bf16<RR, true, false, NW>(g, stream)) \
+                                 : (a_bf16 ? launch_wgrad_bf16<RR, false, true, NW>(g, stream) : launch_wgrad_bf16<RR, false, false, NW>(g, stream)))
+    if (wgrad_bf16_rows() == 2) rc = AIDE_WG(2, 2);
+    else if (wgrad_bf16_nwco(N, Co, Ci, H, W) == 4) rc = AIDE_WG(4, 4);
+    else rc = AIDE_WG(4, 2);
 #undef AIDE_WG
     if (rc != 0) return rc;
     return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, stream);

@@ -316,6 +316,24 @@ WGRAD_CASES = [
 ]
 
 
+@pytest.mark.parametrize('case', [(2, 256, 256, 32, 32), (1, 128, 64, 32, 96), (1, 128, 40, 8, 32)])
+def test_conv3x3_wgrad_bf16_wide_tile(dev, case, monkeypatch):
+    """the 128 co x 64 ci (8-wave) weight-gradient kernel, normally reserved for >= 150 GFLOP layers"""
+    monkeypatch.setenv('AIDE_BF16_WG_NWCO_MINFLOPS', '0')
+    test_conv3x3_wgrad_bf16(dev, case)
+    from aide_amd import ops
+    n, co, ci, h, w = case
+    g = torch.Generator().manual_seed(1)
+    x16 = torch.randn(n, ci - ci % 8, h, w, generator=g).to(dev).bfloat16()
+    dz16 = torch.randn(n, co, h, w, generator=g).to(dev).bfloat16()
+    dw_wide = torch.empty(co, x16.shape[1], 3, 3, device=dev)
+    ops.conv3x3_wgrad_bf16(dz16, x16, dw_wide)                       # bf16-stored operands through the wide tile
+    monkeypatch.setenv('AIDE_BF16_WG_NWCO_MINFLOPS', '1e30')
+    dw_ref = torch.empty_like(dw_wide)
+    ops.conv3x3_wgrad_bf16(dz16, x16, dw_ref)
+    _close(dw_wide, dw_ref, 2e-5, 'wide vs 64x64 tile %s' % (case,))
+
+
 @pytest.mark.parametrize('case', WGRAD_CASES)
 def test_conv3x3_wgrad_bf16(dev, case):
     from aide_amd import ops
