@@ -480,3 +480,32 @@ def test_bf16_mode_close_to_fp32_mode(dev):
     assert _rel(outs['bf16'], outs['fp32']) < 0.3
     with pytest.raises(ValueError):
         net.engine.precision = 'fp16'
+
+
+def test_bf16_step_is_bit_reproducible(dev):
+    """Two identical training steps of the bf16 mode at 256x256 (all three conv tile variants, the LDS epilogue, the 8-wave
+    kernels, split-K and slab reductions, bf16 read-add-round accumulation) give bit-identical logits, loss and parameter
+    gradients: no atomics, no races, fixed summation orders."""
+    from aide_amd import utils as U
+    from aide_amd.models_twomodalinputs import fuseunet
+    g = torch.Generator().manual_seed(11)
+    x1 = torch.randn(2, 3, 256, 256, generator=g).to(dev)
+    x2 = torch.randn(2, 3, 256, 256, generator=g).to(dev)
+    t = (torch.rand(2, 256, 256, generator=g) > 0.7).long().to(dev)
+    w = torch.tensor([1.0, 1.0])
+    crit = U.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(2)
+        net = fuseunet(2).to(dev)
+        net.engine.precision = 'bf16'
+        net.train()
+        out = net(x1, x2)
+        loss = crit(out, t)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((out.detach().clone(), loss.detach().clone(), [p.grad.clone() for p in net.parameters()]))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    for a, b in zip(runs[0][2], runs[1][2]):
+        assert torch.equal(a, b)
+    assert torch.isfinite(runs[0][1])
