@@ -102,6 +102,9 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img):
     from aide_amd.train_files.trainchaos_proposed_30cases1labeled import coteach_step
     n1, n2 = build('fuseunet', device), build('fuseunet', device)
     n1.train(); n2.train()
+    precision = args.precision or 'fp32'
+    n1.engine.precision = n2.engine.precision = precision
+    peak = BF16_MFMA_PEAK_TFLOPS if precision == 'bf16' else FP32_MFMA_PEAK_TFLOPS
     o1, o2 = Adam(n1.parameters(), lr=1e-4, amsgrad=True), Adam(n2.parameters(), lr=1e-4, amsgrad=True)
     op = CoTeachingProposedLoss(cediceweight=[1.0, 1.0], ceclassweight=[1.0, 1.0], segcor_weight=[1.0, 10.0])
     xin, xout, t = chaos_batch(batch, size, seed=1234 + rank)
@@ -126,12 +129,12 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img):
     print(json.dumps(dict(metric='training images/sec AIDE co-teaching (2x FuseUNet) %dx%dx2 bs=%d/GPU' % (size, size, batch),
                           value=round(value, 2), unit='images/sec', n_gpus=1, steps=args.steps, warmup=args.warmup,
                           ms_per_step=round(el / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
-                          vs_baseline=None, dtype='f32', data='synthetic',
+                          vs_baseline=None, dtype='f32' if precision == 'fp32' else 'bf16', data='synthetic',
                           config=dict(workload='c3 two fuseunet co-teaching step (4 aug fwd + fwd + bwd + Adam per net, '
-                                               'on-device reverseaug, fused selection), %dx%d, bs=%d, fp32' % (size, size, batch),
+                                               'on-device reverseaug, fused selection), %dx%d, bs=%d, %s' % (size, size, batch, precision),
                                       alg_gflop_per_image=gflop_img),
                           step_tflops=round(value * gflop_img / 1e3, 2),
-                          step_mfma_frac=round(value * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+                          step_mfma_frac=round(value * gflop_img / 1e3 / peak, 4),
                           final_loss=[round(float(r['loss1']), 6), round(float(r['loss2']), 6)],
                           roofline=None, cpu_baseline=None)))
 
