@@ -100,6 +100,7 @@ class GradAllReduce(object):
     def _launch(self, b):
         start, end, _ = self.sched.buckets[b]
         view = self.flat[start:end]
+        avg = dist.get_backend(self.pg) == 'nccl'          # RCCL averages in the collective itself: no extra pass
         if view.is_cuda:
             ev = torch.cuda.Event()
             ev.record()                                    # all kernels writing this bucket are enqueued
@@ -112,10 +113,15 @@ class GradAllReduce(object):
                 self.comm_stream.wait_event(ev)
                 if ev2 is not None:
                     self.comm_stream.wait_event(ev2)
-                # RCCL averages in the collective itself: no extra elementwise pass over the arena
-                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
+                self._reduce(view, avg)
         else:
-            # gloo (CPU unit tests only) has no AVG: pre-scale, then SUM
+            self._reduce(view, avg)
+
+    def _reduce(self, view, avg):
+        if avg:
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
+        else:
+            # gloo (CPU unit tests; AIDE_BENCH_BACKEND=gloo dry runs of the N>1 bench on one GPU) has no AVG
             view.div_(self.world)
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 

@@ -95,8 +95,10 @@ def cpu_baseline(model_name, batch, size, steps, max_threads):
 
 
 def main_coteach(args, rank, world, device, batch, size, gflop_img):
-    """BASELINE config 3 (not the headline): the AIDE proposed step on one GPU."""
+    """BASELINE config 3 (not the headline): the AIDE proposed step; N>1 = data-parallel replicas with per-replica
+    BatchNorm statistics and small-loss selection, both networks' gradients mean-all-reduced."""
     from aide_amd.optim import Adam
+    from aide_amd.distributed import GradAllReduce, broadcast_module
     from aide_amd.synthetic import chaos_batch
     from aide_amd.utils import CoTeachingProposedLoss
     from aide_amd.train_files.trainchaos_proposed_30cases1labeled import coteach_step
@@ -105,6 +107,9 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img):
     precision = args.precision or 'fp32'
     n1.engine.precision = n2.engine.precision = precision
     peak = BF16_MFMA_PEAK_TFLOPS if precision == 'bf16' else FP32_MFMA_PEAK_TFLOPS
+    if world > 1:
+        broadcast_module(n1); broadcast_module(n2)
+    reducers = [GradAllReduce(n1), GradAllReduce(n2)] if world > 1 else None      # installed on the engines
     o1, o2 = Adam(n1.parameters(), lr=1e-4, amsgrad=True), Adam(n2.parameters(), lr=1e-4, amsgrad=True)
     op = CoTeachingProposedLoss(cediceweight=[1.0, 1.0], ceclassweight=[1.0, 1.0], segcor_weight=[1.0, 10.0])
     xin, xout, t = chaos_batch(batch, size, seed=1234 + rank)
@@ -120,14 +125,26 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         r = step()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    value = batch * args.steps / el
+    if world > 1:
+        tmax = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    if rank != 0:
+        return
+    value = batch * world * args.steps / el
     print(json.dumps(dict(metric='training images/sec AIDE co-teaching (2x FuseUNet) %dx%dx2 bs=%d/GPU' % (size, size, batch),
-                          value=round(value, 2), unit='images/sec', n_gpus=1, steps=args.steps, warmup=args.warmup,
+                          value=round(value, 2), unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
                           ms_per_step=round(el / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
                           vs_baseline=None, dtype='f32' if precision == 'fp32' else 'bf16', data='synthetic',
                           config=dict(workload='c3 two fuseunet co-teaching step (4 aug fwd + fwd + bwd + Adam per net, '
@@ -148,11 +165,17 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product path has no CPU fallback)')
+    backend = os.environ.get('AIDE_BENCH_BACKEND', 'nccl')       # 'gloo': dry run of the N>1 flow with every rank on one GPU
+    if backend != 'nccl':
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from aide_amd import utils as U
     from aide_amd.optim import Adam
@@ -164,7 +187,10 @@ def main():
     if args.batch_size:
         batch = args.batch_size
     if model_name == 'coteach':
-        return main_coteach(args, rank, world, device, batch, size, gflop_img)
+        main_coteach(args, rank, world, device, batch, size, gflop_img)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     net = build(model_name, device)
     net.train()
     precision = args.precision or WORKLOAD_PRECISION.get(args.workload, 'fp32')
