@@ -10,11 +10,17 @@ from ..models_twomodalinputs.netblocks import (UNet_basic_down_block, UNet_basic
 
 class UNet(nn.Module):
     _ATTENTION = False
-    _ENC = ((3, 64), (64, 128), (128, 256), (256, 512), (512, 1024))             # UNet.py:139-143
-    _UP = ((1024, 512, 512), (512, 256, 256), (256, 128, 128), (128, 64, 64))    # UNet.py:145-148
+    _BASE = 64      # first-level width; the variants UNet128 ... UNet2 (UNet.py:210-400) differ only here
 
     def __init__(self, num_classes=2, learned_bilinear=False):
         nn.Module.__init__(self)
+        b0 = self._BASE
+        if b0 % 32:
+            # no silent fallback: the HIP convolution kernels tile output channels in blocks of 32
+            raise NotImplementedError('%s: channel widths below 32 are not covered by the HIP convolution kernels'
+                                      % type(self).__name__)
+        self._ENC = ((3, b0),) + tuple((b0 << k, b0 << (k + 1)) for k in range(4))      # UNet.py:139-143
+        self._UP = tuple((b0 << (5 - i), b0 << (4 - i), b0 << (4 - i)) for i in range(1, 5))   # UNet.py:145-148
         for i, (a, b) in enumerate(self._ENC, 1):
             blk = UNet_basic_down_block(a, b, i > 1)
             blk.max_pool = nn.MaxPool2d(2, 2)          # parameter-free; kept for module-tree parity
@@ -23,7 +29,7 @@ class UNet(nn.Module):
                 setattr(self, 'sa%d' % i, Spatial_Attention(b, reduction=16, dilation=4))
         for i, (a, p, o) in enumerate(self._UP, 1):
             setattr(self, 'up_block%d' % i, UNet_basic_up_block(a, p, o, learned_bilinear))
-        self.last_conv1 = nn.Conv2d(64, num_classes, 1, padding=0)
+        self.last_conv1 = nn.Conv2d(b0, num_classes, 1, padding=0)
         self._engine = [Engine(self, self._build_graph, num_classes)]
 
     @property
@@ -70,3 +76,33 @@ class UNet(nn.Module):
 class UNetsa(UNet):
     """models_singlemodalinput/UNet.py:168-208: UNet with a Spatial_Attention gate after every down block."""
     _ATTENTION = True
+
+
+class UNet128(UNet):
+    """models_singlemodalinput/UNet.py:210-240 (widths 128 ... 2048)."""
+    _BASE = 128
+
+
+class UNet32(UNet):
+    """models_singlemodalinput/UNet.py:242-272 (widths 32 ... 512)."""
+    _BASE = 32
+
+
+class UNet16(UNet):
+    """models_singlemodalinput/UNet.py:274-304; not covered (raises), see UNet.__init__."""
+    _BASE = 16
+
+
+class UNet8(UNet):
+    """models_singlemodalinput/UNet.py:306-336; not covered (raises)."""
+    _BASE = 8
+
+
+class UNet4(UNet):
+    """models_singlemodalinput/UNet.py:338-368; not covered (raises)."""
+    _BASE = 4
+
+
+class UNet2(UNet):
+    """models_singlemodalinput/UNet.py:370-400; not covered (raises)."""
+    _BASE = 2

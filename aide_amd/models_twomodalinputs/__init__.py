@@ -1,1 +1,1 @@
-from .fuseunet import fuseunet, fuseunetsa  # noqa: F401  (reference: models_twomodalinputs/__init__.py:1)
+from .fuseunet import fuseunet, fuseunetsa, fuseunetsaseparate  # noqa: F401  (reference: models_twomodalinputs/__init__.py:1)

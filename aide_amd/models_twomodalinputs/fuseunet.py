@@ -10,6 +10,7 @@ from .netblocks import UNet_basic_down_block, UNet_basic_up_block, Spatial_Atten
 
 class fuseunet(nn.Module):
     _ATTENTION = False
+    _SEPARATE = False       # fuseunetsaseparate: modal-1 pools its own stream instead of the fused tensor
     _M1 = ((3, 32), (64, 64), (128, 128), (256, 256), (512, 512))      # fuseunet.py:12-20
     _M2 = ((3, 32), (32, 64), (64, 128), (128, 256), (256, 512))       # fuseunet.py:24-32
     _UP = ((1024, 512, 512), (512, 256, 256), (256, 128, 128), (128, 64, 64))   # fuseunet.py:36-39
@@ -75,7 +76,9 @@ class fuseunet(nn.Module):
             if s < 5:
                 p = g.tensor('pool_s%d' % s, skip.C, s)
                 g.pool(skip, p)
-                src1, src2 = p, p.slice(c1[s - 1], c2[s - 1])
+                # max-pool is per channel: both encoders of fuseunetsaseparate read their own slice of pool(cat(y, x))
+                src1 = p.slice(0, c1[s - 1]) if self._SEPARATE else p
+                src2 = p.slice(c1[s - 1], c2[s - 1])
         skips = [(cats[4 - k], prev[k - 1]) for k in range(1, 5)]
         add_decoder(g, self, skips, y5, [o for _, _, o in self._UP])
         return g
@@ -93,3 +96,10 @@ class fuseunetsa(fuseunet):
     """models_twomodalinputs/fuseunet.py:93-221: fuseunet with a Spatial_Attention gate after every down block of both
     modalities (same constructor, forward signature, registration order and state_dict keys)."""
     _ATTENTION = True
+
+
+class fuseunetsaseparate(fuseunetsa):
+    """models_twomodalinputs/fuseunet.py:210-322: two independent attention encoders (3-32-64-128-256-512 each); the
+    gated level outputs meet only in the decoder's skip concatenations."""
+    _SEPARATE = True
+    _M1 = fuseunet._M2                                                   # fuseunet.py:216-229

@@ -10,7 +10,8 @@ It is pinned by ``tests/golden/*.npz`` which were produced by importing the
 real reference (``oracle/gen_golden.py``, run in the build container where
 ``/root/reference`` exists); see DESIGN.md "Oracle pinning".
 """
-from .nets import fuseunet, UNet, fuseunetsa, UNetsa, Spatial_Attention  # noqa: F401
+from .nets import (fuseunet, UNet, fuseunetsa, UNetsa, Spatial_Attention, fuseunetsaseparate,  # noqa: F401
+                   UNet128, UNet32, UNet16, UNet8, UNet4, UNet2)
 from .losses import (  # noqa: F401
     CrossEntropyLoss2d, DiceLoss, MulticlassDiceLoss, MulticlassMSELoss,
     CEMDiceLoss, CEMDiceLossImage, Coteachingloss_dropimage,

@@ -441,6 +441,12 @@ def g8_pixelcoreg(ref_utils):
     np.savez_compressed(os.path.join(OUT, 'g8_pixelcoreg.npz'), **fx)
 
 
+def g10_variants(ref_f, ref_u, ref_utils, oracle):
+    g1_model('fuseunetsaseparate', ref_f.fuseunetsaseparate, oracle.fuseunetsaseparate, {}, True, ref_utils)
+    for w in (128, 32, 16, 2):
+        g1_model('unet%d' % w, getattr(ref_u, 'UNet%d' % w), getattr(oracle, 'UNet%d' % w), {}, False, ref_utils)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ['g8']:
@@ -457,6 +463,11 @@ def main():
         import oracle
         g1_model('fuseunetsa', ref_f.fuseunetsa, oracle.fuseunetsa, {}, True, ref_utils)
         return g1_model('unetsa', ref_u.UNetsa, oracle.UNetsa, {}, False, ref_utils)
+    if sys.argv[1:] == ['g10']:          # separate-encoder attention net and the UNet width variants
+        torch.set_num_threads(8)
+        ref_f, ref_u, ref_utils = _import_reference()
+        import oracle
+        return g10_variants(ref_f, ref_u, ref_utils, oracle)
     if sys.argv[1:] == ['g6']:
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()
@@ -477,6 +488,7 @@ def main():
     g6_inference(ref_f, ref_u, ref_utils)
     g7_coteach_ext(ref_utils)
     g8_pixelcoreg(ref_utils)
+    g10_variants(ref_f, ref_u, ref_utils, oracle)
     print('all golden fixtures written to', OUT)
 
 

@@ -102,12 +102,15 @@ class fuseunet(nn.Module):
             setattr(self, 'up_block%d' % i, _Up(a, p, o, learned_bilinear))
         self.last_conv1 = nn.Conv2d(64, num_classes, 1, padding=0)
 
+    SEPARATE = False
+
     def forward(self, modal1_inputs, modal2_inputs):
         y, x = modal1_inputs, modal2_inputs
         skips = []
         for i in range(1, 6):                                         # fuseunet.py:45-81
             if i > 1:
-                y = F.max_pool2d(skips[-1], 2, 2)   # modal-1 consumes the fused tensor
+                # modal-1 consumes the fused tensor; fuseunetsaseparate pools its own stream (fuseunet.py:270-271)
+                y = F.max_pool2d(y if self.SEPARATE else skips[-1], 2, 2)
                 x = F.max_pool2d(x, 2, 2)
             y = getattr(self, 'modal1_downblock%d' % i)(y)
             x = getattr(self, 'modal2_downblock%d' % i)(x)
@@ -126,20 +129,31 @@ class fuseunetsa(fuseunet):
     ATTENTION = True
 
 
+class fuseunetsaseparate(fuseunet):
+    """fuseunet.py:210-322: two independent attention encoders (3-32-64-128-256-512 each) whose gated outputs are
+    concatenated per level for the decoder only."""
+    ATTENTION = True
+    SEPARATE = True
+    M1 = fuseunet.M2                                                  # fuseunet.py:216-229
+
+
 class UNet(nn.Module):
-    """UNet.py:135-165."""
+    """UNet.py:135-165; the width variants UNet128 ... UNet2 (UNet.py:210-400) differ only in BASE."""
     ATTENTION = False
-    ENC = [(3, 64), (64, 128), (128, 256), (256, 512), (512, 1024)]  # UNet.py:139-143
+    BASE = 64
 
     def __init__(self, num_classes=2, learned_bilinear=False):
         super().__init__()
-        for i, (a, b) in enumerate(self.ENC, 1):
+        b0 = self.BASE
+        enc = [(3, b0)] + [(b0 << k, b0 << (k + 1)) for k in range(4)]       # UNet.py:139-143
+        for i, (a, b) in enumerate(enc, 1):
             setattr(self, 'down_block%d' % i, _Down(a, b, pool=(i > 1)))
             if self.ATTENTION:                                        # UNet.py:172-181
                 setattr(self, 'sa%d' % i, Spatial_Attention(b, reduction=16, dilation=4))
-        for i, (a, p, o) in enumerate(fuseunet.UP, 1):
-            setattr(self, 'up_block%d' % i, _Up(a, p, o, learned_bilinear))
-        self.last_conv1 = nn.Conv2d(64, num_classes, 1, padding=0)
+        for i in range(1, 5):                                         # UNet.py:145-148
+            w = b0 << (4 - i)
+            setattr(self, 'up_block%d' % i, _Up(2 * w, w, w, learned_bilinear))
+        self.last_conv1 = nn.Conv2d(b0, num_classes, 1, padding=0)
 
     def forward(self, x):
         feats = []
@@ -156,3 +170,33 @@ class UNet(nn.Module):
 class UNetsa(UNet):
     """UNet.py:168-208."""
     ATTENTION = True
+
+
+class UNet128(UNet):
+    """UNet.py:210-240."""
+    BASE = 128
+
+
+class UNet32(UNet):
+    """UNet.py:242-272."""
+    BASE = 32
+
+
+class UNet16(UNet):
+    """UNet.py:274-304."""
+    BASE = 16
+
+
+class UNet8(UNet):
+    """UNet.py:306-336."""
+    BASE = 8
+
+
+class UNet4(UNet):
+    """UNet.py:338-368."""
+    BASE = 4
+
+
+class UNet2(UNet):
+    """UNet.py:370-400."""
+    BASE = 2

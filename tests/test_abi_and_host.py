@@ -102,6 +102,30 @@ def test_state_dict_and_init_match_oracle():
     a.load_state_dict(sb)          # reference-format checkpoints load
 
 
+def test_variant_state_dicts_match_oracle():
+    """fuseunetsaseparate (fuseunet.py:210-322) and the UNet width variants (UNet.py:210-400): same keys and seeded
+    initialisation as the oracle (== reference); widths the HIP kernels do not tile raise instead of falling back."""
+    import oracle
+    from aide_amd.models_twomodalinputs import fuseunetsaseparate
+    from aide_amd.models_singlemodalinput import UNet32, UNet128, UNet16, UNet8, UNet4, UNet2
+    for ours, ref in ((fuseunetsaseparate, oracle.fuseunetsaseparate), (UNet32, oracle.UNet32),
+                      (UNet128, oracle.UNet128)):
+        torch.manual_seed(2)
+        a = ours(2)
+        torch.manual_seed(2)
+        b = ref(2)
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa) == list(sb)
+        assert all(torch.equal(sa[k], sb[k]) for k in sa)
+        a.engine._refresh_params()
+        owned = [id(p) for op in a.engine.graph.ops for key in ('conv', 'bn', 'mod') if op.get(key) is not None
+                 for p in op[key].parameters()]
+        assert sorted(owned) == sorted(id(p) for p in a.parameters())
+    for small in (UNet16, UNet8, UNet4, UNet2):
+        with pytest.raises(NotImplementedError):
+            small(2)
+
+
 def test_no_cpu_fallback():
     from aide_amd.models_twomodalinputs import fuseunet
     from aide_amd import utils as U

@@ -36,11 +36,13 @@ def sub(a, limit=8192):
 
 
 def build_pair(kind, learned, dev):
-    from aide_amd.models_twomodalinputs import fuseunet, fuseunetsa
-    from aide_amd.models_singlemodalinput import UNet, UNetsa
+    from aide_amd.models_twomodalinputs import fuseunet, fuseunetsa, fuseunetsaseparate
+    from aide_amd.models_singlemodalinput import UNet, UNetsa, UNet128, UNet32
     ours_c, ref_c = {'fuseunet': (fuseunet, oracle.fuseunet), 'unet': (UNet, oracle.UNet),
-                     'fuseunetsa': (fuseunetsa, oracle.fuseunetsa), 'unetsa': (UNetsa, oracle.UNetsa)}[kind]
-    if kind.endswith('sa'):
+                     'fuseunetsa': (fuseunetsa, oracle.fuseunetsa), 'unetsa': (UNetsa, oracle.UNetsa),
+                     'fuseunetsaseparate': (fuseunetsaseparate, oracle.fuseunetsaseparate),
+                     'unet128': (UNet128, oracle.UNet128), 'unet32': (UNet32, oracle.UNet32)}[kind]
+    if kind.endswith('sa') or kind.endswith('separate'):
         assert not learned
         torch.manual_seed(2)
         ref = ref_c(2)
@@ -71,6 +73,7 @@ class forced_relu_masks(object):
                 _, idx = torch.nn.functional.max_pool2d(src, 2, 2, return_indices=True)
                 self.pool_idx[tuple(src.shape[2:])] = idx
         self.pool_flips = 0
+        self.pool_calls = {}
         self.ref, self.cur, self.flips, self.hooks = ref, [None], {}, []
         self.total = sum(m.numel() for m in self.masks.values())
 
@@ -94,7 +97,11 @@ class forced_relu_masks(object):
 
         def forced_pool(x, kernel_size, stride=None, *a, **k):
             idx = self.pool_idx[tuple(x.shape[2:])]
-            idx = idx[:, idx.shape[1] - x.shape[1]:]           # modal-2 pools the trailing channel slice
+            calls = self.pool_calls[tuple(x.shape[2:])] = self.pool_calls.get(tuple(x.shape[2:]), 0) + 1
+            if calls == 1:
+                idx = idx[:, :x.shape[1]]                      # modal-1: the whole fused tensor (fuseunetsaseparate: its own leading slice)
+            else:
+                idx = idx[:, idx.shape[1] - x.shape[1]:]       # modal-2 pools the trailing channel slice
             _, own = self.orig_pool(x.detach(), 2, 2, return_indices=True)
             self.pool_flips += int((own != idx).sum())
             n, c, h, w = x.shape
@@ -112,7 +119,9 @@ class forced_relu_masks(object):
 
 CASES = [('fuseunet', False, 'g1_fuseunet.npz'), ('fuseunet', True, 'g1_fuseunet_learned.npz'),
          ('unet', False, 'g1_unet.npz'), ('unet', True, 'g1_unet_learned.npz'),
-         ('fuseunetsa', False, 'g1_fuseunetsa.npz'), ('unetsa', False, 'g1_unetsa.npz')]      # attention variants
+         ('fuseunetsa', False, 'g1_fuseunetsa.npz'), ('unetsa', False, 'g1_unetsa.npz'),      # attention variants
+         ('fuseunetsaseparate', False, 'g1_fuseunetsaseparate.npz'),                         # fuseunet.py:210-322
+         ('unet128', False, 'g1_unet128.npz'), ('unet32', False, 'g1_unet32.npz')]           # UNet.py:210-272
 
 
 @pytest.mark.parametrize('kind,learned,gold', CASES)

@@ -34,7 +34,10 @@ def sub(a, limit=8192):
 
 MODELS = [('fuseunet', oracle.fuseunet, {}, 2), ('fuseunet_learned', oracle.fuseunet, dict(learned_bilinear=True), 2),
           ('unet', oracle.UNet, {}, 1), ('unet_learned', oracle.UNet, dict(learned_bilinear=True), 1),
-          ('fuseunetsa', oracle.fuseunetsa, {}, 2), ('unetsa', oracle.UNetsa, {}, 1)]      # attention variants (§8 f4)
+          ('fuseunetsa', oracle.fuseunetsa, {}, 2), ('unetsa', oracle.UNetsa, {}, 1),      # attention variants (§8 f4)
+          ('fuseunetsaseparate', oracle.fuseunetsaseparate, {}, 2),                       # fuseunet.py:210-322
+          ('unet128', oracle.UNet128, {}, 1), ('unet32', oracle.UNet32, {}, 1),            # UNet.py:210-400
+          ('unet16', oracle.UNet16, {}, 1), ('unet2', oracle.UNet2, {}, 1)]
 
 
 @pytest.mark.parametrize('name,ctor,kw,nin', MODELS)
