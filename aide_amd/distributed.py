@@ -14,9 +14,11 @@ import torch.distributed as dist
 
 
 def make_buckets(offsets, numels, bucket_elems):
-    """Greedy contiguous buckets over the flat arena. -> list of (start, end, [param indices])."""
+    """Greedy contiguous buckets over the flat arena, walked in arena (offset) order -- the engine lays the arena out
+    in backward-completion order, so bucket k is complete before bucket k+1. -> list of (start, end, [param indices])."""
     buckets, cur, start = [], [], None
-    for i, (o, n) in enumerate(zip(offsets, numels)):
+    for i in sorted(range(len(offsets)), key=lambda k: offsets[k]):
+        o, n = offsets[i], numels[i]
         if start is None:
             start = o
         cur.append(i)

@@ -672,12 +672,26 @@ class Engine(object):
         if self.params is None or len(params) != len(self.params) or \
                 any(a is not b for a, b in zip(params, self.params)):
             self.params = params
-            self.offsets, off = [], 0
-            for p in params:
-                self.offsets.append(off)
-                off += (p.numel() + 3) // 4 * 4          # 16-byte aligned slots
-            self.flat_numel = off
             self.graph = self.build_graph()
+            # Gradient arena in BACKWARD-COMPLETION order (reverse graph order): contiguous ranges of it become complete
+            # progressively, so the data-parallel buckets (distributed.py) go out while the rest of the backward still
+            # runs and only the small shallow-encoder tail is reduced after the last kernel.  (In registration order the
+            # two ~30 MB buckets holding the stem convolutions completed at the very end.)
+            index = {id(p): i for i, p in enumerate(params)}
+            order = []
+            for op in reversed(self.graph.ops):
+                for key in ('conv', 'bn', 'mod'):
+                    m = op.get(key)
+                    if m is not None:
+                        order += [index[id(p)] for p in m.parameters()]
+            seen = set(order)
+            assert len(seen) == len(order), 'a parameter is owned by two graph ops'
+            order += [i for i in range(len(params)) if i not in seen]
+            self.offsets, off = [0] * len(params), 0
+            for i in order:
+                self.offsets[i] = off
+                off += (params[i].numel() + 3) // 4 * 4  # 16-byte aligned slots
+            self.flat_numel = off
             self.plans = {}
 
     def plan_for(self, inputs, groups=1):
