@@ -114,7 +114,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     for (int v = 0; v < WV; ++v) {
         const int f = tid + v * 256;
         const int row = f / (TCO / 4), c4 = f - row * (TCO / 4);
-        woff[v] = (f < WL / 4) ? (unsigned)(row * a.ldw + c4 * 4) * 4u : BUF_OOB;
+        // narrow layers (Cout % 32 != 0, the UNet16 ... UNet2 variants): columns past Cout read as zero; a 16-byte piece
+        // that straddles Cout picks up the next row's values in accumulator rows the epilogue never stores
+        woff[v] = (f < WL / 4 && co0 + c4 * 4 < a.Cout) ? (unsigned)(row * a.ldw + c4 * 4) * 4u : BUF_OOB;
     }
     const bool ragged_c = (a.Cin % CK) != 0;   // only the 3-channel stems
 
@@ -452,7 +454,6 @@ int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, c
                        float* y, int64_t y_bs, int N, int Cin, int H, int W, int Cout,
                        int accumulate, int plan, float* ws, hipStream_t stream) {
     if (!x || !wp || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return AIDE_ERR_ARG;
-    if (Cout % 32 != 0) return AIDE_ERR_ARG;
     if (plan < 0) plan = aide_conv3x3_plan(N, Cin, H, W, Cout);
     const int variant = plan & 0xff;
     int splitk = plan >> 8;

@@ -15,10 +15,6 @@ class UNet(nn.Module):
     def __init__(self, num_classes=2, learned_bilinear=False):
         nn.Module.__init__(self)
         b0 = self._BASE
-        if b0 % 32:
-            # no silent fallback: the HIP convolution kernels tile output channels in blocks of 32
-            raise NotImplementedError('%s: channel widths below 32 are not covered by the HIP convolution kernels'
-                                      % type(self).__name__)
         self._ENC = ((3, b0),) + tuple((b0 << k, b0 << (k + 1)) for k in range(4))      # UNet.py:139-143
         self._UP = tuple((b0 << (5 - i), b0 << (4 - i), b0 << (4 - i)) for i in range(1, 5))   # UNet.py:145-148
         for i, (a, b) in enumerate(self._ENC, 1):
@@ -89,20 +85,20 @@ class UNet32(UNet):
 
 
 class UNet16(UNet):
-    """models_singlemodalinput/UNet.py:274-304; not covered (raises), see UNet.__init__."""
+    """models_singlemodalinput/UNet.py:274-304 (widths 16 ... 256; the direct kernels mask the partial channel tile)."""
     _BASE = 16
 
 
 class UNet8(UNet):
-    """models_singlemodalinput/UNet.py:306-336; not covered (raises)."""
+    """models_singlemodalinput/UNet.py:306-336 (widths 8 ... 128)."""
     _BASE = 8
 
 
 class UNet4(UNet):
-    """models_singlemodalinput/UNet.py:338-368; not covered (raises)."""
+    """models_singlemodalinput/UNet.py:338-368 (widths 4 ... 64)."""
     _BASE = 4
 
 
 class UNet2(UNet):
-    """models_singlemodalinput/UNet.py:370-400; not covered (raises)."""
+    """models_singlemodalinput/UNet.py:370-400 (widths 2 ... 32)."""
     _BASE = 2

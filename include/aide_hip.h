@@ -35,7 +35,8 @@ int aide_conv3x3_plan(int N, int Cin, int H, int W, int Cout);    /* variant | s
 size_t aide_conv3x3_ws_bytes(int N, int H, int W, int Cout, int splitk);
 int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, const float* bias,
                        float* y, int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate,
-                       int plan, float* ws, aide_stream_t stream);   /* forward and dgrad */
+                       int plan, float* ws, aide_stream_t stream);   /* forward and dgrad; any Cin, Cout, H, W
+                                                                        (partial channel tiles / chunks are masked) */
 /* Winograd F(2x2,3x3) variant of the same convolution (forward / dgrad) for even H, W % 4 == 0,
  * Cout % 64 == 0, Cin % 8 == 0.  Filters are pre-transformed (G g G^T), channel-blocked by 8:
  * uf [ci_pad/8][16][Co][8 ci], ud [co_pad/8][16][Ci][8 co] (the tensors are allocated as [pad][16][C]). */

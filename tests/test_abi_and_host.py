@@ -104,7 +104,7 @@ def test_state_dict_and_init_match_oracle():
 
 def test_variant_state_dicts_match_oracle():
     """fuseunetsaseparate (fuseunet.py:210-322) and the UNet width variants (UNet.py:210-400): same keys and seeded
-    initialisation as the oracle (== reference); widths the HIP kernels do not tile raise instead of falling back."""
+    initialisation as the oracle (== reference)."""
     import oracle
     from aide_amd.models_twomodalinputs import fuseunetsaseparate
     from aide_amd.models_singlemodalinput import UNet32, UNet128, UNet16, UNet8, UNet4, UNet2
@@ -121,9 +121,8 @@ def test_variant_state_dicts_match_oracle():
         owned = [id(p) for op in a.engine.graph.ops for key in ('conv', 'bn', 'mod') if op.get(key) is not None
                  for p in op[key].parameters()]
         assert sorted(owned) == sorted(id(p) for p in a.parameters())
-    for small in (UNet16, UNet8, UNet4, UNet2):
-        with pytest.raises(NotImplementedError):
-            small(2)
+    for small, ref in ((UNet16, oracle.UNet16), (UNet8, oracle.UNet8), (UNet4, oracle.UNet4), (UNet2, oracle.UNet2)):
+        assert list(small(2).state_dict()) == list(ref(2).state_dict())
 
 
 def test_no_cpu_fallback():

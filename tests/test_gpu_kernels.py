@@ -21,6 +21,9 @@ CONV_CASES = [
     (2, 3, 32, 32, 32), (1, 32, 32, 64, 64), (2, 64, 64, 32, 32), (1, 128, 64, 64, 64),
     (2, 64, 128, 16, 16), (1, 256, 256, 16, 16), (2, 24, 96, 20, 20), (1, 40, 32, 40, 24),
     (1, 64, 128, 80, 80), (4, 512, 512, 16, 16),
+    # narrow layers of the UNet16 ... UNet2 variants (UNet.py:274-400): partial 32-channel tile, masked channel chunk
+    (2, 3, 2, 32, 32), (2, 2, 2, 32, 32), (1, 4, 2, 64, 32), (2, 8, 4, 16, 16), (1, 16, 8, 20, 20), (2, 32, 16, 32, 32),
+    (1, 16, 16, 64, 64), (2, 16, 32, 16, 16), (1, 2, 4, 40, 24),
 ]
 
 
@@ -39,7 +42,7 @@ def test_conv3x3_fwd_dgrad_wgrad(dev, case):
     yr.backward(dy)
 
     xd, wd_, bd, dyd = x.to(dev), wt.to(dev), b.to(dev), dy.to(dev)
-    wf, wdg = ops.pack_weights(wd_, need_dgrad=(ci % 32 == 0))
+    wf, wdg = ops.pack_weights(wd_, need_dgrad=(ci % 32 == 0 or ci < 32 and ci != 3))
     y = torch.empty(n, co, h, w, device=dev)
     ops.conv3x3_igemm(xd, wf, bd, y)
     _close(y, yr, what='fwd %s' % (case,))

@@ -37,11 +37,12 @@ def sub(a, limit=8192):
 
 def build_pair(kind, learned, dev):
     from aide_amd.models_twomodalinputs import fuseunet, fuseunetsa, fuseunetsaseparate
-    from aide_amd.models_singlemodalinput import UNet, UNetsa, UNet128, UNet32
+    from aide_amd.models_singlemodalinput import UNet, UNetsa, UNet128, UNet32, UNet16, UNet2
     ours_c, ref_c = {'fuseunet': (fuseunet, oracle.fuseunet), 'unet': (UNet, oracle.UNet),
                      'fuseunetsa': (fuseunetsa, oracle.fuseunetsa), 'unetsa': (UNetsa, oracle.UNetsa),
                      'fuseunetsaseparate': (fuseunetsaseparate, oracle.fuseunetsaseparate),
-                     'unet128': (UNet128, oracle.UNet128), 'unet32': (UNet32, oracle.UNet32)}[kind]
+                     'unet128': (UNet128, oracle.UNet128), 'unet32': (UNet32, oracle.UNet32),
+                     'unet16': (UNet16, oracle.UNet16), 'unet2': (UNet2, oracle.UNet2)}[kind]
     if kind.endswith('sa') or kind.endswith('separate'):
         assert not learned
         torch.manual_seed(2)
@@ -121,7 +122,8 @@ CASES = [('fuseunet', False, 'g1_fuseunet.npz'), ('fuseunet', True, 'g1_fuseunet
          ('unet', False, 'g1_unet.npz'), ('unet', True, 'g1_unet_learned.npz'),
          ('fuseunetsa', False, 'g1_fuseunetsa.npz'), ('unetsa', False, 'g1_unetsa.npz'),      # attention variants
          ('fuseunetsaseparate', False, 'g1_fuseunetsaseparate.npz'),                         # fuseunet.py:210-322
-         ('unet128', False, 'g1_unet128.npz'), ('unet32', False, 'g1_unet32.npz')]           # UNet.py:210-272
+         ('unet128', False, 'g1_unet128.npz'), ('unet32', False, 'g1_unet32.npz'),           # UNet.py:210-272
+         ('unet16', False, 'g1_unet16.npz'), ('unet2', False, 'g1_unet2.npz')]               # narrow: partial channel tiles
 
 
 @pytest.mark.parametrize('kind,learned,gold', CASES)
