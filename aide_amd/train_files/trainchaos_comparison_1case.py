@@ -15,7 +15,6 @@ import time
 
 import numpy as np
 import torch
-from torch.optim.lr_scheduler import StepLR
 
 
 def parse_args(argv=None):
@@ -44,12 +43,14 @@ def parse_args(argv=None):
 
 
 def build_model(model_name, num_classes):
-    if model_name == 'fuseunet':
-        from aide_amd.models_twomodalinputs import fuseunet
-        return fuseunet(num_classes=num_classes)
-    if model_name == 'UNet':
-        from aide_amd.models_singlemodalinput import UNet
-        return UNet(num_classes=num_classes)
+    """'fuseunet' (trainchaos_*.py:61-65); the single-modality scripts accept 'UNet' / 'UNetsa'
+    (trainkidney_comparison_mask1.py:62-68); the other model classes of the two model files by their class names."""
+    import aide_amd.models_twomodalinputs as two
+    import aide_amd.models_singlemodalinput as one
+    for mod in (two, one):
+        ctor = getattr(mod, model_name, None)
+        if isinstance(ctor, type):
+            return ctor(num_classes=num_classes)
     raise ValueError('Model not implemented')
 
 
@@ -57,6 +58,7 @@ def Train(args=None):
     from aide_amd import utils as U
     from aide_amd.optim import Adam
     from aide_amd.synthetic import chaos_batch
+    from aide_amd.utils.poly_lr_scheduler import make_scheduler
     args = args or parse_args()
     torch.manual_seed(args.torch_seed)
     torch.cuda.manual_seed_all(args.torch_seed)
@@ -78,8 +80,8 @@ def Train(args=None):
     else:
         raise ValueError('Do not have this loss')
     optimizer = Adam(net.parameters(), lr=args.lr, amsgrad=True)
-    scheduler = StepLR(optimizer, step_size=30, gamma=0.5)
-    single = args.model_name != 'fuseunet'
+    scheduler = make_scheduler(args.lr_policy, optimizer, args.num_epoch)
+    single = not args.model_name.startswith('fuseunet')
     history = {'train_loss': [], 'train_dice': []}
     for epoch in range(args.num_epoch):
         ts = time.time()
@@ -100,7 +102,8 @@ def Train(args=None):
             count += inphase.shape[0]
             loss_sum += loss.detach() * inphase.shape[0]      # device-side accumulation: one host
             dice_sum += U.Dice_fn(outputs, targets)           # sync per epoch instead of two per step
-        scheduler.step()
+        if scheduler is not None:
+            scheduler.step()
         history['train_loss'].append(float(loss_sum) / count)
         history['train_dice'].append(float(dice_sum) / count)
         logging.info('epoch %d train_loss %.4f train_dice %.4f time %.1fs', epoch + 1,

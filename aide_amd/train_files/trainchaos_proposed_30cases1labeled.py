@@ -15,7 +15,6 @@ import time
 
 import numpy as np
 import torch
-from torch.optim.lr_scheduler import StepLR
 
 
 def parse_args(argv=None):
@@ -78,6 +77,7 @@ def Train(args=None):
     from aide_amd.optim import Adam
     from aide_amd.synthetic import chaos_batch
     from aide_amd.utils import CoTeachingProposedLoss
+    from aide_amd.utils.poly_lr_scheduler import make_scheduler
     args = args or parse_args()
     if args.model_name != 'fuseunet':
         raise ValueError('Model not implemented')
@@ -91,7 +91,8 @@ def Train(args=None):
                                      segcor_weight=args.segcor_weight, keep=2)
     opt1 = Adam(net1.parameters(), lr=args.lr, amsgrad=True)
     opt2 = Adam(net2.parameters(), lr=args.lr, amsgrad=True)
-    sch1, sch2 = StepLR(opt1, 30, 0.5), StepLR(opt2, 30, 0.5)
+    sch1 = make_scheduler(args.lr_policy, opt1, args.num_epoch)        # :236-240
+    sch2 = make_scheduler(args.lr_policy, opt2, args.num_epoch)
     g = torch.Generator(device='cpu').manual_seed(args.torch_seed)
     for epoch in range(args.num_epoch):
         ts = time.time()
@@ -109,8 +110,9 @@ def Train(args=None):
             r = coteach_step(net1, net2, opt1, opt2, loss_op, xin, xout, augs, t, t, rate, args.temperature)
             l1 += r['loss1']
             l2 += r['loss2']
-        sch1.step()
-        sch2.step()
+        if sch1 is not None:
+            sch1.step()
+            sch2.step()
         logging.info('epoch %d loss1 %.4f loss2 %.4f time %.1fs', epoch + 1, float(l1) / args.steps_per_epoch,
                      float(l2) / args.steps_per_epoch, time.time() - ts)
     return net1, net2

@@ -7,3 +7,4 @@ from .coteach_loss import (Coteachingloss_dropimage, Coteachingloss_weightimage,
                            pseudo_label_ensemble)
 from .augment import reverseaug, reverse_aug_tensor  # noqa: F401
 from .reg_loss import Pixelcoreg_Focalloss, Pixelcoreg_Focalloss_twomodel  # noqa: F401
+from .poly_lr_scheduler import PolyLR  # noqa: F401

@@ -447,6 +447,23 @@ def g10_variants(ref_f, ref_u, ref_utils, oracle):
         g1_model('unet%d' % w, getattr(ref_u, 'UNet%d' % w), getattr(oracle, 'UNet%d' % w), {}, False, ref_utils)
 
 
+def g11_polylr(ref_utils):
+    """utils/poly_lr_scheduler.py:27-47: the learning rates of 25 epochs for two (lr, max_epoch, power) settings."""
+    fx = {}
+    for tag, (lr, max_epoch, power) in (('a', (1e-4, 20, 0.9)), ('b', (3e-3, 7, 2.0))):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=lr)
+        sch = ref_utils.PolyLR(opt, max_epoch=max_epoch, power=power)
+        seq = [opt.param_groups[0]['lr']]
+        for _ in range(24):
+            sch.step()
+            seq.append(opt.param_groups[0]['lr'])
+        fx['cfg_' + tag] = np.array([lr, max_epoch, power])
+        fx['lr_' + tag] = np.array(seq, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'g11_polylr.npz'), **fx)
+    print('g11', fx['lr_a'][:3], fx['lr_b'][:3])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ['g8']:
@@ -468,6 +485,9 @@ def main():
         ref_f, ref_u, ref_utils = _import_reference()
         import oracle
         return g10_variants(ref_f, ref_u, ref_utils, oracle)
+    if sys.argv[1:] == ['g11']:          # PolyLR learning-rate sequence
+        ref_f, ref_u, ref_utils = _import_reference()
+        return g11_polylr(ref_utils)
     if sys.argv[1:] == ['g6']:
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()
@@ -489,6 +509,7 @@ def main():
     g7_coteach_ext(ref_utils)
     g8_pixelcoreg(ref_utils)
     g10_variants(ref_f, ref_u, ref_utils, oracle)
+    g11_polylr(ref_utils)
     print('all golden fixtures written to', OUT)
 
 

@@ -164,3 +164,29 @@ def test_synthetic_contract():
     assert set(np.unique(t.numpy()).tolist()) <= {0, 1}
     a2, _, t2 = chaos_batch(8, 64, seed=3)
     assert torch.equal(a, a2) and torch.equal(t, t2)
+
+
+def test_polylr_matches_reference_sequence():
+    """PolyLR (utils/poly_lr_scheduler.py:27-47) against learning-rate sequences recorded from the reference
+    (tests/golden/g11_polylr.npz, oracle/gen_golden.py g11); --lr_policy dispatch of the train mirrors."""
+    import os
+    import numpy as np
+    from aide_amd.utils import PolyLR
+    from aide_amd.utils.poly_lr_scheduler import make_scheduler
+    fx = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g11_polylr.npz'))
+    for tag in 'ab':
+        lr, max_epoch, power = fx['cfg_' + tag]
+        opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=float(lr))
+        sch = PolyLR(opt, max_epoch=int(max_epoch), power=float(power))
+        seq = [opt.param_groups[0]['lr']]
+        for _ in range(24):
+            opt.step()
+            sch.step()
+            seq.append(opt.param_groups[0]['lr'])
+        assert np.allclose(seq, fx['lr_' + tag], rtol=1e-12, atol=0)
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+    assert type(make_scheduler('StepLR', opt, 10)).__name__ == 'StepLR'
+    assert isinstance(make_scheduler('PolyLR', opt, 10), PolyLR)
+    assert make_scheduler('None', opt, 10) is None
+    with pytest.raises(ValueError):
+        make_scheduler('cosine', opt, 10)
