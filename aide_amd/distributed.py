@@ -60,6 +60,44 @@ class BucketScheduler(object):
         return ready
 
 
+def init_from_env(device_ids=None):
+    """One process per GPU under `python -m torch.distributed.run`: reads RANK / LOCAL_RANK / WORLD_SIZE, selects this
+    rank's device (device_ids[local_rank] if given -- the train scripts' --gpu_order -- else local_rank) and, for
+    WORLD_SIZE > 1, joins the RCCL process group.  -> (rank, world, device).  AIDE_DIST_BACKEND=gloo is a dry-run backend
+    for boxes with fewer GPUs than ranks (ranks wrap around the visible devices; RCCL refuses two ranks per device)."""
+    import os
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    backend = os.environ.get('AIDE_DIST_BACKEND', os.environ.get('AIDE_BENCH_BACKEND', 'nccl'))
+    if not torch.cuda.is_available():
+        raise RuntimeError('aide_amd needs a HIP device (the product path has no CPU fallback)')
+    if device_ids is not None:
+        index = device_ids[local_rank % len(device_ids)]
+    else:
+        index = local_rank
+    if backend != 'nccl':
+        index %= torch.cuda.device_count()
+    torch.cuda.set_device(index)
+    device = torch.device('cuda', index)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this host driver
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
+    return rank, world, device
+
+
+def attach(module):
+    """Data-parallel replica set-up of one aide_amd model: rank 0's parameters / buffers everywhere, then the bucketed
+    gradient mean all-reduce on its engine.  No-op (returns None) for a single process."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    broadcast_module(module)
+    return GradAllReduce(module)
+
+
 def broadcast_module(module, src=0):
     """Make every replica start from rank `src`'s parameters and buffers."""
     for t in list(module.parameters()) + list(module.buffers()):

@@ -59,14 +59,18 @@ def Train(args=None):
     from aide_amd.optim import Adam
     from aide_amd.synthetic import chaos_batch
     from aide_amd.utils.poly_lr_scheduler import make_scheduler
+    from aide_amd.distributed import init_from_env, attach
     args = args or parse_args()
     torch.manual_seed(args.torch_seed)
     torch.cuda.manual_seed_all(args.torch_seed)
     np.random.seed(args.torch_seed)
     random.seed(args.torch_seed)
-    device = torch.device('cuda:%d' % int(args.gpu_order.split(',')[0]))
+    # the reference wraps the net in nn.DataParallel over --gpu_order (:131-134); here: one process per GPU
+    # (python -m torch.distributed.run --nproc-per-node N -m aide_amd.train_files...), rank r on gpu_order[r]
+    rank, world, device = init_from_env([int(g) for g in args.gpu_order.split(',')])
     num_classes = 2
     net = build_model(args.model_name, num_classes).to(device)
+    reducer = attach(net)          # noqa: F841  (bucketed RCCL gradient mean all-reduce, installed on the engine)
     cedice_weight = torch.tensor(args.cedice_weight)
     ceclass_weight = torch.tensor(args.ceclass_weight)
     diceclass_weight = torch.tensor(args.diceclass_weight)
@@ -91,7 +95,7 @@ def Train(args=None):
         count = 0
         for it in range(args.steps_per_epoch):
             inphase, outphase, targets = chaos_batch(args.batch_size, args.img_size,
-                                                     seed=args.torch_seed * 100003 + epoch * 1009 + it,
+                                                     seed=(args.torch_seed * 100003 + epoch * 1009 + it) * world + rank,
                                                      single_modal=single)
             inphase, targets = inphase.to(device), targets.to(device)
             optimizer.zero_grad()
@@ -106,8 +110,9 @@ def Train(args=None):
             scheduler.step()
         history['train_loss'].append(float(loss_sum) / count)
         history['train_dice'].append(float(dice_sum) / count)
-        logging.info('epoch %d train_loss %.4f train_dice %.4f time %.1fs', epoch + 1,
-                     history['train_loss'][-1], history['train_dice'][-1], time.time() - ts)
+        if rank == 0:
+            logging.info('epoch %d train_loss %.4f train_dice %.4f time %.1fs', epoch + 1,
+                         history['train_loss'][-1], history['train_dice'][-1], time.time() - ts)
     return net, history
 
 

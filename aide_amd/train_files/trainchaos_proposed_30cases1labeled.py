@@ -78,6 +78,7 @@ def Train(args=None):
     from aide_amd.synthetic import chaos_batch
     from aide_amd.utils import CoTeachingProposedLoss
     from aide_amd.utils.poly_lr_scheduler import make_scheduler
+    from aide_amd.distributed import init_from_env, attach
     args = args or parse_args()
     if args.model_name != 'fuseunet':
         raise ValueError('Model not implemented')
@@ -85,8 +86,11 @@ def Train(args=None):
     torch.cuda.manual_seed_all(args.torch_seed)
     np.random.seed(args.torch_seed)
     random.seed(args.torch_seed)
-    device = torch.device('cuda:%d' % int(args.gpu_order.split(',')[0]))
+    # reference: nn.DataParallel over --gpu_order (:183-186); here one process per GPU, rank r on gpu_order[r], per-replica
+    # BatchNorm statistics and small-loss selection, both networks' gradients mean-all-reduced over RCCL
+    rank, world, device = init_from_env([int(d) for d in args.gpu_order.split(',')])
     net1, net2 = fuseunet(2).to(device), fuseunet(2).to(device)
+    reducers = (attach(net1), attach(net2))          # noqa: F841
     loss_op = CoTeachingProposedLoss(cediceweight=args.cedice_weight, ceclassweight=args.ceclass_weight,
                                      segcor_weight=args.segcor_weight, keep=2)
     opt1 = Adam(net1.parameters(), lr=args.lr, amsgrad=True)
@@ -103,7 +107,7 @@ def Train(args=None):
         l2 = torch.zeros((), device=device)
         for it in range(args.steps_per_epoch):
             xin, xout, t = chaos_batch(args.batch_size, args.img_size,
-                                       seed=args.torch_seed * 100003 + epoch * 1009 + it)
+                                       seed=(args.torch_seed * 100003 + epoch * 1009 + it) * world + rank)
             augs = [((xin * (1 + 0.1 * torch.randn(1, generator=g))).to(device),
                      (xout * (1 + 0.1 * torch.randn(1, generator=g))).to(device)) for _ in range(4)]
             xin, xout, t = xin.to(device), xout.to(device), t.to(device)
@@ -113,8 +117,9 @@ def Train(args=None):
         if sch1 is not None:
             sch1.step()
             sch2.step()
-        logging.info('epoch %d loss1 %.4f loss2 %.4f time %.1fs', epoch + 1, float(l1) / args.steps_per_epoch,
-                     float(l2) / args.steps_per_epoch, time.time() - ts)
+        if rank == 0:
+            logging.info('epoch %d loss1 %.4f loss2 %.4f time %.1fs', epoch + 1, float(l1) / args.steps_per_epoch,
+                         float(l2) / args.steps_per_epoch, time.time() - ts)
     return net1, net2
 
 

@@ -158,24 +158,12 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img):
 
 def main():
     args = parse()
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product path has no CPU fallback)')
-    backend = os.environ.get('AIDE_BENCH_BACKEND', 'nccl')       # 'gloo': dry run of the N>1 flow with every rank on one GPU
-    if backend != 'nccl':
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
-        else:
-            dist.init_process_group(backend)
+    from aide_amd.distributed import init_from_env
+    rank, world, device = init_from_env()      # one process per GPU; RCCL group when WORLD_SIZE > 1
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
 
     from aide_amd import utils as U
     from aide_amd.optim import Adam
