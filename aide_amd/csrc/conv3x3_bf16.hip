@@ -545,7 +545,6 @@ struct BgArgs {
     int n_co_tiles, n_ci_tiles, splits, chunks_total, segs_w, bands_h;
 };
 
-// R = image rows of dz per stage (4, or 2: half the staging registers -> two workgroups per CU)
 // R = image rows of dz per stage (4, or 2: half the staging registers -> two workgroups per CU); NWCO = co blocks of 32
 // per workgroup: 2 (64 co x 64 ci, 4 waves) or 4 (128 co x 64 ci, 8 waves = two per SIMD: the four co blocks share one
 // x tile, halving the x bytes through L2 / L1 / LDS per MFMA, and a second wave per SIMD covers the other's stalls)
