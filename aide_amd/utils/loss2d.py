@@ -92,6 +92,19 @@ class DiceLoss(nn.Module):
         return loss
 
 
+class Dice_Loss(nn.Module):
+    """utils/loss2d.py:63-85: the logits branch of DiceLoss under a second name."""
+
+    def __init__(self, smooth=1.0, reduction='mean'):
+        super(Dice_Loss, self).__init__()
+        self.smooth, self.reduction = smooth, reduction
+
+    def forward(self, inputs, targets):
+        red = 2 if self.reduction == 'none' else _RED[self.reduction]
+        loss, self.last = _seg.seg_loss(inputs, targets, 1.0, 1.0, 255, red, 0.0, 1.0, float(self.smooth))
+        return loss
+
+
 class MulticlassDiceLoss(nn.Module):
     def __init__(self, weight=None, smooth=1.0, reduction='mean'):
         super(MulticlassDiceLoss, self).__init__()
@@ -151,4 +164,23 @@ class CEMDiceLossImage(nn.Module):
 
     def forward(self, inputs, targets):
         loss, self.last = _seg.seg_loss(inputs, targets, self.w0, self.w1, 255, 2, self.w_ce, self.w_dice, 1.0)
+        return loss
+
+
+class CEDiceLoss(nn.Module):
+    """utils/loss2d.py:156-171: CrossEntropyLoss2d(weight=classweight) * cediceweight[0] + DiceLoss * cediceweight[1]
+    (DiceLoss ignores its weight argument, loss2d.py:35-60) -- one fused statistics pass here."""
+
+    def __init__(self, cediceweight=None, classweight=None, reduction='mean'):
+        super(CEDiceLoss, self).__init__()
+        self.w_ce, self.w_dice = _pair(cediceweight)
+        self.w0, self.w1 = _seg.class_weights(classweight)
+        if reduction not in _RED:
+            raise ValueError("CEDiceLoss: reduction must be 'mean' or 'sum' (the reference's 'none' adds a [N,H,W] map "
+                             "to a [N] vector)")
+        self.reduction = reduction
+
+    def forward(self, inputs, targets):
+        loss, self.last = _seg.seg_loss(inputs, targets, self.w0, self.w1, 255, _RED[self.reduction],
+                                        self.w_ce, self.w_dice, 1.0)
         return loss

@@ -17,5 +17,6 @@ from .losses import (  # noqa: F401
     CEMDiceLoss, CEMDiceLossImage, Coteachingloss_dropimage,
     Coteachingloss_weightimage, Coteachingloss_dropregionce, Coteachingloss_dropimagedroppixel,
     KLbidirection, Pixelcoreg_Focalloss, Pixelcoreg_Focalloss_twomodel, Dice_fn, sharpen,
+    Dice_fn_Nozero, TP_TN_FP_FN, IoU_fn, Dice_Loss, CEDiceLoss,
 )
 from .steps import comparison_step, proposed_step  # noqa: F401

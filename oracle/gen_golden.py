@@ -464,6 +464,57 @@ def g11_polylr(ref_utils):
     print('g11', fx['lr_a'][:3], fx['lr_b'][:3])
 
 
+def g12_metrics(ref_utils):
+    """metrics2d.py:8-84 (Dice_fn, Dice_fn_Nozero, TP_TN_FP_FN, IoU_fn) and loss2d.py:63-85,156-171 (Dice_Loss,
+    CEDiceLoss) on a batch with the edge cases: an image empty in target and prediction, one empty in the target only."""
+    import oracle
+    from aide_amd.synthetic import chaos_batch
+    g = torch.Generator().manual_seed(91)
+    n, s = 5, 48
+    _, _, t = chaos_batch(n, s, seed=9)
+    t[0, 8:30, 10:40] = 1
+    t[1] = 0
+    t[2] = 0
+    t[4, 5:20, 5:20] = 1
+    z = torch.randn(n, 2, s, s, generator=g) * 2.0
+    z[1, 0] += 30.0                              # image 1: empty target, empty prediction
+    z[2, 1, 4:9, 4:9] += 30.0                    # image 2: empty target, non-empty prediction
+    fx = dict(z=_np(z), targets=_np(t))
+    for batch, tag in ((slice(0, n), 'all'), (slice(0, 1), 'first'), (slice(3, 5), 'nonempty')):
+        zz, tt = z[batch], t[batch]
+        vals = {}
+        for key, mod in (('ref', ref_utils), ('ora', oracle)):
+            d = mod.Dice_fn(zz.clone(), tt)
+            dn = mod.Dice_fn_Nozero(zz.clone(), tt)
+            c = mod.TP_TN_FP_FN(zz.clone(), tt)
+            vals[key] = [torch.as_tensor(d).float(), torch.tensor([dn[0], float(dn[1])]),
+                         torch.stack([torch.as_tensor(v).float() for v in c])]
+            if tag == 'nonempty':                # IoU of an image empty in both is 0/0
+                vals[key].append(torch.as_tensor(mod.IoU_fn(zz.clone(), tt)).float())
+        for a, b in zip(vals['ref'], vals['ora']):
+            _same(a, b, 'metrics ' + tag)
+        fx[tag + '/Dice_fn'], fx[tag + '/Dice_fn_Nozero'], fx[tag + '/TP_TN_FP_FN'] = [_np(v) for v in vals['ref'][:3]]
+        if tag == 'nonempty':
+            fx[tag + '/IoU_fn'] = _np(vals['ref'][3])
+    assert torch.isnan(torch.as_tensor(ref_utils.IoU_fn(z.clone(), t)))          # the reference's 0/0
+    cw, cdw = torch.tensor([1.0, 3.0]), torch.tensor([0.7, 1.6])
+    for lname, kw in (('Dice_Loss', dict(smooth=1.0, reduction='mean')), ('Dice_Loss', dict(smooth=0.5, reduction='sum')),
+                      ('Dice_Loss', dict(reduction='none')), ('CEDiceLoss', dict(cediceweight=cdw, classweight=cw)),
+                      ('CEDiceLoss', dict(reduction='sum')), ('CEDiceLoss', dict())):
+        vals = {}
+        for key, mod in (('ref', ref_utils), ('ora', oracle)):
+            zz = z.clone().requires_grad_(True)
+            v = getattr(mod, lname)(**kw)(zz, t)
+            (v.sum() if v.dim() else v).backward()
+            vals[key] = (v.detach(), zz.grad.clone())
+        _same(vals['ref'][0], vals['ora'][0], lname)
+        _same(vals['ref'][1], vals['ora'][1], lname + ' grad')
+        key = '%s/%s' % (lname, '_'.join('%s=%s' % (k, 'w' if torch.is_tensor(v) else v) for k, v in sorted(kw.items())))
+        fx[key], fx[key + '/grad'] = _np(vals['ref'][0]), _np(vals['ref'][1])
+    np.savez_compressed(os.path.join(OUT, 'g12_metrics.npz'), **fx)
+    print('g12', [k for k in fx if '/' in k and not k.endswith('grad')])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ['g8']:
@@ -488,6 +539,9 @@ def main():
     if sys.argv[1:] == ['g11']:          # PolyLR learning-rate sequence
         ref_f, ref_u, ref_utils = _import_reference()
         return g11_polylr(ref_utils)
+    if sys.argv[1:] == ['g12']:          # binary metrics and the two remaining loss classes
+        ref_f, ref_u, ref_utils = _import_reference()
+        return g12_metrics(ref_utils)
     if sys.argv[1:] == ['g6']:
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()
@@ -510,6 +564,7 @@ def main():
     g8_pixelcoreg(ref_utils)
     g10_variants(ref_f, ref_u, ref_utils, oracle)
     g11_polylr(ref_utils)
+    g12_metrics(ref_utils)
     print('all golden fixtures written to', OUT)
 
 

@@ -339,6 +339,62 @@ def Dice_fn(inputs, targets, threshold=0.5):
     return total
 
 
+def _hard_fg(inputs, threshold):
+    return (F.softmax(inputs, dim=1)[:, 1] >= threshold).float()
+
+
+def Dice_fn_Nozero(inputs, targets, threshold=0.5):
+    """metrics2d.py:31-52 — (Dice sum as a float, images that are not empty in both target and prediction)."""
+    count = 0
+    for p, t in zip(_hard_fg(inputs, threshold), targets):
+        if t.sum() != 0 or p.sum() != 0:
+            count += 1
+    return float(Dice_fn(inputs, targets, threshold)), count
+
+
+def TP_TN_FP_FN(inputs, targets, threshold=0.5):
+    """metrics2d.py:54-70 — the loop overwrites the counts per image: the LAST image's values are returned."""
+    p, t = _hard_fg(inputs, threshold)[-1].reshape(-1), targets[-1].reshape(-1).float()
+    return (p * t).sum(), ((1 - p) * (1 - t)).sum(), (p * (1 - t)).sum(), ((1 - p) * t).sum()
+
+
+def IoU_fn(inputs, targets, threshold=0.5):
+    """metrics2d.py:72-84 — sum over the batch of intersection / union (0/0 = NaN is kept)."""
+    total = 0.0
+    for p, t in zip(_hard_fg(inputs, threshold), targets):
+        p, t = p.reshape(-1), t.reshape(-1).float()
+        inter = (p * t).sum()
+        total = total + inter / (p.sum() + t.sum() - inter)
+    return total
+
+
+class Dice_Loss(nn.Module):
+    """loss2d.py:63-85 — DiceLoss's logits branch."""
+
+    def __init__(self, smooth=1.0, reduction='mean'):
+        super().__init__()
+        self.inner = DiceLoss(smooth=smooth, reduction=reduction)
+
+    def forward(self, inputs, targets):
+        return self.inner(inputs, targets)
+
+
+class CEDiceLoss(nn.Module):
+    """loss2d.py:156-171."""
+
+    def __init__(self, cediceweight=None, classweight=None, reduction='mean'):
+        super().__init__()
+        self.cediceweight = cediceweight
+        self.ce = CrossEntropyLoss2d(weight=classweight, reduction=reduction)
+        self.dice = DiceLoss(weight=classweight, reduction=reduction)
+
+    def forward(self, inputs, targets):
+        a, b = self.ce(inputs, targets), self.dice(inputs, targets)
+        if self.cediceweight is not None:
+            return a * self.cediceweight[0] + b * self.cediceweight[1]
+        return a + b
+
+
 def sharpen(mask, temperature):
     """trainchaos_proposed_30cases1labeled.py:97-101 — p^T / sum_c p^T."""
     m = torch.pow(mask, temperature)

@@ -283,3 +283,39 @@ def test_pixelcoreg_g8(dev, cname):
             assert bad.mean() < 2e-4, (key, i, bad.sum())
     with pytest.raises(NotImplementedError):
         getattr(U, cname)(reduction='none')
+
+
+G12_LOSSES = [('Dice_Loss', dict(smooth=1.0, reduction='mean'), 'Dice_Loss/reduction=mean_smooth=1.0'),
+              ('Dice_Loss', dict(smooth=0.5, reduction='sum'), 'Dice_Loss/reduction=sum_smooth=0.5'),
+              ('Dice_Loss', dict(reduction='none'), 'Dice_Loss/reduction=none'),
+              ('CEDiceLoss', dict(cediceweight=[0.7, 1.6], classweight=[1.0, 3.0]), 'CEDiceLoss/cediceweight=w_classweight=w'),
+              ('CEDiceLoss', dict(reduction='sum'), 'CEDiceLoss/reduction=sum'), ('CEDiceLoss', dict(), 'CEDiceLoss/')]
+G12_BATCHES = [(slice(0, 5), 'all'), (slice(0, 1), 'first'), (slice(3, 5), 'nonempty')]
+
+
+def test_golden_metrics_and_remaining_losses(dev):
+    """Dice_fn / Dice_fn_Nozero / TP_TN_FP_FN / IoU_fn (metrics2d.py:8-84) from the fused statistics kernel and Dice_Loss /
+    CEDiceLoss (loss2d.py:63-85,156-171) against values of the reference (tests/golden/g12_metrics.npz), including the
+    images that are empty in the target (and in the prediction)."""
+    from aide_amd import utils as U
+    fx = np.load(os.path.join(GOLD, 'g12_metrics.npz'))
+    z, t = torch.from_numpy(fx['z']).to(dev), torch.from_numpy(fx['targets']).to(dev)
+    for batch, tag in G12_BATCHES:
+        zz, tt = z[batch].contiguous(), t[batch].contiguous()
+        close(U.Dice_fn(zz, tt), fx[tag + '/Dice_fn'], what='Dice_fn ' + tag)
+        d, c = U.Dice_fn_Nozero(zz, tt)
+        assert isinstance(d, float) and isinstance(c, int)
+        close(torch.tensor([d, float(c)]), fx[tag + '/Dice_fn_Nozero'], what='Dice_fn_Nozero ' + tag)
+        got = torch.stack([v.cpu() for v in U.TP_TN_FP_FN(zz, tt)])
+        assert torch.equal(got, torch.from_numpy(fx[tag + '/TP_TN_FP_FN'])), 'confusion counts are integers: exact'
+    close(U.IoU_fn(z[3:5].contiguous(), t[3:5].contiguous()), fx['nonempty/IoU_fn'], what='IoU_fn')
+    assert torch.isnan(U.IoU_fn(z, t))            # an image empty in both: 0/0, as the reference
+    with pytest.raises(NotImplementedError):
+        U.Dice_fn(z, t, threshold=0.3)
+    for lname, kw, key in G12_LOSSES:
+        kw = {k: torch.tensor(v) if isinstance(v, list) else v for k, v in kw.items()}
+        zz = z.clone().requires_grad_(True)
+        v = getattr(U, lname)(**kw)(zz, t)
+        (v.sum() if v.dim() else v).backward()
+        close(v, fx[key], what=key)
+        close(zz.grad, fx[key + '/grad'], what=key + ' grad')

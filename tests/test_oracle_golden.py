@@ -252,3 +252,32 @@ def test_pixelcoreg_g8(cname):
         loss.backward()
         for i, x in enumerate(a):
             close(torch.zeros_like(zs[0]) if x.grad is None else x.grad, fx[key + '/grad%d' % (i + 1)], what=key)
+
+
+G12_LOSSES = [('Dice_Loss', dict(smooth=1.0, reduction='mean'), 'Dice_Loss/reduction=mean_smooth=1.0'),
+              ('Dice_Loss', dict(smooth=0.5, reduction='sum'), 'Dice_Loss/reduction=sum_smooth=0.5'),
+              ('Dice_Loss', dict(reduction='none'), 'Dice_Loss/reduction=none'),
+              ('CEDiceLoss', dict(cediceweight=[0.7, 1.6], classweight=[1.0, 3.0]), 'CEDiceLoss/cediceweight=w_classweight=w'),
+              ('CEDiceLoss', dict(reduction='sum'), 'CEDiceLoss/reduction=sum'), ('CEDiceLoss', dict(), 'CEDiceLoss/')]
+G12_BATCHES = [(slice(0, 5), 'all'), (slice(0, 1), 'first'), (slice(3, 5), 'nonempty')]
+
+
+def test_g12_metrics_and_remaining_losses():
+    """metrics2d.py:8-84 and loss2d.py:63-85,156-171 restated in the oracle, against values of the reference."""
+    fx = load('g12_metrics.npz')
+    z, t = torch.from_numpy(fx['z']), torch.from_numpy(fx['targets'])
+    for batch, tag in G12_BATCHES:
+        zz, tt = z[batch], t[batch]
+        close(torch.as_tensor(oracle.Dice_fn(zz.clone(), tt)).float(), fx[tag + '/Dice_fn'])
+        d, c = oracle.Dice_fn_Nozero(zz.clone(), tt)
+        close(torch.tensor([d, float(c)]), fx[tag + '/Dice_fn_Nozero'])
+        close(torch.stack([torch.as_tensor(v).float() for v in oracle.TP_TN_FP_FN(zz.clone(), tt)]), fx[tag + '/TP_TN_FP_FN'])
+    close(torch.as_tensor(oracle.IoU_fn(z[3:5].clone(), t[3:5])).float(), fx['nonempty/IoU_fn'])
+    assert torch.isnan(torch.as_tensor(oracle.IoU_fn(z.clone(), t)))
+    for lname, kw, key in G12_LOSSES:
+        kw = {k: torch.tensor(v) if isinstance(v, list) else v for k, v in kw.items()}
+        zz = z.clone().requires_grad_(True)
+        v = getattr(oracle, lname)(**kw)(zz, t)
+        (v.sum() if v.dim() else v).backward()
+        close(v.detach(), fx[key], what=key)
+        close(zz.grad, fx[key + '/grad'], what=key + ' grad')
