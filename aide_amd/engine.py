@@ -703,6 +703,12 @@ class Engine(object):
         key = (n, h, w, x.device.index, bool(self.module.training), self._precision, groups)
         plan = self.plans.get(key)
         if plan is None:
+            # the kernels address one image of one operand with 32-bit byte offsets below 2^31 (buffer descriptors)
+            for op in self.graph.ops:
+                for t in (op.get('src'), op.get('dst')):
+                    if t is not None and t.C * (h >> t.level) * (w >> t.level) * 4 >= 2 ** 31:
+                        raise RuntimeError('aide_amd: %dx%d is too large: %d channels of %s exceed the 2 GiB per-image '
+                                           'operand limit of the kernels' % (h, w, t.C, t.name))
             plan = Plan(self.graph, self.params, n, h, w, x.device, bool(self.module.training), self._precision,
                         groups)
             self.plans[key] = plan

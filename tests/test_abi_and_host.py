@@ -190,3 +190,13 @@ def test_polylr_matches_reference_sequence():
     assert make_scheduler('None', opt, 10) is None
     with pytest.raises(ValueError):
         make_scheduler('cosine', opt, 10)
+
+
+def test_per_image_operand_limit():
+    """Planes whose channel slices exceed the 32-bit (2 GiB) per-image offsets of the kernels raise instead of
+    wrapping: FuseUNet's 128-channel skip buffer at 2048x2048 is exactly 2 GiB."""
+    from aide_amd.models_twomodalinputs import fuseunet
+    net = fuseunet(2)
+    x = torch.empty(1, 3, 2048, 2048, device='meta')
+    with pytest.raises(RuntimeError, match='too large'):
+        net.engine.plan_for((x, x))
