@@ -34,6 +34,12 @@
 //     columns, pixel range split over workgroups into slabs [split][tap][co][ci] reduced in fixed order
 //     (aide_wgrad_reduce_launch, shared with the fp32 kernels) -> bit-reproducible.
 #include "common.h"
+
+extern "C" int aide_conv3x3_wgrad_stem_splits(int N, int H, int W);
+extern "C" int aide_conv3x3_wgrad_stem_supported(int Co, int Ci, int H, int W);                  // conv3x3_wgrad_stem.hip
+extern "C" int aide_conv3x3_wgrad_stem(const void* dz, int dz_bf16, int64_t dz_bs, const float* x, int64_t x_bs, float* dw,
+                                       int N, int Co, int Ci, int H, int W, float* ws, int splits, int round_bf16,
+                                       hipStream_t stream);
 #include <stdlib.h>
 
 int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream);
@@ -933,6 +939,8 @@ int aide_conv3x3_wgrad_bf16_supported(int Co, int Ci, int H, int W) {
 }
 
 int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W) {
+    if (aide_conv3x3_wgrad_stem_supported(Co, Ci, H, W))        // folded-tap kernel (conv3x3_wgrad_stem.hip)
+        return aide_conv3x3_wgrad_stem_splits(N, H, W);
     const int tco = 32 * wgrad_bf16_nwco(N, Co, Ci, H, W);
     const long tiles = (long)((Co + tco - 1) / tco) * ((Ci + 63) / 64);
     const long chunks = (long)N * (H / wgrad_bf16_rows()) * (W / 32);
@@ -954,6 +962,10 @@ int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, co
                                   float* dw, int N, int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
     if (!dz || !a || !dw || !ws || N <= 0 || !aide_conv3x3_wgrad_bf16_supported(Co, Ci, H, W)) return AIDE_ERR_ARG;
     if ((dz_bs % (dz_bf16 ? 8 : 4)) || (a_bs % (a_bf16 ? 8 : 4))) return AIDE_ERR_ARG;
+    if (a_bf16 && aide_conv3x3_wgrad_stem_supported(Co, Ci, H, W)) return AIDE_ERR_ARG;   // stems read the fp32 images
+    if (aide_conv3x3_wgrad_stem_supported(Co, Ci, H, W))                        // Ci <= 3
+        return aide_conv3x3_wgrad_stem(dz, dz_bf16, dz_bs, (const float*)a, a_bs, dw, N, Co, Ci, H, W, ws,
+                                       aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W), 1, stream);
     BgArgs g;
     g.dz = dz; g.x = a; g.slabs = ws; g.dz_bs = dz_bs; g.x_bs = a_bs;
     g.N = N; g.Co = Co; g.Ci = Ci; g.H = H; g.W = W;

@@ -14,6 +14,12 @@
 // order into dW[Co][Ci][3][3] (deterministic, no atomics).
 #include "common.h"
 
+extern "C" int aide_conv3x3_wgrad_stem_splits(int N, int H, int W);
+extern "C" int aide_conv3x3_wgrad_stem_supported(int Co, int Ci, int H, int W);                  // conv3x3_wgrad_stem.hip
+extern "C" int aide_conv3x3_wgrad_stem(const void* dz, int dz_bf16, int64_t dz_bs, const float* x, int64_t x_bs, float* dw,
+                                       int N, int Co, int Ci, int H, int W, float* ws, int splits, int round_bf16,
+                                       hipStream_t stream);
+
 namespace {
 
 struct WgradArgs {
@@ -386,6 +392,8 @@ extern "C" {
 
 // Number of pixel-range splits (= slabs) used for this problem.
 int aide_conv3x3_wgrad_splits(int N, int Co, int Ci, int H, int W) {
+    if (aide_conv3x3_wgrad_stem_supported(Co, Ci, H, W))        // folded-tap kernel: 4 x 64-pixel tiles, 4 workgroups per CU
+        return aide_conv3x3_wgrad_stem_splits(N, H, W);
     int nco, nci;
     wgrad_tiles(wgrad_variant(Co, Ci), Co, Ci, &nco, &nci);
     const long tiles = (long)N * ((H + 3) / 4) * ((W + 15) / 16);
@@ -407,6 +415,9 @@ size_t aide_conv3x3_wgrad_ws_bytes(int N, int Co, int Ci, int H, int W) {
 int aide_conv3x3_wgrad(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw,
                        int N, int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
     if (!dz || !a || !dw || !ws || N <= 0 || Co <= 0 || Ci <= 0) return AIDE_ERR_ARG;
+    if (aide_conv3x3_wgrad_stem_supported(Co, Ci, H, W) && dz_bs % 4 == 0)      // Ci <= 3: taps folded into the GEMM's N
+        return aide_conv3x3_wgrad_stem(dz, 0, dz_bs, a, a_bs, dw, N, Co, Ci, H, W, ws,
+                                       aide_conv3x3_wgrad_splits(N, Co, Ci, H, W), 0, stream);
     WgradArgs g;
     g.dz = dz; g.a = a; g.slabs = ws; g.dz_bs = dz_bs; g.a_bs = a_bs;
     g.N = N; g.Co = Co; g.Ci = Ci; g.H = H; g.W = W;

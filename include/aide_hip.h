@@ -72,6 +72,15 @@ int aide_conv3x3_wgrad_wino_splits(int N, int Co, int Ci, int H, int W);
 size_t aide_conv3x3_wgrad_wino_ws_bytes(int N, int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_wino(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
                             int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
+/* stem layers (Ci <= 3; H % 4 == 0, W % 64 == 0): the nine taps folded into the GEMM's N dimension, bound by reading dz once.
+ * dz fp32 or bf16-stored (dz_bf16), x fp32; round_bf16: operands rounded to bf16 when staged (the bf16 mode's contract);
+ * ws / splits as for aide_conv3x3_wgrad / aide_conv3x3_wgrad_bf16 (which dispatch here themselves).
+ * Replaces autograd's weight gradient of nn.Conv2d(3, C, 3, padding=1) (netblocks.py:24 in modal*_downblock1, UNet.py:19). */
+int aide_conv3x3_wgrad_stem_supported(int Co, int Ci, int H, int W);
+int aide_conv3x3_wgrad_stem_splits(int N, int H, int W);
+int aide_conv3x3_wgrad_stem(const void* dz, int dz_bf16, int64_t dz_bs, const float* x, int64_t x_bs, float* dw,
+                            int N, int Co, int Ci, int H, int W, float* ws, int splits, int round_bf16,
+                            aide_stream_t stream);
 /* transposed F(4x4,3x3) for the large layers: H % 4 == 0, W % 4 == 0, H >= 8, W >= 16, Co % 64 == 0, Ci % 32 == 0 */
 int aide_conv3x3_wgrad_wino4_supported(int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_wino4_splits(int N, int Co, int Ci, int H, int W);

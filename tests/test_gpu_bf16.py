@@ -313,6 +313,7 @@ WGRAD_CASES = [
     # N, Co, Ci, H, W
     (2, 32, 32, 32, 32), (1, 64, 64, 64, 64), (2, 64, 128, 16, 32), (1, 128, 64, 32, 96), (2, 256, 256, 32, 32),
     (1, 96, 32, 8, 64), (3, 64, 64, 4, 32), (2, 32, 3, 16, 64), (1, 64, 40, 8, 32),     # ragged input channels
+    (1, 64, 3, 8, 128), (2, 96, 2, 4, 64), (2, 32, 3, 32, 32),       # stems: folded-tap kernel (W % 64 == 0) / general kernel
 ]
 
 
@@ -356,6 +357,10 @@ def test_conv3x3_wgrad_bf16(dev, case):
     dw2 = torch.empty_like(dw)
     ops.conv3x3_wgrad_bf16(dy.to(dev), x.to(dev), dw2)
     assert torch.equal(dw, dw2), 'wgrad must be bit-reproducible'
+    if ci <= 3:            # the stem layers read a bf16-STORED dz next to the fp32 image
+        dw3 = torch.empty_like(dw)
+        ops.conv3x3_wgrad_bf16(dy.to(dev).bfloat16(), x.to(dev), dw3)
+        _close(dw3, dw_exact, 5e-5, 'wgrad, bf16-stored dz %s' % (case,))
 
 
 # ------------------------------------------------------------------------------------------ whole network

@@ -24,6 +24,8 @@ CONV_CASES = [
     # narrow layers of the UNet16 ... UNet2 variants (UNet.py:274-400): partial 32-channel tile, masked channel chunk
     (2, 3, 2, 32, 32), (2, 2, 2, 32, 32), (1, 4, 2, 64, 32), (2, 8, 4, 16, 16), (1, 16, 8, 20, 20), (2, 32, 16, 32, 32),
     (1, 16, 16, 64, 64), (2, 16, 32, 16, 16), (1, 2, 4, 40, 24),
+    # stem layers on the folded-tap weight-gradient kernel (Ci <= 3, W % 64 == 0, H % 4 == 0)
+    (2, 3, 32, 64, 64), (1, 3, 64, 8, 128), (3, 2, 40, 4, 64), (1, 1, 32, 12, 192), (4, 3, 32, 128, 128),
 ]
 
 
