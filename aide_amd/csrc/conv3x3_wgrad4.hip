@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
 
     // ---- dz tiles: thread = (co_l, tile), four 16-byte row loads straight into registers ----
     const int zco = 16 * wid + (lane >> 2), zt = lane & 3;
-    const unsigned offZ = (unsigned)(zco * HW + 4 * zt) * 4u;
+    // (Co % 64 == 32: the trailing half tile reads zeros for its upper 32 channels and drops their rows in the epilogue)
+    const unsigned offZ = co0 + zco < g.Co ? (unsigned)(zco * HW + 4 * zt) * 4u : BUF_OOB;
     // ---- raw input units: interior 32 ci x 6 rows x 4 float4 (3 rounds), edges 32 x 6 x 2 dwords (2 rounds) ----
     // Which lanes must read zeros depends on the chunk (top / bottom image row, first / last column block) but
     // the lane sets are fixed: they are kept as 64-bit lane masks in scalar registers, the per-chunk halo
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
             const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
             for (int o = 0; o < 9; ++o)
-                slab[((long)o * g.Co + co) * g.Ci + ci] = wp[o] + xbuf[(((wid ^ 1) * 72) + rr * 9 + o) * 64 + lane];
+                if (co < g.Co) slab[((long)o * g.Co + co) * g.Ci + ci] = wp[o] + xbuf[(((wid ^ 1) * 72) + rr * 9 + o) * 64 + lane];
         }
     };
     if (ph == 0) epilogue(ic<0>{}); else epilogue(ic<1>{});
@@ -384,11 +385,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
 extern "C" {
 
 int aide_conv3x3_wgrad_wino4_supported(int Co, int Ci, int H, int W) {
-    return (H % 4 == 0 && W % 4 == 0 && H >= 8 && W >= 16 && Co % 64 == 0 && Ci % 32 == 0) ? 1 : 0;
+    return (H % 4 == 0 && W % 4 == 0 && H >= 8 && W >= 16 && Co % 32 == 0 && Ci % 32 == 0) ? 1 : 0;
 }
 
 int aide_conv3x3_wgrad_wino4_splits(int N, int Co, int Ci, int H, int W) {
-    const long blocks = (long)(Co / 64) * (Ci / 32);
+    const long blocks = (long)((Co + 63) / 64) * (Ci / 32);
     const long chunks = (long)N * (H / 4) * ((W + 15) / 16);
     long s = (256 + blocks - 1) / blocks;
     if (s > chunks / 2) s = chunks / 2;
@@ -415,7 +416,7 @@ int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int
     g.dz = dz; g.a = a; g.slabs = ws; g.dz_bs = dz_bs; g.a_bs = a_bs;
     g.N = N; g.Co = Co; g.Ci = Ci; g.H = H; g.W = W;
     g.rows_t = H / 4; g.cols_c = (W + 15) / 16;
-    g.n_co_tiles = Co / 64; g.n_ci_tiles = Ci / 32;
+    g.n_co_tiles = (Co + 63) / 64; g.n_ci_tiles = Ci / 32;
     g.chunks_total = N * g.rows_t * g.cols_c;
     g.splits = aide_conv3x3_wgrad_wino4_splits(N, Co, Ci, H, W);
     const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;

@@ -221,7 +221,10 @@ class Plan(object):
                     if bf16 and lib.aide_conv3x3_wgrad_bf16_supported(cout, cin, hh, ww):
                         st['wino_w'] = BF16
                         max_wg = max(max_wg, lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, cout, cin, hh, ww))
-                    elif USE_WINOGRAD[0] and USE_WINOGRAD4[0] and lib.aide_conv3x3_wgrad_wino4_supported(cout, cin, hh, ww):
+                    elif USE_WINOGRAD[0] and USE_WINOGRAD4[0] and cout % 64 == 0 and \
+                            lib.aide_conv3x3_wgrad_wino4_supported(cout, cin, hh, ww):
+                        # (a trailing half tile -- 32->32 @256x256 -- is 71 -> 56 us alone, but the 144 KB workgroups keep
+                        # the main stream's kernels off the CUs: the step lost 0.5 %, so those layers stay on the direct kernel)
                         st['wino_w'] = 4
                         max_wg = max(max_wg, lib.aide_conv3x3_wgrad_wino4_ws_bytes(n, cout, cin, hh, ww))
                     elif USE_WINOGRAD[0] and lib.aide_conv3x3_wgrad_wino_supported(cout, cin, hh, ww):

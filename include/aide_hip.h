@@ -81,7 +81,8 @@ int aide_conv3x3_wgrad_stem_splits(int N, int H, int W);
 int aide_conv3x3_wgrad_stem(const void* dz, int dz_bf16, int64_t dz_bs, const float* x, int64_t x_bs, float* dw,
                             int N, int Co, int Ci, int H, int W, float* ws, int splits, int round_bf16,
                             aide_stream_t stream);
-/* transposed F(4x4,3x3) for the large layers: H % 4 == 0, W % 4 == 0, H >= 8, W >= 16, Co % 64 == 0, Ci % 32 == 0 */
+/* transposed F(4x4,3x3) for the large layers: H % 4 == 0, W % 4 == 0, H >= 8, W >= 16, Co % 32 == 0 (a trailing half tile of 32
+ * is computed and dropped), Ci % 32 == 0 */
 int aide_conv3x3_wgrad_wino4_supported(int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_wino4_splits(int N, int Co, int Ci, int H, int W);
 size_t aide_conv3x3_wgrad_wino4_ws_bytes(int N, int Co, int Ci, int H, int W);

@@ -304,7 +304,8 @@ def test_conv3x3_wgrad_winograd(dev, case):
 
 
 @pytest.mark.parametrize('case', [(2, 64, 64, 32, 32), (1, 128, 64, 64, 64), (2, 32, 128, 16, 16), (1, 256, 256, 32, 32),
-                                  (1, 64, 128, 80, 80), (3, 32, 64, 8, 16), (1, 96, 192, 40, 24), (2, 64, 64, 12, 36)])
+                                  (1, 64, 128, 80, 80), (3, 32, 64, 8, 16), (1, 96, 192, 40, 24), (2, 64, 64, 12, 36),
+                                  (2, 32, 32, 32, 32), (1, 64, 96, 16, 48), (1, 32, 160, 8, 16)])   # trailing half co tile
 def test_conv3x3_wgrad_winograd4(dev, case):
     """Weight gradient via the transposed Winograd F(4x4,3x3) vs aten, incl. ragged column blocks (W % 16 != 0),
     odd chunk counts per split and channel-slice operands.  Bound 1e-4 of the gradient scale (north star: 1e-3)."""
