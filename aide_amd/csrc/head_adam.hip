@@ -211,6 +211,7 @@ int head_bwd_t(const float* dy, int64_t dy_bs, const XT* x, int64_t x_bs, const 
         switch (K) { case 1: AIDE_HEAD_DG(1); break; case 2: AIDE_HEAD_DG(2); break; case 3: AIDE_HEAD_DG(3); break; default: AIDE_HEAD_DG(4); }
 #undef AIDE_HEAD_DG
     }
+    if (!dw) return aide_launch_status();      // data gradient only (the weight gradient is issued on another stream)
     const int nblocks = (int)max(1L, min((total4 + 255) / 256, 256L));
     int rc;
     switch (K) {
@@ -235,7 +236,7 @@ int aide_head1x1_fwd(const float* x, int64_t x_bs, const float* w, const float* 
 }
 size_t aide_head1x1_ws_bytes(int C, int K) { return (size_t)256 * (K * C + K) * sizeof(double); }
 
-// dy: [N][K][HW] -> dx [N][C][HW] (may be NULL), dw [K][C], db [K]
+// dy: [N][K][HW] -> dx [N][C][HW] (may be NULL), dw [K][C] + db [K] (dw may be NULL: data gradient only)
 int aide_head1x1_bwd(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, const float* w, float* dx,
                      int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
                      hipStream_t stream) {

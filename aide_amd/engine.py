@@ -88,6 +88,7 @@ PRECISIONS = ('fp32', 'bf16')
 USE_WINOGRAD4 = [True]
 import os as _os
 PROBE_SKIP_WGRAD = [bool(_os.environ.get('AIDE_PROBE_SKIP_WGRAD'))]
+HEAD_WGRAD_SIDE = [_os.environ.get('AIDE_HEAD_WGRAD_SIDE', '1') != '0']      # A-B switch
 STORE_BF16 = [True]            # precision='bf16': z / dz stored as bf16 (A-B switch)
 STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 where every reader / writer allows it
 STORE_G_BF16 = [True]          # ... and the gradients of those activations
@@ -503,10 +504,19 @@ class Plan(object):
             if kind == 'head':
                 conv = st['conv']
                 k = conv.out_channels
-                ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1),
-                                self.gview(st['src']) if sg is not None else None,
-                                gslot(conv.weight).view(k, -1), gslot(conv.bias), ws=self.head_ws)
                 assert sg is None or not sg['accumulate']
+                if side is not None and sg is not None and HEAD_WGRAD_SIDE[0]:
+                    # the head's weight gradient (one pass over the widest feature map) has no consumer until the
+                    # optimizer: side stream, so that the dependent chain starts with the data gradient alone
+                    with torch.cuda.stream(side):
+                        ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1), None,
+                                        gslot(conv.weight).view(k, -1), gslot(conv.bias), ws=self.head_ws)
+                    ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1),
+                                    self.gview(st['src']), None, None, ws=self.head_ws)
+                else:
+                    ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1),
+                                    self.gview(st['src']) if sg is not None else None,
+                                    gslot(conv.weight).view(k, -1), gslot(conv.bias), ws=self.head_ws)
             elif kind in ('conv', 'convT'):
                 conv, bn = st['conv'], st['bn']
                 z = st['z']
