@@ -387,13 +387,12 @@ struct W4PackDesc {
     long block_start;
 };
 
-// One workgroup transforms a 32 co x 32 ci filter tile (see wino_pack_multi_kernel): filters -> LDS, one
+// One workgroup transforms a 32 co x 32 ci filter tile (see wino_pack_multi_kernel): one
 // (co, ci) pair per thread and group, 36 runs of 128 floats per group of 4 channels:
 //   uf [ci/4][36][2][Co][2]   ud [co/4][36][2][Ci][2] (taps reversed): per (channel group, position) the two
 //   channel pairs as separate [row][2] runs = the A-operand lane order of the kernel's direct fragment loads
-constexpr int P4_T = 32, P4_ROW = P4_T * 9 + 1;
+constexpr int P4_T = 32;
 __global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc* __restrict__ descs, int n) {
-    __shared__ float wt[P4_T * P4_ROW];
     __shared__ __attribute__((aligned(16))) float ot[36 * 128];
     const long blk = blockIdx.x;
     int lo = 0, hi = n - 1;
@@ -407,13 +406,6 @@ __global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc*
     const int tb = (int)(blk - d.block_start);
     const int co0 = (tb / tiles_ci) * P4_T, ci0 = (tb % tiles_ci) * P4_T;
     const int nci = min(P4_T, d.Ci - ci0);
-    for (int e = tid; e < P4_T * P4_T * 9; e += 128) {
-        const int co = e / (P4_T * 9), r = e - co * (P4_T * 9);
-        float v = 0.f;
-        if (co0 + co < d.Co && r < nci * 9) v = d.w[((long)(co0 + co) * d.Ci + ci0) * 9 + r];
-        wt[co * P4_ROW + r] = v;
-    }
-    __syncthreads();
     float g[9], u[36];
     const int lo2 = tid & 3, hi5 = tid >> 2;
     for (int grp = 0; grp < 16; ++grp) {                   // 8 forward groups of 4 ci, 8 dgrad groups of 4 co
@@ -424,8 +416,14 @@ __global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc*
         const int co = fwd ? hi5 : 4 * q + lo2, ci = fwd ? 4 * q + lo2 : hi5;
         const bool live = fwd ? (ci0 + 4 * q < d.Ci) : (co0 + 4 * q < d.Co);
         if (!live) continue;
+        {
+            // straight from global: the 32 x 32 tile (36 KB) is read by 16 groups and stays in L1 / L2; the LDS copy of
+            // it (37 KB per workgroup) held the kernel at two workgroups per CU (re-layout of a FuseUNet step 0.39 -> 0.31 ms)
+            const bool in = co0 + co < d.Co && ci < nci;
+            const float* wp = d.w + ((long)(co0 + co) * d.Ci + ci0 + ci) * 9;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) g[t] = wt[co * P4_ROW + ci * 9 + (fwd ? t : 8 - t)];
+            for (int t = 0; t < 9; ++t) g[t] = in ? wp[fwd ? t : 8 - t] : 0.f;
+        }
         wino4_g(g, u);
         // per position two runs (channel pair 0 / 1) of [row][2]: row = co (forward) resp. ci (dgrad)
         const int otid = (lo2 >> 1) * 64 + hi5 * 2 + (lo2 & 1);

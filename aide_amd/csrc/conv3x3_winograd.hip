@@ -312,13 +312,11 @@ __device__ __forceinline__ void wino_g(const float g[9], float u[16]) {
     }
 }
 
-// One workgroup transforms a 32 co x 32 ci filter tile.  The 9-tap filters are read as 32 contiguous
-// 1152-byte runs into LDS; every thread computes G g G^T for one (co, ci) pair per group and the 16
-// transformed values go back through LDS so that global stores are contiguous 1 KB runs of the packed
+// One workgroup transforms a 32 co x 32 ci filter tile.  Every thread computes G g G^T for one (co, ci) pair per group
+// (filters straight from global: the tile stays in L1 / L2) and the 16 transformed values go through LDS so that global stores are contiguous 1 KB runs of the packed
 // layouts  uf [ci/8][16][Co][8 ci]  and  ud [co/8][16][Ci][8 co]  (4 groups of 8 channels each).
-constexpr int WP_T = 32, WP_ROW = WP_T * 9 + 1;          // odd LDS row stride
+constexpr int WP_T = 32;
 __global__ __launch_bounds__(256) void wino_pack_multi_kernel(const WinoPackDesc* __restrict__ descs, int n) {
-    __shared__ float wt[WP_T * WP_ROW];                  // [co][ci * 9 + tap]
     __shared__ __attribute__((aligned(16))) float ot[16 * 256];   // [p][256 pairs]
     const long blk = blockIdx.x;
     int lo = 0, hi = n - 1;
@@ -332,14 +330,6 @@ __global__ __launch_bounds__(256) void wino_pack_multi_kernel(const WinoPackDesc
     const int tb = (int)(blk - d.block_start);
     const int co0 = (tb / tiles_ci) * WP_T, ci0 = (tb % tiles_ci) * WP_T;
     const int nci = min(WP_T, d.Ci - ci0);               // valid input channels of this tile
-    // ---- filters -> LDS (zero outside [Co] x [Ci]) ----
-    for (int e = tid; e < WP_T * WP_T * 9; e += 256) {
-        const int co = e / (WP_T * 9), r = e - co * (WP_T * 9);
-        float v = 0.f;
-        if (co0 + co < d.Co && r < nci * 9) v = d.w[((long)(co0 + co) * d.Ci + ci0) * 9 + r];
-        wt[co * WP_ROW + r] = v;
-    }
-    __syncthreads();
     float g[9], u[16];
     const int lo3 = tid & 7, hi5 = tid >> 3;
     for (int grp = 0; grp < 8; ++grp) {
@@ -351,8 +341,12 @@ __global__ __launch_bounds__(256) void wino_pack_multi_kernel(const WinoPackDesc
         const int co = fwd ? hi5 : 8 * q + lo3, ci = fwd ? 8 * q + lo3 : hi5;
         const bool live = fwd ? (ci0 + 8 * q < d.ci_pad) : (co0 + 8 * q < d.co_pad);   // uniform
         if (!live) continue;
+        {   // straight from global (zero outside [Co] x [Ci]): the tile is read by 8 groups and stays in L1 / L2
+            const bool in = co0 + co < d.Co && ci < nci;
+            const float* wp = d.w + ((long)(co0 + co) * d.Ci + ci0 + ci) * 9;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) g[t] = wt[co * WP_ROW + ci * 9 + (fwd ? t : 8 - t)];
+            for (int t = 0; t < 9; ++t) g[t] = in ? wp[fwd ? t : 8 - t] : 0.f;
+        }
         wino_g(g, u);
 #pragma unroll
         for (int p = 0; p < 16; ++p) ot[p * 256 + tid] = u[p];
