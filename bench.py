@@ -49,7 +49,8 @@ def parse():
     ap.add_argument('--precision', default=None, choices=('fp32', 'bf16'),
                     help='conv arithmetic (default: fp32, bf16 for workload c5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=None,
+                    help='oracle steps timed for cpu_baseline (default: 5 for c2 = about 10 s of CPU work, 2 for the larger workloads)')
     ap.add_argument('--no-kernel-events', action='store_true',
                     help='do not bracket the MFMA conv launches with HIP events (roofline -> null)')
     ap.add_argument('--event-steps', type=int, default=1,
@@ -263,8 +264,9 @@ def main():
                             avg_launch_ms=round(a['avg_ms'], 5),
                             alg_gflop_per_launch=round(a['flops'] / a['launches'] / 1e9, 3))
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and args.cpu_steps > 0:
-            cpu = cpu_baseline(model_name, batch, size, args.cpu_steps, args.cpu_threads)
+        cpu_steps = args.cpu_steps if args.cpu_steps is not None else (5 if args.workload in ('c2', 'tiny') else 2)
+        if world == 1 and not args.no_cpu_baseline and cpu_steps > 0:
+            cpu = cpu_baseline(model_name, batch, size, cpu_steps, args.cpu_threads)
         line = dict(metric='training images/sec %s bs=%d/GPU' % (
                         ('FuseUNet %dx%dx2' if model_name == 'fuseunet' else 'UNet %dx%d') % (size, size), batch),
                     value=round(value, 2), unit='images/sec', n_gpus=world, steps=args.steps,
