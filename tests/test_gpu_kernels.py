@@ -150,7 +150,8 @@ def test_maxpool_ties_and_backward(dev):
     assert torch.equal(dx2.cpu(), xr.grad + 1.0)
 
 
-@pytest.mark.parametrize('shape', [(2, 8, 16, 16), (1, 4, 20, 12), (2, 3, 1, 1)])
+@pytest.mark.parametrize('shape', [(2, 8, 16, 16), (1, 4, 20, 12), (2, 3, 1, 1),
+                                   (1, 3, 64, 64), (2, 2, 16, 128), (1, 2, 48, 192)])      # whole 32 x 128 output tiles
 def test_upsample_bilinear(dev, shape):
     from aide_amd import ops
     n, c, h, w = shape
