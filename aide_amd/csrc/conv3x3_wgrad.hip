@@ -400,7 +400,8 @@ int aide_conv3x3_wgrad_splits(int N, int Co, int Ci, int H, int W) {
     // one workgroup per CU (two 45 KB tile buffers + 144 accumulator registers per lane): aim for
     // one full round of 256 workgroups, each paying the tile-pipeline prologue only once
     const long blocks = (long)nco * nci;
-    long s = (256 + blocks - 1) / blocks;
+    static const long target = getenv("AIDE_WGD_TARGET") ? atol(getenv("AIDE_WGD_TARGET")) : 256;     // probe switch
+    long s = (target + blocks - 1) / blocks;
     if (s > tiles) s = tiles;
     if (s < 1) s = 1;
     return (int)s;
@@ -715,7 +716,8 @@ int aide_conv3x3_wgrad_wino_supported(int Co, int Ci, int H, int W) {
 int aide_conv3x3_wgrad_wino_splits(int N, int Co, int Ci, int H, int W) {
     const long blocks = (long)((Co + 63) / 64) * ((Ci + 63) / 64);
     const long chunks = (long)N * (H / 2) * ((W + 15) / 16);
-    long s = (256 + blocks - 1) / blocks;
+    static const long target = getenv("AIDE_WG2_TARGET") ? atol(getenv("AIDE_WG2_TARGET")) : 256;     // probe switch
+    long s = (target + blocks - 1) / blocks;
     if (s > chunks) s = chunks;
     return (int)(s < 1 ? 1 : s);
 }

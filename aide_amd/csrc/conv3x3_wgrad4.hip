@@ -391,7 +391,13 @@ int aide_conv3x3_wgrad_wino4_supported(int Co, int Ci, int H, int W) {
 int aide_conv3x3_wgrad_wino4_splits(int N, int Co, int Ci, int H, int W) {
     const long blocks = (long)((Co + 63) / 64) * (Ci / 32);
     const long chunks = (long)N * (H / 4) * ((W + 15) / 16);
-    long s = (256 + blocks - 1) / blocks;
+    // Workgroups per launch.  One per CU (256) is NOT the optimum for a kernel that lives on the side stream: its 144 KB
+    // workgroups own a CU and keep the main stream's kernels off it.  With 128 the weight gradient takes half of the chip
+    // for twice as long and the dependent chain (BatchNorm backward, dgrad, pooling / up-sampling backward) runs on the
+    // other half undisturbed: same-box C2 step 537 -> 566 images/s (256 -> 128; 192: 552, 144: 550, 112: 552, 96: 525,
+    // 64: 448, 384: 526, 512: 520), co-teaching step 123.7 -> 126.9.  (Probe switch AIDE_WG4_TARGET.)
+    static const long target = getenv("AIDE_WG4_TARGET") ? atol(getenv("AIDE_WG4_TARGET")) : 128;
+    long s = (target + blocks - 1) / blocks;
     if (s > chunks / 2) s = chunks / 2;
     if (s < 1) s = 1;
     return (int)s;
