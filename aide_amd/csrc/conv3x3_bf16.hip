@@ -944,9 +944,11 @@ int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W) {
     const int tco = 32 * wgrad_bf16_nwco(N, Co, Ci, H, W);
     const long tiles = (long)((Co + tco - 1) / tco) * ((Ci + 63) / 64);
     const long chunks = (long)N * (H / wgrad_bf16_rows()) * (W / 32);
-    static const long target = getenv("AIDE_BF16_WG_TARGET") ? atol(getenv("AIDE_BF16_WG_TARGET")) : 256;   // probe
-    long s = (target + tiles - 1) / tiles;       // one round of workgroups, one per CU (512 / 1024 measured 6 % / 16 % slower:
-                                                 // twice the slab bytes for the fixed-order reduce, twice the prologues)
+    static const long target = getenv("AIDE_BF16_WG_TARGET") ? atol(getenv("AIDE_BF16_WG_TARGET")) : 192;   // probe
+    long s = (target + tiles - 1) / tiles;       // fewer workgroups than CUs: the kernel runs on the side stream and leaves
+                                                 // CUs to the dependent chain (same-box C5 step: 256 -> 439.9, 224 -> 442.9,
+                                                 // 192 -> 444.4, 128 -> 428; 512 / 1024 measured 6 % / 16 % slower: twice the
+                                                 // slab bytes for the fixed-order reduce, twice the prologues)
     if (s > chunks / 2) s = chunks / 2;          // at least two stages per workgroup
     if (s < 1) s = 1;
     return (int)s;

@@ -455,8 +455,9 @@ int aide_conv3x3_wino4_supported(int Cin, int H, int W, int Cout) {
 int aide_conv3x3_wino4_splitk(int N, int Cin, int H, int W, int Cout) {
     const long nb = (long)((H + 15) / 16) * ((W + 31) / 32) * N * ((Cout + 63) / 64);
     const int pairs = Cin / 8;                             // a split gets a whole number of stage pairs
+    static const long target = getenv("AIDE_W4_SK_TARGET") ? atol(getenv("AIDE_W4_SK_TARGET")) : 200;     // probe switch
     int s = 1;
-    while (nb * s < 200 && pairs % (s * 2) == 0 && s * 2 <= pairs / 4) s *= 2;
+    while (nb * s < target && pairs % (s * 2) == 0 && s * 2 <= pairs / 4) s *= 2;
     return s;
 }
 
