@@ -1,6 +1,7 @@
 // Shared helpers for the AIDE hot-path HIP kernels (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -63,6 +64,21 @@ __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(bf16_store_t* p, float v) { *p = (bf16_store_t)(cvt_pk_bf16(v, 0.f) & 0xffffu); }
 
 static inline int aide_launch_status() { return (int)hipGetLastError(); }
+
+// ---- optional per-kernel timing (ktimer.hip; include/aide_hip.h "kernel timer"): a launch of an armed family carries
+// a start / stop event pair that receives the dispatch's own begin / end timestamps
+enum { AIDE_KT_IGEMM = 0, AIDE_KT_WINO2 = 1, AIDE_KT_WINO4 = 2, AIDE_KT_WGRAD = 3, AIDE_KT_WGRAD_WINO2 = 4,
+       AIDE_KT_WGRAD4 = 5, AIDE_KT_WGRAD_STEM = 6, AIDE_KT_BF16 = 7, AIDE_KT_WGRAD_BF16 = 8, AIDE_KT_CONVT = 9 };
+extern "C" int aide_ktimer_slot(int family, double flops, hipEvent_t* e0, hipEvent_t* e1);
+#define AIDE_LAUNCH_TIMED(FAM, FLOPS, kernel, grid, block, lds, stream, ...)                                  \
+    do {                                                                                                      \
+        hipEvent_t kt_e0_, kt_e1_;                                                                            \
+        if (aide_ktimer_slot(FAM, FLOPS, &kt_e0_, &kt_e1_))                                                   \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, kt_e0_, kt_e1_, 0, __VA_ARGS__);          \
+        else                                                                                                  \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                \
+    } while (0)
+#define AIDE_CONV_FLOPS(N, H, W, Co, Ci) (2.0 * (double)(N) * (double)(H) * (double)(W) * (double)(Co) * (double)(Ci) * 9.0)
 
 // XCD-aware bijective remap of a 1-D block id: the hardware dispatches block b to XCD b % 8;
 // give every XCD a contiguous range of logical tiles so neighbouring tiles (shared halo rows,

@@ -346,12 +346,14 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
     const long nb = (long)a.tiles_w * a.tiles_h * a.N * a.n_co_tiles * a.splitk;
     const bool vec = (a.W % 4 == 0) && (a.x_bs % 4 == 0);
     if (vec) {
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<TCO, WAVES_M, WM, WN, PT_W, CK, true>), dim3((unsigned)nb),
-                           dim3(256), 0, stream, a);
+        AIDE_LAUNCH_TIMED(AIDE_KT_IGEMM, AIDE_CONV_FLOPS(a.N, a.H, a.W, a.Cout, a.Cin),
+                          (conv3x3_mfma_kernel<TCO, WAVES_M, WM, WN, PT_W, CK, true>), dim3((unsigned)nb),
+                          dim3(256), 0, stream, a);
     } else {
         if constexpr (CAN_SCALAR)
-            hipLaunchKernelGGL((conv3x3_mfma_kernel<TCO, WAVES_M, WM, WN, PT_W, CK, false>), dim3((unsigned)nb),
-                               dim3(256), 0, stream, a);
+            AIDE_LAUNCH_TIMED(AIDE_KT_IGEMM, AIDE_CONV_FLOPS(a.N, a.H, a.W, a.Cout, a.Cin),
+                              (conv3x3_mfma_kernel<TCO, WAVES_M, WM, WN, PT_W, CK, false>), dim3((unsigned)nb),
+                              dim3(256), 0, stream, a);
         else
             return AIDE_ERR_ARG;
     }

@@ -494,8 +494,9 @@ int launch_bf16_t(BfArgs a, hipStream_t stream) {
     a.tiles_h = (a.H + TH - 1) / TH;
     a.n_co_tiles = a.Cout / TCO;
     const long nb = (long)a.tiles_w * a.tiles_h * a.N * a.n_co_tiles * a.splitk;
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, TW, NW>), dim3((unsigned)nb), dim3(64 * NW),
-                       LDS_BYTES, stream, a);
+    AIDE_LAUNCH_TIMED(AIDE_KT_BF16, AIDE_CONV_FLOPS(a.N, a.H, a.W, a.Cout, a.Cin),
+                      (conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, TW, NW>), dim3((unsigned)nb), dim3(64 * NW),
+                      LDS_BYTES, stream, a);
     return aide_launch_status();
 }
 
@@ -826,8 +827,9 @@ int launch_wgrad_bf16(BgArgs g, hipStream_t stream) {
     g.chunks_total = g.N * g.segs_w * g.bands_h;
     g.n_co_tiles = (g.Co + 32 * NWCO - 1) / (32 * NWCO);
     const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
-    hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<R, DZ_BF16, X_BF16, NWCO>), dim3((unsigned)nb), dim3(128 * NWCO), LDS_BYTES,
-                       stream, g);
+    AIDE_LAUNCH_TIMED(AIDE_KT_WGRAD_BF16, AIDE_CONV_FLOPS(g.N, g.H, g.W, g.Co, g.Ci),
+                      (conv3x3_wgrad_bf16_kernel<R, DZ_BF16, X_BF16, NWCO>), dim3((unsigned)nb), dim3(128 * NWCO), LDS_BYTES,
+                      stream, g);
     return aide_launch_status();
 }
 

@@ -358,11 +358,13 @@ int launch_wgrad(WgradArgs g, hipStream_t stream) {
     g.n_ci_tiles = (g.Ci + WAVES_CI * 32 - 1) / (WAVES_CI * 32);
     const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
     if (g.H % 4 != 0 || g.W % 16 != 0)
-        hipLaunchKernelGGL((conv3x3_wgrad_kernel<WAVES_CO, WAVES_CI, WAVES_PX, true>), dim3((unsigned)nb),
-                           dim3(256), 0, stream, g);
+        AIDE_LAUNCH_TIMED(AIDE_KT_WGRAD, AIDE_CONV_FLOPS(g.N, g.H, g.W, g.Co, g.Ci),
+                          (conv3x3_wgrad_kernel<WAVES_CO, WAVES_CI, WAVES_PX, true>), dim3((unsigned)nb),
+                          dim3(256), 0, stream, g);
     else
-        hipLaunchKernelGGL((conv3x3_wgrad_kernel<WAVES_CO, WAVES_CI, WAVES_PX, false>), dim3((unsigned)nb),
-                           dim3(256), 0, stream, g);
+        AIDE_LAUNCH_TIMED(AIDE_KT_WGRAD, AIDE_CONV_FLOPS(g.N, g.H, g.W, g.Co, g.Ci),
+                          (conv3x3_wgrad_kernel<WAVES_CO, WAVES_CI, WAVES_PX, false>), dim3((unsigned)nb),
+                          dim3(256), 0, stream, g);
     return aide_launch_status();
 }
 
@@ -745,7 +747,8 @@ int aide_conv3x3_wgrad_wino(const float* dz, int64_t dz_bs, const float* a, int6
     g.chunks_total = N * g.rows_t * g.cols_c;
     g.splits = aide_conv3x3_wgrad_wino_splits(N, Co, Ci, H, W);
     const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
-    hipLaunchKernelGGL(conv3x3_wgrad_wino_kernel, dim3((unsigned)nb), dim3(256), WW_LDS * sizeof(float), stream, g);
+    AIDE_LAUNCH_TIMED(AIDE_KT_WGRAD_WINO2, AIDE_CONV_FLOPS(N, H, W, Co, Ci), conv3x3_wgrad_wino_kernel, dim3((unsigned)nb),
+                      dim3(256), WW_LDS * sizeof(float), stream, g);
     int rc = aide_launch_status();
     if (rc != 0) return rc;
     return launch_wgrad_reduce(ws, g.splits, Co, Ci, dw, stream);

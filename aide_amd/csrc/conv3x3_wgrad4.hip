@@ -426,7 +426,8 @@ int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int
     g.chunks_total = N * g.rows_t * g.cols_c;
     g.splits = aide_conv3x3_wgrad_wino4_splits(N, Co, Ci, H, W);
     const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
-    hipLaunchKernelGGL(conv3x3_wgrad4_kernel, dim3((unsigned)nb), dim3(256), G4_LDS * sizeof(float), stream, g);
+    AIDE_LAUNCH_TIMED(AIDE_KT_WGRAD4, AIDE_CONV_FLOPS(N, H, W, Co, Ci), conv3x3_wgrad4_kernel, dim3((unsigned)nb), dim3(256),
+                      G4_LDS * sizeof(float), stream, g);
     const int rc = aide_launch_status();
     if (rc != 0) return rc;
     return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, stream);

@@ -210,9 +210,10 @@ int aide_conv3x3_wgrad_stem(const void* dz, int dz_bf16, int64_t dz_bs, const fl
     g.tiles_w = W / ST_C; g.tiles_h = H / ST_R; g.tiles_total = N * g.tiles_w * g.tiles_h;
     g.splits = splits < g.tiles_total ? splits : g.tiles_total;
     const unsigned nb = (unsigned)(g.n_co_tiles * g.splits);
-    if (dz_bf16) hipLaunchKernelGGL((wgrad_stem_kernel<true, true>), dim3(nb), dim3(256), 0, stream, g);     // bf16 storage: bf16 mode
-    else if (round_bf16) hipLaunchKernelGGL((wgrad_stem_kernel<false, true>), dim3(nb), dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((wgrad_stem_kernel<false, false>), dim3(nb), dim3(256), 0, stream, g);
+    const double fl = AIDE_CONV_FLOPS(N, H, W, Co, Ci);
+    if (dz_bf16) AIDE_LAUNCH_TIMED(AIDE_KT_WGRAD_STEM, fl, (wgrad_stem_kernel<true, true>), dim3(nb), dim3(256), 0, stream, g);     // bf16 storage: bf16 mode
+    else if (round_bf16) AIDE_LAUNCH_TIMED(AIDE_KT_WGRAD_STEM, fl, (wgrad_stem_kernel<false, true>), dim3(nb), dim3(256), 0, stream, g);
+    else AIDE_LAUNCH_TIMED(AIDE_KT_WGRAD_STEM, fl, (wgrad_stem_kernel<false, false>), dim3(nb), dim3(256), 0, stream, g);
     const int rc = aide_launch_status();
     if (rc != 0) return rc;
     return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, stream);

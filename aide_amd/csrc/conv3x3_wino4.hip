@@ -503,7 +503,8 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
         a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = accumulate;
     }
     const long nb = (long)a.blocks_w * a.blocks_h * N * a.n_co_tiles * splitk;
-    hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)nb), dim3(256), F4_LDS * sizeof(float), stream, a);
+    AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), conv3x3_wino4_kernel, dim3((unsigned)nb), dim3(256),
+                      F4_LDS * sizeof(float), stream, a);
     int rc = aide_launch_status();
     if (rc != 0) return rc;
     if (splitk > 1) {

@@ -1,0 +1,68 @@
+// Optional per-kernel timing of the MFMA convolution kernels (bench.py's `roofline` object).
+//
+// When a timer is armed for a kernel family, its launcher passes a start/stop event pair to hipExtLaunchKernelGGL:
+// the pair then carries the DISPATCH's own begin / end timestamps (what rocprofv3 --kernel-trace reports for the
+// kernel), with no extra marker packets in the queue -- so every launch of every timed step can be measured under the
+// real two-stream schedule without perturbing it.  Events are created once, before the timed region.
+#include "common.h"
+#include <vector>
+
+namespace {
+struct KTimer {
+    unsigned mask = 0;
+    size_t used = 0;
+    long dropped = 0;
+    std::vector<hipEvent_t> ev;        // 2 per slot
+    std::vector<int> fam;
+    std::vector<double> flops;
+} T;
+}  // namespace
+
+extern "C" {
+
+int aide_ktimer_slot(int family, double flops, hipEvent_t* e0, hipEvent_t* e1) {
+    if (!(T.mask >> family & 1u)) return 0;
+    if (T.used >= T.fam.size()) { ++T.dropped; return 0; }
+    const size_t s = T.used++;
+    T.fam[s] = family; T.flops[s] = flops;
+    *e0 = T.ev[2 * s]; *e1 = T.ev[2 * s + 1];
+    return 1;
+}
+
+// arm the timer for the families in `family_mask` (bit = AIDE_KT_* id) with room for `capacity` launches
+int aide_ktimer_start(int family_mask, int capacity) {
+    if (capacity < 0) return AIDE_ERR_ARG;
+    T.mask = 0;
+    while (T.ev.size() < 2 * (size_t)capacity) {
+        hipEvent_t e;
+        const hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) return (int)rc;
+        T.ev.push_back(e);
+    }
+    T.fam.assign(capacity, 0); T.flops.assign(capacity, 0.0);
+    T.used = 0; T.dropped = 0;
+    T.mask = (unsigned)family_mask;
+    return AIDE_OK;
+}
+
+int aide_ktimer_stop(void) { T.mask = 0; return AIDE_OK; }
+
+// after the device is idle: launches / total milliseconds / total algorithmic flop of one family since aide_ktimer_start;
+// returns the number of launches that found no free slot (all families) or a negative / hip error code
+int aide_ktimer_read(int family, int64_t* launches, double* ms, double* flops, double* max_ms) {
+    if (!launches || !ms || !flops) return AIDE_ERR_ARG;
+    int64_t n = 0; double t = 0.0, f = 0.0, mx = 0.0;
+    for (size_t s = 0; s < T.used; ++s) {
+        if (T.fam[s] != family) continue;
+        float el = 0.f;
+        const hipError_t rc = hipEventElapsedTime(&el, T.ev[2 * s], T.ev[2 * s + 1]);
+        if (rc != hipSuccess) return -(int)rc - 1000;
+        ++n; t += el; f += T.flops[s];
+        if (el > mx) mx = el;
+    }
+    *launches = n; *ms = t; *flops = f;
+    if (max_ms) *max_ms = mx;
+    return (int)(T.dropped > 0x7fffffff ? 0x7fffffff : T.dropped);
+}
+
+}  // extern "C"

@@ -90,12 +90,20 @@ __device__ __forceinline__ double dice_of(const double* S, double smooth) {
     return 1.0 - (2.0 * S[S_I] + smooth) / (S[S_P] + S[S_T] + smooth);
 }
 
-// stable ascending argsort of the fp32 values v[0..N) by rank counting (N is a batch size)
+// stable ascending argsort of the fp32 values v[0..N) by rank counting (N is a batch size).  NaN has a total order
+// here: larger than every number (torch.sort / np.argsort place NaN last), NaNs among themselves by index -- so the
+// ranks are always a permutation of 0..N-1 and every idx slot is written, also for a diverged step.
 __device__ void argsort_stable(const float* v, int N, long long* idx) {
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
         int rank = 0;
         const float vi = v[i];
-        for (int j = 0; j < N; ++j) rank += (v[j] < vi) || (v[j] == vi && j < i);
+        const bool ni = vi != vi;
+        for (int j = 0; j < N; ++j) {
+            const float vj = v[j];
+            const bool nj = vj != vj;
+            const bool eq = (ni && nj) || (vj == vi);
+            rank += (vj < vi) || (ni && !nj) || (eq && j < i);
+        }
         idx[rank] = i;
     }
 }
@@ -196,7 +204,7 @@ __global__ void coteach_finalize_kernel(const CoteachFinalizeArgs a) {
         const float* L = shf + me * N;
         const double* stats = me ? a.stats2 : a.stats1;
         float* coef = me ? a.coef2 : a.coef1;
-        const int R = a.keep, D = N - R;
+        const int R = a.keep < N ? a.keep : N, D = N - R;      // the reference slices indx[0:keep]: at most N images
         double keep_sum = 0.0, drop_sum = 0.0, mse_sum = 0.0;
         for (int r = 0; r < N; ++r) {
             const int i = (int)sel[r];

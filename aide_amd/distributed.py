@@ -102,6 +102,10 @@ def broadcast_module(module, src=0):
     """Make every replica start from rank `src`'s parameters and buffers."""
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src)
+    # writes through .data bump neither tensor._version nor the optimizer's epoch: the engine's packed / Winograd-
+    # transformed filter copies are keyed on those, so tell it explicitly (any other `.data` edit of weights needs the same)
+    from . import engine
+    engine.PARAM_EPOCH[0] += 1
 
 
 class GradAllReduce(object):

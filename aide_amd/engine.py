@@ -294,6 +294,8 @@ class Plan(object):
         self.profiler = None             # set by Engine (bench.py's per-kernel HIP-event timing)
         self._pack_key, self._pack_tab, self.side_fwd = None, None, None
         self.overlap = True              # weight gradients on a side stream (see backward)
+        self.serial = 0                  # forwards run on this plan; _NetFunction.backward checks it still owns the buffers
+        self.key = None
 
     # ------------------------------------------------------------------ helpers
     def view(self, t, inputs=None):
@@ -404,6 +406,7 @@ class Plan(object):
 
     def forward(self, inputs, out):
         n = self.N
+        self.serial += 1                 # the saved activations of this plan now belong to THIS forward (any kind)
         gate = self._pack_filters()
         for st in self.steps:
             kind = st['kind']
@@ -623,16 +626,15 @@ class _NetFunction(torch.autograd.Function):
         n, _, h, w = inputs[0].shape
         out = torch.empty(n, k, h, w, device=inputs[0].device, dtype=torch.float32)
         plan.forward(inputs, out)
-        engine.forward_serial += 1
-        ctx.engine, ctx.plan, ctx.serial, ctx.inputs = engine, plan, engine.forward_serial, inputs
+        ctx.engine, ctx.plan, ctx.serial, ctx.inputs = engine, plan, plan.serial, inputs
         return out
 
     @staticmethod
     def backward(ctx, dlogits):
         eng, plan = ctx.engine, ctx.plan
-        if ctx.serial != eng.forward_serial:
-            raise RuntimeError('aide_amd: backward() after a newer forward() of the same module — its '
-                               'activations were overwritten (the engine keeps one set per module)')
+        if ctx.serial != plan.serial or eng.plans.get(plan.key) is not plan:
+            raise RuntimeError('aide_amd: backward() after a newer forward() of the same module at the same input shape '
+                               '— its activations were overwritten (the engine keeps one set per module and shape)')
         if not plan.training:
             raise RuntimeError('aide_amd: backward through an eval-mode forward is not supported')
         dlogits = dlogits.contiguous()
@@ -652,11 +654,11 @@ class _NetFunction(torch.autograd.Function):
 
 class Engine(object):
     """Owned by a model (fuseunet / UNet); compiles and caches plans, runs forward/backward."""
+    MAX_PLANS = 6
 
     def __init__(self, module, build_graph, num_classes):
         self.module, self.build_graph, self.num_classes = module, build_graph, num_classes
         self.plans = {}
-        self.forward_serial = 0
         self.params = None
         self.grad_hook = None            # callable(flat_grad) e.g. DDP all-reduce of the whole arena
         self.after_backward_op = None    # callable(step) e.g. bucketed all-reduce overlap
@@ -724,7 +726,14 @@ class Engine(object):
                                            'operand limit of the kernels' % (h, w, t.C, t.name))
             plan = Plan(self.graph, self.params, n, h, w, x.device, bool(self.module.training), self._precision,
                         groups)
+            plan.key = key
             self.plans[key] = plan
+            # a plan owns full activation (+ gradient) buffers: ragged last batches / many input shapes must not pile
+            # them up -- least recently used plans beyond MAX_PLANS are dropped (a backward of a dropped plan raises)
+            while len(self.plans) > self.MAX_PLANS:
+                self.plans.pop(next(iter(self.plans)))
+        else:
+            self.plans[key] = self.plans.pop(key)        # most recently used last
         return plan
 
     def run_groups(self, input_groups):

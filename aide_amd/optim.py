@@ -23,8 +23,16 @@ class Adam(torch.optim.Optimizer):
                                                 amsgrad=amsgrad))
         self._tables = {}
 
+    def load_state_dict(self, state_dict):
+        super(Adam, self).load_state_dict(state_dict)
+        self._tables = {}                          # raw pointers to the old moment tensors
+
     def _static_table(self, gi, plist):
-        key = tuple(p.data_ptr() for p in plist)
+        # the table holds raw pointers to the parameters AND their moment tensors: load_state_dict (or any replacement
+        # of a state tensor) must invalidate it
+        key = tuple(p.data_ptr() for p in plist) + tuple(
+            t.data_ptr() for p in plist for t in (self.state[p]['exp_avg'], self.state[p]['exp_avg_sq'],
+                                                  self.state[p].get('max_exp_avg_sq')) if t is not None)
         tab = self._tables.get(gi)
         if tab is not None and tab['key'] == key:
             return tab
@@ -61,6 +69,8 @@ class Adam(torch.optim.Optimizer):
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError('aide_amd.optim.Adam: parameters must be contiguous fp32 HIP tensors')
                 st = self.state[p]
+                if len(st) and group['amsgrad'] and 'max_exp_avg_sq' not in st:
+                    st['max_exp_avg_sq'] = st['exp_avg_sq'].clone()       # state loaded from a non-amsgrad run
                 if len(st) == 0:
                     st['step'] = 0
                     st['exp_avg'] = torch.zeros_like(p)
@@ -78,7 +88,8 @@ class Adam(torch.optim.Optimizer):
                 grads.append(g)
             gtab = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64).to(plist[0].device,
                                                                                       non_blocking=True)
-            step = self.state[plist[0]]['step'] + 1
+            # a torch.optim.Adam checkpoint stores 'step' as a (float) tensor: coerce
+            step = int(self.state[plist[0]]['step']) + 1
             for p in plist:
                 self.state[p]['step'] = step
             b1, b2 = group['betas']

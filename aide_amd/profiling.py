@@ -50,3 +50,52 @@ class KernelTimer(object):
             a['tflops'] = a['flops'] / (a['ms'] * 1e-3) / 1e12 if a['ms'] > 0 else 0.0
             a['executed_tflops'] = a['executed'] / (a['ms'] * 1e-3) / 1e12 if a['ms'] > 0 else 0.0
         return agg
+
+
+# family ids of the C-side kernel timer (include/aide_hip.h "kernel timer") -> (kernel name, executed / algorithmic multiplies)
+KT_FAMILIES = {
+    0: ('conv3x3_mfma_kernel', 1.0), 1: ('conv3x3_wino_kernel', 16.0 / 36.0), 2: ('conv3x3_wino4_kernel', 36.0 / 144.0),
+    3: ('conv3x3_wgrad_kernel', 1.0), 4: ('conv3x3_wgrad_wino_kernel', 16.0 / 36.0),
+    5: ('conv3x3_wgrad4_kernel', 36.0 / 144.0), 6: ('wgrad_stem_kernel', 1.0), 7: ('conv3x3_bf16_kernel', 1.0),
+    8: ('conv3x3_wgrad_bf16_kernel', 1.0),
+}
+
+
+class DispatchTimer(object):
+    """Per-dispatch timing of the MFMA convolution kernels through the C ABI's kernel timer: while armed, every launch of
+    a family's main kernel carries a hipExtLaunchKernelGGL start / stop event pair = the dispatch's own begin / end
+    timestamps (the duration rocprofv3 --kernel-trace reports), on whatever stream it runs -- the timed steps keep
+    their two-stream schedule.  start() creates the events (outside the timed region); summary() needs an idle device."""
+
+    def __init__(self, capacity, families=None):
+        from ._lib import lib, check
+        self.lib, self.check = lib, check
+        self.capacity = int(capacity)
+        self.mask = sum(1 << f for f in (families if families is not None else KT_FAMILIES))
+
+    def start(self):
+        self.check(self.lib.aide_ktimer_start(self.mask, self.capacity), 'ktimer_start')
+
+    def stop(self):
+        self.lib.aide_ktimer_stop()
+
+    def summary(self):
+        import ctypes
+        torch.cuda.synchronize()
+        agg = collections.OrderedDict()
+        dropped = 0
+        for fam, (name, exec_frac) in KT_FAMILIES.items():
+            n, ms, fl, mx = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            rc = self.lib.aide_ktimer_read(fam, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(mx))
+            if rc < 0:
+                raise RuntimeError('aide_amd: ktimer_read failed (%d)' % rc)
+            dropped = rc
+            if n.value == 0:
+                continue
+            a = dict(launches=n.value, ms=ms.value, flops=fl.value, executed=fl.value * exec_frac, max_ms=mx.value)
+            a['avg_ms'] = a['ms'] / a['launches']
+            a['tflops'] = a['flops'] / (a['ms'] * 1e-3) / 1e12 if a['ms'] > 0 else 0.0
+            a['executed_tflops'] = a['executed'] / (a['ms'] * 1e-3) / 1e12 if a['ms'] > 0 else 0.0
+            agg[name] = a
+        self.dropped = dropped
+        return agg

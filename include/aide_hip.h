@@ -184,6 +184,20 @@ int aide_reverse_aug(const float* x, int64_t x_bs, float* y, int64_t y_bs, const
                      int H, int W, aide_stream_t stream);
 int aide_fill_zero(float* p, int64_t bs, int N, int C, int H, int W, aide_stream_t stream);
 
+/* ---- kernel timer (measurement only; bench.py `roofline`) --------------------------------------------------------
+ * While armed for a family, every launch of that family's MAIN kernel carries a start / stop HIP event pair on its own
+ * stream (hipExtLaunchKernelGGL): the pair records the dispatch's begin / end timestamps -- the duration rocprofv3
+ * --kernel-trace reports -- without extra packets in the queue, so the two-stream schedule of the timed steps is
+ * measured as it runs.  Families (bit ids of `family_mask`): 0 conv3x3_mfma_kernel, 1 conv3x3_wino_kernel,
+ * 2 conv3x3_wino4_kernel, 3 conv3x3_wgrad_kernel, 4 conv3x3_wgrad_wino_kernel, 5 conv3x3_wgrad4_kernel,
+ * 6 wgrad_stem_kernel, 7 conv3x3_bf16_kernel, 8 conv3x3_wgrad_bf16_kernel, 9 convT kernels.
+ * aide_ktimer_start creates the events (call it outside the timed region); aide_ktimer_read needs an idle device and
+ * returns the number of launches that found no free slot (>= 0) or an error (< 0).  `flops` = algorithmic
+ * (direct-convolution) flop, 2 N H W Co Ci 9 per launch. */
+int aide_ktimer_start(int family_mask, int capacity);
+int aide_ktimer_stop(void);
+int aide_ktimer_read(int family, int64_t* launches, double* ms, double* flops, double* max_ms);
+
 /* ---- Spatial_Attention branch of the attention variants (fuseunetsa / UNetsa) -----------------------------------
  * replaces Spatial_Attention.forward (models_twomodalinputs/netblocks.py:68-89, models_singlemodalinput/UNet.py:85-107)
  * and `y = sa(y) * y` (fuseunet.py:139-141, UNet.py:191-200) with their autograd backward:

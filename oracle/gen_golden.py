@@ -297,6 +297,17 @@ def g5_adam(ref_f, ref_utils):
     print('g5 losses', fx['losses'])
 
 
+# element-wise gradient fixtures at full size: the first conv, a mid-decoder conv, its BatchNorm, the up conv, the head
+C2_GRAD_KEYS = ('modal1_downblock1.block.conv1.weight', 'modal2_downblock3.block.conv2.weight',
+                'up_block1.bilinear_up.1.weight', 'up_block1.block.conv1.weight',
+                'up_block1.block.bn1.weight', 'up_block1.block.bn1.bias', 'up_block4.block.conv2.weight',
+                'last_conv1.weight', 'last_conv1.bias')
+C4_GRAD_KEYS = ('down_block1.block.conv1.weight', 'down_block3.block.conv2.weight',
+                'up_block1.bilinear_up.1.weight', 'up_block1.block.conv1.weight',
+                'up_block1.block.bn1.weight', 'up_block1.block.bn1.bias', 'up_block4.block.conv2.weight',
+                'last_conv1.weight', 'last_conv1.bias')
+
+
 def g2_config(ref_f, ref_utils):
     """BASELINE config 2 digests: FuseUNet N=4, 256x256, synthetic CHAOS-shaped batch."""
     import oracle
@@ -315,10 +326,15 @@ def g2_config(ref_f, ref_utils):
         loss.backward()
         res[tag] = (out.detach(), loss.detach(), per.detach(),
                     torch.stack([p.grad.double().norm() for p in net.parameters()]),
-                    [k for k, _ in net.named_parameters()])
+                    [k for k, _ in net.named_parameters()],
+                    {k: p.grad.detach().clone() for k, p in net.named_parameters() if k in C2_GRAD_KEYS})
     for i in range(4):
         _same(res['ref'][i], res['ora'][i], 'g2 #%d' % i)
-    out, loss, per, gn, names = res['ref']
+    for k in C2_GRAD_KEYS:
+        _same(res['ref'][5][k], res['ora'][5][k], 'g2 grad ' + k)
+    out, loss, per, gn, names, grads = res['ref']
+    for k in C2_GRAD_KEYS:                      # element-wise gradients of the real reference (full tensor or _sub stride)
+        fx['grad/' + k] = _sub(grads[k])
     fx['logits_sum'] = np.array(out.double().sum().item())
     fx['logits_abs_sum'] = np.array(out.double().abs().sum().item())
     fx['logits_rows'] = _np(out[:, :, ::37, :])          # 7 rows per image/class
@@ -327,6 +343,143 @@ def g2_config(ref_f, ref_utils):
     fx['seed'] = np.array(1234)
     np.savez_compressed(os.path.join(OUT, 'g2_config2.npz'), **fx)
     print('g2 loss', float(loss), 'per-image', per.tolist())
+
+
+
+def g13_config4(ref_u, ref_utils):
+    """BASELINE config 4 at its own size: UNet(2), N=4, 3x320x320 (prostate-shaped synthetic, single modality) --
+    digests and element-wise gradient slices of the real reference (models_singlemodalinput/UNet.py:152-165)."""
+    import oracle
+    from aide_amd.synthetic import chaos_batch
+    fx = {}
+    xin, _, t = chaos_batch(4, 320, seed=1234, single_modal=True)
+    w = torch.tensor([1.0, 1.0])
+    res = {}
+    for tag, umod, lmod in (('ref', ref_u, ref_utils), ('ora', oracle, oracle)):
+        torch.manual_seed(2)
+        net = umod.UNet(2)
+        net.train()
+        out = net(xin)
+        loss = lmod.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)(out, t)
+        per = lmod.CEMDiceLossImage(cediceweight=w, ceclassweight=w, diceclassweight=w)(out, t)
+        loss.backward()
+        res[tag] = (out.detach(), loss.detach(), per.detach(),
+                    torch.stack([p.grad.double().norm() for p in net.parameters()]),
+                    [k for k, _ in net.named_parameters()],
+                    {k: p.grad.detach().clone() for k, p in net.named_parameters() if k in C4_GRAD_KEYS})
+    for i in range(4):
+        _same(res['ref'][i], res['ora'][i], 'g13 #%d' % i)
+    out, loss, per, gn, names, grads = res['ref']
+    assert set(grads) == set(C4_GRAD_KEYS), sorted(set(C4_GRAD_KEYS) - set(grads))
+    for k in C4_GRAD_KEYS:
+        _same(grads[k], res['ora'][5][k], 'g13 grad ' + k)
+        fx['grad/' + k] = _sub(grads[k])
+    fx['logits_sum'] = np.array(out.double().sum().item())
+    fx['logits_abs_sum'] = np.array(out.double().abs().sum().item())
+    fx['logits_rows'] = _np(out[:, :, ::37, :])
+    fx['loss'], fx['per_image_loss'] = _np(loss), _np(per)
+    fx['grad_norms'], fx['param_names'] = _np(gn), np.array(names)
+    fx['seed'] = np.array(1234)
+    np.savez_compressed(os.path.join(OUT, 'g13_config4.npz'), **fx)
+    print('g13 (C4 UNet 320) loss', float(loss), 'per-image', per.tolist())
+
+
+def c3_inputs(n=4, size=256):
+    """Inputs of the full-size proposed-step fixture (shared by the generator and tests/test_gpu_fullsize.py):
+    CHAOS-shaped batch, the labels of the two networks from two different label draws, four intensity-augmented
+    copies (identity reverse-aug, as the parity runs of SURVEY 8d prescribe)."""
+    from aide_amd.synthetic import chaos_batch
+    xin, xout, t1 = chaos_batch(n, size, seed=1234)
+    _, _, t2 = chaos_batch(n, size, seed=977)
+    augs = [(xin * (1 + 0.05 * (k + 1)), xout * (1 - 0.04 * (k + 1))) for k in range(4)]
+    return xin, xout, t1, t2, augs
+
+
+def g14_config3(ref_f, ref_utils):
+    """BASELINE config 3 at its own size: the AIDE proposed co-teaching step (two FuseUNets, 4 augmented train-mode
+    forwards + forward + backward + Adam each) at N=4, 256x256, rate 0.25
+    (train_files/trainchaos_proposed_30cases1labeled.py:260-325 restated in oracle/steps.py, reference modules / losses
+    plugged in)."""
+    import oracle
+    from oracle import steps
+    fx = {}
+    xin, xout, t1, t2, augs = c3_inputs()
+    w = torch.tensor([1.0, 1.0])
+    rate = 0.25
+    res = {}
+    for tag, fmod, umod in (('ref', ref_f, ref_utils), ('ora', oracle, oracle)):
+        torch.manual_seed(2)
+        net1 = fmod.fuseunet(2)
+        net2 = fmod.fuseunet(2)
+        net1.train(), net2.train()
+        crit = umod.CEMDiceLossImage(cediceweight=w, ceclassweight=w, diceclassweight=w)
+        corr = umod.MulticlassMSELoss(reduction='none')
+        o1 = torch.optim.Adam(net1.parameters(), lr=1e-4, amsgrad=True)
+        o2 = torch.optim.Adam(net2.parameters(), lr=1e-4, amsgrad=True)
+        r = steps.proposed_step(net1, net2, crit, corr, o1, o2, xin, xout, augs, t1, t2, rate)
+        r['g1'] = torch.stack([p.grad.double().norm() for p in net1.parameters()])
+        r['g2'] = torch.stack([p.grad.double().norm() for p in net2.parameters()])
+        r['nbt'] = net1.modal1_downblock1.block.bn1.num_batches_tracked.clone()
+        r['rm'] = net1.up_block4.block.bn2.running_mean.clone()
+        res[tag] = r
+    for k in ('outputs1', 'outputs2', 'loss1', 'loss2', 'indx1', 'indx2', 'g1', 'g2', 'rm'):
+        _same(res['ref'][k], res['ora'][k], 'g14 %s' % k)
+    r = res['ref']
+    for k in ('loss1', 'loss2', 'indx1', 'indx2', 'loss1_pre', 'loss2_pre', 'g1', 'g2', 'nbt', 'rm'):
+        fx[k] = _np(r[k])
+    fx['outputs1_rows'] = _np(r['outputs1'][:, :, ::37, :])
+    fx['outputs2_rows'] = _np(r['outputs2'][:, :, ::37, :])
+    fx['min_gap1'] = np.diff(np.sort(_np(r['loss1_pre']))).min()
+    fx['min_gap2'] = np.diff(np.sort(_np(r['loss2_pre']))).min()
+    fx['rate'] = np.array(rate)
+    np.savez_compressed(os.path.join(OUT, 'g14_config3.npz'), **fx)
+    print('g14 (C3 256) loss', float(r['loss1']), float(r['loss2']), r['indx1'].tolist(), r['indx2'].tolist(),
+          'per-image', r['loss1_pre'].tolist(), r['loss2_pre'].tolist(), 'gaps', fx['min_gap1'], fx['min_gap2'])
+
+
+def g15_config5(ref_f, ref_utils):
+    """BASELINE config 5 at its own size: FuseUNet N=8, 2 x 3x512x512.  The reference has no bf16 mode, so this fixture
+    holds (i) the real reference's fp32 forward (logit rows, loss: the anchor) and (ii) the digests of the bf16-operand
+    oracle (oracle/bf16.py: the product's rounding contract applied to the bit-equal restatement) -- logits, loss,
+    per-parameter gradient norms."""
+    import oracle
+    from oracle import bf16 as OB
+    from aide_amd.synthetic import chaos_batch
+    fx = {}
+    xin, xout, t = chaos_batch(8, 512, seed=1234)
+    w = torch.tensor([1.0, 1.0])
+    torch.manual_seed(2)
+    ref = ref_f.fuseunet(2)
+    ref.train()
+    with torch.no_grad():
+        out_ref = ref(xin, xout)
+        loss_ref = ref_utils.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)(out_ref, t)
+    torch.manual_seed(2)
+    ora32 = oracle.fuseunet(2)
+    ora32.train()
+    with torch.no_grad():
+        _same(out_ref, ora32(xin, xout), 'g15 fp32 forward')
+    del ora32
+    fx['ref_fp32_logits_rows'] = _np(out_ref[:, :, ::73, :])
+    fx['ref_fp32_loss'] = _np(loss_ref)
+    torch.manual_seed(2)
+    net = OB.emulate_bf16(oracle.fuseunet(2))
+    net.train()
+    out = net(xin, xout)
+    loss = oracle.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)(out, t)
+    per = oracle.CEMDiceLossImage(cediceweight=w, ceclassweight=w, diceclassweight=w)(out, t)
+    loss.backward()
+    fx['bf16_logits_rows'] = _np(out[:, :, ::73, :])
+    fx['bf16_logits_sum'] = np.array(out.double().sum().item())
+    fx['bf16_logits_abs_sum'] = np.array(out.double().abs().sum().item())
+    fx['bf16_loss'], fx['bf16_per_image_loss'] = _np(loss), _np(per)
+    fx['bf16_grad_norms'] = _np(torch.stack([p.grad.double().norm() for p in net.parameters()]))
+    fx['param_names'] = np.array([k for k, _ in net.named_parameters()])
+    fx['bf16_vs_fp32_logits'] = np.array(((out - out_ref).abs().max() / out_ref.abs().max()).item())
+    fx['seed'] = np.array(1234)
+    np.savez_compressed(os.path.join(OUT, 'g15_config5.npz'), **fx)
+    print('g15 (C5 512 bs8) fp32 loss', float(loss_ref), 'bf16-oracle loss', float(loss), 'bf16 vs fp32 logits',
+          float(fx['bf16_vs_fp32_logits']))
 
 
 def g6_inference(ref_f, ref_u, ref_utils):
@@ -542,6 +695,11 @@ def main():
     if sys.argv[1:] == ['g12']:          # binary metrics and the two remaining loss classes
         ref_f, ref_u, ref_utils = _import_reference()
         return g12_metrics(ref_utils)
+    if sys.argv[1:] and sys.argv[1] in ('g2', 'g13', 'g14', 'g15'):      # full-size digests of BASELINE configs 2, 4, 3, 5
+        torch.set_num_threads(8)
+        ref_f, ref_u, ref_utils = _import_reference()
+        return {'g2': lambda: g2_config(ref_f, ref_utils), 'g13': lambda: g13_config4(ref_u, ref_utils),
+                'g14': lambda: g14_config3(ref_f, ref_utils), 'g15': lambda: g15_config5(ref_f, ref_utils)}[sys.argv[1]]()
     if sys.argv[1:] == ['g6']:
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()
@@ -559,6 +717,9 @@ def main():
     g4_proposed(ref_f, ref_utils)
     g5_adam(ref_f, ref_utils)
     g2_config(ref_f, ref_utils)
+    g13_config4(ref_u, ref_utils)
+    g14_config3(ref_f, ref_utils)
+    g15_config5(ref_f, ref_utils)
     g6_inference(ref_f, ref_u, ref_utils)
     g7_coteach_ext(ref_utils)
     g8_pixelcoreg(ref_utils)

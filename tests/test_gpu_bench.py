@@ -1,0 +1,70 @@
+"""-m gpu: the bench.py contract (one JSON line with `roofline` + `cpu_baseline`) and its own N-rank launcher.
+
+`python bench.py --gpus N` without a launcher must start N ranks itself (the driver's 1-GPU call form); with fewer
+visible devices than ranks it has to fail loudly instead of silently benchmarking one rank, and on the gloo dry-run
+backend (ranks wrap around the visible devices) the rank-0 line reports n_gpus = N."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _run(extra, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'AIDE_DIST_BACKEND', 'AIDE_BENCH_BACKEND'):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + extra, env=e, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def _line(r):
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    return json.loads(lines[0])
+
+
+def test_bench_line_and_dispatch_timer(dev):
+    """One short default-workload run: the contract keys, the live dispatch timing of every MFMA conv launch of the timed
+    steps, the CPU baseline with host core count."""
+    r = _run(['--steps', '4', '--warmup', '2', '--cpu-steps', '1', '--traffic', 'none'])
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in j, k
+    assert j['n_gpus'] == 1 and j['steps'] == 4 and j['dtype'] == 'f32' and j['vs_baseline'] is None
+    roof = j['roofline']
+    assert roof['bound'] == 'mfma' and roof['unit'] == 'TFLOP/s' and roof['peak'] == 157.3
+    assert roof['dropped_launches'] == 0
+    # 28 F(4x4) weight gradients and 38 F(4x4) forward / dgrad launches per FuseUNet step at 256x256
+    ks = j['kernels']
+    assert ks['conv3x3_wgrad4_kernel']['launches_per_step'] == 28
+    assert ks['conv3x3_wino4_kernel']['launches_per_step'] == 38
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+    assert 20 < roof['avg_launch_us'] < 400
+    # the dispatch times of all MFMA kernels of a step cannot exceed two streams' worth of the step
+    assert roof['all_mfma_kernels']['sum_dispatch_ms_per_step'] < 2.0 * j['ms_per_step']
+    cpu = j['cpu_baseline']
+    assert cpu['kind'] == 'port' and cpu['cores'] >= 1 and cpu['host_cores'] == os.cpu_count() and cpu['value'] > 0
+
+
+def test_bench_self_launch(dev):
+    ndev = torch.cuda.device_count()
+    args = ['--gpus', str(ndev + 1), '--workload', 'tiny', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+            '--traffic', 'none']
+    r = _run(args)                                   # RCCL: one device per rank is required
+    assert r.returncode != 0
+    assert 'HIP device' in (r.stderr + r.stdout) and '--gpus %d' % (ndev + 1) in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    r = _run(args, env={'AIDE_DIST_BACKEND': 'gloo'})     # dry-run backend: ranks share the visible devices
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r)
+    assert j['n_gpus'] == ndev + 1 and j['comm']['ranks'] == ndev + 1 and j['comm']['backend'] == 'gloo'
+    assert j['config']['parallelism'] == 'dp%d' % (ndev + 1)

@@ -146,6 +146,22 @@ def test_g2_config2_digest():
     close(oracle.CEMDiceLossImage(w, w, w)(out, t), fx['per_image_loss'], rtol=1e-4)
 
 
+def test_g13_config4_digest():
+    """BASELINE config 4 at its own size (UNet N=4, 3x320x320): the oracle's forward vs the reference's digests."""
+    from aide_amd.synthetic import chaos_batch
+    fx = load('g13_config4.npz')
+    xin, _, t = chaos_batch(4, 320, seed=int(fx['seed']), single_modal=True)
+    torch.manual_seed(2)
+    net = oracle.UNet(2)
+    net.train()
+    with torch.no_grad():
+        out = net(xin)
+    close(out[:, :, ::37, :], fx['logits_rows'], rtol=2e-4, what='logit rows')
+    w = torch.tensor([1.0, 1.0])
+    close(oracle.CEMDiceLoss(w, w, w)(out, t), fx['loss'], rtol=1e-4)
+    close(oracle.CEMDiceLossImage(w, w, w)(out, t), fx['per_image_loss'], rtol=1e-4)
+
+
 def test_trajectory_noise_floor():
     """How much of the 3-step loss trajectory (g5_adam.npz) is determined at fp32?  The oracle is re-run with
     one-ulp multiplicative noise (1e-7 relative) on the weights before each step; the deviation from its
