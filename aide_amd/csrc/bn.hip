@@ -65,9 +65,37 @@ struct PlaneCursor {
 };
 
 // ---------------------------------------------------------------- statistics (sum, sum of squares)
-template <int V, typename ZT>
+// Split-K convolutions of a training forward leave their partial results as slabs [split][N][C][HW] (fp32): the
+// BatchNorm that follows sums them itself (fixed order s = 0, 1, ...; + conv bias), stores z for the backward pass and
+// takes its statistics from the stored value -- the separate split-reduce launch and one pass over z disappear.
+struct SlabSrc {
+    const float* slabs;               // nullptr: z is the input
+    const float* bias;
+    long split_stride, slab_bs;       // elements between splits / between images inside a slab
+    int splitk;
+};
+template <int V> __device__ __forceinline__ void slab_sum(const SlabSrc& sl, long off, int c, float (&o)[V]) {
+    ldv<V>(sl.slabs + off, o);
+    for (int s = 1; s < sl.splitk; ++s) {
+        float t[V];
+        ldv<V>(sl.slabs + (long)s * sl.split_stride + off, t);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] += t[k];
+    }
+    if (sl.bias) {
+        const float b = sl.bias[c];
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] += b;
+    }
+}
+// value as the backward pass will read it back from a ZT-typed z
+__device__ __forceinline__ float as_stored(float v, const float*) { return v; }
+__device__ __forceinline__ float as_stored(float v, const bf16_t*) { return __builtin_bit_cast(float, bn_pk_bf16(v, 0.f) << 16); }
+
+template <int V, typename ZT, bool SLABS>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const ZT* __restrict__ z, long z_bs, int N, int C,
-                                                       int HW, int splits, double* __restrict__ partials) {
+                                                       int HW, int splits, double* __restrict__ partials,
+                                                       const SlabSrc sl) {
     __shared__ double sm[2 * 4];
     const int c = blockIdx.x % C, s = blockIdx.x / C;
     const long total4 = (long)N * HW / V;
@@ -79,7 +107,14 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const ZT* __restrict__ z,
 #pragma unroll 2
     for (PlaneCursor cur(beg, end, hw4); cur.left > 0; cur.next(hw4)) {
         float v[V];
-        ldv<V>(zc + (long)cur.n * z_bs + cur.p * V, v);
+        if constexpr (SLABS) {
+            slab_sum<V>(sl, (long)cur.n * sl.slab_bs + (long)c * HW + cur.p * V, c, v);
+            stv<V>(const_cast<ZT*>(zc) + (long)cur.n * z_bs + cur.p * V, v);
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[k] = as_stored(v[k], (const ZT*)nullptr);
+        } else {
+            ldv<V>(zc + (long)cur.n * z_bs + cur.p * V, v);
+        }
         float s1 = 0.0f;                           // the V-element group sum in fp32, promoted once (squares stay fp64:
 #pragma unroll                                     // E[z^2] - mean^2 cancels)
         for (int k = 0; k < V; ++k) {
@@ -306,13 +341,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const GT* __restrict_
 // the values are read ONCE into registers (<= 16 float4 per thread), reduced in fp64 in a fixed order, and
 // normalised from the registers.  Saves a launch (~4.5 us) and one pass over the tensor per BatchNorm and direction.
 constexpr int BN_FQ = 16;
-template <typename ZT, typename AT>
+template <typename ZT, typename AT, bool SLABS>
 __global__ __launch_bounds__(256) void bn_train_fused_kernel(
     const ZT* __restrict__ z, long z_bs, AT* __restrict__ a, long a_bs, int N, int HW, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ scale_out,
-    float* __restrict__ shift_out, int relu) {
+    float* __restrict__ shift_out, int relu, const SlabSrc sl) {
     __shared__ double sm[2 * 4];
     __shared__ float coef[2];
     const int c = blockIdx.x, hw4 = HW / 4, total4 = N * hw4;
@@ -325,7 +360,14 @@ __global__ __launch_bounds__(256) void bn_train_fused_kernel(
         if (i < total4) {
             const int n = i / hw4, p = i - n * hw4;
             float t4[4];
-            ldv<4>(z + (long)n * z_bs + (long)c * HW + p * 4, t4);
+            if constexpr (SLABS) {
+                slab_sum<4>(sl, (long)n * sl.slab_bs + (long)c * HW + p * 4, c, t4);
+                stv<4>(const_cast<ZT*>(z) + (long)n * z_bs + (long)c * HW + p * 4, t4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t4[e] = as_stored(t4[e], (const ZT*)nullptr);
+            } else {
+                ldv<4>(z + (long)n * z_bs + (long)c * HW + p * 4, t4);
+            }
             v[k] = f32x4{t4[0], t4[1], t4[2], t4[3]};
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const double d = (double)v[k][e]; acc[0] += d; acc[1] += d * d; }
@@ -442,31 +484,32 @@ size_t aide_bn_ws_bytes(int C) { return (size_t)C * 64 * 3 * sizeof(double); }
 
 namespace {
 
-template <typename ZT, typename AT>
+template <typename ZT, typename AT, bool SLABS = false>
 int bn_train_fwd_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C, int H, int W,
                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
-                   float* scale, float* shift, int relu, void* ws, hipStream_t stream) {
+                   float* scale, float* shift, int relu, void* ws, hipStream_t stream, SlabSrc sl = SlabSrc{}) {
     const int HW = H * W;
     if (!z || !a || !ws) return AIDE_ERR_ARG;
     const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && a_bs % 4 == 0;
+    if (SLABS && (!sl.slabs || sl.splitk < 1 || !v4)) return AIDE_ERR_ARG;
     const int splits = pick_splits(N, C, HW);
     double* partials = (double*)ws;
     const double count = (double)N * HW;
     const int gx = max(1, min((HW / (v4 ? 4 : 1) + 255) / 256, 16));
     if (v4 && bn_fused_ok(N, C, HW)) {
-        hipLaunchKernelGGL((bn_train_fused_kernel<ZT, AT>), dim3(C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, N, HW, count,
+        hipLaunchKernelGGL((bn_train_fused_kernel<ZT, AT, SLABS>), dim3(C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, N, HW, count,
                            gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd,
-                           scale, shift, relu);
+                           scale, shift, relu, sl);
         return aide_launch_status();
     }
     if (v4) {
-        hipLaunchKernelGGL((bn_stats_kernel<4, ZT>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
+        hipLaunchKernelGGL((bn_stats_kernel<4, ZT, SLABS>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
         hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
                            num_batches_tracked, mean, rstd, scale, shift, relu);
     } else {
-        hipLaunchKernelGGL((bn_stats_kernel<1, ZT>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials);
+        hipLaunchKernelGGL((bn_stats_kernel<1, ZT, false>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
         hipLaunchKernelGGL((bn_train_apply_kernel<1, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
                            num_batches_tracked, mean, rstd, scale, shift, relu);
@@ -537,6 +580,24 @@ int aide_bn_train_fwd_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, in
     if (z_bf16) return a_bf16 ? AIDE_BN_FWD(bf16_t, bf16_t) : AIDE_BN_FWD(bf16_t, float);
     return a_bf16 ? AIDE_BN_FWD(float, bf16_t) : AIDE_BN_FWD(float, float);
 #undef AIDE_BN_FWD
+}
+
+// The same operator fed by the split-K slabs of the convolution before it (launched with accumulate = 2): sums
+// slabs [splitk][N][C][H][W] (fp32, dense) + bias[c] in split order, WRITES z (kept for the backward pass), normalises.
+// With group batching the caller offsets `slabs` / z / a by whole images; `split_stride` stays the full slab size.
+int aide_bn_train_fwd_slabs(const float* slabs, int splitk, int64_t split_stride, const float* bias, void* z, int z_bf16,
+                            int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C, int H, int W,
+                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, long long* num_batches_tracked, float* mean, float* rstd, float* scale,
+                            float* shift, int relu, void* ws, hipStream_t stream) {
+    SlabSrc sl;
+    sl.slabs = slabs; sl.bias = bias; sl.split_stride = split_stride; sl.slab_bs = (long)C * H * W; sl.splitk = splitk;
+#define AIDE_BN_FWD_S(ZT, AT) bn_train_fwd_t<ZT, AT, true>((const ZT*)z, z_bs, (AT*)a, a_bs, N, C, H, W, gamma, beta, eps,   \
+                                                           momentum, running_mean, running_var, num_batches_tracked, mean, \
+                                                           rstd, scale, shift, relu, ws, stream, sl)
+    if (z_bf16) return a_bf16 ? AIDE_BN_FWD_S(bf16_t, bf16_t) : AIDE_BN_FWD_S(bf16_t, float);
+    return a_bf16 ? AIDE_BN_FWD_S(float, bf16_t) : AIDE_BN_FWD_S(float, float);
+#undef AIDE_BN_FWD_S
 }
 
 int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,

@@ -471,7 +471,7 @@ int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, c
         a.y = ws; a.y_bs = (long)Cout * H * W; a.split_stride = (long)N * Cout * H * W;
         a.bias = nullptr; a.accumulate = 0;
     } else {
-        a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = accumulate;
+        a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = (accumulate == 1);
     }
     int rc;
     switch (pick_ptw(W)) {
@@ -480,7 +480,7 @@ int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, c
         default: rc = launch_ptw<8>(variant, ck, a, stream); break;
     }
     if (rc != 0) return rc;
-    if (splitk > 1) {
+    if (splitk > 1 && accumulate != 2) {           // accumulate == 2: the caller consumes the slabs itself
         const long total = (long)N * Cout * H * W;
         const int blocks = (int)min((total + 255) / 256, (long)2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws,

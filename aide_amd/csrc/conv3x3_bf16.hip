@@ -905,7 +905,7 @@ int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint1
         a.bias = nullptr; a.accumulate = 0;
         kernel_out_bf16 = 0;                     // slabs are fp32; the reduce narrows
     } else {
-        a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = accumulate;
+        a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = (accumulate == 1);
     }
     int rc;
     switch (bf16_variant(N, H, W, Cout)) {
@@ -914,7 +914,7 @@ int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint1
         default: rc = launch_bf16<1, 1, 4, 2, 4>(a, x_bf16, kernel_out_bf16, stream); break;
     }
     if (rc != 0) return rc;
-    if (splitk > 1) {
+    if (splitk > 1 && accumulate != 2) {           // accumulate == 2: the caller consumes the slabs itself
         const long total4 = (long)N * Cout * H * W / 4;
         const int blocks = (int)min((total4 + 255) / 256, (long)2048);
         if (y_bf16)

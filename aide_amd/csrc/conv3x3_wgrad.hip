@@ -382,11 +382,109 @@ void wgrad_tiles(int variant, int Co, int Ci, int* nco, int* nci) {
     *nci = (Ci + tci - 1) / tci;
 }
 
+// ---- deferred, batched slab reduce.  Every weight-gradient kernel of a backward pass leaves its per-split slabs in its
+// own workspace region; ONE launch then reduces the slabs of many layers (descriptors travel in the kernel-argument
+// segment).  Replaces ~32 small, latency-bound reduce launches that serialised the weight-gradient stream.
+struct RDesc {
+    const float* ws; float* dw;
+    int splits, Co, Ci, narrow;
+    long block_start;
+};
+constexpr int RB_MAX = 48;
+struct RBatch { int n, pad; RDesc d[RB_MAX]; };
+
+template <int R, int YG>
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slabs, int splits, int Co, int Ci,
+                                                  float* __restrict__ dw, long blk, float* sm /*[YG][9][R]*/) {
+    const long cc = (long)Co * Ci, total = 9 * cc;
+    const int x = threadIdx.x % R, y = threadIdx.x / R;
+    const long rem0 = blk * R;
+    const bool ok = rem0 + x < cc;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    if (ok) {
+        const float* p = slabs + rem0 + x;
+#pragma unroll 2
+        for (int s = y; s < splits; s += YG) {
+            const float* q = p + (long)s * total;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] += q[t * cc];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sm[(y * 9 + t) * R + x] = acc[t];
+    __syncthreads();
+    const int n_out = (int)min((long)R, cc - rem0) * 9;
+    for (int e = threadIdx.x; e < n_out; e += R * YG) {
+        const int xx = e / 9, t = e - xx * 9;
+        float r = sm[t * R + xx];
+#pragma unroll 8
+        for (int g = 1; g < YG; ++g) r += sm[(g * 9 + t) * R + xx];        // fixed order: deterministic
+        dw[rem0 * 9 + e] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RBatch b) {
+    __shared__ float sm[4 * 9 * 64];
+    const long blk = blockIdx.x;
+    int lo = 0, hi = b.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (b.d[mid].block_start <= blk) lo = mid; else hi = mid - 1;
+    }
+    const RDesc d = b.d[lo];
+    if (d.narrow) wgrad_reduce_body<16, 16>(d.ws, d.splits, d.Co, d.Ci, d.dw, blk - d.block_start, sm);
+    else wgrad_reduce_body<64, 4>(d.ws, d.splits, d.Co, d.Ci, d.dw, blk - d.block_start, sm);
+}
+
+struct RPending { bool defer = false; int n = 0; RDesc d[512]; };
+static RPending g_red;
+
 }  // namespace
 
-// shared with conv3x3_wgrad4.hip
+// shared with conv3x3_wgrad4.hip, conv3x3_wgrad_stem.hip, conv3x3_bf16.hip: reduce now, or (between
+// aide_wgrad_reduce_defer(1) and aide_wgrad_reduce_flush) remember the slabs for the batched launch
 int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream) {
+    if (g_red.defer && g_red.n < 512) {
+        RDesc& r = g_red.d[g_red.n++];
+        r.ws = ws; r.dw = dw; r.splits = splits; r.Co = Co; r.Ci = Ci;
+        const long cc = (long)Co * Ci;
+        r.narrow = (cc / 64 < 256 && splits >= 16) ? 1 : 0;
+        r.block_start = 0;
+        return AIDE_OK;
+    }
     return launch_wgrad_reduce(ws, splits, Co, Ci, dw, stream);
+}
+
+extern "C" int aide_wgrad_reduce_defer(int on) {
+    const int was = g_red.defer ? 1 : 0;
+    g_red.defer = on != 0;
+    return was;
+}
+
+extern "C" int aide_wgrad_reduce_pending(void) { return g_red.n; }
+
+// one launch per RB_MAX pending layers, in the order they were deferred
+extern "C" int aide_wgrad_reduce_flush(hipStream_t stream) {
+    int done = 0, rc = AIDE_OK;
+    while (done < g_red.n && rc == AIDE_OK) {
+        RBatch b;
+        b.n = 0; b.pad = 0;
+        long blocks = 0;
+        while (done < g_red.n && b.n < RB_MAX) {
+            RDesc r = g_red.d[done++];
+            const long cc = (long)r.Co * r.Ci;
+            const int R = r.narrow ? 16 : 64;
+            r.block_start = blocks;
+            blocks += (cc + R - 1) / R;
+            b.d[b.n++] = r;
+        }
+        hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, b);
+        rc = aide_launch_status();
+    }
+    g_red.n = 0;
+    return rc;
 }
 
 

@@ -500,14 +500,14 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
         a.y = ws; a.y_bs = (long)Cout * H * W; a.split_stride = (long)N * Cout * H * W;
         a.bias = nullptr; a.accumulate = 0;
     } else {
-        a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = accumulate;
+        a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = (accumulate == 1);
     }
     const long nb = (long)a.blocks_w * a.blocks_h * N * a.n_co_tiles * splitk;
     AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), conv3x3_wino4_kernel, dim3((unsigned)nb), dim3(256),
                       F4_LDS * sizeof(float), stream, a);
     int rc = aide_launch_status();
     if (rc != 0) return rc;
-    if (splitk > 1) {
+    if (splitk > 1 && accumulate != 2) {           // accumulate == 2: the caller consumes the slabs itself
         const long total4 = (long)N * Cout * H * W / 4;
         hipLaunchKernelGGL(w4_splitk_reduce_kernel, dim3((unsigned)min((total4 + 255) / 256, 4096L)), dim3(256), 0,
                            stream, ws, (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias, accumulate,

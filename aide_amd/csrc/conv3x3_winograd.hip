@@ -423,14 +423,14 @@ int aide_conv3x3_wino(const float* x, int64_t x_bs, const float* u, const float*
         a.y = ws; a.y_bs = (long)Cout * H * W; a.split_stride = (long)N * Cout * H * W;
         a.bias = nullptr; a.accumulate = 0;
     } else {
-        a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = accumulate;
+        a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = (accumulate == 1);
     }
     const long nb = (long)a.tiles_w * a.tiles_h * N * a.n_co_tiles * splitk;
     AIDE_LAUNCH_TIMED(AIDE_KT_WINO2, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), conv3x3_wino_kernel, dim3((unsigned)nb), dim3(256),
                       2 * WBUF * sizeof(float), stream, a);
     int rc = aide_launch_status();
     if (rc != 0) return rc;
-    if (splitk > 1) {
+    if (splitk > 1 && accumulate != 2) {           // accumulate == 2: the caller consumes the slabs itself
         const long total = (long)N * Cout * H * W;
         const int blocks = (int)min((total + 255) / 256, (long)2048);
         hipLaunchKernelGGL(wino_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws,

@@ -47,6 +47,9 @@ int aide_ktimer_start(int family_mask, int capacity) {
 
 int aide_ktimer_stop(void) { T.mask = 0; return AIDE_OK; }
 
+// re-arm after aide_ktimer_stop without touching the recorded slots (start = create + reset + arm)
+int aide_ktimer_arm(int family_mask) { T.mask = (unsigned)family_mask; return AIDE_OK; }
+
 // after the device is idle: launches / total milliseconds / total algorithmic flop of one family since aide_ktimer_start;
 // returns the number of launches that found no free slot (all families) or a negative / hip error code
 int aide_ktimer_read(int family, int64_t* launches, double* ms, double* flops, double* max_ms) {

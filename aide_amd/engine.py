@@ -92,6 +92,9 @@ HEAD_WGRAD_SIDE = [_os.environ.get('AIDE_HEAD_WGRAD_SIDE', '1') != '0']      # A
 STORE_BF16 = [True]            # precision='bf16': z / dz stored as bf16 (A-B switch)
 STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 where every reader / writer allows it
 STORE_G_BF16 = [True]          # ... and the gradients of those activations
+DEFER_WGRAD_REDUCE = [_os.environ.get('AIDE_DEFER_WGRAD_REDUCE', '1') != '0']     # A-B switch: batched slab reduce
+FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
+FLUSH_EVERY = int(_os.environ.get('AIDE_WGRAD_FLUSH_EVERY', '6'))      # layers per batched slab reduce
 
 
 def conv_mode(n, cin, h, w, cout):
@@ -221,19 +224,20 @@ class Plan(object):
                     # else transposed F(2x2,3x3), else the direct kernel
                     if bf16 and lib.aide_conv3x3_wgrad_bf16_supported(cout, cin, hh, ww):
                         st['wino_w'] = BF16
-                        max_wg = max(max_wg, lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, cout, cin, hh, ww))
+                        st['wg_bytes'] = lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, cout, cin, hh, ww)
                     elif USE_WINOGRAD[0] and USE_WINOGRAD4[0] and cout % 64 == 0 and \
                             lib.aide_conv3x3_wgrad_wino4_supported(cout, cin, hh, ww):
                         # (a trailing half tile -- 32->32 @256x256 -- is 71 -> 56 us alone, but the 144 KB workgroups keep
                         # the main stream's kernels off the CUs: the step lost 0.5 %, so those layers stay on the direct kernel)
                         st['wino_w'] = 4
-                        max_wg = max(max_wg, lib.aide_conv3x3_wgrad_wino4_ws_bytes(n, cout, cin, hh, ww))
+                        st['wg_bytes'] = lib.aide_conv3x3_wgrad_wino4_ws_bytes(n, cout, cin, hh, ww)
                     elif USE_WINOGRAD[0] and lib.aide_conv3x3_wgrad_wino_supported(cout, cin, hh, ww):
                         st['wino_w'] = 2
-                        max_wg = max(max_wg, lib.aide_conv3x3_wgrad_wino_ws_bytes(n, cout, cin, hh, ww))
+                        st['wg_bytes'] = lib.aide_conv3x3_wgrad_wino_ws_bytes(n, cout, cin, hh, ww)
                     else:
                         st['wino_w'] = 0
-                        max_wg = max(max_wg, lib.aide_conv3x3_wgrad_ws_bytes(n, cout, cin, hh, ww))
+                        st['wg_bytes'] = lib.aide_conv3x3_wgrad_ws_bytes(n, cout, cin, hh, ww)
+                    max_wg = max(max_wg, st['wg_bytes'])
                     st['pack_key'] = None
                     st['flops'] = 2.0 * n * hh * ww * cout * cin * 9      # algorithmic, per launch
                     # bf16 mode keeps the conv output z (read only by BatchNorm) and its gradient dz (read only by the
@@ -245,7 +249,8 @@ class Plan(object):
                         st['z'] = torch.empty(n, cout, hh, ww, device=device, dtype=torch.bfloat16)
                 else:
                     cin = src.C
-                    max_wg = max(max_wg, lib.aide_convT2x2_wgrad_ws_bytes(n, cin, cout, h >> src.level, w >> src.level))
+                    st['wg_bytes'] = lib.aide_convT2x2_wgrad_ws_bytes(n, cin, cout, h >> src.level, w >> src.level)
+                    max_wg = max(max_wg, st['wg_bytes'])
             elif op['kind'] == 'head':
                 src = op['src']
                 k = op['conv'].out_channels
@@ -322,7 +327,17 @@ class Plan(object):
             if st['kind'] in ('conv', 'convT'):
                 st['dz'] = torch.empty(st['z'].shape, device=self.dev,
                                        dtype=torch.bfloat16 if st.get('dz_bf16') else torch.float32)
-        self.wg_ws = torch.empty(max(self._max_wg // 4, 1), **f32)
+        # weight-gradient slab workspaces: one region per layer, so that the per-split partial results of every layer
+        # survive until the ONE batched reduce launch at the end of the backward pass (aide_wgrad_reduce_flush)
+        off = 0
+        for st in self.steps:
+            if st['kind'] in ('conv', 'convT'):
+                st['wg_off'] = off
+                off += (st['wg_bytes'] // 4 + 63) // 64 * 64
+        self.wg_ws = torch.empty(max(off, 1), **f32)
+        for st in self.steps:
+            if st['kind'] in ('conv', 'convT'):
+                st['wg_ws'] = self.wg_ws[st['wg_off']:st['wg_off'] + max(st['wg_bytes'] // 4, 1)]
         self.head_ws = torch.empty(max(self._max_wg // 4, 1), **f32)
         sa = [st for st in self.steps if st['kind'] == 'sa']
         if sa:                      # small-channel gradient ping-pong buffers + the gate-backward workspace
@@ -418,17 +433,21 @@ class Plan(object):
                 prof = self.profiler
                 if prof is not None:
                     prof.begin(FWD_TAG[st['wino_f']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_f']])
+                # training forward of a split-K layer: the conv leaves its slabs (accumulate = 2) and the BatchNorm that
+                # follows sums them itself -- no split-reduce launch, one pass over z less
+                slabs = self.training and FOLD_SPLITK[0] and (st['plan_f'] >> 8) > 1
+                acc = 2 if slabs else 0
                 if st['wino_f'] == BF16:
-                    ops.conv3x3_bf16(x, st['uf'], conv.bias, st['z'], splitk=st['plan_f'] >> 8, ws=self.sk_ws)
+                    ops.conv3x3_bf16(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=self.sk_ws)
                 elif st['wino_f'] == 4:
-                    ops.conv3x3_wino4(x, st['uf'], conv.bias, st['z'], splitk=st['plan_f'] >> 8, ws=self.sk_ws)
+                    ops.conv3x3_wino4(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=self.sk_ws)
                 elif st['wino_f']:
-                    ops.conv3x3_wino(x, st['uf'], conv.bias, st['z'], splitk=st['plan_f'] >> 8, ws=self.sk_ws)
+                    ops.conv3x3_wino(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=self.sk_ws)
                 else:
-                    ops.conv3x3_igemm(x, st['wf'], conv.bias, st['z'], plan=st['plan_f'], ws=self.sk_ws)
+                    ops.conv3x3_igemm(x, st['wf'], conv.bias, st['z'], accumulate=acc, plan=st['plan_f'], ws=self.sk_ws)
                 if prof is not None:
                     prof.end()
-                self._bn_apply(st, bn)
+                self._bn_apply(st, bn, conv.bias if slabs else None, (st['plan_f'] >> 8) if slabs else 0)
             elif kind == 'convT':
                 conv, bn = st['conv'], st['bn']
                 ops.convT2x2_fwd(self.view(st['src'], inputs), conv.weight, conv.bias, st['z'])
@@ -459,22 +478,31 @@ class Plan(object):
                 ops.sa_mul(st['gate'], y, self.view(st['dst']))
         return out
 
-    def _bn_apply(self, st, bn):
-        if self.training and self.groups > 1:
-            m = self.N // self.groups
-            z, a = st['z'], self.view(st['dst'])
-            for gi in range(self.groups):
-                ops.bn_train_fwd(z[gi * m:(gi + 1) * m], a[gi * m:(gi + 1) * m], bn.weight, bn.bias, bn.eps, bn.momentum,
-                                 bn.running_mean, bn.running_var, bn.num_batches_tracked, st['mean'],
-                                 st['rstd'], st['scale'], st['shift'], self.bn_ws, True)
-        elif self.training:
-            ops.bn_train_fwd(st['z'], self.view(st['dst']), bn.weight, bn.bias, bn.eps, bn.momentum,
-                             bn.running_mean, bn.running_var, bn.num_batches_tracked, st['mean'],
-                             st['rstd'], st['scale'], st['shift'], self.bn_ws, True)
+    def _bn_apply(self, st, bn, slab_bias=None, splitk=0):
+        """BatchNorm(+ReLU) of one conv output.  splitk > 0: z is still in the split-K slabs of self.sk_ws
+        ([splitk][N][C][H][W]) -- the BatchNorm kernels sum them, add `slab_bias` and write z themselves."""
+        z, a = st['z'], self.view(st['dst'])
+        ngroups = self.groups if (self.training and self.groups > 1) else 1
+        m = self.N // ngroups
+        if self.training:
+            stride = z.numel()                              # elements of one slab
+            per_img = stride // self.N
+            for gi in range(ngroups):
+                zg, ag = (z, a) if ngroups == 1 else (z[gi * m:(gi + 1) * m], a[gi * m:(gi + 1) * m])
+                if splitk > 0:
+                    import ctypes
+                    sl = ctypes.c_void_p(self.sk_ws.data_ptr() + 4 * gi * m * per_img)
+                    ops.bn_train_fwd_slabs(sl, splitk, stride, slab_bias, zg, ag, bn.weight, bn.bias, bn.eps, bn.momentum,
+                                           bn.running_mean, bn.running_var, bn.num_batches_tracked, st['mean'],
+                                           st['rstd'], st['scale'], st['shift'], self.bn_ws, True)
+                else:
+                    ops.bn_train_fwd(zg, ag, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                     bn.num_batches_tracked, st['mean'], st['rstd'], st['scale'], st['shift'],
+                                     self.bn_ws, True)
         else:
             ops.bn_eval_coeff(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, st['scale'],
                               st['shift'])
-            ops.bn_relu_apply(st['z'], self.view(st['dst']), st['scale'], st['shift'], True)
+            ops.bn_relu_apply(z, a, st['scale'], st['shift'], True)
 
     # ------------------------------------------------------------------ backward
     def backward(self, inputs, dlogits, flat, offsets, after_op=None):
@@ -498,6 +526,42 @@ class Plan(object):
         side = self.side if (self.overlap and self.profiler is None) else None
         if side is not None:
             side.wait_stream(main)
+        # The slab reduces of the weight gradients run batched, one launch per FLUSH_EVERY layers: fewer latency-bound
+        # launches on the weight-gradient stream, and only the last (small, shallow-encoder) batch sits after the last kernel
+        defer = DEFER_WGRAD_REDUCE[0] and self.profiler is None
+        waiting = []                          # ops whose after_op callback waits for the flush of their weight gradient
+
+        def flush():
+            if lib.aide_wgrad_reduce_pending():
+                if side is not None:
+                    with torch.cuda.stream(side):
+                        ops.check(lib.aide_wgrad_reduce_flush(ops.stream_ptr()), 'wgrad_reduce_flush')
+                else:
+                    ops.check(lib.aide_wgrad_reduce_flush(ops.stream_ptr()), 'wgrad_reduce_flush')
+            if after_op is not None:
+                for w_st in waiting:          # their weight gradients are now enqueued in full
+                    after_op(w_st)
+            del waiting[:]
+
+        hook = after_op
+        if defer:
+            def hook(w_st):
+                waiting.append(w_st)
+                if lib.aide_wgrad_reduce_pending() >= FLUSH_EVERY:
+                    flush()
+        if defer:
+            lib.aide_wgrad_reduce_defer(1)
+        try:
+            self._backward_ops(inputs, dlogits, gslot, main, side, hook)
+            if defer:
+                flush()
+        finally:
+            if defer:
+                lib.aide_wgrad_reduce_defer(0)
+        if side is not None:
+            main.wait_stream(side)
+
+    def _backward_ops(self, inputs, dlogits, gslot, main, side, after_op):
         for st in reversed(self.steps):
             kind = st['kind']
             sg = st.get('src_grad')
@@ -543,13 +607,13 @@ class Plan(object):
                             side.wait_event(ev)
                             if prof is not None:
                                 prof.begin(WGRAD_TAG[st['wino_w']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_w']])
-                            wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
+                            wgrad(dz, x, gslot(conv.weight), ws=st['wg_ws'])
                             if prof is not None:
                                 prof.end()
                     else:
                         if prof is not None:
                             prof.begin(WGRAD_TAG[st['wino_w']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_w']])
-                        wgrad(dz, x, gslot(conv.weight), ws=self.wg_ws)
+                        wgrad(dz, x, gslot(conv.weight), ws=st['wg_ws'])
                         if prof is not None:
                             prof.end()
                     if sg is not None:
@@ -575,9 +639,9 @@ class Plan(object):
                         ev.record(main)
                         with torch.cuda.stream(side):      # shares the slab workspace with conv wgrad
                             side.wait_event(ev)
-                            ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=self.wg_ws)
+                            ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=st['wg_ws'])
                     else:
-                        ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=self.wg_ws)
+                        ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=st['wg_ws'])
                     if sg is not None:
                         ops.convT2x2_dgrad(dz, conv.weight, self.gview(st['src']))
             elif kind == 'sa':
@@ -610,8 +674,6 @@ class Plan(object):
                                        accumulate=sg['accumulate'])
             if after_op is not None:
                 after_op(st)
-        if side is not None:
-            main.wait_stream(side)
 
 
 class _NetFunction(torch.autograd.Function):

@@ -174,6 +174,21 @@ def bn_train_fwd(z, a, gamma, beta, eps, momentum, running_mean, running_var, nb
     return a
 
 
+def bn_train_fwd_slabs(slabs, splitk, split_stride, bias, z, a, gamma, beta, eps, momentum, running_mean, running_var, nbt,
+                       mean, rstd, scale, shift, ws, relu=True):
+    """bn_train_fwd whose input is the split-K slabs [splitk][N_total][C][H][W] of the convolution before it (launched with
+    accumulate=2): sums them (+ bias) in split order, writes z, normalises.  `slabs` points at the first image of this
+    (group) batch inside slab 0; `split_stride` is the full slab size in elements."""
+    zp, zbs = planes(z, bf16_ok=True)
+    ap, abs_ = planes(a, bf16_ok=True)
+    n, c, h, w = z.shape
+    check(lib.aide_bn_train_fwd_slabs(slabs, splitk, split_stride, ptr(bias), zp, int(is_bf16(z)), zbs, ap, int(is_bf16(a)),
+                                      abs_, n, c, h, w, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
+                                      ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), int(relu),
+                                      ptr(ws), stream_ptr()), 'bn_train_fwd_slabs')
+    return a
+
+
 def bn_eval_coeff(gamma, beta, running_mean, running_var, eps, scale, shift):
     check(lib.aide_bn_eval_coeff(scale.numel(), ptr(gamma), ptr(beta), ptr(running_mean),
                                  ptr(running_var), eps, ptr(scale), ptr(shift), stream_ptr()),

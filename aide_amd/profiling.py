@@ -79,6 +79,9 @@ class DispatchTimer(object):
     def stop(self):
         self.lib.aide_ktimer_stop()
 
+    def arm(self):
+        self.check(self.lib.aide_ktimer_arm(self.mask), 'ktimer_arm')
+
     def summary(self):
         import ctypes
         torch.cuda.synchronize()

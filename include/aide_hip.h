@@ -150,6 +150,14 @@ int aide_bn_train_fwd_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, in
                             int H, int W, const float* gamma, const float* beta, float eps, float momentum,
                             float* running_mean, float* running_var, long long* num_batches_tracked, float* mean,
                             float* rstd, float* scale, float* shift, int relu, void* ws, aide_stream_t stream);
+/* BatchNorm(train)+ReLU fed directly by the split-K slabs of the convolution before it: a conv launched with
+ * accumulate = 2 leaves its partial results in ws as [splitk][N][C][H][W] fp32 (no reduce launch); this entry sums them in
+ * split order (+ bias), writes z for the backward pass and normalises -- one launch and one pass over z less per layer. */
+int aide_bn_train_fwd_slabs(const float* slabs, int splitk, int64_t split_stride, const float* bias, void* z, int z_bf16,
+                            int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C, int H, int W,
+                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, long long* num_batches_tracked, float* mean, float* rstd, float* scale,
+                            float* shift, int relu, void* ws, aide_stream_t stream);
 int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
                              int H, int W, const float* scale, const float* shift, int relu, aide_stream_t stream);
 int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz,
@@ -184,6 +192,17 @@ int aide_reverse_aug(const float* x, int64_t x_bs, float* y, int64_t y_bs, const
                      int H, int W, aide_stream_t stream);
 int aide_fill_zero(float* p, int64_t bs, int N, int C, int H, int W, aide_stream_t stream);
 
+/* ---- deferred slab reduce of the weight gradients ------------------------------------------------------------------
+ * Every aide_conv3x3_wgrad* call leaves per-split partial results ("slabs") in its workspace and reduces them into dw
+ * with a small launch.  Between aide_wgrad_reduce_defer(1) and aide_wgrad_reduce_flush(stream) those reduces are
+ * collected instead (each call then needs a workspace region of its own that stays untouched until the flush) and run
+ * as ONE launch over all layers (fixed summation order per element: deterministic, identical results).
+ * aide_wgrad_reduce_defer returns the previous mode; aide_wgrad_reduce_flush reduces everything pending (<= 512 layers)
+ * on `stream`, which must be ordered after the weight-gradient kernels. */
+int aide_wgrad_reduce_defer(int on);
+int aide_wgrad_reduce_pending(void);
+int aide_wgrad_reduce_flush(aide_stream_t stream);
+
 /* ---- kernel timer (measurement only; bench.py `roofline`) --------------------------------------------------------
  * While armed for a family, every launch of that family's MAIN kernel carries a start / stop HIP event pair on its own
  * stream (hipExtLaunchKernelGGL): the pair records the dispatch's begin / end timestamps -- the duration rocprofv3
@@ -195,7 +214,10 @@ int aide_fill_zero(float* p, int64_t bs, int N, int C, int H, int W, aide_stream
  * returns the number of launches that found no free slot (>= 0) or an error (< 0).  `flops` = algorithmic
  * (direct-convolution) flop, 2 N H W Co Ci 9 per launch. */
 int aide_ktimer_start(int family_mask, int capacity);
+/* the launchers' own hook (not for callers): claims an event pair (hipEvent_t*) for one launch of `family`; 0 = not armed */
+int aide_ktimer_slot(int family, double flops, void** e0, void** e1);
 int aide_ktimer_stop(void);
+int aide_ktimer_arm(int family_mask);        /* re-arm after a stop, keeping what was recorded */
 int aide_ktimer_read(int family, int64_t* launches, double* ms, double* flops, double* max_ms);
 
 /* ---- Spatial_Attention branch of the attention variants (fuseunetsa / UNetsa) -----------------------------------

@@ -308,6 +308,27 @@ C4_GRAD_KEYS = ('down_block1.block.conv1.weight', 'down_block3.block.conv2.weigh
                 'last_conv1.weight', 'last_conv1.bias')
 
 
+def _fp64_truth(ctor, ref_utils, inputs, t, keys):
+    """The SAME reference network evaluated in float64 (`.double()`): the ground truth both fp32 implementations round
+    differently around.  A ReLU pre-activation that is ~1e-7 from zero lands on either side of it in two fp32
+    evaluations; one such flip changes a gradient element by far more than 1e-3 of its value, so the reference's own
+    fp32 gradients differ from this truth by up to 2e-3 element-wise at 256x256.  Stored: per-parameter norms and the
+    element-wise slices of `keys`, so that a test can bound |ours - truth| by the reference's own |fp32 - truth|."""
+    torch.manual_seed(2)
+    net = ctor().double()
+    net.train()
+    w = torch.tensor([1.0, 1.0], dtype=torch.float64)
+    out = net(*[x.double() for x in inputs])
+    loss = ref_utils.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)(out, t)
+    loss.backward()
+    fx = {'grad_norms64': _np(torch.stack([p.grad.norm() for p in net.parameters()])),
+          'logits_rows64': _np(out[:, :, ::37, :]), 'loss64': _np(loss.detach())}
+    named = dict(net.named_parameters())
+    for k in keys:
+        fx['grad64/' + k] = _sub(named[k].grad)
+    return fx
+
+
 def g2_config(ref_f, ref_utils):
     """BASELINE config 2 digests: FuseUNet N=4, 256x256, synthetic CHAOS-shaped batch."""
     import oracle
@@ -335,6 +356,7 @@ def g2_config(ref_f, ref_utils):
     out, loss, per, gn, names, grads = res['ref']
     for k in C2_GRAD_KEYS:                      # element-wise gradients of the real reference (full tensor or _sub stride)
         fx['grad/' + k] = _sub(grads[k])
+    fx.update(_fp64_truth(lambda: ref_f.fuseunet(2), ref_utils, (xin, xout), t, C2_GRAD_KEYS))
     fx['logits_sum'] = np.array(out.double().sum().item())
     fx['logits_abs_sum'] = np.array(out.double().abs().sum().item())
     fx['logits_rows'] = _np(out[:, :, ::37, :])          # 7 rows per image/class
@@ -374,6 +396,7 @@ def g13_config4(ref_u, ref_utils):
     for k in C4_GRAD_KEYS:
         _same(grads[k], res['ora'][5][k], 'g13 grad ' + k)
         fx['grad/' + k] = _sub(grads[k])
+    fx.update(_fp64_truth(lambda: ref_u.UNet(2), ref_utils, (xin,), t, C4_GRAD_KEYS))
     fx['logits_sum'] = np.array(out.double().sum().item())
     fx['logits_abs_sum'] = np.array(out.double().abs().sum().item())
     fx['logits_rows'] = _np(out[:, :, ::37, :])

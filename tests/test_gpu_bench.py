@@ -33,7 +33,7 @@ def _line(r):
 def test_bench_line_and_dispatch_timer(dev):
     """One short default-workload run: the contract keys, the live dispatch timing of every MFMA conv launch of the timed
     steps, the CPU baseline with host core count."""
-    r = _run(['--steps', '4', '--warmup', '2', '--cpu-steps', '1', '--traffic', 'none'])
+    r = _run(['--steps', '4', '--warmup', '2', '--event-steps', '3', '--cpu-steps', '1', '--traffic', 'none'])
     assert r.returncode == 0, r.stderr[-3000:]
     j = _line(r)
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
