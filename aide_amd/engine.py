@@ -93,6 +93,7 @@ STORE_BF16 = [True]            # precision='bf16': z / dz stored as bf16 (A-B sw
 STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 where every reader / writer allows it
 STORE_G_BF16 = [True]          # ... and the gradients of those activations
 DEFER_WGRAD_REDUCE = [_os.environ.get('AIDE_DEFER_WGRAD_REDUCE', '1') != '0']     # A-B switch: batched slab reduce
+HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switch: backward chain on a high-priority stream
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
 FLUSH_EVERY = int(_os.environ.get('AIDE_WGRAD_FLUSH_EVERY', '6'))      # layers per batched slab reduce
 
@@ -299,6 +300,7 @@ class Plan(object):
         self.profiler = None             # set by Engine (bench.py's per-kernel HIP-event timing)
         self._pack_key, self._pack_tab, self.side_fwd = None, None, None
         self.overlap = True              # weight gradients on a side stream (see backward)
+        self.hp = None                   # high-priority stream of the backward chain (HP_CHAIN)
         self.serial = 0                  # forwards run on this plan; _NetFunction.backward checks it still owns the buffers
         self.key = None
 
@@ -435,7 +437,8 @@ class Plan(object):
                     prof.begin(FWD_TAG[st['wino_f']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_f']])
                 # training forward of a split-K layer: the conv leaves its slabs (accumulate = 2) and the BatchNorm that
                 # follows sums them itself -- no split-reduce launch, one pass over z less
-                slabs = self.training and FOLD_SPLITK[0] and (st['plan_f'] >> 8) > 1
+                slabs = self.training and FOLD_SPLITK[0] and (st['plan_f'] >> 8) > 1 and \
+                    (st['z'].shape[2] * st['z'].shape[3]) % 4 == 0          # (the slab loader reads 16 bytes)
                 acc = 2 if slabs else 0
                 if st['wino_f'] == BF16:
                     ops.conv3x3_bf16(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=self.sk_ws)
@@ -520,10 +523,25 @@ class Plan(object):
         # up-sampling backward); every weight-gradient kernel (MFMA-bound, off the critical path) goes to
         # a side stream as soon as its dz exists, so the HBM-bound kernels of the next layer run in
         # its shadow instead of between two MFMA kernels.
-        main = torch.cuda.current_stream()
+        main = outer = torch.cuda.current_stream()
         # (with a profiler attached the step runs on ONE stream: an event pair then brackets exactly one kernel's own time,
         # not its time under contention with the side stream -- bench.py instruments a single step for that reason)
         side = self.side if (self.overlap and self.profiler is None) else None
+        if side is not None and HP_CHAIN[0]:
+            # the dependent chain on a HIGH-priority stream: when both streams have workgroups ready the dispatcher serves
+            # the chain first and the weight gradients soak up what is left
+            if self.hp is None:
+                self.hp = torch.cuda.Stream(device=self.dev, priority=-1)
+            self.hp.wait_stream(outer)
+            main = self.hp
+        if main is not outer:
+            with torch.cuda.stream(main):
+                self._backward_streams(inputs, dlogits, gslot, main, side, after_op)
+            outer.wait_stream(main)
+        else:
+            self._backward_streams(inputs, dlogits, gslot, main, side, after_op)
+
+    def _backward_streams(self, inputs, dlogits, gslot, main, side, after_op):
         if side is not None:
             side.wait_stream(main)
         # The slab reduces of the weight gradients run batched, one launch per FLUSH_EVERY layers: fewer latency-bound

