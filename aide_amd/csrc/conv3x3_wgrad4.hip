@@ -192,7 +192,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
             to[6 * i + 3] = o34.x; to[6 * i + 4] = o34.y; to[6 * i + 5] = o05.y;
         }
     };
-    const int vpos = (vtile >> 1) * 64 + vci * 2 + (vtile & 1);       // V[p][tile pair][ci][2]
+    // V[p][tile pair][ci][2]; the second pair's run is XOR-swizzled by 16 dwords: a wave's 32-lane store group then
+    // covers all 32 banks (unswizzled, pairs 0 and 1 of the same channel share a bank: 2-way conflict on every store --
+    // rocprofv3 SQ_LDS_BANK_CONFLICT was 37 % of the kernel's LDS cycles); the fragment reads apply the same XOR
+    const int vpos = (vtile >> 1) * 64 + ((vci * 2 + (vtile & 1)) ^ ((vtile >> 1) * 16));
     auto v_store = [&](int o, float* vbuf) { vbuf[(18 * hs + o) * 128 + vpos] = to[o]; };
 
     // ---- dz transform (A Z A^T), thread = (co_l, tile), all 36 values ----
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
             zo[6 * i + 3] = o34.x; zo[6 * i + 4] = o34.y; zo[6 * i + 5] = t23.y;
         }
     };
-    const int zpos = (zt >> 1) * 128 + zco * 2 + (zt & 1);            // ZT[p][tile pair][co][2]
+    const int zpos = (zt >> 1) * 128 + ((zco * 2 + (zt & 1)) ^ ((zt >> 1) * 16));   // ZT[p][tile pair][co][2], swizzled as V
     auto z_store = [&](int o, float* zbuf) { zbuf[o * 256 + zpos] = zo[o]; };
 
     float* const set0 = lds;
@@ -268,8 +271,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
     auto chunk = [&](int c, float* sc, float* sn, float* rawc, auto CUR) {
         constexpr int kcur = decltype(CUR)::value;
         // operands are stored [p][tile pair][channel][2]: a wave's ds_read_b64 covers 512 contiguous bytes
-        const float* la = sc + (18 * ph) * 256 + half * 128 + (cb * 32 + j) * 2;                // ZT[p][pair][co 64][2]
-        const float* lb = sc + G4_ZT + (18 * ph) * 128 + half * 64 + j * 2;                     // V[p][pair][ci 32][2]
+        const float* la = sc + (18 * ph) * 256 + half * 128 + (((cb * 32 + j) * 2) ^ (half * 16));     // ZT[p][pair][co 64][2]
+        const float* lb = sc + G4_ZT + (18 * ph) * 128 + half * 64 + ((j * 2) ^ (half * 16));          // V[p][pair][ci 32][2]
         f32x2 fa[6], fb[6];
         auto frag = [&](int pi, int s2) {
             fa[s2] = *reinterpret_cast<const f32x2*>(la + pi * 256);

@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     // wait for the filter fragments it has just requested.
     auto run = [&](auto HS) {
     auto xf_math = [&]() { xf_half(HS); };
-    const int vitem = ((item >> 1) & 1) * 64 + (item >> 2) * 2 + (item & 1);      // [pair][tile][2]
+    // [pair][tile][2]; pair 1's run XOR-swizzled by 16 dwords so that a 32-lane store group covers all 32 banks
+    // (see conv3x3_wgrad4.hip); the B-fragment reads apply the same XOR
+    const int vitem = ((item >> 1) & 1) * 64 + (((item >> 2) * 2 + (item & 1)) ^ (((item >> 1) & 1) * 16));
     auto xf_store = [&](int o, float* vbuf) { vbuf[(18 * hs + o) * 128 + vitem] = to[o]; };
 
     f32x16 acc[18];
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
         constexpr int kcur = decltype(CUR)::value;
         // V[p][channel pair][tile][2]: a wave's ds_read_b64 covers 512 contiguous bytes in lane order (a
         // [tile][4] row layout measured 2-way bank conflicts on every fragment read, with or without swizzle)
-        const float* lb = sc + F4_RAW + (18 * ph) * 128 + half * 64 + j * 2;
+        const float* lb = sc + F4_RAW + (18 * ph) * 128 + half * 64 + ((j * 2) ^ (half * 16));
         f32x2 fb[6];                                       // B fragments, requested 4 slots ahead
         auto frag = [&](int pi, int slot2) { fb[slot2] = *reinterpret_cast<const f32x2*>(lb + pi * 128); };
         frag(0, 0); frag(1, 1); frag(2, 2); frag(3, 3);

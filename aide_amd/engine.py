@@ -93,6 +93,7 @@ STORE_BF16 = [True]            # precision='bf16': z / dz stored as bf16 (A-B sw
 STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 where every reader / writer allows it
 STORE_G_BF16 = [True]          # ... and the gradients of those activations
 DEFER_WGRAD_REDUCE = [_os.environ.get('AIDE_DEFER_WGRAD_REDUCE', '1') != '0']     # A-B switch: batched slab reduce
+LATE_DGRAD_PACK = [_os.environ.get('AIDE_LATE_DGRAD_PACK', '0') != '0']   # A-B switch (measured: no effect, off)
 HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switch: backward chain on a high-priority stream
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
 FLUSH_EVERY = int(_os.environ.get('AIDE_WGRAD_FLUSH_EVERY', '6'))      # layers per batched slab reduce
@@ -299,7 +300,9 @@ class Plan(object):
         self._bwd_ready = False
         self.profiler = None             # set by Engine (bench.py's per-kernel HIP-event timing)
         self._pack_key, self._pack_tab, self.side_fwd = None, None, None
+        self._late_pending, self._late_inflight = None, False
         self.overlap = True              # weight gradients on a side stream (see backward)
+        self.trace = None                # tools/phase_trace.py: callable(direction, step) before every op
         self.hp = None                   # high-priority stream of the backward chain (HP_CHAIN)
         self.serial = 0                  # forwards run on this plan; _NetFunction.backward checks it still owns the buffers
         self.key = None
@@ -374,26 +377,38 @@ class Plan(object):
             import struct
             split = min(4, len(convs))
 
-            def tables(group):
-                direct = [(st['conv'].weight, st['wf'], st['wd']) for st in group
-                          if st['wf'] is not None or st['wd'] is not None]
+            def tables(group, fwd=True, dgrad=True):
+                """pack tables of a group of convs; fwd / dgrad select which direction's packs they write"""
+                F = lambda st, key: st[key] if fwd else None
+                D = lambda st, key: st[key] if dgrad else None
+                direct = [(st['conv'].weight, F(st, 'wf'), D(st, 'wd')) for st in group
+                          if F(st, 'wf') is not None or D(st, 'wd') is not None]
                 # a conv may use different modes forward and backward: each table gets only its own packs
-                wino = [(st['conv'].weight, st['uf'] if st['wino_f'] == 2 else None,
-                         st['ud'] if st['wino_d'] == 2 else None) for st in group
-                        if (st['uf'] is not None and st['wino_f'] == 2) or (st['ud'] is not None and st['wino_d'] == 2)]
-                wino4 = [(st['conv'].weight, st['uf'] if st['wino_f'] == 4 else None,
-                          st['ud'] if st['wino_d'] == 4 else None) for st in group
-                         if (st['uf'] is not None and st['wino_f'] == 4) or (st['ud'] is not None and st['wino_d'] == 4)]
-                b16 = [(st['conv'].weight, st['uf'] if st['wino_f'] == BF16 else None,
-                        st['ud'] if st['wino_d'] == BF16 else None) for st in group
-                       if (st['uf'] is not None and st['wino_f'] == BF16) or (st['ud'] is not None and st['wino_d'] == BF16)]
+                def by_mode(mode):
+                    out = []
+                    for st in group:
+                        uf = F(st, 'uf') if st['wino_f'] == mode else None
+                        ud = D(st, 'ud') if st['wino_d'] == mode else None
+                        if uf is not None or ud is not None:
+                            out.append((st['conv'].weight, uf, ud))
+                    return out
+                wino, wino4, b16 = by_mode(2), by_mode(4), by_mode(BF16)
                 return (ops.pack_table(direct, self.dev) if direct else None,
                         ops.wino_pack_table(wino, self.dev) if wino else None,
                         ops.wino4_pack_table(wino4, self.dev) if wino4 else None,
                         ops.bf16_pack_table(b16, self.dev) if b16 else None)
-            self._pack_tab = (ptrs, tables(convs[:split]), tables(convs[split:]) if len(convs) > split else None,
-                              convs[split] if len(convs) > split else None)
-        _, first, rest, gate = self._pack_tab
+            rest = convs[split:]
+            late = LATE_DGRAD_PACK[0] and self.training and len(rest) > 0
+            # the dgrad-direction packs of all but the first convs (half of the re-layout bytes) are needed only in the
+            # backward pass: they are launched when the decoder starts (first up-sampling / ConvT op), under its MFMA-bound
+            # convolutions, instead of next to the HBM-bound first level
+            ups = [st for st in self.steps if st['kind'] in ('up', 'convT')]
+            self._pack_tab = (ptrs, tables(convs[:split]),
+                              tables(rest, True, not late) if rest else None,
+                              convs[split] if rest else None,
+                              tables(rest, False, True) if late else None,
+                              (ups[0] if ups else self.steps[-1]) if late else None)
+        _, first, rest, gate, late_tab, late_gate = self._pack_tab
 
         def launch(tabs):
             d, wn, w4, b16 = tabs
@@ -409,8 +424,10 @@ class Plan(object):
             if wn is not None:
                 ops.check(lib.aide_conv3x3_wino_pack_multi(ops.ptr(wn[0]), wn[1], wn[2], ops.stream_ptr()),
                           'conv3x3_wino_pack_multi')
+        self._launch_pack = launch
         launch(first)
         self._pack_key = key
+        self._late_pending = (late_tab, late_gate) if late_tab is not None else None
         if rest is None:
             return None
         if self.side_fwd is None:
@@ -421,12 +438,27 @@ class Plan(object):
             launch(rest)
         return gate
 
+    def _late_pack(self, st):
+        """launch the deferred dgrad-direction packs on the side stream when the forward reaches their gate op"""
+        if self._late_pending is not None and (st is None or st is self._late_pending[1]):
+            tab = self._late_pending[0]
+            self._late_pending = None
+            main = torch.cuda.current_stream()
+            self.side_fwd.wait_stream(main)
+            with torch.cuda.stream(self.side_fwd):
+                self._launch_pack(tab)
+            self._late_inflight = True
+
     def forward(self, inputs, out):
         n = self.N
         self.serial += 1                 # the saved activations of this plan now belong to THIS forward (any kind)
         gate = self._pack_filters()
         for st in self.steps:
             kind = st['kind']
+            if self.trace is not None:
+                self.trace('f', st)
+            if self._late_pending is not None:
+                self._late_pack(st)
             if kind == 'conv':
                 conv, bn = st['conv'], st['bn']
                 if st is gate:                 # the remaining filters were re-packed on the side stream
@@ -479,6 +511,8 @@ class Plan(object):
                 else:
                     ops.sa_gate_fwd(st['t4'], m.bn, self.training, st['stat'], st['gate'])
                 ops.sa_mul(st['gate'], y, self.view(st['dst']))
+        if self._late_pending is not None:
+            self._late_pack(None)
         return out
 
     def _bn_apply(self, st, bn, slab_bias=None, splitk=0):
@@ -542,6 +576,9 @@ class Plan(object):
             self._backward_streams(inputs, dlogits, gslot, main, side, after_op)
 
     def _backward_streams(self, inputs, dlogits, gslot, main, side, after_op):
+        if self._late_inflight:              # the dgrad-direction filter packs launched under the decoder forward
+            main.wait_stream(self.side_fwd)
+            self._late_inflight = False
         if side is not None:
             side.wait_stream(main)
         # The slab reduces of the weight gradients run batched, one launch per FLUSH_EVERY layers: fewer latency-bound
@@ -583,6 +620,8 @@ class Plan(object):
         for st in reversed(self.steps):
             kind = st['kind']
             sg = st.get('src_grad')
+            if self.trace is not None:
+                self.trace('b', st)
             if sg is not None:
                 for gap in sg['gaps']:
                     ops.fill_zero(self.gview(gap))
