@@ -184,8 +184,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
         for (int i = 0; i < 3; ++i) {
             const f32x2 t01 = T[i][0], t23 = T[i][1], t45 = T[i][2];
             const f32x2 ac = f32x2{t23.x, t23.x} * f32x2{-4.f, -1.f} + f32x2{t45.x, t45.x};
-            const f32x2 be = f32x2{t01.y, t01.y} * f32x2{4.f, -1.f} + f32x2{-t23.y, t23.y};
-            const f32x2 o12 = f32x2{ac.x, ac.x} + f32x2{-be.x, be.x};
+            // (nb, e) = (-(4 t1 - t3), t3 - t1): keeping the first component NEGATED makes every line one packed FMA with
+            // splat operands and constant multipliers -- a `{-x, x}` pair costs a v_xor + v_mov on the MFMA's own pipe
+            const f32x2 be = f32x2{t01.y, t01.y} * f32x2{-4.f, -1.f} + f32x2{t23.y, t23.y};
+            const f32x2 o12 = f32x2{be.x, be.x} * f32x2{1.f, -1.f} + f32x2{ac.x, ac.x};
             const f32x2 o34 = f32x2{be.y, be.y} * f32x2{2.f, -2.f} + f32x2{ac.y, ac.y};
             const f32x2 o05 = t23 * f32x2{-5.f, -5.f} + (t01 * f32x2{4.f, 4.f} + t45);
             to[6 * i] = o05.x; to[6 * i + 1] = o12.x; to[6 * i + 2] = o12.y;
@@ -196,7 +198,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
     // covers all 32 banks (unswizzled, pairs 0 and 1 of the same channel share a bank: 2-way conflict on every store --
     // rocprofv3 SQ_LDS_BANK_CONFLICT was 37 % of the kernel's LDS cycles); the fragment reads apply the same XOR
     const int vpos = (vtile >> 1) * 64 + ((vci * 2 + (vtile & 1)) ^ ((vtile >> 1) * 16));
-    auto v_store = [&](int o, float* vbuf) { vbuf[(18 * hs + o) * 128 + vpos] = to[o]; };
+    // per-set store bases as live registers (as xr0 / xr1): with one base + a > 64 KB constant the offsets do not fit the
+    // 16-bit DS immediate and hipcc re-derives the address with a v_add per store (17 per chunk, on the MFMA's pipe)
+    int vb0 = G4_ZT + 18 * hs * 128 + vpos, vb1 = G4_SET + G4_ZT + 18 * hs * 128 + vpos;
+    asm volatile("" : "+v"(vb0), "+v"(vb1));
+    auto v_store = [&](int o, int set) { lds[(set ? vb1 : vb0) + o * 128] = to[o]; };
 
     // ---- dz transform (A Z A^T), thread = (co_l, tile), all 36 values ----
     float zo[36];
@@ -217,14 +223,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
             const f32x2 t01 = Y[i][0], t23 = Y[i][1];
             const f32x2 sa = f32x2{t23.x, t23.x} * f32x2{1.f, 4.f} + f32x2{t01.x, t01.x};
             const f32x2 sb = f32x2{t23.y, t23.y} * f32x2{1.f, 4.f} + f32x2{t01.y, t01.y};
-            const f32x2 o12 = f32x2{sa.x, sa.x} + f32x2{sb.x, -sb.x};
+            const f32x2 o12 = f32x2{sb.x, sb.x} * f32x2{1.f, -1.f} + f32x2{sa.x, sa.x};
             const f32x2 o34 = f32x2{sb.y, sb.y} * f32x2{2.f, -2.f} + f32x2{sa.y, sa.y};
             zo[6 * i] = t01.x; zo[6 * i + 1] = o12.x; zo[6 * i + 2] = o12.y;
             zo[6 * i + 3] = o34.x; zo[6 * i + 4] = o34.y; zo[6 * i + 5] = t23.y;
         }
     };
     const int zpos = (zt >> 1) * 128 + ((zco * 2 + (zt & 1)) ^ ((zt >> 1) * 16));   // ZT[p][tile pair][co][2], swizzled as V
-    auto z_store = [&](int o, float* zbuf) { zbuf[o * 256 + zpos] = zo[o]; };
+    int zb0 = zpos, zb1 = G4_SET + zpos;
+    asm volatile("" : "+v"(zb0), "+v"(zb1));
+    auto z_store = [&](int o, int set) { lds[(set ? zb1 : zb0) + o * 256] = zo[o]; };
 
     float* const set0 = lds;
     float* const set1 = lds + G4_SET;
@@ -256,10 +264,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
     for (int r = 0; r < 6; ++r) v_read(r, xr0);
     v_math(HS);
 #pragma unroll
-    for (int o = 0; o < 18; ++o) v_store(o, set0 + G4_ZT);
+    for (int o = 0; o < 18; ++o) v_store(o, 0);
     z_math();
 #pragma unroll
-    for (int o = 0; o < 36; ++o) z_store(o, set0);
+    for (int o = 0; o < 36; ++o) z_store(o, 0);
 #pragma unroll
     for (int w = 0; w < 14; ++w) put_d(w, raw1);
     __syncthreads();
@@ -299,13 +307,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
 #ifndef AIDE_PROBE_GNOV
             if (st >= 1 && st < 7) v_read(st - 1, kcur ? xr0 : xr1);
             if (st == 14) v_math(HS);
-            if (st >= 15 && st < 24) { v_store(2 * (st - 15), sn + G4_ZT); v_store(2 * (st - 15) + 1, sn + G4_ZT); }
+            if (st >= 15 && st < 24) { v_store(2 * (st - 15), 1 - kcur); v_store(2 * (st - 15) + 1, 1 - kcur); }
 #endif
 #ifndef AIDE_PROBE_GNOZ
             if (st == 20) z_math();
             if (st >= 21 && st < 33) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) z_store(3 * (st - 21) + q, sn);
+                for (int q = 0; q < 3; ++q) z_store(3 * (st - 21) + q, 1 - kcur);
             }
 #endif
 #ifndef AIDE_PROBE_GNOFETCH

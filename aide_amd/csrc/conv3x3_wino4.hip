@@ -165,8 +165,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
         for (int i = 0; i < 3; ++i) {
             const f32x2 t01 = T[i][0], t23 = T[i][1], t45 = T[i][2];
             const f32x2 ac = f32x2{t23.x, t23.x} * f32x2{-4.f, -1.f} + f32x2{t45.x, t45.x};
-            const f32x2 be = f32x2{t01.y, t01.y} * f32x2{4.f, -1.f} + f32x2{-t23.y, t23.y};
-            const f32x2 o12 = f32x2{ac.x, ac.x} + f32x2{-be.x, be.x};
+            // (nb, e) = (-(4 t1 - t3), t3 - t1): keeping the first component NEGATED makes every line one packed FMA with
+            // splat operands and constant multipliers -- a `{-x, x}` pair costs a v_xor + v_mov on the MFMA's own pipe
+            const f32x2 be = f32x2{t01.y, t01.y} * f32x2{-4.f, -1.f} + f32x2{t23.y, t23.y};
+            const f32x2 o12 = f32x2{be.x, be.x} * f32x2{1.f, -1.f} + f32x2{ac.x, ac.x};
             const f32x2 o34 = f32x2{be.y, be.y} * f32x2{2.f, -2.f} + f32x2{ac.y, ac.y};
             const f32x2 o05 = t23 * f32x2{-5.f, -5.f} + (t01 * f32x2{4.f, 4.f} + t45);
             to[6 * i] = o05.x; to[6 * i + 1] = o12.x; to[6 * i + 2] = o12.y;
