@@ -131,6 +131,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const ZT* __restrict__ z,
     }
 }
 
+// ---- statistics emitted by the convolution itself.  A forward conv launch that finds a sink armed writes, per output
+// channel and workgroup tile, the fp32 sum and sum of squares of its PRE-BIAS outputs: parts[c][nparts][2].  The apply
+// kernel below then derives mean / variance from them (fp64 across the parts, fixed order) -- the statistics pass over z
+// (bn_stats_kernel: one more read of the tensor and a launch) disappears.  Pre-bias sums keep E[y^2] - E[y]^2 benign: the
+// conv part of a BatchNorm input is close to zero-mean, the bias only shifts the mean.
 // Training forward, second pass: every block re-derives its channel's (scale, shift) from the fp64
 // partials (one wave, <= 64 splits) and applies a = relu(z*scale + shift); the (x == 0, n == 0) block
 // of each channel also publishes mean / rstd / scale / shift and updates the running statistics.
@@ -141,21 +146,29 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(
     const double* __restrict__ partials, int splits, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
     float* __restrict__ running_var, long long* __restrict__ nbt, float* __restrict__ mean_out,
-    float* __restrict__ rstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out, int relu) {
+    float* __restrict__ rstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out, int relu,
+    const float* __restrict__ fparts, int nparts, const float* __restrict__ cbias) {
     __shared__ float coef[2];
     const int plane = blockIdx.y;                 // n*C + c
     const int n = plane / C, c = plane - n * C;
     if (threadIdx.x < 64) {
         double s = 0.0, ss = 0.0;
-        if ((int)threadIdx.x < splits) {
+        if (fparts) {                             // statistics from the convolution's epilogue: [c][nparts][2], pre-bias
+            for (int i = threadIdx.x; i < nparts; i += 64) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(fparts + ((long)c * nparts + i) * 2);
+                s += (double)v[0];
+                ss += (double)v[1];
+            }
+        } else if ((int)threadIdx.x < splits) {
             s = partials[((long)c * splits + threadIdx.x) * 2 + 0];
             ss = partials[((long)c * splits + threadIdx.x) * 2 + 1];
         }
         s = wave_sum_d(s);
         ss = wave_sum_d(ss);
         if (threadIdx.x == 0) {
-            const double mean = s / count;
+            double mean = s / count;
             double var = ss / count - mean * mean;
+            if (fparts && cbias) mean += (double)cbias[c];           // the sums are of z - bias
             if (var < 0.0) var = 0.0;
             const float rstd = (float)(1.0 / sqrt(var + (double)eps));
             const float g = gamma ? gamma[c] : 1.0f, bb = beta ? beta[c] : 0.0f;
@@ -507,12 +520,12 @@ int bn_train_fwd_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C,
         hipLaunchKernelGGL((bn_stats_kernel<4, ZT, SLABS>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
         hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
-                           num_batches_tracked, mean, rstd, scale, shift, relu);
+                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr);
     } else {
         hipLaunchKernelGGL((bn_stats_kernel<1, ZT, false>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
         hipLaunchKernelGGL((bn_train_apply_kernel<1, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
-                           num_batches_tracked, mean, rstd, scale, shift, relu);
+                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr);
     }
     return aide_launch_status();
 }
@@ -599,6 +612,32 @@ int aide_bn_train_fwd_slabs(const float* slabs, int splitk, int64_t split_stride
     return a_bf16 ? AIDE_BN_FWD_S(float, bf16_t) : AIDE_BN_FWD_S(float, float);
 #undef AIDE_BN_FWD_S
 }
+
+// BatchNorm(train)+ReLU whose statistics were emitted by the convolution's own epilogue (aide_conv_stats_sink): parts
+// [C][nparts][2] fp32 = per channel and conv workgroup tile the sum and sum of squares of z - conv_bias.  One launch, one
+// read of z.  (H*W % 4 == 0 and 16-byte aligned batch strides.)
+int aide_bn_train_fwd_parts(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C, int H,
+                            int W, const float* parts, int nparts, const float* conv_bias, const float* gamma,
+                            const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                            long long* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift,
+                            int relu, hipStream_t stream) {
+    const int HW = H * W;
+    if (!z || !a || !parts || nparts <= 0 || HW % 4 || z_bs % 4 || a_bs % 4) return AIDE_ERR_ARG;
+    const double count = (double)N * HW;
+    const int gx = max(1, min((HW / 4 + 255) / 256, 16));
+#define AIDE_BN_PARTS(ZT, AT)                                                                                                  \
+    hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, (const ZT*)z, (long)z_bs,    \
+                       (AT*)a, (long)a_bs, C, HW, (const double*)nullptr, 0, count, gamma, beta, eps, momentum, running_mean, \
+                       running_var, num_batches_tracked, mean, rstd, scale, shift, relu, parts, nparts, conv_bias)
+    if (z_bf16) { if (a_bf16) AIDE_BN_PARTS(bf16_t, bf16_t); else AIDE_BN_PARTS(bf16_t, float); }
+    else { if (a_bf16) AIDE_BN_PARTS(float, bf16_t); else AIDE_BN_PARTS(float, float); }
+#undef AIDE_BN_PARTS
+    return aide_launch_status();
+}
+
+// two-pass (statistics kernel + apply kernel) or single small-plane kernel?  1 = two passes: only then do epilogue
+// statistics save a launch
+int aide_bn_two_pass(int N, int C, int H, int W) { return bn_fused_ok(N, C, H * W) ? 0 : 1; }
 
 int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
                              int H, int W, const float* scale, const float* shift, int relu, hipStream_t stream) {

@@ -171,10 +171,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
             if (khs == 0) {
                 const f32x2 aa = d4 - 4.f * d2, bb = 4.f * d1 - d3;
                 T[0][cp] = (4.f * d0 + d4) - 5.f * d2;
-                T[1][cp] = aa - bb;
+                T[1][cp] = bb * f32x2{-1.f, -1.f} + aa;        // (packed subtracts are scalarised by hipcc: v_sub x2 + v_mov x2)
                 T[2][cp] = aa + bb;
             } else {
-                const f32x2 cc = d4 - d2, ee = d3 - d1;
+                const f32x2 cc = d2 * f32x2{-1.f, -1.f} + d4, ee = d1 * f32x2{-1.f, -1.f} + d3;
                 T[0][cp] = cc + 2.f * ee;
                 T[1][cp] = cc - 2.f * ee;
                 T[2][cp] = (4.f * d1 + d5) - 5.f * d3;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
             const f32x2 z0 = f32x2{rz[0][2 * cp], rz[0][2 * cp + 1]}, z1 = f32x2{rz[1][2 * cp], rz[1][2 * cp + 1]},
                         z2 = f32x2{rz[2][2 * cp], rz[2][2 * cp + 1]}, z3 = f32x2{rz[3][2 * cp], rz[3][2 * cp + 1]};
             const f32x2 s02 = z0 + z2, s13 = z1 + z3, aa = z0 + 4.f * z2, bb = z1 + 4.f * z3;
-            Y[0][cp] = z0; Y[1][cp] = s02 + s13; Y[2][cp] = s02 - s13;
+            Y[0][cp] = z0; Y[1][cp] = s02 + s13; Y[2][cp] = s13 * f32x2{-1.f, -1.f} + s02;    // (one packed FMA; a packed subtract is scalarised)
             Y[3][cp] = aa + 2.f * bb; Y[4][cp] = aa - 2.f * bb; Y[5][cp] = z3;
         }
         // row pass, four packed ops per row: (s02, a) (s13, b) (o1, o2) (o3, o4); o0 = t0, o5 = t3

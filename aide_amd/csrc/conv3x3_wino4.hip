@@ -36,6 +36,8 @@ struct W4Args {
     long x_bs, y_bs, split_stride;
     int N, Cin, H, W, Cout;
     int blocks_w, blocks_h, n_co_tiles, splitk, stages_total, accumulate;
+    float* stats;        // optional [Cout][N * blocks_h * blocks_w][2]: per (channel, workgroup tile) sum / sum of squares of the
+                         // pre-bias outputs -- the BatchNorm statistics of the forward pass without a pass over z
 };
 
 constexpr int F4_NAGPR = 16;               // accumulators (of 18) kept in the AGPR file; the rest are pinned to VGPRs
@@ -151,10 +153,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             if (khs == 0) {
                 const f32x2 aa = d4 - 4.f * d2, bb = 4.f * d1 - d3;
                 T[0][cp] = (4.f * d0 + d4) - 5.f * d2;
-                T[1][cp] = aa - bb;
+                T[1][cp] = bb * f32x2{-1.f, -1.f} + aa;        // (packed subtracts are scalarised by hipcc: v_sub x2 + v_mov x2)
                 T[2][cp] = aa + bb;
             } else {
-                const f32x2 cc = d4 - d2, ee = d3 - d1;
+                const f32x2 cc = d2 * f32x2{-1.f, -1.f} + d4, ee = d1 * f32x2{-1.f, -1.f} + d3;
                 T[0][cp] = cc + 2.f * ee;
                 T[1][cp] = cc - 2.f * ee;
                 T[2][cp] = (4.f * d1 + d5) - 5.f * d3;
@@ -323,6 +325,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
 #pragma unroll
             for (int o = 0; o < 16; ++o) yp[o] += xbuf[(((wid ^ 1) * 128) + rr * 16 + o) * 64 + lane];
             const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (a.stats) {                                   // wave-uniform
+                float s1 = 0.f, s2 = 0.f;
+                if (pok) {
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) { s1 += yp[o]; s2 = __builtin_fmaf(yp[o], yp[o], s2); }
+                }
+#pragma unroll
+                for (int m = 16; m > 0; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }   // the 32 tiles of this half
+                if (j == 0 && co < a.Cout) {
+                    const int nparts = a.N * a.blocks_h * a.blocks_w, blk = (n * a.blocks_h + th) * a.blocks_w + tw;
+                    *reinterpret_cast<f32x2*>(a.stats + ((long)co * nparts + blk) * 2) = f32x2{s1, s2};
+                }
+            }
             if (pok && co < a.Cout) {
                 const float bv = add_bias ? a.bias[co] : 0.f;
 #pragma unroll
@@ -465,6 +480,9 @@ int aide_conv3x3_wino4_splitk(int N, int Cin, int H, int W, int Cout) {
     return s;
 }
 
+// partial-statistics entries per channel written by a forward launch when a sink is armed (aide_conv_stats_sink)
+int aide_conv3x3_wino4_stats_parts(int N, int H, int W) { return N * ((H + 15) / 16) * ((W + 31) / 32); }
+
 int aide_conv3x3_wino4_pack_blocks(int Co, int Ci) {
     return ((Co + P4_T - 1) / P4_T) * ((Ci + P4_T - 1) / P4_T);
 }
@@ -493,6 +511,7 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
         attr_set = true;
     }
     W4Args a;
+    a.stats = (splitk <= 1 && accumulate == 0) ? aide_conv_stats_take() : nullptr;
     a.x = x; a.u = u; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.blocks_w = (W + 31) / 32; a.blocks_h = (H + 15) / 16; a.n_co_tiles = (Cout + 63) / 64;
     a.stages_total = Cin / 4;

@@ -94,7 +94,9 @@ STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 wh
 STORE_G_BF16 = [True]          # ... and the gradients of those activations
 DEFER_WGRAD_REDUCE = [_os.environ.get('AIDE_DEFER_WGRAD_REDUCE', '1') != '0']     # A-B switch: batched slab reduce
 LATE_DGRAD_PACK = [_os.environ.get('AIDE_LATE_DGRAD_PACK', '0') != '0']   # A-B switch (measured: no effect, off)
+SIDE_CUMASK = ['']               # default CU mask of the weight-gradient stream ('' = none); see _side_stream
 HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switch: backward chain on a high-priority stream
+EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B switch: BN statistics from the conv epilogue
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
 FLUSH_EVERY = int(_os.environ.get('AIDE_WGRAD_FLUSH_EVERY', '6'))      # layers per batched slab reduce
 
@@ -118,6 +120,24 @@ def use_winograd(n, cin, h, w, cout):
     (tools/bench_conv.py all) has Winograd ahead on every layer shape it supports (1.2x-1.9x; the one
     exception, 64->128 @64x64 forward, loses 4 us), so it is used wherever it is supported."""
     return bool(USE_WINOGRAD[0] and lib.aide_conv3x3_wino_supported(cin, h, w, cout))
+
+
+def _side_stream(dev):
+    """Stream of the weight-gradient kernels.  AIDE_SIDE_CUMASK=<k>/<m> restricts it to k of every m compute units
+    (bit pattern repeated over the 256 CUs), e.g. 1/2 = every other CU."""
+    spec = _os.environ.get('AIDE_SIDE_CUMASK', SIDE_CUMASK[0])
+    if not spec:
+        return torch.cuda.Stream(device=dev)
+    import ctypes
+    k, m = [int(v) for v in spec.split('/')]
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    words = (ncu + 31) // 32
+    bits = [1 if (i % m) < k else 0 for i in range(words * 32)]
+    arr = (ctypes.c_uint32 * words)(*[sum(b << j for j, b in enumerate(bits[w * 32:(w + 1) * 32])) for w in range(words)])
+    out = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        _check(lib.aide_stream_create_cumask(ctypes.byref(out), arr, words), 'stream_create_cumask')
+    return torch.cuda.ExternalStream(out.value, device=dev)
 
 
 class _Cover(object):
@@ -240,6 +260,12 @@ class Plan(object):
                         st['wino_w'] = 0
                         st['wg_bytes'] = lib.aide_conv3x3_wgrad_ws_bytes(n, cout, cin, hh, ww)
                     max_wg = max(max_wg, st['wg_bytes'])
+                    # BatchNorm statistics from the conv epilogue (big planes, non-split F(4x4) forward, ungrouped training)
+                    st['stats'] = None
+                    if training and groups == 1 and EPILOGUE_STATS[0] and st['wino_f'] == 4 and (st['plan_f'] >> 8) <= 1 \
+                            and (hh * ww) % 4 == 0 and lib.aide_bn_two_pass(n, cout, hh, ww):
+                        st['stats_parts'] = lib.aide_conv3x3_wino4_stats_parts(n, hh, ww)
+                        st['stats'] = torch.empty(cout * st['stats_parts'] * 2, **f32)
                     st['pack_key'] = None
                     st['flops'] = 2.0 * n * hh * ww * cout * cin * 9      # algorithmic, per launch
                     # bf16 mode keeps the conv output z (read only by BatchNorm) and its gradient dz (read only by the
@@ -349,7 +375,7 @@ class Plan(object):
             big = max(st['t1'].numel() for st in sa)
             self.sa_da, self.sa_db = torch.empty(big, **f32), torch.empty(big, **f32)
             self.sa_ws = torch.empty(max(st['gate'].numel() for st in sa) * 2 + 8, **f32)
-        self.side = torch.cuda.Stream(device=self.dev)
+        self.side = _side_stream(self.dev)
         cover = {id(t): _Cover() for t in self.g.roots}
         for st in reversed(self.steps):
             src = st['src']
@@ -475,6 +501,8 @@ class Plan(object):
                 if st['wino_f'] == BF16:
                     ops.conv3x3_bf16(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=self.sk_ws)
                 elif st['wino_f'] == 4:
+                    if st['stats'] is not None:
+                        lib.aide_conv_stats_sink(ops.ptr(st['stats']))
                     ops.conv3x3_wino4(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=self.sk_ws)
                 elif st['wino_f']:
                     ops.conv3x3_wino(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=self.sk_ws)
@@ -526,7 +554,11 @@ class Plan(object):
             per_img = stride // self.N
             for gi in range(ngroups):
                 zg, ag = (z, a) if ngroups == 1 else (z[gi * m:(gi + 1) * m], a[gi * m:(gi + 1) * m])
-                if splitk > 0:
+                if st.get('stats') is not None:
+                    ops.bn_train_fwd_parts(zg, ag, st['stats'], st['stats_parts'], st['conv'].bias, bn.weight, bn.bias, bn.eps,
+                                           bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                           st['mean'], st['rstd'], st['scale'], st['shift'], True)
+                elif splitk > 0:
                     import ctypes
                     sl = ctypes.c_void_p(self.sk_ws.data_ptr() + 4 * gi * m * per_img)
                     ops.bn_train_fwd_slabs(sl, splitk, stride, slab_bias, zg, ag, bn.weight, bn.bias, bn.eps, bn.momentum,

@@ -158,6 +158,20 @@ int aide_bn_train_fwd_slabs(const float* slabs, int splitk, int64_t split_stride
                             const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                             float* running_var, long long* num_batches_tracked, float* mean, float* rstd, float* scale,
                             float* shift, int relu, void* ws, aide_stream_t stream);
+/* BatchNorm statistics from the convolution's epilogue.  aide_conv_stats_sink(parts) arms a one-shot sink: the NEXT
+ * forward conv launch of a family that supports it (non-split, accumulate = 0; today: aide_conv3x3_wino4) writes, per output
+ * channel and workgroup tile, the fp32 sum and sum of squares of its pre-bias outputs to parts[Cout][nparts][2]
+ * (nparts = aide_conv3x3_wino4_stats_parts) and disarms it; aide_bn_train_fwd_parts then normalises with ONE pass over z
+ * (replaces the statistics pass of nn.BatchNorm2d in train mode, netblocks.py:25,27).  aide_bn_two_pass tells whether the
+ * plain aide_bn_train_fwd would need two launches for this shape. */
+int aide_conv_stats_sink(float* parts);
+int aide_conv3x3_wino4_stats_parts(int N, int H, int W);
+int aide_bn_two_pass(int N, int C, int H, int W);
+int aide_bn_train_fwd_parts(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C, int H,
+                            int W, const float* parts, int nparts, const float* conv_bias, const float* gamma,
+                            const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                            long long* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift,
+                            int relu, aide_stream_t stream);
 int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
                              int H, int W, const float* scale, const float* shift, int relu, aide_stream_t stream);
 int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz,
@@ -191,6 +205,12 @@ int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int6
 int aide_reverse_aug(const float* x, int64_t x_bs, float* y, int64_t y_bs, const double* par, int N, int C,
                      int H, int W, aide_stream_t stream);
 int aide_fill_zero(float* p, int64_t bs, int N, int C, int H, int W, aide_stream_t stream);
+
+/* ---- CU-masked stream (host pointers) ---------------------------------------------------------------------------
+ * A HIP stream restricted to the compute units whose bits are set in mask[words] (hipExtStreamCreateWithCUMask).  The
+ * backward pass runs its weight-gradient kernels on one: the dependent chain on the main stream then always finds free
+ * CUs, whatever the grid of the weight-gradient launch. */
+int aide_stream_create_cumask(void** stream, const void* mask, int words);
 
 /* ---- deferred slab reduce of the weight gradients ------------------------------------------------------------------
  * Every aide_conv3x3_wgrad* call leaves per-split partial results ("slabs") in its workspace and reduces them into dw
