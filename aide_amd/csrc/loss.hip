@@ -457,3 +457,164 @@ int aide_pseudo_label(const float* const* logits, int K, int64_t l_bs, int N, in
 }
 
 }  // extern "C"
+
+// ---- branches of the reference's loss modules that no shipped script reaches (utils/loss2d.py:11-12 one-hot targets ->
+// arg-max, :44-61 DiceLoss on PROBABILITY input, :98-104 MulticlassDiceLoss with one-hot targets and class weights).
+// Plain streaming kernels, fp64 fixed-order reductions (bit-reproducible), one launch per pass.
+namespace {
+
+// idx[n][p] = first arg-max over C channels of t[n][c][p]   (torch.argmax(targets.float(), dim=1))
+__global__ __launch_bounds__(256) void onehot_argmax_kernel(const float* __restrict__ t, long t_bs, int C, int HW,
+                                                            long long* __restrict__ idx, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / HW, p = i - n * HW;
+        const float* tp = t + n * t_bs + p;
+        float best = tp[0];
+        int bi = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = tp[(long)c * HW];
+            if (v > best) { best = v; bi = c; }
+        }
+        idx[i] = bi;
+    }
+}
+
+// terms per image: K = 1 (probability input p [N][HW], target t [N][HW]) or K = 2 (logits [N][2][HW], p0 = 1 - p1,
+// one-hot target [N][2][HW]).  partials[n][b][k][3] = { sum p_k t_k, sum p_k, sum t_k }
+template <int K>
+__global__ __launch_bounds__(256) void dice_terms_stats_kernel(const float* __restrict__ x, long x_bs,
+                                                               const float* __restrict__ t, long t_bs, int HW, int bpi,
+                                                               double* __restrict__ partials) {
+    __shared__ double sm[3 * K * 4];
+    const int n = blockIdx.y, b = blockIdx.x;
+    const float* xn = x + (long)n * x_bs;
+    const float* tn = t + (long)n * t_bs;
+    double acc[3 * K];
+#pragma unroll
+    for (int k = 0; k < 3 * K; ++k) acc[k] = 0.0;
+    for (int i = b * 256 + threadIdx.x; i < HW; i += bpi * 256) {
+        if (K == 1) {
+            const float p = xn[i], tv = tn[i];
+            acc[0] += (double)(p * tv); acc[1] += (double)p; acc[2] += (double)tv;
+        } else {
+            const float d = xn[HW + i] - xn[i];
+            const float p1 = 1.0f / (1.0f + __expf(-d)), p0 = 1.0f - p1;
+            const float t0 = tn[i], t1 = tn[HW + i];
+            acc[0] += (double)(p0 * t0); acc[1] += (double)p0; acc[2] += (double)t0;
+            acc[3] += (double)(p1 * t1); acc[4] += (double)p1; acc[5] += (double)t1;
+        }
+    }
+    block_sum_d<3 * K>(acc, sm);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 3 * K; ++k) partials[((long)n * bpi + b) * 3 * K + k] = acc[k];
+}
+
+// stats[n][k][3] from the partials; per_image[n] = sum_k w_k (1 - (2 I + s) / (P + T + s)); out by reduction (0 mean / N,
+// 1 sum, 2 none)
+__global__ void dice_terms_finalize_kernel(const double* __restrict__ partials, int N, int bpi, int K, float w0, float w1,
+                                           float smooth, int reduction, double* __restrict__ stats,
+                                           float* __restrict__ per_image, float* __restrict__ out) {
+    for (int e = threadIdx.x; e < N * 3 * K; e += blockDim.x) {
+        const int n = e / (3 * K), k = e - n * 3 * K;
+        double v = 0.0;
+        for (int b = 0; b < bpi; ++b) v += partials[((long)n * bpi + b) * 3 * K + k];
+        stats[e] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double total = 0.0;
+        for (int n = 0; n < N; ++n) {
+            float li = 0.f;
+            for (int k = 0; k < K; ++k) {
+                const double* S = stats + ((long)n * K + k) * 3;
+                // fp32 like the reference's per-image expression on fp32 sums
+                const float I = (float)S[0], P = (float)S[1], T = (float)S[2];
+                const float d = 1.0f - (2.0f * I + smooth) / (P + T + smooth);
+                li += (k == 0 ? w0 : w1) * d;
+            }
+            per_image[n] = li;
+            total += (double)li;
+            if (reduction == 2) out[n] = li;
+        }
+        if (reduction == 0) out[0] = (float)(total / N);
+        else if (reduction == 1) out[0] = (float)total;
+    }
+}
+
+// gradient wrt the input: probability (K = 1) or the two logit planes (K = 2).  g: [1] (mean / sum) or [N] (none)
+template <int K>
+__global__ __launch_bounds__(256) void dice_terms_bwd_kernel(const float* __restrict__ x, long x_bs,
+                                                             const float* __restrict__ t, long t_bs, int HW, int N,
+                                                             const double* __restrict__ stats, float w0, float w1,
+                                                             float smooth, int reduction, const float* __restrict__ g,
+                                                             float* __restrict__ dx, long dx_bs) {
+    const int n = blockIdx.y;
+    const float gi = reduction == 2 ? g[n] : (reduction == 0 ? g[0] / (float)N : g[0]);
+    float c2[K], c1[K];                         // d loss_k / d p_k = -w (2 t D - Nn) / D^2 = c1 - c2 t
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double* S = stats + ((long)n * K + k) * 3;
+        const float D = (float)S[1] + (float)S[2] + smooth, Nn = 2.0f * (float)S[0] + smooth;
+        const float w = (k == 0 ? w0 : w1) * gi;
+        c2[k] = w * 2.0f / D;
+        c1[k] = w * Nn / (D * D);
+    }
+    const float* xn = x + (long)n * x_bs;
+    const float* tn = t + (long)n * t_bs;
+    float* dn = dx + (long)n * dx_bs;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        if (K == 1) {
+            dn[i] = c1[0] - c2[0] * tn[i];
+        } else {
+            const float d = xn[HW + i] - xn[i];
+            const float p1 = 1.0f / (1.0f + __expf(-d)), p0 = 1.0f - p1;
+            const float g0 = c1[0] - c2[0] * tn[i], g1 = c1[1] - c2[1] * tn[HW + i];
+            const float dz1 = (g1 - g0) * p1 * p0;          // d p1 / d z1 = p1 p0 = -d p0 / d z1
+            dn[HW + i] = dz1;
+            dn[i] = -dz1;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int aide_onehot_argmax(const float* t, int64_t t_bs, int N, int C, int HW, long long* idx, hipStream_t stream) {
+    if (!t || !idx || N <= 0 || C <= 0 || HW <= 0) return AIDE_ERR_ARG;
+    const long total = (long)N * HW;
+    hipLaunchKernelGGL(onehot_argmax_kernel, dim3((unsigned)min((total + 255) / 256, 8192L)), dim3(256), 0, stream, t,
+                       (long)t_bs, C, HW, idx, total);
+    return aide_launch_status();
+}
+
+size_t aide_dice_terms_ws_bytes(int N, int HW) { return ((size_t)N * bpi_for(HW) * 6 + (size_t)N * 6) * sizeof(double); }
+
+// K = 1: x = probabilities [N][HW] (batch stride x_bs), t [N][HW];  K = 2: x = logits [N][2][HW], t = one-hot [N][2][HW].
+// ws: aide_dice_terms_ws_bytes; its tail (N * 3 K doubles at ws + N * bpi * 3 K) holds the per-image sums the backward needs.
+int aide_dice_terms_fwd(const float* x, int64_t x_bs, const float* t, int64_t t_bs, int N, int HW, int K, float w0,
+                        float w1, float smooth, int reduction, double* ws, float* per_image, float* out,
+                        hipStream_t stream) {
+    if (!x || !t || !ws || !per_image || !out || N <= 0 || HW <= 0 || (K != 1 && K != 2) || reduction < 0 || reduction > 2)
+        return AIDE_ERR_ARG;
+    const int bpi = bpi_for(HW);
+    double* stats = ws + (size_t)N * bpi * 3 * K;
+    if (K == 1) hipLaunchKernelGGL(dice_terms_stats_kernel<1>, dim3(bpi, N), dim3(256), 0, stream, x, (long)x_bs, t, (long)t_bs, HW, bpi, ws);
+    else hipLaunchKernelGGL(dice_terms_stats_kernel<2>, dim3(bpi, N), dim3(256), 0, stream, x, (long)x_bs, t, (long)t_bs, HW, bpi, ws);
+    hipLaunchKernelGGL(dice_terms_finalize_kernel, dim3(1), dim3(256), 0, stream, (const double*)ws, N, bpi, K, w0, w1,
+                       smooth, reduction, stats, per_image, out);
+    return aide_launch_status();
+}
+
+int aide_dice_terms_bwd(const float* x, int64_t x_bs, const float* t, int64_t t_bs, int N, int HW, int K, float w0,
+                        float w1, float smooth, int reduction, const double* ws, const float* g, float* dx,
+                        int64_t dx_bs, hipStream_t stream) {
+    if (!x || !t || !ws || !g || !dx || (K != 1 && K != 2)) return AIDE_ERR_ARG;
+    const int bpi = bpi_for(HW);
+    const double* stats = ws + (size_t)N * bpi * 3 * K;
+    if (K == 1) hipLaunchKernelGGL(dice_terms_bwd_kernel<1>, dim3(bpi * 4, N), dim3(256), 0, stream, x, (long)x_bs, t, (long)t_bs, HW, N, stats, w0, w1, smooth, reduction, g, dx, (long)dx_bs);
+    else hipLaunchKernelGGL(dice_terms_bwd_kernel<2>, dim3(bpi * 4, N), dim3(256), 0, stream, x, (long)x_bs, t, (long)t_bs, HW, N, stats, w0, w1, smooth, reduction, g, dx, (long)dx_bs);
+    return aide_launch_status();
+}
+
+}  // extern "C"

@@ -27,8 +27,13 @@ def _logits(x):
 def _targets(t, logits):
     """int64 index targets [N,H,W]; a non-contiguous batch stride (the reference's mask[:,1] view,
     SURVEY.md §A.3 item 10) is consumed in place."""
+    if t.device != logits.device:
+        raise RuntimeError('aide_amd: targets on %s but logits on %s' % (t.device, logits.device))
     if t.dim() > 3:          # one-hot -> arg-max first (utils/loss2d.py:11-12); not on the hot path
-        t = torch.argmax(t.float(), dim=1)
+        oh = t.float().contiguous()
+        n_, c_, h_, w_ = oh.shape
+        t = torch.empty(n_, h_, w_, device=oh.device, dtype=torch.int64)
+        check(lib.aide_onehot_argmax(ptr(oh), c_ * h_ * w_, n_, c_, h_ * w_, ptr(t), stream_ptr()), 'onehot_argmax')
     if t.dtype != torch.int64:
         raise RuntimeError('aide_amd: targets must be int64 class indices')
     if t.device != logits.device:

@@ -60,6 +60,42 @@ class _MSEMap(torch.autograd.Function):
         return dl, None
 
 
+class _DiceTerms(torch.autograd.Function):
+    """K = 1: DiceLoss on a probability input [N,H,W] (utils/loss2d.py:47-61); K = 2: MulticlassDiceLoss with one-hot
+    targets [N,2,H,W] and class weights on logits [N,2,H,W] (utils/loss2d.py:96-104)."""
+
+    @staticmethod
+    def forward(ctx, x, t, k, w0, w1, smooth, red):
+        n = x.shape[0]
+        hw = x.shape[-1] * x.shape[-2]
+        ws = torch.empty(lib.aide_dice_terms_ws_bytes(n, hw) // 8, device=x.device, dtype=torch.float64)
+        per = torch.empty(n, device=x.device, dtype=torch.float32)
+        out = torch.empty(n if red == 2 else 1, device=x.device, dtype=torch.float32)
+        check(lib.aide_dice_terms_fwd(ptr(x), k * hw, ptr(t), k * hw, n, hw, k, w0, w1, smooth, red, ptr(ws), ptr(per),
+                                      ptr(out), stream_ptr()), 'dice_terms_fwd')
+        ctx.save_for_backward(x, t, ws)
+        ctx.cfg = (k, w0, w1, smooth, red, hw)
+        return out if red == 2 else out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t, ws = ctx.saved_tensors
+        k, w0, w1, smooth, red, hw = ctx.cfg
+        g = g.contiguous().float().reshape(-1)
+        dx = torch.empty_like(x)
+        check(lib.aide_dice_terms_bwd(ptr(x), k * hw, ptr(t), k * hw, x.shape[0], hw, k, w0, w1, smooth, red, ptr(ws),
+                                      ptr(g), ptr(dx), k * hw, stream_ptr()), 'dice_terms_bwd')
+        return dx, None, None, None, None, None, None
+
+
+def _dense_f32(t, shape, what):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('aide_amd losses run on a HIP device only; there is no CPU fallback')
+    if tuple(t.shape) != tuple(shape):
+        raise RuntimeError('aide_amd: %s shape %s, expected %s' % (what, tuple(t.shape), tuple(shape)))
+    return t.float().contiguous()          # the reference's `.float()` (loss2d.py:50)
+
+
 class CrossEntropyLoss2d(nn.Module):
     def __init__(self, weight=None, reduction='mean', ignore_index=255):
         super(CrossEntropyLoss2d, self).__init__()
@@ -82,11 +118,12 @@ class DiceLoss(nn.Module):
         self.weight, self.smooth, self.reduction = weight, smooth, reduction
 
     def forward(self, input, target):
-        if input.dim() <= 3:
-            raise NotImplementedError('aide_amd.DiceLoss takes logits [N,2,H,W] (utils/loss2d.py:44-46); the '
-                                      'probability-input branch is only used inside MulticlassDiceLoss, '
-                                      'which is fused here')
         red = 2 if self.reduction == 'none' else _RED[self.reduction]
+        if input.dim() <= 3:                # utils/loss2d.py:47-48: a probability map, no softmax
+            if input.dtype != torch.float32 or not input.is_cuda:
+                raise RuntimeError('aide_amd.DiceLoss: probability input must be an fp32 tensor on a HIP device')
+            x = input.contiguous()
+            return _DiceTerms.apply(x, _dense_f32(target, x.shape, 'DiceLoss target'), 1, 1.0, 1.0, float(self.smooth), red)
         loss, self.last = _seg.seg_loss(input, target, 1.0, 1.0, 255, red, 0.0, 1.0 if red else 1.0,
                                         float(self.smooth))
         return loss
@@ -111,10 +148,12 @@ class MulticlassDiceLoss(nn.Module):
         self.weight, self.smooth, self.reduction = weight, smooth, reduction
 
     def forward(self, input, target):
-        if target.dim() > 3:
-            raise NotImplementedError('aide_amd.MulticlassDiceLoss: one-hot targets (utils/loss2d.py:98-104) '
-                                      'are not on the hot path; pass int64 index targets')
         red = 2 if self.reduction == 'none' else _RED[self.reduction]
+        if target.dim() > 3:                # utils/loss2d.py:98-104: one Dice term per class, weighted
+            logits = _seg._logits(input)
+            w0, w1 = _seg.class_weights(self.weight)
+            return _DiceTerms.apply(logits, _dense_f32(target, logits.shape, 'MulticlassDiceLoss one-hot target'), 2,
+                                    w0, w1, float(self.smooth), red)
         # index targets: class-1 Dice only, class weights ignored (utils/loss2d.py:105-106)
         loss, self.last = _seg.seg_loss(input, target, 1.0, 1.0, 255, red, 0.0, 1.0, float(self.smooth))
         return loss

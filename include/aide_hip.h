@@ -206,6 +206,21 @@ int aide_reverse_aug(const float* x, int64_t x_bs, float* y, int64_t y_bs, const
                      int H, int W, aide_stream_t stream);
 int aide_fill_zero(float* p, int64_t bs, int N, int C, int H, int W, aide_stream_t stream);
 
+/* ---- loss-module branches off the hot path ----------------------------------------------------------------------
+ * aide_onehot_argmax: targets given one-hot [N][C][HW] -> int64 class indices (utils/loss2d.py:11-12).
+ * aide_dice_terms_{fwd,bwd}: per image sum_k w_k (1 - (2 sum p_k t_k + s) / (sum p_k + sum t_k + s)), reduction 0 mean
+ * (/N), 1 sum, 2 none.  K = 1: DiceLoss on a PROBABILITY input x [N][HW] (loss2d.py:47-61); K = 2: MulticlassDiceLoss with
+ * one-hot targets t [N][2][HW] and class weights (w0, w1) on logits x [N][2][HW] (loss2d.py:96-104; softmax inside).
+ * ws: aide_dice_terms_ws_bytes (kept by the caller between fwd and bwd).  g: [1] or [N] upstream gradient. */
+int aide_onehot_argmax(const float* t, int64_t t_bs, int N, int C, int HW, long long* idx, aide_stream_t stream);
+size_t aide_dice_terms_ws_bytes(int N, int HW);
+int aide_dice_terms_fwd(const float* x, int64_t x_bs, const float* t, int64_t t_bs, int N, int HW, int K, float w0,
+                        float w1, float smooth, int reduction, double* ws, float* per_image, float* out,
+                        aide_stream_t stream);
+int aide_dice_terms_bwd(const float* x, int64_t x_bs, const float* t, int64_t t_bs, int N, int HW, int K, float w0,
+                        float w1, float smooth, int reduction, const double* ws, const float* g, float* dx,
+                        int64_t dx_bs, aide_stream_t stream);
+
 /* ---- CU-masked stream (host pointers) ---------------------------------------------------------------------------
  * A HIP stream restricted to the compute units whose bits are set in mask[words] (hipExtStreamCreateWithCUMask).  The
  * backward pass runs its weight-gradient kernels on one: the dependent chain on the main stream then always finds free

@@ -687,6 +687,31 @@ def g12_metrics(ref_utils):
         _same(vals['ref'][1], vals['ora'][1], lname + ' grad')
         key = '%s/%s' % (lname, '_'.join('%s=%s' % (k, 'w' if torch.is_tensor(v) else v) for k, v in sorted(kw.items())))
         fx[key], fx[key + '/grad'] = _np(vals['ref'][0]), _np(vals['ref'][1])
+    # branches no shipped script reaches: one-hot targets in CrossEntropyLoss2d (loss2d.py:11-12) and MulticlassDiceLoss
+    # (:98-104, class weights), DiceLoss on a probability input (:47-48)
+    onehot = torch.nn.functional.one_hot(t, 2).permute(0, 3, 1, 2).float().contiguous()
+    prob = torch.rand(n, s, s, generator=g)
+    fx['onehot'], fx['prob'] = _np(onehot), _np(prob)
+    mw = torch.tensor([0.3, 1.7])
+    cases = [('CrossEntropyLoss2d', dict(weight=cw), 'z', 'onehot'), ('CrossEntropyLoss2d', dict(reduction='sum'), 'z', 'onehot'),
+             ('MulticlassDiceLoss', dict(weight=mw), 'z', 'onehot'), ('MulticlassDiceLoss', dict(reduction='none'), 'z', 'onehot'),
+             ('MulticlassDiceLoss', dict(weight=mw, smooth=0.5, reduction='sum'), 'z', 'onehot'),
+             ('DiceLoss', dict(), 'prob', 't'), ('DiceLoss', dict(smooth=0.25, reduction='none'), 'prob', 't'),
+             ('DiceLoss', dict(reduction='sum'), 'prob', 'onehot1')]
+    srcs = dict(z=z, prob=prob)
+    tgts = dict(onehot=onehot, t=t, onehot1=onehot[:, 1].contiguous())
+    for lname, kw, xin, tin in cases:
+        vals = {}
+        for key, mod in (('ref', ref_utils), ('ora', oracle)):
+            xx = srcs[xin].clone().requires_grad_(True)
+            v = getattr(mod, lname)(**kw)(xx, tgts[tin])
+            # weighted upstream gradient so that the per-image ('none') backward is exercised with distinct factors
+            (v * torch.arange(1, v.numel() + 1).float()).sum().backward() if v.dim() else v.backward()
+            vals[key] = (v.detach(), xx.grad.clone())
+        _same(vals['ref'][0], vals['ora'][0], 'branch ' + lname)
+        _same(vals['ref'][1], vals['ora'][1], 'branch grad ' + lname)
+        key = 'branch/%s/%s/%s' % (lname, tin, '_'.join('%s=%s' % (k, 'w' if torch.is_tensor(v) else v) for k, v in sorted(kw.items())))
+        fx[key], fx[key + '/grad'] = _np(vals['ref'][0]), _np(vals['ref'][1])
     np.savez_compressed(os.path.join(OUT, 'g12_metrics.npz'), **fx)
     print('g12', [k for k in fx if '/' in k and not k.endswith('grad')])
 

@@ -319,3 +319,35 @@ def test_golden_metrics_and_remaining_losses(dev):
         (v.sum() if v.dim() else v).backward()
         close(v, fx[key], what=key)
         close(zz.grad, fx[key + '/grad'], what=key + ' grad')
+
+
+G12_BRANCHES = [('CrossEntropyLoss2d', dict(weight=[1.0, 3.0]), 'z', 'onehot', 'weight=w'),
+                ('CrossEntropyLoss2d', dict(reduction='sum'), 'z', 'onehot', 'reduction=sum'),
+                ('MulticlassDiceLoss', dict(weight=[0.3, 1.7]), 'z', 'onehot', 'weight=w'),
+                ('MulticlassDiceLoss', dict(reduction='none'), 'z', 'onehot', 'reduction=none'),
+                ('MulticlassDiceLoss', dict(weight=[0.3, 1.7], smooth=0.5, reduction='sum'), 'z', 'onehot',
+                 'reduction=sum_smooth=0.5_weight=w'),
+                ('DiceLoss', dict(), 'prob', 't', ''), ('DiceLoss', dict(smooth=0.25, reduction='none'), 'prob', 't',
+                                                       'reduction=none_smooth=0.25'),
+                ('DiceLoss', dict(reduction='sum'), 'prob', 'onehot1', 'reduction=sum')]
+
+
+def test_loss_branches_off_the_hot_path(dev):
+    """One-hot targets in CrossEntropyLoss2d (utils/loss2d.py:11-12) and MulticlassDiceLoss with class weights (:98-104),
+    DiceLoss on a probability input (:47-48): values and input gradients of the reference (g12_metrics.npz 'branch/...')."""
+    from aide_amd import utils as U
+    fx = np.load(os.path.join(GOLD, 'g12_metrics.npz'))
+    src = dict(z=torch.from_numpy(fx['z']).to(dev), prob=torch.from_numpy(fx['prob']).to(dev))
+    onehot = torch.from_numpy(fx['onehot']).to(dev)
+    tgt = dict(onehot=onehot, t=torch.from_numpy(fx['targets']).to(dev), onehot1=onehot[:, 1].contiguous())
+    for lname, kw, xin, tin, tag in G12_BRANCHES:
+        kw = {k: torch.tensor(v) if isinstance(v, list) else v for k, v in kw.items()}
+        x = src[xin].clone().requires_grad_(True)
+        v = getattr(U, lname)(**kw)(x, tgt[tin])
+        if v.dim():
+            (v * torch.arange(1, v.numel() + 1, device=dev).float()).sum().backward()
+        else:
+            v.backward()
+        key = 'branch/%s/%s/%s' % (lname, tin, tag)
+        close(v, fx[key], what=key)
+        close(x.grad, fx[key + '/grad'], what=key + ' grad')
