@@ -40,9 +40,46 @@ def parse_header(path=HEADER):
     return protos
 
 
+TAPE = [None]          # the Tape that records the calls of the running forward / backward (aide_amd/tape.py), or None
+
+
+class _Fn(object):
+    """One entry point of the C ABI.  Calls go straight to ctypes; while a Tape is recording they are converted to
+    ctypes argument objects once and appended to it, so that later steps can re-issue the same launch sequence without
+    any of the Python-side marshalling (aide_amd/tape.py)."""
+    __slots__ = ('cfn', 'argtypes', 'name')
+
+    def __init__(self, cfn, argtypes, name):
+        self.cfn, self.argtypes, self.name = cfn, argtypes, name
+
+    def __call__(self, *args):
+        tape = TAPE[0]
+        if tape is None:
+            return self.cfn(*args)
+        cargs = []
+        for a, t in zip(args, self.argtypes):
+            if t is ctypes.c_void_p:
+                # pointers: int / None / c_void_p / byref()-style objects.  A fresh c_void_p per argument: the tape patches
+                # the addresses of per-call tensors in place
+                if a is None or isinstance(a, int):
+                    a = ctypes.c_void_p(a)
+                elif isinstance(a, ctypes.c_void_p):
+                    a = ctypes.c_void_p(a.value)
+                # anything else (arrays, byref): keep the object (and with it its referent) alive as is
+            elif not isinstance(a, t):
+                a = t(a)
+            cargs.append(a)
+        if len(cargs) != len(self.argtypes):
+            raise TypeError('%s: %d arguments, %d expected' % (self.name, len(cargs), len(self.argtypes)))
+        rc = self.cfn(*cargs)
+        tape.calls.append((self.cfn, cargs, rc, self.name))
+        return rc
+
+
 class _Lib(object):
     def __init__(self):
         self._dll = None
+        self._fns = {}
         self.protos = parse_header()
 
     def load(self):
@@ -65,7 +102,11 @@ class _Lib(object):
 
     def __getattr__(self, name):
         if name.startswith('aide_'):
-            return getattr(self.load(), name)
+            fn = self._fns.get(name)
+            if fn is None:
+                cfn = getattr(self.load(), name)
+                fn = self._fns[name] = _Fn(cfn, self.protos[name][1], name)
+            return fn
         raise AttributeError(name)
 
 

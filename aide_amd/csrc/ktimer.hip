@@ -88,4 +88,23 @@ int aide_stream_create_cumask(void** stream, const void* mask, int words) {
     return AIDE_OK;
 }
 
+
+// ---- stream ordering without torch objects (the engine's launch tapes re-issue these like any other call)
+int aide_event_create(void** ev) {
+    if (!ev) return AIDE_ERR_ARG;
+    hipEvent_t e;
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (rc != hipSuccess) return (int)rc;
+    *ev = (void*)e;
+    return AIDE_OK;
+}
+
+// everything enqueued on `to` after this call runs after everything enqueued on `from` before it
+int aide_stream_order(void* ev, hipStream_t from, hipStream_t to) {
+    if (!ev) return AIDE_ERR_ARG;
+    hipError_t rc = hipEventRecord((hipEvent_t)ev, from);
+    if (rc == hipSuccess) rc = hipStreamWaitEvent(to, (hipEvent_t)ev, 0);
+    return (int)rc;
+}
+
 }  // extern "C"

@@ -16,6 +16,7 @@ import torch
 
 from . import ops
 from ._lib import lib, check as _check
+from .tape import Tape
 
 # bumped by aide_amd.optim.Adam (which updates parameters through raw pointers, invisible to
 # tensor._version) so that cached packed filters are refreshed
@@ -95,6 +96,7 @@ STORE_G_BF16 = [True]          # ... and the gradients of those activations
 DEFER_WGRAD_REDUCE = [_os.environ.get('AIDE_DEFER_WGRAD_REDUCE', '1') != '0']     # A-B switch: batched slab reduce
 LATE_DGRAD_PACK = [_os.environ.get('AIDE_LATE_DGRAD_PACK', '0') != '0']   # A-B switch (measured: no effect, off)
 SIDE_CUMASK = ['']               # default CU mask of the weight-gradient stream ('' = none); see _side_stream
+REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch tapes (aide_amd/tape.py); A-B switch
 HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switch: backward chain on a high-priority stream
 EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B switch: BN statistics from the conv epilogue
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
@@ -327,6 +329,9 @@ class Plan(object):
         self.profiler = None             # set by Engine (bench.py's per-kernel HIP-event timing)
         self._pack_key, self._pack_tab, self.side_fwd = None, None, None
         self._late_pending, self._late_inflight = None, False
+        self._gate_conv = None           # the first conv that needs the side-stream filter packs
+        self._tape_f = self._tape_b = None
+        self._fp = None
         self.overlap = True              # weight gradients on a side stream (see backward)
         self.trace = None                # tools/phase_trace.py: callable(direction, step) before every op
         self.hp = None                   # high-priority stream of the backward chain (HP_CHAIN)
@@ -376,6 +381,10 @@ class Plan(object):
             self.sa_da, self.sa_db = torch.empty(big, **f32), torch.empty(big, **f32)
             self.sa_ws = torch.empty(max(st['gate'].numel() for st in sa) * 2 + 8, **f32)
         self.side = _side_stream(self.dev)
+        self.ev_fork, self.ev_join = ops.new_event(), ops.new_event()
+        for st in self.steps:
+            if st['kind'] in ('conv', 'convT'):
+                st['ev'] = ops.new_event()     # main -> side fork of this layer's weight gradient
         cover = {id(t): _Cover() for t in self.g.roots}
         for st in reversed(self.steps):
             src = st['src']
@@ -435,6 +444,7 @@ class Plan(object):
                               tables(rest, False, True) if late else None,
                               (ups[0] if ups else self.steps[-1]) if late else None)
         _, first, rest, gate, late_tab, late_gate = self._pack_tab
+        self._gate_conv = gate
 
         def launch(tabs):
             d, wn, w4, b16 = tabs
@@ -475,10 +485,45 @@ class Plan(object):
                 self._launch_pack(tab)
             self._late_inflight = True
 
+    def _fingerprint(self):
+        """addresses of every parameter and buffer the launch sequence bakes in (a tape is only valid for these)"""
+        fp = []
+        for st in self.steps:
+            for key in ('conv', 'bn'):
+                m = st.get(key)
+                if m is not None:
+                    fp += [t.data_ptr() for t in m.parameters(recurse=False)]
+                    fp += [t.data_ptr() for t in m.buffers(recurse=False)]
+            m = st.get('mod')
+            if m is not None:
+                fp += [t.data_ptr() for t in m.parameters()] + [t.data_ptr() for t in m.buffers()]
+        return tuple(fp)
+
+    def _tapeable(self):
+        return REPLAY[0] and self.profiler is None and self.trace is None and not LATE_DGRAD_PACK[0] and not HP_CHAIN[0] \
+            and not PROBE_SKIP_WGRAD[0]
+
     def forward(self, inputs, out):
-        n = self.N
         self.serial += 1                 # the saved activations of this plan now belong to THIS forward (any kind)
         gate = self._pack_filters()
+        if not self._tapeable():
+            self._tape_f = self._tape_b = None
+            return self._forward_impl(inputs, out, gate, None)
+        self._fp = self._fingerprint()
+        dyn = list(inputs) + [out]
+        key = (torch.cuda.current_stream().cuda_stream, self._fp, tuple((tuple(t.shape), t.stride()) for t in dyn))
+        tp = self._tape_f
+        if tp is not None and tp.key == key:
+            tp.replay(dyn, skip_tags=() if gate is not None else ('gate',))
+            return out
+        tp = Tape(key)
+        with tp:
+            self._forward_impl(inputs, out, gate, tp)
+        self._tape_f = tp.finish(dyn)
+        return out
+
+    def _forward_impl(self, inputs, out, gate, tape):
+        n = self.N
         for st in self.steps:
             kind = st['kind']
             if self.trace is not None:
@@ -487,8 +532,12 @@ class Plan(object):
                 self._late_pack(st)
             if kind == 'conv':
                 conv, bn = st['conv'], st['bn']
-                if st is gate:                 # the remaining filters were re-packed on the side stream
-                    torch.cuda.current_stream().wait_stream(self.side_fwd)
+                if st is self._gate_conv:      # (when) the remaining filters were re-packed on the side stream
+                    wait = lambda: torch.cuda.current_stream().wait_stream(self.side_fwd)
+                    if tape is not None:
+                        tape.py(wait, 'gate')
+                    if gate is not None:
+                        wait()
                 x = self.view(st['src'], inputs)
                 prof = self.profiler
                 if prof is not None:
@@ -593,6 +642,26 @@ class Plan(object):
         # (with a profiler attached the step runs on ONE stream: an event pair then brackets exactly one kernel's own time,
         # not its time under contention with the side stream -- bench.py instruments a single step for that reason)
         side = self.side if (self.overlap and self.profiler is None) else None
+        if self._tapeable() and self._fp is not None and self._tape_f is not None:
+            # re-issue the recorded launch sequence (aide_amd/tape.py); Python callbacks of a gradient all-reduce hook are
+            # tape entries.  Keyed on everything the sequence bakes in.
+            dyn = list(inputs) + [dlogits, flat]
+            key = (main.cuda_stream, side.cuda_stream if side is not None else 0, self._fp, after_op,
+                   tuple((tuple(t.shape), t.stride()) for t in dyn))
+            tp = self._tape_b
+            if tp is not None and tp.key == key:
+                tp.replay(dyn)
+                return
+            tp = Tape(key)
+            cb = None
+            if after_op is not None:
+                def cb(w_st):
+                    tp.py(lambda: after_op(w_st))
+                    after_op(w_st)
+            with tp:
+                self._backward_streams(inputs, dlogits, gslot, main, side, cb)
+            self._tape_b = tp.finish(dyn)
+            return
         if side is not None and HP_CHAIN[0]:
             # the dependent chain on a HIGH-priority stream: when both streams have workgroups ready the dispatcher serves
             # the chain first and the weight gradients soak up what is left
@@ -611,20 +680,23 @@ class Plan(object):
         if self._late_inflight:              # the dgrad-direction filter packs launched under the decoder forward
             main.wait_stream(self.side_fwd)
             self._late_inflight = False
+        # raw stream handles: every fork / join below is a C-ABI call (ops.order) and every side-stream launch takes the
+        # stream explicitly (ops.use_stream) -- nothing here depends on torch's stream context, so the whole sequence can be
+        # recorded and re-issued by a launch tape
+        import ctypes
+        mp = ctypes.c_void_p(main.cuda_stream)
+        sp = ctypes.c_void_p(side.cuda_stream) if side is not None else None
         if side is not None:
-            side.wait_stream(main)
+            ops.order(self.ev_fork, mp, sp)
         # The slab reduces of the weight gradients run batched, one launch per FLUSH_EVERY layers: fewer latency-bound
         # launches on the weight-gradient stream, and only the last (small, shallow-encoder) batch sits after the last kernel
-        defer = DEFER_WGRAD_REDUCE[0] and self.profiler is None
+        # (bf16 mode: its weight-gradient slabs are several times larger and the batched reduce measured 1 % slower -> per layer)
+        defer = DEFER_WGRAD_REDUCE[0] and self.profiler is None and self.precision != 'bf16'
         waiting = []                          # ops whose after_op callback waits for the flush of their weight gradient
 
         def flush():
             if lib.aide_wgrad_reduce_pending():
-                if side is not None:
-                    with torch.cuda.stream(side):
-                        ops.check(lib.aide_wgrad_reduce_flush(ops.stream_ptr()), 'wgrad_reduce_flush')
-                else:
-                    ops.check(lib.aide_wgrad_reduce_flush(ops.stream_ptr()), 'wgrad_reduce_flush')
+                ops.check(lib.aide_wgrad_reduce_flush(sp if side is not None else mp), 'wgrad_reduce_flush')
             if after_op is not None:
                 for w_st in waiting:          # their weight gradients are now enqueued in full
                     after_op(w_st)
@@ -639,14 +711,15 @@ class Plan(object):
         if defer:
             lib.aide_wgrad_reduce_defer(1)
         try:
-            self._backward_ops(inputs, dlogits, gslot, main, side, hook)
+            with ops.use_stream(mp):
+                self._backward_ops(inputs, dlogits, gslot, mp, sp, hook)
             if defer:
                 flush()
         finally:
             if defer:
                 lib.aide_wgrad_reduce_defer(0)
         if side is not None:
-            main.wait_stream(side)
+            ops.order(self.ev_join, sp, mp)
 
     def _backward_ops(self, inputs, dlogits, gslot, main, side, after_op):
         for st in reversed(self.steps):
@@ -664,7 +737,7 @@ class Plan(object):
                 if side is not None and sg is not None and HEAD_WGRAD_SIDE[0]:
                     # the head's weight gradient (one pass over the widest feature map) has no consumer until the
                     # optimizer: side stream, so that the dependent chain starts with the data gradient alone
-                    with torch.cuda.stream(side):
+                    with ops.use_stream(side):
                         ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1), None,
                                         gslot(conv.weight).view(k, -1), gslot(conv.bias), ws=self.head_ws)
                     ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1),
@@ -690,10 +763,8 @@ class Plan(object):
                                  ops.conv3x3_wgrad_wino4 if st['wino_w'] == 4 else
                                  ops.conv3x3_wgrad_wino if st['wino_w'] else ops.conv3x3_wgrad)
                     if side is not None:
-                        ev = torch.cuda.Event()
-                        ev.record(main)
-                        with torch.cuda.stream(side):
-                            side.wait_event(ev)
+                        ops.order(st['ev'], main, side)
+                        with ops.use_stream(side):
                             if prof is not None:
                                 prof.begin(WGRAD_TAG[st['wino_w']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_w']])
                             wgrad(dz, x, gslot(conv.weight), ws=st['wg_ws'])
@@ -724,10 +795,8 @@ class Plan(object):
                             prof.end()
                 else:
                     if side is not None:
-                        ev = torch.cuda.Event()
-                        ev.record(main)
-                        with torch.cuda.stream(side):      # shares the slab workspace with conv wgrad
-                            side.wait_event(ev)
+                        ops.order(st['ev'], main, side)
+                        with ops.use_stream(side):
                             ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=st['wg_ws'])
                     else:
                         ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=st['wg_ws'])

@@ -11,8 +11,40 @@ import torch
 from ._lib import lib, check
 
 
+_STREAM = [None]        # explicit launch stream (use_stream); None = torch's current stream
+
+
 def stream_ptr():
+    if _STREAM[0] is not None:
+        return _STREAM[0]
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class use_stream(object):
+    """Launch the enclosed ops on the given HIP stream (raw pointer) without switching torch's current stream."""
+
+    def __init__(self, sptr):
+        self.sptr = sptr if isinstance(sptr, ctypes.c_void_p) else ctypes.c_void_p(sptr)
+
+    def __enter__(self):
+        self.prev = _STREAM[0]
+        _STREAM[0] = self.sptr
+        return self
+
+    def __exit__(self, *a):
+        _STREAM[0] = self.prev
+        return False
+
+
+def new_event():
+    ev = ctypes.c_void_p()
+    check(lib.aide_event_create(ctypes.byref(ev)), 'event_create')
+    return ev
+
+
+def order(ev, src, dst):
+    """work enqueued on stream `dst` from now on waits for the work enqueued on `src` so far"""
+    check(lib.aide_stream_order(ev, src, dst), 'stream_order')
 
 
 def _req(t, dtype=torch.float32):

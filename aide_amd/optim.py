@@ -22,6 +22,7 @@ class Adam(torch.optim.Optimizer):
         super(Adam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                                 amsgrad=amsgrad))
         self._tables = {}
+        self._gtabs = {}
 
     def load_state_dict(self, state_dict):
         super(Adam, self).load_state_dict(state_dict)
@@ -86,8 +87,15 @@ class Adam(torch.optim.Optimizer):
                 if not g.is_contiguous():
                     g = g.contiguous()
                 grads.append(g)
-            gtab = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64).to(plist[0].device,
-                                                                                      non_blocking=True)
+            # the gradient pointer table only changes when the gradients move (the engine's arena usually comes back at
+            # the same address every step): rebuild + upload it only then
+            gkey = tuple(g.data_ptr() for g in grads)
+            cached = self._gtabs.get(gi)
+            if cached is not None and cached[0] == gkey:
+                gtab = cached[1]
+            else:
+                gtab = torch.tensor(gkey, dtype=torch.int64).to(plist[0].device, non_blocking=True)
+                self._gtabs[gi] = (gkey, gtab)
             # a torch.optim.Adam checkpoint stores 'step' as a (float) tensor: coerce
             step = int(self.state[plist[0]]['step']) + 1
             for p in plist:

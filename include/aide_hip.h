@@ -221,6 +221,12 @@ int aide_dice_terms_bwd(const float* x, int64_t x_bs, const float* t, int64_t t_
                         float w1, float smooth, int reduction, const double* ws, const float* g, float* dx,
                         int64_t dx_bs, aide_stream_t stream);
 
+/* ---- stream ordering (host pointers): fork / join between the main stream and the weight-gradient stream as plain C
+ * calls, so that a recorded launch sequence (aide_amd/tape.py) can re-issue them.  aide_stream_order(ev, from, to):
+ * work enqueued on `to` afterwards waits for the work enqueued on `from` so far (hipEventRecord + hipStreamWaitEvent). */
+int aide_event_create(void** ev);
+int aide_stream_order(void* ev, aide_stream_t from, aide_stream_t to);
+
 /* ---- CU-masked stream (host pointers) ---------------------------------------------------------------------------
  * A HIP stream restricted to the compute units whose bits are set in mask[words] (hipExtStreamCreateWithCUMask).  The
  * backward pass runs its weight-gradient kernels on one: the dependent chain on the main stream then always finds free
