@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     for (int p = 0; p < 18; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+    f32x2 fb[6];                                           // B fragments, requested 4 slots ahead
 
     float* const set0 = lds;
     float* const set1 = lds + F4_SET;
@@ -226,11 +227,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
         // V[p][channel pair][tile][2]: a wave's ds_read_b64 covers 512 contiguous bytes in lane order (a
         // [tile][4] row layout measured 2-way bank conflicts on every fragment read, with or without swizzle)
         const float* lb = sc + F4_RAW + (18 * ph) * 128 + half * 64 + ((j * 2) ^ (half * 16));
-        f32x2 fb[6];                                       // B fragments, requested 4 slots ahead
         auto frag = [&](int pi, int slot2) { fb[slot2] = *reinterpret_cast<const f32x2*>(lb + pi * 128); };
+#ifndef AIDE_F4_EARLY_BARRIER
         frag(0, 0); frag(1, 1); frag(2, 2); frag(3, 3);
+#endif
 #pragma unroll
         for (int st = 0; st < 36; ++st) {
+#ifdef AIDE_F4_EARLY_BARRIER
+            // The stage barrier sits BEFORE the last four MFMAs (they only use registers) and is followed at once by the
+            // first four fragment reads of the NEXT stage: barrier skew and LDS latency hide under 256 cycles of MFMA
+            // instead of idling the matrix pipe at every stage boundary.  All LDS stores of the stage are issued by slot 31.
+            if (st == 32) {
+                __syncthreads();
+                const float* lbn = sn + F4_RAW + (18 * ph) * 128 + half * 64 + ((j * 2) ^ (half * 16));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fb[q] = *reinterpret_cast<const f32x2*>(lbn + q * 128);
+            }
+#endif
             // slot order inside a position pair g: (2g,k0) (2g+1,k0) (2g,k1) (2g+1,k1)
             const int g = st >> 2, w = st & 3, pi = 2 * g + (w & 1), k = w >> 1;
             const int fs = pi % 6;
@@ -247,30 +260,45 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             if (st < 4) fetch(st, s + 2);
             else if (st < 22) fetch_u(st - 4, s + 1, ua[1 - kcur]);
 #endif
+#ifdef AIDE_F4_EARLY_BARRIER
+            constexpr int XM = 18, XS = 19, PR = 27;        // transform slot, first V-store slot, first raw-store slot
+#else
+            constexpr int XM = 20, XS = 21, PR = 31;
+#endif
 #ifndef AIDE_PROBE_4NOXF
             if (st < 18) { xf_read(2 * st, kcur ? xr0 : xr1); xf_read(2 * st + 1, kcur ? xr0 : xr1); }
-            if (st == 20) xf_math();
-            if (st >= 21 && st < 30) { xf_store(2 * (st - 21), sn + F4_RAW); xf_store(2 * (st - 21) + 1, sn + F4_RAW); }
+            if (st == XM) xf_math();
+            if (st >= XS && st < XS + 9) { xf_store(2 * (st - XS), sn + F4_RAW); xf_store(2 * (st - XS) + 1, sn + F4_RAW); }
 #endif
 #ifndef AIDE_PROBE_4NOFETCH
-            if (st >= 31) {
+            if (st >= PR && st < PR + 5) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
-                    if (3 * (st - 31) + q < 13) put_raw(3 * (st - 31) + q, sc);
+                    if (3 * (st - PR) + q < 13) put_raw(3 * (st - PR) + q, sc);
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
-#ifndef AIDE_PROBE_4NOBAR
+#if !defined(AIDE_PROBE_4NOBAR) && !defined(AIDE_F4_EARLY_BARRIER)
         __syncthreads();
 #endif
     };
     // two stages per iteration, unconditionally (the host makes the stage count of a split even): with a
     // conditional second stage hipcc reconciles the accumulator registers of the two paths by copying them
+#ifdef AIDE_F4_EARLY_BARRIER
+    {   // first fragments of the first stage (every later stage gets them from its predecessor, after the barrier)
+        const float* lb0 = set0 + F4_RAW + (18 * ph) * 128 + half * 64 + ((j * 2) ^ (half * 16));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fb[q] = *reinterpret_cast<const f32x2*>(lb0 + q * 128);
+    }
+#endif
     for (int s = s_begin; s < s_end; s += 2) {
         stage(s, set0, set1, ic<0>{});
         stage(s + 1, set1, set0, ic<1>{});
     }
+#ifdef AIDE_F4_EARLY_BARRIER
+    __syncthreads();      // the epilogue reuses the staging buffers: every wave past its last fragment reads
+#endif
 
     // ---- output transform.  Partial over this wave's rows i = 3ph..3ph+2:
     //   T[i][b] = sum_c M[i][c] A[c][b];   Yp[a][b] = sum_i A^T[a][i] T[i][b]

@@ -4,9 +4,14 @@
 //
 //   y[n][co][2h+kh][2w+kw] = b[co] + sum_ci x[n][ci][h][w] * W[ci][co][kh][kw]     (windows never overlap)
 //
-// The four taps are four independent 1x1 GEMMs.  No shipped train script enables this variant
-// (SURVEY.md §0), so it is served by one generic LDS-tiled fp32 FMA GEMM (64x64 tile, 4x4 per
-// thread) with problem-specific load/store functors rather than a dedicated MFMA kernel.
+// The four taps are four independent 1x1 GEMMs.  No shipped train script enables this variant; it is served
+// by one LDS-tiled GEMM skeleton on the fp32 MATRIX cores (v_mfma_f32_32x32x2_f32: 64 x 64 tile, four waves of 32 x 32,
+// K staged 16 at a time) with problem-specific load / store functors:
+//   forward  D[co][pix]      = sum_ci  W[ci][co][t] X[ci][pix]            (per tap t; pixel-shuffle store)
+//   dgrad    D[ci][pix]      = sum_(co,t) W[ci][co][t] dY[co][2h+kh][2w+kw]
+//   wgrad    D[ci][(co,t)]   = sum_pix X[ci][pix] dY[co][2h+kh][2w+kw]     (split over pixels, fixed-order slab sum)
+// The MFMA is a k-ordered fp32 fmaf chain (exact fp32, no TF32 on gfx950): results are bit-identical to the scalar-FMA
+// form of this kernel.
 #include "common.h"
 
 namespace {
@@ -19,12 +24,12 @@ __device__ __forceinline__ void tile_gemm(int m0, int n0, int M, int Nn, int k0,
                                           Store st) {
     __shared__ float As[TK][TM + 4];
     __shared__ float Bs[TK][TN + 4];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    float acc[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32;          // this wave's 32 x 32 block of the 64 x 64 tile
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     for (int kb = k0; kb < k1; kb += TK) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -35,24 +40,19 @@ __device__ __forceinline__ void tile_gemm(int m0, int n0, int M, int Nn, int k0,
             Bs[kk][mm] = (k < k1 && n0 + mm < Nn) ? lb(k, n0 + mm) : 0.f;
         }
         __syncthreads();
+        // one MFMA per K pair: A[i = j][k = half], B[k = half][n = j] (rows of 68 floats: the two K slots of a wave read
+        // two different rows, 32 consecutive floats each)
 #pragma unroll
-        for (int kk = 0; kk < TK; ++kk) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[kk][ty * 4]);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[kk][tx * 4]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-        }
+        for (int kk = 0; kk < TK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + half][wm + j], Bs[kk + half][wn + j], acc, 0, 0, 0);
         __syncthreads();
     }
+    // D layout: row = (r & 3) + 8 (r >> 2) + 4 half, column = j
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-            if (m < M && n < Nn) st(m, n, acc[i][j]);
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * half, n = n0 + wn + j;
+        if (m < M && n < Nn) st(m, n, acc[r]);
+    }
 }
 
 __global__ __launch_bounds__(256) void convt_fwd_kernel(const float* __restrict__ x, long x_bs,

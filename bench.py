@@ -36,6 +36,8 @@ WORKLOADS = {
     # fp32 master weights / BatchNorm statistics / loss / Adam)
     'c5': ('fuseunet', 8, 512, 1393.58),
     'tiny': ('fuseunet', 2, 64, 348.40 / 16),
+    # learned_bilinear=True variant (ConvTranspose2d(2,2) up path, netblocks.py:12): 245.32 GF / image
+    'c2-learned': ('fuseunet_learned', 4, 256, 245.32),
 }
 
 
@@ -68,7 +70,10 @@ def build(model_name, device):
     from aide_amd.models_twomodalinputs import fuseunet
     from aide_amd.models_singlemodalinput import UNet
     torch.manual_seed(2)                                  # reference default --torch_seed 2
-    net = fuseunet(2) if model_name == 'fuseunet' else UNet(2)
+    if model_name == 'fuseunet_learned':
+        net = fuseunet(2, learned_bilinear=True)
+    else:
+        net = fuseunet(2) if model_name == 'fuseunet' else UNet(2)
     return net.to(device)
 
 
@@ -81,12 +86,13 @@ def cpu_baseline(model_name, batch, size, steps, max_threads):
     cores = min(os.cpu_count() or 1, max_threads)
     torch.set_num_threads(cores)
     torch.manual_seed(2)
-    net = oracle.fuseunet(2) if model_name == 'fuseunet' else oracle.UNet(2)
+    net = (oracle.fuseunet(2, learned_bilinear=True) if model_name == 'fuseunet_learned' else
+           oracle.fuseunet(2) if model_name == 'fuseunet' else oracle.UNet(2))
     net.train()
     w = torch.tensor([1.0, 1.0])
     crit = oracle.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, amsgrad=True)
-    xin, xout, t = chaos_batch(batch, size, seed=1234, single_modal=(model_name != 'fuseunet'))
+    xin, xout, t = chaos_batch(batch, size, seed=1234, single_modal=(not model_name.startswith('fuseunet')))
     oracle.comparison_step(net, crit, opt, xin, xout, t)          # warm-up
     t0 = time.time()
     for _ in range(steps):
@@ -271,7 +277,7 @@ def main():
     w = torch.tensor([1.0, 1.0])
     crit = U.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
     opt = Adam(net.parameters(), lr=1e-4, amsgrad=True)
-    xin, xout, tgt = chaos_batch(batch, size, seed=1234 + rank, single_modal=(model_name != 'fuseunet'))
+    xin, xout, tgt = chaos_batch(batch, size, seed=1234 + rank, single_modal=(not model_name.startswith('fuseunet')))
     xin, tgt = xin.to(device), tgt.to(device)
     xout = xout.to(device) if xout is not None else None
 
@@ -367,14 +373,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline and cpu_steps > 0:
             cpu = cpu_baseline(model_name, batch, size, cpu_steps, args.cpu_threads)
         line = dict(metric='training images/sec %s bs=%d/GPU' % (
-                        ('FuseUNet %dx%dx2' if model_name == 'fuseunet' else 'UNet %dx%d') % (size, size), batch),
+                        ('FuseUNet %dx%dx2' if model_name.startswith('fuseunet') else 'UNet %dx%d') % (size, size), batch),
                     value=round(value, 2), unit='images/sec', n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True,
                     scaling='weak', vs_baseline=None, dtype='f32' if precision == 'fp32' else 'bf16',
                     data='synthetic',
                     config=dict(workload='%s %s fwd+loss+bwd+Adam(amsgrad), %dx%d %s, bs=%d/GPU, %s'
                                          % (args.workload, model_name, size, size,
-                                            '2-modal' if model_name == 'fuseunet' else '1-modal', batch,
+                                            '2-modal' if model_name.startswith('fuseunet') else '1-modal', batch,
                                             'fp32' if precision == 'fp32' else
                                             'bf16 conv operands / fp32 accumulate, fp32 BN+loss+Adam'),
                                 global_batch=batch * world, parallelism='dp%d' % world,
