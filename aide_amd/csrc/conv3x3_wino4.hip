@@ -30,7 +30,7 @@ template <int V> using ic = std::integral_constant<int, V>;
 
 struct W4Args {
     const float* x;
-    const float* u;      // [Cin/4][36][2][Cout][2]  (stage, position, channel pair, co, channel of the pair)
+    const float* u;      // [Cin/4][18][2][Cout][2][2]  (stage, position pair, channel pair, co, position of the pair, channel of the pair)
     const float* bias;
     float* y;
     long x_bs, y_bs, split_stride;
@@ -47,6 +47,13 @@ constexpr int F4_RAW = 4 * F4_RCS;         // 3100 floats
 constexpr int F4_V = 36 * 32 * 4;          // V[p][2 channel pairs][32 tiles][2]
 constexpr int F4_SET = F4_RAW + F4_V;      // 7708 floats = 30832 B; two sets = 60.2 KB (filters never touch LDS)
 constexpr int F4_LDS = 2 * F4_SET > 4 * 128 * 64 ? 2 * F4_SET : 4 * 128 * 64;   // epilogue swap needs 32768
+
+// Position pairs: pair q = 3 i + t of transform row i holds columns (1,2), (3,4), (0,5) for t = 0, 1, 2 (the pairs the packed
+// input transform produces).  Accumulator slot 2 q + b <-> position F4_P(q, b); slot of column c in row i: F4_SLOT.
+__host__ __device__ constexpr int f4_pos(int q, int b) {
+    return 6 * (q / 3) + ((q % 3) == 0 ? 1 + b : (q % 3) == 1 ? 3 + b : 5 * b);
+}
+__host__ __device__ constexpr int f4_slot(int c) { return c == 0 ? 4 : c == 5 ? 5 : c - 1; }   // within a row of 6
 
 // 1-D input transform B^T (F(4,3), points 0, +-1, +-2, inf), all six outputs
 __device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, float d4, float d5, float* o, int st) {
@@ -110,18 +117,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     // contiguous 512-byte dwordx2 load in exactly the MFMA A-operand lane order (lane = pair * 32 + co).
     // (Cout % 64 == 32: the upper co block of the last workgroup reads past its rows - into the next run, or past the
     // tensor, where the exact-size descriptor returns zeros; those accumulator rows are never stored)
-    const long ubase = ((long)18 * ph * 2 * a.Cout + co0 + cb * 32) * 2;
+    // packed layout [stage][position pair q (18)][channel pair][Co][p & 1][2]: one dwordx4 per lane carries the A
+    // operands of BOTH K slots of two adjacent positions -- 9 filter loads per stage instead of 18 (vector-memory issue
+    // slots are the scarce resource beside the MFMAs: the ablation without any fetch ran 12-14 % faster)
+    const long ubase = ((long)9 * ph * 2 * a.Cout + co0 + cb * 32) * 4;
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.u + ubase), 0, (int)(((long)a.Cin * 36 * a.Cout - ubase) * 4), 0x00020000);
-    const unsigned uoff = (unsigned)(half * a.Cout + j) * 8u;
-    const unsigned upos = (unsigned)a.Cout * 16u;          // bytes per position
+    const unsigned uoff = (unsigned)(half * a.Cout + j) * 16u;
+    const unsigned upos = (unsigned)a.Cout * 32u;          // bytes per position pair
 
     f32x4 rb[3];
     float rc;
-    f32x2 ua[2][18];                                       // A fragments of the current / next stage
-    auto fetch_u = [&](int pi, int stage, f32x2* dst) {
-        const unsigned us = ((unsigned)min(stage, s_end - 1) * 36u + (unsigned)pi) * upos;
-        dst[pi] = buf_load_f32x2(urs, uoff, us);
+    f32x4 ua[2][9];                                        // A fragments of the current / next stage: [q] = {p0k0, p0k1, p1k0, p1k1}
+    auto fetch_u = [&](int q, int stage, f32x4* dst) {
+        const unsigned us = ((unsigned)min(stage, s_end - 1) * 18u + (unsigned)q) * upos;
+        dst[q] = buf_load_f32x4(urs, uoff, us);
     };
     auto fetch = [&](int l, int stage) {                   // 4 raw loads
         const unsigned xs = (unsigned)(min(stage, s_end - 1) * 4) * (unsigned)HW * 4u;
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     const int xr_off = (item & 3) * F4_RCS + (item >> 5) * 4 * F4_RRS + 3 + 4 * ((item >> 2) & 7);
     // patch rows as pairs of columns: the column pass is element-wise over columns -> v_pk_fma_f32 / v_pk_add_f32
     f32x2 tp[6][3];
-    float to[18];
+    f32x2 tq[9];
     auto xf_read = [&](int i, int xo) {                    // xo = patch origin of this thread in a set
         const float v = lds[xo + (i / 6) * F4_RRS + (i % 6)];
         if ((i % 6) & 1) tp[i / 6][(i % 6) >> 1].y = v; else tp[i / 6][(i % 6) >> 1].x = v;
@@ -173,8 +183,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             const f32x2 o12 = f32x2{be.x, be.x} * f32x2{1.f, -1.f} + f32x2{ac.x, ac.x};
             const f32x2 o34 = f32x2{be.y, be.y} * f32x2{2.f, -2.f} + f32x2{ac.y, ac.y};
             const f32x2 o05 = t23 * f32x2{-5.f, -5.f} + (t01 * f32x2{4.f, 4.f} + t45);
-            to[6 * i] = o05.x; to[6 * i + 1] = o12.x; to[6 * i + 2] = o12.y;
-            to[6 * i + 3] = o34.x; to[6 * i + 4] = o34.y; to[6 * i + 5] = o05.y;
+            // position pairs as they fall out of the packed arithmetic: (1,2) (3,4) (0,5) of transform row i -- the V / U
+            // layouts and the accumulator slots use THIS pairing (F4_P0 / F4_P1), so no register shuffling is needed
+            tq[3 * i] = o12; tq[3 * i + 1] = o34; tq[3 * i + 2] = o05;
         }
     };
     // The transform half is wave-uniform.  Everything from here on is instantiated once per half and
@@ -182,17 +193,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     // wait for the filter fragments it has just requested.
     auto run = [&](auto HS) {
     auto xf_math = [&]() { xf_half(HS); };
-    // [pair][tile][2]; pair 1's run XOR-swizzled by 16 dwords so that a 32-lane store group covers all 32 banks
-    // (see conv3x3_wgrad4.hip); the B-fragment reads apply the same XOR
-    const int vitem = ((item >> 1) & 1) * 64 + (((item >> 2) * 2 + (item & 1)) ^ (((item >> 1) & 1) * 16));
-    auto xf_store = [&](int o, float* vbuf) { vbuf[(18 * hs + o) * 128 + vitem] = to[o]; };
+    // V[q = p / 2][channel pair][tile][e = channel of the pair][p & 1]: a thread stores the two positions of a pair as ONE
+    // 8-byte store (9 per stage instead of 18) and a lane's 16-byte fragment read carries both K slots of both positions
+    // (18 ds_read_b128 per stage instead of 36 ds_read_b64).  Pair 1's run is XOR-swizzled by 16 dwords: the 16-lane
+    // store groups then cover all 32 banks; the reads apply the same XOR (a permutation of 16-byte slots: conflict-free).
+    const int vitem = ((item >> 1) & 1) * 128 + ((((item >> 2) * 4 + (item & 1) * 2)) ^ (((item >> 1) & 1) * 16));
+    auto xf_store = [&](int m, float* vbuf) {
+        *reinterpret_cast<f32x2*>(vbuf + (9 * hs + m) * 256 + vitem) = tq[m];
+    };
 
     f32x16 acc[18];
 #pragma unroll
     for (int p = 0; p < 18; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
-    f32x2 fb[6];                                           // B fragments, requested 4 slots ahead
+    f32x4 fb[3];                                           // B fragments of a position pair, requested 8 slots ahead
 
     float* const set0 = lds;
     float* const set1 = lds + F4_SET;
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
 #pragma unroll
     for (int l = 0; l < 4; ++l) fetch(l, s_begin);
 #pragma unroll
-    for (int pi = 0; pi < 18; ++pi) fetch_u(pi, s_begin, ua[0]);
+    for (int q = 0; q < 9; ++q) fetch_u(q, s_begin, ua[0]);
 #pragma unroll
     for (int w = 0; w < 13; ++w) put_raw(w, set0);
 #pragma unroll
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     for (int i = 0; i < 36; ++i) xf_read(i, xr0);
     xf_math();
 #pragma unroll
-    for (int o = 0; o < 18; ++o) xf_store(o, set0 + F4_RAW);
+    for (int m = 0; m < 9; ++m) xf_store(m, set0 + F4_RAW);
 #pragma unroll
     for (int w = 0; w < 13; ++w) put_raw(w, set1);
     __syncthreads();
@@ -226,39 +241,38 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
         constexpr int kcur = decltype(CUR)::value;
         // V[p][channel pair][tile][2]: a wave's ds_read_b64 covers 512 contiguous bytes in lane order (a
         // [tile][4] row layout measured 2-way bank conflicts on every fragment read, with or without swizzle)
-        const float* lb = sc + F4_RAW + (18 * ph) * 128 + half * 64 + ((j * 2) ^ (half * 16));
-        auto frag = [&](int pi, int slot2) { fb[slot2] = *reinterpret_cast<const f32x2*>(lb + pi * 128); };
+        const float* lb = sc + F4_RAW + (9 * ph) * 256 + half * 128 + ((j * 4) ^ (half * 16));
+        auto frag = [&](int q, int slot3) { fb[slot3] = *reinterpret_cast<const f32x4*>(lb + q * 256); };
 #ifndef AIDE_F4_EARLY_BARRIER
-        frag(0, 0); frag(1, 1); frag(2, 2); frag(3, 3);
+        frag(0, 0); frag(1, 1);
 #endif
 #pragma unroll
         for (int st = 0; st < 36; ++st) {
 #ifdef AIDE_F4_EARLY_BARRIER
-            // The stage barrier sits BEFORE the last four MFMAs (they only use registers) and is followed at once by the
-            // first four fragment reads of the NEXT stage: barrier skew and LDS latency hide under 256 cycles of MFMA
-            // instead of idling the matrix pipe at every stage boundary.  All LDS stores of the stage are issued by slot 31.
+            // (probe, no gain) The stage barrier BEFORE the last four MFMAs (they only use registers), followed at once by
+            // the first fragment reads of the NEXT stage.  All LDS stores of the stage are issued by slot 31.
             if (st == 32) {
                 __syncthreads();
-                const float* lbn = sn + F4_RAW + (18 * ph) * 128 + half * 64 + ((j * 2) ^ (half * 16));
+                const float* lbn = sn + F4_RAW + (9 * ph) * 256 + half * 128 + ((j * 4) ^ (half * 16));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) fb[q] = *reinterpret_cast<const f32x2*>(lbn + q * 128);
+                for (int q = 0; q < 2; ++q) fb[q] = *reinterpret_cast<const f32x4*>(lbn + q * 256);
             }
 #endif
             // slot order inside a position pair g: (2g,k0) (2g+1,k0) (2g,k1) (2g+1,k1)
             const int g = st >> 2, w = st & 3, pi = 2 * g + (w & 1), k = w >> 1;
-            const int fs = pi % 6;
-            if (w == 0 && pi + 4 < 18) { frag(pi + 4, (pi + 4) % 6); frag(pi + 5, (pi + 5) % 6); }
+            const int fs = g % 3;
+            if (w == 0 && g + 2 < 9) frag(g + 2, (g + 2) % 3);          // fragments of a pair, two pairs (8 slots) ahead
             // 18 x 16 accumulator registers exceed the 256 AGPRs: positions 16 and 17 are pinned to VGPRs,
             // and the register classes are spelled out (hipcc otherwise shuffles whole accumulators
             // between the two files every stage)
-            if (pi < F4_NAGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pi]) : "v"(ua[kcur][pi][k]), "v"(fb[fs][k]));
-            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[pi]) : "v"(ua[kcur][pi][k]), "v"(fb[fs][k]));
+            if (pi < F4_NAGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pi]) : "v"(ua[kcur][g][(w & 1) * 2 + k]), "v"(fb[fs][k * 2 + (w & 1)]));
+            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[pi]) : "v"(ua[kcur][g][(w & 1) * 2 + k]), "v"(fb[fs][k * 2 + (w & 1)]));
             // staging schedule: only slot 20 carries vector-ALU work
             //   0..3 raw[s+2] global fetches, 4..21 U[s+1] fragment fetches;  0..17 patch reads (2 per slot)
             //   20 transform;  21..29 V stores (2 per slot);  31..35 raw stores (3 per slot)
 #ifndef AIDE_PROBE_4NOFETCH
             if (st < 4) fetch(st, s + 2);
-            else if (st < 22) fetch_u(st - 4, s + 1, ua[1 - kcur]);
+            else if (st < 22 && ((st - 4) & 1) == 0) fetch_u((st - 4) >> 1, s + 1, ua[1 - kcur]);
 #endif
 #ifdef AIDE_F4_EARLY_BARRIER
             constexpr int XM = 18, XS = 19, PR = 27;        // transform slot, first V-store slot, first raw-store slot
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
 #ifndef AIDE_PROBE_4NOXF
             if (st < 18) { xf_read(2 * st, kcur ? xr0 : xr1); xf_read(2 * st + 1, kcur ? xr0 : xr1); }
             if (st == XM) xf_math();
-            if (st >= XS && st < XS + 9) { xf_store(2 * (st - XS), sn + F4_RAW); xf_store(2 * (st - XS) + 1, sn + F4_RAW); }
+            if (st >= XS && st < XS + 9) xf_store(st - XS, sn + F4_RAW);
 #endif
 #ifndef AIDE_PROBE_4NOFETCH
             if (st >= PR && st < PR + 5) {
@@ -287,9 +301,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     // conditional second stage hipcc reconciles the accumulator registers of the two paths by copying them
 #ifdef AIDE_F4_EARLY_BARRIER
     {   // first fragments of the first stage (every later stage gets them from its predecessor, after the barrier)
-        const float* lb0 = set0 + F4_RAW + (18 * ph) * 128 + half * 64 + ((j * 2) ^ (half * 16));
+        const float* lb0 = set0 + F4_RAW + (9 * ph) * 256 + half * 128 + ((j * 4) ^ (half * 16));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fb[q] = *reinterpret_cast<const f32x2*>(lb0 + q * 128);
+        for (int q = 0; q < 2; ++q) fb[q] = *reinterpret_cast<const f32x4*>(lb0 + q * 256);
     }
 #endif
     for (int s = s_begin; s < s_end; s += 2) {
@@ -315,8 +329,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             float T[3][4];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float m0 = acc[6 * i][r], m1 = acc[6 * i + 1][r], m2 = acc[6 * i + 2][r],
-                            m3 = acc[6 * i + 3][r], m4 = acc[6 * i + 4][r], m5 = acc[6 * i + 5][r];
+                const float m0 = acc[6 * i + f4_slot(0)][r], m1 = acc[6 * i + f4_slot(1)][r], m2 = acc[6 * i + f4_slot(2)][r],
+                            m3 = acc[6 * i + f4_slot(3)][r], m4 = acc[6 * i + f4_slot(4)][r], m5 = acc[6 * i + f4_slot(5)][r];
                 const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
                 T[i][0] = m0 + s12 + s34;
                 T[i][1] = __builtin_fmaf(2.f, d34, d12);
@@ -472,20 +486,24 @@ __global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc*
             for (int t = 0; t < 9; ++t) g[t] = in ? wp[fwd ? t : 8 - t] : 0.f;
         }
         wino4_g(g, u);
-        // per position two runs (channel pair 0 / 1) of [row][2]: row = co (forward) resp. ci (dgrad)
+        // staging tile ot[p][channel pair][row][2]: row = co (forward) resp. ci (dgrad)
         const int otid = (lo2 >> 1) * 64 + hi5 * 2 + (lo2 & 1);
 #pragma unroll
         for (int p = 0; p < 36; ++p) ot[p * 128 + otid] = u[p];
         __syncthreads();
         const int C = fwd ? d.Co : d.Ci, c0 = fwd ? co0 : ci0;
-        const long gbase = (long)((fwd ? ci0 : co0) / 4 + q) * 36;
-        const int nrun = min(P4_T, C - c0) * 2;            // floats per run that exist
+        const long gbase = (long)((fwd ? ci0 : co0) / 4 + q) * 18;
+        const int nrow = min(P4_T, C - c0);                // rows that exist
+        // output [group][position pair][channel pair][row][p & 1][2]: 16 bytes per row = the kernel's dwordx4 fragment
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int f = tid + k * 128, p = f >> 5, hh = (f >> 4) & 1, x4 = (f & 15) * 4;
-            if (x4 < nrun)
-                *reinterpret_cast<f32x4*>(dst + (((gbase + p) * 2 + hh) * C + c0) * 2 + x4) =
-                    *reinterpret_cast<const f32x4*>(ot + p * 128 + hh * 64 + x4);
+            const int f = tid + k * 128, pq = f >> 6, hh = (f >> 5) & 1, row = f & 31;
+            if (row < nrow) {
+                const float* o0 = ot + f4_pos(pq, 0) * 128 + hh * 64 + row * 2;
+                const float* o1 = ot + f4_pos(pq, 1) * 128 + hh * 64 + row * 2;
+                *reinterpret_cast<f32x4*>(dst + (((gbase + pq) * 2 + hh) * C + c0 + row) * 4) =
+                    f32x4{o0[0], o0[1], o1[0], o1[1]};
+            }
         }
         __syncthreads();
     }
