@@ -35,11 +35,14 @@ struct G4Args {
 };
 
 constexpr int G4_NAGPR = 16;
+// Position pairs (as conv3x3_wino4.hip): pair q = 3 i + t of transform row i holds columns (1,2), (3,4), (0,5) for t = 0, 1, 2
+// -- the pairs both packed transforms produce.  Accumulator slot of column c within a row of 6: g4_slot.
+__host__ __device__ constexpr int g4_slot(int c) { return c == 0 ? 4 : c == 5 ? 5 : c - 1; }
 constexpr int G4_RS = 20;                  // raw input row: [-1][0..15][16][2 pad]: patch of tile t starts at 4 t (16-byte aligned)
 constexpr int G4_DS = 144;                 // raw channel stride (= 16 mod 64: conflict-free b128 patch reads)
 constexpr int G4_RAW = 32 * G4_DS;         // 4608 floats
-constexpr int G4_ZT = 36 * 64 * 4;         // ZT[p][2 tile pairs][64 co][2]
-constexpr int G4_V = 36 * 32 * 4;          // V[p][2 tile pairs][32 ci][2]
+constexpr int G4_ZT = 36 * 64 * 4;         // ZT[18 position pairs][2 tile pairs][64 co][tile & 1][p & 1]
+constexpr int G4_V = 36 * 32 * 4;          // V[18 position pairs][2 tile pairs][32 ci][tile & 1][p & 1]
 constexpr int G4_SET = G4_ZT + G4_V;       // 13824 floats
 constexpr int G4_LDS = 2 * G4_SET + 2 * G4_RAW;   // 36864 floats = 144 KB (epilogue swap needs 4 x 72 x 64 = 18432)
 
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
     int xr0 = 2 * G4_SET + vci * G4_DS + 4 * vtile, xr1 = xr0 + G4_RAW;
     asm volatile("" : "+v"(xr0), "+v"(xr1));
     f32x2 tp[6][3];
-    float to[18];
+    f32x2 tq[9];
     auto v_read = [&](int r, int xo) {                     // one 16-byte + one 8-byte read per patch row
         const f32x4 q = *reinterpret_cast<const f32x4*>(lds + xo + r * G4_RS);
         const f32x2 e = *reinterpret_cast<const f32x2*>(lds + xo + r * G4_RS + 4);
@@ -190,22 +193,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
             const f32x2 o12 = f32x2{be.x, be.x} * f32x2{1.f, -1.f} + f32x2{ac.x, ac.x};
             const f32x2 o34 = f32x2{be.y, be.y} * f32x2{2.f, -2.f} + f32x2{ac.y, ac.y};
             const f32x2 o05 = t23 * f32x2{-5.f, -5.f} + (t01 * f32x2{4.f, 4.f} + t45);
-            to[6 * i] = o05.x; to[6 * i + 1] = o12.x; to[6 * i + 2] = o12.y;
-            to[6 * i + 3] = o34.x; to[6 * i + 4] = o34.y; to[6 * i + 5] = o05.y;
+            tq[3 * i] = o12; tq[3 * i + 1] = o34; tq[3 * i + 2] = o05;     // position pairs (1,2) (3,4) (0,5)
         }
     };
-    // V[p][tile pair][ci][2]; the second pair's run is XOR-swizzled by 16 dwords: a wave's 32-lane store group then
-    // covers all 32 banks (unswizzled, pairs 0 and 1 of the same channel share a bank: 2-way conflict on every store --
-    // rocprofv3 SQ_LDS_BANK_CONFLICT was 37 % of the kernel's LDS cycles); the fragment reads apply the same XOR
-    const int vpos = (vtile >> 1) * 64 + ((vci * 2 + (vtile & 1)) ^ ((vtile >> 1) * 16));
+    // Operand layouts [position pair q][tile pair][channel][tile & 1][p & 1]: a lane's 16-byte fragment read carries both K
+    // slots (tiles) of both positions of a pair -- 18 + 18 ds_read_b128 per chunk instead of 36 + 36 ds_read_b64 (which hipcc
+    // merged into ds_read2st64_b64 at half the LDS rate) -- and a thread stores the two positions of a pair as one 8-byte
+    // store.  Tile pair 1's run is XOR-swizzled by 16 dwords so that the 16-lane store groups cover all 32 banks; the reads
+    // apply the same XOR (a permutation of 16-byte slots: conflict-free).
+    const int vpos = (vtile >> 1) * 128 + ((vci * 4 + (vtile & 1) * 2) ^ ((vtile >> 1) * 16));
     // per-set store bases as live registers (as xr0 / xr1): with one base + a > 64 KB constant the offsets do not fit the
-    // 16-bit DS immediate and hipcc re-derives the address with a v_add per store (17 per chunk, on the MFMA's pipe)
-    int vb0 = G4_ZT + 18 * hs * 128 + vpos, vb1 = G4_SET + G4_ZT + 18 * hs * 128 + vpos;
+    // 16-bit DS immediate and hipcc re-derives the address with a v_add per store (on the MFMA's pipe)
+    // (bases in units of 8 bytes: the stores are then provably 8-byte aligned -> ds_write_b64 with a 16-bit immediate)
+    f32x2* const lds2 = reinterpret_cast<f32x2*>(lds);
+    int vb0 = (G4_ZT + 9 * hs * 256 + vpos) / 2, vb1 = (G4_SET + G4_ZT + 9 * hs * 256 + vpos) / 2;
     asm volatile("" : "+v"(vb0), "+v"(vb1));
-    auto v_store = [&](int o, int set) { lds[(set ? vb1 : vb0) + o * 128] = to[o]; };
+    auto v_store = [&](int m, int set) { lds2[(set ? vb1 : vb0) + m * 128] = tq[m]; };
 
     // ---- dz transform (A Z A^T), thread = (co_l, tile), all 36 values ----
-    float zo[36];
+    f32x2 zq[12];               // position pairs (1,2) and (3,4) of the six transform rows
+    float z0[6], z5[6];          // columns 0 and 5 (the third pair of a row), stored as two dwords
     auto z_math = [&]() {
         // column pass over column pairs: y0 = z0, y1/y2 = (z0 + z2) +- (z1 + z3), y3/y4 = (z0 + 4 z2) +- 2 (z1 + 4 z3), y5 = z3
         f32x2 Y[6][2];
@@ -225,14 +232,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
             const f32x2 sb = f32x2{t23.y, t23.y} * f32x2{1.f, 4.f} + f32x2{t01.y, t01.y};
             const f32x2 o12 = f32x2{sb.x, sb.x} * f32x2{1.f, -1.f} + f32x2{sa.x, sa.x};
             const f32x2 o34 = f32x2{sb.y, sb.y} * f32x2{2.f, -2.f} + f32x2{sa.y, sa.y};
-            zo[6 * i] = t01.x; zo[6 * i + 1] = o12.x; zo[6 * i + 2] = o12.y;
-            zo[6 * i + 3] = o34.x; zo[6 * i + 4] = o34.y; zo[6 * i + 5] = t23.y;
+            zq[2 * i] = o12; zq[2 * i + 1] = o34; z0[i] = t01.x; z5[i] = t23.y;
         }
     };
-    const int zpos = (zt >> 1) * 128 + ((zco * 2 + (zt & 1)) ^ ((zt >> 1) * 16));   // ZT[p][tile pair][co][2], swizzled as V
-    int zb0 = zpos, zb1 = G4_SET + zpos;
+    const int zpos = (zt >> 1) * 256 + ((zco * 4 + (zt & 1) * 2) ^ ((zt >> 1) * 16));   // ZT[q][tile pair][co 64][tile & 1][p & 1]
+    int zb0 = zpos / 2, zb1 = (G4_SET + zpos) / 2;
     asm volatile("" : "+v"(zb0), "+v"(zb1));
-    auto z_store = [&](int o, int set) { lds[(set ? zb1 : zb0) + o * 256] = zo[o]; };
+    // 24 stores per chunk: k = 4 i + {0, 1}: the 8-byte pairs of row i; 4 i + {2, 3}: columns 0 and 5 (pair q = 3 i + 2)
+    auto z_store = [&](int k, int set) {
+        const int i = k >> 2, t = k & 3, zb = set ? zb1 : zb0;
+        if (t < 2) lds2[zb + (3 * i + t) * 256] = zq[2 * i + t];
+        else lds[2 * zb + (3 * i + 2) * 512 + (t - 2)] = (t == 2) ? z0[i] : z5[i];
+    };
 
     float* const set0 = lds;
     float* const set1 = lds + G4_SET;
@@ -264,10 +275,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
     for (int r = 0; r < 6; ++r) v_read(r, xr0);
     v_math(HS);
 #pragma unroll
-    for (int o = 0; o < 18; ++o) v_store(o, 0);
+    for (int m = 0; m < 9; ++m) v_store(m, 0);
     z_math();
 #pragma unroll
-    for (int o = 0; o < 36; ++o) z_store(o, 0);
+    for (int k = 0; k < 24; ++k) z_store(k, 0);
 #pragma unroll
     for (int w = 0; w < 14; ++w) put_d(w, raw1);
     __syncthreads();
@@ -278,22 +289,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
     //   the raw input of c + 2 is fetched and stored into rawc (consumed by the previous chunk's transform).
     auto chunk = [&](int c, float* sc, float* sn, float* rawc, auto CUR) {
         constexpr int kcur = decltype(CUR)::value;
-        // operands are stored [p][tile pair][channel][2]: a wave's ds_read_b64 covers 512 contiguous bytes
-        const float* la = sc + (18 * ph) * 256 + half * 128 + (((cb * 32 + j) * 2) ^ (half * 16));     // ZT[p][pair][co 64][2]
-        const float* lb = sc + G4_ZT + (18 * ph) * 128 + half * 64 + ((j * 2) ^ (half * 16));          // V[p][pair][ci 32][2]
-        f32x2 fa[6], fb[6];
-        auto frag = [&](int pi, int s2) {
-            fa[s2] = *reinterpret_cast<const f32x2*>(la + pi * 256);
-            fb[s2] = *reinterpret_cast<const f32x2*>(lb + pi * 128);
+        const float* la = sc + (9 * ph) * 512 + half * 256 + (((cb * 32 + j) * 4) ^ (half * 16));     // ZT[q][tile pair][co 64][4]
+        const float* lb = sc + G4_ZT + (9 * ph) * 256 + half * 128 + ((j * 4) ^ (half * 16));        // V[q][tile pair][ci 32][4]
+        f32x4 fa[3], fb[3];                                 // fragments of a position pair: {t0p0, t0p1, t1p0, t1p1}
+        auto frag = [&](int q, int s3) {
+            fa[s3] = *reinterpret_cast<const f32x4*>(la + q * 512);
+            fb[s3] = *reinterpret_cast<const f32x4*>(lb + q * 256);
         };
-        frag(0, 0); frag(1, 1); frag(2, 2); frag(3, 3);
+        frag(0, 0); frag(1, 1);
 #pragma unroll
         for (int st = 0; st < 36; ++st) {
             const int gq = st >> 2, w = st & 3, pi = 2 * gq + (w & 1), k = w >> 1;
-            const int fs = pi % 6;
-            if (w == 0 && pi + 4 < 18) { frag(pi + 4, (pi + 4) % 6); frag(pi + 5, (pi + 5) % 6); }
-            if (pi < G4_NAGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pi]) : "v"(fa[fs][k]), "v"(fb[fs][k]));
-            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[pi]) : "v"(fa[fs][k]), "v"(fb[fs][k]));
+            const int fs = gq % 3, e = k * 2 + (w & 1);
+            if (w == 0 && gq + 2 < 9) frag(gq + 2, (gq + 2) % 3);
+            if (pi < G4_NAGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pi]) : "v"(fa[fs][e]), "v"(fb[fs][e]));
+            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[pi]) : "v"(fa[fs][e]), "v"(fb[fs][e]));
             // schedule (vector-ALU work only in slots 0, 14 and 20):
             //   0 offsets;  0..3 dz[c+1] loads, 4..8 raw[c+2] loads;  1..6 patch reads
             //   14 input transform, 15..23 V stores;  20 dz transform, 21..32 ZT stores (3 per slot)
@@ -307,13 +317,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
 #ifndef AIDE_PROBE_GNOV
             if (st >= 1 && st < 7) v_read(st - 1, kcur ? xr0 : xr1);
             if (st == 14) v_math(HS);
-            if (st >= 15 && st < 24) { v_store(2 * (st - 15), 1 - kcur); v_store(2 * (st - 15) + 1, 1 - kcur); }
+            if (st >= 15 && st < 24) v_store(st - 15, 1 - kcur);
 #endif
 #ifndef AIDE_PROBE_GNOZ
             if (st == 20) z_math();
             if (st >= 21 && st < 33) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) z_store(3 * (st - 21) + q, 1 - kcur);
+                for (int q = 0; q < 2; ++q) z_store(2 * (st - 21) + q, 1 - kcur);
             }
 #endif
 #ifndef AIDE_PROBE_GNOFETCH
@@ -345,8 +355,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
             float T[3][3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float m0 = acc[6 * i][r], m1 = acc[6 * i + 1][r], m2 = acc[6 * i + 2][r],
-                            m3 = acc[6 * i + 3][r], m4 = acc[6 * i + 4][r], m5 = acc[6 * i + 5][r];
+                const float m0 = acc[6 * i + g4_slot(0)][r], m1 = acc[6 * i + g4_slot(1)][r], m2 = acc[6 * i + g4_slot(2)][r],
+                            m3 = acc[6 * i + g4_slot(3)][r], m4 = acc[6 * i + g4_slot(4)][r], m5 = acc[6 * i + g4_slot(5)][r];
                 const float s12 = m1 + m2, d21 = m2 - m1, s34 = m3 + m4, d34 = m3 - m4;
                 T[i][0] = 0.25f * m0 - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
                 T[i][1] = (1.f / 6.f) * d21 + (1.f / 12.f) * d34;
