@@ -4,12 +4,13 @@
 Two FuseUNets are co-trained; per step each net does 4 augmented forwards (train-mode BatchNorm, as
 in the reference) + 1 training forward + 1 backward.  Pseudo-label ensemble, sharpening, weight
 maps, both per-image CE+Dice vectors, the two ascending sorts, the keep/drop split and the composite
-losses run as fused HIP kernels (aide_amd.utils.coteach_loss).  The PIL reverse-augmentation
-(:81-95) is a "next" row: synthetic augmentations here are intensity-only, so the
-reverse map is the identity.
+losses run as fused HIP kernels (aide_amd.utils.coteach_loss).  The PIL reverse-augmentation (:81-95) runs on
+the device (`aide_reverse_aug`) from the loader-style `augset` dict; per-case evaluation and the best-checkpoint rule
+(:495-526) are mirrored on synthetic cases.
 """
 import argparse
 import logging
+import os
 import random
 import time
 
@@ -92,12 +93,13 @@ def Train(args=None):
     net1, net2 = fuseunet(2).to(device), fuseunet(2).to(device)
     reducers = (attach(net1), attach(net2))          # noqa: F841
     loss_op = CoTeachingProposedLoss(cediceweight=args.cedice_weight, ceclassweight=args.ceclass_weight,
-                                     segcor_weight=args.segcor_weight, keep=2)
+                                     segcor_weight=args.segcor_weight, keep=min(2, args.batch_size))
     opt1 = Adam(net1.parameters(), lr=args.lr, amsgrad=True)
     opt2 = Adam(net2.parameters(), lr=args.lr, amsgrad=True)
     sch1 = make_scheduler(args.lr_policy, opt1, args.num_epoch)        # :236-240
     sch2 = make_scheduler(args.lr_policy, opt2, args.num_epoch)
     g = torch.Generator(device='cpu').manual_seed(args.torch_seed)
+    best = -1.0
     for epoch in range(args.num_epoch):
         ts = time.time()
         rate = min((float(epoch) / float(args.warmup_epoch)) ** 2, 1.0)          # :248
@@ -111,15 +113,33 @@ def Train(args=None):
             augs = [((xin * (1 + 0.1 * torch.randn(1, generator=g))).to(device),
                      (xout * (1 + 0.1 * torch.randn(1, generator=g))).to(device)) for _ in range(4)]
             xin, xout, t = xin.to(device), xout.to(device), t.to(device)
-            r = coteach_step(net1, net2, opt1, opt2, loss_op, xin, xout, augs, t, t, rate, args.temperature)
+            # augmentation bookkeeping as the loader's dict (:81-95): 4 augmentations per sample, random flips and rotations
+            # within +-args.rotation; the logits are mapped back on the device (aide_reverse_aug)
+            augset = {'augno': [4] * args.batch_size}
+            for k in range(4):
+                augset['hflip%d' % (k + 1)] = [int(torch.randint(0, 2, (1,), generator=g)) for _ in range(args.batch_size)]
+                augset['degree%d' % (k + 1)] = [float((torch.rand(1, generator=g) * 2 - 1) * args.rotation)
+                                                for _ in range(args.batch_size)]
+            r = coteach_step(net1, net2, opt1, opt2, loss_op, xin, xout, augs, t, t, rate, args.temperature, augset=augset)
             l1 += r['loss1']
             l2 += r['loss2']
         if sch1 is not None:
             sch1.step()
             sch2.step()
+        # per-case evaluation of both networks and the best-checkpoint rule of :495-526 (average of the two case Dice values)
+        from aide_amd.train_files.trainchaos_comparison_1case import evaluate_case
+        cd1 = evaluate_case(net1, args, device, False, epoch)
+        cd2 = evaluate_case(net2, args, device, False, epoch)
         if rank == 0:
-            logging.info('epoch %d loss1 %.4f loss2 %.4f time %.1fs', epoch + 1, float(l1) / args.steps_per_epoch,
-                         float(l2) / args.steps_per_epoch, time.time() - ts)
+            logging.info('epoch %d loss1 %.4f loss2 %.4f traincase_dice %.3f %.3f time %.1fs', epoch + 1,
+                         float(l1) / args.steps_per_epoch, float(l2) / args.steps_per_epoch, cd1, cd2, time.time() - ts)
+            if args.checkpoint and (cd1 + cd2) / 2.0 > best:
+                best = (cd1 + cd2) / 2.0
+                os.makedirs(args.checkpoint, exist_ok=True)
+                for k, net in ((1, net1), (2, net2)):
+                    torch.save({'net': net.state_dict(), 'loss': float(l1 if k == 1 else l2) / args.steps_per_epoch,
+                                'epoch': epoch + 1},
+                               os.path.join(args.checkpoint, '%s_net%d_besttraincasedice.pkl' % (args.model_name, k)))
     return net1, net2
 
 

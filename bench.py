@@ -61,7 +61,7 @@ def parse():
     ap.add_argument('--traffic', default='live', choices=('live', 'none'),
                     help="roofline.traffic: 'live' = two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, separately, "
                          "--kernel-trace only) of this workload run as sub-processes after the timed region (rank 0, N=1)")
-    ap.add_argument('--traffic-timeout', type=int, default=240)
+    ap.add_argument('--traffic-timeout', type=int, default=150)
     ap.add_argument('--cpu-threads', type=int, default=32)
     return ap.parse_args()
 

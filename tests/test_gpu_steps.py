@@ -76,16 +76,35 @@ def test_proposed_coteaching_step(dev):
         assert np.median(np.abs(gn[live] - fx[key + 'g1'][live]) / fx[key + 'g1'][live]) < 1e-3
 
 
-def test_cli_smoke(dev):
-    """The restated CLI (--model_name / --batch_size as in README.md:32) trains and the loss falls."""
+def test_cli_smoke(dev, tmp_path):
+    """The restated CLI (--model_name / --batch_size as in README.md:32) trains, the loss falls, every epoch evaluates a
+    case and the best checkpoint is written in the reference's format ({'net': state_dict, ...}, :329-345) and loads back."""
     from aide_amd.train_files.trainchaos_comparison_1case import parse_args, Train, build_model
     args = parse_args(['--model_name', 'fuseunet', '--batch_size', '2', '--img_size', '64', '--num_epoch', '3',
-                       '--steps_per_epoch', '4'])
+                       '--steps_per_epoch', '4', '--checkpoint', str(tmp_path / 'ck')])
     assert args.lr == 1e-4 and args.torch_seed == 2 and args.loss == 'cedice'
-    _, hist = Train(args)
+    net, hist = Train(args)
     assert hist['train_loss'][-1] < hist['train_loss'][0]
+    assert len(hist['traincase_dice']) == 3 and all(0.0 <= d <= 1.0 for d in hist['traincase_dice'])
+    files = os.listdir(str(tmp_path / 'ck'))
+    assert len(files) == 1 and files[0].endswith('_besttraincasedice.pkl')
+    state = torch.load(os.path.join(str(tmp_path / 'ck'), files[0]), map_location='cpu', weights_only=False)
+    assert set(state) >= {'net', 'loss', 'dice', 'epoch', 'history'}
+    build_model('fuseunet', 2).load_state_dict(state['net'])
     with pytest.raises(ValueError, match='Model not implemented'):
         build_model('resnet', 2)
+
+
+def test_cli_proposed_smoke(dev, tmp_path):
+    """The proposed co-teaching CLI: two epochs with the loader-style augmentation dict (on-device reverse augmentation
+    with random flips / rotations), per-case evaluation of both networks, both checkpoints written (:495-526)."""
+    from aide_amd.train_files.trainchaos_proposed_30cases1labeled import parse_args, Train
+    args = parse_args(['--batch_size', '2', '--img_size', '64', '--num_epoch', '2', '--steps_per_epoch', '2',
+                       '--warmup_epoch', '2', '--checkpoint', str(tmp_path / 'ck')])
+    n1, n2 = Train(args)
+    files = sorted(os.listdir(str(tmp_path / 'ck')))
+    assert files == ['fuseunet_net1_besttraincasedice.pkl', 'fuseunet_net2_besttraincasedice.pkl']
+    assert all(torch.isfinite(p).all() for p in n1.parameters())
 
 
 def test_rccl_gradient_allreduce_single_rank(dev):
