@@ -264,10 +264,15 @@ class Plan(object):
                     max_wg = max(max_wg, st['wg_bytes'])
                     # BatchNorm statistics from the conv epilogue (big planes, non-split F(4x4) forward, ungrouped training)
                     st['stats'] = None
-                    if training and groups == 1 and EPILOGUE_STATS[0] and st['wino_f'] == 4 and (st['plan_f'] >> 8) <= 1 \
+                    if training and groups == 1 and EPILOGUE_STATS[0] and (st['plan_f'] >> 8) <= 1 \
                             and (hh * ww) % 4 == 0 and lib.aide_bn_two_pass(n, cout, hh, ww):
-                        st['stats_parts'] = lib.aide_conv3x3_wino4_stats_parts(n, hh, ww)
-                        st['stats'] = torch.empty(cout * st['stats_parts'] * 2, **f32)
+                        # F(4x4) forward only.  The same epilogue in the direct and F(2x2) kernels was built and measured: C2
+                        # 575 -> 572 images/s (their epilogues are short and the butterflies cost more than the saved pass) and
+                        # the fp32 partial sums of the 3->64 stem at 320x320 (|mean| >> std) moved a gradient norm by 3e-3.
+                        parts = lib.aide_conv3x3_wino4_stats_parts(n, hh, ww) if st['wino_f'] == 4 else 0
+                        if parts > 0:
+                            st['stats_parts'] = parts
+                            st['stats'] = torch.empty(cout * parts * 2, **f32)
                     st['pack_key'] = None
                     st['flops'] = 2.0 * n * hh * ww * cout * cin * 9      # algorithmic, per launch
                     # bf16 mode keeps the conv output z (read only by BatchNorm) and its gradient dz (read only by the
@@ -547,11 +552,11 @@ class Plan(object):
                 slabs = self.training and FOLD_SPLITK[0] and (st['plan_f'] >> 8) > 1 and \
                     (st['z'].shape[2] * st['z'].shape[3]) % 4 == 0          # (the slab loader reads 16 bytes)
                 acc = 2 if slabs else 0
+                if st['stats'] is not None:        # one-shot: this launch writes the BatchNorm statistics partials
+                    lib.aide_conv_stats_sink(ops.ptr(st['stats']))
                 if st['wino_f'] == BF16:
                     ops.conv3x3_bf16(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=self.sk_ws)
                 elif st['wino_f'] == 4:
-                    if st['stats'] is not None:
-                        lib.aide_conv_stats_sink(ops.ptr(st['stats']))
                     ops.conv3x3_wino4(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=self.sk_ws)
                 elif st['wino_f']:
                     ops.conv3x3_wino(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=self.sk_ws)
