@@ -18,19 +18,33 @@ namespace {
 
 // planes whose size is not a multiple of 4 (e.g. the 3x2 bottom level of a 48x32 input) take the
 // scalar instantiation V = 1; everything on the BASELINE shapes runs the 16-byte V = 4 form
+// V = 8: the bf16-stored tensors of the precision='bf16' mode move 16 bytes per lane as well (8 values; an fp32 partner
+// tensor moves two 16-byte pieces) -- with V = 4 their loads were 8 bytes per lane and the two-stream reduce ran at 3.1 TB/s
 template <int V> __device__ __forceinline__ void ldv(const float* p, float (&o)[V]) {
-    if constexpr (V == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(p); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+    if constexpr (V == 8) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p), w = *reinterpret_cast<const f32x4*>(p + 4);
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; o[4] = w[0]; o[5] = w[1]; o[6] = w[2]; o[7] = w[3];
+    } else if constexpr (V == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(p); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
     else { o[0] = p[0]; }
 }
 template <int V> __device__ __forceinline__ void stv(float* p, const float (&o)[V]) {
-    if constexpr (V == 4) { *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]}; }
+    if constexpr (V == 8) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    } else if constexpr (V == 4) { *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]}; }
     else { p[0] = o[0]; }
 }
 // bf16 storage (precision='bf16': conv outputs z and their gradients dz live in HBM as bf16, the arithmetic
 // here stays fp32/fp64): widening is exact, narrowing is round-to-nearest-even (v_cvt_pk_bf16_f32)
 typedef uint16_t bf16_t;
 template <int V> __device__ __forceinline__ void ldv(const bf16_t* p, float (&o)[V]) {
-    if constexpr (V == 4) {
+    if constexpr (V == 8) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[2 * k] = __builtin_bit_cast(float, v[k] << 16); o[2 * k + 1] = __builtin_bit_cast(float, v[k] & 0xffff0000u);
+        }
+    } else if constexpr (V == 4) {
         const u32x2 v = *reinterpret_cast<const u32x2*>(p);
         o[0] = __builtin_bit_cast(float, v[0] << 16); o[1] = __builtin_bit_cast(float, v[0] & 0xffff0000u);
         o[2] = __builtin_bit_cast(float, v[1] << 16); o[3] = __builtin_bit_cast(float, v[1] & 0xffff0000u);
@@ -42,7 +56,9 @@ __device__ __forceinline__ unsigned bn_pk_bf16(float lo, float hi) {
     return r;
 }
 template <int V> __device__ __forceinline__ void stv(bf16_t* p, const float (&o)[V]) {
-    if constexpr (V == 4) { *reinterpret_cast<u32x2*>(p) = u32x2{bn_pk_bf16(o[0], o[1]), bn_pk_bf16(o[2], o[3])}; }
+    if constexpr (V == 8) {
+        *reinterpret_cast<u32x4*>(p) = u32x4{bn_pk_bf16(o[0], o[1]), bn_pk_bf16(o[2], o[3]), bn_pk_bf16(o[4], o[5]), bn_pk_bf16(o[6], o[7])};
+    } else if constexpr (V == 4) { *reinterpret_cast<u32x2*>(p) = u32x2{bn_pk_bf16(o[0], o[1]), bn_pk_bf16(o[2], o[3])}; }
     else { p[0] = (bf16_t)(bn_pk_bf16(o[0], 0.f) & 0xffffu); }
 }
 
@@ -516,7 +532,16 @@ int bn_train_fwd_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C,
                            scale, shift, relu, sl);
         return aide_launch_status();
     }
-    if (v4) {
+    // 8 values per lane: 16-byte accesses for the bf16-stored tensors of the precision='bf16' mode
+    // (for every storage type: the bf16-storage kernels stay bit-identical to the fp32-storage ones on the widened tensor)
+    const bool v8 = v4 && !SLABS && HW % 8 == 0 && z_bs % 8 == 0 && a_bs % 8 == 0;
+    if (v8) {
+        const int gx8 = max(1, min((HW / 8 + 255) / 256, 16));
+        hipLaunchKernelGGL((bn_stats_kernel<8, ZT, false>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
+        hipLaunchKernelGGL((bn_train_apply_kernel<8, ZT, AT>), dim3(gx8, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+                           partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
+                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr);
+    } else if (v4) {
         hipLaunchKernelGGL((bn_stats_kernel<4, ZT, SLABS>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
         hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
@@ -557,7 +582,11 @@ int bn_relu_bwd_t(const GT* dA, int64_t d_bs, const ZT* z, int64_t z_bs, DT* dz,
                            N, HW, count, mean, rstd, scale, shift, relu, dgamma, dbeta, dbias);
         return aide_launch_status();
     }
-    if (v4) {
+    const bool v8 = v4 && HW % 8 == 0 && z_bs % 8 == 0 && d_bs % 8 == 0 && dz_bs % 8 == 0;
+    if (v8) {
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<8, ZT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<8, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
+    } else if (v4) {
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, ZT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
         hipLaunchKernelGGL((bn_bwd_apply_kernel<4, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
     } else {
