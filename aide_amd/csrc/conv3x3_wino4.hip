@@ -325,69 +325,75 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     const bool pok = oh < a.H && ow < a.W;                 // H, W multiples of 4: a tile is in or out
     auto epilogue = [&](auto PH) {
         constexpr int kph = decltype(PH)::value;
-        auto partial = [&](int r, float* yp) {             // r is a compile-time constant after unrolling
-            float T[3][4];
+        // two accumulator rows (r, r + 1: adjacent registers) per pass as f32x2: the output transform is ~800 scalar VALU
+        // instructions per wave otherwise, on the pipe the MFMAs share -- packed, half of that; the partner exchange moves
+        // 8-byte pairs
+        auto partial = [&](int r, f32x2* yp) {             // r (even) is a compile-time constant after unrolling
+            f32x2 T[3][4];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float m0 = acc[6 * i + f4_slot(0)][r], m1 = acc[6 * i + f4_slot(1)][r], m2 = acc[6 * i + f4_slot(2)][r],
-                            m3 = acc[6 * i + f4_slot(3)][r], m4 = acc[6 * i + f4_slot(4)][r], m5 = acc[6 * i + f4_slot(5)][r];
-                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                auto m = [&](int c) { return f32x2{acc[6 * i + f4_slot(c)][r], acc[6 * i + f4_slot(c)][r + 1]}; };
+                const f32x2 m0 = m(0), m1 = m(1), m2 = m(2), m3 = m(3), m4 = m(4), m5 = m(5);
+                const f32x2 s12 = m1 + m2, d12 = m2 * f32x2{-1.f, -1.f} + m1, s34 = m3 + m4, d34 = m4 * f32x2{-1.f, -1.f} + m3;
                 T[i][0] = m0 + s12 + s34;
-                T[i][1] = __builtin_fmaf(2.f, d34, d12);
-                T[i][2] = __builtin_fmaf(4.f, s34, s12);
-                T[i][3] = __builtin_fmaf(8.f, d34, d12) + m5;
+                T[i][1] = d34 * f32x2{2.f, 2.f} + d12;
+                T[i][2] = s34 * f32x2{4.f, 4.f} + s12;
+                T[i][3] = d34 * f32x2{8.f, 8.f} + d12 + m5;
             }
 #pragma unroll
             for (int bq = 0; bq < 4; ++bq) {
                 if (kph == 0) {                             // A^T columns 0,1,2: (1,0,0,0) (1,1,1,1) (1,-1,1,-1)
-                    const float sm = T[1][bq] + T[2][bq], df = T[1][bq] - T[2][bq];
+                    const f32x2 sm = T[1][bq] + T[2][bq], df = T[2][bq] * f32x2{-1.f, -1.f} + T[1][bq];
                     yp[bq] = T[0][bq] + sm; yp[4 + bq] = df; yp[8 + bq] = sm; yp[12 + bq] = df;
                 } else {                                    // columns 3,4,5: (1,2,4,8) (1,-2,4,-8) (0,0,0,1)
-                    const float sm = T[0][bq] + T[1][bq], df = T[0][bq] - T[1][bq];
-                    yp[bq] = sm; yp[4 + bq] = 2.f * df; yp[8 + bq] = 4.f * sm;
-                    yp[12 + bq] = __builtin_fmaf(8.f, df, T[2][bq]);
+                    const f32x2 sm = T[0][bq] + T[1][bq], df = T[1][bq] * f32x2{-1.f, -1.f} + T[0][bq];
+                    yp[bq] = sm; yp[4 + bq] = df * f32x2{2.f, 2.f}; yp[8 + bq] = sm * f32x2{4.f, 4.f};
+                    yp[12 + bq] = df * f32x2{8.f, 8.f} + T[2][bq];
                 }
             }
         };
+        f32x2* const xbuf2 = reinterpret_cast<f32x2*>(xbuf);       // [wave][row pair 4][output 16][lane] pairs
         // (the main loop ended with a barrier: the staging buffers are free)
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            float yp[16];
-            partial(rr + 8 * (1 - kph), yp);               // the partner's rows
+        for (int rp = 0; rp < 4; ++rp) {
+            f32x2 yp[16];
+            partial(2 * rp + 8 * (1 - kph), yp);           // the partner's rows
 #pragma unroll
-            for (int o = 0; o < 16; ++o) xbuf[((wid * 128) + rr * 16 + o) * 64 + lane] = yp[o];
+            for (int o = 0; o < 16; ++o) xbuf2[((wid * 64) + rp * 16 + o) * 64 + lane] = yp[o];
         }
         __syncthreads();
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            constexpr int dummy = 0; (void)dummy;
-            const int r = rr + 8 * kph;
-            float yp[16];
-            partial(r, yp);
+        for (int rp = 0; rp < 4; ++rp) {
+            f32x2 yp[16];
+            partial(2 * rp + 8 * kph, yp);
 #pragma unroll
-            for (int o = 0; o < 16; ++o) yp[o] += xbuf[(((wid ^ 1) * 128) + rr * 16 + o) * 64 + lane];
-            const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (a.stats) {                                   // wave-uniform
-                float s1 = 0.f, s2 = 0.f;
-                if (pok) {
+            for (int o = 0; o < 16; ++o) yp[o] += xbuf2[(((wid ^ 1) * 64) + rp * 16 + o) * 64 + lane];
 #pragma unroll
-                    for (int o = 0; o < 16; ++o) { s1 += yp[o]; s2 = __builtin_fmaf(yp[o], yp[o], s2); }
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * rp + e + 8 * kph;
+                const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (a.stats) {                                   // wave-uniform
+                    float s1 = 0.f, s2 = 0.f;
+                    if (pok) {
+#pragma unroll
+                        for (int o = 0; o < 16; ++o) { s1 += yp[o][e]; s2 = __builtin_fmaf(yp[o][e], yp[o][e], s2); }
+                    }
+#pragma unroll
+                    for (int m = 16; m > 0; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }   // the 32 tiles of this half
+                    if (j == 0 && co < a.Cout) {
+                        const int nparts = a.N * a.blocks_h * a.blocks_w, blk = (n * a.blocks_h + th) * a.blocks_w + tw;
+                        *reinterpret_cast<f32x2*>(a.stats + ((long)co * nparts + blk) * 2) = f32x2{s1, s2};
+                    }
                 }
+                if (pok && co < a.Cout) {
+                    const float bv = add_bias ? a.bias[co] : 0.f;
 #pragma unroll
-                for (int m = 16; m > 0; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }   // the 32 tiles of this half
-                if (j == 0 && co < a.Cout) {
-                    const int nparts = a.N * a.blocks_h * a.blocks_w, blk = (n * a.blocks_h + th) * a.blocks_w + tw;
-                    *reinterpret_cast<f32x2*>(a.stats + ((long)co * nparts + blk) * 2) = f32x2{s1, s2};
-                }
-            }
-            if (pok && co < a.Cout) {
-                const float bv = add_bias ? a.bias[co] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x4 o = {yp[4 * i] + bv, yp[4 * i + 1] + bv, yp[4 * i + 2] + bv, yp[4 * i + 3] + bv};
-                    f32x4* p = reinterpret_cast<f32x4*>(yn + (long)co * HW + (long)(oh + i) * a.W + ow);
-                    if (a.accumulate) { const f32x4 old = *p; o += old; }
-                    *p = o;
+                    for (int i = 0; i < 4; ++i) {
+                        f32x4 o = {yp[4 * i][e] + bv, yp[4 * i + 1][e] + bv, yp[4 * i + 2][e] + bv, yp[4 * i + 3][e] + bv};
+                        f32x4* p = reinterpret_cast<f32x4*>(yn + (long)co * HW + (long)(oh + i) * a.W + ow);
+                        if (a.accumulate) { const f32x4 old = *p; o += old; }
+                        *p = o;
+                    }
                 }
             }
         }
