@@ -385,7 +385,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
                         *reinterpret_cast<f32x2*>(a.stats + ((long)co * nparts + blk) * 2) = f32x2{s1, s2};
                     }
                 }
+#ifdef AIDE_PROBE_4NOSTORE
+                if (pok && co < a.Cout && a.N < 0) {             // (probe: everything but the output stores)
+#else
                 if (pok && co < a.Cout) {
+#endif
                     const float bv = add_bias ? a.bias[co] : 0.f;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -398,7 +402,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             }
         }
     };
+#ifdef AIDE_PROBE_4NOEPI
+#pragma unroll
+    for (int p = 0; p < 18; ++p) { if (p < F4_NAGPR) asm volatile("" :: "a"(acc[p])); else asm volatile("" :: "v"(acc[p])); }
+    (void)epilogue;
+#else
     if (ph == 0) epilogue(ic<0>{}); else epilogue(ic<1>{});
+#endif
     };   // run
     if (hs == 0) run(ic<0>{}); else run(ic<1>{});
 }
