@@ -434,12 +434,14 @@ __global__ __launch_bounds__(256) void bn_train_fused_kernel(
     }
 }
 
-template <typename ZT, typename DT, typename GT>
+// SLABS: dA is still in the split-K slabs of the data-gradient convolution that produced it ([split][N][C][HW], fp32):
+// the kernel sums them itself in the order of the split reduce (s = 0, 1, ...) -- that launch and its pass disappear.
+template <typename ZT, typename DT, typename GT, bool SLABS = false>
 __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(
     const GT* __restrict__ dA, long d_bs, const ZT* __restrict__ z, long z_bs, DT* __restrict__ dz,
     long dz_bs, int N, int HW, double count, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ scale, const float* __restrict__ shift, int relu, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, float* __restrict__ dbias) {
+    float* __restrict__ dbeta, float* __restrict__ dbias, const SlabSrc sl) {
     __shared__ double sm[3 * 4];
     __shared__ float coef[2];
     const int c = blockIdx.x, hw4 = HW / 4, total4 = N * hw4;
@@ -455,7 +457,8 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(
             float zv[4];
             ldv<4>(z + (long)n * z_bs + (long)c * HW + p * 4, zv);
             float dv[4];
-            ldv<4>(dA + (long)n * d_bs + (long)c * HW + p * 4, dv);
+            if (SLABS) slab_sum<4>(sl, (long)n * sl.slab_bs + (long)c * HW + p * 4, c, dv);
+            else ldv<4>(dA + (long)n * d_bs + (long)c * HW + p * 4, dv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bool on = !relu || fmaf(zv[e], sc, sh) > 0.0f;
@@ -579,7 +582,7 @@ int bn_relu_bwd_t(const GT* dA, int64_t d_bs, const ZT* z, int64_t z_bs, DT* dz,
     const double count = (double)N * HW;
     if (v4 && bn_fused_ok(N, C, HW)) {
         hipLaunchKernelGGL((bn_bwd_fused_kernel<ZT, DT, GT>), dim3(C), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs,
-                           N, HW, count, mean, rstd, scale, shift, relu, dgamma, dbeta, dbias);
+                           N, HW, count, mean, rstd, scale, shift, relu, dgamma, dbeta, dbias, SlabSrc{});
         return aide_launch_status();
     }
     const bool v8 = v4 && HW % 8 == 0 && z_bs % 8 == 0 && d_bs % 8 == 0 && dz_bs % 8 == 0;
@@ -687,6 +690,23 @@ int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void
     return dz_bf16 ? AIDE_BN_BWD_G(float, bf16_t) : AIDE_BN_BWD_G(float, float);
 #undef AIDE_BN_BWD_G
 #undef AIDE_BN_BWD
+}
+
+// Backward of relu(bn(z)) with dA taken from the split-K slabs [splitk][N][C][H][W] of the data-gradient convolution that
+// produced it (launched with accumulate = 2).  Small planes only: aide_bn_two_pass(N, C, H, W) == 0.
+int aide_bn_relu_bwd_slabs(const float* slabs, int splitk, int64_t split_stride, const float* z, int64_t z_bs, float* dz,
+                           int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
+                           const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
+                           hipStream_t stream) {
+    const int HW = H * W;
+    if (!slabs || splitk < 1 || !z || !dz || HW % 4 || z_bs % 4 || dz_bs % 4 || split_stride % 4 || !bn_fused_ok(N, C, HW))
+        return AIDE_ERR_ARG;
+    SlabSrc sl;
+    sl.slabs = slabs; sl.bias = nullptr; sl.split_stride = split_stride; sl.slab_bs = (long)C * HW; sl.splitk = splitk;
+    hipLaunchKernelGGL((bn_bwd_fused_kernel<float, float, float, true>), dim3(C), dim3(256), 0, stream, (const float*)nullptr, 0L,
+                       z, (long)z_bs, dz, (long)dz_bs, N, HW, (double)N * HW, mean, rstd, scale, shift, relu, dgamma, dbeta,
+                       dbias, sl);
+    return aide_launch_status();
 }
 
 int aide_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean,

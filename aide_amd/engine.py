@@ -100,6 +100,7 @@ REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch ta
 HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switch: backward chain on a high-priority stream
 EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B switch: BN statistics from the conv epilogue
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
+FOLD_SPLITK_BWD = [_os.environ.get('AIDE_FOLD_SPLITK_BWD', '1') != '0']   # ... and BatchNorm backward the data-gradient slabs
 FLUSH_EVERY = int(_os.environ.get('AIDE_WGRAD_FLUSH_EVERY', '6'))      # layers per batched slab reduce
 
 
@@ -400,6 +401,28 @@ class Plan(object):
             st['src_grad'] = dict(accumulate=acc, gaps=[src.root.slice(a, b - a) for a, b in gaps])
             if st['kind'] == 'convT' and acc:
                 raise NotImplementedError('ConvTranspose input with several consumers')
+        # A split-K data gradient whose ONLY reader is the BatchNorm backward of the conv right before it (conv1 -> conv2 of
+        # a block) stays in its slabs: that kernel sums them (ops.bn_relu_bwd_slabs) -- one launch and one pass less per pair.
+        for i, st in enumerate(self.steps):
+            st['fold_dgrad'] = False
+            sg = st.get('src_grad')
+            if i == 0 or st['kind'] != 'conv' or sg is None or sg['accumulate'] or sg['gaps'] or not FOLD_SPLITK_BWD[0]:
+                continue
+            prod = self.steps[i - 1]
+            src, dst = st['src'], prod.get('dst')
+            if prod['kind'] != 'conv' or dst is None or dst.root is not src.root or (dst.c0, dst.C) != (src.c0, src.C):
+                continue
+            if sum(1 for o in self.steps if o.get('src') is not None and o['src'].root is src.root
+                   and o['src'].c0 < src.c0 + src.C and src.c0 < o['src'].c0 + o['src'].C) != 1:
+                continue                                   # another reader of (part of) the tensor: its gradient accumulates
+            if st['wino_d'] not in (2, 4) or (st['plan_d'] >> 8) <= 1 or prod.get('dz_bf16') or st.get('dz_bf16'):
+                continue
+            if self.grad[id(src.root)].dtype != torch.float32 or prod['z'].dtype != torch.float32:
+                continue
+            pn, pc, ph, pw = prod['z'].shape
+            if lib.aide_bn_two_pass(pn, pc, ph, pw) or (ph * pw) % 4:
+                continue
+            st['fold_dgrad'] = True
         self._bwd_ready = True
 
     # ------------------------------------------------------------------ forward
@@ -727,6 +750,7 @@ class Plan(object):
             ops.order(self.ev_join, sp, mp)
 
     def _backward_ops(self, inputs, dlogits, gslot, main, side, after_op):
+        folded = 0                       # split count of the data gradient the NEXT BatchNorm backward reads from sk_ws
         for st in reversed(self.steps):
             kind = st['kind']
             sg = st.get('src_grad')
@@ -755,9 +779,14 @@ class Plan(object):
                 conv, bn = st['conv'], st['bn']
                 z = st['z']
                 dz = st['dz']
-                ops.bn_relu_bwd(self.gview(st['dst']), z, dz, st['mean'], st['rstd'], st['scale'],
-                                st['shift'], gslot(bn.weight), gslot(bn.bias), gslot(conv.bias),
-                                self.bn_ws, True)
+                if folded:                     # dA is still in the split-K slabs of the conv after this one
+                    ops.bn_relu_bwd_slabs(self.sk_ws, folded, z, dz, st['mean'], st['rstd'], st['scale'], st['shift'],
+                                          gslot(bn.weight), gslot(bn.bias), gslot(conv.bias), True)
+                    folded = 0
+                else:
+                    ops.bn_relu_bwd(self.gview(st['dst']), z, dz, st['mean'], st['rstd'], st['scale'],
+                                    st['shift'], gslot(bn.weight), gslot(bn.bias), gslot(conv.bias),
+                                    self.bn_ws, True)
                 x = self.view(st['src'], inputs)
                 if kind == 'conv':
                     prof = self.profiler
@@ -789,15 +818,19 @@ class Plan(object):
                                              accumulate=sg['accumulate'], splitk=st['plan_d'] >> 8, ws=self.sk_ws)
                         elif st['wino_d'] == 4:
                             ops.conv3x3_wino4(dz, st['ud'], None, self.gview(st['src']),
-                                              accumulate=sg['accumulate'], splitk=st['plan_d'] >> 8, ws=self.sk_ws)
+                                              accumulate=2 if st['fold_dgrad'] else sg['accumulate'],
+                                              splitk=st['plan_d'] >> 8, ws=self.sk_ws)
                         elif st['wino_d']:
                             ops.conv3x3_wino(dz, st['ud'], None, self.gview(st['src']),
-                                             accumulate=sg['accumulate'], splitk=st['plan_d'] >> 8, ws=self.sk_ws)
+                                             accumulate=2 if st['fold_dgrad'] else sg['accumulate'],
+                                             splitk=st['plan_d'] >> 8, ws=self.sk_ws)
                         else:
                             ops.conv3x3_igemm(dz, st['wd'], None, self.gview(st['src']),
                                               accumulate=sg['accumulate'], plan=st['plan_d'], ws=self.sk_ws)
                         if prof is not None:
                             prof.end()
+                        if st['fold_dgrad']:
+                            folded = st['plan_d'] >> 8
                 else:
                     if side is not None:
                         ops.order(st['ev'], main, side)

@@ -260,6 +260,18 @@ def bn_relu_bwd(dA, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, r
     return dz
 
 
+def bn_relu_bwd_slabs(slabs, splitk, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, relu=True):
+    """bn_relu_bwd whose dA is the split-K slabs [splitk][N][C][H][W] (fp32 tensor `slabs`, at its start) left by the
+    data-gradient convolution (accumulate=2); fp32 z / dz, small planes (lib.aide_bn_two_pass(...) == 0)."""
+    zp, zbs = planes(z)
+    dp, dbs = planes(dz)
+    n, c, h, w = z.shape
+    check(lib.aide_bn_relu_bwd_slabs(ptr(slabs), splitk, n * c * h * w, zp, zbs, dp, dbs, n, c, h, w, ptr(mean), ptr(rstd),
+                                     ptr(scale), ptr(shift), int(relu), ptr(dgamma), ptr(dbeta), ptr(dbias), stream_ptr()),
+          'bn_relu_bwd_slabs')
+    return dz
+
+
 # ------------------------------------------------------------------------------- pool / upsample
 def maxpool2x2_fwd(x, y):
     xp, xbs = planes(x, bf16_ok=True)

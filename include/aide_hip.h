@@ -144,6 +144,14 @@ int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs
                      int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                      const float* scale, const float* shift, int relu, float* dgamma, float* dbeta,
                      float* dbias, void* ws, aide_stream_t stream);
+/* aide_bn_relu_bwd with dA still in the split-K slabs [splitk][N][C][H][W] (fp32, split_stride elements apart) of the
+ * data-gradient convolution that produced it (aide_conv3x3_wino4 / aide_conv3x3_wino launched with accumulate = 2): the
+ * kernel sums the slabs itself, in the order of the split reduce, so that launch and one pass over dA disappear.  Small
+ * planes only (aide_bn_two_pass(N, C, H, W) == 0, where split-K is used); AIDE_ERR_ARG otherwise. */
+int aide_bn_relu_bwd_slabs(const float* slabs, int splitk, int64_t split_stride, const float* z, int64_t z_bs, float* dz,
+                           int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
+                           const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
+                           aide_stream_t stream);
 /* the same three operators on bf16-STORED z / a / dz (precision='bf16'): z_bf16 / a_bf16 / dz_bf16 give the element type behind the
  * untyped pointers; the arithmetic (fp32 per element, fp64 reductions) is unchanged, widening is exact, dz is narrowed RNE */
 int aide_bn_train_fwd_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,

@@ -128,6 +128,55 @@ def test_bn_relu_fwd_bwd(dev, shape):
     assert dbias.abs().max().item() < 1e-3      # mathematically zero (dead conv bias)
 
 
+@pytest.mark.parametrize('case', [(4, 512, 16, 16, 8), (4, 256, 32, 32, 4), (2, 128, 64, 64, 2)])
+def test_bn_relu_bwd_from_splitk_slabs(dev, case):
+    """BatchNorm backward that reads its dA from the split-K slabs of the data-gradient convolution (the engine's
+    conv2 -> conv1 pairs at the 64x64 .. 16x16 levels): bit-identical to the split reduce followed by bn_relu_bwd, and the
+    F(4x4) / F(2x2) kernels leave exactly those slabs with accumulate = 2."""
+    from aide_amd import ops
+    from aide_amd._lib import lib
+    n, c, h, w, splitk = case
+    assert lib.aide_bn_two_pass(n, c, h, w) == 0
+    g = torch.Generator().manual_seed(c + h)
+    z = (torch.randn(n, c, h, w, generator=g) * 2.0).to(dev)
+    slabs = torch.randn(splitk, n, c, h, w, generator=g).to(dev)
+    dA = slabs[0].clone()
+    for s in range(1, splitk):
+        dA += slabs[s]                                     # the order of the split reduce
+    mean, rstd, scale, shift = (torch.empty(c, device=dev) for _ in range(4))
+    ws = ops.bn_ws(c, dev)
+    rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    ops.bn_train_fwd(z, torch.empty_like(z), torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.3, 1e-5, 0.1,
+                     rm, rv, nbt, mean, rstd, scale, shift, ws, True)
+    ref = [torch.empty_like(z)] + [torch.empty(c, device=dev) for _ in range(3)]
+    ops.bn_relu_bwd(dA, z, ref[0], mean, rstd, scale, shift, ref[1], ref[2], ref[3], ws, True)
+    out = [torch.empty_like(z)] + [torch.empty(c, device=dev) for _ in range(3)]
+    ops.bn_relu_bwd_slabs(slabs, splitk, z, out[0], mean, rstd, scale, shift, out[1], out[2], out[3], True)
+    for a, b, what in zip(out, ref, ('dz', 'dgamma', 'dbeta', 'dbias')):
+        assert torch.equal(a, b), what
+    # the convolution side: accumulate = 2 leaves the slabs, their sum in split order is the reduced result
+    ci = c
+    x = torch.randn(n, ci, h, w, generator=g).to(dev)
+    wt = (torch.randn(c, ci, 3, 3, generator=g) * 0.05).to(dev)
+    for pack, conv, sk in ((ops.wino4_pack, ops.conv3x3_wino4, lib.aide_conv3x3_wino4_splitk(n, ci, h, w, c)),
+                           (ops.wino_pack, ops.conv3x3_wino, lib.aide_conv3x3_wino_splitk(n, ci, h, w, c))):
+        if conv is ops.conv3x3_wino4 and not ops.wino4_supported(ci, h, w, c):
+            continue
+        if sk <= 1:
+            continue
+        u, _ = pack(wt)
+        wsk = torch.zeros(sk * n * c * h * w, device=dev)
+        y = conv(x, u, None, torch.empty(n, c, h, w, device=dev), splitk=sk, ws=wsk)
+        wsk2 = torch.zeros_like(wsk)
+        conv(x, u, None, torch.empty(n, c, h, w, device=dev), accumulate=2, splitk=sk, ws=wsk2)
+        sl = wsk2.view(sk, n, c, h, w)
+        acc = sl[0].clone()
+        for s in range(1, sk):
+            acc += sl[s]
+        assert torch.equal(acc, y)
+
+
 def test_maxpool_ties_and_backward(dev):
     from aide_amd import ops
     g = torch.Generator().manual_seed(3)
