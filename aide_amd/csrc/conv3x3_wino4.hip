@@ -46,7 +46,11 @@ constexpr int F4_RCS = 775;                // raw channel stride: (41, 775) make
 constexpr int F4_RAW = 4 * F4_RCS;         // 3100 floats
 constexpr int F4_V = 36 * 32 * 4;          // V[p][2 channel pairs][32 tiles][2]
 constexpr int F4_SET = F4_RAW + F4_V;      // 7708 floats = 30832 B; two sets = 60.2 KB (filters never touch LDS)
+#if defined(AIDE_PROBE_4HALF) && !defined(AIDE_PROBE_4HALF_ONE)
+constexpr int F4_LDS = 2 * F4_SET;                       // (probe) two workgroups per CU; _ONE: the same kernel held at one
+#else
 constexpr int F4_LDS = 2 * F4_SET > 4 * 128 * 64 ? 2 * F4_SET : 4 * 128 * 64;   // epilogue swap needs 32768
+#endif
 
 // Position pairs: pair q = 3 i + t of transform row i holds columns (1,2), (3,4), (0,5) for t = 0, 1, 2 (the pairs the packed
 // input transform produces).  Accumulator slot 2 q + b <-> position F4_P(q, b); slot of column c in row i: F4_SLOT.
@@ -67,7 +71,15 @@ __device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, floa
     o[5 * st] = __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5));
 }
 
+#ifdef AIDE_PROBE_4HALF
+// (timing probe, wrong results) half of the positions per workgroup -- 9 accumulators, 18 MFMAs per stage -- so that TWO
+// workgroups fit a CU (2 waves per SIMD): does a co-resident workgroup hide the fixed cost and the stalls of the other?
+#define F4_PROBE_KEEP(g, w) ((g) == 0 || (g) == 2 || (g) == 4 || (g) == 6)       /* 8 accumulators, 16 MFMAs per stage */
+__global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const W4Args a) {
+#else
+#define F4_PROBE_KEEP(g, w) true
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform (scalar) roles
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
 #pragma unroll
     for (int l = 0; l < 4; ++l) fetch(l, s_begin);
 #pragma unroll
-    for (int q = 0; q < 9; ++q) fetch_u(q, s_begin, ua[0]);
+    for (int q = 0; q < 9; ++q) if (F4_PROBE_KEEP(q, 0)) fetch_u(q, s_begin, ua[0]);
 #pragma unroll
     for (int w = 0; w < 13; ++w) put_raw(w, set0);
 #pragma unroll
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
         const float* lb = sc + F4_RAW + (9 * ph) * 256 + half * 128 + ((j * 4) ^ (half * 16));
         auto frag = [&](int q, int slot3) { fb[slot3] = *reinterpret_cast<const f32x4*>(lb + q * 256); };
 #ifndef AIDE_F4_EARLY_BARRIER
-        frag(0, 0); frag(1, 1);
+        frag(0, 0); if (F4_PROBE_KEEP(1, 0)) frag(1, 1);
 #endif
 #pragma unroll
         for (int st = 0; st < 36; ++st) {
@@ -261,18 +273,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             // slot order inside a position pair g: (2g,k0) (2g+1,k0) (2g,k1) (2g+1,k1)
             const int g = st >> 2, w = st & 3, pi = 2 * g + (w & 1), k = w >> 1;
             const int fs = g % 3;
-            if (w == 0 && g + 2 < 9) frag(g + 2, (g + 2) % 3);          // fragments of a pair, two pairs (8 slots) ahead
+            if (w == 0 && g + 2 < 9 && F4_PROBE_KEEP(g + 2, 0)) frag(g + 2, (g + 2) % 3);   // fragments of a pair, two pairs (8 slots) ahead
             // 18 x 16 accumulator registers exceed the 256 AGPRs: positions 16 and 17 are pinned to VGPRs,
             // and the register classes are spelled out (hipcc otherwise shuffles whole accumulators
             // between the two files every stage)
-            if (pi < F4_NAGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pi]) : "v"(ua[kcur][g][(w & 1) * 2 + k]), "v"(fb[fs][k * 2 + (w & 1)]));
+            if (!F4_PROBE_KEEP(g, w)) {}
+            else if (pi < F4_NAGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pi]) : "v"(ua[kcur][g][(w & 1) * 2 + k]), "v"(fb[fs][k * 2 + (w & 1)]));
             else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[pi]) : "v"(ua[kcur][g][(w & 1) * 2 + k]), "v"(fb[fs][k * 2 + (w & 1)]));
             // staging schedule: only slot 20 carries vector-ALU work
             //   0..3 raw[s+2] global fetches, 4..21 U[s+1] fragment fetches;  0..17 patch reads (2 per slot)
             //   20 transform;  21..29 V stores (2 per slot);  31..35 raw stores (3 per slot)
 #ifndef AIDE_PROBE_4NOFETCH
             if (st < 4) fetch(st, s + 2);
-            else if (st < 22 && ((st - 4) & 1) == 0) fetch_u((st - 4) >> 1, s + 1, ua[1 - kcur]);
+            else if (st < 22 && ((st - 4) & 1) == 0 && F4_PROBE_KEEP((st - 4) >> 1, 0)) fetch_u((st - 4) >> 1, s + 1, ua[1 - kcur]);
 #endif
 #ifdef AIDE_F4_EARLY_BARRIER
             constexpr int XM = 18, XS = 19, PR = 27;        // transform slot, first V-store slot, first raw-store slot
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     };
 #ifdef AIDE_PROBE_4NOEPI
 #pragma unroll
-    for (int p = 0; p < 18; ++p) { if (p < F4_NAGPR) asm volatile("" :: "a"(acc[p])); else asm volatile("" :: "v"(acc[p])); }
+    for (int p = 0; p < 18; ++p) { if (!F4_PROBE_KEEP(p >> 1, p & 1)) continue; if (p < F4_NAGPR) asm volatile("" :: "a"(acc[p])); else asm volatile("" :: "v"(acc[p])); }
     (void)epilogue;
 #else
     if (ph == 0) epilogue(ic<0>{}); else epilogue(ic<1>{});
