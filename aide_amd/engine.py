@@ -53,8 +53,10 @@ class Graph(object):
         self.inputs.append(t)
         return t
 
-    def conv_bn_relu(self, src, dst, conv, bn):
-        self.ops.append(dict(kind='conv', src=src, dst=dst, conv=conv, bn=bn))
+    def conv_bn_relu(self, src, dst, conv, bn, lane=0):
+        """lane = 1 marks a chain that is independent of the lane-0 ops next to it (the second encoder of a two-modality
+        net): the forward pass may run it on a second stream (Plan._forward_impl)."""
+        self.ops.append(dict(kind='conv', src=src, dst=dst, conv=conv, bn=bn, lane=lane))
 
     def convT_bn_relu(self, src, dst, conv, bn):
         self.ops.append(dict(kind='convT', src=src, dst=dst, conv=conv, bn=bn))
@@ -100,6 +102,7 @@ REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch ta
 HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switch: backward chain on a high-priority stream
 EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B switch: BN statistics from the conv epilogue
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
+DUAL_FWD = [_os.environ.get('AIDE_DUAL_FWD', '1') != '0']        # A-B switch: lane-1 chains of the forward pass on a second stream
 FOLD_SPLITK_BWD = [_os.environ.get('AIDE_FOLD_SPLITK_BWD', '1') != '0']   # ... and BatchNorm backward the data-gradient slabs
 FLUSH_EVERY = int(_os.environ.get('AIDE_WGRAD_FLUSH_EVERY', '6'))      # layers per batched slab reduce
 
@@ -329,6 +332,12 @@ class Plan(object):
                 self.narrow_grad[id(st['src'].root)] = False
         self.bn_ws = ops.bn_ws(max(max_bnc, 1), device)
         self.sk_ws = torch.empty(max(max_sk // 4, 1), **f32)
+        self.lane_b = None               # second forward stream + its own BatchNorm / split-K workspaces (lane-1 chains)
+        if any(st.get('lane') for st in self.steps):
+            self.lane_b = torch.cuda.Stream(device=device)
+            self.bn_ws_b = ops.bn_ws(max(max_bnc, 1), device)
+            self.sk_ws_b = torch.empty(max(max_sk // 4, 1), **f32)
+            self.ev_lane_fork, self.ev_lane_join = ops.new_event(), ops.new_event()
         self._max_dz, self._max_wg = max_dz, max_wg
         self.wg_ws = None
         self._bwd_ready = False
@@ -551,21 +560,55 @@ class Plan(object):
         return out
 
     def _forward_impl(self, inputs, out, gate, tape):
+        import ctypes
         n = self.N
+        # Two lanes: the ops a graph marks lane = 1 (the second encoder of a two-modality net: an independent conv -> BN ->
+        # conv -> BN chain per level) run on a second stream, beside the lane-0 chain of the same level -- one chain's
+        # HBM-bound BatchNorm and launch boundaries under the other's convolutions.  Fork: lane 1 waits for everything
+        # enqueued on the main stream so far; join: before the first main-stream op that touches channels lane 1 wrote.
+        dual = self.lane_b is not None and DUAL_FWD[0] and self.profiler is None and self.trace is None
+        mp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        bp = ctypes.c_void_p(self.lane_b.cuda_stream) if dual else None
+        on_b, pend = False, []
+
+        def overlaps(t):
+            return any(r is t.root and c0 < t.c0 + t.C and t.c0 < c0 + c for r, c0, c in pend)
         for st in self.steps:
             kind = st['kind']
             if self.trace is not None:
                 self.trace('f', st)
             if self._late_pending is not None:
                 self._late_pack(st)
+            lane = st.get('lane', 0) if dual else 0
+            if kind == 'conv' and st is self._gate_conv:      # (when) the remaining filters were re-packed on the side stream
+                wait = lambda: torch.cuda.current_stream().wait_stream(self.side_fwd)
+                if tape is not None:
+                    tape.py(wait, 'gate')
+                if gate is not None:
+                    wait()
+            if lane and not on_b:
+                ops.order(self.ev_lane_fork, mp, bp)
+            on_b = bool(lane)
+            if not lane and pend and (overlaps(st['src']) or (st.get('dst') is not None and overlaps(st['dst']))):
+                ops.order(self.ev_lane_join, bp, mp)
+                del pend[:]
+            if lane:
+                pend.append((st['dst'].root, st['dst'].c0, st['dst'].C))
+                with ops.use_stream(bp):
+                    self._forward_op(st, inputs, out, self.bn_ws_b, self.sk_ws_b)
+            else:
+                self._forward_op(st, inputs, out, self.bn_ws, self.sk_ws)
+        if pend:
+            ops.order(self.ev_lane_join, bp, mp)
+        if self._late_pending is not None:
+            self._late_pack(None)
+        return out
+
+    def _forward_op(self, st, inputs, out, bn_ws, sk_ws):
+        kind = st['kind']
+        if True:
             if kind == 'conv':
                 conv, bn = st['conv'], st['bn']
-                if st is self._gate_conv:      # (when) the remaining filters were re-packed on the side stream
-                    wait = lambda: torch.cuda.current_stream().wait_stream(self.side_fwd)
-                    if tape is not None:
-                        tape.py(wait, 'gate')
-                    if gate is not None:
-                        wait()
                 x = self.view(st['src'], inputs)
                 prof = self.profiler
                 if prof is not None:
@@ -578,20 +621,20 @@ class Plan(object):
                 if st['stats'] is not None:        # one-shot: this launch writes the BatchNorm statistics partials
                     lib.aide_conv_stats_sink(ops.ptr(st['stats']))
                 if st['wino_f'] == BF16:
-                    ops.conv3x3_bf16(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=self.sk_ws)
+                    ops.conv3x3_bf16(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=sk_ws)
                 elif st['wino_f'] == 4:
-                    ops.conv3x3_wino4(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=self.sk_ws)
+                    ops.conv3x3_wino4(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=sk_ws)
                 elif st['wino_f']:
-                    ops.conv3x3_wino(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=self.sk_ws)
+                    ops.conv3x3_wino(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=sk_ws)
                 else:
-                    ops.conv3x3_igemm(x, st['wf'], conv.bias, st['z'], accumulate=acc, plan=st['plan_f'], ws=self.sk_ws)
+                    ops.conv3x3_igemm(x, st['wf'], conv.bias, st['z'], accumulate=acc, plan=st['plan_f'], ws=sk_ws)
                 if prof is not None:
                     prof.end()
-                self._bn_apply(st, bn, conv.bias if slabs else None, (st['plan_f'] >> 8) if slabs else 0)
+                self._bn_apply(st, bn, conv.bias if slabs else None, (st['plan_f'] >> 8) if slabs else 0, bn_ws, sk_ws)
             elif kind == 'convT':
                 conv, bn = st['conv'], st['bn']
                 ops.convT2x2_fwd(self.view(st['src'], inputs), conv.weight, conv.bias, st['z'])
-                self._bn_apply(st, bn)
+                self._bn_apply(st, bn, None, 0, bn_ws, sk_ws)
             elif kind == 'pool':
                 ops.maxpool2x2_fwd(self.view(st['src'], inputs), self.view(st['dst']))
             elif kind == 'up':
@@ -616,14 +659,13 @@ class Plan(object):
                 else:
                     ops.sa_gate_fwd(st['t4'], m.bn, self.training, st['stat'], st['gate'])
                 ops.sa_mul(st['gate'], y, self.view(st['dst']))
-        if self._late_pending is not None:
-            self._late_pack(None)
-        return out
 
-    def _bn_apply(self, st, bn, slab_bias=None, splitk=0):
+    def _bn_apply(self, st, bn, slab_bias=None, splitk=0, bn_ws=None, sk_ws=None):
         """BatchNorm(+ReLU) of one conv output.  splitk > 0: z is still in the split-K slabs of self.sk_ws
         ([splitk][N][C][H][W]) -- the BatchNorm kernels sum them, add `slab_bias` and write z themselves."""
         z, a = st['z'], self.view(st['dst'])
+        bn_ws = self.bn_ws if bn_ws is None else bn_ws
+        sk_ws = self.sk_ws if sk_ws is None else sk_ws
         ngroups = self.groups if (self.training and self.groups > 1) else 1
         m = self.N // ngroups
         if self.training:
@@ -637,14 +679,14 @@ class Plan(object):
                                            st['mean'], st['rstd'], st['scale'], st['shift'], True)
                 elif splitk > 0:
                     import ctypes
-                    sl = ctypes.c_void_p(self.sk_ws.data_ptr() + 4 * gi * m * per_img)
+                    sl = ctypes.c_void_p(sk_ws.data_ptr() + 4 * gi * m * per_img)
                     ops.bn_train_fwd_slabs(sl, splitk, stride, slab_bias, zg, ag, bn.weight, bn.bias, bn.eps, bn.momentum,
                                            bn.running_mean, bn.running_var, bn.num_batches_tracked, st['mean'],
-                                           st['rstd'], st['scale'], st['shift'], self.bn_ws, True)
+                                           st['rstd'], st['scale'], st['shift'], bn_ws, True)
                 else:
                     ops.bn_train_fwd(zg, ag, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
                                      bn.num_batches_tracked, st['mean'], st['rstd'], st['scale'], st['shift'],
-                                     self.bn_ws, True)
+                                     bn_ws, True)
         else:
             ops.bn_eval_coeff(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, st['scale'],
                               st['shift'])

@@ -66,13 +66,15 @@ class fuseunet(nn.Module):
             for m, src, d, cw in (('modal2', src2, d2, c2[s - 1]), ('modal1', src1, d1, c1[s - 1])):
                 blk = getattr(self, '%s_downblock%d' % (m, s)).block
                 t = g.tensor('%s_s%d_mid' % (m, s), cw, lvl)
-                g.conv_bn_relu(src, t, blk.conv1, blk.bn1)
+                # the two encoders of a level are independent chains: modal-2's may run beside modal-1's (second stream)
+                lane = 1 if (m == 'modal2' and not self._ATTENTION) else 0
+                g.conv_bn_relu(src, t, blk.conv1, blk.bn1, lane=lane)
                 if self._ATTENTION:            # y = sa(y) * y  (fuseunet.py:139-141): the gated tensor is the skip
                     pre = g.tensor('%s_s%d_pre' % (m, s), cw, lvl)
                     g.conv_bn_relu(t, pre, blk.conv2, blk.bn2)
                     g.spatial_attention(pre, d, getattr(self, '%s_sa%d' % (m, s)))
                 else:
-                    g.conv_bn_relu(t, d, blk.conv2, blk.bn2)
+                    g.conv_bn_relu(t, d, blk.conv2, blk.bn2, lane=lane)
             if s < 5:
                 p = g.tensor('pool_s%d' % s, skip.C, s)
                 g.pool(skip, p)
