@@ -153,10 +153,17 @@ class GradAllReduce(object):
             if side is not None:                           # ... the weight gradients on the side stream
                 ev2 = torch.cuda.Event()
                 ev2.record(side)
+            lane = getattr(self.engine, 'lane_stream', None)
+            ev3 = None
+            if lane is not None:                           # ... and the second encoder's lane (BatchNorm parameter gradients)
+                ev3 = torch.cuda.Event()
+                ev3.record(lane)
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 if ev2 is not None:
                     self.comm_stream.wait_event(ev2)
+                if ev3 is not None:
+                    self.comm_stream.wait_event(ev3)
                 self._reduce(view, avg)
         else:
             self._reduce(view, avg)

@@ -102,6 +102,7 @@ REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch ta
 HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switch: backward chain on a high-priority stream
 EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B switch: BN statistics from the conv epilogue
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
+DUAL_BWD = [_os.environ.get('AIDE_DUAL_BWD', '0') != '0']        # ... and of the backward pass (measured +-0 beside the weight-gradient stream: off)
 DUAL_FWD = [_os.environ.get('AIDE_DUAL_FWD', '1') != '0']        # A-B switch: lane-1 chains of the forward pass on a second stream
 FOLD_SPLITK_BWD = [_os.environ.get('AIDE_FOLD_SPLITK_BWD', '1') != '0']   # ... and BatchNorm backward the data-gradient slabs
 FLUSH_EVERY = int(_os.environ.get('AIDE_WGRAD_FLUSH_EVERY', '6'))      # layers per batched slab reduce
@@ -337,7 +338,7 @@ class Plan(object):
             self.lane_b = torch.cuda.Stream(device=device)
             self.bn_ws_b = ops.bn_ws(max(max_bnc, 1), device)
             self.sk_ws_b = torch.empty(max(max_sk // 4, 1), **f32)
-            self.ev_lane_fork, self.ev_lane_join = ops.new_event(), ops.new_event()
+            self.ev_lane_fork, self.ev_lane_join, self.ev_lane_acc = ops.new_event(), ops.new_event(), ops.new_event()
         self._max_dz, self._max_wg = max_dz, max_wg
         self.wg_ws = None
         self._bwd_ready = False
@@ -792,12 +793,49 @@ class Plan(object):
             ops.order(self.ev_join, sp, mp)
 
     def _backward_ops(self, inputs, dlogits, gslot, main, side, after_op):
-        folded = 0                       # split count of the data gradient the NEXT BatchNorm backward reads from sk_ws
+        """The backward launch sequence.  Two lanes as in the forward pass: the lane-1 chains (second encoder) run on their
+        own stream beside the lane-0 chain of the same level.  Lane 1 is released after every lane-0 op that is not a
+        conv (the pool / up-sampling backward that produces the level's skip gradient), waits for the main stream before a
+        data gradient that ACCUMULATES into a buffer lane 0 writes first, and is joined before the first main-stream op
+        that touches a gradient range it wrote (and at the end)."""
+        import ctypes
+        dual = self.lane_b is not None and DUAL_BWD[0] and side is not None and self.profiler is None and \
+            self.trace is None and not HP_CHAIN[0]
+        bp = ctypes.c_void_p(self.lane_b.cuda_stream) if dual else None
+        fold = [[0], [0]]                # per lane: split count of the data gradient the NEXT BatchNorm backward reads from its sk_ws
+        pend = []                        # gradient ranges lane 1 wrote since the last join
+
+        def overlaps(t):
+            return t is not None and any(r is t.root and c0 < t.c0 + t.C and t.c0 < c0 + c for r, c0, c in pend)
         for st in reversed(self.steps):
-            kind = st['kind']
+            lane = st.get('lane', 0) if dual else 0
             sg = st.get('src_grad')
             if self.trace is not None:
                 self.trace('b', st)
+            if lane:
+                if sg is not None and (sg['accumulate'] or sg['gaps']):
+                    ops.order(self.ev_lane_acc, main, bp)      # lane 0 wrote (or zeroed) the buffer first
+                if sg is not None:
+                    pend.append((st['src'].root, st['src'].c0, st['src'].C))
+                with ops.use_stream(bp):
+                    self._backward_op(st, inputs, dlogits, gslot, bp, side, self.bn_ws_b, self.sk_ws_b, fold[1])
+            else:
+                if pend and (overlaps(st.get('dst')) or overlaps(st.get('src'))):
+                    ops.order(self.ev_lane_join, bp, main)
+                    del pend[:]
+                self._backward_op(st, inputs, dlogits, gslot, main, side, self.bn_ws, self.sk_ws, fold[0])
+                if dual and st['kind'] != 'conv':
+                    ops.order(self.ev_lane_fork, main, bp)     # the gradients this op wrote release lane 1
+            if after_op is not None:
+                after_op(st)
+        if dual:
+            ops.order(self.ev_lane_join, bp, main)
+
+    def _backward_op(self, st, inputs, dlogits, gslot, main, side, bn_ws, sk_ws, folded):
+        """one op of the backward sequence on stream `main` (its lane's stream); folded: [split count] cell of the lane"""
+        if True:
+            kind = st['kind']
+            sg = st.get('src_grad')
             if sg is not None:
                 for gap in sg['gaps']:
                     ops.fill_zero(self.gview(gap))
@@ -821,14 +859,14 @@ class Plan(object):
                 conv, bn = st['conv'], st['bn']
                 z = st['z']
                 dz = st['dz']
-                if folded:                     # dA is still in the split-K slabs of the conv after this one
-                    ops.bn_relu_bwd_slabs(self.sk_ws, folded, z, dz, st['mean'], st['rstd'], st['scale'], st['shift'],
+                if folded[0]:                  # dA is still in the split-K slabs of the conv after this one
+                    ops.bn_relu_bwd_slabs(sk_ws, folded[0], z, dz, st['mean'], st['rstd'], st['scale'], st['shift'],
                                           gslot(bn.weight), gslot(bn.bias), gslot(conv.bias), True)
-                    folded = 0
+                    folded[0] = 0
                 else:
                     ops.bn_relu_bwd(self.gview(st['dst']), z, dz, st['mean'], st['rstd'], st['scale'],
                                     st['shift'], gslot(bn.weight), gslot(bn.bias), gslot(conv.bias),
-                                    self.bn_ws, True)
+                                    bn_ws, True)
                 x = self.view(st['src'], inputs)
                 if kind == 'conv':
                     prof = self.profiler
@@ -857,22 +895,22 @@ class Plan(object):
                             prof.begin(FWD_TAG[st['wino_d']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_d']])
                         if st['wino_d'] == BF16:
                             ops.conv3x3_bf16(dz, st['ud'], None, self.gview(st['src']),
-                                             accumulate=sg['accumulate'], splitk=st['plan_d'] >> 8, ws=self.sk_ws)
+                                             accumulate=sg['accumulate'], splitk=st['plan_d'] >> 8, ws=sk_ws)
                         elif st['wino_d'] == 4:
                             ops.conv3x3_wino4(dz, st['ud'], None, self.gview(st['src']),
                                               accumulate=2 if st['fold_dgrad'] else sg['accumulate'],
-                                              splitk=st['plan_d'] >> 8, ws=self.sk_ws)
+                                              splitk=st['plan_d'] >> 8, ws=sk_ws)
                         elif st['wino_d']:
                             ops.conv3x3_wino(dz, st['ud'], None, self.gview(st['src']),
                                              accumulate=2 if st['fold_dgrad'] else sg['accumulate'],
-                                             splitk=st['plan_d'] >> 8, ws=self.sk_ws)
+                                             splitk=st['plan_d'] >> 8, ws=sk_ws)
                         else:
                             ops.conv3x3_igemm(dz, st['wd'], None, self.gview(st['src']),
-                                              accumulate=sg['accumulate'], plan=st['plan_d'], ws=self.sk_ws)
+                                              accumulate=sg['accumulate'], plan=st['plan_d'], ws=sk_ws)
                         if prof is not None:
                             prof.end()
                         if st['fold_dgrad']:
-                            folded = st['plan_d'] >> 8
+                            folded[0] = st['plan_d'] >> 8
                 else:
                     if side is not None:
                         ops.order(st['ev'], main, side)
@@ -910,8 +948,6 @@ class Plan(object):
                 if sg is not None:
                     ops.upsample2x_bwd(self.gview(st['dst']), self.gview(st['src']),
                                        accumulate=sg['accumulate'])
-            if after_op is not None:
-                after_op(st)
 
 
 class _NetFunction(torch.autograd.Function):
@@ -940,9 +976,11 @@ class _NetFunction(torch.autograd.Function):
         dlogits = dlogits.contiguous()
         flat = torch.empty(eng.flat_numel, device=dlogits.device, dtype=torch.float32)
         eng.side_stream = plan.side if (plan._bwd_ready and plan.overlap) else None
+        eng.lane_stream = plan.lane_b if (plan.overlap and DUAL_BWD[0]) else None
         if not plan._bwd_ready:
             plan._prepare_backward()
             eng.side_stream = plan.side if plan.overlap else None
+            eng.lane_stream = plan.lane_b if (plan.overlap and DUAL_BWD[0]) else None
         if eng.before_backward is not None:
             eng.before_backward(flat)
         plan.backward(ctx.inputs, dlogits, flat, eng.offsets, eng.after_backward_op)
@@ -965,6 +1003,7 @@ class Engine(object):
         self.profiler = None             # object with begin(tag, flops) / end(): per-kernel HIP events
         self.before_backward = None      # callable(flat_grad) at the start of every backward
         self.side_stream = None          # stream carrying the weight-gradient kernels of the running backward
+        self.lane_stream = None          # ... and the stream of the lane-1 chains (second encoder), if any
         self.graph = None
         self._precision = 'fp32'
 
