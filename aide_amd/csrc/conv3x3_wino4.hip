@@ -36,6 +36,7 @@ struct W4Args {
     long x_bs, y_bs, split_stride;
     int N, Cin, H, W, Cout;
     int blocks_w, blocks_h, n_co_tiles, splitk, stages_total, accumulate;
+    int pair;            // W == 16: a workgroup tile is 16 rows x (16 columns of image 2n | 16 columns of image 2n + 1)
     float* stats;        // optional [Cout][N * blocks_h * blocks_w][2]: per (channel, workgroup tile) sum / sum of squares of the
                          // pre-bias outputs -- the BatchNorm statistics of the forward pass without a pass over z
 };
@@ -94,6 +95,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     const int n = b / a.blocks_h;
     const int h0 = th * 16, w0 = tw * 32, co0 = co_tile * 64;
     const int HW = a.H * a.W;
+    // 16-pixel-wide images (the 16 x 16 bottleneck level): the 32-column tile holds the rows of TWO images side by side, each
+    // with its own zero halo columns -- raw row [3 pad][-1][A 0..15][16][-1][B 0..15][16]: image B sits two words further right.
+    // Only these stage-invariant descriptors and the output addresses know about it; the main loop is the same.
+    const int pair = a.pair;
 
     const int sps = a.stages_total / a.splitk;             // even, and splitk divides stages_total (host)
     const int s_begin = split * sps;
@@ -109,21 +114,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
         if (q >= 576) q -= 256;
         const int c = q / 144, rem = q - c * 144, r = rem >> 3, s4 = rem & 7;
         const int ih = h0 - 1 + r, iw = w0 + 4 * s4;
-        const bool ok = ih >= 0 && ih < a.H && iw < a.W;
-        offB[e] = ok ? (unsigned)(c * HW + r * a.W + 1 + 4 * s4) * 4u : BUF_OOB;
-        ldsB[e] = (unsigned)(c * F4_RCS + r * F4_RRS + 4 + 4 * s4);
+        const int imgB = pair && s4 >= 4;
+        const bool ok = ih >= 0 && ih < a.H && (pair || iw < a.W);
+        offB[e] = ok ? (unsigned)((long)imgB * a.x_bs + c * HW + r * a.W + 1 + 4 * (pair ? (s4 & 3) : s4)) * 4u : BUF_OOB;
+        ldsB[e] = (unsigned)(c * F4_RCS + r * F4_RRS + 4 + 4 * s4 + 2 * imgB);
     }
     {
         int q = tid;
         if (q >= 144) q -= 144;
         const int c = q / 36, rem = q - c * 36, r = rem >> 1, side = rem & 1;
         const int ih = h0 - 1 + r, iw = side ? w0 + 32 : w0 - 1;
-        const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        const bool ok = !pair && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
         offC = ok ? (unsigned)(c * HW + r * a.W + (side ? 33 : 0)) * 4u : BUF_OOB;
-        ldsC = (unsigned)(c * F4_RCS + r * F4_RRS + (side ? 36 : 3));
+        // (pair: every halo column is an image border; the edge units keep the two seam columns zero, the outer two are
+        // zeroed once in the prologue)
+        ldsC = (unsigned)(c * F4_RCS + r * F4_RRS + (pair ? (side ? 21 : 20) : (side ? 36 : 3)));
     }
     const __amdgpu_buffer_rsrc_t xrs =
-        make_rsrc(a.x + (long)n * a.x_bs + (long)h0 * a.W + w0 - (a.W + 1));
+        make_rsrc(a.x + (long)(pair ? 2 * n : n) * a.x_bs + (long)h0 * a.W + w0 - (a.W + 1));
     // Filter fragments go global -> registers, never through LDS: wave (cb, ph) is the only consumer of
     // U[p in its half][co in its block], and the packed layout [stage][p][pair][Co][2] makes one position a
     // contiguous 512-byte dwordx2 load in exactly the MFMA A-operand lane order (lane = pair * 32 + co).
@@ -157,7 +165,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
 
     // ---- input transform: thread = (half hs, ci, tile) ----
     const int item = tid & 127, hs = wid >> 1;             // hs is wave-uniform
-    const int xr_off = (item & 3) * F4_RCS + (item >> 5) * 4 * F4_RRS + 3 + 4 * ((item >> 2) & 7);
+    const int xr_off = (item & 3) * F4_RCS + (item >> 5) * 4 * F4_RRS + 3 + 4 * ((item >> 2) & 7) +
+                       ((pair && ((item >> 2) & 7) >= 4) ? 2 : 0);
     // patch rows as pairs of columns: the column pass is element-wise over columns -> v_pk_fma_f32 / v_pk_add_f32
     f32x2 tp[6][3];
     f32x2 tq[9];
@@ -232,6 +241,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     for (int l = 0; l < 4; ++l) fetch(l, s_begin);
 #pragma unroll
     for (int q = 0; q < 9; ++q) if (F4_PROBE_KEEP(q, 0)) fetch_u(q, s_begin, ua[0]);
+    if (pair) {                                            // the outer halo columns (-1 of A, 16 of B) of both sets, once
+        for (int q = tid; q < 2 * 4 * 18 * 2; q += 256) {
+            const int set = q / 144, rem = q - set * 144, c = rem / 36, rr = (rem % 36) >> 1, side = rem & 1;
+            lds[set * F4_SET + c * F4_RCS + rr * F4_RRS + (side ? 38 : 3)] = 0.f;
+        }
+    }
 #pragma unroll
     for (int w = 0; w < 13; ++w) put_raw(w, set0);
 #pragma unroll
@@ -332,9 +347,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     // The wave with ph = 0 finishes accumulator rows r < 8, its partner r >= 8; the other half of the
     // partials travels through LDS ([wave][128][64 lanes]).
     float* xbuf = lds;
-    float* yn = a.y + (long)split * a.split_stride + (long)n * a.y_bs;
+    float* yn = a.y + (long)split * a.split_stride + (long)(pair ? 2 * n + ((j & 7) >> 2) : n) * a.y_bs;
     const bool add_bias = (a.bias != nullptr) && (split == 0);
-    const int oh = h0 + 4 * (j >> 3), ow = w0 + 4 * (j & 7);
+    const int oh = h0 + 4 * (j >> 3), ow = pair ? 4 * (j & 3) : w0 + 4 * (j & 7);
     const bool pok = oh < a.H && ow < a.W;                 // H, W multiples of 4: a tile is in or out
     auto epilogue = [&](auto PH) {
         constexpr int kph = decltype(PH)::value;
@@ -543,11 +558,12 @@ __global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc*
 extern "C" {
 
 int aide_conv3x3_wino4_supported(int Cin, int H, int W, int Cout) {
-    return (H % 4 == 0 && W % 4 == 0 && H >= 16 && W >= 32 && Cout % 32 == 0 && Cin % 8 == 0) ? 1 : 0;
+    // W == 16: two images per workgroup tile (the caller's N must be even: checked at launch and in aide_conv3x3_wino4_splitk)
+    return (H % 4 == 0 && W % 4 == 0 && H >= 16 && (W >= 32 || W == 16) && Cout % 32 == 0 && Cin % 8 == 0) ? 1 : 0;
 }
 
 int aide_conv3x3_wino4_splitk(int N, int Cin, int H, int W, int Cout) {
-    const long nb = (long)((H + 15) / 16) * ((W + 31) / 32) * N * ((Cout + 63) / 64);
+    const long nb = (long)((H + 15) / 16) * ((W + 31) / 32) * (W == 16 ? N / 2 : N) * ((Cout + 63) / 64);
     const int pairs = Cin / 8;                             // a split gets a whole number of stage pairs
     static const long target = getenv("AIDE_W4_SK_TARGET") ? atol(getenv("AIDE_W4_SK_TARGET")) : 200;     // probe switch
     int s = 1;
@@ -556,7 +572,7 @@ int aide_conv3x3_wino4_splitk(int N, int Cin, int H, int W, int Cout) {
 }
 
 // partial-statistics entries per channel written by a forward launch when a sink is armed (aide_conv_stats_sink)
-int aide_conv3x3_wino4_stats_parts(int N, int H, int W) { return N * ((H + 15) / 16) * ((W + 31) / 32); }
+int aide_conv3x3_wino4_stats_parts(int N, int H, int W) { return W < 32 ? 0 : N * ((H + 15) / 16) * ((W + 31) / 32); }
 
 int aide_conv3x3_wino4_pack_blocks(int Co, int Ci) {
     return ((Co + P4_T - 1) / P4_T) * ((Ci + P4_T - 1) / P4_T);
@@ -577,7 +593,7 @@ int aide_conv3x3_wino4_pack_multi(const void* descs, int n, int64_t total_blocks
 int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float* bias, float* y,
                        int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,
                        float* ws, hipStream_t stream) {
-    if (!x || !u || !y || !aide_conv3x3_wino4_supported(Cin, H, W, Cout) || x_bs % 4 || y_bs % 4)
+    if (!x || !u || !y || !aide_conv3x3_wino4_supported(Cin, H, W, Cout) || x_bs % 4 || y_bs % 4 || (W == 16 && N % 2))
         return AIDE_ERR_ARG;
     static bool attr_set = false;
     if (!attr_set) {
@@ -586,7 +602,8 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
         attr_set = true;
     }
     W4Args a;
-    a.stats = (splitk <= 1 && accumulate == 0) ? aide_conv_stats_take() : nullptr;
+    a.stats = (splitk <= 1 && accumulate == 0 && W >= 32) ? aide_conv_stats_take() : nullptr;
+    a.pair = W == 16 ? 1 : 0;
     a.x = x; a.u = u; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.blocks_w = (W + 31) / 32; a.blocks_h = (H + 15) / 16; a.n_co_tiles = (Cout + 63) / 64;
     a.stages_total = Cin / 4;
@@ -600,7 +617,7 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
     } else {
         a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = (accumulate == 1);
     }
-    const long nb = (long)a.blocks_w * a.blocks_h * N * a.n_co_tiles * splitk;
+    const long nb = (long)a.blocks_w * a.blocks_h * (a.pair ? N / 2 : N) * a.n_co_tiles * splitk;
     AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), conv3x3_wino4_kernel, dim3((unsigned)nb), dim3(256),
                       F4_LDS * sizeof(float), stream, a);
     int rc = aide_launch_status();

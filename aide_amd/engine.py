@@ -102,6 +102,7 @@ REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch ta
 HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switch: backward chain on a high-priority stream
 EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B switch: BN statistics from the conv epilogue
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
+W16_PAIRS = [_os.environ.get('AIDE_W16_PAIRS', '0') != '0']      # F(4x4) on the 16-pixel-wide level (image pairs per tile): 11 % faster per launch than F(2x2), -0.6 % on the C2 step (larger filter pack, more slabs for BatchNorm to sum): off
 DUAL_BWD = [_os.environ.get('AIDE_DUAL_BWD', '0') != '0']        # ... and of the backward pass (measured +-0 beside the weight-gradient stream: off)
 DUAL_FWD = [_os.environ.get('AIDE_DUAL_FWD', '1') != '0']        # A-B switch: lane-1 chains of the forward pass on a second stream
 FOLD_SPLITK_BWD = [_os.environ.get('AIDE_FOLD_SPLITK_BWD', '1') != '0']   # ... and BatchNorm backward the data-gradient slabs
@@ -113,7 +114,8 @@ def conv_mode(n, cin, h, w, cout):
     sweep (tools/bench_conv.py wino): F(4x4) wins on every layer of >= 8 GFLOP and on the >= 128x128-channel
     layers (1.3-1.5x over F(2x2) on the 19 / 39 GFLOP decoder layers); F(2x2) elsewhere; direct where neither
     is supported."""
-    if USE_WINOGRAD[0] and USE_WINOGRAD4[0] and lib.aide_conv3x3_wino4_supported(cin, h, w, cout):
+    if USE_WINOGRAD[0] and USE_WINOGRAD4[0] and lib.aide_conv3x3_wino4_supported(cin, h, w, cout) and \
+            not (w == 16 and (n % 2 or not W16_PAIRS[0])):         # 16-wide images go two per workgroup tile
         flops = 2.0 * n * h * w * cin * cout * 9
         if cout % 64:                       # trailing half block computed and dropped: 42 vs 52 us on 32->32 @256x256,
             return 0                        # but the 4x larger filter pack eats the gain in the whole step
