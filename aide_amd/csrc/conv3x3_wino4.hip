@@ -497,9 +497,11 @@ struct W4PackDesc {
 //   uf [ci/4][36][2][Co][2]   ud [co/4][36][2][Ci][2] (taps reversed): per (channel group, position) the two
 //   channel pairs as separate [row][2] runs = the A-operand lane order of the kernel's direct fragment loads
 constexpr int P4_T = 32;
-__global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc* __restrict__ descs, int n) {
+__global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc* __restrict__ descs, int n, long total_blocks) {
     __shared__ __attribute__((aligned(16))) float ot[36 * 128];
-    const long blk = blockIdx.x;
+    // grid-stride over the filter tiles: the host may launch FEWER workgroups than tiles so that the (HBM-bound) re-layout
+    // trickles along on a few CUs beside the first convolutions of the forward pass instead of flooding the chip
+    for (long blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -551,6 +553,7 @@ __global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc*
         }
         __syncthreads();
     }
+    }
 }
 
 }  // namespace
@@ -582,8 +585,10 @@ int aide_conv3x3_wino4_pack_blocks(int Co, int Ci) {
 int aide_conv3x3_wino4_pack_multi(const void* descs, int n, int64_t total_blocks, hipStream_t stream) {
     if (!descs || n <= 0 || total_blocks <= 0) return AIDE_ERR_ARG;
     static_assert(sizeof(W4PackDesc) == 48, "descriptor layout");
-    hipLaunchKernelGGL(wino4_pack_multi_kernel, dim3((unsigned)total_blocks), dim3(128), 0, stream,
-                       (const W4PackDesc*)descs, n);
+    static const long cap = getenv("AIDE_PACK_MAX_WGS") ? atol(getenv("AIDE_PACK_MAX_WGS")) : 0;      // 0: one workgroup per tile
+    const long grid = (cap > 0 && cap < total_blocks) ? cap : total_blocks;
+    hipLaunchKernelGGL(wino4_pack_multi_kernel, dim3((unsigned)grid), dim3(128), 0, stream,
+                       (const W4PackDesc*)descs, n, (long)total_blocks);
     return aide_launch_status();
 }
 

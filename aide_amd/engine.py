@@ -102,6 +102,7 @@ REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch ta
 HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switch: backward chain on a high-priority stream
 EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B switch: BN statistics from the conv epilogue
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
+PROBE_NO_REPACK = [_os.environ.get('AIDE_PROBE_NO_REPACK', '0') != '0']   # timing probe (stale filters): what the per-step re-layout costs
 W16_PAIRS = [_os.environ.get('AIDE_W16_PAIRS', '0') != '0']      # F(4x4) on the 16-pixel-wide level (image pairs per tile): 11 % faster per launch than F(2x2), -0.6 % on the C2 step (larger filter pack, more slabs for BatchNorm to sum): off
 DUAL_BWD = [_os.environ.get('AIDE_DUAL_BWD', '0') != '0']        # ... and of the backward pass (measured +-0 beside the weight-gradient stream: off)
 DUAL_FWD = [_os.environ.get('AIDE_DUAL_FWD', '1') != '0']        # A-B switch: lane-1 chains of the forward pass on a second stream
@@ -445,7 +446,7 @@ class Plan(object):
         under the first convolutions; returns the index of the first conv that must wait for it."""
         convs = [st for st in self.steps if st['kind'] == 'conv']
         key = (PARAM_EPOCH[0],) + tuple((st['conv'].weight.data_ptr(), st['conv'].weight._version) for st in convs)
-        if key == self._pack_key:
+        if key == self._pack_key or (PROBE_NO_REPACK[0] and self._pack_key is not None):
             return None
         ptrs = tuple(k[0] for k in key[1:])
         if self._pack_tab is None or self._pack_tab[0] != ptrs:

@@ -286,7 +286,8 @@ def main():
         out = net(xin, xout) if xout is not None else net(xin)
         loss = crit(out, tgt)
         loss.backward()
-        opt.step()
+        if not os.environ.get('AIDE_PROBE_NO_OPTIM'):      # (timing probe: the step without its optimizer -- an INVALID bench line)
+            opt.step()
         return loss
 
     for w_i in range(args.warmup):
