@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(
     const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
     float* __restrict__ running_var, long long* __restrict__ nbt, float* __restrict__ mean_out,
     float* __restrict__ rstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out, int relu,
-    const float* __restrict__ fparts, int nparts, const float* __restrict__ cbias) {
+    const float* __restrict__ fparts, int nparts, const float* __restrict__ cbias, int pstride) {
     __shared__ float coef[2];
     const int plane = blockIdx.y;                 // n*C + c
     const int n = plane / C, c = plane - n * C;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(
         double s = 0.0, ss = 0.0;
         if (fparts) {                             // statistics from the convolution's epilogue: [c][nparts][2], pre-bias
             for (int i = threadIdx.x; i < nparts; i += 64) {
-                const f32x2 v = *reinterpret_cast<const f32x2*>(fparts + ((long)c * nparts + i) * 2);
+                const f32x2 v = *reinterpret_cast<const f32x2*>(fparts + ((long)c * pstride + i) * 2);
                 s += (double)v[0];
                 ss += (double)v[1];
             }
@@ -543,17 +543,17 @@ int bn_train_fwd_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C,
         hipLaunchKernelGGL((bn_stats_kernel<8, ZT, false>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
         hipLaunchKernelGGL((bn_train_apply_kernel<8, ZT, AT>), dim3(gx8, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
-                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr);
+                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0);
     } else if (v4) {
         hipLaunchKernelGGL((bn_stats_kernel<4, ZT, SLABS>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
         hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
-                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr);
+                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0);
     } else {
         hipLaunchKernelGGL((bn_stats_kernel<1, ZT, false>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
         hipLaunchKernelGGL((bn_train_apply_kernel<1, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
-                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr);
+                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0);
     }
     return aide_launch_status();
 }
@@ -648,19 +648,37 @@ int aide_bn_train_fwd_slabs(const float* slabs, int splitk, int64_t split_stride
 // BatchNorm(train)+ReLU whose statistics were emitted by the convolution's own epilogue (aide_conv_stats_sink): parts
 // [C][nparts][2] fp32 = per channel and conv workgroup tile the sum and sum of squares of z - conv_bias.  One launch, one
 // read of z.  (H*W % 4 == 0 and 16-byte aligned batch strides.)
+// parts_stride: entries per channel in `parts` (>= nparts).  A group of a stacked batch passes the pointer to ITS first
+// entry of channel 0 and the count of its own entries (the conv writes the entries of an image contiguously).
+int aide_bn_train_fwd_parts_strided(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
+                                    int H, int W, const float* parts, int nparts, int parts_stride, const float* conv_bias,
+                                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                    float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                                    float* scale, float* shift, int relu, hipStream_t stream);
+
 int aide_bn_train_fwd_parts(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C, int H,
                             int W, const float* parts, int nparts, const float* conv_bias, const float* gamma,
                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                             long long* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift,
                             int relu, hipStream_t stream) {
+    return aide_bn_train_fwd_parts_strided(z, z_bf16, z_bs, a, a_bf16, a_bs, N, C, H, W, parts, nparts, nparts, conv_bias, gamma,
+                                           beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd,
+                                           scale, shift, relu, stream);
+}
+
+int aide_bn_train_fwd_parts_strided(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
+                                    int H, int W, const float* parts, int nparts, int parts_stride, const float* conv_bias,
+                                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                    float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                                    float* scale, float* shift, int relu, hipStream_t stream) {
     const int HW = H * W;
-    if (!z || !a || !parts || nparts <= 0 || HW % 4 || z_bs % 4 || a_bs % 4) return AIDE_ERR_ARG;
+    if (!z || !a || !parts || nparts <= 0 || parts_stride < nparts || HW % 4 || z_bs % 4 || a_bs % 4) return AIDE_ERR_ARG;
     const double count = (double)N * HW;
     const int gx = max(1, min((HW / 4 + 255) / 256, 16));
 #define AIDE_BN_PARTS(ZT, AT)                                                                                                  \
     hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, (const ZT*)z, (long)z_bs,    \
                        (AT*)a, (long)a_bs, C, HW, (const double*)nullptr, 0, count, gamma, beta, eps, momentum, running_mean, \
-                       running_var, num_batches_tracked, mean, rstd, scale, shift, relu, parts, nparts, conv_bias)
+                       running_var, num_batches_tracked, mean, rstd, scale, shift, relu, parts, nparts, conv_bias, parts_stride)
     if (z_bf16) { if (a_bf16) AIDE_BN_PARTS(bf16_t, bf16_t); else AIDE_BN_PARTS(bf16_t, float); }
     else { if (a_bf16) AIDE_BN_PARTS(float, bf16_t); else AIDE_BN_PARTS(float, float); }
 #undef AIDE_BN_PARTS

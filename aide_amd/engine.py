@@ -103,6 +103,7 @@ HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switc
 EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B switch: BN statistics from the conv epilogue
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
 PROBE_NO_REPACK = [_os.environ.get('AIDE_PROBE_NO_REPACK', '0') != '0']   # timing probe (stale filters): what the per-step re-layout costs
+GROUP_STATS = [_os.environ.get('AIDE_GROUP_STATS', '1') != '0']    # A-B switch: epilogue BatchNorm statistics in grouped (stacked-batch) forwards
 W16_PAIRS = [_os.environ.get('AIDE_W16_PAIRS', '0') != '0']      # F(4x4) on the 16-pixel-wide level (image pairs per tile): 11 % faster per launch than F(2x2), -0.6 % on the C2 step (larger filter pack, more slabs for BatchNorm to sum): off
 DUAL_BWD = [_os.environ.get('AIDE_DUAL_BWD', '0') != '0']        # ... and of the backward pass (measured +-0 beside the weight-gradient stream: off)
 DUAL_FWD = [_os.environ.get('AIDE_DUAL_FWD', '1') != '0']        # A-B switch: lane-1 chains of the forward pass on a second stream
@@ -272,8 +273,8 @@ class Plan(object):
                     max_wg = max(max_wg, st['wg_bytes'])
                     # BatchNorm statistics from the conv epilogue (big planes, non-split F(4x4) forward, ungrouped training)
                     st['stats'] = None
-                    if training and groups == 1 and EPILOGUE_STATS[0] and (st['plan_f'] >> 8) <= 1 \
-                            and (hh * ww) % 4 == 0 and lib.aide_bn_two_pass(n, cout, hh, ww):
+                    if training and (groups == 1 or GROUP_STATS[0]) and EPILOGUE_STATS[0] and (st['plan_f'] >> 8) <= 1 \
+                            and (hh * ww) % 4 == 0 and lib.aide_bn_two_pass(n // max(groups, 1), cout, hh, ww):
                         # F(4x4) forward only.  The same epilogue in the direct and F(2x2) kernels was built and measured: C2
                         # 575 -> 572 images/s (their epilogues are short and the butterflies cost more than the saved pass) and
                         # the fp32 partial sums of the 3->64 stem at 320x320 (|mean| >> std) moved a gradient norm by 3e-3.
@@ -678,9 +679,12 @@ class Plan(object):
             for gi in range(ngroups):
                 zg, ag = (z, a) if ngroups == 1 else (z[gi * m:(gi + 1) * m], a[gi * m:(gi + 1) * m])
                 if st.get('stats') is not None:
-                    ops.bn_train_fwd_parts(zg, ag, st['stats'], st['stats_parts'], st['conv'].bias, bn.weight, bn.bias, bn.eps,
+                    # (a group of a stacked batch owns a contiguous run of the per-image entries of every channel)
+                    gparts = st['stats_parts'] // ngroups
+                    ops.bn_train_fwd_parts(zg, ag, st['stats'], gparts, st['conv'].bias, bn.weight, bn.bias, bn.eps,
                                            bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                           st['mean'], st['rstd'], st['scale'], st['shift'], True)
+                                           st['mean'], st['rstd'], st['scale'], st['shift'], True,
+                                           first=gi * gparts, stride=st['stats_parts'])
                 elif splitk > 0:
                     import ctypes
                     sl = ctypes.c_void_p(sk_ws.data_ptr() + 4 * gi * m * per_img)

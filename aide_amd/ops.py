@@ -222,15 +222,18 @@ def bn_train_fwd_slabs(slabs, splitk, split_stride, bias, z, a, gamma, beta, eps
 
 
 def bn_train_fwd_parts(z, a, parts, nparts, conv_bias, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean,
-                       rstd, scale, shift, relu=True):
-    """bn_train_fwd with the statistics emitted by the conv epilogue (lib.aide_conv_stats_sink): one pass over z."""
+                       rstd, scale, shift, relu=True, first=0, stride=None):
+    """bn_train_fwd with the statistics emitted by the conv epilogue (lib.aide_conv_stats_sink): one pass over z.
+    A group of a stacked batch: first = index of the group's first entry, nparts = its entry count, stride = entries per
+    channel of the whole launch."""
     zp, zbs = planes(z, bf16_ok=True)
     ap, abs_ = planes(a, bf16_ok=True)
     n, c, h, w = z.shape
-    check(lib.aide_bn_train_fwd_parts(zp, int(is_bf16(z)), zbs, ap, int(is_bf16(a)), abs_, n, c, h, w, ptr(parts), nparts,
-                                      ptr(conv_bias), ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
-                                      ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), int(relu),
-                                      stream_ptr()), 'bn_train_fwd_parts')
+    pp = ctypes.c_void_p(parts.data_ptr() + 8 * first)
+    check(lib.aide_bn_train_fwd_parts_strided(zp, int(is_bf16(z)), zbs, ap, int(is_bf16(a)), abs_, n, c, h, w, pp, nparts,
+                                              nparts if stride is None else stride, ptr(conv_bias), ptr(gamma), ptr(beta), eps,
+                                              momentum, ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd),
+                                              ptr(scale), ptr(shift), int(relu), stream_ptr()), 'bn_train_fwd_parts')
     return a
 
 

@@ -180,6 +180,13 @@ int aide_bn_train_fwd_parts(const void* z, int z_bf16, int64_t z_bs, void* a, in
                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                             long long* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift,
                             int relu, aide_stream_t stream);
+/* the same for ONE group of a stacked batch (Engine.run_groups): `parts` points at the group's first entry of channel 0,
+ * nparts counts the group's entries, parts_stride the entries per channel of the whole launch */
+int aide_bn_train_fwd_parts_strided(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
+                                    int H, int W, const float* parts, int nparts, int parts_stride, const float* conv_bias,
+                                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                    float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                                    float* scale, float* shift, int relu, aide_stream_t stream);
 int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
                              int H, int W, const float* scale, const float* shift, int relu, aide_stream_t stream);
 int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz,
