@@ -104,6 +104,7 @@ EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B sw
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
 PROBE_NO_REPACK = [_os.environ.get('AIDE_PROBE_NO_REPACK', '0') != '0']   # timing probe (stale filters): what the per-step re-layout costs
 GROUP_STATS = [_os.environ.get('AIDE_GROUP_STATS', '1') != '0']    # A-B switch: epilogue BatchNorm statistics in grouped (stacked-batch) forwards
+F4_HALF_TILES = [_os.environ.get('AIDE_F4_HALF_TILES', '0') != '0']   # A-B switch: F(4x4) on layers whose Cout is 32 mod 64
 W16_PAIRS = [_os.environ.get('AIDE_W16_PAIRS', '0') != '0']      # F(4x4) on the 16-pixel-wide level (image pairs per tile): 11 % faster per launch than F(2x2), -0.6 % on the C2 step (larger filter pack, more slabs for BatchNorm to sum): off
 DUAL_BWD = [_os.environ.get('AIDE_DUAL_BWD', '0') != '0']        # ... and of the backward pass (measured +-0 beside the weight-gradient stream: off)
 DUAL_FWD = [_os.environ.get('AIDE_DUAL_FWD', '1') != '0']        # A-B switch: lane-1 chains of the forward pass on a second stream
@@ -119,7 +120,7 @@ def conv_mode(n, cin, h, w, cout):
     if USE_WINOGRAD[0] and USE_WINOGRAD4[0] and lib.aide_conv3x3_wino4_supported(cin, h, w, cout) and \
             not (w == 16 and (n % 2 or not W16_PAIRS[0])):         # 16-wide images go two per workgroup tile
         flops = 2.0 * n * h * w * cin * cout * 9
-        if cout % 64:                       # trailing half block computed and dropped: 42 vs 52 us on 32->32 @256x256,
+        if cout % 64 and not F4_HALF_TILES[0]:   # trailing half block computed and dropped: 42 vs 52 us on 32->32 @256x256,
             return 0                        # but the 4x larger filter pack eats the gain in the whole step
         if flops >= 8e9 or cin * cout >= 128 * 128:
             return 4
