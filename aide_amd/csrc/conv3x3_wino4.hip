@@ -72,6 +72,9 @@ __device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, floa
     o[5 * st] = __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5));
 }
 
+// PAIR: 16-pixel-wide images, two per workgroup tile (a compile-time variant: the descriptors of the common case keep their
+// register allocation -- as a runtime flag the extra live values put a scratch reload into the main loop)
+template <int PAIR>
 #ifdef AIDE_PROBE_4HALF
 // (timing probe, wrong results) half of the positions per workgroup -- 9 accumulators, 18 MFMAs per stage -- so that TWO
 // workgroups fit a CU (2 waves per SIMD): does a co-resident workgroup hide the fixed cost and the stalls of the other?
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     // 16-pixel-wide images (the 16 x 16 bottleneck level): the 32-column tile holds the rows of TWO images side by side, each
     // with its own zero halo columns -- raw row [3 pad][-1][A 0..15][16][-1][B 0..15][16]: image B sits two words further right.
     // Only these stage-invariant descriptors and the output addresses know about it; the main loop is the same.
-    const int pair = a.pair;
+    constexpr int pair = PAIR;
 
     const int sps = a.stages_total / a.splitk;             // even, and splitk divides stages_total (host)
     const int s_begin = split * sps;
@@ -602,7 +605,9 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
         return AIDE_ERR_ARG;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv3x3_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            F4_LDS * (int)sizeof(float));
+        hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             F4_LDS * (int)sizeof(float));
         attr_set = true;
     }
@@ -623,8 +628,13 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
         a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = (accumulate == 1);
     }
     const long nb = (long)a.blocks_w * a.blocks_h * (a.pair ? N / 2 : N) * a.n_co_tiles * splitk;
-    AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), conv3x3_wino4_kernel, dim3((unsigned)nb), dim3(256),
-                      F4_LDS * sizeof(float), stream, a);
+    if (a.pair) {
+        AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), conv3x3_wino4_kernel<1>, dim3((unsigned)nb), dim3(256),
+                          F4_LDS * sizeof(float), stream, a);
+    } else {
+        AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), conv3x3_wino4_kernel<0>, dim3((unsigned)nb), dim3(256),
+                          F4_LDS * sizeof(float), stream, a);
+    }
     int rc = aide_launch_status();
     if (rc != 0) return rc;
     if (splitk > 1 && accumulate != 2) {           // accumulate == 2: the caller consumes the slabs itself
