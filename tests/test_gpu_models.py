@@ -280,6 +280,38 @@ def test_side_stream_wgrad_is_bit_identical(dev):
             assert torch.equal(a, b) and torch.equal(a, c)
 
 
+def test_two_lane_schedules_are_bit_identical(dev):
+    """The second encoder's chains on their own stream (forward: default on; backward: AIDE_DUAL_BWD) must give the single-lane
+    results bit for bit -- same kernels, own workspaces -- over several steps (also a race detector for the lane's
+    BatchNorm / split-K workspaces and the fork / join points), with and without launch tapes' replays."""
+    from aide_amd import engine, utils as U
+    net, _ = build_pair('fuseunet', False, dev)
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(4, 3, 128, 128, generator=g).to(dev) for _ in range(2)]
+    t = (torch.rand(4, 128, 128, generator=g) > 0.8).long().to(dev)
+    w = torch.tensor([1.0, 1.0])
+    saved = (engine.DUAL_FWD[0], engine.DUAL_BWD[0])
+    results = []
+    try:
+        for fwd, bwd in ((False, False), (True, False), (True, True), (True, False)):
+            engine.DUAL_FWD[0], engine.DUAL_BWD[0] = fwd, bwd
+            for plan in net.engine.plans.values():
+                plan._tape_f = plan._tape_b = None           # the recorded launch sequence bakes the schedule in
+            outs = []
+            for _ in range(3):                                 # recorded pass + two replays (BatchNorm running stats move on)
+                net.zero_grad()
+                out = net(*xs)
+                U.CEMDiceLoss(w, w, w)(out, t).backward()
+                outs.append([out.detach().clone()] + [p.grad.clone() for p in net.parameters()])
+            results.append(outs[-1])
+            torch.cuda.synchronize()
+    finally:
+        engine.DUAL_FWD[0], engine.DUAL_BWD[0] = saved
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert torch.equal(a, b)
+
+
 def test_unet_ragged_sizes(dev):
     """UNet at 160x176 (levels 160x176 ... 10x11): exercises the PT_W = 16 / 8 tiles, widths that are
     not multiples of 4 (dword loaders), ragged wgrad tiles and the scalar BN / pool kernels."""
