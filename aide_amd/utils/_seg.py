@@ -81,6 +81,8 @@ class SegBackward(torch.autograd.Function):
     def forward(ctx, logits, value, pack):
         ctx.pack = pack
         ctx.save_for_backward(logits)
+        if callable(value):           # the finalize launch itself: its output tensor is born here, no copy
+            return value()
         return value.clone()
 
     @staticmethod
@@ -113,18 +115,20 @@ def seg_loss(logits, targets, w0, w1, ignore_index, reduction, w_ce, w_dice, smo
     with torch.no_grad():
         partials = stats_pass(logits, targets, t_bs, w0, w1, ignore_index)
         stats = torch.empty(n * NS, device=dev, dtype=torch.float64)
-        out = torch.empty(n if reduction == 2 else 1, device=dev, dtype=torch.float32)
         per_image = torch.empty(n, device=dev, dtype=torch.float32)
         idx = torch.empty(n, device=dev, dtype=torch.int64)
         coef = torch.empty(3 * n, device=dev, dtype=torch.float32)
         hard = torch.empty(1, device=dev, dtype=torch.float32)
+
+    def finalize():                   # runs inside SegBackward.forward: the loss tensor is that node's own output
+        out = torch.empty(n if reduction == 2 else 1, device=dev, dtype=torch.float32)
         check(lib.aide_seg_loss_finalize(ptr(partials), n, hw, reduction, w_ce, w_dice, smooth, ptr(stats),
                                          ptr(out), ptr(per_image), ptr(idx), ptr(coef), ptr(hard),
                                          stream_ptr()), 'seg_loss_finalize')
-        value = out if reduction == 2 else out.view(())
+        return out if reduction == 2 else out.view(())
     pack = dict(targets=targets, t_bs=t_bs, w0=w0, w1=w1, ignore=ignore_index, stats=stats, coef=coef,
                 smooth=smooth)
-    loss = SegBackward.apply(logits, value, pack)
+    loss = SegBackward.apply(logits, finalize, pack)
     return loss, dict(per_image=per_image, argsort=idx, hard_dice=hard.view(()), stats=stats.view(n, NS))
 
 
