@@ -505,8 +505,19 @@ int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float*
 
 extern "C" int aide_wgrad_reduce_defer(int on) {
     const int was = g_red.defer ? 1 : 0;
+    // entering the deferred mode with descriptors still pending means an earlier pass died between its launches and its
+    // flush: their workspace / dw pointers are stale, never reduce through them
+    if (on && !g_red.defer) g_red.n = 0;
     g_red.defer = on != 0;
     return was;
+}
+
+// error path of a backward pass: forget every pending descriptor and leave the deferred mode
+extern "C" int aide_wgrad_reduce_discard(void) {
+    const int n = g_red.n;
+    g_red.n = 0;
+    g_red.defer = false;
+    return n;
 }
 
 extern "C" int aide_wgrad_reduce_pending(void) { return g_red.n; }

@@ -99,6 +99,11 @@ int aide_event_create(void** ev) {
     return AIDE_OK;
 }
 
+int aide_event_destroy(void* ev) {
+    if (!ev) return AIDE_ERR_ARG;
+    return (int)hipEventDestroy((hipEvent_t)ev);
+}
+
 // everything enqueued on `to` after this call runs after everything enqueued on `from` before it
 int aide_stream_order(void* ev, hipStream_t from, hipStream_t to) {
     if (!ev) return AIDE_ERR_ARG;

@@ -120,6 +120,8 @@ class GradAllReduce(object):
         self.flat = None
         self.works = []
         self.comm_stream = None
+        self.time_exposed = False        # bench.py: event-time the main stream's wait for the communication stream
+        self._exposed = []
         if self.world > 1 or force:          # force: exercise the RCCL path on a single-rank group (tests)
             self.engine.after_backward_op = self._after_op
             self.engine.grad_hook = self._finish
@@ -191,7 +193,30 @@ class GradAllReduce(object):
             if pend > 0:
                 self.sched.pending[b] = 0
                 self._launch(b)
+        timed = self.time_exposed and flat.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self.works:
             w.wait()
         if flat.is_cuda:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if timed:
+            e1.record()
+            self._exposed.append((e0, e1))
+
+    # ---- what bench.py reports about the exchange
+    def describe(self):
+        """-> dict(buckets, bytes_per_step): the bucket plan of this module's gradient arena"""
+        self._ensure()
+        return dict(buckets=len(self.sched.buckets),
+                    bytes_per_step=int(sum(4 * (end - start) for start, end, _ in self.sched.buckets)))
+
+    def exposed_ms(self, last=8):
+        """mean time (ms) the compute stream stalled at the end of a backward pass waiting for the all-reduces still in
+        flight, over the last `last` timed steps (event pair around the wait; needs time_exposed = True and an idle device)"""
+        pairs = self._exposed[-last:]
+        if not pairs:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)

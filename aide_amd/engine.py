@@ -530,8 +530,13 @@ class Plan(object):
 
     def _fingerprint(self):
         """addresses of every parameter and buffer the launch sequence bakes in (a tape is only valid for these)"""
-        fp = []
+        # ... and everything else a recorded sequence depends on: the runtime schedule switches and the BatchNorm scalars
+        fp = [DUAL_FWD[0], DUAL_BWD[0], FOLD_SPLITK[0], FOLD_SPLITK_BWD[0], DEFER_WGRAD_REDUCE[0], FLUSH_EVERY,
+              HEAD_WGRAD_SIDE[0], EPILOGUE_STATS[0], self.overlap]
         for st in self.steps:
+            bn = st.get('bn')
+            if bn is not None:
+                fp += [bn.eps, bn.momentum]
             for key in ('conv', 'bn'):
                 m = st.get(key)
                 if m is not None:
@@ -592,6 +597,7 @@ class Plan(object):
                     tape.py(wait, 'gate')
                 if gate is not None:
                     wait()
+                on_b = False                  # a gate conv on lane 1 re-forks: its lane must see the wait as well
             if lane and not on_b:
                 ops.order(self.ev_lane_fork, mp, bp)
             on_b = bool(lane)
@@ -729,7 +735,14 @@ class Plan(object):
                    tuple((tuple(t.shape), t.stride()) for t in dyn))
             tp = self._tape_b
             if tp is not None and tp.key == key:
-                tp.replay(dyn)
+                try:
+                    tp.replay(dyn)
+                except BaseException:
+                    # a replay that stops between the recorded defer(1) and defer(0) must not leave the library collecting
+                    # slab reduces for ever (nor keep descriptors of this step)
+                    lib.load().aide_wgrad_reduce_discard()
+                    self._tape_b = None
+                    raise
                 return
             tp = Tape(key)
             cb = None
@@ -789,14 +802,20 @@ class Plan(object):
                     flush()
         if defer:
             lib.aide_wgrad_reduce_defer(1)
+        done = False
         try:
             with ops.use_stream(mp):
                 self._backward_ops(inputs, dlogits, gslot, mp, sp, hook)
             if defer:
                 flush()
+            done = True
         finally:
-            if defer:
+            if defer and done:
                 lib.aide_wgrad_reduce_defer(0)
+            elif defer:
+                # the pass died between its launches and its flush: the queued descriptors point into this step's arena
+                # and workspaces -- drop them and leave the deferred mode (never reduced through later)
+                lib.load().aide_wgrad_reduce_discard()
         if side is not None:
             ops.order(self.ev_join, sp, mp)
 
@@ -958,11 +977,21 @@ class Plan(object):
                                        accumulate=sg['accumulate'])
 
 
+DIRECT_GRADS = [_os.environ.get('AIDE_DIRECT_GRADS', '1') != '0']    # A-B switch: parameter gradients assigned by the engine
+
+
 class _NetFunction(torch.autograd.Function):
-    """forward/backward of the whole network as one autograd node."""
+    """forward/backward of the whole network as one autograd node.
+
+    The parameters are NOT inputs of the node (130 autograd inputs / outputs and as many AccumulateGrad nodes cost more host
+    time per step than the whole launch sequence): the node hangs on one anchor tensor of the engine and its backward
+    assigns `p.grad` itself -- views of the engine's persistent flat gradient arena when no gradient exists yet (the
+    state after `optimizer.zero_grad()`), an accumulation into the existing gradients otherwise (what AccumulateGrad
+    does).  AIDE_DIRECT_GRADS=0 is the plain form (every parameter an autograd input) for tensor hooks /
+    torch.autograd.grad on parameters."""
 
     @staticmethod
-    def forward(ctx, engine, n_inputs, *tensors):
+    def forward(ctx, engine, n_inputs, direct, *tensors):
         inputs = tensors[:n_inputs]
         plan = engine.plan_for(inputs)
         plan.profiler = engine.profiler
@@ -970,7 +999,8 @@ class _NetFunction(torch.autograd.Function):
         n, _, h, w = inputs[0].shape
         out = torch.empty(n, k, h, w, device=inputs[0].device, dtype=torch.float32)
         plan.forward(inputs, out)
-        ctx.engine, ctx.plan, ctx.serial, ctx.inputs = engine, plan, plan.serial, inputs
+        ctx.engine, ctx.plan, ctx.serial, ctx.inputs, ctx.direct = engine, plan, plan.serial, inputs, direct
+        ctx.ntensors = len(tensors)
         return out
 
     @staticmethod
@@ -982,7 +1012,20 @@ class _NetFunction(torch.autograd.Function):
         if not plan.training:
             raise RuntimeError('aide_amd: backward through an eval-mode forward is not supported')
         dlogits = dlogits.contiguous()
-        flat = torch.empty(eng.flat_numel, device=dlogits.device, dtype=torch.float32)
+        params = eng.params
+        mode = 0                         # 0: plain autograd outputs; 1: fresh gradients = arena views; 2: arena += ; 3: per parameter
+        if ctx.direct:
+            arena, views = eng.grad_arena(dlogits.device)
+            base = arena.data_ptr()
+            have = [p.grad for p in params]
+            if all(g is None for g in have):
+                mode = 1
+            elif all(g is not None and g.data_ptr() == base + 4 * o and g.dtype == torch.float32
+                     for g, o in zip(have, eng.offsets)):
+                mode = 2                 # every gradient still lives in the arena (zero_grad(set_to_none=False), or a
+            else:                        # second backward before the optimizer): one add over the whole arena
+                mode = 3
+        flat = arena if mode == 1 else torch.empty(eng.flat_numel, device=dlogits.device, dtype=torch.float32)
         eng.side_stream = plan.side if (plan._bwd_ready and plan.overlap) else None
         eng.lane_stream = plan.lane_b if (plan.overlap and DUAL_BWD[0]) else None
         if not plan._bwd_ready:
@@ -994,8 +1037,25 @@ class _NetFunction(torch.autograd.Function):
         plan.backward(ctx.inputs, dlogits, flat, eng.offsets, eng.after_backward_op)
         if eng.grad_hook is not None:
             eng.grad_hook(flat)
-        grads = tuple(flat[o:o + p.numel()].view(p.shape) for o, p in zip(eng.offsets, eng.params))
-        return (None, None) + (None,) * len(ctx.inputs) + grads
+        if mode == 0:
+            grads = tuple(flat[o:o + p.numel()].view(p.shape) for o, p in zip(eng.offsets, params))
+            return (None, None, None) + (None,) * len(ctx.inputs) + grads
+        if mode == 1:
+            for p, v in zip(params, views):
+                if p.requires_grad:
+                    p.grad = v
+        elif mode == 2:
+            arena.add_(flat)
+        else:
+            for p, o, g in zip(params, eng.offsets, have):
+                if not p.requires_grad:
+                    continue
+                v = flat[o:o + p.numel()].view(p.shape)
+                if g is None:
+                    p.grad = v
+                else:
+                    g.add_(v)
+        return (None,) * (3 + ctx.ntensors)
 
 
 class Engine(object):
@@ -1014,6 +1074,15 @@ class Engine(object):
         self.lane_stream = None          # ... and the stream of the lane-1 chains (second encoder), if any
         self.graph = None
         self._precision = 'fp32'
+        self._arena = self._views = self._anchor = None
+
+    def grad_arena(self, device):
+        """the persistent flat gradient arena of this module and the per-parameter views into it (offsets: _refresh_params)"""
+        a = self._arena
+        if a is None or a.numel() != self.flat_numel or a.device != device:
+            a = self._arena = torch.zeros(self.flat_numel, device=device, dtype=torch.float32)
+            self._views = [a[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
+        return a, self._views
 
     @property
     def precision(self):
@@ -1055,6 +1124,7 @@ class Engine(object):
                 off += (params[i].numel() + 3) // 4 * 4  # 16-byte aligned slots
             self.flat_numel = off
             self.plans = {}
+            self._arena = self._views = None
 
     def plan_for(self, inputs, groups=1):
         self._refresh_params()
@@ -1123,4 +1193,8 @@ class Engine(object):
         for p in self.params:
             if not p.is_cuda:
                 raise RuntimeError('aide_amd: module parameters are on %s; call .to(device) first' % p.device)
-        return _NetFunction.apply(self, len(ins), *(tuple(ins) + tuple(self.params)))
+        if DIRECT_GRADS[0] and torch.is_grad_enabled() and any(p.requires_grad for p in self.params):
+            if self._anchor is None or self._anchor.device != ins[0].device:
+                self._anchor = torch.zeros(1, device=ins[0].device, requires_grad=True)
+            return _NetFunction.apply(self, len(ins), True, *(tuple(ins) + (self._anchor,)))
+        return _NetFunction.apply(self, len(ins), False, *(tuple(ins) + tuple(self.params)))

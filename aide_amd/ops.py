@@ -36,8 +36,20 @@ class use_stream(object):
         return False
 
 
+class Event(ctypes.c_void_p):
+    """a HIP event owned by a plan (aide_event_create); destroyed with its owner"""
+
+    def __del__(self):
+        try:
+            if self.value:
+                lib.load().aide_event_destroy(ctypes.c_void_p(self.value))
+                self.value = None
+        except Exception:       # interpreter shutdown
+            pass
+
+
 def new_event():
-    ev = ctypes.c_void_p()
+    ev = Event()
     check(lib.aide_event_create(ctypes.byref(ev)), 'event_create')
     return ev
 

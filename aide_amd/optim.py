@@ -23,10 +23,33 @@ class Adam(torch.optim.Optimizer):
                                                 amsgrad=amsgrad))
         self._tables = {}
         self._gtabs = {}
+        self._fast = {}
 
     def load_state_dict(self, state_dict):
         super(Adam, self).load_state_dict(state_dict)
         self._tables = {}                          # raw pointers to the old moment tensors
+        self._fast = {}
+
+    def add_param_group(self, param_group):
+        super(Adam, self).add_param_group(param_group)
+        self._fast = {}
+
+    def zero_grad(self, set_to_none=True):
+        """set_to_none=True (torch's default): drop the gradients -- the next backward of an aide_amd model then hands out
+        views of its gradient arena without any accumulation pass."""
+        if not set_to_none:
+            return super(Adam, self).zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group['params']:
+                p.grad = None
+
+    def _launch(self, tab, gtab, n, group, step):
+        b1, b2 = group['betas']
+        check(lib.aide_adam_amsgrad_multi(ptr(tab['p']), ptr(gtab), ptr(tab['m']), ptr(tab['v']),
+                                          ptr(tab['vmax']), ptr(tab['sizes']), ptr(tab['starts']),
+                                          n, tab['total_blocks'], float(group['lr']), float(b1),
+                                          float(b2), float(group['eps']), float(group['weight_decay']),
+                                          int(bool(group['amsgrad'])), step, stream_ptr()), 'adam')
 
     def _static_table(self, gi, plist):
         # the table holds raw pointers to the parameters AND their moment tensors: load_state_dict (or any replacement
@@ -63,6 +86,23 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
+            # steady state: same parameters, same moment tensors, every gradient present and where it was last step (the
+            # engine's arena views) -- nothing to validate or rebuild, one launch
+            fast = self._fast.get(gi)
+            if fast is not None:
+                params = group['params']
+                grads = [p.grad for p in params]
+                if fast['params'] is params and len(params) == fast['n'] and None not in grads and \
+                        tuple(g.data_ptr() for g in grads) == fast['gkey'] and \
+                        tuple(p.data_ptr() for p in params) == fast['pkey'] and \
+                        bool(group['amsgrad']) == fast['amsgrad']:
+                    step = fast['step'] = fast['step'] + 1
+                    for st in fast['states']:
+                        st['step'] = step
+                    self._launch(fast['tab'], fast['gtab'], fast['n'], group, step)
+                    self._keep = (fast['gtab'], grads)
+                    continue
+                self._fast.pop(gi, None)
             plist = [p for p in group['params'] if p.grad is not None]
             if not plist:
                 continue
@@ -100,12 +140,11 @@ class Adam(torch.optim.Optimizer):
             step = int(self.state[plist[0]]['step']) + 1
             for p in plist:
                 self.state[p]['step'] = step
-            b1, b2 = group['betas']
-            check(lib.aide_adam_amsgrad_multi(ptr(tab['p']), ptr(gtab), ptr(tab['m']), ptr(tab['v']),
-                                              ptr(tab['vmax']), ptr(tab['sizes']), ptr(tab['starts']),
-                                              len(plist), tab['total_blocks'], float(group['lr']), float(b1),
-                                              float(b2), float(group['eps']), float(group['weight_decay']),
-                                              int(bool(group['amsgrad'])), step, stream_ptr()), 'adam')
+            self._launch(tab, gtab, len(plist), group, step)
             self._keep = (gtab, grads)            # keep alive until the next step (async launch)
+            if len(plist) == len(group['params']) and all(g is p.grad for g, p in zip(grads, plist)):
+                self._fast[gi] = dict(params=group['params'], n=len(plist), gkey=gkey,
+                                      pkey=tuple(p.data_ptr() for p in plist), amsgrad=bool(group['amsgrad']),
+                                      step=step, states=[self.state[p] for p in plist], tab=tab, gtab=gtab)
         engine.PARAM_EPOCH[0] += 1                # parameters changed behind tensor._version's back
         return loss

@@ -63,7 +63,132 @@ def parse():
                          "--kernel-trace only) of this workload run as sub-processes after the timed region (rank 0, N=1)")
     ap.add_argument('--traffic-timeout', type=int, default=150)
     ap.add_argument('--cpu-threads', type=int, default=32)
+    ap.add_argument('--allow-probes', action='store_true',
+                    help='run although AIDE_PROBE_* timing probes are set; the line is then marked INVALID (A-B tooling only)')
     return ap.parse_args()
+
+
+def switches():
+    """every AIDE_* switch active in this process' environment (echoed in the line) and the probe switches among them.
+    AIDE_PROBE_* builds / runs skip work or use stale data: a bench line produced under one is not a measurement."""
+    act = {k: v for k, v in sorted(os.environ.items()) if k.startswith('AIDE_')}
+    probes = sorted(k for k, v in act.items() if k.startswith('AIDE_PROBE_') and v not in ('', '0'))
+    return act, probes
+
+
+def probe_guard(args):
+    act, probes = switches()
+    if probes and not args.allow_probes:
+        raise SystemExit('bench.py: refusing to run with timing probes set (%s): they skip work or use stale data, the '
+                         'line would not be a measurement (--allow-probes marks it INVALID instead)' % ', '.join(probes))
+    return act, probes
+
+
+def timed_steps(step, args, world, device, timer, ev_steps):
+    """W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides.  -> (max over ranks of the
+    elapsed seconds, this rank's elapsed seconds, [per-rank seconds], last step's return value)"""
+    for _ in range(args.warmup):
+        step()
+    if timer is not None:
+        timer.start()                             # creates the events: outside the timed region
+        timer.stop()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(args.steps):
+        if timer is not None and i == args.steps - ev_steps:
+            timer.arm()                           # the last ev_steps timed steps: their MFMA conv launches carry events
+        out = step()
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0            # this rank's own K steps (before it waits for the others)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if timer is not None:
+        timer.stop()
+    per_rank = [t_local]
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        mine = torch.tensor([t_local], device=device, dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(v.item()) for v in allr]
+    return elapsed, t_local, per_rank, out
+
+
+def comm_block(world, reducers, per_rank, steps):
+    """N > 1: what was exchanged and what of it the step had to wait for."""
+    if world == 1:
+        return dict(backend=None, ranks=1)
+    desc = [r.describe() for r in reducers]
+    exposed = [r.exposed_ms() for r in reducers]
+    try:
+        ver = '.'.join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == 'nccl' else None
+    except Exception:
+        ver = None
+    ms = [t / steps * 1e3 for t in per_rank]
+    return dict(backend=dist.get_backend(), ranks=world, rccl_version=ver,
+                buckets=sum(d['buckets'] for d in desc), bytes_per_step=sum(d['bytes_per_step'] for d in desc),
+                exposed_ms=(round(sum(e for e in exposed if e is not None), 4)
+                            if any(e is not None for e in exposed) else None),
+                exposed_note='mean over the last 8 timed steps of the event-timed wait of the compute stream for the '
+                             'all-reduces still in flight at the end of a backward pass (rank 0; summed over the models)',
+                rank_ms_per_step=dict(min=round(min(ms), 3), max=round(max(ms), 3)))
+
+
+def roofline_block(timer, ev_steps, steps, peak, args, precision, batch, world):
+    """`roofline` + per-family `kernels` from the dispatch timer."""
+    agg = timer.summary()
+    kernels = {}
+    for k, a in agg.items():
+        kernels[k] = dict(launches_per_step=round(a['launches'] / ev_steps, 2), avg_us=round(a['avg_ms'] * 1e3, 2),
+                          max_us=round(a['max_ms'] * 1e3, 2), total_ms_per_step=round(a['ms'] / ev_steps, 4),
+                          tflops=round(a['tflops'], 2), executed_tflops=round(a['executed_tflops'], 2))
+    if not agg:
+        return None, kernels
+    # dominant kernel = the MFMA family with the largest summed dispatch time over the timed steps
+    dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
+    a = dom[1]
+    traffic, tnote = None, 'not measured (--traffic none)'
+    if args.traffic == 'live' and world == 1:
+        traffic, tnote = measure_traffic(args, dom[0], precision, batch)
+    elif world > 1:
+        tnote = 'measured at N=1 only'
+    roof = dict(bound='mfma', kernel=dom[0], achieved=round(a['tflops'], 2),
+                peak=peak, unit='TFLOP/s',
+                frac=round(a['tflops'] / peak, 4), traffic=traffic, traffic_source=tnote,
+                # `achieved` counts ALGORITHMIC (direct-convolution) flop per launch, as the contract defines it;
+                # a Winograd F(4x4) launch executes 36/144 of those multiplies (F(2x2): 16/36), so `achieved`
+                # may exceed the MFMA peak.  `executed` is what the MFMA pipe really sustains.
+                executed=round(a['executed_tflops'], 2),
+                executed_frac=round(a['executed_tflops'] / peak, 4),
+                launches_per_step=round(a['launches'] / ev_steps, 2),
+                avg_launch_us=round(a['avg_ms'] * 1e3, 2),
+                alg_gflop_per_launch=round(a['flops'] / a['launches'] / 1e9, 3),
+                timing='hipExtLaunchKernelGGL start/stop events on the launch stream, every launch of the last %d of '
+                       'the %d timed steps, multi-stream schedule (dispatch begin..end, as rocprofv3 --kernel-trace)'
+                       % (ev_steps, steps),
+                dropped_launches=timer.dropped)
+    rest = sorted(((k, v) for k, v in agg.items() if k != dom[0]), key=lambda kv: -kv[1]['ms'])
+    if rest:
+        k2, a2 = rest[0]
+        roof['next'] = dict(kernel=k2, achieved=round(a2['tflops'], 2), frac=round(a2['tflops'] / peak, 4),
+                            executed_frac=round(a2['executed_tflops'] / peak, 4),
+                            launches_per_step=round(a2['launches'] / ev_steps, 2),
+                            avg_launch_us=round(a2['avg_ms'] * 1e3, 2))
+    # all MFMA conv dispatches of a step together: executed multiplies / summed dispatch time
+    tot_ms = sum(v['ms'] for v in agg.values())
+    roof['all_mfma_kernels'] = dict(
+        sum_dispatch_ms_per_step=round(tot_ms / ev_steps, 3),
+        executed_tflops=round(sum(v['executed'] for v in agg.values()) / (tot_ms * 1e-3) / 1e12, 2),
+        executed_frac=round(sum(v['executed'] for v in agg.values()) / (tot_ms * 1e-3) / 1e12 / peak, 4))
+    return roof, kernels
 
 
 def build(model_name, device):
@@ -155,11 +280,49 @@ def measure_traffic(args, kernel, precision, batch):
                                 % (per['FETCH_SIZE'][1], per['WRITE_SIZE'][1], fetch / 1e6, write / 1e6))
 
 
-def main_coteach(args, rank, world, device, batch, size, gflop_img):
+def cpu_baseline_coteach(batch, size, steps, max_threads, augset):
+    """The oracle's proposed step (oracle/steps.py::proposed_step = trainchaos_proposed_30cases1labeled.py:260-325, with
+    its PIL reverse augmentation) timed on the host cores on the SAME synthetic batch: 1 warm-up + `steps` steps."""
+    import oracle
+    from oracle.steps import reverseaug as pil_reverseaug
+    from aide_amd.synthetic import chaos_batch
+    cores = min(os.cpu_count() or 1, max_threads)
+    torch.set_num_threads(cores)
+    torch.manual_seed(2)
+    n1 = oracle.fuseunet(2)
+    torch.manual_seed(2)
+    n2 = oracle.fuseunet(2)
+    n1.train(); n2.train()
+    w = torch.tensor([1.0, 1.0])
+    crit = oracle.CEMDiceLossImage(cediceweight=w, ceclassweight=w, diceclassweight=w)
+    corr = oracle.MulticlassMSELoss(reduction='none')
+    o1 = torch.optim.Adam(n1.parameters(), lr=1e-4, amsgrad=True)
+    o2 = torch.optim.Adam(n2.parameters(), lr=1e-4, amsgrad=True)
+    xin, xout, t = chaos_batch(batch, size, seed=1234)
+    augs = [((xin * (1 + 0.05 * k)), (xout * (1 - 0.05 * k))) for k in range(4)]
+    rev = lambda lst: pil_reverseaug(augset, lst, 2)
+
+    def step():
+        return oracle.proposed_step(n1, n2, crit, corr, o1, o2, xin, xout, augs, t, t, 0.25, reverse=rev)
+    step()                                                        # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        step()
+    dt = (time.time() - t0) / steps
+    return dict(value=batch / dt, unit='images/sec', cores=torch.get_num_threads(), host_cores=os.cpu_count(),
+                kind='port',
+                sample='%d co-teaching step(s) of the same two-fuseunet bs=%d %dx%d fp32 workload (oracle = aten CPU + PIL '
+                       'restatement of the proposed inner loop, pinned bit-equal to the reference; 1 warm-up)'
+                       % (steps, batch, size, size),
+                sec_per_step=dt)
+
+
+def main_coteach(args, rank, world, device, batch, size, gflop_img, act, probes):
     """BASELINE config 3 (not the headline): the AIDE proposed step; N>1 = data-parallel replicas with per-replica
     BatchNorm statistics and small-loss selection, both networks' gradients mean-all-reduced."""
     from aide_amd.optim import Adam
     from aide_amd.distributed import GradAllReduce, broadcast_module
+    from aide_amd.profiling import DispatchTimer
     from aide_amd.synthetic import chaos_batch
     from aide_amd.utils import CoTeachingProposedLoss
     from aide_amd.train_files.trainchaos_proposed_30cases1labeled import coteach_step
@@ -170,7 +333,9 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img):
     peak = BF16_MFMA_PEAK_TFLOPS if precision == 'bf16' else FP32_MFMA_PEAK_TFLOPS
     if world > 1:
         broadcast_module(n1); broadcast_module(n2)
-    reducers = [GradAllReduce(n1), GradAllReduce(n2)] if world > 1 else None      # installed on the engines
+    reducers = [GradAllReduce(n1), GradAllReduce(n2)] if world > 1 else []      # installed on the engines
+    for r in reducers:
+        r.time_exposed = True
     o1, o2 = Adam(n1.parameters(), lr=1e-4, amsgrad=True), Adam(n2.parameters(), lr=1e-4, amsgrad=True)
     op = CoTeachingProposedLoss(cediceweight=[1.0, 1.0], ceclassweight=[1.0, 1.0], segcor_weight=[1.0, 10.0])
     xin, xout, t = chaos_batch(batch, size, seed=1234 + rank)
@@ -183,38 +348,34 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img):
 
     def step():
         return coteach_step(n1, n2, o1, o2, op, xin, xout, augs, t, t, 0.25, augset=augset)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([el], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        el = float(tmax.item())
+    ev_steps = max(1, min(args.event_steps, args.steps))
+    timer = None if args.no_kernel_events else DispatchTimer(capacity=1200 * ev_steps)
+    el, _, per_rank, r = timed_steps(step, args, world, device, timer, ev_steps)
+    final = [round(float(r['loss1']), 6), round(float(r['loss2']), 6)]
     if rank != 0:
         return
     value = batch * world * args.steps / el
-    print(json.dumps(dict(metric='training images/sec AIDE co-teaching (2x FuseUNet) %dx%dx2 bs=%d/GPU' % (size, size, batch),
-                          value=round(value, 2), unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
-                          ms_per_step=round(el / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
-                          vs_baseline=None, dtype='f32' if precision == 'fp32' else 'bf16', data='synthetic',
-                          config=dict(workload='c3 two fuseunet co-teaching step (4 aug fwd + fwd + bwd + Adam per net, '
-                                               'on-device reverseaug, fused selection), %dx%d, bs=%d, %s' % (size, size, batch, precision),
-                                      alg_gflop_per_image=gflop_img),
-                          step_tflops=round(value * gflop_img / 1e3, 2),
-                          step_mfma_frac=round(value * gflop_img / 1e3 / peak, 4),
-                          final_loss=[round(float(r['loss1']), 6), round(float(r['loss2']), 6)],
-                          roofline=None, cpu_baseline=None)))
+    roof, kernels = (None, {}) if timer is None else roofline_block(timer, ev_steps, args.steps, peak, args, precision,
+                                                                    batch, world)
+    cpu = None
+    cpu_steps = args.cpu_steps if args.cpu_steps is not None else 1
+    if world == 1 and not args.no_cpu_baseline and cpu_steps > 0:
+        cpu = cpu_baseline_coteach(batch, size, cpu_steps, args.cpu_threads, augset)
+    line = dict(metric='training images/sec AIDE co-teaching (2x FuseUNet) %dx%dx2 bs=%d/GPU' % (size, size, batch),
+                value=round(value, 2), unit='images/sec', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                ms_per_step=round(el / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
+                vs_baseline=None, dtype='f32' if precision == 'fp32' else 'bf16', data='synthetic',
+                config=dict(workload='c3 two fuseunet co-teaching step (4 aug fwd + fwd + bwd + Adam per net, '
+                                     'on-device reverseaug, fused selection), %dx%d, bs=%d/GPU, %s'
+                                     % (size, size, batch, precision),
+                            global_batch=batch * world, parallelism='dp%d' % world, alg_gflop_per_image=gflop_img),
+                step_tflops=round(value * gflop_img / 1e3, 2),
+                step_mfma_frac=round(value * gflop_img / 1e3 / world / peak, 4),
+                final_loss=final, comm=comm_block(world, reducers, per_rank, args.steps), switches=act,
+                roofline=roof, kernels=kernels, cpu_baseline=cpu)
+    if probes:
+        line['INVALID'] = 'timing probes active: %s' % ', '.join(probes)
+    print(json.dumps(line))
 
 
 def self_launch(args):
@@ -239,6 +400,7 @@ def self_launch(args):
 
 def main():
     args = parse()
+    act, probes = probe_guard(args)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product path has no CPU fallback)')
     if args.gpus < 1:
@@ -262,7 +424,7 @@ def main():
     if args.batch_size:
         batch = args.batch_size
     if model_name == 'coteach':
-        main_coteach(args, rank, world, device, batch, size, gflop_img)
+        main_coteach(args, rank, world, device, batch, size, gflop_img, act, probes)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -273,102 +435,38 @@ def main():
     peak = BF16_MFMA_PEAK_TFLOPS if precision == 'bf16' else FP32_MFMA_PEAK_TFLOPS
     if world > 1:
         broadcast_module(net)
-    reducer = GradAllReduce(net) if world > 1 else None
+    reducers = [GradAllReduce(net)] if world > 1 else []
+    for r in reducers:
+        r.time_exposed = True
     w = torch.tensor([1.0, 1.0])
     crit = U.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
     opt = Adam(net.parameters(), lr=1e-4, amsgrad=True)
     xin, xout, tgt = chaos_batch(batch, size, seed=1234 + rank, single_modal=(not model_name.startswith('fuseunet')))
     xin, tgt = xin.to(device), tgt.to(device)
     xout = xout.to(device) if xout is not None else None
+    no_optim = 'AIDE_PROBE_NO_OPTIM' in probes           # (timing probe: the step without its optimizer -- INVALID line)
 
     def step():
         opt.zero_grad()
         out = net(xin, xout) if xout is not None else net(xin)
         loss = crit(out, tgt)
         loss.backward()
-        if not os.environ.get('AIDE_PROBE_NO_OPTIM'):      # (timing probe: the step without its optimizer -- an INVALID bench line)
+        if not no_optim:
             opt.step()
         return loss
 
-    for w_i in range(args.warmup):
-        step()
     # every launch of every MFMA conv kernel in the timed steps carries a start / stop event pair holding the dispatch's
-    # own begin / end timestamps (C ABI kernel timer): the steps keep their two-stream schedule, nothing is serialised
+    # own begin / end timestamps (C ABI kernel timer): the steps keep their multi-stream schedule, nothing is serialised
     ev_steps = max(1, min(args.event_steps, args.steps))
     timer = None if args.no_kernel_events else DispatchTimer(capacity=200 * ev_steps)
-    if timer is not None:
-        timer.start()                             # creates the events: outside the timed region
-        timer.stop()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if timer is not None and i == args.steps - ev_steps:
-            timer.arm()                           # the last ev_steps timed steps: their MFMA conv launches carry events
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if timer is not None:
-        timer.stop()
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed, _, per_rank, loss = timed_steps(step, args, world, device, timer, ev_steps)
     final_loss = float(loss.item())
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = batch * world * args.steps / elapsed
-        roof = None
-        kernels = {}
-        if timer is not None:
-            agg = timer.summary()
-            for k, a in agg.items():
-                kernels[k] = dict(launches_per_step=round(a['launches'] / ev_steps, 2), avg_us=round(a['avg_ms'] * 1e3, 2),
-                                  max_us=round(a['max_ms'] * 1e3, 2), total_ms_per_step=round(a['ms'] / ev_steps, 4),
-                                  tflops=round(a['tflops'], 2), executed_tflops=round(a['executed_tflops'], 2))
-            if agg:
-                # dominant kernel = the MFMA family with the largest summed dispatch time over the timed steps
-                dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
-                a = dom[1]
-                traffic, tnote = None, 'not measured (--traffic none)'
-                if args.traffic == 'live' and world == 1:
-                    traffic, tnote = measure_traffic(args, dom[0], precision, batch)
-                elif world > 1:
-                    tnote = 'measured at N=1 only'
-                roof = dict(bound='mfma', kernel=dom[0], achieved=round(a['tflops'], 2),
-                            peak=peak, unit='TFLOP/s',
-                            frac=round(a['tflops'] / peak, 4), traffic=traffic, traffic_source=tnote,
-                            # `achieved` counts ALGORITHMIC (direct-convolution) flop per launch, as the contract defines it;
-                            # a Winograd F(4x4) launch executes 36/144 of those multiplies (F(2x2): 16/36), so `achieved`
-                            # may exceed the MFMA peak.  `executed` is what the MFMA pipe really sustains.
-                            executed=round(a['executed_tflops'], 2),
-                            executed_frac=round(a['executed_tflops'] / peak, 4),
-                            launches_per_step=round(a['launches'] / ev_steps, 2),
-                            avg_launch_us=round(a['avg_ms'] * 1e3, 2),
-                            alg_gflop_per_launch=round(a['flops'] / a['launches'] / 1e9, 3),
-                            timing='hipExtLaunchKernelGGL start/stop events on the launch stream, every launch of the last %d of '
-                                   'the %d timed steps, two-stream schedule (dispatch begin..end, as rocprofv3 --kernel-trace)'
-                                   % (ev_steps, args.steps),
-                            dropped_launches=timer.dropped)
-                rest = sorted(((k, v) for k, v in agg.items() if k != dom[0]), key=lambda kv: -kv[1]['ms'])
-                if rest:
-                    k2, a2 = rest[0]
-                    roof['next'] = dict(kernel=k2, achieved=round(a2['tflops'], 2), frac=round(a2['tflops'] / peak, 4),
-                                        executed_frac=round(a2['executed_tflops'] / peak, 4),
-                                        launches_per_step=round(a2['launches'] / ev_steps, 2),
-                                        avg_launch_us=round(a2['avg_ms'] * 1e3, 2))
-                # all MFMA conv dispatches of a step together: executed multiplies / summed dispatch time
-                tot_ms = sum(v['ms'] for v in agg.values())
-                roof['all_mfma_kernels'] = dict(
-                    sum_dispatch_ms_per_step=round(tot_ms / ev_steps, 3),
-                    executed_tflops=round(sum(v['executed'] for v in agg.values()) / (tot_ms * 1e-3) / 1e12, 2),
-                    executed_frac=round(sum(v['executed'] for v in agg.values()) / (tot_ms * 1e-3) / 1e12 / peak, 4))
+        roof, kernels = (None, {}) if timer is None else roofline_block(timer, ev_steps, args.steps, peak, args,
+                                                                        precision, batch, world)
         cpu = None
         cpu_steps = args.cpu_steps if args.cpu_steps is not None else (5 if args.workload in ('c2', 'tiny') else 2)
         if world == 1 and not args.no_cpu_baseline and cpu_steps > 0:
@@ -389,8 +487,10 @@ def main():
                     step_tflops=round(value * gflop_img / 1e3, 2),
                     step_mfma_frac=round(value * gflop_img / 1e3 / world / peak, 4),
                     final_loss=round(final_loss, 6),
-                    comm=dict(backend=(dist.get_backend() if world > 1 else None), ranks=world),
+                    comm=comm_block(world, reducers, per_rank, args.steps), switches=act,
                     roofline=roof, kernels=kernels, cpu_baseline=cpu)
+        if probes:
+            line['INVALID'] = 'timing probes active: %s' % ', '.join(probes)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

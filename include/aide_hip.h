@@ -240,6 +240,7 @@ int aide_dice_terms_bwd(const float* x, int64_t x_bs, const float* t, int64_t t_
  * calls, so that a recorded launch sequence (aide_amd/tape.py) can re-issue them.  aide_stream_order(ev, from, to):
  * work enqueued on `to` afterwards waits for the work enqueued on `from` so far (hipEventRecord + hipStreamWaitEvent). */
 int aide_event_create(void** ev);
+int aide_event_destroy(void* ev);
 int aide_stream_order(void* ev, aide_stream_t from, aide_stream_t to);
 
 /* ---- CU-masked stream (host pointers) ---------------------------------------------------------------------------
@@ -258,6 +259,9 @@ int aide_stream_create_cumask(void** stream, const void* mask, int words);
 int aide_wgrad_reduce_defer(int on);
 int aide_wgrad_reduce_pending(void);
 int aide_wgrad_reduce_flush(aide_stream_t stream);
+/* Error path: drop every pending descriptor (they point into a pass that did not finish) and leave the deferred mode.
+ * Returns the number of descriptors dropped.  aide_wgrad_reduce_defer(1) drops stale descriptors as well. */
+int aide_wgrad_reduce_discard(void);
 
 /* ---- kernel timer (measurement only; bench.py `roofline`) --------------------------------------------------------
  * While armed for a family, every launch of that family's MAIN kernel carries a start / stop HIP event pair on its own

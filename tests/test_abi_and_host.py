@@ -200,3 +200,23 @@ def test_per_image_operand_limit():
     x = torch.empty(1, 3, 2048, 2048, device='meta')
     with pytest.raises(RuntimeError, match='too large'):
         net.engine.plan_for((x, x))
+
+
+def test_bench_probe_guard_needs_no_gpu():
+    """bench.py refuses AIDE_PROBE_* switches before it touches a device (a probe run is not a measurement)"""
+    import subprocess
+    import sys
+    env = dict(os.environ, AIDE_PROBE_SKIP_WGRAD='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1'], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and 'AIDE_PROBE_SKIP_WGRAD' in r.stderr and not r.stdout.strip()
+
+
+def test_wgrad_reduce_discard_and_event_destroy_exported(built):
+    """the error-path entry points of the deferred slab reduce (no launches: host state only)"""
+    from aide_amd._lib import lib
+    dll = lib.load()
+    assert dll.aide_wgrad_reduce_defer(1) == 0
+    assert dll.aide_wgrad_reduce_pending() == 0
+    assert dll.aide_wgrad_reduce_discard() == 0          # nothing pending; leaves the deferred mode
+    assert dll.aide_wgrad_reduce_defer(0) == 0           # ... so the previous mode reads 0

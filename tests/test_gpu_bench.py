@@ -68,3 +68,45 @@ def test_bench_self_launch(dev):
     j = _line(r)
     assert j['n_gpus'] == ndev + 1 and j['comm']['ranks'] == ndev + 1 and j['comm']['backend'] == 'gloo'
     assert j['config']['parallelism'] == 'dp%d' % (ndev + 1)
+    _check_comm(j, ndev + 1)
+
+
+def _check_comm(j, world):
+    """the N > 1 fields of the line: bucket plan, bytes exchanged per step, exposed communication, per-rank step times"""
+    c = j['comm']
+    assert c['ranks'] == world and c['buckets'] >= 1
+    assert c['bytes_per_step'] >= 4 * 26_000_000          # the FuseUNet gradient arena (26.7 M parameters) per model
+    assert c['exposed_ms'] is not None and 0.0 <= c['exposed_ms'] < j['ms_per_step']
+    rk = c['rank_ms_per_step']
+    assert 0 < rk['min'] <= rk['max'] <= j['ms_per_step'] * 1.001
+    assert isinstance(j['switches'], dict)
+
+
+@pytest.mark.parametrize('workload', ['c2', 'c3', 'c4', 'c5'])
+def test_bench_two_ranks(dev, workload):
+    """The N = 2 bench flow of every BASELINE configuration (broadcast, overlapped bucket reduces, barrier, max-over-ranks
+    timing, the rank-0 line with its comm block): over RCCL with one rank per device where two devices are visible, as a
+    gloo dry run with both ranks on the one device otherwise."""
+    two = torch.cuda.device_count() >= 2
+    args = ['--gpus', '2', '--workload', workload, '--steps', '3', '--warmup', '2', '--event-steps', '2',
+            '--no-cpu-baseline', '--traffic', 'none']
+    r = _run(args, env=None if two else {'AIDE_DIST_BACKEND': 'gloo'}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r)
+    assert j['n_gpus'] == 2 and j['comm']['backend'] == ('nccl' if two else 'gloo')
+    assert (j['comm']['rccl_version'] is not None) == two
+    assert j['config']['global_batch'] == 2 * (8 if workload == 'c5' else 4)
+    _check_comm(j, 2)
+    assert j['roofline'] is not None and j['roofline']['dropped_launches'] == 0
+
+
+def test_bench_refuses_probe_switches(dev):
+    r = _run(['--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--traffic', 'none'], env={'AIDE_PROBE_NO_OPTIM': '1'})
+    assert r.returncode != 0 and 'AIDE_PROBE_NO_OPTIM' in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    r = _run(['--workload', 'tiny', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--traffic', 'none',
+              '--allow-probes'], env={'AIDE_PROBE_NO_OPTIM': '1', 'AIDE_DUAL_FWD': '1'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r)
+    assert 'AIDE_PROBE_NO_OPTIM' in j['INVALID']
+    assert j['switches'].get('AIDE_DUAL_FWD') == '1' and j['switches'].get('AIDE_PROBE_NO_OPTIM') == '1'

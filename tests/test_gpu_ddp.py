@@ -1,6 +1,11 @@
-"""Two data-parallel ranks on ONE MI355X (-m gpu): the real engine, streams, events and bucket schedule of
-aide_amd.distributed with a real exchange between two processes.  RCCL refuses two ranks on one device, so the exchange
-itself goes over gloo (AIDE_DIST_BACKEND=gloo, the dry-run backend); everything on the GPU side is the product path.
+"""Two data-parallel ranks (-m gpu): the real engine, streams, events and bucket schedule of aide_amd.distributed with a
+real exchange between two processes.
+
+backend = gloo: both ranks on ONE MI355X (RCCL refuses two ranks on one device, so the exchange itself goes over gloo,
+AIDE_DIST_BACKEND=gloo, the dry-run backend); everything on the GPU side is the product path.
+backend = nccl: one rank per device over real RCCL (ReduceOp.AVG on the communication stream, `device_id=` init, the
+tape-replayed bucket hooks); switches itself on wherever >= 2 HIP devices are visible, skipped (with the reason) on a
+1-GPU box.
 
 Checked: the reduced gradient arena equals the mean of the two ranks' local gradients (bit-exact against an all-gather of
 the local arenas reduced in rank order ... up to the (a+b)/2 vs a/2+b/2 rounding: 1e-6), and both ranks hold identical
@@ -22,9 +27,9 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, kind, out):
+def _worker(rank, world, port, kind, out, backend='gloo'):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                      MASTER_PORT=str(port), AIDE_DIST_BACKEND='gloo')
+                      MASTER_PORT=str(port), AIDE_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0')
     import torch.distributed as dist
     from aide_amd import utils as U
     from aide_amd.distributed import init_from_env, attach
@@ -33,6 +38,9 @@ def _worker(rank, world, port, kind, out):
     from aide_amd.train_files.trainchaos_comparison_1case import build_model
     r, w, dev = init_from_env()
     assert (r, w) == (rank, world)
+    assert dist.get_backend() == backend
+    if backend == 'nccl':
+        assert dev.index == rank            # one device per rank
     torch.manual_seed(2 + rank)                    # different initial weights per rank: attach() must broadcast rank 0's
     net = build_model(kind, 2).to(dev)
     net.train()
@@ -56,7 +64,11 @@ def _worker(rank, world, port, kind, out):
     local = [p.grad.detach().clone() for p in net.parameters()]
     net.zero_grad()
     eng.after_backward_op, eng.grad_hook, eng.before_backward = hooks
-    crit(net(*args), t.to(dev)).backward()
+    # three steps through the reducer: the first records the backward launch tape (bucket hooks are tape entries), the
+    # later ones replay it -- the replayed exchange must produce the same mean
+    for _ in range(3):
+        net.zero_grad()
+        crit(net(*args), t.to(dev)).backward()
     worst = 0.0
     for p, g in zip(net.parameters(), local):
         parts = [torch.empty_like(g) for _ in range(world)]
@@ -78,13 +90,16 @@ def _worker(rank, world, port, kind, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
 @pytest.mark.parametrize('kind', ['fuseunet', 'UNet'])
-def test_two_ranks_one_gpu(dev, kind):
+def test_two_ranks(dev, kind, backend):
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        pytest.skip('RCCL needs one HIP device per rank: %d visible (runs on any box with >= 2)' % torch.cuda.device_count())
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, out, backend)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
