@@ -12,6 +12,8 @@ reference training loops (`net(...)`, `loss.backward()`, `optimizer.step()`) wor
 
 All arithmetic is in libaide_hip.so (see include/aide_hip.h); torch only owns memory and streams.
 """
+import ctypes
+
 import torch
 
 from . import ops
@@ -103,6 +105,7 @@ HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switc
 EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B switch: BN statistics from the conv epilogue
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
 PROBE_NO_REPACK = [_os.environ.get('AIDE_PROBE_NO_REPACK', '0') != '0']   # timing probe (stale filters): what the per-step re-layout costs
+BF16_EPILOGUE_STATS = [_os.environ.get('AIDE_BF16_EPILOGUE_STATS', '1') != '0']   # A-B switch: ... of the bf16 forward kernel
 GROUP_STATS = [_os.environ.get('AIDE_GROUP_STATS', '1') != '0']    # A-B switch: epilogue BatchNorm statistics in grouped (stacked-batch) forwards
 F4_HALF_TILES = [_os.environ.get('AIDE_F4_HALF_TILES', '0') != '0']   # A-B switch: F(4x4) on layers whose Cout is 32 mod 64
 W16_PAIRS = [_os.environ.get('AIDE_W16_PAIRS', '0') != '0']      # F(4x4) on the 16-pixel-wide level (image pairs per tile): 11 % faster per launch than F(2x2), -0.6 % on the C2 step (larger filter pack, more slabs for BatchNorm to sum): off
@@ -280,7 +283,12 @@ class Plan(object):
                         # 575 -> 572 images/s (their epilogues are short and the butterflies cost more than the saved pass) and
                         # the fp32 partial sums of the 3->64 stem at 320x320 (|mean| >> std) moved a gradient norm by 3e-3.
                         parts = lib.aide_conv3x3_wino4_stats_parts(n, hh, ww) if st['wino_f'] == 4 else 0
-                        if parts > 0:
+                        # bf16 forward storing a bf16 z: its epilogue sums the STORED values (bias included)
+                        st['stats_biased'] = False
+                        if st['wino_f'] == BF16 and STORE_BF16[0] and BF16_EPILOGUE_STATS[0]:
+                            parts = lib.aide_conv3x3_bf16_stats_parts(n, hh, ww, cout)
+                            st['stats_biased'] = True
+                        if parts > 0 and parts % max(groups, 1) == 0:
                             st['stats_parts'] = parts
                             st['stats'] = torch.empty(cout * parts * 2, **f32)
                     st['pack_key'] = None
@@ -349,10 +357,12 @@ class Plan(object):
         self._bwd_ready = False
         self.profiler = None             # set by Engine (bench.py's per-kernel HIP-event timing)
         self._pack_key, self._pack_tab, self.side_fwd = None, None, None
+        self._convs = self._conv_wslots = None
         self._late_pending, self._late_inflight = None, False
         self._gate_conv = None           # the first conv that needs the side-stream filter packs
         self._tape_f = self._tape_b = None
         self._fp = None
+        self._fp_slots = self._fp_bns = None
         self.overlap = True              # weight gradients on a side stream (see backward)
         self.trace = None                # tools/phase_trace.py: callable(direction, step) before every op
         self.hp = None                   # high-priority stream of the backward chain (HP_CHAIN)
@@ -446,8 +456,12 @@ class Plan(object):
         torch optimizers, PARAM_EPOCH for the fused Adam).  Two launches: the first few (tiny, stage-1)
         filters on the main stream, all the others on the side stream so that the 0.25 ms re-layout runs
         under the first convolutions; returns the index of the first conv that must wait for it."""
-        convs = [st for st in self.steps if st['kind'] == 'conv']
-        key = (PARAM_EPOCH[0],) + tuple((st['conv'].weight.data_ptr(), st['conv'].weight._version) for st in convs)
+        convs = self._convs
+        if convs is None:
+            convs = self._convs = [st for st in self.steps if st['kind'] == 'conv']
+            self._conv_wslots = [st['conv']._parameters for st in convs]          # (every forward: no module __getattr__)
+        ws = [d['weight'] for d in self._conv_wslots]
+        key = (PARAM_EPOCH[0],) + tuple((w.data_ptr(), w._version) for w in ws)
         if key == self._pack_key or (PROBE_NO_REPACK[0] and self._pack_key is not None):
             return None
         ptrs = tuple(k[0] for k in key[1:])
@@ -511,9 +525,10 @@ class Plan(object):
             return None
         if self.side_fwd is None:
             self.side_fwd = torch.cuda.Stream(device=self.dev)
-        main = torch.cuda.current_stream()
-        self.side_fwd.wait_stream(main)
-        with torch.cuda.stream(self.side_fwd):
+            self._side_fwd_ptr = ctypes.c_void_p(self.side_fwd.cuda_stream)
+            self.ev_pack_fork = ops.new_event()
+        ops.order(self.ev_pack_fork, ops.stream_ptr(), self._side_fwd_ptr)
+        with ops.use_stream(self._side_fwd_ptr):
             launch(rest)
         return gate
 
@@ -532,19 +547,27 @@ class Plan(object):
         """addresses of every parameter and buffer the launch sequence bakes in (a tape is only valid for these)"""
         # ... and everything else a recorded sequence depends on: the runtime schedule switches and the BatchNorm scalars
         fp = [DUAL_FWD[0], DUAL_BWD[0], FOLD_SPLITK[0], FOLD_SPLITK_BWD[0], DEFER_WGRAD_REDUCE[0], FLUSH_EVERY,
-              HEAD_WGRAD_SIDE[0], EPILOGUE_STATS[0], self.overlap]
-        for st in self.steps:
-            bn = st.get('bn')
-            if bn is not None:
-                fp += [bn.eps, bn.momentum]
-            for key in ('conv', 'bn'):
-                m = st.get(key)
-                if m is not None:
-                    fp += [t.data_ptr() for t in m.parameters(recurse=False)]
-                    fp += [t.data_ptr() for t in m.buffers(recurse=False)]
-            m = st.get('mod')
-            if m is not None:
-                fp += [t.data_ptr() for t in m.parameters()] + [t.data_ptr() for t in m.buffers()]
+              HEAD_WGRAD_SIDE[0], EPILOGUE_STATS[0], BF16_EPILOGUE_STATS[0], self.overlap]
+        # (this runs every forward: the tensors are looked up through the modules' own _parameters / _buffers dicts -- a
+        # replaced parameter or buffer is seen -- without walking the module tree)
+        slots = self._fp_slots
+        if slots is None:
+            slots, bns = [], []
+            for st in self.steps:
+                if st.get('bn') is not None:
+                    bns.append(st['bn'])
+                for key in ('conv', 'bn', 'mod'):
+                    m = st.get(key)
+                    if m is None:
+                        continue
+                    for sub in (m.modules() if key == 'mod' else (m,)):
+                        slots += [(sub._parameters, k) for k, v in sub._parameters.items() if v is not None]
+                        slots += [(sub._buffers, k) for k, v in sub._buffers.items() if v is not None]
+            self._fp_slots, self._fp_bns = slots, bns
+        for bn in self._fp_bns:
+            fp.append(bn.eps)
+            fp.append(bn.momentum)
+        fp += [d[k].data_ptr() for d, k in slots]
         return tuple(fp)
 
     def _tapeable(self):
@@ -688,7 +711,8 @@ class Plan(object):
                 if st.get('stats') is not None:
                     # (a group of a stacked batch owns a contiguous run of the per-image entries of every channel)
                     gparts = st['stats_parts'] // ngroups
-                    ops.bn_train_fwd_parts(zg, ag, st['stats'], gparts, st['conv'].bias, bn.weight, bn.bias, bn.eps,
+                    ops.bn_train_fwd_parts(zg, ag, st['stats'], gparts, None if st['stats_biased'] else st['conv'].bias,
+                                           bn.weight, bn.bias, bn.eps,
                                            bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                            st['mean'], st['rstd'], st['scale'], st['shift'], True,
                                            first=gi * gparts, stride=st['stats_parts'])
@@ -1075,6 +1099,7 @@ class Engine(object):
         self.graph = None
         self._precision = 'fp32'
         self._arena = self._views = self._anchor = None
+        self._pslots = None
 
     def grad_arena(self, device):
         """the persistent flat gradient arena of this module and the per-parameter views into it (offsets: _refresh_params)"""
@@ -1099,7 +1124,14 @@ class Engine(object):
             self.plans = {}
 
     def _refresh_params(self):
+        # every forward: the known parameters are checked where they live (their owner's _parameters dict) -- walking the
+        # module tree costs ~0.4 ms for 130 parameters.  A replaced parameter fails the check and triggers the full walk.
+        slots = self._pslots
+        if slots is not None and self.params is not None and all(d.get(k) is p for d, k, p in slots):
+            return
         params = list(self.module.parameters())
+        self._pslots = [(m._parameters, k, p) for m in self.module.modules() for k, p in m._parameters.items()
+                        if p is not None]
         if self.params is None or len(params) != len(self.params) or \
                 any(a is not b for a, b in zip(params, self.params)):
             self.params = params

@@ -92,7 +92,7 @@ class Adam(torch.optim.Optimizer):
             if fast is not None:
                 params = group['params']
                 grads = [p.grad for p in params]
-                if fast['params'] is params and len(params) == fast['n'] and None not in grads and \
+                if fast['params'] is params and len(params) == fast['n'] and all(g is not None for g in grads) and \
                         tuple(g.data_ptr() for g in grads) == fast['gkey'] and \
                         tuple(p.data_ptr() for p in params) == fast['pkey'] and \
                         bool(group['amsgrad']) == fast['amsgrad']:

@@ -122,8 +122,16 @@ class DiceLoss(nn.Module):
         if input.dim() <= 3:                # utils/loss2d.py:47-48: a probability map, no softmax
             if input.dtype != torch.float32 or not input.is_cuda:
                 raise RuntimeError('aide_amd.DiceLoss: probability input must be an fp32 tensor on a HIP device')
-            x = input.contiguous()
-            return _DiceTerms.apply(x, _dense_f32(target, x.shape, 'DiceLoss target'), 1, 1.0, 1.0, float(self.smooth), red)
+            # the reference flattens both per image (`input.view(N, -1)`, `target.view(N, -1)`, N = target.size(0)): any
+            # rank <= 3 input and any target with the same number of elements per image, e.g. [N,1,H,W] beside [N,H,W]
+            n = target.shape[0]
+            if input.numel() % max(n, 1) or target.numel() != input.numel():
+                raise RuntimeError('aide_amd.DiceLoss: input %s and target %s do not flatten to the same [N, -1]'
+                                   % (tuple(input.shape), tuple(target.shape)))
+            x = input.contiguous().view(n, 1, -1)
+            t = _dense_f32(target.reshape(n, 1, -1), x.shape, 'DiceLoss target')
+            out = _DiceTerms.apply(x, t, 1, 1.0, 1.0, float(self.smooth), red)
+            return out
         loss, self.last = _seg.seg_loss(input, target, 1.0, 1.0, 255, red, 0.0, 1.0 if red else 1.0,
                                         float(self.smooth))
         return loss

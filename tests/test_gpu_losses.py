@@ -351,3 +351,15 @@ def test_loss_branches_off_the_hot_path(dev):
         key = 'branch/%s/%s/%s' % (lname, tin, tag)
         close(v, fx[key], what=key)
         close(x.grad, fx[key + '/grad'], what=key + ' grad')
+        if lname == 'DiceLoss':
+            # the reference flattens per image (`view(N, -1)`, loss2d.py:47-50): a 2-D [N, H*W] input and an [N,1,H,W]
+            # target are the same problem and must give the same value and gradient
+            n = x.shape[0]
+            x2 = src[xin].clone().reshape(n, -1).requires_grad_(True)
+            v2 = getattr(U, lname)(**kw)(x2, tgt[tin].unsqueeze(1))
+            if v2.dim():
+                (v2 * torch.arange(1, v2.numel() + 1, device=dev).float()).sum().backward()
+            else:
+                v2.backward()
+            close(v2, fx[key], what=key + ' (flattened)')
+            close(x2.grad.reshape(x.shape), fx[key + '/grad'], what=key + ' grad (flattened)')
