@@ -674,16 +674,13 @@ int aide_bn_train_fwd_parts_strided(const void* z, int z_bf16, int64_t z_bs, voi
     const int HW = H * W;
     if (!z || !a || !parts || nparts <= 0 || parts_stride < nparts || HW % 4 || z_bs % 4 || a_bs % 4) return AIDE_ERR_ARG;
     const double count = (double)N * HW;
-    // 16-byte accesses: 8 values per lane on bf16-stored tensors, 4 on fp32 ones
-    const bool v8 = z_bf16 && a_bf16 && HW % 8 == 0 && z_bs % 8 == 0 && a_bs % 8 == 0;
-    const int gx = max(1, min((HW / (v8 ? 8 : 4) + 255) / 256, 16));
-#define AIDE_BN_PARTS(V, ZT, AT)                                                                                               \
-    hipLaunchKernelGGL((bn_train_apply_kernel<V, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, (const ZT*)z, (long)z_bs,    \
+    const int gx = max(1, min((HW / 4 + 255) / 256, 16));
+#define AIDE_BN_PARTS(ZT, AT)                                                                                                  \
+    hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, (const ZT*)z, (long)z_bs,    \
                        (AT*)a, (long)a_bs, C, HW, (const double*)nullptr, 0, count, gamma, beta, eps, momentum, running_mean, \
                        running_var, num_batches_tracked, mean, rstd, scale, shift, relu, parts, nparts, conv_bias, parts_stride)
-    if (v8) AIDE_BN_PARTS(8, bf16_t, bf16_t);
-    else if (z_bf16) { if (a_bf16) AIDE_BN_PARTS(4, bf16_t, bf16_t); else AIDE_BN_PARTS(4, bf16_t, float); }
-    else { if (a_bf16) AIDE_BN_PARTS(4, float, bf16_t); else AIDE_BN_PARTS(4, float, float); }
+    if (z_bf16) { if (a_bf16) AIDE_BN_PARTS(bf16_t, bf16_t); else AIDE_BN_PARTS(bf16_t, float); }
+    else { if (a_bf16) AIDE_BN_PARTS(float, bf16_t); else AIDE_BN_PARTS(float, float); }
 #undef AIDE_BN_PARTS
     return aide_launch_status();
 }

@@ -66,8 +66,6 @@ struct BfArgs {
     long x_bs, y_bs, split_stride;
     int N, Cin, H, W, Cout;
     int tiles_w, tiles_h, n_co_tiles, splitk, chunks_total, accumulate;
-    float* stats;             // optional [Cout][N * tiles_h * tiles_w][2]: per (channel, workgroup tile) sum / sum of squares of
-                              // the STORED bf16 outputs (bias included) -- the BatchNorm statistics partials
 };
 
 
@@ -368,28 +366,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
                 const int q = tid + k * NT;
                 const int seg = q % SEG, row = (q / SEG) % TH, cl = q / (SEG * TH);
                 const int oh = h0 + row;
-                u32x4 v = u32x4{0u, 0u, 0u, 0u};
                 if (q < NCH && oh < a.H) {
-                    v = *reinterpret_cast<const u32x4*>(ep + cl * EP + row * (TW / 2) + seg * 4);
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(ep + cl * EP + row * (TW / 2) + seg * 4);
                     *reinterpret_cast<u32x4*>(yn + (long)(co0 + pass * WM * 32 + cl) * HW + (long)oh * a.W + w0 + seg * 8) = v;
-                }
-                // BatchNorm statistics of what was just stored: the 64 pieces of one channel's tile are one wave's lanes
-                // (SEG * TH == 64), so a channel's partial sums are one butterfly over the wave
-                if (a.stats) {                                   // workgroup-uniform
-                    static_assert(SEG * TH == 64, "one wave per channel tile");
-                    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const float lo = bf16_lo(v[d]), hi = bf16_hi(v[d]);
-                        s1 += lo + hi;
-                        s2 = __builtin_fmaf(lo, lo, __builtin_fmaf(hi, hi, s2));
-                    }
-#pragma unroll
-                    for (int m = 32; m > 0; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
-                    if (lane == 0 && q < NCH) {
-                        const int nparts = a.N * a.tiles_h * a.tiles_w, blk = (n * a.tiles_h + th) * a.tiles_w + tw;
-                        *reinterpret_cast<f32x2*>(a.stats + ((long)(co0 + pass * WM * 32 + cl) * nparts + blk) * 2) = f32x2{s1, s2};
-                    }
                 }
             }
             if (pass + 1 < WAVES_M) __syncthreads();
@@ -889,14 +868,6 @@ int aide_conv3x3_bf16_splitk(int N, int Cin, int H, int W, int Cout) {
     return s;
 }
 
-// partial-statistics entries per channel a bf16-storing forward launch writes when a sink is armed (aide_conv_stats_sink):
-// one per (image, pixel tile); 0 = this shape has no statistics epilogue
-int aide_conv3x3_bf16_stats_parts(int N, int H, int W, int Cout) {
-    if (W < 32 || W % 32 || Cout % 32 || getenv("AIDE_BF16_TW")) return 0;      // (tile-width probe switch: no statistics)
-    const int tw = (bf16_wide_tile(W, H) && W % 64 == 0) ? 64 : 32, th = 512 / tw;
-    return N * ((H + th - 1) / th) * (W / tw);
-}
-
 size_t aide_conv3x3_bf16_pack_elems(int Cout, int Cin) {    // bf16 elements of one direction's pack
     return (size_t)((Cin + 15) / 16) * 18 * Cout * 8;
 }
@@ -924,10 +895,6 @@ int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint1
     BfArgs a;
     a.x = x; a.wp = u; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.chunks_total = (Cin + 15) / 16;
-    // a one-shot statistics sink armed by the caller (aide_conv_stats_sink) belongs to this launch if it is a plain bf16-storing
-    // forward; any other launch form leaves it armed for nobody: take it either way so that it never leaks to a later conv
-    float* sink = aide_conv_stats_take();
-    a.stats = (y_bf16 && splitk <= 1 && accumulate == 0) ? sink : nullptr;
     if (splitk < 1) splitk = 1;
     if (splitk > a.chunks_total) splitk = a.chunks_total;
     if (splitk > 1 && (!ws || (y_bs % 4) != 0)) return AIDE_ERR_ARG;

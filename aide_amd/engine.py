@@ -105,7 +105,6 @@ HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switc
 EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B switch: BN statistics from the conv epilogue
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
 PROBE_NO_REPACK = [_os.environ.get('AIDE_PROBE_NO_REPACK', '0') != '0']   # timing probe (stale filters): what the per-step re-layout costs
-BF16_EPILOGUE_STATS = [_os.environ.get('AIDE_BF16_EPILOGUE_STATS', '1') != '0']   # A-B switch: ... of the bf16 forward kernel
 GROUP_STATS = [_os.environ.get('AIDE_GROUP_STATS', '1') != '0']    # A-B switch: epilogue BatchNorm statistics in grouped (stacked-batch) forwards
 F4_HALF_TILES = [_os.environ.get('AIDE_F4_HALF_TILES', '0') != '0']   # A-B switch: F(4x4) on layers whose Cout is 32 mod 64
 W16_PAIRS = [_os.environ.get('AIDE_W16_PAIRS', '0') != '0']      # F(4x4) on the 16-pixel-wide level (image pairs per tile): 11 % faster per launch than F(2x2), -0.6 % on the C2 step (larger filter pack, more slabs for BatchNorm to sum): off
@@ -283,12 +282,9 @@ class Plan(object):
                         # 575 -> 572 images/s (their epilogues are short and the butterflies cost more than the saved pass) and
                         # the fp32 partial sums of the 3->64 stem at 320x320 (|mean| >> std) moved a gradient norm by 3e-3.
                         parts = lib.aide_conv3x3_wino4_stats_parts(n, hh, ww) if st['wino_f'] == 4 else 0
-                        # bf16 forward storing a bf16 z: its epilogue sums the STORED values (bias included)
-                        st['stats_biased'] = False
-                        if st['wino_f'] == BF16 and STORE_BF16[0] and BF16_EPILOGUE_STATS[0]:
-                            parts = lib.aide_conv3x3_bf16_stats_parts(n, hh, ww, cout)
-                            st['stats_biased'] = True
-                        if parts > 0 and parts % max(groups, 1) == 0:
+                        # (the same epilogue in the bf16 forward kernel -- sums of the stored bf16 z, one wave butterfly per
+                        # channel tile -- was built in round 3 and measured: C5 444 -> 434 images/s, dropped)
+                        if parts > 0:
                             st['stats_parts'] = parts
                             st['stats'] = torch.empty(cout * parts * 2, **f32)
                     st['pack_key'] = None
@@ -547,7 +543,7 @@ class Plan(object):
         """addresses of every parameter and buffer the launch sequence bakes in (a tape is only valid for these)"""
         # ... and everything else a recorded sequence depends on: the runtime schedule switches and the BatchNorm scalars
         fp = [DUAL_FWD[0], DUAL_BWD[0], FOLD_SPLITK[0], FOLD_SPLITK_BWD[0], DEFER_WGRAD_REDUCE[0], FLUSH_EVERY,
-              HEAD_WGRAD_SIDE[0], EPILOGUE_STATS[0], BF16_EPILOGUE_STATS[0], self.overlap]
+              HEAD_WGRAD_SIDE[0], EPILOGUE_STATS[0], self.overlap]
         # (this runs every forward: the tensors are looked up through the modules' own _parameters / _buffers dicts -- a
         # replaced parameter or buffer is seen -- without walking the module tree)
         slots = self._fp_slots
@@ -711,8 +707,7 @@ class Plan(object):
                 if st.get('stats') is not None:
                     # (a group of a stacked batch owns a contiguous run of the per-image entries of every channel)
                     gparts = st['stats_parts'] // ngroups
-                    ops.bn_train_fwd_parts(zg, ag, st['stats'], gparts, None if st['stats_biased'] else st['conv'].bias,
-                                           bn.weight, bn.bias, bn.eps,
+                    ops.bn_train_fwd_parts(zg, ag, st['stats'], gparts, st['conv'].bias, bn.weight, bn.bias, bn.eps,
                                            bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                            st['mean'], st['rstd'], st['scale'], st['shift'], True,
                                            first=gi * gparts, stride=st['stats_parts'])

@@ -174,9 +174,6 @@ int aide_bn_train_fwd_slabs(const float* slabs, int splitk, int64_t split_stride
  * plain aide_bn_train_fwd would need two launches for this shape. */
 int aide_conv_stats_sink(float* parts);
 int aide_conv3x3_wino4_stats_parts(int N, int H, int W);
-/* ... and of a bf16-storing forward launch of aide_conv3x3_bf16_mixed (non-split, accumulate == 0, y_bf16): there the
- * partials are sums of the STORED bf16 values (bias included): pass conv_bias = NULL to aide_bn_train_fwd_parts. */
-int aide_conv3x3_bf16_stats_parts(int N, int H, int W, int Cout);
 int aide_bn_two_pass(int N, int C, int H, int W);
 int aide_bn_train_fwd_parts(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C, int H,
                             int W, const float* parts, int nparts, const float* conv_bias, const float* gamma,
