@@ -805,8 +805,11 @@ class Plan(object):
         defer = DEFER_WGRAD_REDUCE[0] and self.profiler is None and self.precision != 'bf16'
         waiting = []                          # ops whose after_op callback waits for the flush of their weight gradient
 
+        pending = lib.load().aide_wgrad_reduce_pending     # raw entry point: a host-state query decides WHERE the flushes go
+                                                           # while recording; a replayed tape has no use for it
+
         def flush():
-            if lib.aide_wgrad_reduce_pending():
+            if pending():
                 ops.check(lib.aide_wgrad_reduce_flush(sp if side is not None else mp), 'wgrad_reduce_flush')
             if after_op is not None:
                 for w_st in waiting:          # their weight gradients are now enqueued in full
@@ -817,7 +820,7 @@ class Plan(object):
         if defer:
             def hook(w_st):
                 waiting.append(w_st)
-                if lib.aide_wgrad_reduce_pending() >= FLUSH_EVERY:
+                if pending() >= FLUSH_EVERY:
                     flush()
         if defer:
             lib.aide_wgrad_reduce_defer(1)

@@ -33,6 +33,35 @@ def step():
 for _ in range(5):
     step()
 torch.cuda.synchronize()
+
+# where the host time of a step goes inside the engine (the backward runs on autograd's device thread, which cProfile does
+# not see): wall time of the wrapped functions, accumulated over the measured steps
+import collections
+from aide_amd import engine as E, tape as T
+acc = collections.defaultdict(float)
+def wrap(owner, name, tag):
+    fn = getattr(owner, name)
+    def w(*a, **k):
+        t = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            acc[tag] += time.perf_counter() - t
+    setattr(owner, name, w)
+wrap(T.Tape, 'replay', 'tape.replay (forward + backward)')
+wrap(E.Plan, '_pack_filters', 'plan._pack_filters')
+wrap(E.Plan, 'backward', 'plan.backward')
+wrap(E.Plan, 'forward', 'plan.forward')
+wrap(E.Plan, '_fingerprint', 'plan._fingerprint')
+wrap(E.Engine, '_refresh_params', 'engine._refresh_params')
+bw = E._NetFunction.backward
+def bwd(ctx, g):
+    t = time.perf_counter()
+    try:
+        return bw(ctx, g)
+    finally:
+        acc['_NetFunction.backward'] += time.perf_counter() - t
+E._NetFunction.backward = staticmethod(bwd)
 phases = [0.0] * 5
 t_all = time.perf_counter()
 for _ in range(steps):
@@ -49,6 +78,13 @@ torch.cuda.synchronize()
 gpu = (time.perf_counter() - t_all) / steps
 print('host enqueue time per step: %.3f ms (zero_grad %.3f, forward %.3f, loss %.3f, backward %.3f, optimizer %.3f); '
       'wall per step incl. GPU drain: %.3f ms' % (host * 1e3, *[p * 1e3 for p in phases], gpu * 1e3))
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
+    print('  %-40s %.3f ms / step' % (k, v / steps * 1e3))
+plan = [p for p in net.engine.plans.values() if p.training][0]
+for nm, tp in (('forward', plan._tape_f), ('backward', plan._tape_b)):
+    if tp is not None:
+        c = collections.Counter(('py' if e[0] is None else e[3]) for e in tp.calls)
+        print('  %s tape: %d entries: %s' % (nm, len(tp.calls), ', '.join('%s x%d' % kv for kv in c.most_common())))
 if '--profile' in sys.argv:
     import cProfile, pstats
     pr = cProfile.Profile()
