@@ -88,7 +88,7 @@ def Train(args=None):
     scheduler = make_scheduler(args.lr_policy, optimizer, args.num_epoch)
     single = not args.model_name.startswith('fuseunet')
     history = {'train_loss': [], 'train_dice': []}
-    best_casedice = -1.0
+    best_casedice = 0.0                      # :188 (a case Dice of 0 never saves, as in the reference)
     for epoch in range(args.num_epoch):
         ts = time.time()
         net.train()
@@ -122,7 +122,10 @@ def Train(args=None):
             if args.checkpoint and casedice > best_casedice:
                 best_casedice = casedice
                 os.makedirs(args.checkpoint, exist_ok=True)
-                name = '%s_%s_rep%d_besttraincasedice.pkl' % (args.model_name, args.loss, args.repetition)
+                # file name of :125, :343-344 ('{model}_r{rep}.pkl' -> '{model}_r{rep}_besttraincasedice.pkl'): what the
+                # reference's evaluation scripts look for.  (The synthetic case Dice here is taken without the skimage
+                # keep_largest_connected_components post-processing of :267 -- SURVEY 2 #12, out of scope.)
+                name = '%s_r%d_besttraincasedice.pkl' % (args.model_name, args.repetition)
                 torch.save({'net': net.state_dict(), 'loss': history['train_loss'][-1], 'dice': history['train_dice'][-1],
                             'epoch': epoch + 1, 'history': history}, os.path.join(args.checkpoint, name))
     return net, history

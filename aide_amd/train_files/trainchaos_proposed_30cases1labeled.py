@@ -99,7 +99,7 @@ def Train(args=None):
     sch1 = make_scheduler(args.lr_policy, opt1, args.num_epoch)        # :236-240
     sch2 = make_scheduler(args.lr_policy, opt2, args.num_epoch)
     g = torch.Generator(device='cpu').manual_seed(args.torch_seed)
-    best = -1.0
+    best = 0.0                                                        # :244
     for epoch in range(args.num_epoch):
         ts = time.time()
         rate = min((float(epoch) / float(args.warmup_epoch)) ** 2, 1.0)          # :248
@@ -136,10 +136,13 @@ def Train(args=None):
             if args.checkpoint and (cd1 + cd2) / 2.0 > best:
                 best = (cd1 + cd2) / 2.0
                 os.makedirs(args.checkpoint, exist_ok=True)
-                for k, net in ((1, net1), (2, net2)):
+                # file names of :178-179, :512-513, :524-525 -- including the reference's own spelling of the second one
+                # ('..._net2_besttraincasedicde.pkl'), which its test scripts open
+                stem = '%s_temp%s_r%d' % (args.model_name, args.temperature, args.repetition)
+                for k, net, suffix in ((1, net1, 'besttraincasedice'), (2, net2, 'besttraincasedicde')):
                     torch.save({'net': net.state_dict(), 'loss': float(l1 if k == 1 else l2) / args.steps_per_epoch,
                                 'epoch': epoch + 1},
-                               os.path.join(args.checkpoint, '%s_net%d_besttraincasedice.pkl' % (args.model_name, k)))
+                               os.path.join(args.checkpoint, '%s_net%d_%s.pkl' % (stem, k, suffix)))
     return net1, net2
 
 
