@@ -241,6 +241,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     // ---- epilogue: D layout row i = (r&3) + 8*(r>>2) + 4*half, col j ----
     float* yn = a.y + (long)split * a.split_stride + (long)n * a.y_bs;
     const bool add_bias = (a.bias != nullptr) && (split == 0);
+    // The lane's 16 WM bias values first, as one batch of loads.  (Read next to their use, every one was a dependent
+    // global_load -> s_waitcnt vmcnt(0) that also waited for the stores issued before it -- stores count in vmcnt on gfx9 --
+    // i.e. one memory round trip per output element.)  The accumulate form batches its 16 old values per tile the same way.
+    float bv[WM][16];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            bv[m][r] = (add_bias && co < a.Cout) ? a.bias[co] : 0.0f;
+        }
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt) {
         const int oh = h0 + (wave_n * WN + nt) * RPT + j / PT_W;
@@ -248,16 +259,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
         const bool pok = oh < a.H && ow < a.W;
 #pragma unroll
         for (int m = 0; m < WM; ++m) {
+            float* const pb = yn + (long)(co0 + (wave_m * WM + m) * 32 + 4 * half) * HW + oh * a.W + ow;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[m][nt][r] + bv[m][r];
+            if (a.accumulate) {
+                float old[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = (r & 3) + 8 * (r >> 2);
+                    old[r] = (pok && co0 + (wave_m * WM + m) * 32 + 4 * half + cl < a.Cout) ? pb[(long)cl * HW] : 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += old[r];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (pok && co < a.Cout) {
-                    float v = acc[m][nt][r];
-                    if (add_bias) v += a.bias[co];
-                    float* p = yn + (long)co * HW + oh * a.W + ow;
-                    if (a.accumulate) v += *p;
-                    *p = v;
-                }
+                const int cl = (r & 3) + 8 * (r >> 2);
+                if (pok && co0 + (wave_m * WM + m) * 32 + 4 * half + cl < a.Cout) pb[(long)cl * HW] = v[r];
             }
         }
     }

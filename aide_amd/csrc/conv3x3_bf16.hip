@@ -99,7 +99,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
     constexpr int NOPS = NUX + NOPA;                    // one staging op per tap
     static_assert(NOPS <= 9, "staging schedule");
     static_assert(WN % CB == 0, "a wave's column blocks must cover whole tile rows");
-    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * BUF slots
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * BUF slots + TCO floats (this tile's bias)
+    // The epilogue adds the bias from LDS.  (Read from global memory inside the epilogue it was one dependent
+    // global_load -> s_waitcnt vmcnt(0) per accumulator pair, 64 times per thread: 30-48 % of the short-K layers.)
+    float* sbias = reinterpret_cast<float*>(lds + 2 * BUF);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int half = lane >> 5, j = lane & 31;
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
     const int cps = (a.chunks_total + a.splitk - 1) / a.splitk;
     const int c_begin = split * cps;
     const int c_end = min(c_begin + cps, a.chunks_total);
+    if (tid < TCO) sbias[tid] = (a.bias != nullptr && split == 0) ? a.bias[co0 + tid] : 0.0f;   // (visible after the prologue barrier)
 
     // ---- per-thread staging descriptors (the same for every chunk) ----
     unsigned offX[NUX], ldsX[NUX];
@@ -295,7 +299,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
 #ifdef AIDE_PROBE_NO_STORE
     if (a.N > 0) { if (acc[0][0][0] == 123.456f) ((float*)a.y)[0] = acc[WM - 1][WN - 1][15]; return; }
 #endif
-    const bool add_bias = (a.bias != nullptr) && (split == 0);
     if constexpr (OUT_BF16) {
         // bf16 output through LDS.  Registers r, r+1 are channels i, i+1 at pixel j: neighbouring lanes swap one value
         // (DPP) so that an even lane owns channel i at pixels (j, j+1) and an odd lane channel i+1 at (j-1, j), one
@@ -318,6 +321,12 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
                 const int ow = w0 + ((wave_n * WN + nt) % CB) * 32 + (j & ~1);
 #pragma unroll
                 for (int m = 0; m < WM; ++m) {
+                    unsigned olds[8];              // the eight stored pairs first, as one batch of loads (one wait, no store in between)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
+                        olds[r >> 1] = oh < a.H ? *reinterpret_cast<const unsigned*>(yn + (long)co * HW + oh * a.W + ow) : 0u;
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         const float own0 = acc[m][nt][r], own1 = acc[m][nt][r + 1];
@@ -325,10 +334,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
                         const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own1), 0xB1, 0xf, 0xf, true));
                         const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
                         float lo = odd ? t1 : own0, hi = odd ? own1 : t0;
-                        if (add_bias) { const float b = a.bias[co]; lo += b; hi += b; }
+                        { const float b = sbias[co - co0]; lo += b; hi += b; }
                         if (oh < a.H) {
                             unsigned* q = reinterpret_cast<unsigned*>(yn + (long)co * HW + oh * a.W + ow);
-                            const unsigned old = *q;
+                            const unsigned old = olds[r >> 1];
                             *q = pk_bf16(lo + bf16_lo(old), hi + bf16_hi(old));
                         }
                     }
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
                             const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own1), 0xB1, 0xf, 0xf, true));
                             const int cl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;      // channel within the pass
                             float lo = odd ? t1 : own0, hi = odd ? own1 : t0;
-                            if (add_bias) { const float b = a.bias[co0 + pass * WM * 32 + cl]; lo += b; hi += b; }
+                            { const float b = sbias[pass * WM * 32 + cl]; lo += b; hi += b; }
                             ep[cl * EP + row * (TW / 2) + colp] = pk_bf16(lo, hi);
                         }
                     }
@@ -386,8 +395,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (pok) {
-                        float v = acc[m][nt][r];
-                        if (add_bias) v += a.bias[co];
+                        float v = acc[m][nt][r] + sbias[co - co0];
                         float* p = yn + (long)co * HW + oh * a.W + ow;
                         if (a.accumulate) v += *p;
                         *p = v;
@@ -412,6 +420,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
 // One workgroup barrier per chunk orders the two roles.  Same arithmetic, same summation order per output as the kernel
 // above (chunks in order, taps in order): results are bit-identical.
 // Covers: bf16-stored input and output, no split-K, accumulate == 0, Cin % 16 == 0, W % 64 == 0, Cout % (32 WM) == 0.
+template <int V> struct wsic { static constexpr int value = V; };
 template <int WM>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const BfArgs a) {
     constexpr int NM = 256;                        // mover threads
@@ -425,9 +434,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const BfArgs a)
     static_assert(NM % TCO == 0 && NCH % NM == 0, "mover work must divide evenly");
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * BUF slots, then TCO * EP dwords
     unsigned* ep = reinterpret_cast<unsigned*>(lds + 2 * BUF);
+    float* sbias = reinterpret_cast<float*>(ep + TCO * EP);         // Cout floats: the bias of every co tile this workgroup visits
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < a.Cout; i += 512) sbias[i] = a.bias != nullptr ? a.bias[i] : 0.0f;    // (visible after the first barrier)
     const int half = lane >> 5, j = lane & 31;
     const int HW = a.H * a.W;
     const int nch = a.chunks_total;
@@ -481,9 +492,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const BfArgs a)
             xbase = (const char*)a.x + ((long)n * a.x_bs + (long)(h0 - 1) * a.W + (w0 - 2)) * 2L;
             wbase = a.wp + (long)co0 * 8;
         };
-        float xr[NUX][8];
-        u32x4 wr[NUA];
-        auto fetch = [&]() {                       // loads of chunk (f_i, f_c); past the end: empty descriptors (zeros)
+        // PD register sets: chunk k lives in set k % PD from its loads (issued PD iterations before the matrix waves reach it)
+        // to its LDS store -- with ONE chunk in flight the movers waited out a full HBM latency (~2 us) per 1.1 us chunk
+        constexpr int PD = 3;
+        float xr[PD][NUX][8];
+        u32x4 wr[PD][NUA];
+        auto fetch = [&](auto SET) {               // loads of chunk (f_i, f_c); past the end: empty descriptors (zeros)
+            constexpr int S = decltype(SET)::value;
             const unsigned nrec = f_i < my_tiles ? BUF_OOB : 0u;
             const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, nrec, 0x00020000);
             const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wbase), 0, nrec, 0x00020000);
@@ -492,20 +507,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const BfArgs a)
 #pragma unroll
             for (int e = 0; e < NUX; ++e)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) xr[e][c] = buf_load_f32(xrs, offX[e], xs + (unsigned)c * (unsigned)HW * 2u);
+                for (int c = 0; c < 8; ++c) xr[S][e][c] = buf_load_f32(xrs, offX[e], xs + (unsigned)c * (unsigned)HW * 2u);
 #pragma unroll
             for (int v = 0; v < NUA; ++v)
-                wr[v] = buf_load_u32x4(wrs, (A_TAIL && v == NUA - 1) ? offAt : offA0, ws + (unsigned)v * strideA);
+                wr[S][v] = buf_load_u32x4(wrs, (A_TAIL && v == NUA - 1) ? offAt : offA0, ws + (unsigned)v * strideA);
             if (++f_c == nch) { f_c = 0; ++f_i; fetch_tile(f_i); }
         };
-        auto put = [&](u32x4* buf) {
+        auto put = [&](auto SET, u32x4* buf) {
+            constexpr int S = decltype(SET)::value;
 #pragma unroll
             for (int e = 0; e < NUX; ++e) {
                 u32x4 s0, s1;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {      // dword = (pixel 0, pixel 1) of one channel -> (channel 2q, 2q+1) of one pixel
-                    const unsigned lo = __builtin_bit_cast(unsigned, xr[e][2 * q]);
-                    const unsigned hi = __builtin_bit_cast(unsigned, xr[e][2 * q + 1]);
+                    const unsigned lo = __builtin_bit_cast(unsigned, xr[S][e][2 * q]);
+                    const unsigned hi = __builtin_bit_cast(unsigned, xr[S][e][2 * q + 1]);
                     s0[q] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
                     s1[q] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
                 }
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const BfArgs a)
                 buf[ldsX[e] + 1] = s1;
             }
 #pragma unroll
-            for (int v = 0; v < NUA; ++v) buf[(A_TAIL && v == NUA - 1) ? ldsAt : (unsigned)(XS + t + v * NM)] = wr[v];
+            for (int v = 0; v < NUA; ++v) buf[(A_TAIL && v == NUA - 1) ? ldsAt : (unsigned)(XS + t + v * NM)] = wr[S][v];
         };
         // output tile of the previous tile -> global (16-byte pieces: 128 contiguous bytes per (channel, row))
         auto store_out = [&](int i) {
@@ -533,17 +549,32 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const BfArgs a)
         };
 
         fetch_tile(0);
-        fetch();                                   // chunk 0
-        put(lds);                                  // -> buffer 0
-        fetch();                                   // chunk 1 stays in registers
+        fetch(wsic<0>{});                          // chunks 0, 1, 2 -> sets 0, 1, 2
+        fetch(wsic<1>{});
+        fetch(wsic<2>{});
+        put(wsic<0>{}, lds);                       // chunk 0 -> buffer 0; its set re-issues for chunk 3
+        fetch(wsic<0>{});
         __syncthreads();
         int c = 0, ti = 0;
-        for (int s = 0; s < total_s; ++s) {
+        // iteration s (the matrix waves multiply chunk s): chunk s + 1 leaves set (s + 1) % 3 for the other buffer and the
+        // set re-issues its loads for chunk s + 4
+        auto iter = [&](auto SET, int s) {
+#ifndef AIDE_PROBE_WS_NO_GSTORE
             if (c == 0 && ti > 0) store_out(ti - 1);           // the tile the matrix waves dropped before the last barrier
-            put(lds + ((s + 1) & 1) * BUF);                    // chunk s + 1 -> the other buffer
-            fetch();                                           // its registers re-issue their loads (chunk s + 2)
+#endif
+#ifndef AIDE_PROBE_WS_NO_PUT
+            put(SET, lds + ((s + 1) & 1) * BUF);
+#endif
+#ifndef AIDE_PROBE_WS_NO_FETCH
+            fetch(SET);
+#endif
             if (++c == nch) { c = 0; ++ti; }
             __syncthreads();
+        };
+        for (int s = 0; s < total_s; s += 3) {
+            iter(wsic<1>{}, s);
+            if (s + 1 < total_s) iter(wsic<2>{}, s + 1);
+            if (s + 2 < total_s) iter(wsic<0>{}, s + 2);
         }
         if (my_tiles > 0) store_out(my_tiles - 1);
     } else {
@@ -578,10 +609,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const BfArgs a)
             auto kstep = [&](int tp, bf16x8 (&afc)[WM], bf16x8 (&bfc)[WN], bf16x8 (&afn)[WM], bf16x8 (&bfn)[WN]) {
                 if (tp + 1 < 9) frag(tp + 1, afn, bfn);
 #pragma unroll
+#ifndef AIDE_PROBE_WS_NO_MFMA
                 for (int m = 0; m < WM; ++m)
 #pragma unroll
                     for (int nt = 0; nt < WN; ++nt)
                         acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[m], bfc[nt], acc[m][nt], 0, 0, 0);
+#else
+                for (int m = 0; m < WM; ++m) acc[m][0][0] += __builtin_bit_cast(f32x4, afc[m])[0];
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt) acc[0][nt][1] += __builtin_bit_cast(f32x4, bfc[nt])[0];
+#endif
 #pragma unroll
                 for (int i = 0; i < WM * WN; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
@@ -599,7 +636,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const BfArgs a)
             kstep(6, afA, bfA, afB, bfB);
             kstep(7, afB, bfB, afA, bfA);
             kstep(8, afA, bfA, afB, bfB);
+#ifdef AIDE_PROBE_WS_NO_DUMP
+            if (++c == nch) { if (acc[0][0][0] == 123.456f) ep[lane] = 1u; zero(); c = 0; ++ti; } else if (false) {
+#else
             if (++c == nch) {
+#endif
                 // ---- the tile is complete: accumulators -> bf16 output tile in LDS (D row = channel, column = pixel;
                 // neighbouring lanes swap one value so that a lane owns one channel at a pixel PAIR: one dword)
                 int n, h0, w0, co0;
@@ -618,7 +659,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const BfArgs a)
                             const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own1), 0xB1, 0xf, 0xf, true));
                             const int cl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
                             float lo = odd ? t1 : own0, hi = odd ? own1 : t0;
-                            if (a.bias != nullptr) { const float b = a.bias[co0 + cl]; lo += b; hi += b; }
+                            { const float b = sbias[co0 + cl]; lo += b; hi += b; }
                             ep[cl * EP + row * (TW / 2) + colp] = pk_bf16(lo, hi);
                         }
                     }
@@ -716,7 +757,7 @@ template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool 
 int launch_bf16_t(BfArgs a, hipStream_t stream) {
     constexpr int WAVES_N = NW / WAVES_M, TCO = 32 * WM * WAVES_M, TH = WAVES_N * WN / (TW / 32);
     constexpr int BUF = 2 * (TH + 2) * (TW + 4) + 18 * TCO + 2;
-    constexpr int LDS_BYTES = 2 * BUF * 16;
+    constexpr int LDS_BYTES = 2 * BUF * 16 + TCO * 4;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, TW, NW>,
@@ -778,10 +819,12 @@ int bf16_variant(int N, int H, int W, int Cout) {
 template <int WM>
 int launch_bf16_ws(BfArgs a, hipStream_t stream) {
     constexpr int TCO = 32 * WM, BUF = 2 * 10 * 68 + 18 * TCO + 2, EP = 8 * 64 / 2 + 16;
-    constexpr int LDS_BYTES = 2 * BUF * 16 + TCO * EP * 4;
+    if (a.Cout > 2048) return AIDE_ERR_ARG;
+    constexpr int LDS_MAX = 2 * BUF * 16 + TCO * EP * 4 + 2048 * 4;
+    const int LDS_BYTES = 2 * BUF * 16 + TCO * EP * 4 + ((a.Cout * 4 + 15) & ~15);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_bf16_ws_kernel<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16_ws_kernel<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         attr_set = true;
     }
     a.tiles_w = a.W / 64;

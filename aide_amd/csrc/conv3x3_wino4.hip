@@ -393,6 +393,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             for (int o = 0; o < 16; ++o) xbuf2[((wid * 64) + rp * 16 + o) * 64 + lane] = yp[o];
         }
         __syncthreads();
+        // The eight bias values of this lane's output rows are fetched up front.  (Read next to their use they were eight
+        // dependent global_load -> s_waitcnt vmcnt(0) round trips per wave, each of which also waited for the output stores
+        // issued before it to be acknowledged -- stores count in vmcnt on gfx9: most of the "3.5 us of output stores" of
+        // DESIGN 4.8.)
+        float bvs[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = q + 8 * kph;
+            const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            bvs[q] = (add_bias && co < a.Cout) ? a.bias[co] : 0.f;
+        }
 #pragma unroll
         for (int rp = 0; rp < 4; ++rp) {
             f32x2 yp[16];
@@ -421,14 +432,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
 #else
                 if (pok && co < a.Cout) {
 #endif
-                    const float bv = add_bias ? a.bias[co] : 0.f;
+                    const float bv = bvs[2 * rp + e];
+                    f32x4* const p0 = reinterpret_cast<f32x4*>(yn + (long)co * HW + (long)oh * a.W + ow);
+                    f32x4 o[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        f32x4 o = {yp[4 * i][e] + bv, yp[4 * i + 1][e] + bv, yp[4 * i + 2][e] + bv, yp[4 * i + 3][e] + bv};
-                        f32x4* p = reinterpret_cast<f32x4*>(yn + (long)co * HW + (long)(oh + i) * a.W + ow);
-                        if (a.accumulate) { const f32x4 old = *p; o += old; }
-                        *p = o;
+                    for (int i = 0; i < 4; ++i)
+                        o[i] = f32x4{yp[4 * i][e] + bv, yp[4 * i + 1][e] + bv, yp[4 * i + 2][e] + bv, yp[4 * i + 3][e] + bv};
+                    if (a.accumulate) {                          // (the four old rows as one batch of loads, one wait)
+                        f32x4 old[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) old[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p0) + (long)i * a.W);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] += old[i];
                     }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p0) + (long)i * a.W) = o[i];
                 }
             }
         }

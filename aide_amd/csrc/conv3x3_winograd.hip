@@ -248,26 +248,48 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     const int tile = wave_n * 32 + j, ti = tile >> 3, tj = tile & 7;
     const int oh = h0 + 2 * ti, ow = w0 + 2 * tj;
     const bool pok = oh < a.H && ow < a.W;                 // H, W are even: the 2x2 block is in or out
+    // bias values and (accumulate form) the old outputs are fetched as ONE batch before the first store: next to their use
+    // each was a dependent global_load -> s_waitcnt vmcnt(0) that also waited for the stores issued before it (stores count
+    // in vmcnt on gfx9) -- one memory round trip per output row
+    float bvs[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = co0 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float s[2][4];
+        bvs[r] = (add_bias && pok && co < a.Cout) ? a.bias[co] : 0.f;
+    }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float m0 = acc[c][r], m1 = acc[4 + c][r], m2 = acc[8 + c][r], m3 = acc[12 + c][r];
-            s[0][c] = m0 + m1 + m2;
-            s[1][c] = m1 - m2 - m3;
+    for (int r4 = 0; r4 < 16; r4 += 4) {                   // (old outputs: four accumulator rows per batch -- all 16 spilled)
+        float2 olds[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int co = co0 + wave_m * 32 + q + 8 * (r4 >> 2) + 4 * half;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                olds[q][i] = (a.accumulate && pok && co < a.Cout)
+                                 ? *reinterpret_cast<const float2*>(yn + (long)co * HW + (long)(oh + i) * a.W + ow) : make_float2(0.f, 0.f);
         }
-        if (pok && co < a.Cout) {
-            const float bv = add_bias ? a.bias[co] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float2 o;
-                o.x = s[i][0] + s[i][1] + s[i][2] + bv;
-                o.y = s[i][1] - s[i][2] - s[i][3] + bv;
-                float2* p = reinterpret_cast<float2*>(yn + (long)co * HW + (long)(oh + i) * a.W + ow);
-                if (a.accumulate) { const float2 old = *p; o.x += old.x; o.y += old.y; }
-                *p = o;
+        for (int q = 0; q < 4; ++q) {
+            const int r = r4 + q;
+            const int co = co0 + wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float s[2][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float m0 = acc[c][r], m1 = acc[4 + c][r], m2 = acc[8 + c][r], m3 = acc[12 + c][r];
+                s[0][c] = m0 + m1 + m2;
+                s[1][c] = m1 - m2 - m3;
+            }
+            if (pok && co < a.Cout) {
+                const float bv = bvs[r];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float2 o;
+                    o.x = s[i][0] + s[i][1] + s[i][2] + bv;
+                    o.y = s[i][1] - s[i][2] - s[i][3] + bv;
+                    float2* p = reinterpret_cast<float2*>(yn + (long)co * HW + (long)(oh + i) * a.W + ow);
+                    o.x += olds[q][i].x; o.y += olds[q][i].y;
+                    *p = o;
+                }
             }
         }
     }

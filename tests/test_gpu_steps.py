@@ -90,7 +90,7 @@ def test_cli_smoke(dev, tmp_path):
     if max(hist['traincase_dice']) <= 0.0:         # best starts at 0.0 as in the reference (:188): nothing to save
         assert files == []
         return
-    assert files == ['fuseunet_r1_besttraincasedice.pkl']          # the reference's name (:125, :343-344)
+    assert files == ['fuseunet_r%d_besttraincasedice.pkl' % args.repetition]          # the reference's name (:125, :343-344)
     state = torch.load(os.path.join(str(tmp_path / 'ck'), files[0]), map_location='cpu', weights_only=False)
     assert set(state) >= {'net', 'loss', 'dice', 'epoch', 'history'}
     build_model('fuseunet', 2).load_state_dict(state['net'])
@@ -107,7 +107,8 @@ def test_cli_proposed_smoke(dev, tmp_path):
     n1, n2 = Train(args)
     files = sorted(os.listdir(str(tmp_path / 'ck'))) if os.path.isdir(str(tmp_path / 'ck')) else []
     # the reference's names (:178-179, :512-513, :524-525), its spelling of the second one included; best starts at 0.0 (:244)
-    assert files in ([], ['fuseunet_temp1.0_r1_net1_besttraincasedice.pkl', 'fuseunet_temp1.0_r1_net2_besttraincasedicde.pkl'])
+    stem = 'fuseunet_temp%s_r%d' % (args.temperature, args.repetition)
+    assert files in ([], [stem + '_net1_besttraincasedice.pkl', stem + '_net2_besttraincasedicde.pkl'])
     assert all(torch.isfinite(p).all() for p in n1.parameters())
 
 

@@ -9,5 +9,5 @@ done
 for w in c2 c5; do cp $O/${tag}_pmc_mfma_$w.md $P/ 2>/dev/null; cp $O/${tag}_hbm_traffic_$w.md $O/${tag}_traffic_$w.json $P/ 2>/dev/null; done
 grep -v amdgpu.ids $O/${tag}_phase_c2.txt > $P/${tag}_phase_c2.txt
 grep -v amdgpu.ids $O/${tag}_host_c2.txt > $P/${tag}_host_c2.txt
-[ -f $O/${tag}_gputests.log ] && tail -1 $O/${tag}_gputests.log > $P/${tag}_gputests_summary.txt
+[ -f $O/${tag}_gputests.log ] && grep -E "passed|failed" $O/${tag}_gputests.log | tail -1 > $P/${tag}_gputests_summary.txt
 ls $P | grep "^${tag}_"
