@@ -406,272 +406,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
     }
 }
 
-// ---------------------------------------------------------------------------------- persistent, role-split forward / dgrad
-// The big-plane layers (<= 128 channels at 512 x 512 / 256 x 256) have 2 .. 8 channel chunks per pixel tile: in the kernel
-// above a tile's prologue (two chunks of exposed HBM latency), its epilogue (accumulators -> LDS -> 16-byte stores) and its
-// main loop run one after the other in every wave, and the ablation builds (tools/ab_bf16_probes.sh) put 30-48 % of such a
-// layer into the epilogue alone with the matrix pipe idle.  Here a workgroup is PERSISTENT (one per CU, a strided list of
-// tiles) and its eight waves have two roles:
-//   * waves 0-3 ("matrix"): nothing but fragment reads and MFMAs over the current stage buffer; after a tile's last chunk
-//     they drop the accumulators as bf16 into an LDS output tile and go straight on to the next tile;
-//   * waves 4-7 ("movers"): global -> registers -> LDS staging of chunk s + 1 / s + 2 of ONE continuous chunk stream that
-//     runs across tile boundaries (the next tile's first chunks are in flight during this tile's last MFMAs: no prologue
-//     after the first tile), and the 16-byte global stores of the previous tile's output tile.
-// One workgroup barrier per chunk orders the two roles.  Same arithmetic, same summation order per output as the kernel
-// above (chunks in order, taps in order): results are bit-identical.
-// Covers: bf16-stored input and output, no split-K, accumulate == 0, Cin % 16 == 0, W % 64 == 0, Cout % (32 WM) == 0.
-template <int V> struct wsic { static constexpr int value = V; };
-template <int WM>
-__global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const BfArgs a) {
-    constexpr int NM = 256;                        // mover threads
-    constexpr int WN = 4, CB = 2, TW = 64, TH = 8;
-    constexpr int TCO = 32 * WM;
-    constexpr int BF_PITCH = TW + 4, NPR = BF_PITCH / 2, PLANE = (TH + 2) * BF_PITCH, XS = 2 * PLANE;
-    constexpr int AS = 18 * TCO, BUF = XS + AS + 2, DUMP = XS + AS;
-    constexpr int UX = 2 * (TH + 2) * NPR, NUX = (UX + NM - 1) / NM, NUA = (AS + NM - 1) / NM;
-    constexpr int EP = TH * TW / 2 + 16;           // dwords per channel of the output tile
-    constexpr int SEG = TW / 8, NCH = TCO * TH * SEG;
-    static_assert(NM % TCO == 0 && NCH % NM == 0, "mover work must divide evenly");
-    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * BUF slots, then TCO * EP dwords
-    unsigned* ep = reinterpret_cast<unsigned*>(lds + 2 * BUF);
-    float* sbias = reinterpret_cast<float*>(ep + TCO * EP);         // Cout floats: the bias of every co tile this workgroup visits
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < a.Cout; i += 512) sbias[i] = a.bias != nullptr ? a.bias[i] : 0.0f;    // (visible after the first barrier)
-    const int half = lane >> 5, j = lane & 31;
-    const int HW = a.H * a.W;
-    const int nch = a.chunks_total;
-    const int total_tiles = a.tiles_w * a.tiles_h * a.N * a.n_co_tiles;
-    const int first = xcd_remap(blockIdx.x, gridDim.x);
-    const int my_tiles = first < total_tiles ? (total_tiles - first + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    const int total_s = my_tiles * nch;            // chunk stream of this workgroup
-    auto tile_coords = [&](int i, int& n, int& h0, int& w0, int& co0) {
-        int b = first + i * (int)gridDim.x;
-        const int co_tile = b % a.n_co_tiles; b /= a.n_co_tiles;
-        const int tw = b % a.tiles_w;         b /= a.tiles_w;
-        const int th = b % a.tiles_h;
-        n = b / a.tiles_h; h0 = th * TH; w0 = tw * TW; co0 = co_tile * TCO;
-    };
-
-    if (wid >= 4) {
-        // ================================================================ movers
-        const int t = tid - 256;
-        unsigned ldsX[NUX];
-#pragma unroll
-        for (int e = 0; e < NUX; ++e) {
-            const int u = t + e * NM;
-            const int g = u / ((TH + 2) * NPR), rem = u - g * ((TH + 2) * NPR);
-            const int row = rem / NPR, pr = rem - row * NPR;
-            ldsX[e] = u < UX ? (unsigned)(g * PLANE + row * BF_PITCH + 2 * pr) : (unsigned)DUMP;
-        }
-        const unsigned offA0 = (unsigned)((t / TCO) * a.Cout + (t % TCO)) * 16u;
-        const unsigned strideA = (unsigned)(NM / TCO) * (unsigned)a.Cout * 16u;
-        constexpr bool A_TAIL = (AS % NM) != 0;
-        const bool tail_ok = t + (NUA - 1) * NM < AS;
-        const unsigned offAt = tail_ok ? offA0 : BUF_OOB;
-        const unsigned ldsAt = tail_ok ? (unsigned)(XS + t + (NUA - 1) * NM) : (unsigned)DUMP;
-
-        // fetch cursor: (tile, chunk) of the NEXT chunk to load; descriptors of its tile
-        int f_i = 0, f_c = 0;
-        unsigned offX[NUX];
-        const char* xbase = (const char*)a.x;
-        const uint16_t* wbase = a.wp;
-        auto fetch_tile = [&](int i) {
-            int n = 0, h0 = 0, w0 = 0, co0 = 0;
-            if (i < my_tiles) tile_coords(i, n, h0, w0, co0);
-#pragma unroll
-            for (int e = 0; e < NUX; ++e) {
-                const int u = t + e * NM;
-                const int g = u / ((TH + 2) * NPR), rem = u - g * ((TH + 2) * NPR);
-                const int row = rem / NPR, pr = rem - row * NPR;
-                const int ih = h0 - 1 + row, iw = w0 - 2 + 2 * pr;
-                const bool ok = u < UX && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-                offX[e] = ok ? (unsigned)(g * 8 * HW + row * a.W + 2 * pr) * 2u : BUF_OOB;
-            }
-            xbase = (const char*)a.x + ((long)n * a.x_bs + (long)(h0 - 1) * a.W + (w0 - 2)) * 2L;
-            wbase = a.wp + (long)co0 * 8;
-        };
-        // PD register sets: chunk k lives in set k % PD from its loads (issued PD iterations before the matrix waves reach it)
-        // to its LDS store -- with ONE chunk in flight the movers waited out a full HBM latency (~2 us) per 1.1 us chunk
-        constexpr int PD = 3;
-        float xr[PD][NUX][8];
-        u32x4 wr[PD][NUA];
-        auto fetch = [&](auto SET) {               // loads of chunk (f_i, f_c); past the end: empty descriptors (zeros)
-            constexpr int S = decltype(SET)::value;
-            const unsigned nrec = f_i < my_tiles ? BUF_OOB : 0u;
-            const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, nrec, 0x00020000);
-            const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wbase), 0, nrec, 0x00020000);
-            const unsigned xs = (unsigned)(f_c * 16) * (unsigned)HW * 2u;
-            const unsigned ws = (unsigned)f_c * 18u * (unsigned)a.Cout * 16u;
-#pragma unroll
-            for (int e = 0; e < NUX; ++e)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) xr[S][e][c] = buf_load_f32(xrs, offX[e], xs + (unsigned)c * (unsigned)HW * 2u);
-#pragma unroll
-            for (int v = 0; v < NUA; ++v)
-                wr[S][v] = buf_load_u32x4(wrs, (A_TAIL && v == NUA - 1) ? offAt : offA0, ws + (unsigned)v * strideA);
-            if (++f_c == nch) { f_c = 0; ++f_i; fetch_tile(f_i); }
-        };
-        auto put = [&](auto SET, u32x4* buf) {
-            constexpr int S = decltype(SET)::value;
-#pragma unroll
-            for (int e = 0; e < NUX; ++e) {
-                u32x4 s0, s1;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {      // dword = (pixel 0, pixel 1) of one channel -> (channel 2q, 2q+1) of one pixel
-                    const unsigned lo = __builtin_bit_cast(unsigned, xr[S][e][2 * q]);
-                    const unsigned hi = __builtin_bit_cast(unsigned, xr[S][e][2 * q + 1]);
-                    s0[q] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-                    s1[q] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
-                }
-                buf[ldsX[e]] = s0;
-                buf[ldsX[e] + 1] = s1;
-            }
-#pragma unroll
-            for (int v = 0; v < NUA; ++v) buf[(A_TAIL && v == NUA - 1) ? ldsAt : (unsigned)(XS + t + v * NM)] = wr[S][v];
-        };
-        // output tile of the previous tile -> global (16-byte pieces: 128 contiguous bytes per (channel, row))
-        auto store_out = [&](int i) {
-            int n, h0, w0, co0;
-            tile_coords(i, n, h0, w0, co0);
-            uint16_t* yn = (uint16_t*)a.y + (long)n * a.y_bs;
-#pragma unroll
-            for (int k = 0; k < NCH / NM; ++k) {
-                const int q = t + k * NM;
-                const int seg = q % SEG, row = (q / SEG) % TH, cl = q / (SEG * TH);
-                const int oh = h0 + row;
-                if (oh < a.H) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(ep + cl * EP + row * (TW / 2) + seg * 4);
-                    *reinterpret_cast<u32x4*>(yn + (long)(co0 + cl) * HW + (long)oh * a.W + w0 + seg * 8) = v;
-                }
-            }
-        };
-
-        fetch_tile(0);
-        fetch(wsic<0>{});                          // chunks 0, 1, 2 -> sets 0, 1, 2
-        fetch(wsic<1>{});
-        fetch(wsic<2>{});
-        put(wsic<0>{}, lds);                       // chunk 0 -> buffer 0; its set re-issues for chunk 3
-        fetch(wsic<0>{});
-        __syncthreads();
-        int c = 0, ti = 0;
-        // iteration s (the matrix waves multiply chunk s): chunk s + 1 leaves set (s + 1) % 3 for the other buffer and the
-        // set re-issues its loads for chunk s + 4
-        auto iter = [&](auto SET, int s) {
-#ifndef AIDE_PROBE_WS_NO_GSTORE
-            if (c == 0 && ti > 0) store_out(ti - 1);           // the tile the matrix waves dropped before the last barrier
-#endif
-#ifndef AIDE_PROBE_WS_NO_PUT
-            put(SET, lds + ((s + 1) & 1) * BUF);
-#endif
-#ifndef AIDE_PROBE_WS_NO_FETCH
-            fetch(SET);
-#endif
-            if (++c == nch) { c = 0; ++ti; }
-            __syncthreads();
-        };
-        for (int s = 0; s < total_s; s += 3) {
-            iter(wsic<1>{}, s);
-            if (s + 1 < total_s) iter(wsic<2>{}, s + 1);
-            if (s + 2 < total_s) iter(wsic<0>{}, s + 2);
-        }
-        if (my_tiles > 0) store_out(my_tiles - 1);
-    } else {
-        // ================================================================ matrix waves
-        const int wave_n = wid;
-        const int la = XS + half * TCO + j;
-        const int lb = half * PLANE + j + 1 + (wave_n * WN / CB) * BF_PITCH;
-        f32x16 acc[WM][WN];
-        auto zero = [&]() {
-#pragma unroll
-            for (int m = 0; m < WM; ++m)
-#pragma unroll
-                for (int nt = 0; nt < WN; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.0f;
-        };
-        zero();
-        __syncthreads();                           // buffer 0 holds chunk 0
-        int c = 0, ti = 0;
-        for (int s = 0; s < total_s; ++s) {
-            const u32x4* pa = lds + (s & 1) * BUF + la;
-            const u32x4* pb = lds + (s & 1) * BUF + lb;
-            bf16x8 afA[WM], bfA[WN], afB[WM], bfB[WN];
-            auto frag = [&](int tp, bf16x8 (&af)[WM], bf16x8 (&bf)[WN]) {
-                const int kh = tp / 3, kw = tp % 3;
-#pragma unroll
-                for (int m = 0; m < WM; ++m) af[m] = __builtin_bit_cast(bf16x8, pa[tp * 2 * TCO + m * 32]);
-#pragma unroll
-                for (int nt = 0; nt < WN; ++nt)
-                    bf[nt] = __builtin_bit_cast(bf16x8, pb[((nt / CB) + kh) * BF_PITCH + (nt % CB) * 32 + kw]);
-            };
-            auto kstep = [&](int tp, bf16x8 (&afc)[WM], bf16x8 (&bfc)[WN], bf16x8 (&afn)[WM], bf16x8 (&bfn)[WN]) {
-                if (tp + 1 < 9) frag(tp + 1, afn, bfn);
-#pragma unroll
-#ifndef AIDE_PROBE_WS_NO_MFMA
-                for (int m = 0; m < WM; ++m)
-#pragma unroll
-                    for (int nt = 0; nt < WN; ++nt)
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[m], bfc[nt], acc[m][nt], 0, 0, 0);
-#else
-                for (int m = 0; m < WM; ++m) acc[m][0][0] += __builtin_bit_cast(f32x4, afc[m])[0];
-#pragma unroll
-                for (int nt = 0; nt < WN; ++nt) acc[0][nt][1] += __builtin_bit_cast(f32x4, bfc[nt])[0];
-#endif
-#pragma unroll
-                for (int i = 0; i < WM * WN; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            frag(0, afA, bfA);
-            kstep(0, afA, bfA, afB, bfB);
-            kstep(1, afB, bfB, afA, bfA);
-            kstep(2, afA, bfA, afB, bfB);
-            kstep(3, afB, bfB, afA, bfA);
-            kstep(4, afA, bfA, afB, bfB);
-            kstep(5, afB, bfB, afA, bfA);
-            kstep(6, afA, bfA, afB, bfB);
-            kstep(7, afB, bfB, afA, bfA);
-            kstep(8, afA, bfA, afB, bfB);
-#ifdef AIDE_PROBE_WS_NO_DUMP
-            if (++c == nch) { if (acc[0][0][0] == 123.456f) ep[lane] = 1u; zero(); c = 0; ++ti; } else if (false) {
-#else
-            if (++c == nch) {
-#endif
-                // ---- the tile is complete: accumulators -> bf16 output tile in LDS (D row = channel, column = pixel;
-                // neighbouring lanes swap one value so that a lane owns one channel at a pixel PAIR: one dword)
-                int n, h0, w0, co0;
-                tile_coords(ti, n, h0, w0, co0);
-                const int odd = j & 1;
-#pragma unroll
-                for (int nt = 0; nt < WN; ++nt) {
-                    const int row = (wave_n * WN + nt) / CB;
-                    const int colp = ((wave_n * WN + nt) % CB) * 16 + (j >> 1);
-#pragma unroll
-                    for (int m = 0; m < WM; ++m) {
-#pragma unroll
-                        for (int r = 0; r < 16; r += 2) {
-                            const float own0 = acc[m][nt][r], own1 = acc[m][nt][r + 1];
-                            const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own0), 0xB1, 0xf, 0xf, true));
-                            const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own1), 0xB1, 0xf, 0xf, true));
-                            const int cl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
-                            float lo = odd ? t1 : own0, hi = odd ? own1 : t0;
-                            { const float b = sbias[co0 + cl]; lo += b; hi += b; }
-                            ep[cl * EP + row * (TW / 2) + colp] = pk_bf16(lo, hi);
-                        }
-                    }
-                }
-                zero();
-                c = 0; ++ti;
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // y[n][c][p] (+)= bias[c] + sum_s slab[s][n][c][p]   (fixed summation order, 4 pixels per thread; y fp32 or bf16)
 template <bool OUT_BF16>
 __global__ void bf16_splitk_reduce_kernel(const float* __restrict__ slabs, long split_stride, int splitk,
@@ -814,37 +548,6 @@ int bf16_variant(int N, int H, int W, int Cout) {
     int v = Cout % 128 == 0 ? 2 : (Cout % 64 == 0 ? 1 : 0);
     if (v == 2 && bf16_blocks(2, N, H, W, Cout) < 256) v = 1;
     return (force >= 0 && force < v) ? force : v;
-}
-
-template <int WM>
-int launch_bf16_ws(BfArgs a, hipStream_t stream) {
-    constexpr int TCO = 32 * WM, BUF = 2 * 10 * 68 + 18 * TCO + 2, EP = 8 * 64 / 2 + 16;
-    if (a.Cout > 2048) return AIDE_ERR_ARG;
-    constexpr int LDS_MAX = 2 * BUF * 16 + TCO * EP * 4 + 2048 * 4;
-    const int LDS_BYTES = 2 * BUF * 16 + TCO * EP * 4 + ((a.Cout * 4 + 15) & ~15);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_bf16_ws_kernel<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-        attr_set = true;
-    }
-    a.tiles_w = a.W / 64;
-    a.tiles_h = (a.H + 7) / 8;
-    a.n_co_tiles = a.Cout / TCO;
-    const long tiles = (long)a.tiles_w * a.tiles_h * a.N * a.n_co_tiles;
-    static const int cus = [] { int d = 0; hipDeviceProp_t p; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
-    const long nb = tiles < cus ? tiles : cus;     // persistent: one workgroup per CU
-    AIDE_LAUNCH_TIMED(AIDE_KT_BF16, AIDE_CONV_FLOPS(a.N, a.H, a.W, a.Cout, a.Cin), (conv3x3_bf16_ws_kernel<WM>),
-                      dim3((unsigned)nb), dim3(512), LDS_BYTES, stream, a);
-    return aide_launch_status();
-}
-
-// which launches take the persistent role-split kernel: 0 = none, 1 = the big-plane layers (rule below), 2 = every launch it covers
-int g_bf16_ws_mode = getenv("AIDE_BF16_WS") ? atoi(getenv("AIDE_BF16_WS")) : 1;
-// shapes the role-split kernel handles at all (at least two chunks per tile: the movers store tile t - 1 while tile t runs)
-bool bf16_ws_covers(int Cin, int W, int Cout) { return (Cin % 16) == 0 && Cin >= 32 && (W % 64) == 0 && (Cout % 32) == 0; }
-// ... and where it is ahead (layer sweep, tools/bench_bf16.py): the short-K big-plane layers, with at least one tile per CU
-bool bf16_ws_pays(int N, int Cin, int H, int W, int Cout) {
-    return Cin <= 128 && Cout <= 128 && H * W >= 128 * 128 && (long)(W / 64) * ((H + 7) / 8) * N * (Cout / (Cout % 64 ? 32 : 64)) >= 256;
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient
@@ -1213,9 +916,6 @@ int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint1
         a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = (accumulate == 1);
     }
     int rc;
-    if (x_bf16 && kernel_out_bf16 && splitk <= 1 && !a.accumulate && bf16_ws_covers(Cin, W, Cout) &&
-        (g_bf16_ws_mode == 2 || (g_bf16_ws_mode == 1 && bf16_ws_pays(N, Cin, H, W, Cout))))
-        return (Cout % 64 == 0) ? launch_bf16_ws<2>(a, stream) : launch_bf16_ws<1>(a, stream);
     switch (bf16_variant(N, H, W, Cout)) {
         case 2: rc = launch_bf16<2, 2, 4, 1, 8>(a, x_bf16, kernel_out_bf16, stream); break;
         case 1: rc = launch_bf16<2, 1, 4, 2, 4>(a, x_bf16, kernel_out_bf16, stream); break;
@@ -1234,14 +934,6 @@ int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint1
         rc = aide_launch_status();
     }
     return rc;
-}
-
-// 0 = never use the persistent role-split forward / dgrad kernel, 1 = where it is ahead (default), 2 = wherever it covers
-// the launch (tests / layer sweeps); returns the previous mode.  Results are bit-identical in every mode.
-int aide_conv3x3_bf16_ws_mode(int mode) {
-    const int was = g_bf16_ws_mode;
-    if (mode >= 0 && mode <= 2) g_bf16_ws_mode = mode;
-    return was;
 }
 
 int aide_conv3x3_bf16(const float* x, int64_t x_bs, const uint16_t* u, const float* bias, float* y, int64_t y_bs,

@@ -101,10 +101,6 @@ int aide_conv3x3_bf16_splitk(int N, int Cin, int H, int W, int Cout);
 size_t aide_conv3x3_bf16_pack_elems(int Cout, int Cin);          /* bf16 elements of one direction's pack */
 /* descs = DEVICE array of n 48-byte records {const float* w; uint16_t* uf; uint16_t* ud (or 0); int32 Co, Ci, 0, 0;
  * int64 block_start}; an entry occupies ceil((elems_f + elems_d) / 8 / 256) workgroups */
-/* Forward / dgrad launches with bf16-stored input and output, no split, accumulate == 0, Cin % 16 == 0, Cin >= 32,
- * W % 64 == 0 may run the persistent role-split kernel (matrix waves + mover waves, one workgroup per CU): mode 0 = never,
- * 1 = where it is ahead (default), 2 = wherever it covers the launch.  Returns the previous mode; results are bit-identical. */
-int aide_conv3x3_bf16_ws_mode(int mode);
 int aide_conv3x3_bf16_pack_multi(const void* descs, int n, int64_t total_blocks, aide_stream_t stream);
 int aide_conv3x3_bf16(const float* x, int64_t x_bs, const uint16_t* u, const float* bias, float* y, int64_t y_bs,
                       int N, int Cin, int H, int W, int Cout, int accumulate, int splitk, float* ws,

@@ -83,49 +83,6 @@ def test_conv3x3_bf16_fwd_dgrad(dev, case):
             _close(dx, dx_fp32 + base, 1e-2, 'dgrad vs fp32 %s' % (case,))
 
 
-WS_CASES = [
-    # N, Cin, Cout, H, W: one tile per workgroup, ragged bottom rows, 32-wide co tile (Cout % 64 == 32), several tiles per
-    # workgroup (more tiles than CUs, also not a multiple of them), channel-slice output
-    (1, 32, 64, 16, 64), (2, 64, 64, 20, 128), (1, 48, 96, 24, 64), (1, 128, 32, 40, 192), (4, 64, 64, 256, 256),
-    (3, 32, 128, 256, 256), (2, 128, 64, 72, 320),
-]
-
-
-@pytest.mark.parametrize('case', WS_CASES)
-def test_conv3x3_bf16_role_split_kernel(dev, case):
-    """The persistent role-split forward / dgrad kernel (matrix waves + mover waves, conv3x3_bf16_ws_kernel) against the
-    tile-per-workgroup kernel on the same bf16-stored operands: bit-identical (same chunk / tap order per output), into a
-    plain tensor and into a channel slice of a wider buffer; and against aten on the rounded operands."""
-    from aide_amd import ops
-    from aide_amd._lib import lib
-    n, ci, co, h, w = case
-    g = torch.Generator().manual_seed(ci * 7 + co * 3 + h)
-    x = torch.randn(n, ci, h, w, generator=g).to(dev).bfloat16()
-    wt = (torch.randn(co, ci, 3, 3, generator=g) * (1.0 / (3.0 * ci ** 0.5))).to(dev)
-    b = torch.randn(co, generator=g).to(dev)
-    uf, _ = ops.bf16_pack(wt, need_dgrad=False)
-    was = lib.aide_conv3x3_bf16_ws_mode(0)
-    try:
-        y_ref = torch.full((n, co, h, w), float('nan'), device=dev).bfloat16()
-        ops.conv3x3_bf16(x, uf, b, y_ref, splitk=1)
-        assert lib.aide_conv3x3_bf16_ws_mode(2) == 0
-        y = torch.full((n, co, h, w), float('nan'), device=dev).bfloat16()
-        ops.conv3x3_bf16(x, uf, b, y, splitk=1)
-        wide = torch.full((n, co + 32, h, w), float('nan'), device=dev).bfloat16()
-        ops.conv3x3_bf16(x, uf, None, wide[:, 32:], splitk=1)               # no bias, channel slice of a concat buffer
-        y_nb = torch.empty_like(y_ref)
-        lib.aide_conv3x3_bf16_ws_mode(0)
-        ops.conv3x3_bf16(x, uf, None, y_nb, splitk=1)
-        torch.cuda.synchronize()
-    finally:
-        lib.aide_conv3x3_bf16_ws_mode(was)
-    assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), 'role-split kernel differs %s' % (case,)
-    assert torch.equal(wide[:, 32:].contiguous().view(torch.int16), y_nb.view(torch.int16)), 'channel-slice output %s' % (case,)
-    assert torch.isnan(wide[:, :32].float()).all(), 'wrote outside its channel slice'
-    y_exact = F.conv2d(x.float().cpu(), _rb(wt.cpu()), b.cpu(), padding=1)
-    _close(y.float(), y_exact, 1e-2, 'role-split vs aten %s' % (case,))          # (bf16-stored output: 2^-9 relative)
-
-
 def test_bf16_storage_variants(dev):
     """z stored as bf16 by the forward (= RNE of the fp32-output kernel's result, bit for bit), dz read as bf16 by the
     dgrad / wgrad (= the fp32-input kernels on the widened values, bit for bit), with and without split-K."""
