@@ -541,12 +541,15 @@ long bf16_blocks(int variant, int N, int H, int W, int Cout) {
     const int tw = (bf16_wide_tile(W, H) && W % 64 == 0) ? 64 : 32, th = 512 / tw;
     return (long)(W / tw) * ((H + th - 1) / th) * N * (Cout / tco);
 }
-// the 128-co tile needs one full round of workgroups (256) to pay: below that the 64-co tile has twice the blocks
-// (measured: 256->256 @64x64 x8 and smaller planes lose 5-10 % with the wide tile, everything above gains 4-10 %)
+// 32 or 64 output channels per workgroup, two workgroups per CU.  (The 128-co tile on 8 waves, one workgroup per CU, was
+// 4-10 % ahead on the >= 256-workgroup layers while every epilogue stalled on its bias loads; with those batched the
+// two-workgroup form is level on the long-K layers and 5-10 % ahead on the short-K ones -- dgrad 64->128 @512x512 0.409 ->
+// 0.371 ms, 128->128 @256x256 0.147 -> 0.135 -- whose prologue and epilogue nothing overlaps at one workgroup per CU:
+// round 3, tools/bench_bf16.py with AIDE_BF16_V=1.)
 int bf16_variant(int N, int H, int W, int Cout) {
-    static const int force = getenv("AIDE_BF16_V") ? atoi(getenv("AIDE_BF16_V")) : -1;     // probe switch
-    int v = Cout % 128 == 0 ? 2 : (Cout % 64 == 0 ? 1 : 0);
-    if (v == 2 && bf16_blocks(2, N, H, W, Cout) < 256) v = 1;
+    static const int force = getenv("AIDE_BF16_V") ? atoi(getenv("AIDE_BF16_V")) : -1;     // probe switch (2 = the 128-co tile)
+    if (force == 2 && Cout % 128 == 0) return 2;
+    const int v = Cout % 64 == 0 ? 1 : 0;
     return (force >= 0 && force < v) ? force : v;
 }
 
