@@ -280,6 +280,54 @@ def test_side_stream_wgrad_is_bit_identical(dev):
             assert torch.equal(a, b) and torch.equal(a, c)
 
 
+def test_engine_assigned_gradients_follow_autograd_semantics(dev):
+    """Parameter gradients are assigned by the engine (one autograd anchor, persistent arena): the values equal the plain
+    autograd form bit for bit, a second backward ACCUMULATES (as AccumulateGrad does), zero_grad(set_to_none=False) keeps
+    working, a frozen parameter gets no gradient, and the fused Adam steps identically from either form."""
+    from aide_amd import engine as E, utils as U
+    from aide_amd.optim import Adam
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(2, 3, 32, 32, generator=g).to(dev) for _ in range(2)]
+    t = (torch.rand(2, 32, 32, generator=g) > 0.7).long().to(dev)
+    w = torch.tensor([1.0, 1.0])
+    crit = U.CEMDiceLoss(w, w, w)
+
+    def grads_of(direct, passes=1, zero_in_place=False, freeze=False):
+        was = E.DIRECT_GRADS[0]
+        E.DIRECT_GRADS[0] = direct
+        try:
+            net, _ = build_pair('fuseunet', False, dev)
+            params = list(net.parameters())
+            if freeze:
+                params[5].requires_grad_(False)
+            opt = Adam([p for p in params if p.requires_grad], lr=1e-3, amsgrad=True)
+            if zero_in_place:                       # gradients exist and are zero: the backward must add into them
+                crit(net(*xs), t).backward()
+                opt.zero_grad(set_to_none=False)
+                assert all(float(p.grad.abs().max()) == 0.0 for p in params if p.requires_grad)
+            for _ in range(passes):
+                crit(net(*xs), t).backward()
+            out = [None if p.grad is None else p.grad.clone() for p in params]
+            opt.step()
+            torch.cuda.synchronize()
+            return out, [p.detach().clone() for p in params]
+        finally:
+            E.DIRECT_GRADS[0] = was
+    ref, pref = grads_of(False)
+    got, pgot = grads_of(True)
+    assert all(torch.equal(a, b) for a, b in zip(ref, got)), 'engine-assigned gradients differ from the autograd form'
+    assert all(torch.equal(a, b) for a, b in zip(pref, pgot)), 'Adam step differs'
+    twice, _ = grads_of(True, passes=2)
+    twice_ref, _ = grads_of(False, passes=2)
+    for a, b, c in zip(ref, twice, twice_ref):
+        assert torch.equal(b, c), 'accumulated gradients differ from the autograd form'
+        assert torch.allclose(b, 2 * a, rtol=1e-6, atol=1e-12)
+    inplace, _ = grads_of(True, zero_in_place=True)
+    assert all(torch.equal(a, b) for a, b in zip(ref, inplace)), 'zero_grad(set_to_none=False) path'
+    frozen, _ = grads_of(True, freeze=True)
+    assert frozen[5] is None and all(torch.equal(a, b) for k, (a, b) in enumerate(zip(ref, frozen)) if k != 5)
+
+
 def test_two_lane_schedules_are_bit_identical(dev):
     """The second encoder's chains on their own stream (forward: default on; backward: AIDE_DUAL_BWD) must give the single-lane
     results bit for bit -- same kernels, own workspaces -- over several steps (also a race detector for the lane's
