@@ -64,3 +64,19 @@ def Dice3d_fn(inputs, targets):
     t = torch.as_tensor(targets).reshape(-1).to(i.device, torch.int64)
     inter, union = 2 * int((i * t).sum().item()), int(i.sum().item()) + int(t.sum().item())
     return np.float64(inter) / np.float64(union) if union else np.float64('nan')
+
+
+def keep_largest_connected_components(mask):
+    """trainchaos_comparison_1case.py:68-77 / trainchaos_proposed_30cases1labeled.py:103-112: the largest connected blob of a
+    label volume (connectivity 1: face neighbours), uint8.  CPU post-processing in the reference (skimage.measure.label +
+    regionprops); the same labelling with scipy.ndimage.label here -- its default structure is connectivity 1 and it numbers
+    the blobs in the same raster order, so `np.argmax(area)` picks the same blob on ties."""
+    from scipy import ndimage
+    mask = np.asarray(mask)
+    out = np.zeros(mask.shape, dtype=np.uint8)
+    if mask.size == 0 or mask.max() <= 0:
+        return out
+    blobs, count = ndimage.label(mask)
+    area = np.bincount(blobs.reshape(-1), minlength=count + 1)[1:]
+    out[blobs == (int(np.argmax(area)) + 1)] = 1
+    return out

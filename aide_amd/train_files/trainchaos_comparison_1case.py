@@ -123,8 +123,7 @@ def Train(args=None):
                 best_casedice = casedice
                 os.makedirs(args.checkpoint, exist_ok=True)
                 # file name of :125, :343-344 ('{model}_r{rep}.pkl' -> '{model}_r{rep}_besttraincasedice.pkl'): what the
-                # reference's evaluation scripts look for.  (The synthetic case Dice here is taken without the skimage
-                # keep_largest_connected_components post-processing of :267 -- SURVEY 2 #12, out of scope.)
+                # reference's evaluation scripts look for
                 name = '%s_r%d_besttraincasedice.pkl' % (args.model_name, args.repetition)
                 torch.save({'net': net.state_dict(), 'loss': history['train_loss'][-1], 'dice': history['train_dice'][-1],
                             'epoch': epoch + 1, 'history': history}, os.path.join(args.checkpoint, name))
@@ -133,12 +132,13 @@ def Train(args=None):
 
 def evaluate_case(net, args, device, single, epoch, slices=8):
     """3-D Dice of one synthetic case predicted slice-batch-wise in eval mode (aide_amd.inference.predict_case)."""
-    from aide_amd.inference import predict_case, Dice3d_fn
+    from aide_amd.inference import predict_case, Dice3d_fn, keep_largest_connected_components
     from aide_amd.synthetic import chaos_batch
     inphase, outphase, targets = chaos_batch(slices, args.img_size, seed=args.torch_seed * 7919 + 13, single_modal=single)
     net.eval()
     pred = predict_case(net, inphase, batch_size=slices) if single else predict_case(net, inphase, outphase, batch_size=slices)
     net.train()
+    pred = keep_largest_connected_components(pred)                   # :267-268 (CPU post-processing, as in the reference)
     tgt = targets.permute(1, 2, 0).contiguous().numpy()
     if tgt.sum() == 0 and pred.sum() == 0:
         return 1.0

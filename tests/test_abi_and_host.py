@@ -220,3 +220,21 @@ def test_wgrad_reduce_discard_and_event_destroy_exported(built):
     assert dll.aide_wgrad_reduce_pending() == 0
     assert dll.aide_wgrad_reduce_discard() == 0          # nothing pending; leaves the deferred mode
     assert dll.aide_wgrad_reduce_defer(0) == 0           # ... so the previous mode reads 0
+
+
+def test_keep_largest_connected_components():
+    """CPU post-processing of the per-case evaluation (trainchaos_comparison_1case.py:68-77): face connectivity, the
+    largest blob only, the FIRST of equally large blobs (np.argmax over regionprops order = raster label order)."""
+    from aide_amd.inference import keep_largest_connected_components as keep
+    m = np.zeros((6, 6, 3), dtype=np.int64)
+    m[0:2, 0:2, 0] = 1                      # 4 voxels
+    m[4:6, 3:6, 1:3] = 1                    # 12 voxels: the largest
+    m[3, 0, 0] = 1                          # touches nothing by a face (diagonal to the first blob's corner)
+    out = keep(m)
+    assert out.dtype == np.uint8 and out.sum() == 12 and out[4:6, 3:6, 1:3].all()
+    tie = np.zeros((1, 7, 1), dtype=np.int64)
+    tie[0, 0:2, 0] = 1
+    tie[0, 4:6, 0] = 1                      # two blobs of two: the first one in raster order is kept
+    out = keep(tie)
+    assert out[0, 0:2, 0].all() and out.sum() == 2
+    assert keep(np.zeros((4, 4, 2), dtype=np.int64)).sum() == 0
