@@ -232,8 +232,10 @@ def cpu_baseline(model_name, batch, size, steps, max_threads):
 
 def measure_traffic(args, kernel, precision, batch):
     """HBM bytes per launch of `kernel` from the PMC counters, collected as MI355X_MICROARCH.md's HBM / rocprofv3 section
-    prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (with --kernel-trace only), raw unit KB,
-    FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 bytes).  Each pass profiles a
+    prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (with --kernel-trace only), raw unit KiB,
+    FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 bytes; calibrated on this stack
+    for 16-byte-per-lane reads in 64 / 128 / 256 / 1024-byte segments -- the row pieces the conv kernels read -- by
+    tools/fetch_calib.sh: FETCH_SIZE = 0.500 x bytes, WRITE_SIZE = 1.00-1.03 x bytes, profiles/r03_fetch_calib.txt).  Each pass profiles a
     short run (1 warm-up + 2 steps) of this same workload in a sub-process.  -> (bytes per launch | None, note)"""
     import csv
     import glob
@@ -273,7 +275,7 @@ def measure_traffic(args, kernel, precision, batch):
         shutil.rmtree(d, ignore_errors=True)
         if n == 0:
             return None, 'kernel %s not found in the %s pass' % (kernel, ctr)
-        per[ctr] = (kb * 1e3 / n, n)
+        per[ctr] = (kb * 1024.0 / n, n)          # the counter unit is KiB (tools/fetch_calib.sh: WRITE_SIZE = 0.977 x bytes / 1000)
     fetch, write = 2.0 * per['FETCH_SIZE'][0], per['WRITE_SIZE'][0]
     return int(fetch + write), ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over %d / %d launches of a 3-step run of '
                                 'this workload: fetch %.1f MB (raw x2, gfx950 correction) + write %.1f MB per launch'

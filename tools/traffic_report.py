@@ -29,7 +29,7 @@ fam = {'conv3x3_wino4_kernel': ('conv3x3_wino4_kernel', 'w4_splitk_reduce_kernel
 main = {k: v[0] for k, v in fam.items()}
 title = sys.argv[6] if len(sys.argv) > 6 else 'FuseUNet C2 step'
 lines = ['# HBM traffic per kernel, ' + title + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)', '',
-         'Raw counter units are KB. FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads on gfx950',
+         'Raw counter units are KiB (tools/fetch_calib.sh). FETCH_SIZE reports 1/2 of the bytes of 16 B/lane reads on gfx950, down to 64-byte segments',
          '(MI355X_MICROARCH.md, HBM section): the x2 column applies that correction; adam_kernel (20 B/param read, 16 B/param',
          'written, 26.68 M params = 533.5 / 426.8 MB) is the calibration row.', '',
          '| kernel | launches/step | FETCH raw MB/launch | x2 corrected | WRITE MB/launch |', '|---|---|---|---|---|']
@@ -37,12 +37,12 @@ tf = tw = 0.0
 famtot = {k: [0.0, 0.0] for k in fam}
 for n, (cnt, kb) in F.items():
     wkb = W.get(n, [cnt, 0.0])[1]
-    lines.append('| `%s` | %.1f | %.2f | %.2f | %.2f |' % (n, cnt / steps, kb / cnt / 1e3, 2 * kb / cnt / 1e3, wkb / max(W.get(n, [cnt])[0], 1) / 1e3))
+    lines.append('| `%s` | %.1f | %.2f | %.2f | %.2f |' % (n, cnt / steps, kb * 1.024 / cnt / 1e3, 2 * kb * 1.024 / cnt / 1e3, wkb * 1.024 / max(W.get(n, [cnt])[0], 1) / 1e3))
     tf += kb; tw += wkb
     for k, pats in fam.items():
         if any(p.lstrip('`') in n and not (p.startswith('`') and not n.startswith(p[1:])) for p in pats):
-            famtot[k][0] += 2 * kb * 1e3 / steps; famtot[k][1] += wkb * 1e3 / steps
-lines += ['', 'Whole step: FETCH raw %.2f GB (<= %.2f GB corrected), WRITE %.2f GB per step.' % (tf / steps / 1e6, 2 * tf / steps / 1e6, tw / steps / 1e6)]
+            famtot[k][0] += 2 * kb * 1024.0 / steps; famtot[k][1] += wkb * 1024.0 / steps
+lines += ['', 'Whole step: FETCH raw %.2f GB (%.2f GB corrected), WRITE %.2f GB per step.' % (tf * 1.024 / steps / 1e6, 2 * tf * 1.024 / steps / 1e6, tw * 1.024 / steps / 1e6)]
 open(out_md, 'w').write('\n'.join(lines) + '\n')
 js = {}
 for k, (fb, wb) in famtot.items():
