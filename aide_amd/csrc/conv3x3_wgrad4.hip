@@ -18,6 +18,7 @@
 //     the fixed-order slab reduce (launch_wgrad_reduce, conv3x3_wgrad.hip).
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream);
 
@@ -32,6 +33,7 @@ struct G4Args {
     long dz_bs, a_bs;
     int N, Co, Ci, H, W;
     int rows_t, cols_c, n_co_tiles, n_ci_tiles, splits, chunks_total;
+    int gco, gci;        // XCD group: gco x gci neighbouring (co, ci) tiles are consecutive logical blocks (see the launcher)
 };
 
 constexpr int G4_NAGPR = 16;
@@ -54,10 +56,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
     const int ph = wid & 1, cb = wid >> 1;                 // position half, co block of the MFMA role
     const int hs = wid >> 1, vt_hi = wid & 1;              // input-transform role: row half, tile pair
 
-    int b = xcd_remap(blockIdx.x, gridDim.x);
-    const int ci_tile = b % g.n_ci_tiles; b /= g.n_ci_tiles;
-    const int co_tile = b % g.n_co_tiles;
-    const int split = b / g.n_co_tiles;
+    // xcd_remap gives every XCD a contiguous range of logical blocks; inside a pixel split they are ordered by RECTANGLES of
+    // gco x gci tiles, so the workgroups of one XCD (which run in step: same chunk count) re-use gco slices of dz and gci
+    // slices of the input from their private L2 instead of one dz slice and every input slice
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_split = g.n_co_tiles * g.n_ci_tiles;
+    const int split = b / per_split, rb = b - split * per_split;
+    const int gsz = g.gco * g.gci, grp = rb / gsz, within = rb - grp * gsz;
+    const int ngci = g.n_ci_tiles / g.gci;
+    const int co_tile = (grp / ngci) * g.gco + within / g.gci;
+    const int ci_tile = (grp % ngci) * g.gci + within % g.gci;
     const int co0 = co_tile * 64, ci0 = ci_tile * 32;
     const int HW = g.H * g.W;
     const int cps = (g.chunks_total + g.splits - 1) / g.splits;
@@ -447,6 +455,25 @@ int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int
     g.chunks_total = N * g.rows_t * g.cols_c;
     g.splits = aide_conv3x3_wgrad_wino4_splits(N, Co, Ci, H, W);
     const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
+    // Tile rectangle per XCD (nb / 8 consecutive logical blocks).  Memory-side reads of a launch: every dz slice once per
+    // rectangle COLUMN that needs it, every input slice (1.5x with its halo rows) once per rectangle ROW:
+    //   bytes ~ |dz| * n_ci / gci + 1.5 |x| * n_co / gco,  gco * gci <= blocks per XCD  ->  2 / gci + 1.5 / gco minimal.
+    // (ci-fastest order = a 1 x n_ci rectangle read 1024->512 @32x32's input 8 times: 208 MB of fetches for 34 MB of operands.)
+    {
+        static const int force = getenv("AIDE_WG4_RECT") ? atoi(getenv("AIDE_WG4_RECT")) : 1;     // A-B switch (0: ci-fastest order)
+        const long per_xcd = nb / 8 > 0 ? nb / 8 : 1;
+        int bco = 1, bci = g.n_ci_tiles;
+        double best = 1e30;
+        for (int gco = 1; gco <= g.n_co_tiles && force; ++gco) {
+            if (g.n_co_tiles % gco) continue;
+            for (int gci = 1; gci <= g.n_ci_tiles; ++gci) {
+                if (g.n_ci_tiles % gci || (long)gco * gci > per_xcd) continue;
+                const double cost = 2.0 / gci + 1.5 / gco;
+                if (cost < best - 1e-12) { best = cost; bco = gco; bci = gci; }
+            }
+        }
+        g.gco = bco; g.gci = bci;
+    }
     AIDE_LAUNCH_TIMED(AIDE_KT_WGRAD4, AIDE_CONV_FLOPS(N, H, W, Co, Ci), conv3x3_wgrad4_kernel, dim3((unsigned)nb), dim3(256),
                       G4_LDS * sizeof(float), stream, g);
     const int rc = aide_launch_status();
