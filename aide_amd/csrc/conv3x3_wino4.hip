@@ -22,6 +22,7 @@
 // Forward error: the transform matrices have entries up to 8 (A) and 5 (B); measured <= 2e-5 relative to
 // the output scale on the network's layers (parity tests hold it to 1e-4; the north-star bound is 1e-3).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -36,6 +37,7 @@ struct W4Args {
     long x_bs, y_bs, split_stride;
     int N, Cin, H, W, Cout;
     int blocks_w, blocks_h, n_co_tiles, splitk, stages_total, accumulate;
+    int gp, gc;          // XCD group: gp pixel tiles x gc co tiles of one split are consecutive logical blocks (see the launcher)
     int pair;            // W == 16: a workgroup tile is 16 rows x (16 columns of image 2n | 16 columns of image 2n + 1)
     float* stats;        // optional [Cout][N * blocks_h * blocks_w][2]: per (channel, workgroup tile) sum / sum of squares of the
                          // pre-bias outputs -- the BatchNorm statistics of the forward pass without a pass over z
@@ -90,12 +92,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     const int half = lane >> 5, j = lane & 31;
     const int ph = wid & 1, cb = wid >> 1;                 // position half (transform rows 3ph..3ph+2), co block
 
+    // xcd_remap gives every XCD a contiguous range of logical blocks.  Their order: [pixel-tile group][split][co group]
+    // [co in group][pixel tile in group] -- gp pixel tiles that stream the SAME filter slice (co tile, channel range) and gc
+    // co tiles that read the SAME input tile sit in one XCD and share them in its L2.  (co-tile-fastest order made every
+    // workgroup of an XCD stream a different filter slice: 512->256 @64x64 fetched its 19 MB of filters 32 times.)
     int b = xcd_remap(blockIdx.x, gridDim.x);
-    const int co_tile = b % a.n_co_tiles; b /= a.n_co_tiles;
+    const int p_in = b % a.gp;            b /= a.gp;
+    const int co_in = b % a.gc;           b /= a.gc;
+    const int ncg = a.n_co_tiles / a.gc;
+    const int cog = b % ncg;              b /= ncg;
     const int split = b % a.splitk;       b /= a.splitk;
-    const int tw = b % a.blocks_w;        b /= a.blocks_w;
-    const int th = b % a.blocks_h;
-    const int n = b / a.blocks_h;
+    const int co_tile = cog * a.gc + co_in;
+    int pt = b * a.gp + p_in;                              // pixel tile = (n, th, tw)
+    const int tw = pt % a.blocks_w;       pt /= a.blocks_w;
+    const int th = pt % a.blocks_h;
+    const int n = pt / a.blocks_h;
     const int h0 = th * 16, w0 = tw * 32, co0 = co_tile * 64;
     const int HW = a.H * a.W;
     // 16-pixel-wide images (the 16 x 16 bottleneck level): the 32-column tile holds the rows of TWO images side by side, each
@@ -646,6 +657,29 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
         a.y = y; a.y_bs = y_bs; a.split_stride = 0; a.bias = bias; a.accumulate = (accumulate == 1);
     }
     const long nb = (long)a.blocks_w * a.blocks_h * (a.pair ? N / 2 : N) * a.n_co_tiles * splitk;
+    {   // tile group per XCD (nb / 8 consecutive logical blocks).  Memory-side reads of a launch: the filter pack once per
+        // pixel-tile GROUP, the input (1.44x with its halo) once per co GROUP:  bytes ~ |U| P / gp + 1.44 |x| C / gc.
+        static const int force = getenv("AIDE_W4_RECT") ? atoi(getenv("AIDE_W4_RECT")) : 1;      // A-B switch (0: co-fastest order)
+        const long P = (long)a.blocks_w * a.blocks_h * (a.pair ? N / 2 : N);
+        const int C = a.n_co_tiles;
+        const long per_xcd = nb / 8 > 0 ? nb / 8 : 1;
+        const double ub = 144.0 * (double)Cin * Cout, xb = 1.44 * 4.0 * (double)N * Cin * H * W;
+        long bp = 1; int bc = C;
+        double best = 1e300;
+        // (layer sweep, tools/bench_conv.py with AIDE_W4_RECT=0/1: the >= 19 GFLOP layers are level or 3-13 % faster with the
+        // groups -- 512->512 @32x32 0.077 -> 0.067 ms -- the <= 5 GFLOP split-K layers 5-10 % slower, 32 workgroups of an XCD
+        // then stream one small filter slice in step: they keep the co-fastest order)
+        const bool grouped = force == 2 || (force == 1 && AIDE_CONV_FLOPS(N, H, W, Cout, Cin) >= 8e9);
+        for (long gp = 1; gp <= P && gp <= per_xcd && grouped; gp *= 2) {      // (powers of two: a handful of candidates per launch)
+            if (P % gp) continue;
+            for (int gc = 1; gc <= C; ++gc) {
+                if (C % gc || gp * gc > per_xcd) continue;
+                const double cost = ub * (double)P / (double)gp + xb * (double)C / (double)gc;
+                if (cost < best) { best = cost; bp = gp; bc = gc; }
+            }
+        }
+        a.gp = (int)bp; a.gc = bc;
+    }
     if (a.pair) {
         AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), conv3x3_wino4_kernel<1>, dim3((unsigned)nb), dim3(256),
                           F4_LDS * sizeof(float), stream, a);

@@ -89,10 +89,19 @@ def _check_config(dev, net, ref, inputs, t, fx, tag):
     assert flips <= 2e-4 * fm.total, 'implausibly many ReLU mask flips: %d of %d' % (flips, fm.total)
     assert rel(out, out_r.detach()) < RTOL
     worst, worst_k = 0.0, None
+    named = dict(ref.named_parameters())
     for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         scale = q.grad.abs().max().item()
+        if k.endswith('.bias') and k[:-5] + '.weight' in named and named[k[:-5] + '.weight'].dim() == 4 \
+                and not k.startswith('last_conv'):
+            # a 3x3 / transposed conv bias feeding a BatchNorm: zero true gradient, both sides hold rounding noise of their
+            # own summation order (aten's is thread-schedule dependent: its magnitude straddled a 1e-6 cut-off from run to
+            # run) -- both must be negligible beside the same conv's weight gradient
+            wscale = named[k[:-5] + '.weight'].grad.abs().max().item()
+            assert max(scale, p.grad.abs().max().item()) <= 1e-4 * wscale + 1e-12, (k, scale, p.grad.abs().max().item(), wscale)
+            continue
         if scale < 1e-6:
-            continue                       # conv biases feeding a BatchNorm: zero true gradient
+            continue
         e = (p.grad.cpu() - q.grad).abs().max().item() / scale
         if e > worst:
             worst, worst_k = e, k
