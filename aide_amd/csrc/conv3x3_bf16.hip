@@ -26,10 +26,12 @@
 //
 // Weight gradient (conv3x3_wgrad_bf16_kernel): dW[co][ci][tap] = sum_pix dz[co][pix] x[ci][pix+tap], K = pixels.
 //   * an MFMA consumes 16 consecutive pixels of one image row: NCHW rows are already K-contiguous, so both LDS
-//     images stay channel-major (dz [co][4 rows][32 px], x [ci][6 rows][-1..38 px], bf16);
-//   * the +-1 column shift of the x operand would need 2-byte-misaligned 16-byte reads; instead the x rows are
-//     stored starting at column -1, one aligned 32-byte window per (row, k-step) is read and the three shifted
-//     fragments are formed in registers (kw=0: the window itself, kw=1: four v_alignbit, kw=2: a register slice);
+//     images stay channel-major (dz [co][4 rows][-1..38 px], x [ci][6 rows][32 px], bf16);
+//   * the +-1 column shift of the taps is carried by the dz operand (dW[kh][kw] = sum_q dz[q - (kw-1)] x[q + (kh-1) W] over
+//     the aligned pixels q): one shifted dz fragment serves all three kh.  A 2-byte shift would need misaligned 16-byte LDS
+//     reads; instead the dz rows are stored starting at column -1, one aligned 32-byte window per (row, k-step) is read and
+//     the three fragments are formed in registers (kw=2: the window itself, kw=1: four v_alignbit, kw=0: a register slice);
+//     the x rows are plain aligned copies with a row halo;
 //   * workgroup = 64 co x 64 ci x 9 taps (a wave owns 32 x 32 x 9 = 144 accumulators), stage = 4 image rows x 32
 //     columns, pixel range split over workgroups into slabs [split][tap][co][ci] reduced in fixed order
 //     (aide_wgrad_reduce_launch, shared with the fp32 kernels) -> bit-reproducible.
@@ -565,18 +567,25 @@ struct BgArgs {
 
 // R = image rows of dz per stage (4, or 2: half the staging registers -> two workgroups per CU); NWCO = co blocks of 32
 // per workgroup: 2 (64 co x 64 ci, 4 waves) or 4 (128 co x 64 ci, 8 waves = two per SIMD: the four co blocks share one
-// x tile, halving the x bytes through L2 / L1 / LDS per MFMA, and a second wave per SIMD covers the other's stalls)
+// x tile, halving the x bytes through L2 / L1 / LDS per MFMA, and a second wave per SIMD covers the other's stalls).
+//
+// Which operand carries the +-1 column shift of the taps (round 3): dW[kh][kw] = sum_q dz[q - (kw - 1)] x[q + (kh - 1) W], q
+// running over the ALIGNED pixels of the stage -- the shift sits on dz, whose shifted fragment serves all three kh, instead
+// of on x, where each of the three row windows needed its own two shifted copies: 2 instead of 6 shifted fragments (6
+// instead of 18 vector instructions) and 5 instead of 7 LDS reads per k-step of 9 MFMAs.  So the dz rows are stored from
+// column -1 (one aligned 32-byte window per (row, k-step): kw = 2 is the window, kw = 1 four v_alignbit, kw = 0 a register
+// slice), zero where the neighbouring column lies outside the image, and the x rows are plain aligned copies with their row halo.
 template <int R, int NWCO> struct GCfg {
     static constexpr int NT = 128 * NWCO;            // threads
     static constexpr int TCO = 32 * NWCO;            // output channels per workgroup
-    static constexpr int DZP = R * 4 + 1;            // slots per dz channel (odd: conflict-free b128 across channels)
-    static constexpr int XP = (R + 2) * 5 + 1;       // slots per x channel: R + 2 rows x 5 slots (columns -1 .. 38)
+    static constexpr int DZP = R * 5 + 1;            // slots per dz channel: R rows x 5 slots (columns -1 .. 38); odd: conflict-free
+    static constexpr int XP = (R + 2) * 4 + 1;       // slots per x channel: R + 2 rows x 4 slots (columns 0 .. 31)
     static constexpr int DZS = TCO * DZP;
     static constexpr int BUF = DZS + 64 * XP + 1;    // slots per stage buffer (+ 1 dump slot for idle staging lanes)
-    static constexpr int ND = TCO * R * 4 / NT;                  // dz units per thread      (TCO co x R rows x 4 blocks)
-    static constexpr int NM = (64 * (R + 2) * 4 + NT - 1) / NT;  // x main units per thread  (64 ci x (R + 2) rows x 4 slots)
-    static constexpr int NE = (64 * (R + 2) + NT - 1) / NT;      // x edge units per thread
-    static constexpr int NOPS = ND + NM + NE;
+    static constexpr int NDM = TCO * R * 4 / NT;                 // dz main units per thread (TCO co x R rows x 4 slots)
+    static constexpr int NDE = (TCO * R + NT - 1) / NT;          // dz edge units per thread (columns 31, 32)
+    static constexpr int NX = 64 * (R + 2) * 4 / NT;             // x units per thread       (64 ci x (R + 2) rows x 4 blocks)
+    static constexpr int NOPS = NDM + NDE + NX;
     static constexpr int KS = 2 * R;                 // k-steps per stage
     static_assert(TCO * R * 4 % NT == 0 && 64 * (R + 2) * 4 % NT == 0, "staging units must divide evenly");
 };
@@ -585,8 +594,9 @@ constexpr int G_RMIN = 2;
 template <int R, bool DZ_BF16, bool X_BF16, int NWCO>
 __global__ __launch_bounds__(128 * NWCO, (R == 2 && NWCO == 2) ? 2 : 1) void conv3x3_wgrad_bf16_kernel(const BgArgs g) {
     constexpr unsigned XE = X_BF16 ? 2u : 4u;        // bytes per x element
+    constexpr unsigned DE = DZ_BF16 ? 2u : 4u;       // bytes per dz element
     using G = GCfg<R, NWCO>;
-    constexpr int ND = G::ND, NM = G::NM, NE = G::NE, NOPS = G::NOPS, KS = G::KS, NT = G::NT;
+    constexpr int NDM = G::NDM, NDE = G::NDE, NX = G::NX, NOPS = G::NOPS, KS = G::KS, NT = G::NT;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // 2 * G::BUF slots
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int half = lane >> 5, j = lane & 31;
@@ -603,115 +613,114 @@ __global__ __launch_bounds__(128 * NWCO, (R == 2 && NWCO == 2) ? 2 : 1) void con
     const int c_end = min(c_begin + cps, g.chunks_total);
 
     // ---- staging descriptors ----
-    // dz: unit = (co, row, 8-pixel block): 16 (bf16) or 2 x 16 (fp32) bytes -> one slot
-    unsigned offD[ND], ldsD[ND];
+    // dz main: unit = (co, row, slot s): columns 8s-1 .. 8s+6 of the segment -> one slot.  fp32: descriptor base = column -1,
+    // the unit's 16-byte loads start at column 8s; bf16: base = column -2 (the (8s-2, 8s-1) pair is one aligned dword), the
+    // unit's 16-byte load starts at column 8s.  ownL: the unit owns column -1 (zero when the segment starts the image row)
+    unsigned offDM[NDM], ldsDM[NDM], ownL[NDM];
 #pragma unroll
-    for (int e = 0; e < ND; ++e) {
+    for (int e = 0; e < NDM; ++e) {
         const int u = tid + e * NT;
-        const int blk = u & 3, row = (u >> 2) % R, co = u / (4 * R);
-        offD[e] = (co0 + co < g.Co) ? (unsigned)(co * HW + row * g.W + blk * 8) * (DZ_BF16 ? 2u : 4u) : BUF_OOB;
-        ldsD[e] = (unsigned)(co * G::DZP + row * 4 + blk);
+        const int sl = u & 3, rr = u >> 2;
+        const int row = rr % R, co = rr / R;
+        offDM[e] = (co0 + co < g.Co) ? (unsigned)(co * HW + row * g.W + sl * 8 + (DZ_BF16 ? 2 : 1)) * DE : BUF_OOB;
+        ldsDM[e] = (unsigned)(co * G::DZP + row * 5 + sl);
+        ownL[e] = sl == 0 ? 1u : 0u;
     }
-    // x main: unit = (ci, tile row, slot s): columns 8s-1 .. 8s+6 of the segment -> one slot.  flagM: bit 0 = top halo
-    // row, bit 1 = bottom halo row, bit 2 = the unit owns column -1 (zero padding when the segment starts the image row)
-    unsigned offM[NM], ldsM[NM], flagM[NM];
+    // dz edge: unit = (co, row): columns 31, 32 -> first dword of slot 4
+    unsigned offDE[NDE], ldsDE[NDE];
 #pragma unroll
-    for (int e = 0; e < NM; ++e) {
+    for (int e = 0; e < NDE; ++e) {
         const int u = tid + e * NT;
-        const int s = u & 3, rr = u >> 2;
+        const int row = u % R, co = u / R;
+        const bool ok = u < G::TCO * R && co0 + co < g.Co;
+        offDE[e] = ok ? (unsigned)(co * HW + row * g.W + 32) * DE : BUF_OOB;   // fp32: column 31 (base = column -1); bf16: pair (30, 31) (base = column -2)
+        ldsDE[e] = u < G::TCO * R ? (unsigned)(co * G::DZP + row * 5 + 4) : (unsigned)(G::BUF - 1);   // dump slot
+    }
+    // x: unit = (ci, tile row, 8-pixel block): 16 (bf16) or 2 x 16 (fp32) bytes -> one slot.  flagX: bit 0 = top halo row,
+    // bit 1 = bottom halo row
+    unsigned offX[NX], ldsX[NX], flagX[NX];
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+        const int u = tid + e * NT;
+        const int blk = u & 3, rr = u >> 2;
         const int row = rr % (R + 2), ci = rr / (R + 2);
-        // fp32: descriptor base = column -1, the unit's 16-byte loads start at column 8s; bf16: base = column -2 (the
-        // (8s-2, 8s-1) pair is one aligned dword), the unit's 16-byte load starts at column 8s
-        offM[e] = (ci0 + ci < g.Ci) ? (unsigned)(ci * HW + row * g.W + s * 8 + (X_BF16 ? 2 : 1)) * XE : BUF_OOB;
-        ldsM[e] = (unsigned)(G::DZS + ci * G::XP + row * 5 + s);
-        flagM[e] = (row == 0 ? 1u : 0u) | (row == R + 1 ? 2u : 0u) | (s == 0 ? 4u : 0u);
-    }
-    // x edge: unit = (ci, tile row): columns 31, 32 -> first dword of slot 4
-    unsigned offE[NE], ldsE[NE], flagE[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const int u = tid + e * NT;
-        const int row = u % (R + 2), ci = u / (R + 2);
-        const bool ok = u < 64 * (R + 2) && ci0 + ci < g.Ci;
-        offE[e] = ok ? (unsigned)(ci * HW + row * g.W + 32) * XE : BUF_OOB;   // fp32: column 31 (base = column -1); bf16: pair (30, 31) (base = column -2)
-        ldsE[e] = u < 64 * (R + 2) ? (unsigned)(G::DZS + ci * G::XP + row * 5 + 4) : (unsigned)(G::BUF - 1);   // dump slot
-        flagE[e] = (row == 0 ? 1u : 0u) | (row == R + 1 ? 2u : 0u);
+        offX[e] = (ci0 + ci < g.Ci) ? (unsigned)(ci * HW + row * g.W + blk * 8) * XE : BUF_OOB;
+        ldsX[e] = (unsigned)(G::DZS + ci * G::XP + row * 4 + blk);
+        flagX[e] = (row == 0 ? 1u : 0u) | (row == R + 1 ? 2u : 0u);
     }
 
-    f32x4 dr[ND][2];
-    float me[NM];
-    f32x4 mr[NM][2];
-    float er[NE][2];
-    // Per-chunk scalars (descriptor bases, halo masks) are derived ONCE per stage -- the per-operation form of this
-    // (a scalar div/mod chain and a handful of selects in front of every load) made the kernel instruction-issue
-    // bound: 2.7 scalar + 4.1 vector instructions per MFMA (PMC), one wave per SIMD.  A chunk past the end of the
-    // split reads through empty descriptors; image-border rows / columns are one v_cndmask per unit.
+    float dme[NDM];
+    f32x4 dmr[NDM][2];
+    float der[NDE][2];
+    f32x4 xr[NX][2];
+    // Per-chunk scalars (descriptor bases, halo masks) are derived ONCE per stage.  A chunk past the end of the split reads
+    // through empty descriptors; image-border rows / columns are one v_cndmask per unit.
     __amdgpu_buffer_rsrc_t rsD, rsX;
-    unsigned edge_mask = 0;                      // bit 0: top row outside, 1: bottom row outside, 2: column -1 outside
-    bool right_ok = false;
+    unsigned edge_mask = 0;                      // bit 0: top row outside, 1: bottom row outside
+    bool left_out = false, right_ok = false;
     auto set_chunk = [&](int chunk) {
         const unsigned nrec = chunk < c_end ? BUF_OOB : 0u;
         const int seg = chunk % g.segs_w;
         const int t2 = chunk / g.segs_w;
         const int band = t2 % g.bands_h, n = t2 / g.bands_h;
         const int h0 = band * R, w0 = seg * 32;
-        const long eoff = (long)n * g.dz_bs + (long)co0 * HW + (long)h0 * g.W + w0;
-        rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((const char*)g.dz + eoff * (DZ_BF16 ? 2 : 4)), 0, nrec,
-                                                0x00020000);
-        const long xoff = (long)n * g.x_bs + (long)ci0 * HW + (long)(h0 - 1) * g.W + w0 - (X_BF16 ? 2 : 1);
+        const long doff = (long)n * g.dz_bs + (long)co0 * HW + (long)h0 * g.W + w0 - (DZ_BF16 ? 2 : 1);
+        rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((const char*)g.dz + doff * (long)DE), 0, nrec, 0x00020000);
+        const long xoff = (long)n * g.x_bs + (long)ci0 * HW + (long)(h0 - 1) * g.W + w0;
         rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((const char*)g.x + xoff * (long)XE), 0, nrec, 0x00020000);
-        edge_mask = (h0 == 0 ? 1u : 0u) | (h0 + R >= g.H ? 2u : 0u) | (w0 == 0 ? 4u : 0u);
+        edge_mask = (h0 == 0 ? 1u : 0u) | (h0 + R >= g.H ? 2u : 0u);
+        left_out = w0 == 0;
         right_ok = w0 + 32 < g.W;
     };
-    // ops 0 .. ND-1 = dz units, then NM x main units, then NE x edge units
+    // ops 0 .. NDM-1 = dz main units, then NDE dz edge units, then NX x units
     auto fetch = [&](int op) {
-        if (op < ND) {
-            dr[op][0] = buf_load_f32x4(rsD, offD[op], 0);                 // bf16: the 8 pixels of the slot as stored
-            if constexpr (!DZ_BF16) dr[op][1] = buf_load_f32x4(rsD, offD[op], 16);
-        } else if (op < ND + NM) {
-            const int e = op - ND;
-            const unsigned off = (flagM[e] & edge_mask & 3u) ? BUF_OOB : offM[e];
-            me[e] = buf_load_f32(rsX, ((flagM[e] & edge_mask & 4u) || off == BUF_OOB) ? BUF_OOB : off - 4u, 0);
-            mr[e][0] = buf_load_f32x4(rsX, off, 0);              // bf16: columns 8s .. 8s+7 as stored, me = pair (8s-2, 8s-1)
-            if constexpr (!X_BF16) mr[e][1] = buf_load_f32x4(rsX, off, 16);
-        } else {
-            const int e = op - ND - NM;
-            const unsigned off = (flagE[e] & edge_mask) ? BUF_OOB : offE[e];
+        if (op < NDM) {
+            const unsigned off = offDM[op];
+            dme[op] = buf_load_f32(rsD, ((ownL[op] && left_out) || off == BUF_OOB) ? BUF_OOB : off - 4u, 0);
+            dmr[op][0] = buf_load_f32x4(rsD, off, 0);          // bf16: columns 8s .. 8s+7 as stored, dme = pair (8s-2, 8s-1)
+            if constexpr (!DZ_BF16) dmr[op][1] = buf_load_f32x4(rsD, off, 16);
+        } else if (op < NDM + NDE) {
+            const int e = op - NDM;
             // fp32: columns 31 and 32; bf16: the pairs (30, 31) and (32, 33)
-            er[e][0] = buf_load_f32(rsX, off, 0);
-            er[e][1] = buf_load_f32(rsX, right_ok ? off + 4u : BUF_OOB, 0);
+            der[e][0] = buf_load_f32(rsD, offDE[e], 0);
+            der[e][1] = buf_load_f32(rsD, (right_ok && offDE[e] != BUF_OOB) ? offDE[e] + 4u : BUF_OOB, 0);
+        } else {
+            const int e = op - NDM - NDE;
+            const unsigned off = (flagX[e] & edge_mask) ? BUF_OOB : offX[e];
+            xr[e][0] = buf_load_f32x4(rsX, off, 0);                // bf16: the 8 pixels of the slot as stored
+            if constexpr (!X_BF16) xr[e][1] = buf_load_f32x4(rsX, off, 16);
         }
     };
     auto put = [&](int op, u32x4* buf) {
-        if (op < ND) {
+        if (op < NDM) {
             u32x4 s;
-            if constexpr (DZ_BF16) {
-                s = __builtin_bit_cast(u32x4, dr[op][0]);
-            } else {
-                s[0] = pk_bf16(dr[op][0].x, dr[op][0].y); s[1] = pk_bf16(dr[op][0].z, dr[op][0].w);
-                s[2] = pk_bf16(dr[op][1].x, dr[op][1].y); s[3] = pk_bf16(dr[op][1].z, dr[op][1].w);
-            }
-            buf[ldsD[op]] = s;
-        } else if (op < ND + NM) {
-            const int e = op - ND;
-            u32x4 s;
-            if constexpr (X_BF16) {        // shift the stored pairs by one pixel: slot = columns 8s-1 .. 8s+6
-                const unsigned d = __builtin_bit_cast(unsigned, me[e]);
-                const u32x4 q = __builtin_bit_cast(u32x4, mr[e][0]);
+            if constexpr (DZ_BF16) {       // shift the stored pairs by one pixel: slot = columns 8s-1 .. 8s+6
+                const unsigned d = __builtin_bit_cast(unsigned, dme[op]);
+                const u32x4 q = __builtin_bit_cast(u32x4, dmr[op][0]);
                 s[0] = __builtin_amdgcn_alignbit(q[0], d, 16);    s[1] = __builtin_amdgcn_alignbit(q[1], q[0], 16);
                 s[2] = __builtin_amdgcn_alignbit(q[2], q[1], 16); s[3] = __builtin_amdgcn_alignbit(q[3], q[2], 16);
             } else {
-                s[0] = pk_bf16(me[e], mr[e][0].x);        s[1] = pk_bf16(mr[e][0].y, mr[e][0].z);
-                s[2] = pk_bf16(mr[e][0].w, mr[e][1].x);   s[3] = pk_bf16(mr[e][1].y, mr[e][1].z);
+                s[0] = pk_bf16(dme[op], dmr[op][0].x);          s[1] = pk_bf16(dmr[op][0].y, dmr[op][0].z);
+                s[2] = pk_bf16(dmr[op][0].w, dmr[op][1].x);     s[3] = pk_bf16(dmr[op][1].y, dmr[op][1].z);
             }
-            buf[ldsM[e]] = s;
-        } else {
-            const int e = op - ND - NM;
-            if constexpr (X_BF16)          // (column 31 = high half of the first pair, column 32 = low half of the second)
-                reinterpret_cast<unsigned*>(buf + ldsE[e])[0] = __builtin_amdgcn_alignbit(
-                    __builtin_bit_cast(unsigned, er[e][1]), __builtin_bit_cast(unsigned, er[e][0]), 16);
+            buf[ldsDM[op]] = s;
+        } else if (op < NDM + NDE) {
+            const int e = op - NDM;
+            if constexpr (DZ_BF16)         // (column 31 = high half of the first pair, column 32 = low half of the second)
+                reinterpret_cast<unsigned*>(buf + ldsDE[e])[0] = __builtin_amdgcn_alignbit(
+                    __builtin_bit_cast(unsigned, der[e][1]), __builtin_bit_cast(unsigned, der[e][0]), 16);
             else
-                reinterpret_cast<unsigned*>(buf + ldsE[e])[0] = pk_bf16(er[e][0], er[e][1]);
+                reinterpret_cast<unsigned*>(buf + ldsDE[e])[0] = pk_bf16(der[e][0], der[e][1]);
+        } else {
+            const int e = op - NDM - NDE;
+            u32x4 s;
+            if constexpr (X_BF16) {
+                s = __builtin_bit_cast(u32x4, xr[e][0]);
+            } else {
+                s[0] = pk_bf16(xr[e][0].x, xr[e][0].y); s[1] = pk_bf16(xr[e][0].z, xr[e][0].w);
+                s[2] = pk_bf16(xr[e][1].x, xr[e][1].y); s[3] = pk_bf16(xr[e][1].z, xr[e][1].w);
+            }
+            buf[ldsX[e]] = s;
         }
     };
 
@@ -742,68 +751,51 @@ __global__ __launch_bounds__(128 * NWCO, (R == 2 && NWCO == 2) ? 2 : 1) void con
         u32x4* nxt = lds + (cur ^ 1) * G::BUF;
         set_chunk(chunk + 2);
         // Operand registers are double buffered by hand: the LDS reads of k-step ks + 1 are ISSUED FIRST in k-step ks
-        // (one group, ahead of its MFMAs) and consumed a whole k-step later.  The ablation build without MFMAs ran at
-        // 88 % of the full kernel: every "read window -> s_waitcnt lgkmcnt(0) -> shift -> MFMA" group exposed the LDS
-        // round trip (~150 cycles, 40 times per stage) with one wave per SIMD to hide it.
-        bf16x8 afA, afB;
-        u32x4 wA[3][2], wB[3][2];
-        auto load_ops = [&](int ks, bf16x8& af, u32x4 (&wv)[3][2]) {
+        // (one group, ahead of its MFMAs) and consumed a whole k-step later (one wave per SIMD: nothing else would hide
+        // the LDS round trip, ~150 cycles, 40 times per stage).
+        u32x4 dA[2], dB[2];
+        bf16x8 xA[3], xB[3];
+        auto load_ops = [&](int ks, u32x4 (&dw)[2], bf16x8 (&xf)[3]) {
             const int r = ks >> 1, hs = ks & 1;
-            af = __builtin_bit_cast(bf16x8, pa[r * 4 + hs * 2]);
+            dw[0] = pa[r * 5 + hs * 2];
+            dw[1] = pa[r * 5 + hs * 2 + 1];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                wv[kh][0] = pb[(r + kh) * 5 + hs * 2];
-                wv[kh][1] = pb[(r + kh) * 5 + hs * 2 + 1];
-            }
+            for (int kh = 0; kh < 3; ++kh) xf[kh] = __builtin_bit_cast(bf16x8, pb[(r + kh) * 4 + hs * 2]);
         };
-        load_ops(0, afA, wA);
+        load_ops(0, dA, xA);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {             // k-step = (dz row r, 16-pixel half segment hs)
-            const bf16x8& af = (ks & 1) ? afB : afA;
-            u32x4 (&wv)[3][2] = (ks & 1) ? wB : wA;
-            if (ks + 1 < KS) { if (ks & 1) load_ops(ks + 1, afA, wA); else load_ops(ks + 1, afB, wB); }
+            u32x4 (&dw)[2] = (ks & 1) ? dB : dA;
+            bf16x8 (&xf)[3] = (ks & 1) ? xB : xA;
+            if (ks + 1 < KS) { if (ks & 1) load_ops(ks + 1, dA, xA); else load_ops(ks + 1, dB, xB); }
+            const u32x4 w0v = dw[0], w1v = dw[1];    // dz columns q-1 .. q+14 of this lane's 8 aligned pixels q .. q+7
+            u32x4 s1, s0;
+            s1[0] = __builtin_amdgcn_alignbit(w0v[1], w0v[0], 16);       // kw = 1: dz[q .. q+7]
+            s1[1] = __builtin_amdgcn_alignbit(w0v[2], w0v[1], 16);
+            s1[2] = __builtin_amdgcn_alignbit(w0v[3], w0v[2], 16);
+            s1[3] = __builtin_amdgcn_alignbit(w1v[0], w0v[3], 16);
+            s0[0] = w0v[1]; s0[1] = w0v[2]; s0[2] = w0v[3]; s0[3] = w1v[0];   // kw = 0: dz[q+1 .. q+8]
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, w0v), a1 = __builtin_bit_cast(bf16x8, s1), a0 = __builtin_bit_cast(bf16x8, s0);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                const u32x4 w0v = wv[kh][0];
-                const u32x4 w1v = wv[kh][1];
-                u32x4 s1, s2;
-#ifndef AIDE_PROBE_WG_NO_SHIFT
-                s1[0] = __builtin_amdgcn_alignbit(w0v[1], w0v[0], 16);
-                s1[1] = __builtin_amdgcn_alignbit(w0v[2], w0v[1], 16);
-                s1[2] = __builtin_amdgcn_alignbit(w0v[3], w0v[2], 16);
-                s1[3] = __builtin_amdgcn_alignbit(w1v[0], w0v[3], 16);
-                s2[0] = w0v[1]; s2[1] = w0v[2]; s2[2] = w0v[3]; s2[3] = w1v[0];
-#else
-                s1 = w0v; s2 = w1v;
-#endif
-#ifndef AIDE_PROBE_WG_NO_MFMA
-                acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, w0v), acc[kh * 3 + 0], 0, 0, 0);
-                acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, s1), acc[kh * 3 + 1], 0, 0, 0);
-                acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, s2), acc[kh * 3 + 2], 0, 0, 0);
-#else
-                acc[kh * 3 + 0][0] += __builtin_bit_cast(f32x4, w0v)[0] + __builtin_bit_cast(f32x4, af)[0];
-                acc[kh * 3 + 1][0] += __builtin_bit_cast(f32x4, s1)[1];
-                acc[kh * 3 + 2][0] += __builtin_bit_cast(f32x4, s2)[2];
-#endif
+                acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, xf[kh], acc[kh * 3 + 0], 0, 0, 0);
+                acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xf[kh], acc[kh * 3 + 1], 0, 0, 0);
+                acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xf[kh], acc[kh * 3 + 2], 0, 0, 0);
             }
             // staging: chunk + 1 registers -> the other buffer, then re-issue their loads for chunk + 2
 #pragma unroll
             for (int k = 0; k < OPK; ++k) {
                 const int op = ks * OPK + k;
-#ifndef AIDE_PROBE_WG_NO_PUT
                 if (op < NOPS) put(op, nxt);
-#endif
-#ifndef AIDE_PROBE_WG_NO_FETCH
                 if (op < NOPS) fetch(op);
-#endif
             }
-            // issue order: ALL operand reads of the next k-step first, then per MFMA three VALU (shifts / conversions),
+            // issue order: ALL operand reads of the next k-step first, then per MFMA two VALU (shifts / conversions),
             // one LDS store, one global load
-            __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);       // DS reads (next k-step's operands)
+            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);       // DS reads (next k-step's operands)
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // VALU
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
             }
