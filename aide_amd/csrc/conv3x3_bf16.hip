@@ -658,11 +658,13 @@ __global__ __launch_bounds__(128 * NWCO, (R == 2 && NWCO == 2) ? 2 : 1) void con
     __amdgpu_buffer_rsrc_t rsD, rsX;
     unsigned edge_mask = 0;                      // bit 0: top row outside, 1: bottom row outside
     bool left_out = false, right_ok = false;
+    // chunk cursor (segment, band, image), advanced incrementally: set_chunk is called for consecutive chunks, and the
+    // div / mod form of it was ~40 scalar instructions per stage of a loop that is bound by instruction issue
+    int cu_seg = c_begin % g.segs_w, cu_band = (c_begin / g.segs_w) % g.bands_h, cu_n = c_begin / g.segs_w / g.bands_h;
     auto set_chunk = [&](int chunk) {
         const unsigned nrec = chunk < c_end ? BUF_OOB : 0u;
-        const int seg = chunk % g.segs_w;
-        const int t2 = chunk / g.segs_w;
-        const int band = t2 % g.bands_h, n = t2 / g.bands_h;
+        const int seg = cu_seg, band = cu_band, n = cu_n;
+        if (++cu_seg == g.segs_w) { cu_seg = 0; if (++cu_band == g.bands_h) { cu_band = 0; ++cu_n; } }
         const int h0 = band * R, w0 = seg * 32;
         const long doff = (long)n * g.dz_bs + (long)co0 * HW + (long)h0 * g.W + w0 - (DZ_BF16 ? 2 : 1);
         rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((const char*)g.dz + doff * (long)DE), 0, nrec, 0x00020000);
