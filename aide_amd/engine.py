@@ -92,7 +92,6 @@ WGRAD_TAG = {0: 'conv3x3_wgrad_kernel', 2: 'conv3x3_wgrad_wino_kernel', 4: 'conv
 PRECISIONS = ('fp32', 'bf16')
 USE_WINOGRAD4 = [True]
 import os as _os
-PROBE_SKIP_WGRAD = [bool(_os.environ.get('AIDE_PROBE_SKIP_WGRAD'))]
 HEAD_WGRAD_SIDE = [_os.environ.get('AIDE_HEAD_WGRAD_SIDE', '1') != '0']      # A-B switch
 STORE_BF16 = [True]            # precision='bf16': z / dz stored as bf16 (A-B switch)
 STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 where every reader / writer allows it
@@ -104,7 +103,6 @@ REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch ta
 HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switch: backward chain on a high-priority stream
 EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B switch: BN statistics from the conv epilogue
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
-PROBE_NO_REPACK = [_os.environ.get('AIDE_PROBE_NO_REPACK', '0') != '0']   # timing probe (stale filters): what the per-step re-layout costs
 GROUP_STATS = [_os.environ.get('AIDE_GROUP_STATS', '1') != '0']    # A-B switch: epilogue BatchNorm statistics in grouped (stacked-batch) forwards
 F4_HALF_TILES = [_os.environ.get('AIDE_F4_HALF_TILES', '0') != '0']   # A-B switch: F(4x4) on layers whose Cout is 32 mod 64
 W16_PAIRS = [_os.environ.get('AIDE_W16_PAIRS', '0') != '0']      # F(4x4) on the 16-pixel-wide level (image pairs per tile): 11 % faster per launch than F(2x2), -0.6 % on the C2 step (larger filter pack, more slabs for BatchNorm to sum): off
@@ -458,7 +456,7 @@ class Plan(object):
             self._conv_wslots = [st['conv']._parameters for st in convs]          # (every forward: no module __getattr__)
         ws = [d['weight'] for d in self._conv_wslots]
         key = (PARAM_EPOCH[0],) + tuple((w.data_ptr(), w._version) for w in ws)
-        if key == self._pack_key or (PROBE_NO_REPACK[0] and self._pack_key is not None):
+        if key == self._pack_key:
             return None
         ptrs = tuple(k[0] for k in key[1:])
         if self._pack_tab is None or self._pack_tab[0] != ptrs:
@@ -567,8 +565,7 @@ class Plan(object):
         return tuple(fp)
 
     def _tapeable(self):
-        return REPLAY[0] and self.profiler is None and self.trace is None and not LATE_DGRAD_PACK[0] and not HP_CHAIN[0] \
-            and not PROBE_SKIP_WGRAD[0]
+        return REPLAY[0] and self.profiler is None and self.trace is None and not LATE_DGRAD_PACK[0] and not HP_CHAIN[0]
 
     def forward(self, inputs, out):
         self.serial += 1                 # the saved activations of this plan now belong to THIS forward (any kind)
@@ -919,12 +916,9 @@ class Plan(object):
                 x = self.view(st['src'], inputs)
                 if kind == 'conv':
                     prof = self.profiler
-                    if PROBE_SKIP_WGRAD[0]:            # ablation probe (results wrong): upper bound of what a faster wgrad buys
-                        wgrad = lambda *a, **k: None
-                    else:
-                        wgrad = (ops.conv3x3_wgrad_bf16 if st['wino_w'] == BF16 else
-                                 ops.conv3x3_wgrad_wino4 if st['wino_w'] == 4 else
-                                 ops.conv3x3_wgrad_wino if st['wino_w'] else ops.conv3x3_wgrad)
+                    wgrad = (ops.conv3x3_wgrad_bf16 if st['wino_w'] == BF16 else
+                             ops.conv3x3_wgrad_wino4 if st['wino_w'] == 4 else
+                             ops.conv3x3_wgrad_wino if st['wino_w'] else ops.conv3x3_wgrad)
                     if side is not None:
                         ops.order(st['ev'], main, side)
                         with ops.use_stream(side):

@@ -446,15 +446,13 @@ def main():
     xin, xout, tgt = chaos_batch(batch, size, seed=1234 + rank, single_modal=(not model_name.startswith('fuseunet')))
     xin, tgt = xin.to(device), tgt.to(device)
     xout = xout.to(device) if xout is not None else None
-    no_optim = 'AIDE_PROBE_NO_OPTIM' in probes           # (timing probe: the step without its optimizer -- INVALID line)
 
     def step():
         opt.zero_grad()
         out = net(xin, xout) if xout is not None else net(xin)
         loss = crit(out, tgt)
         loss.backward()
-        if not no_optim:
-            opt.step()
+        opt.step()
         return loss
 
     # every launch of every MFMA conv kernel in the timed steps carries a start / stop event pair holding the dispatch's
