@@ -505,6 +505,44 @@ def g15_config5(ref_f, ref_utils):
           float(fx['bf16_vs_fp32_logits']))
 
 
+def g16_config5_autocast(ref_f, ref_utils):
+    """A second, reference-held anchor for the bf16 mode (BASELINE config 5 at its own size): the REAL reference's modules run
+    under PyTorch's own CPU bf16 autocast (convolutions on bf16 operands with fp32 accumulation, bf16-stored activations) --
+    not this repo's oracle -- next to the same network in fp32: logit rows, loss, per-parameter gradient norms of both.  The
+    GPU test requires the HIP bf16 path to be no further from the reference's fp32 results than the reference under autocast is."""
+    from aide_amd.synthetic import chaos_batch
+    fx = {}
+    xin, xout, t = chaos_batch(8, 512, seed=1234)
+    w = torch.tensor([1.0, 1.0])
+    crit = ref_utils.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
+    for tag, ctx in (('fp32', None), ('autocast', torch.autocast('cpu', dtype=torch.bfloat16))):
+        torch.manual_seed(2)
+        net = ref_f.fuseunet(2)
+        net.train()
+        if ctx is None:
+            out = net(xin, xout)
+        else:
+            with ctx:
+                out = net(xin, xout)
+        out32 = out.float()
+        loss = crit(out32, t)                      # the loss in fp32 on the network's logits (as the HIP path computes it)
+        loss.backward()
+        fx[tag + '_logits_rows'] = _np(out32[:, :, ::73, :])
+        fx[tag + '_loss'] = _np(loss.detach())
+        fx[tag + '_grad_norms'] = _np(torch.stack([p.grad.double().norm() for p in net.parameters()]))
+        fx['param_names'] = np.array([k for k, _ in net.named_parameters()])
+        print('g16', tag, 'loss', float(loss))
+    a, b = torch.from_numpy(fx['autocast_logits_rows']), torch.from_numpy(fx['fp32_logits_rows'])
+    fx['autocast_vs_fp32_logits'] = np.array(((a - b).abs().max() / b.abs().max()).item())
+    live = fx['fp32_grad_norms'] > 1e-5
+    e = np.abs(fx['autocast_grad_norms'][live] - fx['fp32_grad_norms'][live]) / fx['fp32_grad_norms'][live]
+    fx['seed'] = np.array(1234)
+    np.savez_compressed(os.path.join(OUT, 'g16_config5_autocast.npz'), **fx)
+    print('g16 autocast vs fp32: logits %.3e, loss %.3e, gradient norms median %.3e worst %.3e' % (
+        float(fx['autocast_vs_fp32_logits']), abs(float(fx['autocast_loss']) - float(fx['fp32_loss'])) / float(fx['fp32_loss']),
+        np.median(e), e.max()))
+
+
 def g6_inference(ref_f, ref_u, ref_utils):
     """Per-case inference (trainchaos_comparison_1case.py:233-273): two training steps move the BN running
     statistics, then eval-mode bs=1 slices -> softmax -> argmax -> [H,W,S] volume and Dice3d_fn."""
@@ -743,11 +781,11 @@ def main():
     if sys.argv[1:] == ['g12']:          # binary metrics and the two remaining loss classes
         ref_f, ref_u, ref_utils = _import_reference()
         return g12_metrics(ref_utils)
-    if sys.argv[1:] and sys.argv[1] in ('g2', 'g13', 'g14', 'g15'):      # full-size digests of BASELINE configs 2, 4, 3, 5
+    if sys.argv[1:] and sys.argv[1] in ('g2', 'g13', 'g14', 'g15', 'g16'):      # full-size digests of BASELINE configs 2, 4, 3, 5
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()
         return {'g2': lambda: g2_config(ref_f, ref_utils), 'g13': lambda: g13_config4(ref_u, ref_utils),
-                'g14': lambda: g14_config3(ref_f, ref_utils), 'g15': lambda: g15_config5(ref_f, ref_utils)}[sys.argv[1]]()
+                'g14': lambda: g14_config3(ref_f, ref_utils), 'g15': lambda: g15_config5(ref_f, ref_utils), 'g16': lambda: g16_config5_autocast(ref_f, ref_utils)}[sys.argv[1]]()
     if sys.argv[1:] == ['g6']:
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()
@@ -768,6 +806,7 @@ def main():
     g13_config4(ref_u, ref_utils)
     g14_config3(ref_f, ref_utils)
     g15_config5(ref_f, ref_utils)
+    g16_config5_autocast(ref_f, ref_utils)
     g6_inference(ref_f, ref_u, ref_utils)
     g7_coteach_ext(ref_utils)
     g8_pixelcoreg(ref_utils)

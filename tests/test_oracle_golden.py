@@ -297,3 +297,15 @@ def test_g12_metrics_and_remaining_losses():
         (v.sum() if v.dim() else v).backward()
         close(v.detach(), fx[key], what=key)
         close(zz.grad, fx[key + '/grad'], what=key + ' grad')
+
+
+def test_g16_autocast_anchor_is_consistent():
+    """g16 (the real reference under torch.autocast(cpu, bf16) at BASELINE config 5's size, oracle/gen_golden.py g16) shares
+    its fp32 run with g15 and its bf16 perturbation is of the size the bf16-operand oracle predicts."""
+    a = np.load(os.path.join(GOLD, 'g16_config5_autocast.npz'))
+    b = np.load(os.path.join(GOLD, 'g15_config5.npz'))
+    assert np.array_equal(a['fp32_logits_rows'], b['ref_fp32_logits_rows'])
+    assert abs(float(a['fp32_loss']) - float(b['ref_fp32_loss'])) == 0.0
+    assert list(a['param_names']) == list(b['param_names'])
+    assert 0.5 * float(b['bf16_vs_fp32_logits']) < float(a['autocast_vs_fp32_logits']) < 2.0 * float(b['bf16_vs_fp32_logits'])
+    assert abs(float(a['autocast_loss']) - float(a['fp32_loss'])) < 1e-3 * float(a['fp32_loss'])
