@@ -593,8 +593,12 @@ __global__ __launch_bounds__(128) void wino4_pack_multi_kernel(const W4PackDesc*
 extern "C" {
 
 int aide_conv3x3_wino4_supported(int Cin, int H, int W, int Cout) {
-    // W == 16: two images per workgroup tile (the caller's N must be even: checked at launch and in aide_conv3x3_wino4_splitk)
-    return (H % 4 == 0 && W % 4 == 0 && H >= 16 && (W >= 32 || W == 16) && Cout % 32 == 0 && Cin % 8 == 0) ? 1 : 0;
+    // W == 16: two images per workgroup tile (the caller's N must be even: checked at launch and in aide_conv3x3_wino4_splitk).
+    // 16 < W < 32 (the 20 x 20 bottleneck of the 320 x 320 workload): one tile column, its right part masked -- the same
+    // 39 % tile use as F(2x2)'s 16 x 16 tiles there, at 2.25x fewer multiplies.
+    static const bool narrow = !(getenv("AIDE_W4_NARROW") && atoi(getenv("AIDE_W4_NARROW")) == 0);   // A-B switch
+    return (H % 4 == 0 && W % 4 == 0 && H >= 16 && (W >= 32 || W == 16 || (narrow && W > 16)) && Cout % 32 == 0 &&
+            Cin % 8 == 0) ? 1 : 0;
 }
 
 int aide_conv3x3_wino4_splitk(int N, int Cin, int H, int W, int Cout) {
