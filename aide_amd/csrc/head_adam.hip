@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr int MAXK = 4;      // num_classes supported by the head kernels (reference uses 2)
+constexpr int MAXK = 8;      // num_classes supported by the head kernels (the reference's scripts use 2) = aide_seg_max_classes()
 constexpr int HEAD_WG_BLOCKS = 1024;   // workgroups (= fp64 partial rows) of the head weight gradient: four per CU
 
 template <int K, typename XT>
@@ -69,7 +69,7 @@ template <int K, typename XT>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dy, long dy_bs,
                                                          const XT* __restrict__ x, long x_bs, int C, int HW,
                                                          long total4, double* __restrict__ partials) {
-    constexpr int G = 8;
+    constexpr int G = K > 4 ? 4 : 8;          // (G x K fp64 accumulators per thread)
     __shared__ double sm[4][G * K];
     const int hw4 = HW / 4;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -195,7 +195,8 @@ int head_fwd_t(const XT* x, int64_t x_bs, const float* w, const float* b, float*
     const int grid = grid_for(total4);
     const size_t sh = (size_t)K * C * sizeof(float);
 #define AIDE_HEAD_FWD(KK) hipLaunchKernelGGL((head_fwd_kernel<KK, XT>), dim3(grid), dim3(256), sh, stream, x, (long)x_bs, w, b, y, (long)y_bs, C, HW, total4)
-    switch (K) { case 1: AIDE_HEAD_FWD(1); break; case 2: AIDE_HEAD_FWD(2); break; case 3: AIDE_HEAD_FWD(3); break; default: AIDE_HEAD_FWD(4); }
+    switch (K) { case 1: AIDE_HEAD_FWD(1); break; case 2: AIDE_HEAD_FWD(2); break; case 3: AIDE_HEAD_FWD(3); break; case 4: AIDE_HEAD_FWD(4); break;
+                 case 5: AIDE_HEAD_FWD(5); break; case 6: AIDE_HEAD_FWD(6); break; case 7: AIDE_HEAD_FWD(7); break; default: AIDE_HEAD_FWD(8); }
 #undef AIDE_HEAD_FWD
     return aide_launch_status();
 }
@@ -210,7 +211,8 @@ int head_bwd_t(const float* dy, int64_t dy_bs, const XT* x, int64_t x_bs, const 
     if (dx) {
         const int grid = grid_for(total4);
 #define AIDE_HEAD_DG(KK) hipLaunchKernelGGL((head_dgrad_kernel<KK, DT>), dim3(grid), dim3(256), sh, stream, dy, (long)dy_bs, w, dx, (long)dx_bs, C, HW, total4)
-        switch (K) { case 1: AIDE_HEAD_DG(1); break; case 2: AIDE_HEAD_DG(2); break; case 3: AIDE_HEAD_DG(3); break; default: AIDE_HEAD_DG(4); }
+        switch (K) { case 1: AIDE_HEAD_DG(1); break; case 2: AIDE_HEAD_DG(2); break; case 3: AIDE_HEAD_DG(3); break; case 4: AIDE_HEAD_DG(4); break;
+                     case 5: AIDE_HEAD_DG(5); break; case 6: AIDE_HEAD_DG(6); break; case 7: AIDE_HEAD_DG(7); break; default: AIDE_HEAD_DG(8); }
 #undef AIDE_HEAD_DG
     }
     if (!dw) return aide_launch_status();      // data gradient only (the weight gradient is issued on another stream)
@@ -220,7 +222,11 @@ int head_bwd_t(const float* dy, int64_t dy_bs, const XT* x, int64_t x_bs, const 
         case 1: rc = head_wgrad_launch<1>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
         case 2: rc = head_wgrad_launch<2>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
         case 3: rc = head_wgrad_launch<3>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
-        default: rc = head_wgrad_launch<4>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream);
+        case 4: rc = head_wgrad_launch<4>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
+        case 5: rc = head_wgrad_launch<5>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
+        case 6: rc = head_wgrad_launch<6>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
+        case 7: rc = head_wgrad_launch<7>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
+        default: rc = head_wgrad_launch<8>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream);
     }
     if (rc) return rc;
     hipLaunchKernelGGL(head_wgrad_finalize_kernel, dim3(K * C + K), dim3(64), 0, stream,

@@ -169,6 +169,7 @@ __global__ void seg_finalize_kernel(const SegFinalizeArgs a) {
 struct CoteachFinalizeArgs {
     const double* partials1; const double* partials2;
     int N, bpi, HW, variant, keep;      // variant: 0 proposed inline (:303-321), 1 dropimage, 2 weightimage
+    int nclass;                         // channels of the consistency map (its `.mean()` runs over D x C x HW elements)
     float w_ce, w_dice, smooth, rate, w_seg, w_cor;
     double* stats1; double* stats2;
     float* loss;                        // [2]
@@ -218,14 +219,14 @@ __global__ void coteach_finalize_kernel(const CoteachFinalizeArgs a) {
         else { wk = 1.0; wd = (D > 0) ? 0.1 : 0.0; wm = 0.0; }
         double loss = wk * (keep_sum / R);
         if (wd != 0.0 || a.variant == 0) loss += wd * (drop_sum / D);
-        if (wm != 0.0 || a.variant == 0) loss += wm * (mse_sum / ((double)D * 2.0 * a.HW));
+        if (wm != 0.0 || a.variant == 0) loss += wm * (mse_sum / ((double)D * (double)a.nclass * a.HW));
         a.loss[me] = (float)loss;
         for (int r = 0; r < N; ++r) {
             const int i = (int)sel[r];
             const double wi = (r < R) ? wk / R : wd / D;          // d loss / d L_i
             coef[i] = (float)(wi * a.w_ce / a.HW);
             coef[N + i] = (float)(wi * a.w_dice);
-            coef[2 * N + i] = (r < R) ? 0.f : (float)(wm / ((double)D * 2.0 * a.HW));
+            coef[2 * N + i] = (r < R) ? 0.f : (float)(wm / ((double)D * (double)a.nclass * a.HW));
         }
         if (a.hard_dice) a.hard_dice[me] = (float)hard_dice_sum(stats, N);
     }
@@ -397,19 +398,31 @@ int aide_seg_loss_finalize(const double* partials, int N, int HW, int reduction,
     return aide_launch_status();
 }
 
-int aide_coteach_finalize(const double* partials1, const double* partials2, int N, int HW, int variant,
-                          int keep, float w_ce, float w_dice, float smooth, float rate, float w_seg,
-                          float w_cor, double* stats1, double* stats2, float* loss, float* per_image1,
-                          float* per_image2, long long* idx1, long long* idx2, float* coef1, float* coef2,
-                          float* hard_dice, hipStream_t stream) {
+// C = classes of the logits the statistics came from (aide_seg_stats: 2, aide_seg_stats_mc: 3 .. 8)
+int aide_coteach_finalize_mc(const double* partials1, const double* partials2, int N, int HW, int C, int variant,
+                             int keep, float w_ce, float w_dice, float smooth, float rate, float w_seg,
+                             float w_cor, double* stats1, double* stats2, float* loss, float* per_image1,
+                             float* per_image2, long long* idx1, long long* idx2, float* coef1, float* coef2,
+                             float* hard_dice, hipStream_t stream) {
+    if (C < 2) return AIDE_ERR_ARG;
     CoteachFinalizeArgs a;
-    a.partials1 = partials1; a.partials2 = partials2; a.N = N; a.bpi = bpi_for(HW); a.HW = HW;
+    a.partials1 = partials1; a.partials2 = partials2; a.N = N; a.bpi = bpi_for(HW); a.HW = HW; a.nclass = C;
     a.variant = variant; a.keep = keep; a.w_ce = w_ce; a.w_dice = w_dice; a.smooth = smooth; a.rate = rate;
     a.w_seg = w_seg; a.w_cor = w_cor; a.stats1 = stats1; a.stats2 = stats2; a.loss = loss;
     a.per_image1 = per_image1; a.per_image2 = per_image2; a.idx1 = idx1; a.idx2 = idx2;
     a.coef1 = coef1; a.coef2 = coef2; a.hard_dice = hard_dice;
     hipLaunchKernelGGL(coteach_finalize_kernel, dim3(1), dim3(256), 2 * N * sizeof(float), stream, a);
     return aide_launch_status();
+}
+
+int aide_coteach_finalize(const double* partials1, const double* partials2, int N, int HW, int variant,
+                          int keep, float w_ce, float w_dice, float smooth, float rate, float w_seg,
+                          float w_cor, double* stats1, double* stats2, float* loss, float* per_image1,
+                          float* per_image2, long long* idx1, long long* idx2, float* coef1, float* coef2,
+                          float* hard_dice, hipStream_t stream) {
+    return aide_coteach_finalize_mc(partials1, partials2, N, HW, 2, variant, keep, w_ce, w_dice, smooth, rate, w_seg,
+                                    w_cor, stats1, stats2, loss, per_image1, per_image2, idx1, idx2, coef1, coef2,
+                                    hard_dice, stream);
 }
 
 int aide_seg_loss_bwd(const float* logits, int64_t l_bs, const long long* targets, int64_t t_bs, float w0,

@@ -1079,6 +1079,8 @@ class Engine(object):
     MAX_PLANS = 6
 
     def __init__(self, module, build_graph, num_classes):
+        if not 1 <= int(num_classes) <= 8:       # the head kernels' template range (csrc/head_adam.hip MAXK)
+            raise NotImplementedError('aide_amd: num_classes must be 1 .. 8, got %r' % (num_classes,))
         self.module, self.build_graph, self.num_classes = module, build_graph, num_classes
         self.plans = {}
         self.params = None

@@ -18,15 +18,18 @@ from .ops import ptr, stream_ptr
 
 
 def label_map(logits):
-    """[N,2,H,W] fp32 logits -> [N,H,W] int64 labels = torch.argmax(F.softmax(logits, 1), 1)."""
-    if logits.dim() != 4 or logits.shape[1] != 2 or logits.dtype != torch.float32 or not logits.is_cuda:
-        raise RuntimeError('label_map expects a [N,2,H,W] fp32 HIP tensor')
+    """[N,C,H,W] fp32 logits (C = 2 .. 8) -> [N,H,W] int64 labels = torch.argmax(F.softmax(logits, 1), 1)."""
+    if logits.dim() != 4 or not 2 <= logits.shape[1] <= 8 or logits.dtype != torch.float32 or not logits.is_cuda:
+        raise RuntimeError('label_map expects a [N,C,H,W] fp32 HIP tensor with 2 <= C <= 8')
     logits = logits.detach()
     if not logits.is_contiguous():
         logits = logits.contiguous()
-    n, _, h, w = logits.shape
+    n, c, h, w = logits.shape
     out = torch.empty(n, h, w, device=logits.device, dtype=torch.int64)
-    check(lib.aide_label_map(ptr(logits), 2 * h * w, n, h * w, ptr(out), stream_ptr()), 'label_map')
+    if c == 2:
+        check(lib.aide_label_map(ptr(logits), 2 * h * w, n, h * w, ptr(out), stream_ptr()), 'label_map')
+    else:
+        check(lib.aide_label_map_mc(ptr(logits), c * h * w, c, n, h * w, ptr(out), stream_ptr()), 'label_map_mc')
     return out
 
 

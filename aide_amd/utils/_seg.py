@@ -9,19 +9,31 @@ from ..ops import stream_ptr, ptr
 
 NS = 8
 S_CE, S_W, S_I, S_P, S_T, S_M, S_HP, S_HI = range(8)
+MAXC = 8                # aide_seg_max_classes()
 
 
 def _logits(x):
     if not isinstance(x, torch.Tensor) or not x.is_cuda:
         raise RuntimeError('aide_amd losses run on a HIP device only (got %s); there is no CPU fallback'
                            % (x.device if isinstance(x, torch.Tensor) else type(x)))
-    if x.dim() != 4 or x.shape[1] != 2:
-        raise NotImplementedError('aide_amd fused losses implement the reference configuration '
-                                  'num_classes == 2 (train_files/trainchaos_comparison_1case.py:121); got %s'
-                                  % (tuple(x.shape),))
+    if x.dim() != 4 or not 2 <= x.shape[1] <= MAXC:
+        raise NotImplementedError('aide_amd fused losses take logits [N, C, H, W] with 2 <= C <= %d (two classes: the '
+                                  'reference configuration, train_files/trainchaos_comparison_1case.py:121, on the '
+                                  'specialised kernels of csrc/loss.hip; 3 .. %d on csrc/loss_mc.hip); got %s'
+                                  % (MAXC, MAXC, tuple(x.shape)))
     if x.dtype != torch.float32:
         raise RuntimeError('aide_amd: logits must be fp32')
     return x if x.is_contiguous() else x.contiguous()
+
+
+def _logits2(x, what):
+    """Logits for the operators whose kernels exist for two classes only (csrc/coteach_ext.hip: the SURVEY §8f rank-4
+    co-teaching / regularisation variants no shipped script instantiates)."""
+    x = _logits(x)
+    if x.shape[1] != 2:
+        raise NotImplementedError('aide_amd: %s is implemented for num_classes == 2 (got logits %s)'
+                                  % (what, tuple(x.shape)))
+    return x
 
 
 def _targets(t, logits):
@@ -47,22 +59,46 @@ def _targets(t, logits):
 
 
 def class_weights(weight):
+    """The class-weight argument of a loss module as the pair (w0, w1) the two-class entry points take; more than two
+    weights travel as (tuple of C floats, None).  None = unweighted, for any class count."""
     if weight is None:
         return 1.0, 1.0
     w = [float(v) for v in weight]
-    if len(w) != 2:
-        raise NotImplementedError('aide_amd fused losses support 2 classes')
-    return w[0], w[1]
+    if len(w) == 2:
+        return w[0], w[1]
+    if not 3 <= len(w) <= MAXC:
+        raise NotImplementedError('aide_amd fused losses support 2 .. %d classes (got %d class weights)' % (MAXC, len(w)))
+    return tuple(w), None
+
+
+def class_w_array(w0, w1, c):
+    """HOST float array of the C class weights for the *_mc entry points (csrc/loss_mc.hip)."""
+    if w1 is None:
+        vals = list(w0)
+    elif (w0, w1) == (1.0, 1.0):
+        vals = [1.0] * c
+    else:
+        vals = [w0, w1]
+    if len(vals) != c:           # nn.CrossEntropyLoss raises for a weight vector that does not match the class count
+        raise RuntimeError('aide_amd: %d class weights for logits with %d classes' % (len(vals), c))
+    return (ctypes.c_float * c)(*vals)
 
 
 def stats_pass(logits, targets, t_bs, w0, w1, ignore_index, pseudo=None, wmap=None):
-    n, _, h, w = logits.shape
+    n, c, h, w = logits.shape
     hw = h * w
     partials = torch.empty(lib.aide_seg_loss_ws_bytes(n, hw) // 8, device=logits.device, dtype=torch.float64)
-    p_bs = 2 * hw if pseudo is not None else 0
+    p_bs = c * hw if pseudo is not None else 0
     w_bs = hw if wmap is not None else 0
-    check(lib.aide_seg_stats(ptr(logits), 2 * hw, ptr(targets), t_bs, w0, w1, ignore_index, ptr(pseudo), p_bs,
-                             ptr(wmap), w_bs, n, hw, ptr(partials), stream_ptr()), 'seg_stats')
+    if c == 2:
+        if w1 is None:
+            raise RuntimeError('aide_amd: %d class weights for logits with 2 classes' % len(w0))
+        check(lib.aide_seg_stats(ptr(logits), 2 * hw, ptr(targets), t_bs, w0, w1, ignore_index, ptr(pseudo), p_bs,
+                                 ptr(wmap), w_bs, n, hw, ptr(partials), stream_ptr()), 'seg_stats')
+    else:
+        check(lib.aide_seg_stats_mc(ptr(logits), c * hw, ptr(targets), t_bs, class_w_array(w0, w1, c), c, ignore_index,
+                                    ptr(pseudo), p_bs, ptr(wmap), w_bs, n, hw, ptr(partials), stream_ptr()),
+              'seg_stats_mc')
     return partials
 
 
@@ -89,7 +125,7 @@ class SegBackward(torch.autograd.Function):
     def backward(ctx, g):
         (logits,) = ctx.saved_tensors
         pk = ctx.pack
-        n, _, h, w = logits.shape
+        n, c, h, w = logits.shape
         hw = h * w
         g = g.contiguous()
         if g.dtype != torch.float32:
@@ -97,11 +133,19 @@ class SegBackward(torch.autograd.Function):
         g_stride = 0 if g.numel() == 1 else 1
         dl = torch.empty_like(logits)
         pseudo, wmap = pk.get('pseudo'), pk.get('wmap')
-        check(lib.aide_seg_loss_bwd(ptr(logits), 2 * hw, ptr(pk['targets']), pk['t_bs'], pk['w0'], pk['w1'],
-                                    pk['ignore'], ptr(pseudo), 2 * hw if pseudo is not None else 0, ptr(wmap),
-                                    hw if wmap is not None else 0, n, hw, ptr(pk['stats']), ptr(pk['coef']),
-                                    pk['smooth'], ptr(g), g_stride, ptr(dl), 2 * hw, stream_ptr()),
-              'seg_loss_bwd')
+        if c == 2:
+            check(lib.aide_seg_loss_bwd(ptr(logits), 2 * hw, ptr(pk['targets']), pk['t_bs'], pk['w0'], pk['w1'],
+                                        pk['ignore'], ptr(pseudo), 2 * hw if pseudo is not None else 0, ptr(wmap),
+                                        hw if wmap is not None else 0, n, hw, ptr(pk['stats']), ptr(pk['coef']),
+                                        pk['smooth'], ptr(g), g_stride, ptr(dl), 2 * hw, stream_ptr()),
+                  'seg_loss_bwd')
+        else:
+            check(lib.aide_seg_loss_bwd_mc(ptr(logits), c * hw, ptr(pk['targets']), pk['t_bs'],
+                                           class_w_array(pk['w0'], pk['w1'], c), c, pk['ignore'], ptr(pseudo),
+                                           c * hw if pseudo is not None else 0, ptr(wmap),
+                                           hw if wmap is not None else 0, n, hw, ptr(pk['stats']), ptr(pk['coef']),
+                                           pk['smooth'], ptr(g), g_stride, ptr(dl), c * hw, stream_ptr()),
+                  'seg_loss_bwd_mc')
         return dl, None, None
 
 
@@ -140,12 +184,15 @@ def coteach_loss(logits1, logits2, targets1, targets2, variant, keep, w_ce, w_di
     logits1, logits2 = _logits(logits1), _logits(logits2)
     targets1, t1_bs = _targets(targets1, logits1)
     targets2, t2_bs = _targets(targets2, logits2)
-    n, _, h, w = logits1.shape
+    n, c, h, w = logits1.shape
+    if logits2.shape != logits1.shape:
+        raise RuntimeError('aide_amd: the two networks\' logits differ in shape: %s vs %s'
+                           % (tuple(logits1.shape), tuple(logits2.shape)))
     hw = h * w
     dev = logits1.device
     w0, w1 = class_w
-    pseudo1 = _dense(pseudo1, (n, 2, h, w), 'pseudo label')
-    pseudo2 = _dense(pseudo2, (n, 2, h, w), 'pseudo label')
+    pseudo1 = _dense(pseudo1, (n, c, h, w), 'pseudo label')
+    pseudo2 = _dense(pseudo2, (n, c, h, w), 'pseudo label')
     wmap1 = _dense(wmap1, (n, 1, h, w), 'weight map')
     wmap2 = _dense(wmap2, (n, 1, h, w), 'weight map')
     with torch.no_grad():
@@ -160,10 +207,16 @@ def coteach_loss(logits1, logits2, targets1, targets2, variant, keep, w_ce, w_di
         i2 = torch.empty(n, device=dev, dtype=torch.int64)
         c1, c2 = torch.empty(3 * n, **f32), torch.empty(3 * n, **f32)
         hard = torch.empty(2, **f32)
-        check(lib.aide_coteach_finalize(ptr(pa1), ptr(pa2), n, hw, variant, keep, w_ce, w_dice, smooth, rate,
-                                        w_seg, w_cor, ptr(st1), ptr(st2), ptr(loss), ptr(pi1), ptr(pi2),
-                                        ptr(i1), ptr(i2), ptr(c1), ptr(c2), ptr(hard), stream_ptr()),
-              'coteach_finalize')
+        if c == 2:
+            check(lib.aide_coteach_finalize(ptr(pa1), ptr(pa2), n, hw, variant, keep, w_ce, w_dice, smooth, rate,
+                                            w_seg, w_cor, ptr(st1), ptr(st2), ptr(loss), ptr(pi1), ptr(pi2),
+                                            ptr(i1), ptr(i2), ptr(c1), ptr(c2), ptr(hard), stream_ptr()),
+                  'coteach_finalize')
+        else:
+            check(lib.aide_coteach_finalize_mc(ptr(pa1), ptr(pa2), n, hw, c, variant, keep, w_ce, w_dice, smooth, rate,
+                                               w_seg, w_cor, ptr(st1), ptr(st2), ptr(loss), ptr(pi1), ptr(pi2),
+                                               ptr(i1), ptr(i2), ptr(c1), ptr(c2), ptr(hard), stream_ptr()),
+                  'coteach_finalize_mc')
     pk1 = dict(targets=targets1, t_bs=t1_bs, w0=w0, w1=w1, ignore=ignore_index, stats=st1, coef=c1,
                smooth=smooth, pseudo=pseudo1, wmap=wmap1)
     pk2 = dict(targets=targets2, t_bs=t2_bs, w0=w0, w1=w1, ignore=ignore_index, stats=st2, coef=c2,

@@ -70,7 +70,7 @@ class _KLFn(torch.autograd.Function):
 
 def KLbidirection(inputs1, inputs2):
     """utils/coteach_loss.py:85-92: per-pixel KL(p1||p2) + KL(p2||p1) of the two softmax maps -> [N,H,W]."""
-    return _KLFn.apply(_seg._logits(inputs1), _seg._logits(inputs2))
+    return _KLFn.apply(_seg._logits2(inputs1, 'KLbidirection'), _seg._logits2(inputs2, 'KLbidirection'))
 
 
 def _select(sel_vals, sum_vals, nseg, m, k_host=-1, rr=-1.0, k_in=None, only_positive=False):
@@ -120,7 +120,7 @@ class Coteachingloss_dropregionce(nn.Module):
         self.scale = scale
 
     def forward(self, inputs1, inputs2, targets, forget_rate):
-        z1, z2 = _seg._logits(inputs1), _seg._logits(inputs2)
+        z1, z2 = _seg._logits2(inputs1, 'Coteachingloss_dropregionce'), _seg._logits2(inputs2, 'Coteachingloss_dropregionce')
         tg, t_bs = _seg._targets(targets, z1)
         n, _, h, w = z1.shape
         if h % 2 or w % 2:
@@ -179,7 +179,7 @@ class Coteachingloss_dropimagedroppixel(_CoteachBase):
         keep = _keep_count(forget_rate, n)
         if keep >= n:                                       # nothing dropped: both extra terms are 0.0
             return l1, l2
-        z1, z2 = _seg._logits(inputs1), _seg._logits(inputs2)
+        z1, z2 = _seg._logits2(inputs1, 'Coteachingloss_dropimagedroppixel'), _seg._logits2(inputs2, 'Coteachingloss_dropimagedroppixel')
         tg, t_bs = _seg._targets(targets, z1)
         rr = 1 - forget_rate
         d1 = self.last['argsort1'][keep:].contiguous()      # images dropped by net 1's ranking
@@ -191,14 +191,20 @@ class Coteachingloss_dropimagedroppixel(_CoteachBase):
 
 def pseudo_label_ensemble(aug_logits, temperature=1.0):
     """mean softmax over the (reverse-augmented) passes -> sharpen -> weightmap
-    (trainchaos_proposed_30cases1labeled.py:274-292). Returns (pseudo_label [N,2,H,W], weightmap [N,1,H,W])."""
+    (trainchaos_proposed_30cases1labeled.py:274-292). Returns (pseudo_label [N,C,H,W], weightmap [N,1,H,W])."""
     lgs = [_seg._logits(t.detach()) for t in aug_logits]
-    n, _, h, w = lgs[0].shape
-    pl = torch.empty(n, 2, h, w, device=lgs[0].device, dtype=torch.float32)
+    n, c, h, w = lgs[0].shape
+    if any(t.shape != lgs[0].shape for t in lgs):
+        raise RuntimeError('aide_amd: the passes of a pseudo-label ensemble differ in shape')
+    pl = torch.empty(n, c, h, w, device=lgs[0].device, dtype=torch.float32)
     wm = torch.empty(n, 1, h, w, device=lgs[0].device, dtype=torch.float32)
     arr = (ctypes.c_void_p * len(lgs))(*[t.data_ptr() for t in lgs])
-    check(lib.aide_pseudo_label(arr, len(lgs), 2 * h * w, n, h * w, float(temperature), ptr(pl), ptr(wm),
-                                stream_ptr()), 'pseudo_label')
+    if c == 2:
+        check(lib.aide_pseudo_label(arr, len(lgs), 2 * h * w, n, h * w, float(temperature), ptr(pl), ptr(wm),
+                                    stream_ptr()), 'pseudo_label')
+    else:
+        check(lib.aide_pseudo_label_mc(arr, len(lgs), c, c * h * w, n, h * w, float(temperature), ptr(pl), ptr(wm),
+                                       stream_ptr()), 'pseudo_label_mc')
     return pl, wm
 
 

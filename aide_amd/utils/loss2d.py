@@ -1,7 +1,8 @@
 """Drop-in loss modules with the reference's names, constructor and forward signatures
 (utils/loss2d.py:5-154), computed by the fused HIP loss kernels (csrc/loss.hip).
 
-Scope: the reference's hot-path configuration — 2 classes, int64 index targets [N,H,W].
+Scope: int64 index targets [N,H,W]; two classes (the reference's hot-path configuration) on the specialised kernels of
+csrc/loss.hip, 3 .. 8 classes on the general form in csrc/loss_mc.hip (same statistics, same finalize kernels).
 `cediceweight` / `ceclassweight` may be CPU tensors exactly as the reference scripts pass them
 (trainchaos_comparison_1case.py:157-166); they are read as host scalars at construction."""
 import torch
@@ -19,10 +20,14 @@ class _CEMap(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, targets, t_bs, w0, w1, ignore):
-        n, _, h, w = logits.shape
+        n, c, h, w = logits.shape
         out = torch.empty(n, h, w, device=logits.device, dtype=torch.float32)
-        check(lib.aide_ce_map(ptr(logits), 2 * h * w, ptr(targets), t_bs, w0, w1, ignore, n, h * w, ptr(out),
-                              None, None, 0, stream_ptr()), 'ce_map')
+        if c == 2:
+            check(lib.aide_ce_map(ptr(logits), 2 * h * w, ptr(targets), t_bs, w0, w1, ignore, n, h * w, ptr(out),
+                                  None, None, 0, stream_ptr()), 'ce_map')
+        else:
+            check(lib.aide_ce_map_mc(ptr(logits), c * h * w, ptr(targets), t_bs, _seg.class_w_array(w0, w1, c), c, ignore,
+                                     n, h * w, ptr(out), None, None, 0, stream_ptr()), 'ce_map_mc')
         ctx.save_for_backward(logits, targets)
         ctx.cfg = (t_bs, w0, w1, ignore)
         return out
@@ -31,10 +36,14 @@ class _CEMap(torch.autograd.Function):
     def backward(ctx, g):
         logits, targets = ctx.saved_tensors
         t_bs, w0, w1, ignore = ctx.cfg
-        n, _, h, w = logits.shape
+        n, c, h, w = logits.shape
         dl = torch.empty_like(logits)
-        check(lib.aide_ce_map(ptr(logits), 2 * h * w, ptr(targets), t_bs, w0, w1, ignore, n, h * w, None,
-                              ptr(g.contiguous()), ptr(dl), 2 * h * w, stream_ptr()), 'ce_map_bwd')
+        if c == 2:
+            check(lib.aide_ce_map(ptr(logits), 2 * h * w, ptr(targets), t_bs, w0, w1, ignore, n, h * w, None,
+                                  ptr(g.contiguous()), ptr(dl), 2 * h * w, stream_ptr()), 'ce_map_bwd')
+        else:
+            check(lib.aide_ce_map_mc(ptr(logits), c * h * w, ptr(targets), t_bs, _seg.class_w_array(w0, w1, c), c, ignore,
+                                     n, h * w, None, ptr(g.contiguous()), ptr(dl), c * h * w, stream_ptr()), 'ce_map_mc_bwd')
         return dl, None, None, None, None, None
 
 
@@ -43,20 +52,28 @@ class _MSEMap(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, target):
-        n, _, h, w = logits.shape
+        n, c, h, w = logits.shape
         out = torch.empty_like(logits)
-        check(lib.aide_mse_map(ptr(logits), 2 * h * w, ptr(target), 2 * h * w, n, h * w, ptr(out), None, None,
-                               0, stream_ptr()), 'mse_map')
+        if c == 2:
+            check(lib.aide_mse_map(ptr(logits), 2 * h * w, ptr(target), 2 * h * w, n, h * w, ptr(out), None, None,
+                                   0, stream_ptr()), 'mse_map')
+        else:
+            check(lib.aide_mse_map_mc(ptr(logits), c * h * w, ptr(target), c * h * w, c, n, h * w, ptr(out), None, None,
+                                      0, stream_ptr()), 'mse_map_mc')
         ctx.save_for_backward(logits, target)
         return out
 
     @staticmethod
     def backward(ctx, g):
         logits, target = ctx.saved_tensors
-        n, _, h, w = logits.shape
+        n, c, h, w = logits.shape
         dl = torch.empty_like(logits)
-        check(lib.aide_mse_map(ptr(logits), 2 * h * w, ptr(target), 2 * h * w, n, h * w, None,
-                               ptr(g.contiguous()), ptr(dl), 2 * h * w, stream_ptr()), 'mse_map_bwd')
+        if c == 2:
+            check(lib.aide_mse_map(ptr(logits), 2 * h * w, ptr(target), 2 * h * w, n, h * w, None,
+                                   ptr(g.contiguous()), ptr(dl), 2 * h * w, stream_ptr()), 'mse_map_bwd')
+        else:
+            check(lib.aide_mse_map_mc(ptr(logits), c * h * w, ptr(target), c * h * w, c, n, h * w, None,
+                                      ptr(g.contiguous()), ptr(dl), c * h * w, stream_ptr()), 'mse_map_mc_bwd')
         return dl, None
 
 
@@ -86,6 +103,34 @@ class _DiceTerms(torch.autograd.Function):
         check(lib.aide_dice_terms_bwd(ptr(x), k * hw, ptr(t), k * hw, x.shape[0], hw, k, w0, w1, smooth, red, ptr(ws),
                                       ptr(g), ptr(dx), k * hw, stream_ptr()), 'dice_terms_bwd')
         return dx, None, None, None, None, None, None
+
+
+class _DiceTermsMC(torch.autograd.Function):
+    """MulticlassDiceLoss with one-hot targets [N,C,H,W], C = 3 .. 8 (utils/loss2d.py:96-104): csrc/loss_mc.hip."""
+
+    @staticmethod
+    def forward(ctx, x, t, cw, smooth, red):
+        n, c, h, w = x.shape
+        hw = h * w
+        ws = torch.empty(lib.aide_dice_terms_mc_ws_bytes(n, hw, c) // 8, device=x.device, dtype=torch.float64)
+        per = torch.empty(n, device=x.device, dtype=torch.float32)
+        out = torch.empty(n if red == 2 else 1, device=x.device, dtype=torch.float32)
+        check(lib.aide_dice_terms_mc_fwd(ptr(x), c * hw, ptr(t), c * hw, n, hw, c, cw, smooth, red, ptr(ws), ptr(per),
+                                         ptr(out), stream_ptr()), 'dice_terms_mc_fwd')
+        ctx.save_for_backward(x, t, ws)
+        ctx.cfg = (cw, smooth, red)
+        return out if red == 2 else out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t, ws = ctx.saved_tensors
+        cw, smooth, red = ctx.cfg
+        n, c, h, w = x.shape
+        g = g.contiguous().float().reshape(-1)
+        dx = torch.empty_like(x)
+        check(lib.aide_dice_terms_mc_bwd(ptr(x), c * h * w, ptr(t), c * h * w, n, h * w, c, cw, smooth, red, ptr(ws),
+                                         ptr(g), ptr(dx), c * h * w, stream_ptr()), 'dice_terms_mc_bwd')
+        return dx, None, None, None, None
 
 
 def _dense_f32(t, shape, what):
@@ -160,8 +205,12 @@ class MulticlassDiceLoss(nn.Module):
         if target.dim() > 3:                # utils/loss2d.py:98-104: one Dice term per class, weighted
             logits = _seg._logits(input)
             w0, w1 = _seg.class_weights(self.weight)
-            return _DiceTerms.apply(logits, _dense_f32(target, logits.shape, 'MulticlassDiceLoss one-hot target'), 2,
-                                    w0, w1, float(self.smooth), red)
+            tgt = _dense_f32(target, logits.shape, 'MulticlassDiceLoss one-hot target')
+            if logits.shape[1] > 2:
+                return _DiceTermsMC.apply(logits, tgt, _seg.class_w_array(w0, w1, logits.shape[1]), float(self.smooth), red)
+            if w1 is None:
+                raise RuntimeError('aide_amd: %d class weights for logits with 2 classes' % len(w0))
+            return _DiceTerms.apply(logits, tgt, 2, w0, w1, float(self.smooth), red)
         # index targets: class-1 Dice only, class weights ignored (utils/loss2d.py:105-106)
         loss, self.last = _seg.seg_loss(input, target, 1.0, 1.0, 255, red, 0.0, 1.0, float(self.smooth))
         return loss

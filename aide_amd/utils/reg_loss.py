@@ -60,7 +60,7 @@ class Pixelcoreg_Focalloss(_Base):
     -> (loss, kept foreground fraction); only inputs3 receives a gradient, as in the reference."""
 
     def forward(self, inputs1, inputs2, inputs3, targets, forget_rate, kdweight, device=None):
-        z1, z2, z3 = (_seg._logits(x) for x in (inputs1, inputs2, inputs3))
+        z1, z2, z3 = (_seg._logits2(x, 'Pixelcoreg_Focalloss') for x in (inputs1, inputs2, inputs3))
         tg, t_bs = _seg._targets(targets, z1)
         return _PixelCoregFn.apply(z1, z2, z3, tg, t_bs, forget_rate, kdweight, self.reduction)
 
@@ -69,6 +69,6 @@ class Pixelcoreg_Focalloss_twomodel(_Base):
     """utils/reg_loss.py:133-193.  forward(inputs1, inputs2, targets, forget_rate, kdweight, device)."""
 
     def forward(self, inputs1, inputs2, targets, forget_rate, kdweight, device=None):
-        z1, z2 = _seg._logits(inputs1), _seg._logits(inputs2)
+        z1, z2 = _seg._logits2(inputs1, 'Pixelcoreg_Focalloss_twomodel'), _seg._logits2(inputs2, 'Pixelcoreg_Focalloss_twomodel')
         tg, t_bs = _seg._targets(targets, z1)
         return _PixelCoregFn.apply(z1, z2, None, tg, t_bs, forget_rate, kdweight, self.reduction)

@@ -311,7 +311,7 @@ int aide_sa_gate_bwd(const float* dout, int64_t dout_bs, const float* y, int64_t
                      int N, int C, int HW, float* ws, aide_stream_t stream);
 
 /* ---- 1x1 head convolution -----------------------------------------------------------------------
- * replaces last_conv1 = nn.Conv2d(64, num_classes, 1): fuseunet.py:41,89 ; UNet.py:150,164 */
+ * replaces last_conv1 = nn.Conv2d(64, num_classes, 1): fuseunet.py:41,89 ; UNet.py:150,164.  K = num_classes, 1 .. 8 */
 int aide_head1x1_fwd(const float* x, int64_t x_bs, const float* w, const float* b, float* y, int64_t y_bs,
                      int N, int C, int K, int H, int W, aide_stream_t stream);
 size_t aide_head1x1_ws_bytes(int C, int K);
@@ -353,6 +353,47 @@ int aide_mse_map(const float* logits, int64_t l_bs, const float* target, int64_t
 int aide_pseudo_label(const float* const* logits /* HOST array of K device pointers */, int K,
                       int64_t l_bs, int N, int HW, float temperature, float* pl, float* wm,
                       aide_stream_t stream);
+
+/* ---- the same losses for num_classes = 3 .. aide_seg_max_classes() (csrc/loss_mc.hip) -------------------------------
+ * The reference's modules are written for any class count (fuseunet(num_classes=...), models_twomodalinputs/
+ * fuseunet.py:7,41; nn.CrossEntropyLoss(weight), utils/loss2d.py:8; softmax(...)[:, 1] in every Dice form,
+ * utils/loss2d.py:44-46,65-66,96,106; MulticlassMSELoss :115-117; sharpen, trainchaos_proposed_30cases1labeled.py:97-101;
+ * argmax(softmax), trainchaos_comparison_1case.py:262-264); its shipped scripts run two.  Logits / pseudo labels /
+ * gradients are [N][C][HW] planes, class_w is a HOST array of C floats (NULL = ones).  The statistics (partials, stats)
+ * have the layout of aide_seg_stats, so aide_seg_loss_finalize serves both; aide_coteach_finalize_mc takes C for the
+ * mean of the consistency map (aide_coteach_finalize = C 2). */
+int aide_seg_max_classes(void);
+int aide_seg_stats_mc(const float* logits, int64_t l_bs, const long long* targets, int64_t t_bs,
+                      const float* class_w /* HOST */, int C, int ignore_index, const float* pseudo, int64_t p_bs,
+                      const float* wmap, int64_t w_bs, int N, int HW, double* partials, aide_stream_t stream);
+int aide_seg_loss_bwd_mc(const float* logits, int64_t l_bs, const long long* targets, int64_t t_bs,
+                         const float* class_w /* HOST */, int C, int ignore_index, const float* pseudo, int64_t p_bs,
+                         const float* wmap, int64_t w_bs, int N, int HW, const double* stats, const float* coef,
+                         float smooth, const float* gout, int g_stride, float* dlogits, int64_t d_bs,
+                         aide_stream_t stream);
+int aide_coteach_finalize_mc(const double* partials1, const double* partials2, int N, int HW, int C, int variant,
+                             int keep, float w_ce, float w_dice, float smooth, float rate, float w_seg,
+                             float w_cor, double* stats1, double* stats2, float* loss, float* per_image1,
+                             float* per_image2, long long* idx1, long long* idx2, float* coef1, float* coef2,
+                             float* hard_dice, aide_stream_t stream);
+int aide_ce_map_mc(const float* logits, int64_t l_bs, const long long* targets, int64_t t_bs,
+                   const float* class_w /* HOST */, int C, int ignore_index, int N, int HW, float* out,
+                   const float* gout, float* dlogits, int64_t d_bs, aide_stream_t stream);
+int aide_mse_map_mc(const float* logits, int64_t l_bs, const float* target, int64_t q_bs, int C, int N, int HW,
+                    float* out, const float* gout, float* dlogits, int64_t d_bs, aide_stream_t stream);
+int aide_label_map_mc(const float* logits, int64_t l_bs, int C, int N, int HW, long long* labels,
+                      aide_stream_t stream);
+int aide_pseudo_label_mc(const float* const* logits /* HOST array of K device pointers */, int K, int C,
+                         int64_t l_bs, int N, int HW, float temperature, float* pl, float* wm,
+                         aide_stream_t stream);
+/* MulticlassDiceLoss with one-hot targets [N][C][HW] (utils/loss2d.py:98-104), one weighted Dice term per class */
+size_t aide_dice_terms_mc_ws_bytes(int N, int HW, int C);
+int aide_dice_terms_mc_fwd(const float* x, int64_t x_bs, const float* t, int64_t t_bs, int N, int HW, int C,
+                           const float* class_w /* HOST */, float smooth, int reduction, double* ws,
+                           float* per_image, float* out, aide_stream_t stream);
+int aide_dice_terms_mc_bwd(const float* x, int64_t x_bs, const float* t, int64_t t_bs, int N, int HW, int C,
+                           const float* class_w /* HOST */, float smooth, int reduction, const double* ws,
+                           const float* g, float* dx, int64_t dx_bs, aide_stream_t stream);
 
 /* ---- remaining co-teaching operators (utils/coteach_loss.py:85-92, 163-196, 198-254), two classes ----
  * aide_kl_map: KLbidirection, out[n][p] = KL(p1||p2) + KL(p2||p1); with gout (per-pixel upstream gradient) also

@@ -754,6 +754,163 @@ def g12_metrics(ref_utils):
     print('g12', [k for k in fx if '/' in k and not k.endswith('grad')])
 
 
+def g17_multiclass(ref_f, ref_u, ref_utils):
+    """num_classes > 2: the reference's modules on 3 / 4 / 5 / 8 classes -- tiny networks (logits,
+    loss, per-image loss, gradients, eval logits) and every loss form that takes index or one-hot targets, with class
+    weights, an ignored pixel, the consistency term and the two image-level co-teaching operators.  The oracle
+    restatement is asserted bit-equal to the reference before anything is written."""
+    import oracle
+    fx = {}
+    # ---- networks
+    for name, rc, oc, two_modal, C in (('fuseunet3', ref_f.fuseunet, oracle.fuseunet, True, 3),
+                                       ('unet4', ref_u.UNet, oracle.UNet, False, 4)):
+        torch.manual_seed(2)
+        rnet = rc(C)
+        torch.manual_seed(2)
+        onet = oc(C)
+        for (k, a), (_, b) in zip(rnet.state_dict().items(), onet.state_dict().items()):
+            _same(a, b, name + ' init ' + k)
+        g = torch.Generator().manual_seed(4321)
+        xs = [torch.randn(2, 3, 32, 32, generator=g) for _ in range(2 if two_modal else 1)]
+        t = torch.randint(0, C, (2, 32, 32), generator=g)
+        cw = torch.tensor([1.0, 2.0, 0.5, 1.5][:C])
+        cdw = torch.tensor([0.8, 1.3])
+        res = {}
+        for tag, net, mod in (('ref', rnet, ref_utils), ('ora', onet, oracle)):
+            net.train()
+            out = net(*xs)
+            loss = mod.CEMDiceLoss(cediceweight=cdw, ceclassweight=cw, diceclassweight=cw)(out, t)
+            per_img = mod.CEMDiceLossImage(cediceweight=cdw, ceclassweight=cw, diceclassweight=cw)(out, t)
+            net.zero_grad()
+            loss.backward()
+            grads = {k: q.grad.clone() for k, q in net.named_parameters()}
+            net.eval()
+            with torch.no_grad():
+                ev = net(*xs)
+            res[tag] = dict(out=out.detach(), loss=loss.detach(), per_img=per_img.detach(), grads=grads, ev=ev)
+        r, o = res['ref'], res['ora']
+        for k in ('out', 'loss', 'per_img', 'ev'):
+            _same(r[k], o[k], name + ' ' + k)
+        for k in r['grads']:
+            _same(r['grads'][k], o['grads'][k], name + ' grad ' + k)
+        names = list(r['grads'].keys())
+        for i, x in enumerate(xs):
+            fx['%s/x%d' % (name, i)] = _np(x)
+        fx[name + '/targets'] = _np(t)
+        fx[name + '/class_w'] = _np(cw)
+        fx[name + '/cedice_w'] = _np(cdw)
+        fx[name + '/logits'] = _np(r['out'])
+        fx[name + '/loss'] = _np(r['loss'])
+        fx[name + '/per_image_loss'] = _np(r['per_img'])
+        fx[name + '/eval_logits'] = _np(r['ev'])
+        fx[name + '/labels'] = _np(torch.argmax(torch.softmax(r['ev'], dim=1), dim=1))
+        fx[name + '/param_names'] = np.array(names)
+        fx[name + '/grad_norms'] = np.array([r['grads'][k].double().norm().item() for k in names])
+        for k in ('last_conv1.weight', 'last_conv1.bias', names[0]):
+            fx['%s/grad/%s' % (name, k)] = _np(r['grads'][k])
+        print('g17', name, 'loss', float(r['loss']))
+    # ---- loss forms
+    for C in (3, 5, 8):
+        g = torch.Generator().manual_seed(100 + C)
+        n, s = 4, 24
+        t = torch.randint(0, C, (n, s, s), generator=g)
+        z1 = torch.randn(n, C, s, s, generator=g) * 2.0
+        z2 = torch.randn(n, C, s, s, generator=g) * 2.0
+        onehot = torch.nn.functional.one_hot(t, C).permute(0, 3, 1, 2).float()
+        # separate the per-image losses (well-defined argsort): push image i towards / away from its target
+        z1 = z1 + torch.tensor([0.0, 0.7, -0.6, 1.2]).view(n, 1, 1, 1) * (2 * onehot - 1)
+        z2 = z2 + torch.tensor([1.0, -0.5, 0.4, -1.1]).view(n, 1, 1, 1) * (2 * onehot - 1)
+        t_ign = t.clone()
+        t_ign[0, 3:9, 5:17] = 255
+        pseudo = torch.softmax(torch.randn(n, C, s, s, generator=g), dim=1)
+        wmap = (1.0 - 4.0 * pseudo[:, 0] * pseudo[:, 1]).unsqueeze(1)
+        cw = torch.tensor([1.0, 3.0, 0.5, 2.0, 1.5, 0.25, 1.0, 4.0][:C])
+        cdw = torch.tensor([0.7, 1.6])
+        pre = 'c%d/' % C
+        fx.update({pre + 'z1': _np(z1), pre + 'z2': _np(z2), pre + 'targets': _np(t), pre + 'targets_ignore': _np(t_ign),
+                   pre + 'pseudo': _np(pseudo), pre + 'wmap': _np(wmap), pre + 'class_w': _np(cw), pre + 'cedice_w': _np(cdw)})
+        cases = (('CrossEntropyLoss2d', dict(weight=cw), t_ign),
+                 ('CrossEntropyLoss2d_sum', dict(weight=cw, reduction='sum'), t_ign),
+                 ('CrossEntropyLoss2d_none', dict(weight=cw, reduction='none'), t_ign),
+                 ('CrossEntropyLoss2d_onehot', dict(weight=cw), onehot),
+                 ('DiceLoss', dict(), t), ('DiceLoss_none', dict(reduction='none'), t), ('Dice_Loss_sum', dict(reduction='sum'), t),
+                 ('MulticlassDiceLoss', dict(weight=cw), t),
+                 ('MulticlassDiceLoss_onehot', dict(weight=cw), onehot),
+                 ('MulticlassDiceLoss_onehot_none', dict(weight=cw, reduction='none'), onehot),
+                 ('CEMDiceLoss', dict(cediceweight=cdw, ceclassweight=cw, diceclassweight=cw), t),
+                 ('CEMDiceLoss_sum', dict(cediceweight=cdw, ceclassweight=cw, diceclassweight=cw, reduction='sum'), t),
+                 ('CEMDiceLossImage', dict(cediceweight=cdw, ceclassweight=cw, diceclassweight=cw), t),
+                 ('CEDiceLoss', dict(cediceweight=cdw, classweight=cw), t))
+        for key, kw, tgt in cases:
+            lname = key.split('_')[0] if not key.startswith('Dice_Loss') else 'Dice_Loss'
+            vals = {}
+            for tag, mod in (('ref', ref_utils), ('ora', oracle)):
+                zz = z1.clone().requires_grad_(True)
+                v = getattr(mod, lname)(**kw)(zz, tgt)
+                gsel = torch.linspace(0.5, 1.5, v.numel()).view(v.shape) if v.dim() else None
+                ((v * gsel).sum() if v.dim() else v).backward()
+                vals[tag] = (v.detach(), zz.grad.clone())
+            _same(vals['ref'][0], vals['ora'][0], pre + key)
+            _same(vals['ref'][1], vals['ora'][1], pre + key + ' grad')
+            fx[pre + key] = _np(vals['ref'][0])
+            fx[pre + key + '/grad'] = _np(vals['ref'][1])
+        vals = {}
+        for tag, mod in (('ref', ref_utils), ('ora', oracle)):
+            zz = z1.clone().requires_grad_(True)
+            v = (wmap * mod.MulticlassMSELoss(reduction='none')(zz, pseudo)).mean()
+            v.backward()
+            vals[tag] = (v.detach(), zz.grad.clone())
+        _same(vals['ref'][0], vals['ora'][0], pre + 'mse')
+        _same(vals['ref'][1], vals['ora'][1], pre + 'mse grad')
+        fx[pre + 'mse_wm_mean'], fx[pre + 'mse_wm_mean/grad'] = _np(vals['ref'][0]), _np(vals['ref'][1])
+        for cname in ('Coteachingloss_dropimage', 'Coteachingloss_weightimage'):
+            for fr in (0.25, 0.5):
+                vals = {}
+                for tag, mod in (('ref', ref_utils), ('ora', oracle)):
+                    a1 = z1.clone().requires_grad_(True)
+                    a2 = z2.clone().requires_grad_(True)
+                    l1, l2 = getattr(mod, cname)(weight=1.0, reduction='none')(a1, a2, t, fr)
+                    (l1 + l2).backward()
+                    vals[tag] = (l1.detach(), l2.detach(), a1.grad.clone(), a2.grad.clone())
+                for i in range(4):
+                    _same(vals['ref'][i], vals['ora'][i], '%s%s fr=%g #%d' % (pre, cname, fr, i))
+                key = '%s%s/fr%g' % (pre, cname, fr)
+                fx[key + '/loss1'], fx[key + '/loss2'] = _np(vals['ref'][0]), _np(vals['ref'][1])
+                fx[key + '/grad1'], fx[key + '/grad2'] = _np(vals['ref'][2]), _np(vals['ref'][3])
+        # the composite loss of the proposed loop (trainchaos_proposed_30cases1labeled.py:303-321) on C classes, keep = 2
+        crit = ref_utils.CEMDiceLossImage(cediceweight=cdw, ceclassweight=cw, diceclassweight=cw)
+        corr = ref_utils.MulticlassMSELoss(reduction='none')
+        rate, segcor = 0.3, (1.0, 10.0)
+        a1 = z1.clone().requires_grad_(True)
+        a2 = z2.clone().requires_grad_(True)
+        pre1, pre2 = crit(a1, t), crit(a2, t)
+        _, indx1 = pre1.sort()
+        _, indx2 = pre2.sort()
+        l1 = segcor[0] * (crit(a1[indx2[0:2]], t[indx2[0:2]]).mean() + (1.0 - rate) * crit(a1[indx2[2:]], t[indx2[2:]]).mean()) + \
+            segcor[1] * rate * (wmap[indx2[2:]] * corr(a1[indx2[2:]], pseudo[indx2[2:]])).mean()
+        l2 = segcor[0] * (crit(a2[indx1[0:2]], t[indx1[0:2]]).mean() + (1.0 - rate) * crit(a2[indx1[2:]], t[indx1[2:]]).mean()) + \
+            segcor[1] * rate * (wmap[indx1[2:]] * corr(a2[indx1[2:]], pseudo[indx1[2:]])).mean()
+        (l1 + l2).backward()
+        fx[pre + 'proposed/loss1'], fx[pre + 'proposed/loss2'] = _np(l1.detach()), _np(l2.detach())
+        fx[pre + 'proposed/grad1'], fx[pre + 'proposed/grad2'] = _np(a1.grad), _np(a2.grad)
+        fx[pre + 'proposed/indx1'], fx[pre + 'proposed/indx2'] = _np(indx1), _np(indx2)
+        fx[pre + 'proposed/min_gap'] = min(np.diff(np.sort(_np(pre1.detach()))).min(), np.diff(np.sort(_np(pre2.detach()))).min())
+        # pseudo-label ensemble (:274-288): mean softmax of 4 passes, sharpen, weight map
+        passes = [torch.randn(n, C, s, s, generator=g) * 1.5 for _ in range(4)]
+        pl = sum(torch.softmax(q, dim=1) for q in passes) / 4.0
+        tmp = torch.pow(pl, 2.0)
+        pl = tmp / tmp.sum(dim=1).unsqueeze(dim=1)
+        fx[pre + 'ensemble/passes'] = _np(torch.stack(passes))
+        fx[pre + 'ensemble/pseudo'] = _np(pl)
+        fx[pre + 'ensemble/wmap'] = _np((1.0 - 4.0 * pl[:, 0] * pl[:, 1]).unsqueeze(1))
+        d_ref = ref_utils.Dice_fn(z1.clone(), t)
+        _same(torch.as_tensor(d_ref), torch.as_tensor(oracle.Dice_fn(z1.clone(), t)), pre + 'Dice_fn')
+        fx[pre + 'Dice_fn'] = _np(torch.as_tensor(d_ref))
+        fx[pre + 'labels'] = _np(torch.argmax(torch.softmax(z1, dim=1), dim=1))
+    np.savez_compressed(os.path.join(OUT, 'g17_multiclass.npz'), **fx)
+    print('g17 multiclass ok')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ['g8']:
@@ -786,6 +943,10 @@ def main():
         ref_f, ref_u, ref_utils = _import_reference()
         return {'g2': lambda: g2_config(ref_f, ref_utils), 'g13': lambda: g13_config4(ref_u, ref_utils),
                 'g14': lambda: g14_config3(ref_f, ref_utils), 'g15': lambda: g15_config5(ref_f, ref_utils), 'g16': lambda: g16_config5_autocast(ref_f, ref_utils)}[sys.argv[1]]()
+    if sys.argv[1:] == ['g17']:         # num_classes > 2
+        torch.set_num_threads(8)
+        ref_f, ref_u, ref_utils = _import_reference()
+        return g17_multiclass(ref_f, ref_u, ref_utils)
     if sys.argv[1:] == ['g6']:
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()
@@ -813,6 +974,7 @@ def main():
     g10_variants(ref_f, ref_u, ref_utils, oracle)
     g11_polylr(ref_utils)
     g12_metrics(ref_utils)
+    g17_multiclass(ref_f, ref_u, ref_utils)
     print('all golden fixtures written to', OUT)
 
 

@@ -309,3 +309,43 @@ def test_g16_autocast_anchor_is_consistent():
     assert list(a['param_names']) == list(b['param_names'])
     assert 0.5 * float(b['bf16_vs_fp32_logits']) < float(a['autocast_vs_fp32_logits']) < 2.0 * float(b['bf16_vs_fp32_logits'])
     assert abs(float(a['autocast_loss']) - float(a['fp32_loss'])) < 1e-3 * float(a['fp32_loss'])
+
+
+@pytest.mark.parametrize('C', [3, 5, 8])
+def test_g17_multiclass_losses(C):
+    """num_classes > 2: the restated loss modules against the reference's values and gradients (fixture g17)."""
+    from multiclass_cases import loss_cases, targets_of, upstream
+    fx, pre = load('g17_multiclass.npz'), 'c%d/' % C
+    z1, z2 = torch.from_numpy(fx[pre + 'z1']), torch.from_numpy(fx[pre + 'z2'])
+    for key, lname, kw, kind in loss_cases(fx, pre):
+        zz = z1.clone().requires_grad_(True)
+        v = getattr(oracle, lname)(**kw)(zz, targets_of(fx, pre, kind, C))
+        ((v * upstream(v)).sum() if v.dim() else v).backward()
+        close(v.detach(), fx[pre + key], what=key)
+        close(zz.grad, fx[pre + key + '/grad'], what=key + ' grad')
+    t = torch.from_numpy(fx[pre + 'targets'])
+    for cname in ('Coteachingloss_dropimage', 'Coteachingloss_weightimage'):
+        for fr in (0.25, 0.5):
+            l1, l2 = getattr(oracle, cname)(weight=1.0, reduction='none')(z1, z2, t, fr)
+            close(l1, fx['%s%s/fr%g/loss1' % (pre, cname, fr)])
+            close(l2, fx['%s%s/fr%g/loss2' % (pre, cname, fr)])
+    close(oracle.Dice_fn(z1.clone(), t), fx[pre + 'Dice_fn'])
+
+
+@pytest.mark.parametrize('name,ctor,C,nin', [('fuseunet3', oracle.fuseunet, 3, 2), ('unet4', oracle.UNet, 4, 1)])
+def test_g17_multiclass_models(name, ctor, C, nin):
+    fx = load('g17_multiclass.npz')
+    torch.manual_seed(2)
+    net = ctor(C)
+    xs = [torch.from_numpy(fx['%s/x%d' % (name, i)]) for i in range(nin)]
+    t = torch.from_numpy(fx[name + '/targets'])
+    cw, cdw = torch.from_numpy(fx[name + '/class_w']), torch.from_numpy(fx[name + '/cedice_w'])
+    net.train()
+    out = net(*xs)
+    loss = oracle.CEMDiceLoss(cediceweight=cdw, ceclassweight=cw, diceclassweight=cw)(out, t)
+    loss.backward()
+    close(out.detach(), fx[name + '/logits'], what='logits')
+    close(loss.detach(), fx[name + '/loss'], what='loss')
+    grads = dict((k, p.grad) for k, p in net.named_parameters())
+    for k in ('last_conv1.weight', 'last_conv1.bias'):
+        close(grads[k], fx['%s/grad/%s' % (name, k)], rtol=1e-4, what=k)
