@@ -74,9 +74,12 @@ __device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, floa
     o[5 * st] = __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5));
 }
 
-// PAIR: 16-pixel-wide images, two per workgroup tile (a compile-time variant: the descriptors of the common case keep their
-// register allocation -- as a runtime flag the extra live values put a scratch reload into the main loop)
-template <int PAIR>
+// MODE 1: 16-pixel-wide images, two per workgroup tile (a compile-time variant: the descriptors of the common case keep their
+// register allocation -- as a runtime flag the extra live values put a scratch reload into the main loop).
+// MODE 2: the workgroup's 32 tile slots as a 5 x 5 canvas of 4x4 tiles = 20 x 20 pixels (25 slots used) instead of 4 x 8 =
+// 16 x 32: the 40 x 40 and 20 x 20 planes of the 320 x 320 workload fill 78 % of their tiles instead of 52 % / 39 %.  Only
+// the staging descriptors, the patch origin and the output address know the canvas; the main loop is the same code.
+template <int MODE>
 #ifdef AIDE_PROBE_4HALF
 // (timing probe, wrong results) half of the positions per workgroup -- 9 accumulators, 18 MFMAs per stage -- so that TWO
 // workgroups fit a CU (2 waves per SIMD): does a co-resident workgroup hide the fixed cost and the stalls of the other?
@@ -107,7 +110,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     const int tw = pt % a.blocks_w;       pt /= a.blocks_w;
     const int th = pt % a.blocks_h;
     const int n = pt / a.blocks_h;
-    const int h0 = th * 16, w0 = tw * 32, co0 = co_tile * 64;
+    constexpr int PAIR = MODE == 1;
+    constexpr bool canv = MODE == 2;
+    // raw rows per channel / 16-byte units per row / row stride in LDS.  Canvas: 22 rows of [3 pad][-1][0..19][20]; the
+    // stride 29 = 5 (mod 8) keeps the patch reads conflict-free (bank = 7 ci + 4 tile for the 8 tiles x 4 channels of a
+    // 32-lane group, as (41, 775) does for the 4 x 8 form)
+    constexpr int NR = canv ? 22 : 18, NI = canv ? 5 : 8, RRS = canv ? 29 : F4_RRS;
+    constexpr int TPH = canv ? 20 : 16, TPW = canv ? 20 : 32;
+    static_assert(NR * RRS <= F4_RCS, "raw channel plane");
+    const int h0 = th * TPH, w0 = tw * TPW, co0 = co_tile * 64;
     const int HW = a.H * a.W;
     // 16-pixel-wide images (the 16 x 16 bottleneck level): the 32-column tile holds the rows of TWO images side by side, each
     // with its own zero halo columns -- raw row [3 pad][-1][A 0..15][16][-1][B 0..15][16]: image B sits two words further right.
@@ -119,30 +130,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     const int s_end = min(s_begin + sps, a.stages_total);
 
     // ---- staging descriptors (stage-invariant) ----
-    // raw interior: 4 ci x 18 rows x 8 float4 = 576 units (3 rounds, spare lanes repeat unit q - 256);
-    // raw edges: 4 x 18 x 2 dwords = 144 units (1 round); U: 2304 float4 (9 rounds)
+    // raw interior: 4 ci x 18 rows x 8 float4 = 576 units (3 rounds, spare lanes repeat an earlier unit; canvas: 4 x 22 x 5 =
+    // 440); raw edges: 4 x 18 x 2 dwords = 144 units (1 round; canvas 176); U: 2304 float4 (9 rounds)
+    constexpr int NUI = 4 * NR * NI, NUE = 4 * NR * 2;
     unsigned offB[3], ldsB[3], offC, ldsC;
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
         int q = tid + e * 256;
-        if (q >= 576) q -= 256;
-        const int c = q / 144, rem = q - c * 144, r = rem >> 3, s4 = rem & 7;
+        while (q >= NUI) q -= 256;
+        const int c = q / (NR * NI), rem = q - c * (NR * NI), r = rem / NI, s4 = rem - r * NI;
         const int ih = h0 - 1 + r, iw = w0 + 4 * s4;
         const int imgB = pair && s4 >= 4;
         const bool ok = ih >= 0 && ih < a.H && (pair || iw < a.W);
         offB[e] = ok ? (unsigned)((long)imgB * a.x_bs + c * HW + r * a.W + 1 + 4 * (pair ? (s4 & 3) : s4)) * 4u : BUF_OOB;
-        ldsB[e] = (unsigned)(c * F4_RCS + r * F4_RRS + 4 + 4 * s4 + 2 * imgB);
+        ldsB[e] = (unsigned)(c * F4_RCS + r * RRS + 4 + 4 * s4 + 2 * imgB);
     }
     {
         int q = tid;
-        if (q >= 144) q -= 144;
-        const int c = q / 36, rem = q - c * 36, r = rem >> 1, side = rem & 1;
-        const int ih = h0 - 1 + r, iw = side ? w0 + 32 : w0 - 1;
+        if (q >= NUE) q -= NUE;
+        const int c = q / (NR * 2), rem = q - c * (NR * 2), r = rem >> 1, side = rem & 1;
+        const int ih = h0 - 1 + r, iw = side ? w0 + TPW : w0 - 1;
         const bool ok = !pair && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        offC = ok ? (unsigned)(c * HW + r * a.W + (side ? 33 : 0)) * 4u : BUF_OOB;
+        offC = ok ? (unsigned)(c * HW + r * a.W + (side ? TPW + 1 : 0)) * 4u : BUF_OOB;
         // (pair: every halo column is an image border; the edge units keep the two seam columns zero, the outer two are
         // zeroed once in the prologue)
-        ldsC = (unsigned)(c * F4_RCS + r * F4_RRS + (pair ? (side ? 21 : 20) : (side ? 36 : 3)));
+        ldsC = (unsigned)(c * F4_RCS + r * RRS + (pair ? (side ? 21 : 20) : (side ? 4 + TPW : 3)));
     }
     const __amdgpu_buffer_rsrc_t xrs =
         make_rsrc(a.x + (long)(pair ? 2 * n : n) * a.x_bs + (long)h0 * a.W + w0 - (a.W + 1));
@@ -179,13 +191,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
 
     // ---- input transform: thread = (half hs, ci, tile) ----
     const int item = tid & 127, hs = wid >> 1;             // hs is wave-uniform
-    const int xr_off = (item & 3) * F4_RCS + (item >> 5) * 4 * F4_RRS + 3 + 4 * ((item >> 2) & 7) +
-                       ((pair && ((item >> 2) & 7) >= 4) ? 2 : 0);
+    // tile slot -> (tile row, tile column) of the workgroup tile; the 7 spare slots of the canvas repeat its last tile
+    const int tslot = canv ? min(item >> 2, 24) : (item >> 2);
+    const int trow = canv ? tslot / 5 : tslot >> 3, tcol = canv ? tslot - 5 * trow : tslot & 7;
+    const int xr_off = (item & 3) * F4_RCS + trow * 4 * RRS + 3 + 4 * tcol + ((pair && tcol >= 4) ? 2 : 0);
     // patch rows as pairs of columns: the column pass is element-wise over columns -> v_pk_fma_f32 / v_pk_add_f32
     f32x2 tp[6][3];
     f32x2 tq[9];
     auto xf_read = [&](int i, int xo) {                    // xo = patch origin of this thread in a set
-        const float v = lds[xo + (i / 6) * F4_RRS + (i % 6)];
+        const float v = lds[xo + (i / 6) * RRS + (i % 6)];
         if ((i % 6) & 1) tp[i / 6][(i % 6) >> 1].y = v; else tp[i / 6][(i % 6) >> 1].x = v;
     };
     auto xf_half = [&](auto HS) {
@@ -363,8 +377,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     float* xbuf = lds;
     float* yn = a.y + (long)split * a.split_stride + (long)(pair ? 2 * n + ((j & 7) >> 2) : n) * a.y_bs;
     const bool add_bias = (a.bias != nullptr) && (split == 0);
-    const int oh = h0 + 4 * (j >> 3), ow = pair ? 4 * (j & 3) : w0 + 4 * (j & 7);
-    const bool pok = oh < a.H && ow < a.W;                 // H, W multiples of 4: a tile is in or out
+    const int oh = h0 + 4 * (canv ? j / 5 : j >> 3), ow = pair ? 4 * (j & 3) : w0 + 4 * (canv ? j % 5 : j & 7);
+    const bool pok = (!canv || j < 25) && oh < a.H && ow < a.W;   // H, W multiples of 4: a tile is in or out
     auto epilogue = [&](auto PH) {
         constexpr int kph = decltype(PH)::value;
         // two accumulator rows (r, r + 1: adjacent registers) per pass as f32x2: the output transform is ~800 scalar VALU
@@ -601,8 +615,21 @@ int aide_conv3x3_wino4_supported(int Cin, int H, int W, int Cout) {
             Cin % 8 == 0) ? 1 : 0;
 }
 
+// workgroup tile of a plane: 0 = 16 x 32 pixels, 1 = two 16-wide images side by side, 2 = the 20 x 20 canvas -- whichever
+// covers the plane with fewer tile slots (canvas: 25 of 32 slots used)
+static int f4_mode(int H, int W, int* bh, int* bw) {
+    static const bool canvas_on = !(getenv("AIDE_W4_CANVAS") && atoi(getenv("AIDE_W4_CANVAS")) == 0);      // A-B switch
+    const int sh = (H + 15) / 16, sw = (W + 31) / 32, ch = (H + 19) / 20, cw = (W + 19) / 20;
+    const int mode = W == 16 ? 1 : (canvas_on && (long)ch * cw < (long)sh * sw) ? 2 : 0;     // (32 slots per workgroup either way)
+    *bh = mode == 2 ? ch : sh;
+    *bw = mode == 2 ? cw : sw;
+    return mode;
+}
+
 int aide_conv3x3_wino4_splitk(int N, int Cin, int H, int W, int Cout) {
-    const long nb = (long)((H + 15) / 16) * ((W + 31) / 32) * (W == 16 ? N / 2 : N) * ((Cout + 63) / 64);
+    int bh, bw;
+    f4_mode(H, W, &bh, &bw);
+    const long nb = (long)bh * bw * (W == 16 ? N / 2 : N) * ((Cout + 63) / 64);
     const int pairs = Cin / 8;                             // a split gets a whole number of stage pairs
     static const long target = getenv("AIDE_W4_SK_TARGET") ? atol(getenv("AIDE_W4_SK_TARGET")) : 200;     // probe switch
     int s = 1;
@@ -611,7 +638,11 @@ int aide_conv3x3_wino4_splitk(int N, int Cin, int H, int W, int Cout) {
 }
 
 // partial-statistics entries per channel written by a forward launch when a sink is armed (aide_conv_stats_sink)
-int aide_conv3x3_wino4_stats_parts(int N, int H, int W) { return W < 32 ? 0 : N * ((H + 15) / 16) * ((W + 31) / 32); }
+int aide_conv3x3_wino4_stats_parts(int N, int H, int W) {
+    int bh, bw;
+    f4_mode(H, W, &bh, &bw);
+    return W < 32 ? 0 : N * bh * bw;
+}
 
 int aide_conv3x3_wino4_pack_blocks(int Co, int Ci) {
     return ((Co + P4_T - 1) / P4_T) * ((Ci + P4_T - 1) / P4_T);
@@ -642,13 +673,16 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
                             F4_LDS * (int)sizeof(float));
         hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             F4_LDS * (int)sizeof(float));
+        hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            F4_LDS * (int)sizeof(float));
         attr_set = true;
     }
     W4Args a;
     a.stats = (splitk <= 1 && accumulate == 0 && W >= 32) ? aide_conv_stats_take() : nullptr;
-    a.pair = W == 16 ? 1 : 0;
+    const int mode = f4_mode(H, W, &a.blocks_h, &a.blocks_w);
+    a.pair = mode == 1 ? 1 : 0;
     a.x = x; a.u = u; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
-    a.blocks_w = (W + 31) / 32; a.blocks_h = (H + 15) / 16; a.n_co_tiles = (Cout + 63) / 64;
+    a.n_co_tiles = (Cout + 63) / 64;
     a.stages_total = Cin / 4;
     if (splitk < 1) splitk = 1;
     if ((Cin / 8) % splitk != 0) return AIDE_ERR_ARG;
@@ -686,6 +720,9 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
     }
     if (a.pair) {
         AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), conv3x3_wino4_kernel<1>, dim3((unsigned)nb), dim3(256),
+                          F4_LDS * sizeof(float), stream, a);
+    } else if (mode == 2) {
+        AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), conv3x3_wino4_kernel<2>, dim3((unsigned)nb), dim3(256),
                           F4_LDS * sizeof(float), stream, a);
     } else {
         AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), conv3x3_wino4_kernel<0>, dim3((unsigned)nb), dim3(256),

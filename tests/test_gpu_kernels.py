@@ -301,6 +301,7 @@ def test_conv3x3_winograd_fwd_dgrad(dev, case):
                                   (1, 64, 128, 80, 80), (1, 8, 64, 20, 44), (1, 96, 192, 40, 48), (2, 40, 64, 48, 36),
                                   (2, 32, 32, 32, 64), (1, 64, 96, 16, 32),
                                   (3, 64, 64, 20, 20), (1, 32, 96, 24, 28), (2, 64, 32, 36, 24),   # 16 < W < 32: one masked tile column
+                                  (2, 64, 64, 40, 40), (1, 64, 32, 60, 100), (2, 32, 64, 44, 40),    # 20 x 20 canvas tiles (fewer slots than 16 x 32)
                                   (4, 64, 64, 16, 16), (2, 128, 96, 32, 16), (6, 32, 64, 20, 16)])   # 16-wide: image pairs per tile
 def test_conv3x3_winograd4_fwd_dgrad(dev, case):
     """Winograd F(4x4,3x3) forward / dgrad vs aten, incl. ragged block edges (H % 16, W % 32 != 0), split-K,
