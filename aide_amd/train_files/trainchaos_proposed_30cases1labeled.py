@@ -46,28 +46,55 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
+# A-B switch.  The two networks of a step are independent until the cross-scored loss: network 2's forwards (the stacked
+# augmentation pass, its reverse augmentation and pseudo labels, the training forward) and its backward run on a second
+# stream, so that the HBM-bound passes of one network (BatchNorm, pooling, up-sampling, reverse augmentation) overlap the
+# matrix-bound convolutions of the other and the launch gaps of one chain are filled by the other.
+TWO_NET_STREAMS = [os.environ.get('AIDE_COTEACH_STREAMS', '1') != '0']
+_NET2_STREAM = {}
+
+
+def _net2_stream(device):
+    s = _NET2_STREAM.get(device)
+    if s is None:
+        s = _NET2_STREAM[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 def coteach_step(net1, net2, opt1, opt2, loss_op, inphase, outphase, aug_pairs, targets1, targets2, rate,
                  temperature=1.0, augset=None):
     """One step of trainchaos_proposed_30cases1labeled.py:260-325 on device tensors. `augset` (the
     loader's dict with 'augno', 'hflip{k}', 'degree{k}') triggers the on-device reverseaug (:271-272)."""
     from aide_amd.utils import pseudo_label_ensemble, reverseaug
+    cur = torch.cuda.current_stream(inphase.device)
+    two = TWO_NET_STREAMS[0]
+    s2 = _net2_stream(inphase.device) if two else cur
+    if two:
+        s2.wait_stream(cur)                                       # the inputs (and last step's optimizer) are cur's work
     # :265-269 -- the four augmented forwards of a network as ONE stacked pass (per-group BatchNorm statistics and
     # running-stat updates, in order: the semantics of the sequential forwards; 4x the pixels per conv launch)
     a1 = net1.forward_groups(aug_pairs)
-    a2 = net2.forward_groups(aug_pairs)
+    with torch.cuda.stream(s2):
+        a2 = net2.forward_groups(aug_pairs)
+        if augset is not None:
+            a2 = reverseaug(augset, a2, 2)                        # :271-272, no host round trip
+        pl2, wm2 = pseudo_label_ensemble(a2, temperature)         # :274-292
     if augset is not None:
-        a1 = reverseaug(augset, a1, 2)                            # :271-272, no host round trip
-        a2 = reverseaug(augset, a2, 2)
-    pl1, wm1 = pseudo_label_ensemble(a1, temperature)             # :274-292
-    pl2, wm2 = pseudo_label_ensemble(a2, temperature)
+        a1 = reverseaug(augset, a1, 2)
+    pl1, wm1 = pseudo_label_ensemble(a1, temperature)
     opt1.zero_grad()
     opt2.zero_grad()
     o1 = net1(inphase, outphase)                                  # :301-302
-    o2 = net2(inphase, outphase)
+    with torch.cuda.stream(s2):
+        o2 = net2(inphase, outphase)
+    if two:
+        cur.wait_stream(s2)
     loss1, loss2, indx1, indx2 = loss_op(o1, o2, targets1, targets2, pl1, wm1, pl2, wm2, rate)   # :303-321
     loss1.backward()                                              # :322-325 (graphs are disjoint)
     opt1.step()
-    loss2.backward()
+    loss2.backward()                                              # (network 2's node runs on the stream of its forward)
+    if two:
+        cur.wait_stream(s2)
     opt2.step()
     return dict(outputs1=o1.detach(), outputs2=o2.detach(), loss1=loss1.detach(), loss2=loss2.detach(),
                 indx1=indx1, indx2=indx2, extra=loss_op.last)
