@@ -76,6 +76,48 @@ def test_proposed_coteaching_step(dev):
         assert np.median(np.abs(gn[live] - fx[key + 'g1'][live]) / fx[key + 'g1'][live]) < 1e-3
 
 
+def test_coteaching_two_streams_is_bit_identical(dev):
+    """Network 2 on its own stream (AIDE_COTEACH_STREAMS, the default) is a schedule, not a different computation: three
+    steps from the same initial state give bit-identical losses, selections and parameters of BOTH networks as the
+    single-stream order -- any missing cross-stream dependency (inputs, optimizer update, engine-assigned gradients) would
+    show here."""
+    from aide_amd.models_twomodalinputs import fuseunet
+    from aide_amd.optim import Adam
+    from aide_amd.utils import CoTeachingProposedLoss
+    from aide_amd.train_files import trainchaos_proposed_30cases1labeled as M
+    fx = np.load(os.path.join(GOLD, 'g4_proposed.npz'))
+    T = lambda k: torch.from_numpy(fx[k]).to(dev)
+    augs = [(T('aug%d_in' % i), T('aug%d_out' % i)) for i in range(4)]
+    n = T('xin').shape[0]
+    augset = {'augno': [4] * n}
+    for k in range(4):
+        augset['hflip%d' % (k + 1)] = [(k + b) % 2 for b in range(n)]
+        augset['degree%d' % (k + 1)] = [15.0 * (k + 1) - 7.0 * b for b in range(n)]
+    res = {}
+    old = M.TWO_NET_STREAMS[0]
+    try:
+        for two in (False, True):
+            M.TWO_NET_STREAMS[0] = two
+            torch.manual_seed(2)
+            n1, n2 = fuseunet(2).to(dev), fuseunet(2).to(dev)
+            n1.train(); n2.train()
+            o1, o2 = Adam(n1.parameters(), lr=1e-3, amsgrad=True), Adam(n2.parameters(), lr=1e-3, amsgrad=True)
+            op = CoTeachingProposedLoss(cediceweight=[1.0, 1.0], ceclassweight=[1.0, 1.0], segcor_weight=[1.0, 10.0])
+            trace = []
+            for _ in range(3):
+                r = M.coteach_step(n1, n2, o1, o2, op, T('xin'), T('xout'), augs, T('t1'), T('t2'), 0.25, augset=augset)
+                trace.append((r['loss1'].clone(), r['loss2'].clone(), r['indx1'].clone(), r['indx2'].clone()))
+            torch.cuda.synchronize()
+            res[two] = (trace, [p.detach().clone() for p in list(n1.parameters()) + list(n2.parameters())],
+                        [b.detach().clone() for b in list(n1.buffers()) + list(n2.buffers())])
+    finally:
+        M.TWO_NET_STREAMS[0] = old
+    for a, b in zip(res[False][0], res[True][0]):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert all(torch.equal(x, y) for x, y in zip(res[False][1], res[True][1]))
+    assert all(torch.equal(x, y) for x, y in zip(res[False][2], res[True][2]))
+
+
 def test_cli_smoke(dev, tmp_path):
     """The restated CLI (--model_name / --batch_size as in README.md:32) trains, the loss falls, every epoch evaluates a
     case and the best checkpoint is written in the reference's format ({'net': state_dict, ...}, :329-345) and loads back."""
