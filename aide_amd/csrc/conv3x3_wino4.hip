@@ -74,6 +74,20 @@ __device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, floa
     o[5 * st] = __builtin_fmaf(-5.f, d3, __builtin_fmaf(4.f, d1, d5));
 }
 
+// sums over lanes 0-31 and 32-63 of a wave, valid in lanes 31 and 63.  Vector-ALU only (DPP): no LDS round trips.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float half_total_dpp(float v) {
+    v = dpp_add<0x111, 0xf>(v);       // row_shr:1  (lanes shifted in from outside the row of 16 read 0)
+    v = dpp_add<0x112, 0xf>(v);       // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);       // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);       // row_shr:8: lane 15 of every row holds the row total
+    v = dpp_add<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
 // MODE 1: 16-pixel-wide images, two per workgroup tile (a compile-time variant: the descriptors of the common case keep their
 // register allocation -- as a runtime flag the extra live values put a scratch reload into the main loop).
 // MODE 2: the workgroup's 32 tile slots as a 5 x 5 canvas of 4x4 tiles = 20 x 20 pixels (25 slots used) instead of 4 x 8 =
@@ -445,9 +459,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
 #pragma unroll
                         for (int o = 0; o < 16; ++o) { s1 += yp[o][e]; s2 = __builtin_fmaf(yp[o][e], yp[o][e], s2); }
                     }
-#pragma unroll
-                    for (int m = 16; m > 0; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }   // the 32 tiles of this half
-                    if (j == 0 && co < a.Cout) {
+                    // the 32 tiles of this half, total in its last lane (j == 31): inclusive scan inside each row of 16 lanes
+                    // (row_shr 1, 2, 4, 8), then the even rows' totals into the odd rows (row_bcast:15) -- five dependent vector
+                    // adds per sum.  (As `__shfl_xor` butterflies these were ten ds_bpermute round trips per (row pair, row),
+                    // each behind its own s_waitcnt lgkmcnt(0): 80 LDS round trips per workgroup epilogue.)
+                    s1 = half_total_dpp(s1);
+                    s2 = half_total_dpp(s2);
+                    if (j == 31 && co < a.Cout) {
                         const int nparts = a.N * a.blocks_h * a.blocks_w, blk = (n * a.blocks_h + th) * a.blocks_w + tw;
                         *reinterpret_cast<f32x2*>(a.stats + ((long)co * nparts + blk) * 2) = f32x2{s1, s2};
                     }
