@@ -92,15 +92,38 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
     return start + k;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide sums on the DPP path: an inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8; lanes shifted in from
+// outside the row, or inactive ones, read 0), then the row totals travel on (row_bcast:15 into rows 1 and 3, row_bcast:31 into
+// rows 2 and 3) -- six dependent vector adds, total in lane 63, broadcast by v_readlane.  (As `__shfl_xor` butterflies every
+// step was a ds_bpermute_b32 LDS round trip behind its own s_waitcnt lgkmcnt(0) -- two per step for a double: 12 / 24 round
+// trips per value at the head or tail of kernels that run for 15-25 us.)  Lane 63 must be active: every caller runs whole waves.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <typename T>
+__device__ __forceinline__ T wave_scan_total(T v) {        // total in lane 63
+    v += dpp_mov<0x111, 0xf>(v);
+    v += dpp_mov<0x112, 0xf>(v);
+    v += dpp_mov<0x114, 0xf>(v);
+    v += dpp_mov<0x118, 0xf>(v);
+    v += dpp_mov<0x142, 0xa>(v);
+    v += dpp_mov<0x143, 0xc>(v);
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {
+    v = wave_scan_total(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = wave_scan_total(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // Block-wide sum of NV doubles per thread (blockDim.x multiple of 64, <= 1024). Result valid in
