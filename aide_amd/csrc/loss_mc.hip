@@ -351,6 +351,192 @@ __global__ __launch_bounds__(256) void dice_terms_mc_bwd_kernel(const float* __r
     }
 }
 
+// ---- the generic co-teaching operators of utils/coteach_loss.py for C classes (the two-class forms: coteach_ext.hip) ----
+// KLbidirection (:85-92): KL(p1||p2) + KL(p2||p1) = sum_c (p1_c - p2_c)(l1_c - l2_c), l = log-softmax.
+//   d/dz1_c = p1_c ((l1_c - l2_c) - E1) + (p1_c - p2_c),  E1 = sum_j p1_j (l1_j - l2_j);  z2 by symmetry.
+template <int C>
+__device__ __forceinline__ float kl_terms(const float (&z1)[C], const float (&p1)[C], float lse1, const float (&z2)[C],
+                                          const float (&p2)[C], float lse2, float (&dl)[C]) {
+    float kl = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        dl[c] = (z1[c] - lse1) - (z2[c] - lse2);            // l1_c - l2_c
+        kl += (p1[c] - p2[c]) * dl[c];
+    }
+    return kl;
+}
+template <int C>
+__device__ __forceinline__ void kl_grads(const float (&p1)[C], const float (&p2)[C], const float (&dl)[C], float (&g1)[C],
+                                         float (&g2)[C]) {
+    float e1 = 0.f, e2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { e1 += p1[c] * dl[c]; e2 -= p2[c] * dl[c]; }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        g1[c] = p1[c] * (dl[c] - e1) + (p1[c] - p2[c]);
+        g2[c] = p2[c] * (-dl[c] - e2) + (p2[c] - p1[c]);
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void kl_map_mc_kernel(const float* __restrict__ z1, long b1, const float* __restrict__ z2,
+                                                        long b2, int HW, long total, float* __restrict__ out,
+                                                        const float* __restrict__ gout, float* __restrict__ g1, long gb1,
+                                                        float* __restrict__ g2, long gb2) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / HW, p = i - n * HW;
+        float a[C], pa[C], la, b[C], pb[C], lb, dl[C];
+        soft_terms<C>(z1 + n * b1 + p, HW, a, pa, la);
+        soft_terms<C>(z2 + n * b2 + p, HW, b, pb, lb);
+        const float kl = kl_terms<C>(a, pa, la, b, pb, lb, dl);
+        if (out) out[i] = kl;
+        if (gout) {
+            float ga[C], gb[C];
+            kl_grads<C>(pa, pb, dl, ga, gb);
+            const float g = gout[i];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                g1[n * gb1 + (long)c * HW + p] = g * ga[c];
+                g2[n * gb2 + (long)c * HW + p] = g * gb[c];
+            }
+        }
+    }
+}
+
+// Coteachingloss_dropregionce (:163-196): cross entropy of the 2x2 max-pooled logits (per class plane) against the 2x2
+// max-pooled target.  aux word: bits 2c..2c+1 the window index of class c's maximum (first maximum in scan order, like
+// max_pool2d), bits 16-23 the pooled target, bit 24 ignored.
+template <int C>
+__global__ __launch_bounds__(256) void region_ce_mc_kernel(const float* __restrict__ z, long zb,
+                                                           const long long* __restrict__ t, long tb, int H, int W,
+                                                           int ignore_index, long total, float* __restrict__ loss,
+                                                           unsigned* __restrict__ aux) {
+    const int Wp = W / 2, P = (H / 2) * Wp, HW = H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / P;
+        const int p = (int)(i - n * P), ph = p / Wp, pw = p - ph * Wp;
+        const long o = (long)(2 * ph) * W + 2 * pw;
+        float m[C];
+        unsigned a = 0;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float* q = z + n * zb + (long)c * HW + o;
+            const float v0 = q[0], v1 = q[1], v2 = q[W], v3 = q[W + 1];
+            m[c] = v0; unsigned am = 0;
+            if (v1 > m[c]) { m[c] = v1; am = 1; }
+            if (v2 > m[c]) { m[c] = v2; am = 2; }
+            if (v3 > m[c]) { m[c] = v3; am = 3; }
+            a |= am << (2 * c);
+            mx = fmaxf(mx, m[c]);
+        }
+        const long long* tq = t + n * tb + o;
+        long long tp = tq[0];
+        tp = tq[1] > tp ? tq[1] : tp; tp = tq[W] > tp ? tq[W] : tp; tp = tq[W + 1] > tp ? tq[W + 1] : tp;
+        const bool ign = tp == ignore_index || tp < 0 || tp >= C;
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) se += expf(m[c] - mx);
+        loss[i] = ign ? 0.0f : (mx + logf(se)) - pick<C>(m, (int)tp);
+        aux[i] = a | ((unsigned)(tp & 0xff) << 16) | ((unsigned)ign << 24);
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void region_ce_bwd_mc_kernel(const float* __restrict__ z, long zb,
+                                                               const unsigned* __restrict__ aux,
+                                                               const unsigned char* __restrict__ mask,
+                                                               const float* __restrict__ coeff, int H, int W, long total,
+                                                               float* __restrict__ dz, long db) {
+    const int Wp = W / 2, P = (H / 2) * Wp, HW = H * W;
+    const float cf = coeff[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / P;
+        const int p = (int)(i - n * P), ph = p / Wp, pw = p - ph * Wp;
+        const long o = (long)(2 * ph) * W + 2 * pw;
+        const unsigned a = aux[i];
+        const int tp = (int)((a >> 16) & 0xff);
+        const bool on = mask[i] && !((a >> 24) & 1);
+        float m[C], mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int am = (a >> (2 * c)) & 3;
+            m[c] = z[n * zb + (long)c * HW + o + (am >> 1) * W + (am & 1)];
+            mx = fmaxf(mx, m[c]);
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { m[c] = expf(m[c] - mx); se += m[c]; }
+        const float inv = 1.0f / se;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int am = (a >> (2 * c)) & 3;
+            const float g = on ? cf * (m[c] * inv - (c == tp ? 1.0f : 0.0f)) : 0.0f;
+            float* d = dz + n * db + (long)c * HW + o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[(k >> 1) * W + (k & 1)] = (k == am) ? g : 0.0f;
+        }
+    }
+}
+
+// Coteachingloss_dropimagedroppixel, pixel term on the dropped images (:221-252):
+// v[m][p] = target * (KL(z1, z2) + CE(z_which, target)) for the images idx[m], the target index taken as a number
+template <int C>
+__global__ __launch_bounds__(256) void droppixel_map_mc_kernel(const float* __restrict__ z1, long b1,
+                                                               const float* __restrict__ z2, long b2,
+                                                               const long long* __restrict__ t, long tb,
+                                                               const long long* __restrict__ idx, int HW, int which,
+                                                               int ignore_index, float* __restrict__ v) {
+    const int m = blockIdx.y;
+    const long n = idx[m];
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        const long long tg = t[n * tb + p];
+        float r = 0.0f;
+        if (tg != 0) {
+            float a[C], pa[C], la, b[C], pb[C], lb, dl[C];
+            soft_terms<C>(z1 + n * b1 + p, HW, a, pa, la);
+            soft_terms<C>(z2 + n * b2 + p, HW, b, pb, lb);
+            float ce = 0.f;
+            if (tg != ignore_index && tg > 0 && tg < C) ce = which ? lb - pick<C>(b, (int)tg) : la - pick<C>(a, (int)tg);
+            r = (kl_terms<C>(a, pa, la, b, pb, lb, dl) + ce) * (float)tg;
+        }
+        v[(long)m * HW + p] = r;
+    }
+}
+
+// g1 / g2 [N][C][HW] (pre-zeroed): coeff * mask * d v / d logits on the images idx[m]
+template <int C>
+__global__ __launch_bounds__(256) void droppixel_bwd_mc_kernel(const float* __restrict__ z1, long b1,
+                                                               const float* __restrict__ z2, long b2,
+                                                               const long long* __restrict__ t, long tb,
+                                                               const long long* __restrict__ idx, int HW, int which,
+                                                               int ignore_index, const unsigned char* __restrict__ mask,
+                                                               const float* __restrict__ coeff, float* __restrict__ g1,
+                                                               float* __restrict__ g2) {
+    const int m = blockIdx.y;
+    const long n = idx[m];
+    const float cf = coeff[0];
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        if (!mask[(long)m * HW + p]) continue;
+        const long long tg = t[n * tb + p];
+        float a[C], pa[C], la, b[C], pb[C], lb, dl[C], ga[C], gb[C];
+        soft_terms<C>(z1 + n * b1 + p, HW, a, pa, la);
+        soft_terms<C>(z2 + n * b2 + p, HW, b, pb, lb);
+        kl_terms<C>(a, pa, la, b, pb, lb, dl);
+        kl_grads<C>(pa, pb, dl, ga, gb);
+        const bool ce_on = tg != ignore_index && tg > 0 && tg < C;
+        const float s = cf * (float)tg;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float hot = ((int)tg == c) ? 1.0f : 0.0f;
+            float x1 = ga[c], x2 = gb[c];
+            if (ce_on) { if (which) x2 += pb[c] - hot; else x1 += pa[c] - hot; }
+            g1[(n * C + c) * HW + p] = s * x1;
+            g2[(n * C + c) * HW + p] = s * x2;
+        }
+    }
+}
+
 bool load_w(const float* class_w, int C, ClassW& cw) {
     if (C < 3 || C > MAXC) return false;
     for (int c = 0; c < MAXC; ++c) cw.w[c] = (class_w && c < C) ? class_w[c] : 1.0f;
@@ -481,6 +667,68 @@ int aide_dice_terms_mc_bwd(const float* x, int64_t x_bs, const float* t, int64_t
     const double* stats = ws + (size_t)N * bpi * 3 * C;
 #define L(CC) hipLaunchKernelGGL(dice_terms_mc_bwd_kernel<CC>, dim3(bpi * 4, N), dim3(256), 0, stream, x, (long)x_bs, t, \
                                  (long)t_bs, HW, N, stats, cw, smooth, reduction, g, dx, (long)dx_bs)
+    AIDE_MC_SWITCH(C, L)
+#undef L
+    return aide_launch_status();
+}
+
+int aide_kl_map_mc(const float* z1, int64_t b1, const float* z2, int64_t b2, int C, int N, int HW, float* out,
+                   const float* gout, float* g1, int64_t gb1, float* g2, int64_t gb2, hipStream_t stream) {
+    if (!z1 || !z2 || N <= 0 || HW <= 0 || C < 3 || C > MAXC || (!out && !gout) || (gout && (!g1 || !g2))) return AIDE_ERR_ARG;
+    const long total = (long)N * HW;
+    const dim3 grid((unsigned)max(1L, min((total + 255) / 256, 4096L)));
+#define L(CC) hipLaunchKernelGGL(kl_map_mc_kernel<CC>, grid, dim3(256), 0, stream, z1, (long)b1, z2, (long)b2, HW, total, out, \
+                                 gout, g1, (long)gb1, g2, (long)gb2)
+    AIDE_MC_SWITCH(C, L)
+#undef L
+    return aide_launch_status();
+}
+
+// aux: one 32-bit word per region (the two-class form packs into a byte)
+int aide_region_ce_fwd_mc(const float* z, int64_t zb, const long long* t, int64_t tb, int C, int N, int H, int W,
+                          int ignore_index, float* loss, unsigned* aux, hipStream_t stream) {
+    if (!z || !t || !loss || !aux || N <= 0 || H % 2 || W % 2 || C < 3 || C > MAXC) return AIDE_ERR_ARG;
+    const long total = (long)N * (H / 2) * (W / 2);
+    const dim3 grid((unsigned)max(1L, min((total + 255) / 256, 4096L)));
+#define L(CC) hipLaunchKernelGGL(region_ce_mc_kernel<CC>, grid, dim3(256), 0, stream, z, (long)zb, t, (long)tb, H, W, \
+                                 ignore_index, total, loss, aux)
+    AIDE_MC_SWITCH(C, L)
+#undef L
+    return aide_launch_status();
+}
+
+int aide_region_ce_bwd_mc(const float* z, int64_t zb, const unsigned* aux, const unsigned char* mask, const float* coeff,
+                          int C, int N, int H, int W, float* dz, int64_t db, hipStream_t stream) {
+    if (!z || !aux || !mask || !coeff || !dz || N <= 0 || H % 2 || W % 2 || C < 3 || C > MAXC) return AIDE_ERR_ARG;
+    const long total = (long)N * (H / 2) * (W / 2);
+    const dim3 grid((unsigned)max(1L, min((total + 255) / 256, 4096L)));
+#define L(CC) hipLaunchKernelGGL(region_ce_bwd_mc_kernel<CC>, grid, dim3(256), 0, stream, z, (long)zb, aux, mask, coeff, H, W, \
+                                 total, dz, (long)db)
+    AIDE_MC_SWITCH(C, L)
+#undef L
+    return aide_launch_status();
+}
+
+int aide_droppixel_map_mc(const float* z1, int64_t b1, const float* z2, int64_t b2, const long long* t, int64_t tb,
+                          const long long* idx, int ndrop, int C, int HW, int which, int ignore_index, float* v,
+                          hipStream_t stream) {
+    if (!z1 || !z2 || !t || !idx || !v || ndrop <= 0 || HW <= 0 || C < 3 || C > MAXC) return AIDE_ERR_ARG;
+    const dim3 grid(min((HW + 255) / 256, 256), ndrop);
+#define L(CC) hipLaunchKernelGGL(droppixel_map_mc_kernel<CC>, grid, dim3(256), 0, stream, z1, (long)b1, z2, (long)b2, t, \
+                                 (long)tb, idx, HW, which, ignore_index, v)
+    AIDE_MC_SWITCH(C, L)
+#undef L
+    return aide_launch_status();
+}
+
+int aide_droppixel_bwd_mc(const float* z1, int64_t b1, const float* z2, int64_t b2, const long long* t, int64_t tb,
+                          const long long* idx, int ndrop, int C, int HW, int which, int ignore_index,
+                          const unsigned char* mask, const float* coeff, float* g1, float* g2, hipStream_t stream) {
+    if (!z1 || !z2 || !t || !idx || !mask || !coeff || !g1 || !g2 || ndrop <= 0 || HW <= 0 || C < 3 || C > MAXC)
+        return AIDE_ERR_ARG;
+    const dim3 grid(min((HW + 255) / 256, 256), ndrop);
+#define L(CC) hipLaunchKernelGGL(droppixel_bwd_mc_kernel<CC>, grid, dim3(256), 0, stream, z1, (long)b1, z2, (long)b2, t, \
+                                 (long)tb, idx, HW, which, ignore_index, mask, coeff, g1, g2)
     AIDE_MC_SWITCH(C, L)
 #undef L
     return aide_launch_status();

@@ -27,8 +27,8 @@ def _logits(x):
 
 
 def _logits2(x, what):
-    """Logits for the operators whose kernels exist for two classes only (csrc/coteach_ext.hip: the SURVEY §8f rank-4
-    co-teaching / regularisation variants no shipped script instantiates)."""
+    """Logits for the operators that are binary in the reference itself (Pixelcoreg_Focalloss: utils/reg_loss.py:70-99 reads
+    soft-max channels 0 and 1 and weights them with t and 1 - t)."""
     x = _logits(x)
     if x.shape[1] != 2:
         raise NotImplementedError('aide_amd: %s is implemented for num_classes == 2 (got logits %s)'

@@ -50,27 +50,38 @@ class Coteachingloss_weightimage(_CoteachBase):
 class _KLFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z1, z2):
-        n, _, h, w = z1.shape
+        n, c, h, w = z1.shape
         out = torch.empty(n, h, w, device=z1.device, dtype=torch.float32)
-        check(lib.aide_kl_map(ptr(z1), 2 * h * w, ptr(z2), 2 * h * w, n, h * w, ptr(out), None, None, 0, None, 0,
-                              stream_ptr()), 'kl_map')
+        if c == 2:
+            check(lib.aide_kl_map(ptr(z1), 2 * h * w, ptr(z2), 2 * h * w, n, h * w, ptr(out), None, None, 0, None, 0,
+                                  stream_ptr()), 'kl_map')
+        else:
+            check(lib.aide_kl_map_mc(ptr(z1), c * h * w, ptr(z2), c * h * w, c, n, h * w, ptr(out), None, None, 0, None, 0,
+                                     stream_ptr()), 'kl_map_mc')
         ctx.save_for_backward(z1, z2)
         return out
 
     @staticmethod
     def backward(ctx, g):
         z1, z2 = ctx.saved_tensors
-        n, _, h, w = z1.shape
+        n, c, h, w = z1.shape
         g = g.contiguous().float()
         g1, g2 = torch.empty_like(z1), torch.empty_like(z2)
-        check(lib.aide_kl_map(ptr(z1), 2 * h * w, ptr(z2), 2 * h * w, n, h * w, None, ptr(g), ptr(g1), 2 * h * w,
-                              ptr(g2), 2 * h * w, stream_ptr()), 'kl_map bwd')
+        if c == 2:
+            check(lib.aide_kl_map(ptr(z1), 2 * h * w, ptr(z2), 2 * h * w, n, h * w, None, ptr(g), ptr(g1), 2 * h * w,
+                                  ptr(g2), 2 * h * w, stream_ptr()), 'kl_map bwd')
+        else:
+            check(lib.aide_kl_map_mc(ptr(z1), c * h * w, ptr(z2), c * h * w, c, n, h * w, None, ptr(g), ptr(g1), c * h * w,
+                                     ptr(g2), c * h * w, stream_ptr()), 'kl_map_mc bwd')
         return g1, g2
 
 
 def KLbidirection(inputs1, inputs2):
     """utils/coteach_loss.py:85-92: per-pixel KL(p1||p2) + KL(p2||p1) of the two softmax maps -> [N,H,W]."""
-    return _KLFn.apply(_seg._logits2(inputs1, 'KLbidirection'), _seg._logits2(inputs2, 'KLbidirection'))
+    z1, z2 = _seg._logits(inputs1), _seg._logits(inputs2)
+    if z1.shape != z2.shape:
+        raise RuntimeError('KLbidirection: logits of different shapes %s / %s' % (tuple(z1.shape), tuple(z2.shape)))
+    return _KLFn.apply(z1, z2)
 
 
 def _select(sel_vals, sum_vals, nseg, m, k_host=-1, rr=-1.0, k_in=None, only_positive=False):
@@ -98,11 +109,15 @@ class _RegionCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         z, aux, mask = ctx.saved_tensors
-        n, _, h, w = z.shape
+        n, c, h, w = z.shape
         coeff = (g.reshape(1).float() / ctx.denom).contiguous()
         dz = torch.empty_like(z)
-        check(lib.aide_region_ce_bwd(ptr(z), 2 * h * w, ptr(aux), ptr(mask), ptr(coeff), n, h, w, ptr(dz), 2 * h * w,
-                                     stream_ptr()), 'region_ce_bwd')
+        if c == 2:
+            check(lib.aide_region_ce_bwd(ptr(z), 2 * h * w, ptr(aux), ptr(mask), ptr(coeff), n, h, w, ptr(dz), 2 * h * w,
+                                         stream_ptr()), 'region_ce_bwd')
+        else:
+            check(lib.aide_region_ce_bwd_mc(ptr(z), c * h * w, ptr(aux), ptr(mask), ptr(coeff), c, n, h, w, ptr(dz),
+                                            c * h * w, stream_ptr()), 'region_ce_bwd_mc')
         return dz, None, None, None, None
 
 
@@ -120,9 +135,11 @@ class Coteachingloss_dropregionce(nn.Module):
         self.scale = scale
 
     def forward(self, inputs1, inputs2, targets, forget_rate):
-        z1, z2 = _seg._logits2(inputs1, 'Coteachingloss_dropregionce'), _seg._logits2(inputs2, 'Coteachingloss_dropregionce')
+        z1, z2 = _seg._logits(inputs1), _seg._logits(inputs2)
+        if z1.shape != z2.shape:
+            raise RuntimeError('Coteachingloss_dropregionce: logits of different shapes')
         tg, t_bs = _seg._targets(targets, z1)
-        n, _, h, w = z1.shape
+        n, c, h, w = z1.shape
         if h % 2 or w % 2:
             raise RuntimeError('Coteachingloss_dropregionce: H and W must be even')
         p = (h // 2) * (w // 2)
@@ -130,10 +147,15 @@ class Coteachingloss_dropregionce(nn.Module):
         dev = z1.device
         with torch.no_grad():
             l1, l2 = torch.empty(n * p, device=dev), torch.empty(n * p, device=dev)
-            a1, a2 = torch.empty(n * p, device=dev, dtype=torch.uint8), torch.empty(n * p, device=dev, dtype=torch.uint8)
+            adt = torch.uint8 if c == 2 else torch.int32           # arg-max bookkeeping: a byte for two classes, a word for C
+            a1, a2 = torch.empty(n * p, device=dev, dtype=adt), torch.empty(n * p, device=dev, dtype=adt)
             for z, l, a in ((z1, l1, a1), (z2, l2, a2)):
-                check(lib.aide_region_ce_fwd(ptr(z), 2 * h * w, ptr(tg), t_bs, n, h, w, 255, ptr(l), ptr(a),
-                                             stream_ptr()), 'region_ce_fwd')
+                if c == 2:
+                    check(lib.aide_region_ce_fwd(ptr(z), 2 * h * w, ptr(tg), t_bs, n, h, w, 255, ptr(l), ptr(a),
+                                                 stream_ptr()), 'region_ce_fwd')
+                else:
+                    check(lib.aide_region_ce_fwd_mc(ptr(z), c * h * w, ptr(tg), t_bs, c, n, h, w, 255, ptr(l), ptr(a),
+                                                    stream_ptr()), 'region_ce_fwd_mc')
         return _RegionCEFn.apply(z1, a1, l1, l2, keep), _RegionCEFn.apply(z2, a2, l2, l1, keep)
 
 
@@ -143,11 +165,15 @@ class _DropPixelFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z1, z2, tg, t_bs, idx, which, rr, k_in):
-        n, _, h, w = z1.shape
+        n, c, h, w = z1.shape
         hw, nd = h * w, idx.numel()
         v = torch.empty(nd * hw, device=z1.device, dtype=torch.float32)
-        check(lib.aide_droppixel_map(ptr(z1), 2 * hw, ptr(z2), 2 * hw, ptr(tg), t_bs, ptr(idx), nd, hw, which, ptr(v),
-                                     stream_ptr()), 'droppixel_map')
+        if c == 2:
+            check(lib.aide_droppixel_map(ptr(z1), 2 * hw, ptr(z2), 2 * hw, ptr(tg), t_bs, ptr(idx), nd, hw, which, ptr(v),
+                                         stream_ptr()), 'droppixel_map')
+        else:
+            check(lib.aide_droppixel_map_mc(ptr(z1), c * hw, ptr(z2), c * hw, ptr(tg), t_bs, ptr(idx), nd, c, hw, which, 255,
+                                            ptr(v), stream_ptr()), 'droppixel_map_mc')
         mask, sums, ks = _select(v, v, 1, nd * hw, rr=(-1.0 if k_in is not None else rr), k_in=k_in,
                                  k_host=0, only_positive=True)
         ctx.save_for_backward(z1, z2, tg, idx, mask, ks)
@@ -158,12 +184,17 @@ class _DropPixelFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gk):
         z1, z2, tg, idx, mask, ks = ctx.saved_tensors
-        n, _, h, w = z1.shape
+        n, c, h, w = z1.shape
         hw, nd = h * w, idx.numel()
         coeff = (g.reshape(1).double() / ks[0].double()).float().contiguous()
         g1, g2 = torch.zeros_like(z1), torch.zeros_like(z2)
-        check(lib.aide_droppixel_bwd(ptr(z1), 2 * hw, ptr(z2), 2 * hw, ptr(tg), ctx.t_bs, ptr(idx), nd, hw, ctx.which,
-                                     ptr(mask), ptr(coeff), ptr(g1), ptr(g2), stream_ptr()), 'droppixel_bwd')
+        if c == 2:
+            check(lib.aide_droppixel_bwd(ptr(z1), 2 * hw, ptr(z2), 2 * hw, ptr(tg), ctx.t_bs, ptr(idx), nd, hw, ctx.which,
+                                         ptr(mask), ptr(coeff), ptr(g1), ptr(g2), stream_ptr()), 'droppixel_bwd')
+        else:
+            check(lib.aide_droppixel_bwd_mc(ptr(z1), c * hw, ptr(z2), c * hw, ptr(tg), ctx.t_bs, ptr(idx), nd, c, hw,
+                                            ctx.which, 255, ptr(mask), ptr(coeff), ptr(g1), ptr(g2), stream_ptr()),
+                  'droppixel_bwd_mc')
         return g1, g2, None, None, None, None, None, None
 
 
@@ -179,7 +210,7 @@ class Coteachingloss_dropimagedroppixel(_CoteachBase):
         keep = _keep_count(forget_rate, n)
         if keep >= n:                                       # nothing dropped: both extra terms are 0.0
             return l1, l2
-        z1, z2 = _seg._logits2(inputs1, 'Coteachingloss_dropimagedroppixel'), _seg._logits2(inputs2, 'Coteachingloss_dropimagedroppixel')
+        z1, z2 = _seg._logits(inputs1), _seg._logits(inputs2)
         tg, t_bs = _seg._targets(targets, z1)
         rr = 1 - forget_rate
         d1 = self.last['argsort1'][keep:].contiguous()      # images dropped by net 1's ranking

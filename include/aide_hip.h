@@ -386,6 +386,22 @@ int aide_label_map_mc(const float* logits, int64_t l_bs, int C, int N, int HW, l
 int aide_pseudo_label_mc(const float* const* logits /* HOST array of K device pointers */, int K, int C,
                          int64_t l_bs, int N, int HW, float temperature, float* pl, float* wm,
                          aide_stream_t stream);
+/* KLbidirection (utils/coteach_loss.py:85-92), the region cross entropy of Coteachingloss_dropregionce (:163-196; aux is one
+ * 32-bit word per 2x2 region here) and the pixel term of Coteachingloss_dropimagedroppixel (:221-252) for C classes; the
+ * selections are aide_select_smallest as in the two-class forms.  (Pixelcoreg_Focalloss reads channels 0 and 1 only in the
+ * reference itself, utils/reg_loss.py:70-99: it has no C-class form.) */
+int aide_kl_map_mc(const float* z1, int64_t b1, const float* z2, int64_t b2, int C, int N, int HW, float* out,
+                   const float* gout, float* g1, int64_t gb1, float* g2, int64_t gb2, aide_stream_t stream);
+int aide_region_ce_fwd_mc(const float* z, int64_t zb, const long long* t, int64_t tb, int C, int N, int H, int W,
+                          int ignore_index, float* loss, unsigned* aux, aide_stream_t stream);
+int aide_region_ce_bwd_mc(const float* z, int64_t zb, const unsigned* aux, const unsigned char* mask, const float* coeff,
+                          int C, int N, int H, int W, float* dz, int64_t db, aide_stream_t stream);
+int aide_droppixel_map_mc(const float* z1, int64_t b1, const float* z2, int64_t b2, const long long* t, int64_t tb,
+                          const long long* idx, int ndrop, int C, int HW, int which, int ignore_index, float* v,
+                          aide_stream_t stream);
+int aide_droppixel_bwd_mc(const float* z1, int64_t b1, const float* z2, int64_t b2, const long long* t, int64_t tb,
+                          const long long* idx, int ndrop, int C, int HW, int which, int ignore_index,
+                          const unsigned char* mask, const float* coeff, float* g1, float* g2, aide_stream_t stream);
 /* MulticlassDiceLoss with one-hot targets [N][C][HW] (utils/loss2d.py:98-104), one weighted Dice term per class */
 size_t aide_dice_terms_mc_ws_bytes(int N, int HW, int C);
 int aide_dice_terms_mc_fwd(const float* x, int64_t x_bs, const float* t, int64_t t_bs, int N, int HW, int C,

@@ -903,6 +903,40 @@ def g17_multiclass(ref_f, ref_u, ref_utils):
         fx[pre + 'ensemble/passes'] = _np(torch.stack(passes))
         fx[pre + 'ensemble/pseudo'] = _np(pl)
         fx[pre + 'ensemble/wmap'] = _np((1.0 - 4.0 * pl[:, 0] * pl[:, 1]).unsqueeze(1))
+        # the generic rank-4 co-teaching operators (utils/coteach_loss.py:85-92, 163-254) on C classes: KL map with both
+        # gradients; region CE / drop-pixel losses, each back-propagated separately, gradients w.r.t. BOTH logit tensors
+        if C <= 5:
+            import importlib
+            ref_ct = importlib.import_module('utils.coteach_loss')
+            vals = {}
+            for tag, fn in (('ref', ref_ct.KLbidirection), ('ora', oracle.KLbidirection)):
+                a1, a2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+                v = fn(a1, a2)
+                (v * torch.linspace(0.5, 1.5, v.numel()).view_as(v)).sum().backward()
+                vals[tag] = (v.detach(), a1.grad.clone(), a2.grad.clone())
+            for i in range(3):
+                _same(vals['ref'][i], vals['ora'][i], pre + 'KLbidirection #%d' % i)
+            fx[pre + 'KL/map'], fx[pre + 'KL/grad1'], fx[pre + 'KL/grad2'] = (_np(x) for x in vals['ref'])
+            for cname, kw in (('Coteachingloss_dropregionce', dict(scale=0.5, reduction='none')),
+                              ('Coteachingloss_dropimagedroppixel', dict(weight=1.0, reduction='none'))):
+                for fr in (0.25, 0.5):
+                    vals = {}
+                    for tag, mod in (('ref', ref_utils), ('ora', oracle)):
+                        out = []
+                        for which in (0, 1):
+                            a1, a2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+                            ls = getattr(mod, cname)(**kw)(a1, a2, t, fr)
+                            ls[which].backward()
+                            out += [ls[which].detach(), a1.grad.clone() if a1.grad is not None else torch.zeros_like(z1),
+                                    a2.grad.clone() if a2.grad is not None else torch.zeros_like(z2)]
+                        vals[tag] = out
+                    for i in range(6):
+                        _same(vals['ref'][i], vals['ora'][i], '%s%s fr=%g #%d' % (pre, cname, fr, i))
+                    key = '%s%s/fr%g' % (pre, cname, fr)
+                    r = vals['ref']
+                    fx[key + '/loss1'], fx[key + '/l1_grad1'], fx[key + '/l1_grad2'] = _np(r[0]), _np(r[1]), _np(r[2])
+                    fx[key + '/loss2'], fx[key + '/l2_grad1'], fx[key + '/l2_grad2'] = _np(r[3]), _np(r[4]), _np(r[5])
+                    print('g17', key, float(r[0]), float(r[3]))
         d_ref = ref_utils.Dice_fn(z1.clone(), t)
         _same(torch.as_tensor(d_ref), torch.as_tensor(oracle.Dice_fn(z1.clone(), t)), pre + 'Dice_fn')
         fx[pre + 'Dice_fn'] = _np(torch.as_tensor(d_ref))

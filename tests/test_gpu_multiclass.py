@@ -155,6 +155,38 @@ def test_golden_multiclass_models(dev, fx, name, C, nin):
     assert torch.equal(label_map(ev).cpu()[sure], torch.from_numpy(fx[name + '/labels'])[sure])
 
 
+@pytest.mark.parametrize('C', [3, 5])
+def test_golden_multiclass_rank4_operators(dev, fx, C):
+    """KLbidirection (utils/coteach_loss.py:85-92), Coteachingloss_dropregionce (:163-196) and _dropimagedroppixel (:198-254)
+    on C classes vs the real reference: the KL map and both its gradients; both losses of the two operators and, back-
+    propagated separately, their gradients w.r.t. BOTH logit tensors, forget rates 0.25 / 0.5."""
+    from aide_amd import utils as U
+    pre = 'c%d/' % C
+    z1, z2, t = (torch.from_numpy(fx[pre + k]).to(dev) for k in ('z1', 'z2', 'targets'))
+    a1, a2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+    v = U.KLbidirection(a1, a2)
+    close(v, fx[pre + 'KL/map'], rtol=2e-5, what='KL map')
+    (v * torch.linspace(0.5, 1.5, v.numel()).view_as(v).to(dev)).sum().backward()
+    close(a1.grad, fx[pre + 'KL/grad1'], rtol=2e-5, what='KL grad1')
+    close(a2.grad, fx[pre + 'KL/grad2'], rtol=2e-5, what='KL grad2')
+    for cname, kw in (('Coteachingloss_dropregionce', dict(scale=0.5, reduction='none')),
+                      ('Coteachingloss_dropimagedroppixel', dict(weight=1.0, reduction='none'))):
+        for fr in (0.25, 0.5):
+            key = '%s%s/fr%g' % (pre, cname, fr)
+            for which in (0, 1):
+                a1, a2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+                ls = getattr(U, cname)(**kw)(a1, a2, t, fr)
+                ref = float(fx[key + '/loss%d' % (which + 1)])
+                assert abs(ls[which].item() - ref) < 1e-5 * abs(ref), (key, which, ls[which].item(), ref)
+                ls[which].backward()
+                for g, gk in ((a1.grad, '/l%d_grad1' % (which + 1)), (a2.grad, '/l%d_grad2' % (which + 1))):
+                    gr = fx[key + gk]
+                    got = np.zeros_like(gr) if g is None else g.cpu().numpy()
+                    # selections may differ from the reference only between values closer than fp32 noise
+                    bad = np.abs(got - gr) > 1e-4 * np.abs(gr).max() + 1e-12
+                    assert bad.mean() < 2e-4, (key, gk, bad.sum(), np.abs(got - gr).max(), np.abs(gr).max())
+
+
 def test_class_count_limits(dev):
     from aide_amd import utils as U
     z = torch.randn(2, 9, 8, 8, device=dev)
@@ -163,5 +195,5 @@ def test_class_count_limits(dev):
         U.CrossEntropyLoss2d()(z, t)
     with pytest.raises(RuntimeError):            # nn.CrossEntropyLoss refuses a weight vector of the wrong length too
         U.CrossEntropyLoss2d(weight=torch.tensor([1.0, 2.0, 3.0]))(z[:, :4].contiguous(), t)
-    with pytest.raises(NotImplementedError):     # the rank-4 co-teaching variants have two-class kernels only
-        U.KLbidirection(z[:, :3].contiguous(), z[:, :3].contiguous())
+    with pytest.raises(NotImplementedError):     # Pixelcoreg_Focalloss reads channels 0 and 1 only in the reference itself
+        U.Pixelcoreg_Focalloss_twomodel()(z[:, :3].contiguous(), z[:, :3].contiguous(), t, 0.2, 0.5, dev)

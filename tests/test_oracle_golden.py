@@ -330,6 +330,14 @@ def test_g17_multiclass_losses(C):
             close(l1, fx['%s%s/fr%g/loss1' % (pre, cname, fr)])
             close(l2, fx['%s%s/fr%g/loss2' % (pre, cname, fr)])
     close(oracle.Dice_fn(z1.clone(), t), fx[pre + 'Dice_fn'])
+    if C <= 5:          # the generic rank-4 operators on C classes
+        close(oracle.KLbidirection(z1, z2), fx[pre + 'KL/map'], what='KL')
+        for cname, kw in (('Coteachingloss_dropregionce', dict(scale=0.5, reduction='none')),
+                          ('Coteachingloss_dropimagedroppixel', dict(weight=1.0, reduction='none'))):
+            for fr in (0.25, 0.5):
+                l1, l2 = getattr(oracle, cname)(**kw)(z1, z2, t, fr)
+                close(l1, fx['%s%s/fr%g/loss1' % (pre, cname, fr)], what=cname)
+                close(l2, fx['%s%s/fr%g/loss2' % (pre, cname, fr)], what=cname)
 
 
 @pytest.mark.parametrize('name,ctor,C,nin', [('fuseunet3', oracle.fuseunet, 3, 2), ('unet4', oracle.UNet, 4, 1)])
