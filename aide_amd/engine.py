@@ -102,6 +102,7 @@ SIDE_CUMASK = ['']               # default CU mask of the weight-gradient stream
 REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch tapes (aide_amd/tape.py); A-B switch
 HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switch: backward chain on a high-priority stream
 EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B switch: BN statistics from the conv epilogue
+SHARED_PACKS = [_os.environ.get('AIDE_SHARED_PACKS', '1') != '0']   # A-B switch: plans of an engine share packed filters; forward-only plans pack no dgrad direction
 FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
 GROUP_STATS = [_os.environ.get('AIDE_GROUP_STATS', '1') != '0']    # A-B switch: epilogue BatchNorm statistics in grouped (stacked-batch) forwards
 F4_HALF_TILES = [_os.environ.get('AIDE_F4_HALF_TILES', '0') != '0']   # A-B switch: F(4x4) on layers whose Cout is 32 mod 64
@@ -187,9 +188,13 @@ class _Cover(object):
 
 
 class Plan(object):
-    def __init__(self, graph, params, n, h, w, device, training, precision='fp32', groups=1):
+    def __init__(self, graph, params, n, h, w, device, training, precision='fp32', groups=1, shared=None):
         self.g, self.N, self.H, self.W, self.dev, self.training = graph, n, h, w, device, training
         self.precision = precision
+        # Packed filters are a function of (layer, direction, kernel family) only: the plans of one engine (the stacked
+        # augmentation pass, the training batch, an evaluation batch) share them, and a plan that finds a pack already
+        # refreshed for the current weights by another plan skips it (`shared['fresh']`: id(tensor) -> pack key).
+        self._shared = shared if shared is not None else dict(buf={}, fresh={}, streams=None)
         # groups > 1: the batch is `groups` independent forwards of n / groups images stacked along N (forward only):
         # convolutions / pooling / up-sampling run once over all of them, every BatchNorm takes its batch statistics
         # and updates its running statistics per group, in order -- the semantics of `groups` sequential forwards
@@ -198,6 +203,14 @@ class Plan(object):
         bf16 = precision == 'bf16'
         self.pindex = {id(p): i for i, p in enumerate(params)}
         f32 = dict(device=device, dtype=torch.float32)
+        forward_only = (groups > 1 or not training) and SHARED_PACKS[0]   # no backward pass will ever run on this plan: no dgrad-direction packs
+
+        def pack_buf(conv, direction, mode, make):
+            key = (id(conv), direction, mode, device.index)
+            t = self._shared['buf'].get(key)
+            if t is None:
+                t = self._shared['buf'][key] = make()
+            return t
         self.act = {}
         self.grad = {}
         self.steps = []
@@ -215,7 +228,7 @@ class Plan(object):
                 max_bnc = max(max_bnc, cout)
                 if op['kind'] == 'conv':
                     cin = src.C
-                    need_dg = not src.root.is_input
+                    need_dg = not src.root.is_input and not forward_only
                     # Winograd F(2x2,3x3) where it is supported and measured faster (16 MFMA-multiplies
                     # per output instead of 36); the direct implicit GEMM otherwise
                     st['wino_f'] = conv_mode(n, cin, hh, ww, cout)
@@ -229,28 +242,28 @@ class Plan(object):
                     st['wf'] = st['wd'] = st['uf'] = st['ud'] = None
                     st['plan_f'] = st['plan_d'] = 0
                     if st['wino_f'] == BF16:
-                        st['uf'] = ops.bf16_pack_alloc(cout, cin, device)
+                        st['uf'] = pack_buf(conv, 'f', BF16, lambda: ops.bf16_pack_alloc(cout, cin, device))
                         st['plan_f'] = lib.aide_conv3x3_bf16_splitk(n, cin, hh, ww, cout) << 8
                     elif st['wino_f'] == 4:
-                        st['uf'] = torch.empty(cin, 36, cout, **f32)
+                        st['uf'] = pack_buf(conv, 'f', 4, lambda: torch.empty(cin, 36, cout, **f32))
                         st['plan_f'] = lib.aide_conv3x3_wino4_splitk(n, cin, hh, ww, cout) << 8
                     elif st['wino_f']:
-                        st['uf'] = torch.empty(ops.pad_to(cin, 8), 16, cout, **f32)
+                        st['uf'] = pack_buf(conv, 'f', 2, lambda: torch.empty(ops.pad_to(cin, 8), 16, cout, **f32))
                         st['plan_f'] = lib.aide_conv3x3_wino_splitk(n, cin, hh, ww, cout) << 8
                     else:
-                        st['wf'] = torch.empty(ops.pad_to(cin, ops.conv_chunk(cin)), 9, cout, **f32)
+                        st['wf'] = pack_buf(conv, 'f', 0, lambda: torch.empty(ops.pad_to(cin, ops.conv_chunk(cin)), 9, cout, **f32))
                         st['plan_f'] = lib.aide_conv3x3_plan(n, cin, hh, ww, cout)
                     if need_dg and st['wino_d'] == BF16:
-                        st['ud'] = ops.bf16_pack_alloc(cin, cout, device)
+                        st['ud'] = pack_buf(conv, 'd', BF16, lambda: ops.bf16_pack_alloc(cin, cout, device))
                         st['plan_d'] = lib.aide_conv3x3_bf16_splitk(n, cout, hh, ww, cin) << 8
                     elif need_dg and st['wino_d'] == 4:
-                        st['ud'] = torch.empty(cout, 36, cin, **f32)
+                        st['ud'] = pack_buf(conv, 'd', 4, lambda: torch.empty(cout, 36, cin, **f32))
                         st['plan_d'] = lib.aide_conv3x3_wino4_splitk(n, cout, hh, ww, cin) << 8
                     elif need_dg and st['wino_d']:
-                        st['ud'] = torch.empty(ops.pad_to(cout, 8), 16, cin, **f32)
+                        st['ud'] = pack_buf(conv, 'd', 2, lambda: torch.empty(ops.pad_to(cout, 8), 16, cin, **f32))
                         st['plan_d'] = lib.aide_conv3x3_wino_splitk(n, cout, hh, ww, cin) << 8
                     elif need_dg:
-                        st['wd'] = torch.empty(ops.pad_to(cout, ops.conv_chunk(cout)), 9, cin, **f32)
+                        st['wd'] = pack_buf(conv, 'd', 0, lambda: torch.empty(ops.pad_to(cout, ops.conv_chunk(cout)), 9, cin, **f32))
                         st['plan_d'] = lib.aide_conv3x3_plan(n, cout, hh, ww, cin)
                     max_sk = max(max_sk, lib.aide_conv3x3_ws_bytes(n, hh, ww, cout, st['plan_f'] >> 8),
                                  lib.aide_conv3x3_ws_bytes(n, hh, ww, cin, st['plan_d'] >> 8) if need_dg else 0)
@@ -350,7 +363,7 @@ class Plan(object):
         self.wg_ws = None
         self._bwd_ready = False
         self.profiler = None             # set by Engine (bench.py's per-kernel HIP-event timing)
-        self._pack_key, self._pack_tab, self.side_fwd = None, None, None
+        self._pack_key, self._pack_tabs, self._pack_ids, self.side_fwd = None, {}, None, None
         self._convs = self._conv_wslots = None
         self._late_pending, self._late_inflight = None, False
         self._gate_conv = None           # the first conv that needs the side-stream filter packs
@@ -449,7 +462,8 @@ class Plan(object):
         """Refresh the packed forward/dgrad filters when any master weight changed (tensor._version for
         torch optimizers, PARAM_EPOCH for the fused Adam).  Two launches: the first few (tiny, stage-1)
         filters on the main stream, all the others on the side stream so that the 0.25 ms re-layout runs
-        under the first convolutions; returns the index of the first conv that must wait for it."""
+        under the first convolutions; returns the index of the first conv that must wait for it.
+        Packs another plan of the same engine has already refreshed for these weights (shared buffers) are skipped."""
         convs = self._convs
         if convs is None:
             convs = self._convs = [st for st in self.steps if st['kind'] == 'conv']
@@ -459,14 +473,22 @@ class Plan(object):
         if key == self._pack_key:
             return None
         ptrs = tuple(k[0] for k in key[1:])
-        if self._pack_tab is None or self._pack_tab[0] != ptrs:
-            import struct
+        fresh_map = self._shared['fresh']
+        mine = self._pack_ids
+        if mine is None:
+            mine = self._pack_ids = tuple(id(st[k]) for st in convs for k in ('wf', 'wd', 'uf', 'ud') if st[k] is not None)
+        fresh = frozenset(i for i in mine if fresh_map.get(i) == key)
+        cached = self._pack_tabs.get((ptrs, fresh))
+        if cached is None:
             split = min(4, len(convs))
 
             def tables(group, fwd=True, dgrad=True):
                 """pack tables of a group of convs; fwd / dgrad select which direction's packs they write"""
-                F = lambda st, key: st[key] if fwd else None
-                D = lambda st, key: st[key] if dgrad else None
+                def pick(st, k, on):
+                    t = st[k] if on else None
+                    return None if (t is None or id(t) in fresh) else t
+                F = lambda st, k: pick(st, k, fwd)
+                D = lambda st, k: pick(st, k, dgrad)
                 direct = [(st['conv'].weight, F(st, 'wf'), D(st, 'wd')) for st in group
                           if F(st, 'wf') is not None or D(st, 'wd') is not None]
                 # a conv may use different modes forward and backward: each table gets only its own packs
@@ -479,22 +501,25 @@ class Plan(object):
                             out.append((st['conv'].weight, uf, ud))
                     return out
                 wino, wino4, b16 = by_mode(2), by_mode(4), by_mode(BF16)
-                return (ops.pack_table(direct, self.dev) if direct else None,
+                tabs = (ops.pack_table(direct, self.dev) if direct else None,
                         ops.wino_pack_table(wino, self.dev) if wino else None,
                         ops.wino4_pack_table(wino4, self.dev) if wino4 else None,
                         ops.bf16_pack_table(b16, self.dev) if b16 else None)
+                return tabs if any(t is not None for t in tabs) else None
             rest = convs[split:]
             late = LATE_DGRAD_PACK[0] and self.training and len(rest) > 0
             # the dgrad-direction packs of all but the first convs (half of the re-layout bytes) are needed only in the
             # backward pass: they are launched when the decoder starts (first up-sampling / ConvT op), under its MFMA-bound
             # convolutions, instead of next to the HBM-bound first level
             ups = [st for st in self.steps if st['kind'] in ('up', 'convT')]
-            self._pack_tab = (ptrs, tables(convs[:split]),
-                              tables(rest, True, not late) if rest else None,
-                              convs[split] if rest else None,
-                              tables(rest, False, True) if late else None,
-                              (ups[0] if ups else self.steps[-1]) if late else None)
-        _, first, rest, gate, late_tab, late_gate = self._pack_tab
+            rest_tabs = tables(rest, True, not late) if rest else None
+            late_tabs = tables(rest, False, True) if late else None
+            cached = (tables(convs[:split]), rest_tabs, convs[split] if rest_tabs is not None else None, late_tabs,
+                      (ups[0] if ups else self.steps[-1]) if late_tabs is not None else None)
+            if len(self._pack_tabs) > 8:
+                self._pack_tabs.clear()
+            self._pack_tabs[(ptrs, fresh)] = cached
+        first, rest, gate, late_tab, late_gate = cached
         self._gate_conv = gate
 
         def launch(tabs):
@@ -512,10 +537,21 @@ class Plan(object):
                 ops.check(lib.aide_conv3x3_wino_pack_multi(ops.ptr(wn[0]), wn[1], wn[2], ops.stream_ptr()),
                           'conv3x3_wino_pack_multi')
         self._launch_pack = launch
-        launch(first)
+        if fresh:
+            # packs taken over from another plan: whatever stream(s) wrote them must be done before this forward reads them
+            # (the same main stream in every flow of this package; a plan driven from another stream pays two waits)
+            cur = torch.cuda.current_stream()
+            for s_ in self._shared['streams'] or ():
+                if s_ is not None and s_ != cur:
+                    cur.wait_stream(s_)
+        if first is not None:
+            launch(first)
         self._pack_key = key
+        for i in mine:
+            fresh_map[i] = key
         self._late_pending = (late_tab, late_gate) if late_tab is not None else None
         if rest is None:
+            self._shared['streams'] = (torch.cuda.current_stream(), None)
             return None
         if self.side_fwd is None:
             self.side_fwd = torch.cuda.Stream(device=self.dev)
@@ -524,6 +560,7 @@ class Plan(object):
         ops.order(self.ev_pack_fork, ops.stream_ptr(), self._side_fwd_ptr)
         with ops.use_stream(self._side_fwd_ptr):
             launch(rest)
+        self._shared['streams'] = (torch.cuda.current_stream(), self.side_fwd)
         return gate
 
     def _late_pack(self, st):
@@ -1083,6 +1120,7 @@ class Engine(object):
             raise NotImplementedError('aide_amd: num_classes must be 1 .. 8, got %r' % (num_classes,))
         self.module, self.build_graph, self.num_classes = module, build_graph, num_classes
         self.plans = {}
+        self._shared_packs = dict(buf={}, fresh={}, streams=None)      # packed filters shared by this engine's plans
         self.params = None
         self.grad_hook = None            # callable(flat_grad) e.g. DDP all-reduce of the whole arena
         self.after_backward_op = None    # callable(step) e.g. bucketed all-reduce overlap
@@ -1116,6 +1154,7 @@ class Engine(object):
         if value != self._precision:
             self._precision = value
             self.plans = {}
+            self._shared_packs = dict(buf={}, fresh={}, streams=None)
 
     def _refresh_params(self):
         # every forward: the known parameters are checked where they live (their owner's _parameters dict) -- walking the
@@ -1150,6 +1189,7 @@ class Engine(object):
                 off += (params[i].numel() + 3) // 4 * 4  # 16-byte aligned slots
             self.flat_numel = off
             self.plans = {}
+            self._shared_packs = dict(buf={}, fresh={}, streams=None)
             self._arena = self._views = None
 
     def plan_for(self, inputs, groups=1):
@@ -1168,7 +1208,7 @@ class Engine(object):
                         raise RuntimeError('aide_amd: %dx%d is too large: %d channels of %s exceed the 2 GiB per-image '
                                            'operand limit of the kernels' % (h, w, t.C, t.name))
             plan = Plan(self.graph, self.params, n, h, w, x.device, bool(self.module.training), self._precision,
-                        groups)
+                        groups, shared=self._shared_packs if SHARED_PACKS[0] else None)
             plan.key = key
             self.plans[key] = plan
             # a plan owns full activation (+ gradient) buffers: ragged last batches / many input shapes must not pile
