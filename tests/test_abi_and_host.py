@@ -238,3 +238,22 @@ def test_keep_largest_connected_components():
     out = keep(tie)
     assert out[0, 0:2, 0].all() and out.sum() == 2
     assert keep(np.zeros((4, 4, 2), dtype=np.int64)).sum() == 0
+
+
+def test_class_weight_host_logic():
+    """utils/_seg.py: class-weight arguments of the loss modules -- two classes stay the (w0, w1) pair of the specialised
+    kernels, more travel as a tuple; the host array handed to the *_mc entry points has exactly C entries."""
+    from aide_amd.utils import _seg
+    assert _seg.class_weights(None) == (1.0, 1.0)
+    assert _seg.class_weights(torch.tensor([1.0, 3.0])) == (1.0, 3.0)
+    w0, w1 = _seg.class_weights([1.0, 2.0, 0.5])
+    assert w1 is None and w0 == (1.0, 2.0, 0.5)
+    arr = _seg.class_w_array(w0, w1, 3)
+    assert len(arr) == 3 and [float(v) for v in arr] == [1.0, 2.0, 0.5]
+    assert [float(v) for v in _seg.class_w_array(1.0, 1.0, 5)] == [1.0] * 5         # unweighted: any class count
+    with pytest.raises(RuntimeError):
+        _seg.class_w_array(w0, w1, 4)                                               # 3 weights, 4 classes
+    with pytest.raises(RuntimeError):
+        _seg.class_w_array(1.0, 3.0, 3)                                             # a 2-class pair on 3 classes
+    with pytest.raises(NotImplementedError):
+        _seg.class_weights([1.0] * 9)

@@ -77,10 +77,11 @@ def test_proposed_coteaching_step(dev):
 
 
 def test_coteaching_two_streams_is_bit_identical(dev):
-    """Network 2 on its own stream (AIDE_COTEACH_STREAMS, the default) is a schedule, not a different computation: three
-    steps from the same initial state give bit-identical losses, selections and parameters of BOTH networks as the
-    single-stream order -- any missing cross-stream dependency (inputs, optimizer update, engine-assigned gradients) would
-    show here."""
+    """Network 2 on its own stream (AIDE_COTEACH_STREAMS, the default) and packed filters shared between a network's plans
+    (AIDE_SHARED_PACKS, the default) are schedules, not different computations: three steps from the same initial state give
+    bit-identical losses, selections and parameters of BOTH networks as the single-stream order with private packs -- any
+    missing cross-stream dependency (inputs, optimizer update, engine-assigned gradients) or a stale shared pack would show
+    here."""
     from aide_amd.models_twomodalinputs import fuseunet
     from aide_amd.optim import Adam
     from aide_amd.utils import CoTeachingProposedLoss
@@ -94,10 +95,12 @@ def test_coteaching_two_streams_is_bit_identical(dev):
         augset['hflip%d' % (k + 1)] = [(k + b) % 2 for b in range(n)]
         augset['degree%d' % (k + 1)] = [15.0 * (k + 1) - 7.0 * b for b in range(n)]
     res = {}
-    old = M.TWO_NET_STREAMS[0]
+    from aide_amd import engine as E
+    old, old_sp = M.TWO_NET_STREAMS[0], E.SHARED_PACKS[0]
     try:
         for two in (False, True):
             M.TWO_NET_STREAMS[0] = two
+            E.SHARED_PACKS[0] = two          # ... and with every plan packing its own filters (both directions) vs shared packs
             torch.manual_seed(2)
             n1, n2 = fuseunet(2).to(dev), fuseunet(2).to(dev)
             n1.train(); n2.train()
@@ -111,7 +114,7 @@ def test_coteaching_two_streams_is_bit_identical(dev):
             res[two] = (trace, [p.detach().clone() for p in list(n1.parameters()) + list(n2.parameters())],
                         [b.detach().clone() for b in list(n1.buffers()) + list(n2.buffers())])
     finally:
-        M.TWO_NET_STREAMS[0] = old
+        M.TWO_NET_STREAMS[0], E.SHARED_PACKS[0] = old, old_sp
     for a, b in zip(res[False][0], res[True][0]):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
     assert all(torch.equal(x, y) for x, y in zip(res[False][1], res[True][1]))
