@@ -43,7 +43,9 @@ int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, c
 int aide_conv3x3_wino_supported(int Cin, int H, int W, int Cout);
 int aide_conv3x3_wino_splitk(int N, int Cin, int H, int W, int Cout);
 /* Winograd F(4x4,3x3) variant for the large layers (36 multiplies per 16 outputs): H % 4 == 0, W % 4 == 0,
- * H >= 16, W >= 32, Cout % 32 == 0 (a trailing half block of 32 is computed and dropped), Cin % 8 == 0.  Filters: uf [Ci/4][36][Co][4 ci], ud [Co/4][36][Ci][4 co]
+ * H >= 16, W >= 16, Cout % 32 == 0 (a trailing half block of 32 is computed and dropped), Cin % 8 == 0; W == 16 needs an even N
+ * (two images per workgroup tile).  Workgroup tile = 32 slots of 4x4 outputs: 16 x 32 pixels, or a 20 x 20 canvas (25 slots used)
+ * where that covers the plane with fewer tiles (20 x 20, 40 x 40, ... planes).  Filters: uf [Ci/4][36][Co][4 ci], ud [Co/4][36][Ci][4 co]
  * (allocated as [C][36][C']); pack descriptors as above with {w, uf|0, ud|0, Co, Ci, 0, 0, block_start}.
  * splitk must divide Cin / 8. */
 int aide_conv3x3_wino4_supported(int Cin, int H, int W, int Cout);
