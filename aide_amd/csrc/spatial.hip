@@ -245,7 +245,12 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const GT* __r
                                                                    DT* __restrict__ dx, long dx_bs, int C, int H,
                                                                    int W, int tiles_w, int accumulate) {
     constexpr int HW2 = UB_RW / 2;                          // 66 column pairs
-    __shared__ float te[UB_RH][HW2 + 1], to[UB_RH][HW2 + 1];
+    // bf16-stored gradients keep their two bytes in the window: one packed word per column pair instead of two floats --
+    // 21 KB of LDS per workgroup instead of 31 KB, i.e. seven resident workgroups per CU instead of five (and more of them
+    // beside the weight-gradient workgroups of the side stream, where this kernel ran at 1.3 TB/s)
+    constexpr bool PK = sizeof(GT) == 2;
+    __shared__ float te[PK ? 1 : UB_RH][HW2 + 1], to[PK ? 1 : UB_RH][HW2 + 1];
+    __shared__ unsigned tp[PK ? UB_RH : 1][HW2 + 1];
     __shared__ float hp[UB_RH][UB_TW + 1];
     const int Ho = 2 * H, Wo = 2 * W;
     const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
@@ -272,22 +277,40 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const GT* __r
     // all ten loads of a thread are issued before the first LDS store (a load -> wait -> store loop exposed the full
     // memory latency ten times per workgroup: 0.9 TB/s); out-of-plane elements read a clamped address and are zeroed
     constexpr int NLD = (UB_RH * HW2 + 255) / 256;
-    float2 v[NLD];
+    if constexpr (PK) {
+        unsigned v[NLD];
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int e = tid + k * 256;
-        const int r = e / HW2, c2 = e - r * HW2;
-        const int oh = R0 + r, ow = C0 + 2 * c2;
-        const bool ok = e < UB_RH * HW2 && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
-        const f32x2 t = ld2(g + (ok ? (long)oh * Wo + ow : 0L));
-        v[k] = ok ? make_float2(t[0], t[1]) : make_float2(0.f, 0.f);
-    }
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int e = tid + k * 256;
-        if (e < UB_RH * HW2) {
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * 256;
             const int r = e / HW2, c2 = e - r * HW2;
-            te[r][c2] = v[k].x; to[r][c2] = v[k].y;
+            const int oh = R0 + r, ow = C0 + 2 * c2;
+            const bool ok = e < UB_RH * HW2 && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
+            const unsigned t = *reinterpret_cast<const unsigned*>(g + (ok ? (long)oh * Wo + ow : 0L));
+            v[k] = ok ? t : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * 256;
+            if (e < UB_RH * HW2) tp[e / HW2][e % HW2] = v[k];
+        }
+    } else {
+        float2 v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * 256;
+            const int r = e / HW2, c2 = e - r * HW2;
+            const int oh = R0 + r, ow = C0 + 2 * c2;
+            const bool ok = e < UB_RH * HW2 && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
+            const f32x2 t = ld2(g + (ok ? (long)oh * Wo + ow : 0L));
+            v[k] = ok ? make_float2(t[0], t[1]) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * 256;
+            if (e < UB_RH * HW2) {
+                const int r = e / HW2, c2 = e - r * HW2;
+                te[r][c2] = v[k].x; to[r][c2] = v[k].y;
+            }
         }
     }
     __syncthreads();
@@ -297,9 +320,17 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const GT* __r
     const int oc = otab[UB_TH + x];                         // first candidate column inside the window
     // column pass: hp[r][x] = sum_l wc[l] * window[r][oc + l]; window column q lives in (q & 1 ? to : te)[r][q >> 1]
     const int q0 = oc >> 1;                                 // oc is even: candidates start at max(0, 2 i - 2), C0 is even
-    for (int r = rq; r < UB_RH; r += 4)
-        hp[r][x] = wc[0] * te[r][q0] + wc[1] * to[r][q0] + wc[2] * te[r][q0 + 1] + wc[3] * to[r][q0 + 1] +
-                   wc[4] * te[r][q0 + 2] + wc[5] * to[r][q0 + 2];
+    for (int r = rq; r < UB_RH; r += 4) {
+        if constexpr (PK) {
+            const unsigned a = tp[r][q0], b = tp[r][q0 + 1], d = tp[r][q0 + 2];       // (even | odd << 16) column pairs
+            hp[r][x] = wc[0] * __builtin_bit_cast(float, a << 16) + wc[1] * __builtin_bit_cast(float, a & 0xffff0000u) +
+                       wc[2] * __builtin_bit_cast(float, b << 16) + wc[3] * __builtin_bit_cast(float, b & 0xffff0000u) +
+                       wc[4] * __builtin_bit_cast(float, d << 16) + wc[5] * __builtin_bit_cast(float, d & 0xffff0000u);
+        } else {
+            hp[r][x] = wc[0] * te[r][q0] + wc[1] * to[r][q0] + wc[2] * te[r][q0 + 1] + wc[3] * to[r][q0 + 1] +
+                       wc[4] * te[r][q0 + 2] + wc[5] * to[r][q0 + 2];
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int k4 = 0; k4 < UB_TH / 4; ++k4) {
