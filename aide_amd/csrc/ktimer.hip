@@ -112,4 +112,17 @@ int aide_stream_order(void* ev, hipStream_t from, hipStream_t to) {
     return (int)rc;
 }
 
+// the two halves of aide_stream_order as separate calls: the record sits right behind the producer on `from`, the wait is
+// enqueued on `to` only where the consumer is -- work enqueued on `to` in between does not wait (a wait on an event that
+// was never recorded is a no-op in HIP, so the caller records first)
+int aide_event_record(void* ev, hipStream_t from) {
+    if (!ev) return AIDE_ERR_ARG;
+    return (int)hipEventRecord((hipEvent_t)ev, from);
+}
+
+int aide_stream_wait_event(hipStream_t to, void* ev) {
+    if (!ev) return AIDE_ERR_ARG;
+    return (int)hipStreamWaitEvent(to, (hipEvent_t)ev, 0);
+}
+
 }  // extern "C"

@@ -63,8 +63,11 @@ class Graph(object):
     def convT_bn_relu(self, src, dst, conv, bn):
         self.ops.append(dict(kind='convT', src=src, dst=dst, conv=conv, bn=bn))
 
-    def pool(self, src, dst):
-        self.ops.append(dict(kind='pool', src=src, dst=dst))
+    def pool(self, src, dst, lane_split=None):
+        """lane_split = c: channels [0, c) of src were written by lane-0 ops, [c, C) by the lane-1 chain.  Max-pooling is per
+        channel, so the forward pass may pool each part on the stream that produced it: lane 1 then runs from level to level
+        without waiting for lane 0 (Plan._forward_impl); the backward pass treats the op as one."""
+        self.ops.append(dict(kind='pool', src=src, dst=dst, lane_split=lane_split))
 
     def upsample(self, src, dst):
         self.ops.append(dict(kind='up', src=src, dst=dst))
@@ -109,6 +112,7 @@ F4_HALF_TILES = [_os.environ.get('AIDE_F4_HALF_TILES', '0') != '0']   # A-B swit
 W16_PAIRS = [_os.environ.get('AIDE_W16_PAIRS', '0') != '0']      # F(4x4) on the 16-pixel-wide level (image pairs per tile): 11 % faster per launch than F(2x2), -0.6 % on the C2 step (larger filter pack, more slabs for BatchNorm to sum): off
 DUAL_BWD = [_os.environ.get('AIDE_DUAL_BWD', '0') != '0']        # ... and of the backward pass (measured +-0 beside the weight-gradient stream: off)
 DUAL_FWD = [_os.environ.get('AIDE_DUAL_FWD', '1') != '0']        # A-B switch: lane-1 chains of the forward pass on a second stream
+FREE_LANE = [_os.environ.get('AIDE_FREE_LANE', '1') != '0']      # A-B switch: lane 1 pools its own channels and runs ahead (no fork / join per level)
 FOLD_SPLITK_BWD = [_os.environ.get('AIDE_FOLD_SPLITK_BWD', '1') != '0']   # ... and BatchNorm backward the data-gradient slabs
 FLUSH_EVERY = int(_os.environ.get('AIDE_WGRAD_FLUSH_EVERY', '6'))      # layers per batched slab reduce
 
@@ -359,6 +363,9 @@ class Plan(object):
             self.bn_ws_b = ops.bn_ws(max(max_bnc, 1), device)
             self.sk_ws_b = torch.empty(max(max_sk // 4, 1), **f32)
             self.ev_lane_fork, self.ev_lane_join, self.ev_lane_acc = ops.new_event(), ops.new_event(), ops.new_event()
+            for st in self.steps:        # one event per split pooling op: "lane 1's half of this level is pooled"
+                if st['kind'] == 'pool' and st.get('lane_split'):
+                    st['ev_b'] = ops.new_event()
         self._max_dz, self._max_wg = max_dz, max_wg
         self.wg_ws = None
         self._bwd_ready = False
@@ -577,7 +584,7 @@ class Plan(object):
     def _fingerprint(self):
         """addresses of every parameter and buffer the launch sequence bakes in (a tape is only valid for these)"""
         # ... and everything else a recorded sequence depends on: the runtime schedule switches and the BatchNorm scalars
-        fp = [DUAL_FWD[0], DUAL_BWD[0], FOLD_SPLITK[0], FOLD_SPLITK_BWD[0], DEFER_WGRAD_REDUCE[0], FLUSH_EVERY,
+        fp = [DUAL_FWD[0], FREE_LANE[0], DUAL_BWD[0], FOLD_SPLITK[0], FOLD_SPLITK_BWD[0], DEFER_WGRAD_REDUCE[0], FLUSH_EVERY,
               HEAD_WGRAD_SIDE[0], EPILOGUE_STATS[0], self.overlap]
         # (this runs every forward: the tensors are looked up through the modules' own _parameters / _buffers dicts -- a
         # replaced parameter or buffer is seen -- without walking the module tree)
@@ -633,10 +640,39 @@ class Plan(object):
         dual = self.lane_b is not None and DUAL_FWD[0] and self.profiler is None and self.trace is None
         mp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         bp = ctypes.c_void_p(self.lane_b.cuda_stream) if dual else None
+        # Free-running lane 1 (FREE_LANE): a pooling op whose source holds lane-0 channels [0, c) and lane-1 channels [c, C)
+        # runs as two launches, each on the stream that produced its channels.  Lane 1 then never waits for lane 0 after the
+        # first fork (its next level reads only what it pooled itself), and lane 0 waits for lane 1 exactly where it reads
+        # lane 1's pooled channels -- on an event recorded right behind that pooling launch, not on lane 1's tail.  (With one
+        # pooling launch per level on the main stream each level cost a join + a fork: ~35 us of idle time per lane and level.)
+        free = dual and FREE_LANE[0]
         on_b, pend = False, []
+        forked = False        # free: lane 1 has been ordered behind the main stream (since the last event that needs it again)
+        touched = []          # free: ranges lane-0 ops read or wrote since the last fork
+        b_reads = []          # free: ranges lane-1 ops read since the last join
+        pooled = []           # free: (root, c0, C, event) of lane-1 pooling halves the main stream has not waited for yet
+
+        def hit(ranges, t):
+            return any(r[0] is t.root and r[1] < t.c0 + t.C and t.c0 < r[1] + r[2] for r in ranges)
 
         def overlaps(t):
-            return any(r is t.root and c0 < t.c0 + t.C and t.c0 < c0 + c for r, c0, c in pend)
+            return hit(pend, t)
+
+        def fork_if_needed(srcs, dsts):
+            nonlocal forked
+            if not forked or any(hit(touched, t) for t in srcs + dsts):
+                ops.order(self.ev_lane_fork, mp, bp)
+                forked = True
+                del touched[:]
+
+        def main_deps(srcs, dsts):
+            """order the main stream behind whatever lane 1 work the op depends on"""
+            if any(hit(pend, t) for t in srcs + dsts) or any(hit(b_reads, t) for t in dsts):
+                ops.order(self.ev_lane_join, bp, mp)
+                del pend[:], b_reads[:], pooled[:]
+            for e in [e for e in pooled if any(hit([e], t) for t in srcs + dsts)]:
+                ops.wait(mp, e[3])
+                pooled.remove(e)
         for st in self.steps:
             kind = st['kind']
             if self.trace is not None:
@@ -650,7 +686,34 @@ class Plan(object):
                     tape.py(wait, 'gate')
                 if gate is not None:
                     wait()
-                on_b = False                  # a gate conv on lane 1 re-forks: its lane must see the wait as well
+                on_b = forked = False         # a gate conv on lane 1 re-forks: its lane must see the wait as well
+            if free:
+                srcs = [st['src']]
+                dsts = [st['dst']] if st.get('dst') is not None else []
+                c = st.get('lane_split') if kind == 'pool' else None
+                if c and forked:
+                    src, dst = st['src'], st['dst']
+                    sa, da, sb, db = src.slice(0, c), dst.slice(0, c), src.slice(c, src.C - c), dst.slice(c, dst.C - c)
+                    fork_if_needed([sb], [db])
+                    with ops.use_stream(bp):
+                        ops.maxpool2x2_fwd(self.view(sb, inputs), self.view(db))
+                    ops.record(st['ev_b'], bp)
+                    pooled.append((db.root, db.c0, db.C, st['ev_b']))
+                    b_reads.append((sb.root, sb.c0, sb.C))
+                    main_deps([sa], [da])
+                    ops.maxpool2x2_fwd(self.view(sa, inputs), self.view(da))
+                    touched.extend((t.root, t.c0, t.C) for t in (sa, da))
+                elif lane:
+                    fork_if_needed(srcs, dsts)
+                    pend.extend((t.root, t.c0, t.C) for t in dsts)
+                    b_reads.extend((t.root, t.c0, t.C) for t in srcs)
+                    with ops.use_stream(bp):
+                        self._forward_op(st, inputs, out, self.bn_ws_b, self.sk_ws_b)
+                else:
+                    main_deps(srcs, dsts)
+                    touched.extend((t.root, t.c0, t.C) for t in srcs + dsts)
+                    self._forward_op(st, inputs, out, self.bn_ws, self.sk_ws)
+                continue
             if lane and not on_b:
                 ops.order(self.ev_lane_fork, mp, bp)
             on_b = bool(lane)
@@ -663,7 +726,7 @@ class Plan(object):
                     self._forward_op(st, inputs, out, self.bn_ws_b, self.sk_ws_b)
             else:
                 self._forward_op(st, inputs, out, self.bn_ws, self.sk_ws)
-        if pend:
+        if pend or pooled:
             ops.order(self.ev_lane_join, bp, mp)
         if self._late_pending is not None:
             self._late_pack(None)

@@ -77,7 +77,8 @@ class fuseunet(nn.Module):
                     g.conv_bn_relu(t, d, blk.conv2, blk.bn2, lane=lane)
             if s < 5:
                 p = g.tensor('pool_s%d' % s, skip.C, s)
-                g.pool(skip, p)
+                # (channels [0, c1) of the skip come from modal-1's chain, the rest from modal-2's: see Graph.pool)
+                g.pool(skip, p, lane_split=None if self._ATTENTION else c1[s - 1])
                 # max-pool is per channel: both encoders of fuseunetsaseparate read their own slice of pool(cat(y, x))
                 src1 = p.slice(0, c1[s - 1]) if self._SEPARATE else p
                 src2 = p.slice(c1[s - 1], c2[s - 1])

@@ -59,6 +59,16 @@ def order(ev, src, dst):
     check(lib.aide_stream_order(ev, src, dst), 'stream_order')
 
 
+def record(ev, src):
+    """mark the work enqueued on stream `src` so far (first half of order())"""
+    check(lib.aide_event_record(ev, src), 'event_record')
+
+
+def wait(dst, ev):
+    """work enqueued on stream `dst` from now on waits for the work marked by record(ev, .) (second half of order())"""
+    check(lib.aide_stream_wait_event(dst, ev), 'stream_wait_event')
+
+
 def _req(t, dtype=torch.float32):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError('aide_amd ops need HIP device tensors (got %s); there is no CPU fallback'

@@ -244,6 +244,10 @@ int aide_dice_terms_bwd(const float* x, int64_t x_bs, const float* t, int64_t t_
 int aide_event_create(void** ev);
 int aide_event_destroy(void* ev);
 int aide_stream_order(void* ev, aide_stream_t from, aide_stream_t to);
+/* the two halves as separate calls (record first): the free-running second lane of the forward pass records an event
+ * behind each of its pooling halves and the main stream waits for it only in front of the first reader */
+int aide_event_record(void* ev, aide_stream_t from);
+int aide_stream_wait_event(aide_stream_t to, void* ev);
 
 /* ---- CU-masked stream (host pointers) ---------------------------------------------------------------------------
  * A HIP stream restricted to the compute units whose bits are set in mask[words] (hipExtStreamCreateWithCUMask).  The
