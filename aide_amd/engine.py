@@ -111,6 +111,8 @@ GROUP_STATS = [_os.environ.get('AIDE_GROUP_STATS', '1') != '0']    # A-B switch:
 F4_HALF_TILES = [_os.environ.get('AIDE_F4_HALF_TILES', '0') != '0']   # A-B switch: F(4x4) on layers whose Cout is 32 mod 64
 W16_PAIRS = [_os.environ.get('AIDE_W16_PAIRS', '0') != '0']      # F(4x4) on the 16-pixel-wide level (image pairs per tile): 11 % faster per launch than F(2x2), -0.6 % on the C2 step (larger filter pack, more slabs for BatchNorm to sum): off
 DUAL_BWD = [_os.environ.get('AIDE_DUAL_BWD', '0') != '0']        # ... and of the backward pass (measured +-0 beside the weight-gradient stream: off)
+DUAL_BWD_MAXLEVEL = [int(_os.environ.get('AIDE_DUAL_BWD_MAXLEVEL', '9'))]   # ... only for the ops of levels <= this (0: the tail of the pass, where nothing is left to overlap the second encoder's chain with)
+EARLY_FLUSH = [_os.environ.get('AIDE_EARLY_FLUSH', '0') != '0']   # A-B switch: the slab reduces still queued go out behind the LAST Winograd weight gradient, not behind the last kernel of the pass
 DUAL_FWD = [_os.environ.get('AIDE_DUAL_FWD', '1') != '0']        # A-B switch: lane-1 chains of the forward pass on a second stream
 FREE_LANE = [_os.environ.get('AIDE_FREE_LANE', '1') != '0']      # A-B switch: lane 1 pools its own channels and runs ahead (no fork / join per level)
 FOLD_SPLITK_BWD = [_os.environ.get('AIDE_FOLD_SPLITK_BWD', '1') != '0']   # ... and BatchNorm backward the data-gradient slabs
@@ -584,7 +586,7 @@ class Plan(object):
     def _fingerprint(self):
         """addresses of every parameter and buffer the launch sequence bakes in (a tape is only valid for these)"""
         # ... and everything else a recorded sequence depends on: the runtime schedule switches and the BatchNorm scalars
-        fp = [DUAL_FWD[0], FREE_LANE[0], DUAL_BWD[0], FOLD_SPLITK[0], FOLD_SPLITK_BWD[0], DEFER_WGRAD_REDUCE[0], FLUSH_EVERY,
+        fp = [DUAL_FWD[0], FREE_LANE[0], DUAL_BWD[0], DUAL_BWD_MAXLEVEL[0], EARLY_FLUSH[0], FOLD_SPLITK[0], FOLD_SPLITK_BWD[0], DEFER_WGRAD_REDUCE[0], FLUSH_EVERY,
               HEAD_WGRAD_SIDE[0], EPILOGUE_STATS[0], self.overlap]
         # (this runs every forward: the tensors are looked up through the modules' own _parameters / _buffers dicts -- a
         # replaced parameter or buffer is seen -- without walking the module tree)
@@ -913,11 +915,20 @@ class Plan(object):
                     after_op(w_st)
             del waiting[:]
 
+        # the last op whose weight gradient leaves slabs of any size (Winograd kernels): what is still queued goes out right
+        # behind it, under the direct / stem weight gradients of the first level -- not as one more launch behind the
+        # last kernel of the pass (the tail of the step: 51 -> ~10 us on the FuseUNet step)
+        last_big = None
+        if defer and EARLY_FLUSH[0]:
+            for st in self.steps:
+                if st['kind'] == 'conv' and st.get('wino_w') in (2, 4):
+                    last_big = st
+                    break
         hook = after_op
         if defer:
             def hook(w_st):
                 waiting.append(w_st)
-                if pending() >= FLUSH_EVERY:
+                if pending() >= FLUSH_EVERY or (w_st is last_big and pending()):
                     flush()
         if defer:
             lib.aide_wgrad_reduce_defer(1)
@@ -953,8 +964,9 @@ class Plan(object):
 
         def overlaps(t):
             return t is not None and any(r is t.root and c0 < t.c0 + t.C and t.c0 < c0 + c for r, c0, c in pend)
+        maxlev = DUAL_BWD_MAXLEVEL[0]
         for st in reversed(self.steps):
-            lane = st.get('lane', 0) if dual else 0
+            lane = st.get('lane', 0) if (dual and st['src'].level <= maxlev) else 0
             sg = st.get('src_grad')
             if self.trace is not None:
                 self.trace('b', st)
@@ -970,7 +982,7 @@ class Plan(object):
                     ops.order(self.ev_lane_join, bp, main)
                     del pend[:]
                 self._backward_op(st, inputs, dlogits, gslot, main, side, self.bn_ws, self.sk_ws, fold[0])
-                if dual and st['kind'] != 'conv':
+                if dual and st['kind'] != 'conv' and st['src'].level <= maxlev:
                     ops.order(self.ev_lane_fork, main, bp)     # the gradients this op wrote release lane 1
             if after_op is not None:
                 after_op(st)
