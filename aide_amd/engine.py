@@ -113,6 +113,7 @@ W16_PAIRS = [_os.environ.get('AIDE_W16_PAIRS', '0') != '0']      # F(4x4) on the
 DUAL_BWD = [_os.environ.get('AIDE_DUAL_BWD', '0') != '0']        # ... and of the backward pass (measured +-0 beside the weight-gradient stream: off)
 DUAL_BWD_MAXLEVEL = [int(_os.environ.get('AIDE_DUAL_BWD_MAXLEVEL', '9'))]   # ... only for the ops of levels <= this (0: the tail of the pass, where nothing is left to overlap the second encoder's chain with)
 EARLY_FLUSH = [_os.environ.get('AIDE_EARLY_FLUSH', '0') != '0']   # A-B switch: the slab reduces still queued go out behind the LAST Winograd weight gradient, not behind the last kernel of the pass
+TAIL_WGRAD_MAIN = [_os.environ.get('AIDE_TAIL_WGRAD_MAIN', '1') != '0']   # A-B switch: the weight gradient of the LAST op of the backward pass (a stem conv: no data gradient) on the main stream, which has nothing left to do, beside the weight-gradient stream's backlog
 DUAL_FWD = [_os.environ.get('AIDE_DUAL_FWD', '1') != '0']        # A-B switch: lane-1 chains of the forward pass on a second stream
 FREE_LANE = [_os.environ.get('AIDE_FREE_LANE', '1') != '0']      # A-B switch: lane 1 pools its own channels and runs ahead (no fork / join per level)
 FOLD_SPLITK_BWD = [_os.environ.get('AIDE_FOLD_SPLITK_BWD', '1') != '0']   # ... and BatchNorm backward the data-gradient slabs
@@ -586,7 +587,7 @@ class Plan(object):
     def _fingerprint(self):
         """addresses of every parameter and buffer the launch sequence bakes in (a tape is only valid for these)"""
         # ... and everything else a recorded sequence depends on: the runtime schedule switches and the BatchNorm scalars
-        fp = [DUAL_FWD[0], FREE_LANE[0], DUAL_BWD[0], DUAL_BWD_MAXLEVEL[0], EARLY_FLUSH[0], FOLD_SPLITK[0], FOLD_SPLITK_BWD[0], DEFER_WGRAD_REDUCE[0], FLUSH_EVERY,
+        fp = [DUAL_FWD[0], FREE_LANE[0], DUAL_BWD[0], DUAL_BWD_MAXLEVEL[0], EARLY_FLUSH[0], TAIL_WGRAD_MAIN[0], FOLD_SPLITK[0], FOLD_SPLITK_BWD[0], DEFER_WGRAD_REDUCE[0], FLUSH_EVERY,
               HEAD_WGRAD_SIDE[0], EPILOGUE_STATS[0], self.overlap]
         # (this runs every forward: the tensors are looked up through the modules' own _parameters / _buffers dicts -- a
         # replaced parameter or buffer is seen -- without walking the module tree)
@@ -937,6 +938,8 @@ class Plan(object):
             with ops.use_stream(mp):
                 self._backward_ops(inputs, dlogits, gslot, mp, sp, hook)
             if defer:
+                if side is not None and TAIL_WGRAD_MAIN[0]:
+                    ops.order(self.ev_fork, mp, sp)       # the last weight gradient may have left its slabs on the main stream
                 flush()
             done = True
         finally:
@@ -1031,7 +1034,11 @@ class Plan(object):
                     wgrad = (ops.conv3x3_wgrad_bf16 if st['wino_w'] == BF16 else
                              ops.conv3x3_wgrad_wino4 if st['wino_w'] == 4 else
                              ops.conv3x3_wgrad_wino if st['wino_w'] else ops.conv3x3_wgrad)
-                    if side is not None:
+                    # the last op of the pass, when it has no data gradient (a stem conv): the dependent chain ends with its
+                    # BatchNorm backward, so its weight gradient runs on that stream beside whatever the weight-gradient
+                    # stream still has queued instead of behind it
+                    tail = TAIL_WGRAD_MAIN[0] and st is self.steps[0] and sg is None and prof is None
+                    if side is not None and not tail:
                         ops.order(st['ev'], main, side)
                         with ops.use_stream(side):
                             if prof is not None:
@@ -1067,7 +1074,11 @@ class Plan(object):
                         if st['fold_dgrad']:
                             folded[0] = st['plan_d'] >> 8
                 else:
-                    if side is not None:
+                    # the last op of the pass, when it has no data gradient (a stem conv): the dependent chain ends with its
+                    # BatchNorm backward, so its weight gradient runs on that stream beside whatever the weight-gradient
+                    # stream still has queued instead of behind it
+                    tail = TAIL_WGRAD_MAIN[0] and st is self.steps[0] and sg is None and prof is None
+                    if side is not None and not tail:
                         ops.order(st['ev'], main, side)
                         with ops.use_stream(side):
                             ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=st['wg_ws'])

@@ -338,18 +338,20 @@ def test_two_lane_schedules_are_bit_identical(dev):
     xs = [torch.randn(4, 3, 128, 128, generator=g).to(dev) for _ in range(2)]
     t = (torch.rand(4, 128, 128, generator=g) > 0.8).long().to(dev)
     w = torch.tensor([1.0, 1.0])
-    saved = (engine.DUAL_FWD[0], engine.DUAL_BWD[0], engine.FREE_LANE[0], engine.DUAL_BWD_MAXLEVEL[0], engine.EARLY_FLUSH[0])
+    saved = (engine.DUAL_FWD[0], engine.DUAL_BWD[0], engine.FREE_LANE[0], engine.DUAL_BWD_MAXLEVEL[0], engine.EARLY_FLUSH[0],
+             engine.TAIL_WGRAD_MAIN[0])
     results = []
     try:
         # (free: lane 1 pools its own channels and runs from level to level without a fork / join per level)
         # (maxlev: the backward lanes only for the ops of levels <= maxlev; early: the queued slab reduces behind the last
         # Winograd weight gradient instead of behind the last kernel)
-        for fwd, bwd, free, maxlev, early in ((False, False, False, 9, False), (True, False, False, 9, True),
-                                              (True, False, True, 9, True), (True, True, True, 9, True),
-                                              (True, True, False, 0, False), (True, True, True, 0, True),
-                                              (True, False, True, 9, False)):
+        # tailm: the last op's weight gradient on the main stream instead of behind the weight-gradient stream's backlog
+        for fwd, bwd, free, maxlev, early, tailm in (
+                (False, False, False, 9, False, False), (True, False, False, 9, True, True), (True, False, True, 9, True, False),
+                (True, True, True, 9, True, True), (True, True, False, 0, False, False), (True, True, True, 0, True, True),
+                (True, False, True, 9, False, True)):
             engine.DUAL_FWD[0], engine.DUAL_BWD[0], engine.FREE_LANE[0] = fwd, bwd, free
-            engine.DUAL_BWD_MAXLEVEL[0], engine.EARLY_FLUSH[0] = maxlev, early
+            engine.DUAL_BWD_MAXLEVEL[0], engine.EARLY_FLUSH[0], engine.TAIL_WGRAD_MAIN[0] = maxlev, early, tailm
             for plan in net.engine.plans.values():
                 plan._tape_f = plan._tape_b = None           # the recorded launch sequence bakes the schedule in
             outs = []
@@ -362,7 +364,7 @@ def test_two_lane_schedules_are_bit_identical(dev):
             torch.cuda.synchronize()
     finally:
         (engine.DUAL_FWD[0], engine.DUAL_BWD[0], engine.FREE_LANE[0], engine.DUAL_BWD_MAXLEVEL[0],
-         engine.EARLY_FLUSH[0]) = saved
+         engine.EARLY_FLUSH[0], engine.TAIL_WGRAD_MAIN[0]) = saved
     for other in results[1:]:
         for a, b in zip(results[0], other):
             assert torch.equal(a, b)
