@@ -417,28 +417,39 @@ int aide_conv3x3_wgrad_wino4_supported(int Co, int Ci, int H, int W) {
     return (H % 4 == 0 && W % 4 == 0 && H >= 8 && W >= 16 && Co % 32 == 0 && Ci % 32 == 0) ? 1 : 0;
 }
 
-int aide_conv3x3_wgrad_wino4_splits(int N, int Co, int Ci, int H, int W) {
+// Workgroups per launch.  One per CU (256) is NOT the optimum for a kernel that lives on the side stream: its 144 KB
+// workgroups own a CU and keep the main stream's kernels off it.  With 128 the weight gradient takes half of the chip
+// for twice as long and the dependent chain (BatchNorm backward, dgrad, pooling / up-sampling backward) runs on the
+// other half undisturbed: same-box C2 step 537 -> 566 images/s (256 -> 128; 192: 552, 144: 550, 112: 552, 96: 525,
+// 64: 448, 384: 526, 512: 520), co-teaching step 123.7 -> 126.9.  (Probe switch AIDE_WG4_TARGET.)
+// target <= 0: that default.  A caller that knows nothing is left to share the chip with (the last such launch of a
+// backward pass whose dependent chain has already ended) asks for 256.
+int aide_conv3x3_wgrad_wino4_splits_t(int N, int Co, int Ci, int H, int W, int target_wgs) {
     const long blocks = (long)((Co + 63) / 64) * (Ci / 32);
     const long chunks = (long)N * (H / 4) * ((W + 15) / 16);
-    // Workgroups per launch.  One per CU (256) is NOT the optimum for a kernel that lives on the side stream: its 144 KB
-    // workgroups own a CU and keep the main stream's kernels off it.  With 128 the weight gradient takes half of the chip
-    // for twice as long and the dependent chain (BatchNorm backward, dgrad, pooling / up-sampling backward) runs on the
-    // other half undisturbed: same-box C2 step 537 -> 566 images/s (256 -> 128; 192: 552, 144: 550, 112: 552, 96: 525,
-    // 64: 448, 384: 526, 512: 520), co-teaching step 123.7 -> 126.9.  (Probe switch AIDE_WG4_TARGET.)
-    static const long target = getenv("AIDE_WG4_TARGET") ? atol(getenv("AIDE_WG4_TARGET")) : 128;
+    static const long dflt = getenv("AIDE_WG4_TARGET") ? atol(getenv("AIDE_WG4_TARGET")) : 128;
+    const long target = target_wgs > 0 ? target_wgs : dflt;
     long s = (target + blocks - 1) / blocks;
     if (s > chunks / 2) s = chunks / 2;
     if (s < 1) s = 1;
     return (int)s;
 }
 
+int aide_conv3x3_wgrad_wino4_splits(int N, int Co, int Ci, int H, int W) {
+    return aide_conv3x3_wgrad_wino4_splits_t(N, Co, Ci, H, W, 0);
+}
+
+size_t aide_conv3x3_wgrad_wino4_ws_bytes_t(int N, int Co, int Ci, int H, int W, int target_wgs) {
+    return (size_t)aide_conv3x3_wgrad_wino4_splits_t(N, Co, Ci, H, W, target_wgs) * 9 * Co * Ci * sizeof(float);
+}
+
 size_t aide_conv3x3_wgrad_wino4_ws_bytes(int N, int Co, int Ci, int H, int W) {
-    return (size_t)aide_conv3x3_wgrad_wino4_splits(N, Co, Ci, H, W) * 9 * Co * Ci * sizeof(float);
+    return aide_conv3x3_wgrad_wino4_ws_bytes_t(N, Co, Ci, H, W, 0);
 }
 
 // dw [Co][Ci][3][3] = sum over images and pixels of dz (x) shifted input; ws: aide_conv3x3_wgrad_wino4_ws_bytes()
-int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
-                             int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
+int aide_conv3x3_wgrad_wino4_t(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
+                               int Co, int Ci, int H, int W, float* ws, int target_wgs, hipStream_t stream) {
     if (!dz || !a || !dw || !ws || N <= 0 || !aide_conv3x3_wgrad_wino4_supported(Co, Ci, H, W) || dz_bs % 4 || a_bs % 4)
         return AIDE_ERR_ARG;
     static bool attr_set = false;
@@ -453,7 +464,7 @@ int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int
     g.rows_t = H / 4; g.cols_c = (W + 15) / 16;
     g.n_co_tiles = (Co + 63) / 64; g.n_ci_tiles = Ci / 32;
     g.chunks_total = N * g.rows_t * g.cols_c;
-    g.splits = aide_conv3x3_wgrad_wino4_splits(N, Co, Ci, H, W);
+    g.splits = aide_conv3x3_wgrad_wino4_splits_t(N, Co, Ci, H, W, target_wgs);
     const long nb = (long)g.n_co_tiles * g.n_ci_tiles * g.splits;
     // Tile rectangle per XCD (nb / 8 consecutive logical blocks).  Memory-side reads of a launch: every dz slice once per
     // rectangle COLUMN that needs it, every input slice (1.5x with its halo rows) once per rectangle ROW:
@@ -479,6 +490,11 @@ int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int
     const int rc = aide_launch_status();
     if (rc != 0) return rc;
     return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, stream);
+}
+
+int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
+                             int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
+    return aide_conv3x3_wgrad_wino4_t(dz, dz_bs, a, a_bs, dw, N, Co, Ci, H, W, ws, 0, stream);
 }
 
 }  // extern "C"

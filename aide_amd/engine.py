@@ -113,6 +113,7 @@ W16_PAIRS = [_os.environ.get('AIDE_W16_PAIRS', '0') != '0']      # F(4x4) on the
 DUAL_BWD = [_os.environ.get('AIDE_DUAL_BWD', '0') != '0']        # ... and of the backward pass (measured +-0 beside the weight-gradient stream: off)
 DUAL_BWD_MAXLEVEL = [int(_os.environ.get('AIDE_DUAL_BWD_MAXLEVEL', '9'))]   # ... only for the ops of levels <= this (0: the tail of the pass, where nothing is left to overlap the second encoder's chain with)
 EARLY_FLUSH = [_os.environ.get('AIDE_EARLY_FLUSH', '0') != '0']   # A-B switch: the slab reduces still queued go out behind the LAST Winograd weight gradient, not behind the last kernel of the pass
+TAIL_WG4_FULL = [_os.environ.get('AIDE_TAIL_WG4_FULL', '1') != '0']   # A-B switch: the last F(4x4) weight gradient of a single-encoder backward pass on 256 workgroups
 TAIL_WGRAD_MAIN = [_os.environ.get('AIDE_TAIL_WGRAD_MAIN', '1') != '0']   # A-B switch: the weight gradient of the LAST op of the backward pass (a stem conv: no data gradient) on the main stream, which has nothing left to do, beside the weight-gradient stream's backlog
 DUAL_FWD = [_os.environ.get('AIDE_DUAL_FWD', '1') != '0']        # A-B switch: lane-1 chains of the forward pass on a second stream
 FREE_LANE = [_os.environ.get('AIDE_FREE_LANE', '1') != '0']      # A-B switch: lane 1 pools its own channels and runs ahead (no fork / join per level)
@@ -284,7 +285,12 @@ class Plan(object):
                         # (a trailing half tile -- 32->32 @256x256 -- is 71 -> 56 us alone, but the 144 KB workgroups keep
                         # the main stream's kernels off the CUs: the step lost 0.5 %, so those layers stay on the direct kernel)
                         st['wino_w'] = 4
-                        st['wg_bytes'] = lib.aide_conv3x3_wgrad_wino4_ws_bytes(n, cout, cin, hh, ww)
+                        # the LAST such launch of a backward pass whose dependent chain ends with it (every op before it in
+                        # the graph is a stem conv without a data gradient -- the single-encoder U-Nets): nothing is left to
+                        # share the chip with, so it takes all of it (the default leaves half to the dependent chain)
+                        if TAIL_WG4_FULL[0] and all(s0['kind'] == 'conv' and s0['src'].root.is_input for s0 in self.steps):
+                            st['wg_target'] = 256
+                        st['wg_bytes'] = lib.aide_conv3x3_wgrad_wino4_ws_bytes_t(n, cout, cin, hh, ww, st.get('wg_target', 0))
                     elif USE_WINOGRAD[0] and lib.aide_conv3x3_wgrad_wino_supported(cout, cin, hh, ww):
                         st['wino_w'] = 2
                         st['wg_bytes'] = lib.aide_conv3x3_wgrad_wino_ws_bytes(n, cout, cin, hh, ww)
@@ -1032,6 +1038,8 @@ class Plan(object):
                 if kind == 'conv':
                     prof = self.profiler
                     wgrad = (ops.conv3x3_wgrad_bf16 if st['wino_w'] == BF16 else
+                             (lambda d_, x_, w_, ws=None: ops.conv3x3_wgrad_wino4(d_, x_, w_, ws=ws, target_wgs=256))
+                             if st.get('wg_target') else
                              ops.conv3x3_wgrad_wino4 if st['wino_w'] == 4 else
                              ops.conv3x3_wgrad_wino if st['wino_w'] else ops.conv3x3_wgrad)
                     # the last op of the pass, when it has no data gradient (a stem conv): the dependent chain ends with its

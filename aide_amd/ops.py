@@ -547,15 +547,19 @@ def wgrad_wino4_supported(co, ci, h, w):
     return bool(lib.aide_conv3x3_wgrad_wino4_supported(co, ci, h, w))
 
 
-def conv3x3_wgrad_wino4(dz, a, dw, ws=None):
-    """dw [Co,Ci,3,3] <- weight gradient via the transposed Winograd F(4x4,3x3) kernel."""
+def conv3x3_wgrad_wino4(dz, a, dw, ws=None, target_wgs=0):
+    """dw [Co,Ci,3,3] <- weight gradient via the transposed Winograd F(4x4,3x3) kernel.  target_wgs: workgroups of the
+    launch (0: the library's default, half of the chip); ws must hold aide_conv3x3_wgrad_wino4_ws_bytes_t() for it."""
     dzp, dzbs = planes(dz)
     ap, abs_ = planes(a)
     n, co, h, w = dz.shape
     ci = a.shape[1]
     if ws is None:
-        ws = torch.empty(lib.aide_conv3x3_wgrad_wino4_ws_bytes(n, co, ci, h, w) // 4, device=dz.device, dtype=torch.float32)
-    check(lib.aide_conv3x3_wgrad_wino4(dzp, dzbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), stream_ptr()),
+        ws = torch.empty(lib.aide_conv3x3_wgrad_wino4_ws_bytes_t(n, co, ci, h, w, target_wgs) // 4, device=dz.device,
+                         dtype=torch.float32)
+    elif ws.numel() * 4 < lib.aide_conv3x3_wgrad_wino4_ws_bytes_t(n, co, ci, h, w, target_wgs):
+        raise RuntimeError('aide_amd: weight-gradient workspace too small for %d workgroups' % target_wgs)
+    check(lib.aide_conv3x3_wgrad_wino4_t(dzp, dzbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), target_wgs, stream_ptr()),
           'conv3x3_wgrad_wino4')
     return dw
 

@@ -90,6 +90,12 @@ int aide_conv3x3_wgrad_wino4_splits(int N, int Co, int Ci, int H, int W);
 size_t aide_conv3x3_wgrad_wino4_ws_bytes(int N, int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
                              int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
+/* the same with the workgroup count of the launch as an argument (target_wgs <= 0: the default, half of the chip --
+ * the kernel normally shares it with the dependent chain of the backward pass; 256 for a launch that has the chip alone) */
+int aide_conv3x3_wgrad_wino4_splits_t(int N, int Co, int Ci, int H, int W, int target_wgs);
+size_t aide_conv3x3_wgrad_wino4_ws_bytes_t(int N, int Co, int Ci, int H, int W, int target_wgs);
+int aide_conv3x3_wgrad_wino4_t(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
+                               int Co, int Ci, int H, int W, float* ws, int target_wgs, aide_stream_t stream);
 
 /* ---- bf16-MFMA mode of the same convolution (BASELINE config 5: "FuseUNet bf16 MFMA path") -------------------
  * replaces the same nn.Conv2d call sites (netblocks.py:17,24,26; UNet.py:12,19,21) when the engine runs with
