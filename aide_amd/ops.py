@@ -557,7 +557,7 @@ def conv3x3_wgrad_wino4(dz, a, dw, ws=None, target_wgs=0):
     if ws is None:
         ws = torch.empty(lib.aide_conv3x3_wgrad_wino4_ws_bytes_t(n, co, ci, h, w, target_wgs) // 4, device=dz.device,
                          dtype=torch.float32)
-    elif ws.numel() * 4 < lib.aide_conv3x3_wgrad_wino4_ws_bytes_t(n, co, ci, h, w, target_wgs):
+    elif target_wgs and ws.numel() * 4 < lib.load().aide_conv3x3_wgrad_wino4_ws_bytes_t(n, co, ci, h, w, target_wgs):   # (raw entry: a host-side size query stays off the launch tape)
         raise RuntimeError('aide_amd: weight-gradient workspace too small for %d workgroups' % target_wgs)
     check(lib.aide_conv3x3_wgrad_wino4_t(dzp, dzbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), target_wgs, stream_ptr()),
           'conv3x3_wgrad_wino4')
