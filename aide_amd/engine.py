@@ -23,6 +23,9 @@ from .tape import Tape
 # bumped by aide_amd.optim.Adam (which updates parameters through raw pointers, invisible to
 # tensor._version) so that cached packed filters are refreshed
 PARAM_EPOCH = [0]
+# bumped by every train-mode forward (its BatchNorm kernels update the running statistics through raw pointers): the cached
+# eval-mode coefficients of every plan are stale afterwards
+STATS_EPOCH = [0]
 
 
 class GTensor(object):
@@ -113,6 +116,7 @@ W16_PAIRS = [_os.environ.get('AIDE_W16_PAIRS', '0') != '0']      # F(4x4) on the
 DUAL_BWD = [_os.environ.get('AIDE_DUAL_BWD', '0') != '0']        # ... and of the backward pass (measured +-0 beside the weight-gradient stream: off)
 DUAL_BWD_MAXLEVEL = [int(_os.environ.get('AIDE_DUAL_BWD_MAXLEVEL', '9'))]   # ... only for the ops of levels <= this (0: the tail of the pass, where nothing is left to overlap the second encoder's chain with)
 EARLY_FLUSH = [_os.environ.get('AIDE_EARLY_FLUSH', '0') != '0']   # A-B switch: the slab reduces still queued go out behind the LAST Winograd weight gradient, not behind the last kernel of the pass
+FOLD_EVAL_BN = [_os.environ.get('AIDE_FOLD_EVAL_BN', '1') != '0']   # A-B switch: eval-mode BatchNorm + ReLU in the F(4x4) conv epilogue (no pass over the conv output)
 TAIL_WG4_FULL = [_os.environ.get('AIDE_TAIL_WG4_FULL', '1') != '0']   # A-B switch: the last F(4x4) weight gradient of a single-encoder backward pass on 256 workgroups
 TAIL_WGRAD_MAIN = [_os.environ.get('AIDE_TAIL_WGRAD_MAIN', '1') != '0']   # A-B switch: the weight gradient of the LAST op of the backward pass (a stem conv: no data gradient) on the main stream, which has nothing left to do, beside the weight-gradient stream's backlog
 DUAL_FWD = [_os.environ.get('AIDE_DUAL_FWD', '1') != '0']        # A-B switch: lane-1 chains of the forward pass on a second stream
@@ -230,7 +234,7 @@ class Plan(object):
                 hh, ww = h >> dst.level, w >> dst.level
                 cout = dst.C
                 st['z'] = torch.empty(n, cout, hh, ww, **f32)
-                for k in ('mean', 'rstd', 'scale', 'shift'):
+                for k in ('mean', 'rstd', 'scale', 'shift', 'fbias'):
                     st[k] = torch.empty(cout, **f32)
                 max_dz = max(max_dz, n * cout * hh * ww)
                 max_bnc = max(max_bnc, cout)
@@ -311,6 +315,10 @@ class Plan(object):
                         if parts > 0:
                             st['stats_parts'] = parts
                             st['stats'] = torch.empty(cout * parts * 2, **f32)
+                    # eval mode (the per-case inference loop): BatchNorm of the running statistics + ReLU as the epilogue of the
+                    # F(4x4) forward kernel -- the conv writes the activation, z is never materialised
+                    st['fold'] = (not training and FOLD_EVAL_BN[0] and st['wino_f'] == 4 and (st['plan_f'] >> 8) <= 1
+                                  and ww != 16)
                     st['pack_key'] = None
                     st['flops'] = 2.0 * n * hh * ww * cout * cin * 9      # algorithmic, per launch
                     # bf16 mode keeps the conv output z (read only by BatchNorm) and its gradient dz (read only by the
@@ -384,6 +392,7 @@ class Plan(object):
         self._late_pending, self._late_inflight = None, False
         self._gate_conv = None           # the first conv that needs the side-stream filter packs
         self._tape_f = self._tape_b = None
+        self._coef_key, self._coef_tensors, self._coef_ok = None, None, False
         self._fp = None
         self._fp_slots = self._fp_bns = None
         self.overlap = True              # weight gradients on a side stream (see backward)
@@ -620,9 +629,29 @@ class Plan(object):
     def _tapeable(self):
         return REPLAY[0] and self.profiler is None and self.trace is None and not LATE_DGRAD_PACK[0] and not HP_CHAIN[0]
 
+    def _coef_fresh(self):
+        """eval mode: are the cached BatchNorm coefficients (scale, shift, folded bias per layer) those of the current
+        parameters and running statistics?  Marks them fresh for the forward that is about to (re)compute them."""
+        if self.training:
+            STATS_EPOCH[0] += 1
+            return True
+        tens = self._coef_tensors
+        if tens is None:
+            tens = []
+            for st in self.steps:
+                if st['kind'] in ('conv', 'convT'):
+                    bn = st['bn']
+                    tens += [st['conv'].bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+            tens = self._coef_tensors = [t for t in tens if t is not None]
+        key = (PARAM_EPOCH[0], STATS_EPOCH[0]) + tuple((t.data_ptr(), t._version) for t in tens)
+        fresh = key == self._coef_key
+        self._coef_key = key
+        return fresh
+
     def forward(self, inputs, out):
         self.serial += 1                 # the saved activations of this plan now belong to THIS forward (any kind)
         gate = self._pack_filters()
+        self._coef_ok = self._coef_fresh()
         if not self._tapeable():
             self._tape_f = self._tape_b = None
             return self._forward_impl(inputs, out, gate, None)
@@ -631,7 +660,7 @@ class Plan(object):
         key = (torch.cuda.current_stream().cuda_stream, self._fp, tuple((tuple(t.shape), t.stride()) for t in dyn))
         tp = self._tape_f
         if tp is not None and tp.key == key:
-            tp.replay(dyn, skip_tags=() if gate is not None else ('gate',))
+            tp.replay(dyn, skip_tags=(() if gate is not None else ('gate',)) + (('aide_bn_eval_fold',) if self._coef_ok else ()))
             return out
         tp = Tape(key)
         with tp:
@@ -654,6 +683,12 @@ class Plan(object):
         # first fork (its next level reads only what it pooled itself), and lane 0 waits for lane 1 exactly where it reads
         # lane 1's pooled channels -- on an event recorded right behind that pooling launch, not on lane 1's tail.  (With one
         # pooling launch per level on the main stream each level cost a join + a fork: ~35 us of idle time per lane and level.)
+        if not self.training and (tape is not None or not self._coef_ok):
+            # eval-mode coefficients of every BatchNorm, once per change of the parameters / running statistics (a replayed
+            # tape skips these entries while they are fresh)
+            for st in self.steps:
+                if st['kind'] in ('conv', 'convT'):
+                    ops.bn_eval_fold(st['bn'], st['conv'].bias, st['scale'], st['shift'], st['fbias'])
         free = dual and FREE_LANE[0]
         on_b, pend = False, []
         forked = False        # free: lane 1 has been ordered behind the main stream (since the last event that needs it again)
@@ -755,6 +790,12 @@ class Plan(object):
                 slabs = self.training and FOLD_SPLITK[0] and (st['plan_f'] >> 8) > 1 and \
                     (st['z'].shape[2] * st['z'].shape[3]) % 4 == 0          # (the slab loader reads 16 bytes)
                 acc = 2 if slabs else 0
+                if st.get('fold'):                 # eval: y = relu(acc * scale + folded bias) straight into the activation
+                    lib.aide_conv_epilogue_affine(ops.ptr(st['scale']), 1)
+                    ops.conv3x3_wino4(x, st['uf'], st['fbias'], self.view(st['dst']), accumulate=0, splitk=1)
+                    if prof is not None:
+                        prof.end()
+                    return
                 if st['stats'] is not None:        # one-shot: this launch writes the BatchNorm statistics partials
                     lib.aide_conv_stats_sink(ops.ptr(st['stats']))
                 if st['wino_f'] == BF16:
@@ -827,9 +868,7 @@ class Plan(object):
                     ops.bn_train_fwd(zg, ag, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
                                      bn.num_batches_tracked, st['mean'], st['rstd'], st['scale'], st['shift'],
                                      bn_ws, True)
-        else:
-            ops.bn_eval_coeff(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, st['scale'],
-                              st['shift'])
+        else:                                # (scale / shift: computed at the head of the forward pass, _forward_impl)
             ops.bn_relu_apply(z, a, st['scale'], st['shift'], True)
 
     # ------------------------------------------------------------------ backward
@@ -944,8 +983,6 @@ class Plan(object):
             with ops.use_stream(mp):
                 self._backward_ops(inputs, dlogits, gslot, mp, sp, hook)
             if defer:
-                if side is not None and TAIL_WGRAD_MAIN[0]:
-                    ops.order(self.ev_fork, mp, sp)       # the last weight gradient may have left its slabs on the main stream
                 flush()
             done = True
         finally:
@@ -1060,6 +1097,10 @@ class Plan(object):
                         wgrad(dz, x, gslot(conv.weight), ws=st['wg_ws'])
                         if prof is not None:
                             prof.end()
+                        if side is not None:
+                            # (tail) its slabs are reduced by a batched launch on the weight-gradient stream -- whichever
+                            # flush picks them up, the hook's or the final one, must run behind this kernel
+                            ops.order(st['ev'], main, side)
                     if sg is not None:
                         if prof is not None:
                             prof.begin(FWD_TAG[st['wino_d']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_d']])
