@@ -230,6 +230,21 @@ __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, con
     shift_out[c] = (beta ? beta[c] : 0.0f) - rm[c] * sc;
 }
 
+// eval mode with the BatchNorm folded into the convolution's epilogue: a = relu(acc * scale + fbias), fbias = conv_bias * scale + shift
+__global__ void bn_eval_fold_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                    const float* __restrict__ conv_bias, float* __restrict__ scale_out,
+                                    float* __restrict__ shift_out, float* __restrict__ fbias_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rstd = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.0f) * rstd;
+    const float sh = (beta ? beta[c] : 0.0f) - rm[c] * sc;
+    scale_out[c] = sc;
+    shift_out[c] = sh;
+    fbias_out[c] = __builtin_fmaf(conv_bias ? conv_bias[c] : 0.0f, sc, sh);
+}
+
 // ---------------------------------------------------------------- a = relu(z*scale + shift)
 template <int V, typename ZT, typename AT>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ZT* __restrict__ z, long z_bs,
@@ -731,6 +746,15 @@ int aide_bn_eval_coeff(int C, const float* gamma, const float* beta, const float
                        const float* running_var, float eps, float* scale, float* shift, hipStream_t stream) {
     hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, C, gamma, beta,
                        running_mean, running_var, eps, scale, shift);
+    return aide_launch_status();
+}
+
+int aide_bn_eval_fold(int C, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, const float* conv_bias, float* scale, float* shift,
+                      float* fbias, hipStream_t stream) {
+    if (C <= 0 || !running_mean || !running_var || !scale || !shift || !fbias) return AIDE_ERR_ARG;
+    hipLaunchKernelGGL(bn_eval_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, C, gamma, beta,
+                       running_mean, running_var, eps, conv_bias, scale, shift, fbias);
     return aide_launch_status();
 }
 

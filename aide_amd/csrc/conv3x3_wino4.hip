@@ -41,6 +41,8 @@ struct W4Args {
     int pair;            // W == 16: a workgroup tile is 16 rows x (16 columns of image 2n | 16 columns of image 2n + 1)
     float* stats;        // optional [Cout][N * blocks_h * blocks_w][2]: per (channel, workgroup tile) sum / sum of squares of the
                          // pre-bias outputs -- the BatchNorm statistics of the forward pass without a pass over z
+    const float* scale;  // AFF variant (eval mode, aide_conv_epilogue_affine): y = relu?(acc * scale[co] + bias[co]) -- the
+    int relu;            // BatchNorm of running statistics folded into the epilogue, no separate pass over the conv output
 };
 
 constexpr int F4_NAGPR = 16;               // accumulators (of 18) kept in the AGPR file; the rest are pinned to VGPRs
@@ -93,7 +95,7 @@ __device__ __forceinline__ float half_total_dpp(float v) {
 // MODE 2: the workgroup's 32 tile slots as a 5 x 5 canvas of 4x4 tiles = 20 x 20 pixels (25 slots used) instead of 4 x 8 =
 // 16 x 32: the 40 x 40 and 20 x 20 planes of the 320 x 320 workload fill 78 % of their tiles instead of 52 % / 39 %.  Only
 // the staging descriptors, the patch origin and the output address know the canvas; the main loop is the same code.
-template <int MODE>
+template <int MODE, bool AFF = false>
 #ifdef AIDE_PROBE_4HALF
 // (timing probe, wrong results) half of the positions per workgroup -- 9 accumulators, 18 MFMAs per stage -- so that TWO
 // workgroups fit a CU (2 waves per SIMD): does a co-resident workgroup hide the fixed cost and the stalls of the other?
@@ -443,6 +445,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             bvs[q] = (add_bias && co < a.Cout) ? a.bias[co] : 0.f;
         }
+        float svs[8];
+        if constexpr (AFF) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = q + 8 * kph;
+                const int co = co0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                svs[q] = co < a.Cout ? a.scale[co] : 1.f;
+            }
+        }
 #pragma unroll
         for (int rp = 0; rp < 4; ++rp) {
             f32x2 yp[16];
@@ -481,6 +492,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         o[i] = f32x4{yp[4 * i][e] + bv, yp[4 * i + 1][e] + bv, yp[4 * i + 2][e] + bv, yp[4 * i + 3][e] + bv};
+                    if constexpr (AFF) {                         // (never with accumulate / split-K: the launcher refuses)
+                        const float sv = svs[2 * rp + e];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float v = __builtin_fmaf(yp[4 * i + k][e], sv, bv);
+                                o[i][k] = a.relu ? fmaxf(v, 0.f) : v;
+                            }
+                        }
+                    }
                     if (a.accumulate) {                          // (the four old rows as one batch of loads, one wait)
                         f32x4 old[4];
 #pragma unroll
@@ -505,17 +527,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     if (hs == 0) run(ic<0>{}); else run(ic<1>{});
 }
 
-// y[n][c][p] (+)= bias[c] + sum_s slab[s][n][c][p], 16 bytes per thread, fixed summation order
+// y[n][c][p] (+)= bias[c] + sum_s slab[s][n][c][p], 16 bytes per thread, fixed summation order.  scale != nullptr (eval mode,
+// aide_conv_epilogue_affine): y = relu?(sum * scale[c] + bias[c])
 __global__ __launch_bounds__(256) void w4_splitk_reduce_kernel(const float* __restrict__ slabs, long split_stride,
                                                                int splitk, float* __restrict__ y, long y_bs, int C,
                                                                int HW, const float* __restrict__ bias, int accumulate,
-                                                               long total4) {
+                                                               long total4, const float* __restrict__ scale, int relu) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
         const long e = i * 4, chw = (long)C * HW;
         const long n = e / chw, rem = e - n * chw;
         f32x4 v = *reinterpret_cast<const f32x4*>(slabs + e);
         for (int s = 1; s < splitk; ++s) v += *reinterpret_cast<const f32x4*>(slabs + (long)s * split_stride + e);
-        if (bias) { const float bv = bias[rem / HW]; v += f32x4{bv, bv, bv, bv}; }
+        if (scale) {
+            const float sv = scale[rem / HW], bv = bias[rem / HW];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float t = __builtin_fmaf(v[k], sv, bv); v[k] = relu ? fmaxf(t, 0.f) : t; }
+        } else if (bias) { const float bv = bias[rem / HW]; v += f32x4{bv, bv, bv, bv}; }
         f32x4* p = reinterpret_cast<f32x4*>(y + n * y_bs + rem);
         if (accumulate) v += *p;
         *p = v;
@@ -693,11 +720,20 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
                             F4_LDS * (int)sizeof(float));
         hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             F4_LDS * (int)sizeof(float));
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  F4_LDS * (int)sizeof(float));
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  F4_LDS * (int)sizeof(float));
         attr_set = true;
     }
     W4Args a;
     a.stats = (splitk <= 1 && accumulate == 0 && W >= 32) ? aide_conv_stats_take() : nullptr;
+    int aff_relu = 0;
+    const float* aff = aide_conv_affine_take(&aff_relu);   // one-shot: armed by aide_conv_epilogue_affine for THIS launch
     const int mode = f4_mode(H, W, &a.blocks_h, &a.blocks_w);
+    if (aff && (accumulate != 0 || !bias || (mode == 1 && splitk <= 1))) return AIDE_ERR_ARG;
+    a.scale = splitk > 1 ? nullptr : aff;           // a split launch leaves plain slabs: its reduce applies the epilogue
+    a.relu = aff_relu;
     a.pair = mode == 1 ? 1 : 0;
     a.x = x; a.u = u; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.n_co_tiles = (Cout + 63) / 64;
@@ -736,7 +772,13 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
         }
         a.gp = (int)bp; a.gc = bc;
     }
-    if (a.pair) {
+    if (a.scale && mode == 2) {
+        AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), (conv3x3_wino4_kernel<2, true>), dim3((unsigned)nb),
+                          dim3(256), F4_LDS * sizeof(float), stream, a);
+    } else if (a.scale) {
+        AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), (conv3x3_wino4_kernel<0, true>), dim3((unsigned)nb),
+                          dim3(256), F4_LDS * sizeof(float), stream, a);
+    } else if (a.pair) {
         AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), conv3x3_wino4_kernel<1>, dim3((unsigned)nb), dim3(256),
                           F4_LDS * sizeof(float), stream, a);
     } else if (mode == 2) {
@@ -752,7 +794,7 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
         const long total4 = (long)N * Cout * H * W / 4;
         hipLaunchKernelGGL(w4_splitk_reduce_kernel, dim3((unsigned)min((total4 + 255) / 256, 4096L)), dim3(256), 0,
                            stream, ws, (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias, accumulate,
-                           total4);
+                           total4, aff, aff_relu);
         rc = aide_launch_status();
     }
     return rc;

@@ -21,10 +21,14 @@ struct KTimer {
 // one-shot sink for the BatchNorm statistics of the next eligible forward conv launch (see bn.hip / conv3x3_wino4.hip)
 static float* g_stats_sink = nullptr;
 float* aide_conv_stats_take() { float* p = g_stats_sink; g_stats_sink = nullptr; return p; }
+static const float* g_affine = nullptr;
+static int g_affine_relu = 0;
+const float* aide_conv_affine_take(int* relu) { const float* p = g_affine; g_affine = nullptr; *relu = p ? g_affine_relu : 0; return p; }
 
 extern "C" {
 
 int aide_conv_stats_sink(float* parts) { g_stats_sink = parts; return AIDE_OK; }
+int aide_conv_epilogue_affine(const float* scale, int relu) { g_affine = scale; g_affine_relu = relu; return AIDE_OK; }
 
 int aide_ktimer_slot(int family, double flops, hipEvent_t* e0, hipEvent_t* e1) {
     if (!(T.mask >> family & 1u)) return 0;

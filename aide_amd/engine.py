@@ -317,8 +317,7 @@ class Plan(object):
                             st['stats'] = torch.empty(cout * parts * 2, **f32)
                     # eval mode (the per-case inference loop): BatchNorm of the running statistics + ReLU as the epilogue of the
                     # F(4x4) forward kernel -- the conv writes the activation, z is never materialised
-                    st['fold'] = (not training and FOLD_EVAL_BN[0] and st['wino_f'] == 4 and (st['plan_f'] >> 8) <= 1
-                                  and ww != 16)
+                    st['fold'] = not training and FOLD_EVAL_BN[0] and st['wino_f'] == 4 and ww != 16
                     st['pack_key'] = None
                     st['flops'] = 2.0 * n * hh * ww * cout * cin * 9      # algorithmic, per launch
                     # bf16 mode keeps the conv output z (read only by BatchNorm) and its gradient dz (read only by the
@@ -792,7 +791,8 @@ class Plan(object):
                 acc = 2 if slabs else 0
                 if st.get('fold'):                 # eval: y = relu(acc * scale + folded bias) straight into the activation
                     lib.aide_conv_epilogue_affine(ops.ptr(st['scale']), 1)
-                    ops.conv3x3_wino4(x, st['uf'], st['fbias'], self.view(st['dst']), accumulate=0, splitk=1)
+                    ops.conv3x3_wino4(x, st['uf'], st['fbias'], self.view(st['dst']), accumulate=0, splitk=st['plan_f'] >> 8,
+                                      ws=sk_ws)
                     if prof is not None:
                         prof.end()
                     return

@@ -265,6 +265,12 @@ def bn_eval_coeff(gamma, beta, running_mean, running_var, eps, scale, shift):
           'bn_eval_coeff')
 
 
+def bn_eval_fold(bn, conv_bias, scale, shift, fbias):
+    """eval-mode coefficients of `bn` and the bias of the convolution before it folded through them"""
+    check(lib.aide_bn_eval_fold(scale.numel(), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+                                bn.eps, ptr(conv_bias), ptr(scale), ptr(shift), ptr(fbias), stream_ptr()), 'bn_eval_fold')
+
+
 def bn_relu_apply(z, a, scale, shift, relu=True):
     zp, zbs = planes(z, bf16_ok=True)
     ap, abs_ = planes(a, bf16_ok=True)

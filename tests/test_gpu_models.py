@@ -430,3 +430,72 @@ def test_large_plane_1024(dev):
         else:
             # per-parameter gradient norms (ReLU-mask flips at 1e-6 forward differences are not forced here)
             assert abs(a - b) <= 5e-3 * b + 1e-7, (k, a, b)
+
+
+def test_eval_fold_tracks_parameters_and_statistics(dev):
+    """Eval mode folds BatchNorm(running statistics) + ReLU into the F(4x4) conv epilogue and caches the per-layer
+    coefficients across forwards (the per-case inference loop, trainchaos_comparison_1case.py:233-273).  The folded form
+    must agree with the unfolded kernels and with the oracle, and must follow every way the coefficients can change: a
+    training step (running statistics through raw pointers, weights through the fused Adam), an in-place edit of a buffer,
+    load_state_dict -- over recorded and replayed launch tapes."""
+    from aide_amd import engine, utils as U
+    from aide_amd.optim import Adam
+    net, ref = build_pair('fuseunet', False, dev)
+    g = torch.Generator().manual_seed(21)
+    xs = [torch.randn(4, 3, 128, 128, generator=g) for _ in range(2)]
+    t = (torch.rand(4, 128, 128, generator=g) > 0.8).long()
+    xd = [x.to(dev) for x in xs]
+    w = torch.tensor([1.0, 1.0])
+    opt = Adam(net.parameters(), lr=1e-3, amsgrad=True)
+
+    def evals():
+        net.eval(); ref.eval()
+        with torch.no_grad():
+            outs = [net(*xd).clone() for _ in range(3)]          # recorded pass + two replays (cached coefficients)
+            out_r = ref(*xs)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert rel(outs[0], out_r) < 5e-3
+        return outs[0]
+
+    def unfolded():
+        saved = engine.FOLD_EVAL_BN[0]
+        keep = dict(net.engine.plans)
+        try:
+            engine.FOLD_EVAL_BN[0] = False
+            net.engine.plans.clear()                               # the choice is made when a plan is built
+            with torch.no_grad():
+                return net(*xd).clone()
+        finally:
+            engine.FOLD_EVAL_BN[0] = saved
+            net.engine.plans.clear(); net.engine.plans.update(keep)
+
+    a0 = evals()
+    plan = [p for p in net.engine.plans.values() if not p.training][0]
+    assert any(st.get('fold') for st in plan.steps), 'no layer took the folded epilogue'
+    assert rel(a0, unfolded()) < 1e-5
+    # a training step moves weights and running statistics
+    net.train()
+    for _ in range(2):
+        opt.zero_grad(); U.CEMDiceLoss(w, w, w)(net(*xd), t.to(dev)).backward(); opt.step()
+    ref.load_state_dict(net.state_dict())        # (the oracle follows the device's trajectory: only the eval arithmetic is under test)
+    a1 = evals()
+    assert rel(a1, a0) > 1e-3, 'eval output did not move with the training steps (stale coefficients?)'
+    assert rel(a1, unfolded()) < 1e-5
+    # an in-place edit of running statistics (tensor._version)
+    with torch.no_grad():
+        for model in (net, ref):
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_var.mul_(1.5)
+    a2 = evals()
+    assert rel(a2, a1) > 1e-3
+    assert rel(a2, unfolded()) < 1e-5
+    # load_state_dict
+    with torch.no_grad():
+        for mr in ref.modules():
+            if isinstance(mr, torch.nn.BatchNorm2d):
+                mr.running_mean.add_(0.05); mr.weight.mul_(0.9)
+    net.load_state_dict(ref.state_dict())
+    a3 = evals()
+    assert rel(a3, a2) > 1e-3
+    assert rel(a3, unfolded()) < 1e-5
