@@ -9,8 +9,35 @@ dgrad/wgrad kernels.  With world_size == 1 nothing is installed.
 The reference only has single-process nn.DataParallel (trainchaos_comparison_1case.py:131-134); this
 is the multi-process replacement BASELINE.json asks for.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# Stream budget.  The HIP runtime maps the streams of a process onto GPU_MAX_HW_QUEUES (4) hardware queues, a fifth stream
+# shares the queue of an earlier one -- and a queue runs its packets in order.  Measured on one MI355X with the bucketed
+# all-reduce installed on a single-rank RCCL group (tools/bench_comm1.py: the collectives are local, the plumbing is all
+# there): with a bucket stream of its own AND RCCL's stream next to main / weight gradients / second forward lane / filter
+# packs, RCCL's kernels landed in the MAIN stream's queue (rocprofv3 --kernel-trace: same Queue_Id), and the event wait in
+# front of a bucket's all-reduce -- for the weight-gradient stream, which runs ~0.4 ms behind the main stream -- stalled the
+# main stream with it: C2 608 -> 567 images/s per rank before a single byte crosses xGMI, and with real peers the whole
+# all-reduce would sit in that queue.  More queues are no way out (GPU_MAX_HW_QUEUES=8 with RCCL: 363 images/s), nor are
+# high-priority streams for RCCL and the buckets (AIDE_RCCL_HIGH_PRIORITY=1: 452).  So the process keeps to FOUR streams:
+# main, second forward lane, weight gradients (which also carries the filter re-layout at the start of the forward pass:
+# engine.PACKS_ON_SIDE) and RCCL's own; a bucket's collective is issued FROM the weight-gradient stream (its tail is a
+# superset of what the bucket waits for; it only has to be ordered behind the main stream, which runs ahead of it).
+HIGH_PRIORITY = [os.environ.get('AIDE_RCCL_HIGH_PRIORITY', '0') != '0']     # A-B switch (measured: worse)
+# AIDE_COMM_FROM_SIDE=0: a dedicated bucket stream, as in round 2 (A-B switch)
+ISSUE_FROM_SIDE = [os.environ.get('AIDE_COMM_FROM_SIDE', '1') != '0']
+# AIDE_PICK_STREAMS=0: take the streams as the runtime hands them out (A-B switch; see aide_amd/streams.py)
+PICK_STREAMS = [os.environ.get('AIDE_PICK_STREAMS', '1') != '0']
+
+
+def nccl_options():
+    """process-group options for init_process_group('nccl', pg_options=...) (None: the defaults)"""
+    if not HIGH_PRIORITY[0]:
+        return None
+    return dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
 
 
 def make_buckets(offsets, numels, bucket_elems):
@@ -65,7 +92,6 @@ def init_from_env(device_ids=None):
     rank's device (device_ids[local_rank] if given -- the train scripts' --gpu_order -- else local_rank) and, for
     WORLD_SIZE > 1, joins the RCCL process group.  -> (rank, world, device).  AIDE_DIST_BACKEND=gloo is a dry-run backend
     for boxes with fewer GPUs than ranks (ranks wrap around the visible devices; RCCL refuses two ranks per device)."""
-    import os
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -83,7 +109,10 @@ def init_from_env(device_ids=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this host driver
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
+            if PICK_STREAMS[0]:
+                from . import streams
+                streams.reserve_queue(device)            # RCCL's stream then gets a hardware queue of its own (streams.py)
+            dist.init_process_group('nccl', device_id=device, pg_options=nccl_options())
         else:
             dist.init_process_group(backend)
     return rank, world, device
@@ -122,7 +151,16 @@ class GradAllReduce(object):
         self.comm_stream = None
         self.time_exposed = False        # bench.py: event-time the main stream's wait for the communication stream
         self._exposed = []
+        self.stream_plan = None
         if self.world > 1 or force:          # force: exercise the RCCL path on a single-rank group (tests)
+            p0 = next(iter(model.parameters()), None) if hasattr(model, 'parameters') else None
+            dev = p0.device if p0 is not None else None
+            if PICK_STREAMS[0] and dev is not None and dev.type == 'cuda' and not getattr(self.engine, 'plans', None):
+                # before the engine builds its first plan: streams that really run beside each other and beside RCCL's
+                from . import streams
+                if dev.index not in streams.PREFERRED:
+                    with torch.cuda.device(dev):
+                        self.stream_plan = streams.pick(dev, process_group)
             self.engine.after_backward_op = self._after_op
             self.engine.grad_hook = self._finish
             self.engine.before_backward = self._begin
@@ -140,32 +178,36 @@ class GradAllReduce(object):
         self.sched.reset()
         self.flat = flat
         self.works = []
-        if flat.is_cuda and self.comm_stream is None:
-            self.comm_stream = torch.cuda.Stream(device=flat.device)
+        if flat.is_cuda and self.comm_stream is None and not ISSUE_FROM_SIDE[0]:
+            self.comm_stream = torch.cuda.Stream(device=flat.device, priority=-1 if HIGH_PRIORITY[0] else 0)
 
     def _launch(self, b):
         start, end, _ = self.sched.buckets[b]
         view = self.flat[start:end]
         avg = dist.get_backend(self.pg) == 'nccl'          # RCCL averages in the collective itself: no extra pass
         if view.is_cuda:
-            ev = torch.cuda.Event()
-            ev.record()                                    # all kernels writing this bucket are enqueued
             side = getattr(self.engine, 'side_stream', None)
-            ev2 = None
-            if side is not None:                           # ... the weight gradients on the side stream
-                ev2 = torch.cuda.Event()
-                ev2.record(side)
             lane = getattr(self.engine, 'lane_stream', None)
-            ev3 = None
-            if lane is not None:                           # ... and the second encoder's lane (BatchNorm parameter gradients)
+            issue = side if (ISSUE_FROM_SIDE[0] and side is not None) else self.comm_stream
+            if issue is None:                              # no weight-gradient stream (single-stream schedule): in line
+                self._reduce(view, avg)
+                return
+            # everything that writes this bucket has been enqueued: on the main stream, on the weight-gradient stream and
+            # (two-lane backward) on the second encoder's lane.  The collective is issued from the weight-gradient stream
+            # itself: RCCL's stream then waits for that stream's tail -- a superset of the bucket's weight gradients -- and
+            # the stream only has to be ordered behind the main stream (and the lane), which run ahead of it anyway.
+            ev = torch.cuda.Event()
+            ev.record()
+            issue.wait_event(ev)
+            if lane is not None:
                 ev3 = torch.cuda.Event()
                 ev3.record(lane)
-            with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
-                if ev2 is not None:
-                    self.comm_stream.wait_event(ev2)
-                if ev3 is not None:
-                    self.comm_stream.wait_event(ev3)
+                issue.wait_event(ev3)
+            if issue is not side and side is not None:
+                ev2 = torch.cuda.Event()
+                ev2.record(side)
+                issue.wait_event(ev2)
+            with torch.cuda.stream(issue):
                 self._reduce(view, avg)
         else:
             self._reduce(view, avg)
@@ -199,7 +241,7 @@ class GradAllReduce(object):
             e0.record()
         for w in self.works:
             w.wait()
-        if flat.is_cuda:
+        if flat.is_cuda and self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         if timed:
             e1.record()
@@ -209,8 +251,12 @@ class GradAllReduce(object):
     def describe(self):
         """-> dict(buckets, bytes_per_step): the bucket plan of this module's gradient arena"""
         self._ensure()
+        sp = self.stream_plan
         return dict(buckets=len(self.sched.buckets),
-                    bytes_per_step=int(sum(4 * (end - start) for start, end, _ in self.sched.buckets)))
+                    bytes_per_step=int(sum(4 * (end - start) for start, end, _ in self.sched.buckets)),
+                    high_priority=bool(HIGH_PRIORITY[0]),
+                    hw_queues=None if sp is None else dict(classes=sp['classes'], main=sp['main_class'], rccl=sp['rccl_class'],
+                                                           side=sp['side'], lane=sp['lane']))
 
     def exposed_ms(self, last=8):
         """mean time (ms) the compute stream stalled at the end of a backward pass waiting for the all-reduces still in

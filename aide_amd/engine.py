@@ -119,6 +119,7 @@ EARLY_FLUSH = [_os.environ.get('AIDE_EARLY_FLUSH', '0') != '0']   # A-B switch: 
 FOLD_EVAL_BN = [_os.environ.get('AIDE_FOLD_EVAL_BN', '1') != '0']   # A-B switch: eval-mode BatchNorm + ReLU in the F(4x4) conv epilogue (no pass over the conv output)
 TAIL_WG4_FULL = [_os.environ.get('AIDE_TAIL_WG4_FULL', '1') != '0']   # A-B switch: the last F(4x4) weight gradient of a single-encoder backward pass on 256 workgroups
 TAIL_WGRAD_MAIN = [_os.environ.get('AIDE_TAIL_WGRAD_MAIN', '1') != '0']   # A-B switch: the weight gradient of the LAST op of the backward pass (a stem conv: no data gradient) on the main stream, which has nothing left to do, beside the weight-gradient stream's backlog
+PACKS_ON_SIDE = [_os.environ.get('AIDE_PACKS_ON_SIDE', '1') != '0']   # A-B switch: the filter re-layout of a training plan on its weight-gradient stream (idle during the forward pass) instead of a stream of its own: one stream less per process (see distributed.py: hardware queues)
 DUAL_FWD = [_os.environ.get('AIDE_DUAL_FWD', '1') != '0']        # A-B switch: lane-1 chains of the forward pass on a second stream
 FREE_LANE = [_os.environ.get('AIDE_FREE_LANE', '1') != '0']      # A-B switch: lane 1 pools its own channels and runs ahead (no fork / join per level)
 FOLD_SPLITK_BWD = [_os.environ.get('AIDE_FOLD_SPLITK_BWD', '1') != '0']   # ... and BatchNorm backward the data-gradient slabs
@@ -152,6 +153,10 @@ def _side_stream(dev):
     (bit pattern repeated over the 256 CUs), e.g. 1/2 = every other CU."""
     spec = _os.environ.get('AIDE_SIDE_CUMASK', SIDE_CUMASK[0])
     if not spec:
+        from . import streams as _streams         # a data-parallel rank measured which streams share a hardware queue
+        pref = _streams.PREFERRED.get(torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device())
+        if pref is not None and pref.get('side') is not None:
+            return pref['side']
         return torch.cuda.Stream(device=dev)
     import ctypes
     k, m = [int(v) for v in spec.split('/')]
@@ -375,7 +380,9 @@ class Plan(object):
         self.sk_ws = torch.empty(max(max_sk // 4, 1), **f32)
         self.lane_b = None               # second forward stream + its own BatchNorm / split-K workspaces (lane-1 chains)
         if any(st.get('lane') for st in self.steps):
-            self.lane_b = torch.cuda.Stream(device=device)
+            from . import streams as _streams
+            pref = _streams.PREFERRED.get(device.index if device.index is not None else torch.cuda.current_device())
+            self.lane_b = pref['lane'] if (pref is not None and pref.get('lane') is not None) else torch.cuda.Stream(device=device)
             self.bn_ws_b = ops.bn_ws(max(max_bnc, 1), device)
             self.sk_ws_b = torch.empty(max(max_sk // 4, 1), **f32)
             self.ev_lane_fork, self.ev_lane_join, self.ev_lane_acc = ops.new_event(), ops.new_event(), ops.new_event()
@@ -387,6 +394,10 @@ class Plan(object):
         self._bwd_ready = False
         self.profiler = None             # set by Engine (bench.py's per-kernel HIP-event timing)
         self._pack_key, self._pack_tabs, self._pack_ids, self.side_fwd = None, {}, None, None
+        # the weight-gradient stream of a plan that will run backward passes; it also carries the filter re-layout at the start
+        # of the forward pass (PACKS_ON_SIDE): the HIP runtime maps a process' streams onto 4 hardware queues, and the
+        # data-parallel path needs one of them for RCCL's own stream (aide_amd/distributed.py)
+        self.side = _side_stream(device) if (training and groups == 1) else None
         self._convs = self._conv_wslots = None
         self._late_pending, self._late_inflight = None, False
         self._gate_conv = None           # the first conv that needs the side-stream filter packs
@@ -442,7 +453,8 @@ class Plan(object):
             big = max(st['t1'].numel() for st in sa)
             self.sa_da, self.sa_db = torch.empty(big, **f32), torch.empty(big, **f32)
             self.sa_ws = torch.empty(max(st['gate'].numel() for st in sa) * 2 + 8, **f32)
-        self.side = _side_stream(self.dev)
+        if self.side is None:
+            self.side = _side_stream(self.dev)
         self.ev_fork, self.ev_join = ops.new_event(), ops.new_event()
         for st in self.steps:
             if st['kind'] in ('conv', 'convT'):
@@ -578,7 +590,7 @@ class Plan(object):
             self._shared['streams'] = (torch.cuda.current_stream(), None)
             return None
         if self.side_fwd is None:
-            self.side_fwd = torch.cuda.Stream(device=self.dev)
+            self.side_fwd = self.side if (self.side is not None and PACKS_ON_SIDE[0]) else torch.cuda.Stream(device=self.dev)
             self._side_fwd_ptr = ctypes.c_void_p(self.side_fwd.cuda_stream)
             self.ev_pack_fork = ops.new_event()
         ops.order(self.ev_pack_fork, ops.stream_ptr(), self._side_fwd_ptr)

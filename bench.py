@@ -135,6 +135,8 @@ def comm_block(world, reducers, per_rank, steps):
     ms = [t / steps * 1e3 for t in per_rank]
     return dict(backend=dist.get_backend(), ranks=world, rccl_version=ver,
                 buckets=sum(d['buckets'] for d in desc), bytes_per_step=sum(d['bytes_per_step'] for d in desc),
+                high_priority_streams=all(d.get('high_priority') for d in desc),
+                hw_queues=next((d['hw_queues'] for d in desc if d.get('hw_queues')), None),
                 exposed_ms=(round(sum(e for e in exposed if e is not None), 4)
                             if any(e is not None for e in exposed) else None),
                 exposed_note='mean over the last 8 timed steps of the event-timed wait of the compute stream for the '

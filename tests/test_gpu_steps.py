@@ -163,11 +163,14 @@ def test_rccl_gradient_allreduce_single_rank(dev):
     import os
     import torch.distributed as dist
     from aide_amd import utils as U
-    from aide_amd.distributed import GradAllReduce, broadcast_module
+    from aide_amd.distributed import GradAllReduce, broadcast_module, nccl_options
     from aide_amd.models_twomodalinputs import fuseunet
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    # (as init_from_env does it)
+    from aide_amd import streams
+    streams.reserve_queue(dev)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, pg_options=nccl_options())
     try:
         torch.manual_seed(2)
         net = fuseunet(2).to(dev)
