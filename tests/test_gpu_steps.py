@@ -221,3 +221,53 @@ def test_grouped_forward_equals_sequential(dev, kind):
             assert (p - q).abs().max().item() <= 2e-5 * (q.abs().max().item() + 1e-6), k
     with pytest.raises(RuntimeError):
         net.forward_groups([groups[0], tuple(t[:1] for t in groups[1])])
+
+
+def test_rank_streams_avoid_shared_hardware_queues(dev):
+    """A data-parallel rank measures which streams share a hardware queue (aide_amd/streams.py) before its engine builds a
+    plan: the weight-gradient stream it hands the engine runs beside the main stream AND beside RCCL's own stream, the lane
+    stream beside the two compute streams; the step on those streams gives the gradients of the plain step bit for bit."""
+    import os
+    import torch.distributed as dist
+    from aide_amd import utils as U, streams
+    from aide_amd.distributed import GradAllReduce, broadcast_module, nccl_options
+    from aide_amd.models_twomodalinputs import fuseunet
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29534')
+    g = torch.Generator().manual_seed(1)
+    x1, x2 = torch.randn(2, 3, 64, 64, generator=g).to(dev), torch.randn(2, 3, 64, 64, generator=g).to(dev)
+    t = (torch.rand(2, 64, 64, generator=g) > 0.8).long().to(dev)
+    w = torch.tensor([1.0, 1.0])
+    torch.manual_seed(2)
+    plain = fuseunet(2).to(dev)
+    plain.train()
+    U.CEMDiceLoss(w, w, w)(plain(x1, x2), t).backward()
+    ref = [p.grad.clone() for p in plain.parameters()]
+    saved = dict(streams.PREFERRED)
+    streams.PREFERRED.clear()
+    streams.reserve_queue(dev)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, pg_options=nccl_options())
+    try:
+        torch.manual_seed(2)
+        net = fuseunet(2).to(dev)
+        net.train()
+        broadcast_module(net)
+        red = GradAllReduce(net, bucket_mb=8.0, force=True)          # no plan yet: the rank picks its streams here
+        sp = red.stream_plan
+        assert sp is not None and len(sp['classes']) >= 3, sp
+        assert sp['side'] is not None and sp['side'] != sp['main_class'] and sp['side'] not in (sp['rccl_class'] or [])
+        assert sp['lane'] is not None and sp['lane'] not in (sp['main_class'], sp['side'])
+        pref = streams.PREFERRED[dev.index if dev.index is not None else torch.cuda.current_device()]
+        for _ in range(2):                                            # recorded pass + a replay
+            net.zero_grad()
+            U.CEMDiceLoss(w, w, w)(net(x1, x2), t).backward()
+        torch.cuda.synchronize()
+        plan = list(net.engine.plans.values())[0]
+        assert plan.side is pref['side'] and plan.lane_b is pref['lane']
+        assert red.describe()['hw_queues']['side'] == sp['side']
+        for a, p in zip(ref, net.parameters()):
+            assert torch.equal(a, p.grad)
+    finally:
+        dist.destroy_process_group()
+        streams.PREFERRED.clear()
+        streams.PREFERRED.update(saved)
