@@ -148,13 +148,27 @@ def use_winograd(n, cin, h, w, cout):
     return bool(USE_WINOGRAD[0] and lib.aide_conv3x3_wino_supported(cin, h, w, cout))
 
 
+SHARED_STREAMS = [_os.environ.get('AIDE_SHARED_STREAMS', '1') != '0']   # A-B switch: ONE weight-gradient stream and ONE lane / pack stream per device, shared by every plan of every engine
+
+
+def _preferred(dev):
+    """the per-device streams every plan should use instead of creating its own (a data-parallel rank's measured choice,
+    aide_amd/streams.py; or SHARED_STREAMS), or None"""
+    from . import streams as _streams
+    d = torch.device(dev)
+    idx = d.index if d.index is not None else torch.cuda.current_device()
+    pref = _streams.PREFERRED.get(idx)
+    if pref is None and SHARED_STREAMS[0]:
+        pref = _streams.PREFERRED[idx] = dict(side=torch.cuda.Stream(device=d), lane=torch.cuda.Stream(device=d))
+    return pref
+
+
 def _side_stream(dev):
     """Stream of the weight-gradient kernels.  AIDE_SIDE_CUMASK=<k>/<m> restricts it to k of every m compute units
     (bit pattern repeated over the 256 CUs), e.g. 1/2 = every other CU."""
     spec = _os.environ.get('AIDE_SIDE_CUMASK', SIDE_CUMASK[0])
     if not spec:
-        from . import streams as _streams         # a data-parallel rank measured which streams share a hardware queue
-        pref = _streams.PREFERRED.get(torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device())
+        pref = _preferred(dev)                    # a data-parallel rank measured which streams share a hardware queue
         if pref is not None and pref.get('side') is not None:
             return pref['side']
         return torch.cuda.Stream(device=dev)
@@ -380,8 +394,7 @@ class Plan(object):
         self.sk_ws = torch.empty(max(max_sk // 4, 1), **f32)
         self.lane_b = None               # second forward stream + its own BatchNorm / split-K workspaces (lane-1 chains)
         if any(st.get('lane') for st in self.steps):
-            from . import streams as _streams
-            pref = _streams.PREFERRED.get(device.index if device.index is not None else torch.cuda.current_device())
+            pref = _preferred(device)
             self.lane_b = pref['lane'] if (pref is not None and pref.get('lane') is not None) else torch.cuda.Stream(device=device)
             self.bn_ws_b = ops.bn_ws(max(max_bnc, 1), device)
             self.sk_ws_b = torch.empty(max(max_sk // 4, 1), **f32)
@@ -590,7 +603,10 @@ class Plan(object):
             self._shared['streams'] = (torch.cuda.current_stream(), None)
             return None
         if self.side_fwd is None:
-            self.side_fwd = self.side if (self.side is not None and PACKS_ON_SIDE[0]) else torch.cuda.Stream(device=self.dev)
+            pref = _preferred(self.dev)
+            self.side_fwd = (self.side if (self.side is not None and PACKS_ON_SIDE[0]) else
+                             pref['lane'] if (pref is not None and pref.get('lane') is not None) else
+                             torch.cuda.Stream(device=self.dev))
             self._side_fwd_ptr = ctypes.c_void_p(self.side_fwd.cuda_stream)
             self.ev_pack_fork = ops.new_event()
         ops.order(self.ev_pack_fork, ops.stream_ptr(), self._side_fwd_ptr)
