@@ -126,7 +126,11 @@ def pick(device, process_group=None, candidates=8, log=None):
         lane_cls = free[1] if len(free) > 1 else (shared[0] if shared else free[0])
         lane_members = [i for i in classes[lane_cls] if streams[i] is not side]
         lane = streams[lane_members[0]] if lane_members else None
-        PREFERRED[device.index if device.index is not None else torch.cuda.current_device()] = dict(side=side, lane=lane)
+        # a third stream for callers that run a second model beside the first (the co-teaching step's network 2): no queue is
+        # left for it, so it shares the lane's -- the least harmful partner (RCCL's queue would put all-reduces in front of
+        # it, the weight-gradient queue would serialise its backward pass)
+        aux = streams[lane_members[1]] if len(lane_members) > 1 else lane
+        PREFERRED[device.index if device.index is not None else torch.cuda.current_device()] = dict(side=side, lane=lane, aux=aux)
         out['side'], out['lane'] = free[0], lane_cls
     if log is not None:
         log(out)

@@ -57,7 +57,9 @@ _NET2_STREAM = {}
 def _net2_stream(device):
     s = _NET2_STREAM.get(device)
     if s is None:
-        s = _NET2_STREAM[device] = torch.cuda.Stream(device=device)
+        from ..engine import _preferred
+        pref = _preferred(device)                     # (a data-parallel rank: a stream whose hardware queue was measured)
+        s = _NET2_STREAM[device] = (pref.get('aux') if pref is not None else None) or torch.cuda.Stream(device=device)
     return s
 
 
