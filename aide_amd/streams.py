@@ -76,6 +76,8 @@ def pick(device, process_group=None, candidates=8, log=None):
     """Choose the weight-gradient and lane streams of a data-parallel rank (see the module docstring) and register them in
     PREFERRED[device.index].  -> dict(side, lane, classes, rccl_class) for the record."""
     import torch.distributed as dist
+    if not hasattr(torch.cuda, '_sleep'):                 # (the spin kernel of the probe)
+        return None
     main = torch.cuda.current_stream(device)
     streams = [main] + [torch.cuda.Stream(device=device) for _ in range(candidates)]
     scratch = [torch.zeros(64, device=device) for _ in streams]
