@@ -32,6 +32,8 @@ struct ConvArgs {
     long x_bs, y_bs, split_stride;
     int N, Cin, H, W, Cout, ldw;
     int tiles_w, tiles_h, n_co_tiles, splitk, chunks_total, accumulate;
+    const float* scale;   // eval mode (aide_conv_epilogue_affine): y = relu?(acc * scale[co] + bias[co]); nullptr: y = acc + bias
+    int relu;
 };
 
 template <int TCO, int WAVES_M, int WM, int WN, int PT_W, int CK, bool VEC>
@@ -263,6 +265,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = acc[m][nt][r] + bv[m][r];
+            if (a.scale) {                     // wave-uniform; never together with accumulate / split-K (the launcher refuses)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (wave_m * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float sv = co < a.Cout ? a.scale[co] : 1.0f;
+                    const float t = __builtin_fmaf(acc[m][nt][r], sv, bv[m][r]);
+                    v[r] = a.relu ? fmaxf(t, 0.0f) : t;
+                }
+            }
             if (a.accumulate) {
                 float old[16];
 #pragma unroll
@@ -486,6 +497,8 @@ int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, c
     ConvArgs a;
     a.x = x; a.wp = wp; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.ldw = ldw; a.splitk = splitk;
+    a.scale = aide_conv_affine_take(&a.relu);      // one-shot: armed by aide_conv_epilogue_affine for THIS launch
+    if (a.scale && (splitk > 1 || accumulate != 0 || !bias)) return AIDE_ERR_ARG;
     if (splitk > 1) {
         a.y = ws; a.y_bs = (long)Cout * H * W; a.split_stride = (long)N * Cout * H * W;
         a.bias = nullptr; a.accumulate = 0;

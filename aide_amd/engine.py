@@ -336,7 +336,8 @@ class Plan(object):
                             st['stats'] = torch.empty(cout * parts * 2, **f32)
                     # eval mode (the per-case inference loop): BatchNorm of the running statistics + ReLU as the epilogue of the
                     # F(4x4) forward kernel -- the conv writes the activation, z is never materialised
-                    st['fold'] = not training and FOLD_EVAL_BN[0] and st['wino_f'] == 4 and ww != 16
+                    st['fold'] = not training and FOLD_EVAL_BN[0] and (
+                        (st['wino_f'] == 4 and ww != 16) or (st['wino_f'] == 0 and (st['plan_f'] >> 8) <= 1))
                     st['pack_key'] = None
                     st['flops'] = 2.0 * n * hh * ww * cout * cin * 9      # algorithmic, per launch
                     # bf16 mode keeps the conv output z (read only by BatchNorm) and its gradient dz (read only by the
@@ -819,8 +820,12 @@ class Plan(object):
                 acc = 2 if slabs else 0
                 if st.get('fold'):                 # eval: y = relu(acc * scale + folded bias) straight into the activation
                     lib.aide_conv_epilogue_affine(ops.ptr(st['scale']), 1)
-                    ops.conv3x3_wino4(x, st['uf'], st['fbias'], self.view(st['dst']), accumulate=0, splitk=st['plan_f'] >> 8,
-                                      ws=sk_ws)
+                    if st['wino_f'] == 4:
+                        ops.conv3x3_wino4(x, st['uf'], st['fbias'], self.view(st['dst']), accumulate=0,
+                                          splitk=st['plan_f'] >> 8, ws=sk_ws)
+                    else:                          # direct kernel (the 32-channel first level, the stems), non-split
+                        ops.conv3x3_igemm(x, st['wf'], st['fbias'], self.view(st['dst']), accumulate=0, plan=st['plan_f'],
+                                          ws=sk_ws)
                     if prof is not None:
                         prof.end()
                     return

@@ -151,9 +151,10 @@ int aide_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, int
 /* Eval-mode BatchNorm folded into the convolution before it (the per-case inference loop,
  * trainchaos_comparison_1case.py:233-273: net.eval(), running statistics): aide_bn_eval_fold also writes
  * fbias = conv_bias * scale + shift; aide_conv_epilogue_affine(scale, relu) arms a one-shot epilogue for the NEXT
- * aide_conv3x3_wino4 launch (accumulate = 0, bias = fbias): y = relu?(acc * scale[co] + bias[co]), written straight
- * into the activation -- no separate BatchNorm pass over the conv output (a split-K launch applies it in its slab
- * reduce).  A launch that cannot honour an armed epilogue returns AIDE_ERR_ARG. */
+ * aide_conv3x3_wino4 or aide_conv3x3_igemm launch (accumulate = 0, bias = fbias): y = relu?(acc * scale[co] + bias[co]),
+ * written straight into the activation -- no separate BatchNorm pass over the conv output (a split-K aide_conv3x3_wino4
+ * launch applies it in its slab reduce; aide_conv3x3_igemm only non-split).  A launch that cannot honour an armed
+ * epilogue returns AIDE_ERR_ARG. */
 int aide_bn_eval_fold(int C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, const float* conv_bias, float* scale, float* shift,
                       float* fbias, aide_stream_t stream);
