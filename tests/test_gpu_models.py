@@ -440,6 +440,8 @@ def test_eval_fold_tracks_parameters_and_statistics(dev):
     load_state_dict -- over recorded and replayed launch tapes."""
     from aide_amd import engine, utils as U
     from aide_amd.optim import Adam
+    if not engine.FOLD_EVAL_BN[0]:
+        pytest.skip('AIDE_FOLD_EVAL_BN=0: the folded epilogue is switched off')
     net, ref = build_pair('fuseunet', False, dev)
     g = torch.Generator().manual_seed(21)
     xs = [torch.randn(4, 3, 128, 128, generator=g) for _ in range(2)]
