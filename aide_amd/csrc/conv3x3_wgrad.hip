@@ -13,6 +13,7 @@
 // Every split writes a partial slab [9][Co][Ci]; aide_conv3x3_wgrad sums the slabs in a fixed
 // order into dW[Co][Ci][3][3] (deterministic, no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 extern "C" int aide_conv3x3_wgrad_stem_splits(int N, int H, int W);
 extern "C" int aide_conv3x3_wgrad_stem_supported(int Co, int Ci, int H, int W);                  // conv3x3_wgrad_stem.hip
@@ -496,7 +497,11 @@ int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float*
         // split groups per workgroup (RDesc::narrow): enough of them to keep every thread busy, few enough to leave
         // >= 64 workgroups per layer
         const long cc = (long)Co * Ci;
-        r.narrow = (splits >= 16 && cc >= 64 * 64) ? 16 : (splits >= 4 ? 4 : (splits >= 2 && cc <= 256 * 256 ? 4 : 1));
+        // (a layer with MANY splits takes 16 groups whatever its size: with 4, the stems -- 96 (co, ci) pairs x 256 slabs -- were ONE
+        // workgroup walking 64 slabs per thread, and 32->64 x 128 slabs eight workgroups walking 32: the last batched reduce of
+        // a backward pass, the launch everything else waits for, took 51 us for 40 MB)
+        static const bool deep16 = !(getenv("AIDE_REDUCE_DEEP16") && atoi(getenv("AIDE_REDUCE_DEEP16")) == 0);    // A-B switch
+        r.narrow = (splits >= 16 && (cc >= 64 * 64 || deep16)) ? 16 : (splits >= 4 ? 4 : (splits >= 2 && cc <= 256 * 256 ? 4 : 1));
         r.block_start = 0;
         return AIDE_OK;
     }
