@@ -337,8 +337,15 @@ __global__ __launch_bounds__(R * YG) void wgrad_reduce_kernel(const float* __res
 }
 
 // R (co, ci) pairs per block: 64 when that still gives >= 256 blocks, else 16 with more split groups
+static int launch_wgrad_reduce_vec(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream);   // below
+
 static int launch_wgrad_reduce(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream) {
     const long cc = (long)Co * Ci;
+    // 16-byte form (one descriptor of the batched kernel): the dword kernels below keep 4 bytes per lane in flight and ran the
+    // bf16 mode's per-layer reduces -- 1.3 ms per C5 step on the weight-gradient stream -- at a fraction of the bandwidth
+    static const bool vec = !(getenv("AIDE_REDUCE_VEC") && atoi(getenv("AIDE_REDUCE_VEC")) == 0);      // A-B switch
+    if (vec && splits >= 2 && cc % 4 == 0 && ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0)
+        return launch_wgrad_reduce_vec(ws, splits, Co, Ci, dw, stream);
     const bool narrow = cc / 64 < 256 && splits >= 16;
     const unsigned nb = (unsigned)((cc + (narrow ? 15 : 63)) / (narrow ? 16 : 64));
     if (narrow)
@@ -470,7 +477,7 @@ __device__ __forceinline__ void wgrad_reduce_body4(const float* __restrict__ sla
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RBatch b) {
-    __shared__ __attribute__((aligned(16))) float sm[9 * (1024 + 16 * RM_PAD)];     // YG x 9 x (1024 / YG + pad)
+    __shared__ __attribute__((aligned(16))) float sm[9 * (1024 + 64 * RM_PAD)];     // YG x 9 x (1024 / YG + pad), YG <= 64
     const long blk = blockIdx.x;
     int lo = 0, hi = b.n - 1;
     while (lo < hi) {
@@ -478,13 +485,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RBatch b)
         if (b.d[mid].block_start <= blk) lo = mid; else hi = mid - 1;
     }
     const RDesc d = b.d[lo];
-    if (d.narrow == 16) wgrad_reduce_body4<16>(d.ws, d.splits, d.Co, d.Ci, d.dw, blk - d.block_start, sm);
+    if (d.narrow == 64) wgrad_reduce_body4<64>(d.ws, d.splits, d.Co, d.Ci, d.dw, blk - d.block_start, sm);
+    else if (d.narrow == 16) wgrad_reduce_body4<16>(d.ws, d.splits, d.Co, d.Ci, d.dw, blk - d.block_start, sm);
     else if (d.narrow == 4) wgrad_reduce_body4<4>(d.ws, d.splits, d.Co, d.Ci, d.dw, blk - d.block_start, sm);
     else wgrad_reduce_body4<1>(d.ws, d.splits, d.Co, d.Ci, d.dw, blk - d.block_start, sm);
 }
 
 struct RPending { bool defer = false; int n = 0; RDesc d[512]; };
 static RPending g_red;
+
+// split groups per workgroup (RDesc::narrow): enough of them to keep every thread busy, few enough to leave
+// >= 64 workgroups per layer
+// (a layer with MANY splits takes 16 groups whatever its size: with 4, the stems -- 96 (co, ci) pairs x 256 slabs -- were ONE
+// workgroup walking 64 slabs per thread, and 32->64 x 128 slabs eight workgroups walking 32: the last batched reduce of
+// a backward pass, the launch everything else waits for, took 51 us for 40 MB)
+static int reduce_groups(int splits, long cc) {
+    static const bool deep16 = !(getenv("AIDE_REDUCE_DEEP16") && atoi(getenv("AIDE_REDUCE_DEEP16")) == 0);    // A-B switch
+    // (... and 64 groups -- 4 lanes x 4 pairs per group, 16 pairs per workgroup -- where a small layer has >= 64 slabs: the
+    // first-level layers of the 512 x 512 bf16 mode leave 192 slabs of 1 024 .. 4 096 pairs)
+    // measured: C5 +-0, C2 +0.25 % (inside the noise): off
+    static const bool deep64 = getenv("AIDE_REDUCE_DEEP64") && atoi(getenv("AIDE_REDUCE_DEEP64")) != 0;       // A-B switch
+    if (deep64 && splits >= 64 && cc <= 64 * 64) return 64;
+    return (splits >= 16 && (cc >= 64 * 64 || deep16)) ? 16 : (splits >= 4 ? 4 : (splits >= 2 && cc <= 256 * 256 ? 4 : 1));
+}
+
+static int launch_wgrad_reduce_vec(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream) {
+    RBatch b;
+    b.n = 1; b.pad = 0;
+    RDesc& r = b.d[0];
+    r.ws = ws; r.dw = dw; r.splits = splits; r.Co = Co; r.Ci = Ci;
+    const long cc = (long)Co * Ci;
+    r.narrow = reduce_groups(splits, cc);
+    r.block_start = 0;
+    const int R = 1024 / r.narrow;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)((cc + R - 1) / R)), dim3(256), 0, stream, b);
+    return aide_launch_status();
+}
 
 }  // namespace
 
@@ -494,14 +530,7 @@ int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float*
     if (g_red.defer && g_red.n < 512 && ((long)Co * Ci) % 4 == 0 && ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0) {
         RDesc& r = g_red.d[g_red.n++];
         r.ws = ws; r.dw = dw; r.splits = splits; r.Co = Co; r.Ci = Ci;
-        // split groups per workgroup (RDesc::narrow): enough of them to keep every thread busy, few enough to leave
-        // >= 64 workgroups per layer
-        const long cc = (long)Co * Ci;
-        // (a layer with MANY splits takes 16 groups whatever its size: with 4, the stems -- 96 (co, ci) pairs x 256 slabs -- were ONE
-        // workgroup walking 64 slabs per thread, and 32->64 x 128 slabs eight workgroups walking 32: the last batched reduce of
-        // a backward pass, the launch everything else waits for, took 51 us for 40 MB)
-        static const bool deep16 = !(getenv("AIDE_REDUCE_DEEP16") && atoi(getenv("AIDE_REDUCE_DEEP16")) == 0);    // A-B switch
-        r.narrow = (splits >= 16 && (cc >= 64 * 64 || deep16)) ? 16 : (splits >= 4 ? 4 : (splits >= 2 && cc <= 256 * 256 ? 4 : 1));
+        r.narrow = reduce_groups(splits, (long)Co * Ci);
         r.block_start = 0;
         return AIDE_OK;
     }
