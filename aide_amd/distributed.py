@@ -152,6 +152,7 @@ class GradAllReduce(object):
         self.time_exposed = False        # bench.py: event-time the main stream's wait for the communication stream
         self._exposed = []
         self.stream_plan = None
+        self._st_idx = {}
         if self.world > 1 or force:          # force: exercise the RCCL path on a single-rank group (tests)
             p0 = next(iter(model.parameters()), None) if hasattr(model, 'parameters') else None
             dev = p0.device if p0 is not None else None
@@ -172,6 +173,7 @@ class GradAllReduce(object):
             self.sched = BucketScheduler(make_buckets(eng.offsets, numels, self.bucket_elems), len(numels))
             self._params = eng.params
             self._pidx = {id(p): i for i, p in enumerate(eng.params)}
+            self._st_idx = {}
 
     def _begin(self, flat):
         self._ensure()
@@ -221,11 +223,14 @@ class GradAllReduce(object):
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _after_op(self, st):
-        idxs = []
-        for key in ('conv', 'bn', 'mod'):
-            m = st.get(key)
-            if m is not None:
-                idxs += [self._pidx[id(p)] for p in m.parameters()]
+        idxs = self._st_idx.get(id(st))
+        if idxs is None:                      # (once per op: this runs as a tape callback in every backward pass)
+            idxs = []
+            for key in ('conv', 'bn', 'mod'):
+                m = st.get(key)
+                if m is not None:
+                    idxs += [self._pidx[id(p)] for p in m.parameters()]
+            self._st_idx[id(st)] = idxs
         for b in self.sched.mark(idxs):
             self._launch(b)
 
