@@ -485,6 +485,8 @@ size_t aide_conv3x3_ws_bytes(int N, int H, int W, int Cout, int splitk) {
 int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, const float* bias,
                        float* y, int64_t y_bs, int N, int Cin, int H, int W, int Cout,
                        int accumulate, int plan, float* ws, hipStream_t stream) {
+    int aff_relu = 0;
+    const float* aff = aide_conv_affine_take(&aff_relu);   // one-shot (aide_conv_epilogue_affine); taken before any early return
     if (!x || !wp || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return AIDE_ERR_ARG;
     if (plan < 0) plan = aide_conv3x3_plan(N, Cin, H, W, Cout);
     const int variant = plan & 0xff;
@@ -497,7 +499,7 @@ int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, c
     ConvArgs a;
     a.x = x; a.wp = wp; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.ldw = ldw; a.splitk = splitk;
-    a.scale = aide_conv_affine_take(&a.relu);      // one-shot: armed by aide_conv_epilogue_affine for THIS launch
+    a.scale = aff; a.relu = aff_relu;
     if (a.scale && (splitk > 1 || accumulate != 0 || !bias)) return AIDE_ERR_ARG;
     if (splitk > 1) {
         a.y = ws; a.y_bs = (long)Cout * H * W; a.split_stride = (long)N * Cout * H * W;

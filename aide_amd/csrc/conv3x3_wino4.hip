@@ -710,6 +710,9 @@ int aide_conv3x3_wino4_pack_multi(const void* descs, int n, int64_t total_blocks
 int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float* bias, float* y,
                        int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,
                        float* ws, hipStream_t stream) {
+    int aff_relu = 0;
+    const float* aff = aide_conv_affine_take(&aff_relu);   // one-shot: armed by aide_conv_epilogue_affine for THIS launch (taken
+                                                            // before any early return: a refused launch must not leave it armed)
     if (!x || !u || !y || !aide_conv3x3_wino4_supported(Cin, H, W, Cout) || x_bs % 4 || y_bs % 4 || (W == 16 && N % 2))
         return AIDE_ERR_ARG;
     static bool attr_set = false;
@@ -728,8 +731,6 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
     }
     W4Args a;
     a.stats = (splitk <= 1 && accumulate == 0 && W >= 32) ? aide_conv_stats_take() : nullptr;
-    int aff_relu = 0;
-    const float* aff = aide_conv_affine_take(&aff_relu);   // one-shot: armed by aide_conv_epilogue_affine for THIS launch
     const int mode = f4_mode(H, W, &a.blocks_h, &a.blocks_w);
     if (aff && (accumulate != 0 || !bias || (mode == 1 && splitk <= 1))) return AIDE_ERR_ARG;
     a.scale = splitk > 1 ? nullptr : aff;           // a split launch leaves plain slabs: its reduce applies the epilogue
