@@ -699,6 +699,12 @@ class Plan(object):
     def _forward_impl(self, inputs, out, gate, tape):
         import ctypes
         n = self.N
+        if not self.training and (tape is not None or not self._coef_ok):
+            # eval-mode coefficients of every BatchNorm, once per change of the parameters / running statistics (a replayed
+            # tape skips these entries while they are fresh)
+            for st in self.steps:
+                if st['kind'] in ('conv', 'convT'):
+                    ops.bn_eval_fold(st['bn'], st['conv'].bias, st['scale'], st['shift'], st['fbias'])
         # Two lanes: the ops a graph marks lane = 1 (the second encoder of a two-modality net: an independent conv -> BN ->
         # conv -> BN chain per level) run on a second stream, beside the lane-0 chain of the same level -- one chain's
         # HBM-bound BatchNorm and launch boundaries under the other's convolutions.  Fork: lane 1 waits for everything
@@ -711,12 +717,6 @@ class Plan(object):
         # first fork (its next level reads only what it pooled itself), and lane 0 waits for lane 1 exactly where it reads
         # lane 1's pooled channels -- on an event recorded right behind that pooling launch, not on lane 1's tail.  (With one
         # pooling launch per level on the main stream each level cost a join + a fork: ~35 us of idle time per lane and level.)
-        if not self.training and (tape is not None or not self._coef_ok):
-            # eval-mode coefficients of every BatchNorm, once per change of the parameters / running statistics (a replayed
-            # tape skips these entries while they are fresh)
-            for st in self.steps:
-                if st['kind'] in ('conv', 'convT'):
-                    ops.bn_eval_fold(st['bn'], st['conv'].bias, st['scale'], st['shift'], st['fbias'])
         free = dual and FREE_LANE[0]
         on_b, pend = False, []
         forked = False        # free: lane 1 has been ordered behind the main stream (since the last event that needs it again)
