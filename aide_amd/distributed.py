@@ -152,7 +152,7 @@ class GradAllReduce(object):
         self.time_exposed = False        # bench.py: event-time the main stream's wait for the communication stream
         self._exposed = []
         self.stream_plan = None
-        self._st_idx = {}
+        self._gen = 0                    # bumped whenever the bucket plan is rebuilt: stamps the per-op index caches
         if self.world > 1 or force:          # force: exercise the RCCL path on a single-rank group (tests)
             p0 = next(iter(model.parameters()), None) if hasattr(model, 'parameters') else None
             dev = p0.device if p0 is not None else None
@@ -173,7 +173,7 @@ class GradAllReduce(object):
             self.sched = BucketScheduler(make_buckets(eng.offsets, numels, self.bucket_elems), len(numels))
             self._params = eng.params
             self._pidx = {id(p): i for i, p in enumerate(eng.params)}
-            self._st_idx = {}
+            self._gen += 1
 
     def _begin(self, flat):
         self._ensure()
@@ -223,14 +223,20 @@ class GradAllReduce(object):
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _after_op(self, st):
-        idxs = self._st_idx.get(id(st))
-        if idxs is None:                      # (once per op: this runs as a tape callback in every backward pass)
+        # The parameter indices of an op are cached ON its step dict (this runs as a tape callback in every backward pass),
+        # stamped with this reducer and its bucket-plan generation: a step dict dies with its plan (MAX_PLANS eviction, a
+        # precision switch), so a new plan's step can never inherit another op's entry -- a cache keyed on id(step) could,
+        # CPython reuses the ids of freed dicts.
+        tag = st.get('_ddp_pidx')
+        if tag is not None and tag[0] is self and tag[1] == self._gen:
+            idxs = tag[2]
+        else:
             idxs = []
             for key in ('conv', 'bn', 'mod'):
                 m = st.get(key)
                 if m is not None:
                     idxs += [self._pidx[id(p)] for p in m.parameters()]
-            self._st_idx[id(st)] = idxs
+            st['_ddp_pidx'] = (self, self._gen, idxs)
         for b in self.sched.mark(idxs):
             self._launch(b)
 

@@ -1201,6 +1201,34 @@ class Plan(object):
 DIRECT_GRADS = [_os.environ.get('AIDE_DIRECT_GRADS', '1') != '0']    # A-B switch: parameter gradients assigned by the engine
 
 
+def _has_param_hooks(params):
+    """tensor hooks on a parameter (register_hook, register_post_accumulate_grad_hook) only fire when the parameter is
+    an autograd input of the node: the engine-assigned gradient path would bypass them silently"""
+    for p in params:
+        if p._backward_hooks or getattr(p, '_post_accumulate_grad_hooks', None):
+            return True
+    return False
+
+
+import sys as _sys
+
+
+def _max_refs(views):
+    m = 0
+    for v in views:
+        m = max(m, _sys.getrefcount(v))
+    return m
+
+
+_REF_BASE = _max_refs([object()])               # what a list element nobody else holds shows inside that loop
+
+
+def _views_held_elsewhere(views):
+    """does anybody besides the engine's own list still hold one of the arena's gradient views (a caller that kept
+    `p.grad` across zero_grad(): a snapshot, manual accumulation, gradient statistics)?"""
+    return _max_refs(views) > _REF_BASE
+
+
 class _NetFunction(torch.autograd.Function):
     """forward/backward of the whole network as one autograd node.
 
@@ -1208,8 +1236,15 @@ class _NetFunction(torch.autograd.Function):
     time per step than the whole launch sequence): the node hangs on one anchor tensor of the engine and its backward
     assigns `p.grad` itself -- views of the engine's persistent flat gradient arena when no gradient exists yet (the
     state after `optimizer.zero_grad()`), an accumulation into the existing gradients otherwise (what AccumulateGrad
-    does).  AIDE_DIRECT_GRADS=0 is the plain form (every parameter an autograd input) for tensor hooks /
-    torch.autograd.grad on parameters."""
+    does).  AIDE_DIRECT_GRADS=0 is the plain form (every parameter an autograd input) for torch.autograd.grad on
+    parameters; a module whose parameters carry tensor hooks (register_hook / register_post_accumulate_grad_hook) takes it
+    by itself.  Not visible from here, so still bypassed: reducers that hook the AccumulateGrad nodes of a WRAPPING module
+    (torch DistributedDataParallel / FSDP) -- use aide_amd.distributed.attach() instead.
+
+    Arena aliasing: `p.grad` after such a pass are views of ONE persistent buffer which the next pass overwrites in place;
+    a view the caller still references at that point is left alone (the pass takes a new arena), as `p.grad = None`
+    leaves a held tensor alone in torch.  The caller's stream is ordered behind the whole pass through the anchor's
+    AccumulateGrad node (see the end of backward)."""
 
     @staticmethod
     def forward(ctx, engine, n_inputs, direct, *tensors):
@@ -1237,15 +1272,20 @@ class _NetFunction(torch.autograd.Function):
         mode = 0                         # 0: plain autograd outputs; 1: fresh gradients = arena views; 2: arena += ; 3: per parameter
         if ctx.direct:
             arena, views = eng.grad_arena(dlogits.device)
-            base = arena.data_ptr()
             have = [p.grad for p in params]
             if all(g is None for g in have):
                 mode = 1
-            elif all(g is not None and g.data_ptr() == base + 4 * o and g.dtype == torch.float32
-                     for g, o in zip(have, eng.offsets)):
-                mode = 2                 # every gradient still lives in the arena (zero_grad(set_to_none=False), or a
-            else:                        # second backward before the optimizer): one add over the whole arena
-                mode = 3
+                if _views_held_elsewhere(views):
+                    # torch semantics: `p.grad = None` leaves a gradient tensor the caller still holds intact.  The arena
+                    # is about to be overwritten in place, so those tensors keep the OLD arena and this pass gets a new one.
+                    arena, views = eng.grad_arena(dlogits.device, fresh=True)
+            else:
+                base = arena.data_ptr()
+                if all(g is not None and g.data_ptr() == base + 4 * o and g.dtype == torch.float32
+                       for g, o in zip(have, eng.offsets)):
+                    mode = 2             # every gradient still lives in the arena (zero_grad(set_to_none=False), or a
+                else:                    # second backward before the optimizer): one add over the whole arena
+                    mode = 3
         flat = arena if mode == 1 else torch.empty(eng.flat_numel, device=dlogits.device, dtype=torch.float32)
         eng.side_stream = plan.side if (plan._bwd_ready and plan.overlap) else None
         eng.lane_stream = plan.lane_b if (plan.overlap and DUAL_BWD[0]) else None
@@ -1276,7 +1316,12 @@ class _NetFunction(torch.autograd.Function):
                     p.grad = v
                 else:
                     g.add_(v)
-        return (None,) * (3 + ctx.ntensors)
+        # The anchor gets a (never read) gradient so that autograd runs its AccumulateGrad node: that node lives on the
+        # stream the anchor was created on, autograd orders it behind this node's stream and -- at the end of the pass --
+        # the caller's current stream behind it.  Without it a forward issued on a non-current stream (network 2 of the
+        # co-teaching step) leaves `optimizer.step()` on the caller's stream racing this backward: the engine assigns the
+        # parameter gradients itself, so autograd's leaf-stream synchronisation never saw them.
+        return (None,) * (3 + ctx.ntensors - 1) + (torch.empty(1, device=dlogits.device),)
 
 
 class Engine(object):
@@ -1301,10 +1346,12 @@ class Engine(object):
         self._arena = self._views = self._anchor = None
         self._pslots = None
 
-    def grad_arena(self, device):
-        """the persistent flat gradient arena of this module and the per-parameter views into it (offsets: _refresh_params)"""
+    def grad_arena(self, device, fresh=False):
+        """the persistent flat gradient arena of this module and the per-parameter views into it (offsets: _refresh_params).
+        `p.grad` of a backward pass that found no gradients ARE these views: the next such pass overwrites them in place
+        (fresh=True: a new arena -- the pass found one of the old views still referenced by the caller)."""
         a = self._arena
-        if a is None or a.numel() != self.flat_numel or a.device != device:
+        if fresh or a is None or a.numel() != self.flat_numel or a.device != device:
             a = self._arena = torch.zeros(self.flat_numel, device=device, dtype=torch.float32)
             self._views = [a[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
         return a, self._views
@@ -1427,8 +1474,10 @@ class Engine(object):
         for p in self.params:
             if not p.is_cuda:
                 raise RuntimeError('aide_amd: module parameters are on %s; call .to(device) first' % p.device)
-        if DIRECT_GRADS[0] and torch.is_grad_enabled() and any(p.requires_grad for p in self.params):
+        if DIRECT_GRADS[0] and torch.is_grad_enabled() and any(p.requires_grad for p in self.params) and \
+                not _has_param_hooks(self.params):
             if self._anchor is None or self._anchor.device != ins[0].device:
                 self._anchor = torch.zeros(1, device=ins[0].device, requires_grad=True)
+            self._anchor.grad = None         # (its AccumulateGrad then takes the returned tensor as it is: no kernel)
             return _NetFunction.apply(self, len(ins), True, *(tuple(ins) + (self._anchor,)))
         return _NetFunction.apply(self, len(ins), False, *(tuple(ins) + tuple(self.params)))

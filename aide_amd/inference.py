@@ -72,14 +72,28 @@ def Dice3d_fn(inputs, targets):
 def keep_largest_connected_components(mask):
     """trainchaos_comparison_1case.py:68-77 / trainchaos_proposed_30cases1labeled.py:103-112: the largest connected blob of a
     label volume (connectivity 1: face neighbours), uint8.  CPU post-processing in the reference (skimage.measure.label +
-    regionprops); the same labelling with scipy.ndimage.label here -- its default structure is connectivity 1 and it numbers
-    the blobs in the same raster order, so `np.argmax(area)` picks the same blob on ties."""
+    regionprops).  skimage connects neighbours of EQUAL value (0 = background) and numbers the blobs in raster order of
+    their first voxel; scipy.ndimage.label connects every non-zero voxel, so it is run once per label value and the blobs
+    are ordered by their first voxel -- the same blob as the reference's `np.argmax(area)` on ties, and for a multi-class
+    volume (num_classes up to 8 here) blobs of different classes stay separate as they do there."""
     from scipy import ndimage
     mask = np.asarray(mask)
     out = np.zeros(mask.shape, dtype=np.uint8)
     if mask.size == 0 or mask.max() <= 0:
         return out
-    blobs, count = ndimage.label(mask)
-    area = np.bincount(blobs.reshape(-1), minlength=count + 1)[1:]
-    out[blobs == (int(np.argmax(area)) + 1)] = 1
+    best = None                                   # (area, -first voxel, value, blob labels, blob id)
+    for v in np.unique(mask):
+        if v == 0:
+            continue
+        blobs, count = ndimage.label(mask == v)
+        flat = blobs.reshape(-1)
+        area = np.bincount(flat, minlength=count + 1)[1:]
+        first = np.full(count + 1, flat.size, dtype=np.int64)
+        idx = np.flatnonzero(flat)
+        np.minimum.at(first, flat[idx], idx)
+        for b in range(count):
+            cand = (int(area[b]), -int(first[b + 1]))
+            if best is None or cand > best[0]:
+                best = (cand, blobs, b + 1)
+    out[best[1] == best[2]] = 1
     return out

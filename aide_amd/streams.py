@@ -12,8 +12,6 @@ So a data-parallel rank measures instead of hoping: `pick()` classifies a handfu
 with a spin kernel (a long spin on one stream, a tiny kernel on the other: does it finish first?), finds the queue RCCL's
 stream lives in the same way (a tiny all-reduce beside a spin), and hands the engine a weight-gradient stream that shares
 neither the main stream's queue nor RCCL's, and a lane stream away from both compute streams.  Costs ~50 ms once per process."""
-import time
-
 import torch
 
 _PLACEHOLDERS = []
@@ -35,27 +33,31 @@ def reserve_queue(device):
 
 PREFERRED = {}          # device index -> dict(side=Stream, lane=Stream): what engine.Plan uses instead of fresh streams
 _SPIN = 3_000_000       # torch.cuda._sleep cycles: ~1.5 ms
-_FAST = 0.6e-3          # a tiny kernel that is done this soon did not wait for the spin
+_BESIDE = 0.25          # "beside" = the probe was done at least this fraction of the spin's duration before the spin ended
 
 
-def _beside(spin_stream, probe):
-    """probe(): enqueue something tiny, return an object with .synchronize().  True when it completes while
-    `spin_stream` is still spinning (different hardware queues)."""
+def _beside(spin_stream, probe, spin=_SPIN):
+    """probe(): enqueue something tiny, return the torch.cuda.Event(enable_timing=True) recorded right behind it.  True when
+    it completed while `spin_stream` was still spinning (different hardware queues).  Decided on DEVICE timestamps (the
+    probe's completion against the spin's begin / end events), not on host wall-clock: host jitter, or a collective that
+    waits for a late peer, cannot turn "ran beside" into "waited" -- only a probe that really finished before the spin did
+    counts as beside."""
     torch.cuda.synchronize()
+    b, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(spin_stream):
-        torch.cuda._sleep(_SPIN)
-    t0 = time.perf_counter()
-    probe().synchronize()
-    dt = time.perf_counter() - t0
+        b.record()
+        torch.cuda._sleep(spin)
+        e.record()
+    done = probe()
     torch.cuda.synchronize()
-    return dt < _FAST
+    return done.elapsed_time(e) > _BESIDE * b.elapsed_time(e)
 
 
 def classify(streams, scratch):
     """-> list of classes (lists of indices into streams) that share a hardware queue"""
     def tiny(i):
         def run():
-            e = torch.cuda.Event()
+            e = torch.cuda.Event(enable_timing=True)
             with torch.cuda.stream(streams[i]):
                 scratch[i].add_(1)
                 e.record()
@@ -92,36 +94,40 @@ def pick(device, process_group=None, candidates=8, log=None):
         tiny = torch.ones(256, device=device)
         dist.all_reduce(tiny, group=process_group)          # communicator and RCCL's stream exist and have run
         torch.cuda.synchronize()
-        class _Done(object):
-            def __init__(self, ev):
-                self.ev = ev
-
-            def synchronize(self):
-                self.ev.synchronize()
-
         def collective(issue_stream):
             def run():
-                e = torch.cuda.Event()
+                e = torch.cuda.Event(enable_timing=True)
                 with torch.cuda.stream(issue_stream):
                     dist.all_reduce(tiny, group=process_group, async_op=True).wait()
                     e.record()
-                return _Done(e)
+                return e
             return run
         # EVERY rank issues the same number of collectives here (a fixed number of rounds, no early exit): ranks whose
-        # streams were handed out differently must not fall out of step.  With real peers a round is slow on all ranks
-        # when RCCL's stream is blocked on any of them -- the class is then avoided everywhere, which is the safe side.
-        flagged = set()
-        for r in range(4):
-            k = r % len(classes)
-            other = (k + 1) % len(classes)                                # issue from a queue that is not the one spinning
-            ok = _beside(streams[classes[k][0]], collective(streams[classes[other][0]]))
-            if not ok and r < len(classes):
-                flagged.add(k)
-        rccl_cls = sorted(flagged)
+        # streams were handed out differently must not fall out of step.  A collective completes only once every rank has
+        # issued it, so each round starts from a barrier (the skew between ranks is then far below the spin, which is twice
+        # as long as the classification's), every class is probed REPS times and flagged by majority.  With real peers a
+        # round is slow on all ranks when RCCL's stream is blocked on any of them -- the class is then avoided everywhere,
+        # which is the safe side.
+        REPS, ROUNDS = 3, 4
+        votes = [0] * len(classes)
+        for rep in range(REPS):
+            for r in range(ROUNDS):
+                k = r % len(classes)
+                other = (k + 1) % len(classes)                            # issue from a queue that is not the one spinning
+                torch.cuda.synchronize()
+                dist.barrier(group=process_group)
+                ok = _beside(streams[classes[k][0]], collective(streams[classes[other][0]]), spin=2 * _SPIN)
+                if not ok and r < len(classes):
+                    votes[k] += 1
+        rccl_cls = sorted(k for k, v in enumerate(votes) if 2 * v > REPS)
     rccl_set = set(rccl_cls or ())
     free = [k for k in range(len(classes)) if k != main_cls and k not in rccl_set]
     out = dict(classes=[[('main' if i == 0 else 's%d' % (i - 1)) for i in c] for c in classes],
                main_class=main_cls, rccl_class=rccl_cls, side=None, lane=None)
+    if not free:
+        import warnings
+        warnings.warn('aide_amd.streams.pick: no hardware queue is free of both the main stream and RCCL (classes %s, main %d, '
+                      'rccl %s): the engine falls back to streams as the runtime hands them out' % (out['classes'], main_cls, rccl_cls))
     if free:
         side = streams[classes[free[0]][0]]
         shared = [k for k in rccl_set if k != main_cls]

@@ -84,3 +84,53 @@ def test_bucketed_grad_mean_allreduce_world2():
     for rank, ok, nb, same in res:
         assert ok, 'rank %d: reduced gradients are not the mean over ranks' % rank
         assert nb >= 2 and same
+
+
+def test_op_index_cache_lives_on_the_step_dict():
+    """The per-op parameter indices are cached on the op's own step dict, stamped with the reducer and its bucket-plan
+    generation.  (A cache keyed on id(step dict) goes stale when a plan is evicted and rebuilt: CPython hands the id of
+    a freed dict to a new one, and a bucket would then be reduced before its gradients are written.)"""
+    from aide_amd.distributed import GradAllReduce
+    torch.manual_seed(0)
+    mods = [nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8), nn.Conv2d(8, 16, 3), nn.BatchNorm2d(16), nn.Conv2d(16, 2, 1)]
+    model = _FakeModel(mods)
+    eng = model.engine
+    red = GradAllReduce(model, bucket_mb=0.002, force=True)
+    launched = []
+    red._launch = launched.append                      # no process group here: record which buckets would go out
+    flat = torch.zeros(eng.flat_numel)
+    idx = {id(p): i for i, p in enumerate(eng.params)}
+
+    def want(*ms):
+        return sorted(idx[id(p)] for m in ms for p in m.parameters())
+
+    # "plan 1": op A = the first conv block
+    red._begin(flat)
+    st = dict(kind='conv', conv=mods[0], bn=mods[1])
+    red._after_op(st)
+    assert sorted(red.sched.done) == want(mods[0], mods[1])
+    stale_id = id(st)
+    del st
+    # "plan 2" after an eviction: fresh step dicts, one of which gets the freed dict's id -- but describes another op
+    red._begin(flat)
+    fresh = None
+    keep = []
+    for _ in range(64):
+        d = dict(kind='conv', conv=mods[2], bn=mods[3])
+        if id(d) == stale_id:
+            fresh = d
+            break
+        keep.append(d)
+    fresh = fresh if fresh is not None else keep[0]    # (no id reuse on this interpreter: the check below still holds)
+    red._after_op(fresh)
+    assert sorted(red.sched.done) == want(mods[2], mods[3])
+    # the same dict seen again: served from its own tag
+    assert fresh['_ddp_pidx'][0] is red and sorted(fresh['_ddp_pidx'][2]) == want(mods[2], mods[3])
+    # a rebuilt parameter list (engine._refresh_params) bumps the generation: tags of the old one are ignored
+    gen = red._gen
+    eng.params = list(eng.params)
+    red._begin(flat)
+    assert red._gen == gen + 1
+    fresh['_ddp_pidx'] = (red, gen, [0])               # a stale tag of the previous generation
+    red._after_op(fresh)
+    assert sorted(red.sched.done) == want(mods[2], mods[3])

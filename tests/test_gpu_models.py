@@ -328,6 +328,71 @@ def test_engine_assigned_gradients_follow_autograd_semantics(dev):
     assert frozen[5] is None and all(torch.equal(a, b) for k, (a, b) in enumerate(zip(ref, frozen)) if k != 5)
 
 
+def test_engine_assigned_gradients_keep_torch_contracts(dev):
+    """What the engine-assigned gradient path must not break (round-3 advisor findings): (1) a gradient tensor the caller
+    still holds after zero_grad() stays intact -- the next backward takes a new arena instead of overwriting it;
+    (2) tensor hooks on parameters fire (the module falls back to the plain autograd form while any are registered);
+    (3) a forward issued on a non-current stream: after backward() the CALLER's stream is ordered behind the whole pass
+    (autograd's leaf-stream synchronisation, through the anchor's AccumulateGrad) -- no hand-written wait_stream."""
+    from aide_amd import utils as U
+    g = torch.Generator().manual_seed(12)
+    w = torch.tensor([1.0, 1.0])
+    crit = U.CEMDiceLoss(w, w, w)
+
+    def batch(n, size):
+        xs = [torch.randn(n, 3, size, size, generator=g).to(dev) for _ in range(2)]
+        return xs, (torch.rand(n, size, size, generator=g) > 0.7).long().to(dev)
+    # (1) held gradients
+    net, _ = build_pair('fuseunet', False, dev)
+    params = list(net.parameters())
+    xs, t = batch(2, 32)
+    crit(net(*xs), t).backward()
+    held = [p.grad for p in params]                    # the caller keeps the tensors ...
+    snap = [h.clone() for h in held]
+    net.zero_grad()                                    # ... across zero_grad (set_to_none)
+    xs2, t2 = batch(2, 32)
+    crit(net(*xs2), t2).backward()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(held, snap)), 'a held gradient was overwritten by the next backward'
+    assert all(p.grad is not h for p, h in zip(params, held))
+    assert any(not torch.equal(p.grad, h) for p, h in zip(params, held))
+    del held
+    net.zero_grad()
+    crit(net(*xs2), t2).backward()                     # nobody holds the views any more: the arena is reused in place
+    a0 = net.engine._arena
+    net.zero_grad()
+    crit(net(*xs2), t2).backward()
+    assert net.engine._arena is a0
+    # (2) parameter hooks
+    ref, _ = build_pair('fuseunet', False, dev)
+    hk, _ = build_pair('fuseunet', False, dev)
+    calls = []
+    wp = list(hk.parameters())[0]
+    wp.register_hook(lambda gr: (calls.append(1), gr * 2.0)[1])
+    crit(ref(*xs), t).backward()
+    crit(hk(*xs), t).backward()
+    assert calls == [1], 'the parameter hook did not fire'
+    rp = list(ref.parameters())
+    assert torch.equal(wp.grad, 2.0 * rp[0].grad)
+    assert all(torch.equal(a.grad, b.grad) for a, b in zip(list(hk.parameters())[1:], rp[1:]))
+    # (3) forward on a non-current stream, gradients read on the caller's stream straight after backward()
+    net2, _ = build_pair('fuseunet', False, dev)
+    xs3, t3 = batch(4, 256)                            # a backward pass of several ms: the host is far ahead of it
+    s2 = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        net2.zero_grad()
+        s2.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s2):
+            out = net2(*xs3)
+            loss = crit(out, t3)
+        loss.backward()
+        early = [p.grad.clone() for p in net2.parameters()]      # caller's stream, no explicit wait
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, p.grad) for a, p in zip(early, net2.parameters())), \
+            "the caller's stream read gradients before the backward pass had written them"
+
+
 def test_two_lane_schedules_are_bit_identical(dev):
     """The second encoder's chains on their own stream (forward: default on; backward: AIDE_DUAL_BWD) must give the single-lane
     results bit for bit -- same kernels, own workspaces -- over several steps (also a race detector for the lane's

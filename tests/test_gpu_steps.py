@@ -193,6 +193,46 @@ def test_rccl_gradient_allreduce_single_rank(dev):
         dist.destroy_process_group()
 
 
+def test_gradient_allreduce_survives_plan_eviction(dev):
+    """Plans are dropped and rebuilt under the reducer (MAX_PLANS eviction with two alternating input shapes): every
+    rebuilt plan's ops must map to their own parameters in the bucket schedule (the per-op index cache lives on the step
+    dict, not in a table keyed on id(step)) -- gradients stay bit-identical to a replica without the reducer."""
+    import copy
+    import os
+    import torch.distributed as dist
+    from aide_amd import utils as U
+    from aide_amd.distributed import GradAllReduce, nccl_options
+    from aide_amd.models_twomodalinputs import fuseunet
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    from aide_amd import streams
+    streams.reserve_queue(dev)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, pg_options=nccl_options())
+    try:
+        torch.manual_seed(2)
+        net = fuseunet(2).to(dev)
+        ref = copy.deepcopy(net)
+        net.train(); ref.train()
+        net.engine.MAX_PLANS = 1
+        red = GradAllReduce(net, bucket_mb=8.0, force=True)
+        w = torch.tensor([1.0, 1.0])
+        g = torch.Generator().manual_seed(3)
+        for it in range(3):
+            for size in (64, 32):
+                x1 = torch.randn(2, 3, size, size, generator=g).to(dev)
+                x2 = torch.randn(2, 3, size, size, generator=g).to(dev)
+                t = (torch.rand(2, size, size, generator=g) > 0.8).long().to(dev)
+                net.zero_grad(); ref.zero_grad()
+                U.CEMDiceLoss(w, w, w)(net(x1, x2), t).backward()
+                U.CEMDiceLoss(w, w, w)(ref(x1, x2), t).backward()
+                torch.cuda.synchronize()
+                assert len(net.engine.plans) == 1 and all(p == 0 for p in red.sched.pending)
+                for (k, a), b in zip(net.named_parameters(), ref.parameters()):
+                    assert torch.equal(a.grad, b.grad), (it, size, k)
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize('kind', ['fuseunet', 'unetsa'])
 def test_grouped_forward_equals_sequential(dev, kind):
     """net.forward_groups([...]) (one stacked pass, per-group BatchNorm statistics) == the sequential train-mode forwards
