@@ -97,7 +97,7 @@ class _Lib(object):
                 try:
                     fn = getattr(dll, name)      # AttributeError if the symbol is not exported
                 except AttributeError:
-                    if 'AIDE_HIP_LIB' in os.environ:     # an A-B build of an older tree (tools/ab_build.sh): fails when called
+                    if 'AIDE_HIP_LIB' in os.environ:     # an A-B build of an older tree (tools/probes/mk_probe.py): fails when called
                         continue
                     raise
                 fn.restype = ret

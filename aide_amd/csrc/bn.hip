@@ -660,7 +660,7 @@ int aide_bn_train_fwd_slabs(const float* slabs, int splitk, int64_t split_stride
 #undef AIDE_BN_FWD_S
 }
 
-// BatchNorm(train)+ReLU whose statistics were emitted by the convolution's own epilogue (aide_conv_stats_sink): parts
+// BatchNorm(train)+ReLU whose statistics were emitted by the convolution's own epilogue (stats_parts of aide_conv3x3_wino4): parts
 // [C][nparts][2] fp32 = per channel and conv workgroup tile the sum and sum of squares of z - conv_bias.  One launch, one
 // read of z.  (H*W % 4 == 0 and 16-byte aligned batch strides.)
 // parts_stride: entries per channel in `parts` (>= nparts).  A group of a stacked batch passes the pointer to ITS first

@@ -78,10 +78,6 @@ extern "C" int aide_ktimer_slot(int family, double flops, hipEvent_t* e0, hipEve
         else                                                                                                  \
             hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                \
     } while (0)
-// one-shot sink for the BatchNorm statistics of the next forward conv launch (bn.hip: aide_conv_stats_sink / _take)
-float* aide_conv_stats_take();
-// one-shot per-channel scale (+ ReLU flag) of the next F(4x4) forward launch's epilogue (ktimer.hip: aide_conv_epilogue_affine)
-const float* aide_conv_affine_take(int* relu);
 #define AIDE_CONV_FLOPS(N, H, W, Co, Ci) (2.0 * (double)(N) * (double)(H) * (double)(W) * (double)(Co) * (double)(Ci) * 9.0)
 
 // XCD-aware bijective remap of a 1-D block id: the hardware dispatches block b to XCD b % 8;

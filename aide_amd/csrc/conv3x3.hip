@@ -32,7 +32,7 @@ struct ConvArgs {
     long x_bs, y_bs, split_stride;
     int N, Cin, H, W, Cout, ldw;
     int tiles_w, tiles_h, n_co_tiles, splitk, chunks_total, accumulate;
-    const float* scale;   // eval mode (aide_conv_epilogue_affine): y = relu?(acc * scale[co] + bias[co]); nullptr: y = acc + bias
+    const float* scale;   // eval mode (epi_scale of aide_conv3x3_igemm): y = relu?(acc * scale[co] + bias[co]); nullptr: y = acc + bias
     int relu;
 };
 
@@ -217,7 +217,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 #pragma unroll
                 for (int nt = 0; nt < WN; ++nt)
                     acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afc[m], bfc[nt], acc[m][nt], 0, 0, 0);
-#ifndef AIDE_PROBE_NOSTAGE
             if (st < HALF) {
 #pragma unroll
                 for (int k = 0; k < PER; ++k)
@@ -227,7 +226,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
                 for (int k = 0; k < PER; ++k)
                     if ((st - HALF) * PER + k < NL) put((st - HALF) * PER + k, nxt);
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         frag(0, afA, bfA);
@@ -484,9 +482,9 @@ size_t aide_conv3x3_ws_bytes(int N, int H, int W, int Cout, int splitk) {
 //   the plan has splitk == 1). accumulate != 0 -> y += result.
 int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, const float* bias,
                        float* y, int64_t y_bs, int N, int Cin, int H, int W, int Cout,
-                       int accumulate, int plan, float* ws, hipStream_t stream) {
-    int aff_relu = 0;
-    const float* aff = aide_conv_affine_take(&aff_relu);   // one-shot (aide_conv_epilogue_affine); taken before any early return
+                       int accumulate, int plan, float* ws, const float* epi_scale, int epi_relu, hipStream_t stream) {
+    const float* aff = epi_scale;                          // eval mode: y = relu?(acc * scale[co] + bias[co]) (nullptr: y = acc + bias)
+    const int aff_relu = aff ? epi_relu : 0;
     if (!x || !wp || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return AIDE_ERR_ARG;
     if (plan < 0) plan = aide_conv3x3_plan(N, Cin, H, W, Cout);
     const int variant = plan & 0xff;

@@ -41,10 +41,9 @@ extern "C" int aide_conv3x3_wgrad_stem_splits(int N, int H, int W);
 extern "C" int aide_conv3x3_wgrad_stem_supported(int Co, int Ci, int H, int W);                  // conv3x3_wgrad_stem.hip
 extern "C" int aide_conv3x3_wgrad_stem(const void* dz, int dz_bf16, int64_t dz_bs, const float* x, int64_t x_bs, float* dw,
                                        int N, int Co, int Ci, int H, int W, float* ws, int splits, int round_bf16,
-                                       hipStream_t stream);
-#include <stdlib.h>
+                                       void* queue, hipStream_t stream);
 
-int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream);
+int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, void* queue, hipStream_t stream);
 
 namespace {
 
@@ -242,31 +241,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
         };
         auto kstep = [&](int t, bf16x8 (&afc)[WM], bf16x8 (&bfc)[WN], bf16x8 (&afn)[WM], bf16x8 (&bfn)[WN]) {
             if (t + 1 < 9) frag(t + 1, afn, bfn);
-#ifdef AIDE_PROBE_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
-#ifndef AIDE_PROBE_NO_MFMA
 #pragma unroll
             for (int m = 0; m < WM; ++m)
 #pragma unroll
                 for (int nt = 0; nt < WN; ++nt)
                     acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[m], bfc[nt], acc[m][nt], 0, 0, 0);
-#else       // ablation probe: keep the fragments alive without the matrix pipe
-#pragma unroll
-            for (int m = 0; m < WM; ++m) acc[m][0][0] += __builtin_bit_cast(f32x4, afc[m])[0];
-#pragma unroll
-            for (int nt = 0; nt < WN; ++nt) acc[0][nt][1] += __builtin_bit_cast(f32x4, bfc[nt])[0];
-#endif
-#ifdef AIDE_PROBE_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
             if (t < NOPS) {
-#ifndef AIDE_PROBE_NO_PUT
                 put(t, nxt);               // chunk + 1 (fetched one stage ago) -> the other buffer
-#endif
-#ifndef AIDE_PROBE_NO_FETCH
                 fetch(t, chunk + 2);       // its registers re-issue their loads at once
-#endif
             }
             // a wave issues in order: left alone, the staging instructions queue up behind the last MFMA and the
             // matrix pipe drains.  Interleave: after each MFMA one fragment read, two conversions, one LDS store,
@@ -279,9 +261,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
             }
-#ifndef AIDE_PROBE_NO_TAP_BARRIER
             __builtin_amdgcn_sched_barrier(0);
-#endif
         };
         frag(0, afA, bfA);
         kstep(0, afA, bfA, afB, bfB);
@@ -298,9 +278,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void conv3x3_bf16_kernel(const BfArgs
     }
 
     // ---- epilogue: D row i = (r&3) + 8*(r>>2) + 4*half (output channel), column j (pixel) ----
-#ifdef AIDE_PROBE_NO_STORE
-    if (a.N > 0) { if (acc[0][0][0] == 123.456f) ((float*)a.y)[0] = acc[WM - 1][WN - 1][15]; return; }
-#endif
     if constexpr (OUT_BF16) {
         // bf16 output through LDS.  Registers r, r+1 are channels i, i+1 at pixel j: neighbouring lanes swap one value
         // (DPP) so that an even lane owns channel i at pixels (j, j+1) and an odd lane channel i+1 at (j-1, j), one
@@ -512,9 +489,7 @@ int launch_bf16_t(BfArgs a, hipStream_t stream) {
 
 template <int WM, int WAVES_M, int WN, int OCC, bool RAGGED, bool IN_BF16, bool OUT_BF16, int NW>
 int launch_bf16_r(const BfArgs& a, hipStream_t stream) {
-    static const int force = getenv("AIDE_BF16_TW") ? atoi(getenv("AIDE_BF16_TW")) : 0;     // probe switch
-    const bool wide = force ? force == 64 : bf16_wide_tile(a.W, a.H);
-    if (wide && a.W % 64 == 0) return launch_bf16_t<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, 64, NW>(a, stream);
+    if (bf16_wide_tile(a.W, a.H)) return launch_bf16_t<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, 64, NW>(a, stream);
     return launch_bf16_t<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, 32, NW>(a, stream);
 }
 
@@ -535,12 +510,12 @@ int launch_bf16(const BfArgs& a, int in_bf16, int out_bf16, hipStream_t stream) 
                         : launch_bf16_r<WM, WAVES_M, WN, OCC, false, false, false, NW>(a, stream);
 }
 
-// variant: 0 = 32 co, 1 = 64 co (4 waves, two workgroups per CU), 2 = 128 co (8 waves, one workgroup per CU, the two co
-// halves share the halo tile); pixel tile 512 = 16 rows x 32 or 8 rows x 64 columns.  (A 4-wave 128 co x 256 px tile at
-// one workgroup per CU lost 1.0-1.3x to variant 1 on every layer and was dropped.)
+// variant: 0 = 32 co, 1 = 64 co (4 waves, two workgroups per CU); pixel tile 512 = 16 rows x 32 or 8 rows x 64 columns.
+// (Dropped after measurement: a 4-wave 128 co x 256 px tile at one workgroup per CU, 1.0-1.3x slower on every layer, and a
+// 128 co tile on 8 waves whose two co halves share the halo tile, level or behind once the epilogues stopped stalling.)
 long bf16_blocks(int variant, int N, int H, int W, int Cout) {
-    const int tco = variant == 2 ? 128 : (variant == 1 ? 64 : 32);
-    const int tw = (bf16_wide_tile(W, H) && W % 64 == 0) ? 64 : 32, th = 512 / tw;
+    const int tco = variant == 1 ? 64 : 32;
+    const int tw = bf16_wide_tile(W, H) ? 64 : 32, th = 512 / tw;
     return (long)(W / tw) * ((H + th - 1) / th) * N * (Cout / tco);
 }
 // 32 or 64 output channels per workgroup, two workgroups per CU.  (The 128-co tile on 8 waves, one workgroup per CU, was
@@ -548,12 +523,7 @@ long bf16_blocks(int variant, int N, int H, int W, int Cout) {
 // two-workgroup form is level on the long-K layers and 5-10 % ahead on the short-K ones -- dgrad 64->128 @512x512 0.409 ->
 // 0.371 ms, 128->128 @256x256 0.147 -> 0.135 -- whose prologue and epilogue nothing overlaps at one workgroup per CU:
 // round 3, tools/bench_bf16.py with AIDE_BF16_V=1.)
-int bf16_variant(int N, int H, int W, int Cout) {
-    static const int force = getenv("AIDE_BF16_V") ? atoi(getenv("AIDE_BF16_V")) : -1;     // probe switch (2 = the 128-co tile)
-    if (force == 2 && Cout % 128 == 0) return 2;
-    const int v = Cout % 64 == 0 ? 1 : 0;
-    return (force >= 0 && force < v) ? force : v;
-}
+int bf16_variant(int N, int H, int W, int Cout) { return Cout % 64 == 0 ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------ weight gradient
 struct BgArgs {
@@ -589,7 +559,6 @@ template <int R, int NWCO> struct GCfg {
     static constexpr int KS = 2 * R;                 // k-steps per stage
     static_assert(TCO * R * 4 % NT == 0 && 64 * (R + 2) * 4 % NT == 0, "staging units must divide evenly");
 };
-constexpr int G_RMIN = 2;
 
 template <int R, bool DZ_BF16, bool X_BF16, int NWCO>
 __global__ __launch_bounds__(128 * NWCO, (R == 2 && NWCO == 2) ? 2 : 1) void conv3x3_wgrad_bf16_kernel(const BgArgs g) {
@@ -838,18 +807,13 @@ int launch_wgrad_bf16(BgArgs g, hipStream_t stream) {
     return aide_launch_status();
 }
 
-// rows per stage: 2 = two workgroups per CU (probe switch AIDE_BF16_WG_R)
-int wgrad_bf16_rows() {
-    static const int r = getenv("AIDE_BF16_WG_R") ? atoi(getenv("AIDE_BF16_WG_R")) : 4;
-    return r == 2 ? 2 : 4;
-}
-// co blocks per workgroup: the 128 x 64 tile (8 waves) pays on the large layers (>= 150 GFLOP: 1.06 vs 0.84 PFLOP/s on
-// 1024->512 @64x64 x8); below that it doubles the split count for nothing (probe switch AIDE_BF16_WG_NWCO: 2 = never)
-int wgrad_bf16_nwco(int N, int Co, int Ci, int H, int W) {
-    static const int f = getenv("AIDE_BF16_WG_NWCO") ? atoi(getenv("AIDE_BF16_WG_NWCO")) : 4;
-    const double flops = 18.0 * N * H * W * (double)Co * Ci;
-    const char* mf = getenv("AIDE_BF16_WG_NWCO_MINFLOPS");       // tests lower the threshold to reach the 8-wave kernel
-    return (f == 4 && Co % 128 == 0 && wgrad_bf16_rows() == 4 && flops >= (mf ? atof(mf) : 1.5e11)) ? 4 : 2;
+// co blocks of 32 per workgroup: the 128 x 64 tile (8 waves) pays on the large layers (>= 150 GFLOP: 1.06 vs 0.84 PFLOP/s on
+// 1024->512 @64x64 x8); below that it doubles the split count for nothing.  co_blocks: the caller's choice (2 or 4; 0 = this
+// rule).  (R = 2 rows per stage -- two workgroups per CU -- measured 3.5 % behind on the C5 step and is not instantiated.)
+int wgrad_bf16_nwco(int N, int Co, int Ci, int H, int W, int co_blocks) {
+    if (co_blocks == 2 || Co % 128 != 0) return 2;
+    if (co_blocks == 4) return 4;
+    return 18.0 * N * H * W * (double)Co * Ci >= 1.5e11 ? 4 : 2;
 }
 
 }  // namespace
@@ -914,7 +878,6 @@ int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint1
     }
     int rc;
     switch (bf16_variant(N, H, W, Cout)) {
-        case 2: rc = launch_bf16<2, 2, 4, 1, 8>(a, x_bf16, kernel_out_bf16, stream); break;
         case 1: rc = launch_bf16<2, 1, 4, 2, 4>(a, x_bf16, kernel_out_bf16, stream); break;
         default: rc = launch_bf16<1, 1, 4, 2, 4>(a, x_bf16, kernel_out_bf16, stream); break;
     }
@@ -945,13 +908,13 @@ int aide_conv3x3_wgrad_bf16_supported(int Co, int Ci, int H, int W) {
     return Co % 32 == 0 && Ci >= 1 && W % 32 == 0 && H % 4 == 0;
 }
 
-int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W) {
+int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W, int co_blocks) {
     if (aide_conv3x3_wgrad_stem_supported(Co, Ci, H, W))        // folded-tap kernel (conv3x3_wgrad_stem.hip)
         return aide_conv3x3_wgrad_stem_splits(N, H, W);
-    const int tco = 32 * wgrad_bf16_nwco(N, Co, Ci, H, W);
+    const int tco = 32 * wgrad_bf16_nwco(N, Co, Ci, H, W, co_blocks);
     const long tiles = (long)((Co + tco - 1) / tco) * ((Ci + 63) / 64);
-    const long chunks = (long)N * (H / wgrad_bf16_rows()) * (W / 32);
-    static const long target = getenv("AIDE_BF16_WG_TARGET") ? atol(getenv("AIDE_BF16_WG_TARGET")) : 192;   // probe
+    const long chunks = (long)N * (H / 4) * (W / 32);
+    const long target = 192;
     long s = (target + tiles - 1) / tiles;       // fewer workgroups than CUs: the kernel runs on the side stream and leaves
                                                  // CUs to the dependent chain (same-box C5 step: 256 -> 439.9, 224 -> 442.9,
                                                  // 192 -> 444.4, 128 -> 428; 512 / 1024 measured 6 % / 16 % slower: twice the
@@ -961,40 +924,41 @@ int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W) {
     return (int)s;
 }
 
-size_t aide_conv3x3_wgrad_bf16_ws_bytes(int N, int Co, int Ci, int H, int W) {
-    return (size_t)aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W) * 9 * Co * Ci * sizeof(float);
+size_t aide_conv3x3_wgrad_bf16_ws_bytes(int N, int Co, int Ci, int H, int W, int co_blocks) {
+    return (size_t)aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W, co_blocks) * 9 * Co * Ci * sizeof(float);
 }
 
 //   dz : [N][Co][H][W] (batch stride dz_bs; fp32, or bf16 storage when dz_bf16)   a : [N][Ci][H][W] (batch stride a_bs;
 //   fp32, or bf16 storage when a_bf16)   dw : [Co][Ci][3][3] fp32
 int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, const void* a, int a_bf16, int64_t a_bs,
-                                  float* dw, int N, int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
+                                  float* dw, int N, int Co, int Ci, int H, int W, float* ws, int co_blocks, void* queue,
+                                  hipStream_t stream) {
     if (!dz || !a || !dw || !ws || N <= 0 || !aide_conv3x3_wgrad_bf16_supported(Co, Ci, H, W)) return AIDE_ERR_ARG;
+    if (co_blocks != 0 && co_blocks != 2 && co_blocks != 4) return AIDE_ERR_ARG;
     if ((dz_bs % (dz_bf16 ? 8 : 4)) || (a_bs % (a_bf16 ? 8 : 4))) return AIDE_ERR_ARG;
     if (a_bf16 && aide_conv3x3_wgrad_stem_supported(Co, Ci, H, W)) return AIDE_ERR_ARG;   // stems read the fp32 images
     if (aide_conv3x3_wgrad_stem_supported(Co, Ci, H, W))                        // Ci <= 3
         return aide_conv3x3_wgrad_stem(dz, dz_bf16, dz_bs, (const float*)a, a_bs, dw, N, Co, Ci, H, W, ws,
-                                       aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W), 1, stream);
+                                       aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W, co_blocks), 1, queue, stream);
     BgArgs g;
     g.dz = dz; g.x = a; g.slabs = ws; g.dz_bs = dz_bs; g.x_bs = a_bs;
     g.N = N; g.Co = Co; g.Ci = Ci; g.H = H; g.W = W;
     g.n_co_tiles = (Co + 63) / 64; g.n_ci_tiles = (Ci + 63) / 64;
     g.segs_w = W / 32;
-    g.splits = aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W);
+    g.splits = aide_conv3x3_wgrad_bf16_splits(N, Co, Ci, H, W, co_blocks);
     int rc;
 #define AIDE_WG(RR, NW) (dz_bf16 ? (a_bf16 ? launch_wgrad_bf16<RR, true, true, NW>(g, stream) : launch_wgrad_bf16<RR, true, false, NW>(g, stream)) \
                                  : (a_bf16 ? launch_wgrad_bf16<RR, false, true, NW>(g, stream) : launch_wgrad_bf16<RR, false, false, NW>(g, stream)))
-    if (wgrad_bf16_rows() == 2) rc = AIDE_WG(2, 2);
-    else if (wgrad_bf16_nwco(N, Co, Ci, H, W) == 4) rc = AIDE_WG(4, 4);
+    if (wgrad_bf16_nwco(N, Co, Ci, H, W, co_blocks) == 4) rc = AIDE_WG(4, 4);
     else rc = AIDE_WG(4, 2);
 #undef AIDE_WG
     if (rc != 0) return rc;
-    return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, stream);
+    return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, queue, stream);
 }
 
 int aide_conv3x3_wgrad_bf16(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N, int Co,
                             int Ci, int H, int W, float* ws, hipStream_t stream) {
-    return aide_conv3x3_wgrad_bf16_mixed(dz, 0, dz_bs, a, 0, a_bs, dw, N, Co, Ci, H, W, ws, stream);
+    return aide_conv3x3_wgrad_bf16_mixed(dz, 0, dz_bs, a, 0, a_bs, dw, N, Co, Ci, H, W, ws, 0, nullptr, stream);
 }
 
 }  // extern "C"

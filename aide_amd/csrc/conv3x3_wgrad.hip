@@ -19,7 +19,7 @@ extern "C" int aide_conv3x3_wgrad_stem_splits(int N, int H, int W);
 extern "C" int aide_conv3x3_wgrad_stem_supported(int Co, int Ci, int H, int W);                  // conv3x3_wgrad_stem.hip
 extern "C" int aide_conv3x3_wgrad_stem(const void* dz, int dz_bf16, int64_t dz_bs, const float* x, int64_t x_bs, float* dw,
                                        int N, int Co, int Ci, int H, int W, float* ws, int splits, int round_bf16,
-                                       hipStream_t stream);
+                                       void* queue, hipStream_t stream);
 
 namespace {
 
@@ -343,8 +343,7 @@ static int launch_wgrad_reduce(const float* ws, int splits, int Co, int Ci, floa
     const long cc = (long)Co * Ci;
     // 16-byte form (one descriptor of the batched kernel): the dword kernels below keep 4 bytes per lane in flight and ran the
     // bf16 mode's per-layer reduces -- 1.3 ms per C5 step on the weight-gradient stream -- at a fraction of the bandwidth
-    static const bool vec = !(getenv("AIDE_REDUCE_VEC") && atoi(getenv("AIDE_REDUCE_VEC")) == 0);      // A-B switch
-    if (vec && splits >= 2 && cc % 4 == 0 && ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0)
+    if (splits >= 2 && cc % 4 == 0 && ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0)
         return launch_wgrad_reduce_vec(ws, splits, Co, Ci, dw, stream);
     const bool narrow = cc / 64 < 256 && splits >= 16;
     const unsigned nb = (unsigned)((cc + (narrow ? 15 : 63)) / (narrow ? 16 : 64));
@@ -491,8 +490,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RBatch b)
     else wgrad_reduce_body4<1>(d.ws, d.splits, d.Co, d.Ci, d.dw, blk - d.block_start, sm);
 }
 
-struct RPending { bool defer = false; int n = 0; RDesc d[512]; };
-static RPending g_red;
+// a caller-owned queue of slab reduces that wait for ONE batched launch (aide_wgrad_queue_*): host memory only
+struct RQueue { int n = 0; RDesc d[512]; };
 
 // split groups per workgroup (RDesc::narrow): enough of them to keep every thread busy, few enough to leave
 // >= 64 workgroups per layer
@@ -500,13 +499,8 @@ static RPending g_red;
 // workgroup walking 64 slabs per thread, and 32->64 x 128 slabs eight workgroups walking 32: the last batched reduce of
 // a backward pass, the launch everything else waits for, took 51 us for 40 MB)
 static int reduce_groups(int splits, long cc) {
-    static const bool deep16 = !(getenv("AIDE_REDUCE_DEEP16") && atoi(getenv("AIDE_REDUCE_DEEP16")) == 0);    // A-B switch
-    // (... and 64 groups -- 4 lanes x 4 pairs per group, 16 pairs per workgroup -- where a small layer has >= 64 slabs: the
-    // first-level layers of the 512 x 512 bf16 mode leave 192 slabs of 1 024 .. 4 096 pairs)
-    // measured: C5 +-0, C2 +0.25 % (inside the noise): off
-    static const bool deep64 = getenv("AIDE_REDUCE_DEEP64") && atoi(getenv("AIDE_REDUCE_DEEP64")) != 0;       // A-B switch
-    if (deep64 && splits >= 64 && cc <= 64 * 64) return 64;
-    return (splits >= 16 && (cc >= 64 * 64 || deep16)) ? 16 : (splits >= 4 ? 4 : (splits >= 2 && cc <= 256 * 256 ? 4 : 1));
+    // (64 groups for small layers with >= 64 slabs measured +-0 and is not built in)
+    return splits >= 16 ? 16 : (splits >= 4 ? 4 : (splits >= 2 && cc <= 256 * 256 ? 4 : 1));
 }
 
 static int launch_wgrad_reduce_vec(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream) {
@@ -524,11 +518,12 @@ static int launch_wgrad_reduce_vec(const float* ws, int splits, int Co, int Ci, 
 
 }  // namespace
 
-// shared with conv3x3_wgrad4.hip, conv3x3_wgrad_stem.hip, conv3x3_bf16.hip: reduce now, or (between
-// aide_wgrad_reduce_defer(1) and aide_wgrad_reduce_flush) remember the slabs for the batched launch
-int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream) {
-    if (g_red.defer && g_red.n < 512 && ((long)Co * Ci) % 4 == 0 && ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0) {
-        RDesc& r = g_red.d[g_red.n++];
+// shared with conv3x3_wgrad4.hip, conv3x3_wgrad_stem.hip, conv3x3_bf16.hip: reduce now (queue == nullptr, or the slabs do
+// not fit the batched kernel), or remember the slabs in the caller's queue for its batched launch (aide_wgrad_queue_flush)
+int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, void* queue, hipStream_t stream) {
+    RQueue* q = static_cast<RQueue*>(queue);
+    if (q != nullptr && q->n < 512 && ((long)Co * Ci) % 4 == 0 && ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0) {
+        RDesc& r = q->d[q->n++];
         r.ws = ws; r.dw = dw; r.splits = splits; r.Co = Co; r.Ci = Ci;
         r.narrow = reduce_groups(splits, (long)Co * Ci);
         r.block_start = 0;
@@ -537,27 +532,32 @@ int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float*
     return launch_wgrad_reduce(ws, splits, Co, Ci, dw, stream);
 }
 
-extern "C" int aide_wgrad_reduce_defer(int on) {
-    const int was = g_red.defer ? 1 : 0;
-    // entering the deferred mode with descriptors still pending means an earlier pass died between its launches and its
-    // flush: their workspace / dw pointers are stale, never reduce through them
-    if (on && !g_red.defer) g_red.n = 0;
-    g_red.defer = on != 0;
-    return was;
+extern "C" int aide_wgrad_queue_create(void** queue) {
+    if (!queue) return AIDE_ERR_ARG;
+    *queue = new (std::nothrow) RQueue();
+    return *queue ? AIDE_OK : AIDE_ERR_ARG;
 }
 
-// error path of a backward pass: forget every pending descriptor and leave the deferred mode
-extern "C" int aide_wgrad_reduce_discard(void) {
-    const int n = g_red.n;
-    g_red.n = 0;
-    g_red.defer = false;
+extern "C" int aide_wgrad_queue_destroy(void* queue) {
+    delete static_cast<RQueue*>(queue);
+    return AIDE_OK;
+}
+
+// error path of a backward pass: forget every pending descriptor (they point into a pass that did not finish)
+extern "C" int aide_wgrad_queue_discard(void* queue) {
+    if (!queue) return AIDE_ERR_ARG;
+    RQueue* q = static_cast<RQueue*>(queue);
+    const int n = q->n;
+    q->n = 0;
     return n;
 }
 
-extern "C" int aide_wgrad_reduce_pending(void) { return g_red.n; }
+extern "C" int aide_wgrad_queue_pending(const void* queue) { return queue ? static_cast<const RQueue*>(queue)->n : AIDE_ERR_ARG; }
 
-// one launch per RB_MAX pending layers, in the order they were deferred
-extern "C" int aide_wgrad_reduce_flush(hipStream_t stream) {
+// one launch per RB_MAX pending layers, in the order they were queued
+extern "C" int aide_wgrad_queue_flush(void* queue, hipStream_t stream) {
+    if (!queue) return AIDE_ERR_ARG;
+    RQueue& g_red = *static_cast<RQueue*>(queue);
     int done = 0, rc = AIDE_OK;
     while (done < g_red.n && rc == AIDE_OK) {
         RBatch b;
@@ -591,7 +591,7 @@ int aide_conv3x3_wgrad_splits(int N, int Co, int Ci, int H, int W) {
     // one workgroup per CU (two 45 KB tile buffers + 144 accumulator registers per lane): aim for
     // one full round of 256 workgroups, each paying the tile-pipeline prologue only once
     const long blocks = (long)nco * nci;
-    static const long target = getenv("AIDE_WGD_TARGET") ? atol(getenv("AIDE_WGD_TARGET")) : 256;     // probe switch
+    const long target = 256;
     long s = (target + blocks - 1) / blocks;
     if (s > tiles) s = tiles;
     if (s < 1) s = 1;
@@ -605,11 +605,11 @@ size_t aide_conv3x3_wgrad_ws_bytes(int N, int Co, int Ci, int H, int W) {
 //   dz : [N][Co][H][W] (batch stride dz_bs)   a : [N][Ci][H][W] (batch stride a_bs)
 //   dw : [Co][Ci][3][3]                       ws : aide_conv3x3_wgrad_ws_bytes() bytes
 int aide_conv3x3_wgrad(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw,
-                       int N, int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
+                       int N, int Co, int Ci, int H, int W, float* ws, void* queue, hipStream_t stream) {
     if (!dz || !a || !dw || !ws || N <= 0 || Co <= 0 || Ci <= 0) return AIDE_ERR_ARG;
     if (aide_conv3x3_wgrad_stem_supported(Co, Ci, H, W) && dz_bs % 4 == 0)      // Ci <= 3: taps folded into the GEMM's N
         return aide_conv3x3_wgrad_stem(dz, 0, dz_bs, a, a_bs, dw, N, Co, Ci, H, W, ws,
-                                       aide_conv3x3_wgrad_splits(N, Co, Ci, H, W), 0, stream);
+                                       aide_conv3x3_wgrad_splits(N, Co, Ci, H, W), 0, queue, stream);
     WgradArgs g;
     g.dz = dz; g.a = a; g.slabs = ws; g.dz_bs = dz_bs; g.a_bs = a_bs;
     g.N = N; g.Co = Co; g.Ci = Ci; g.H = H; g.W = W;
@@ -624,7 +624,7 @@ int aide_conv3x3_wgrad(const float* dz, int64_t dz_bs, const float* a, int64_t a
         default: rc = launch_wgrad<1, 1, 4>(g, stream); break;
     }
     if (rc != 0) return rc;
-    return launch_wgrad_reduce(ws, g.splits, Co, Ci, dw, stream);
+    return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, queue, stream);
 }
 
 }  // extern "C"
@@ -907,7 +907,7 @@ int aide_conv3x3_wgrad_wino_supported(int Co, int Ci, int H, int W) {
 int aide_conv3x3_wgrad_wino_splits(int N, int Co, int Ci, int H, int W) {
     const long blocks = (long)((Co + 63) / 64) * ((Ci + 63) / 64);
     const long chunks = (long)N * (H / 2) * ((W + 15) / 16);
-    static const long target = getenv("AIDE_WG2_TARGET") ? atol(getenv("AIDE_WG2_TARGET")) : 256;     // probe switch
+    const long target = 256;
     long s = (target + blocks - 1) / blocks;
     if (s > chunks) s = chunks;
     return (int)(s < 1 ? 1 : s);
@@ -919,7 +919,7 @@ size_t aide_conv3x3_wgrad_wino_ws_bytes(int N, int Co, int Ci, int H, int W) {
 
 // Same contract as aide_conv3x3_wgrad (dw [Co][Ci][3][3]); requires aide_conv3x3_wgrad_wino_supported.
 int aide_conv3x3_wgrad_wino(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
-                            int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
+                            int Co, int Ci, int H, int W, float* ws, void* queue, hipStream_t stream) {
     if (!dz || !a || !dw || !ws || !aide_conv3x3_wgrad_wino_supported(Co, Ci, H, W) || dz_bs % 4 || a_bs % 4)
         return AIDE_ERR_ARG;
     static bool attr_set = false;
@@ -940,7 +940,7 @@ int aide_conv3x3_wgrad_wino(const float* dz, int64_t dz_bs, const float* a, int6
                       dim3(256), WW_LDS * sizeof(float), stream, g);
     int rc = aide_launch_status();
     if (rc != 0) return rc;
-    return launch_wgrad_reduce(ws, g.splits, Co, Ci, dw, stream);
+    return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, queue, stream);
 }
 
 }  // extern "C"

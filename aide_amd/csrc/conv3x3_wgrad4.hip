@@ -20,7 +20,7 @@
 #include <type_traits>
 #include <stdlib.h>
 
-int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream);
+int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, void* queue, hipStream_t stream);
 
 namespace {
 
@@ -316,36 +316,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
             //   0 offsets;  0..3 dz[c+1] loads, 4..8 raw[c+2] loads;  1..6 patch reads
             //   14 input transform, 15..23 V stores;  20 dz transform, 21..32 ZT stores (3 per slot)
             //   31..35 raw[c+2] stores (3 per slot)
-#ifndef AIDE_PROBE_GNOFETCH
             if (st == 0) { cur_next(kz); prep_z(kz); }
             if (st < 4) fetch_z(st);
             if (st == 3) { cur_next(kd); prep_d(kd); }
             if (st >= 4 && st < 9) fetch_d(st - 4);
-#endif
-#ifndef AIDE_PROBE_GNOV
             if (st >= 1 && st < 7) v_read(st - 1, kcur ? xr0 : xr1);
             if (st == 14) v_math(HS);
             if (st >= 15 && st < 24) v_store(st - 15, 1 - kcur);
-#endif
-#ifndef AIDE_PROBE_GNOZ
             if (st == 20) z_math();
             if (st >= 21 && st < 33) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) z_store(2 * (st - 21) + q, 1 - kcur);
             }
-#endif
-#ifndef AIDE_PROBE_GNOFETCH
             if (st >= 31) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
                     if (3 * (st - 31) + q < 14) put_d(3 * (st - 31) + q, rawc);
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
-#ifndef AIDE_PROBE_GNOBAR
         __syncthreads();
-#endif
     };
     for (int c = c_begin; c < c_stop; c += 2) {
         chunk(c, set0, set1, raw0, ic<0>{});
@@ -427,8 +417,7 @@ int aide_conv3x3_wgrad_wino4_supported(int Co, int Ci, int H, int W) {
 int aide_conv3x3_wgrad_wino4_splits_t(int N, int Co, int Ci, int H, int W, int target_wgs) {
     const long blocks = (long)((Co + 63) / 64) * (Ci / 32);
     const long chunks = (long)N * (H / 4) * ((W + 15) / 16);
-    static const long dflt = getenv("AIDE_WG4_TARGET") ? atol(getenv("AIDE_WG4_TARGET")) : 128;
-    const long target = target_wgs > 0 ? target_wgs : dflt;
+    const long target = target_wgs > 0 ? target_wgs : 128;      // default: half of the chip
     long s = (target + blocks - 1) / blocks;
     if (s > chunks / 2) s = chunks / 2;
     if (s < 1) s = 1;
@@ -449,7 +438,7 @@ size_t aide_conv3x3_wgrad_wino4_ws_bytes(int N, int Co, int Ci, int H, int W) {
 
 // dw [Co][Ci][3][3] = sum over images and pixels of dz (x) shifted input; ws: aide_conv3x3_wgrad_wino4_ws_bytes()
 int aide_conv3x3_wgrad_wino4_t(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
-                               int Co, int Ci, int H, int W, float* ws, int target_wgs, hipStream_t stream) {
+                               int Co, int Ci, int H, int W, float* ws, int target_wgs, void* queue, hipStream_t stream) {
     if (!dz || !a || !dw || !ws || N <= 0 || !aide_conv3x3_wgrad_wino4_supported(Co, Ci, H, W) || dz_bs % 4 || a_bs % 4)
         return AIDE_ERR_ARG;
     static bool attr_set = false;
@@ -471,11 +460,10 @@ int aide_conv3x3_wgrad_wino4_t(const float* dz, int64_t dz_bs, const float* a, i
     //   bytes ~ |dz| * n_ci / gci + 1.5 |x| * n_co / gco,  gco * gci <= blocks per XCD  ->  2 / gci + 1.5 / gco minimal.
     // (ci-fastest order = a 1 x n_ci rectangle read 1024->512 @32x32's input 8 times: 208 MB of fetches for 34 MB of operands.)
     {
-        static const int force = getenv("AIDE_WG4_RECT") ? atoi(getenv("AIDE_WG4_RECT")) : 1;     // A-B switch (0: ci-fastest order)
         const long per_xcd = nb / 8 > 0 ? nb / 8 : 1;
         int bco = 1, bci = g.n_ci_tiles;
         double best = 1e30;
-        for (int gco = 1; gco <= g.n_co_tiles && force; ++gco) {
+        for (int gco = 1; gco <= g.n_co_tiles; ++gco) {
             if (g.n_co_tiles % gco) continue;
             for (int gci = 1; gci <= g.n_ci_tiles; ++gci) {
                 if (g.n_ci_tiles % gci || (long)gco * gci > per_xcd) continue;
@@ -489,12 +477,12 @@ int aide_conv3x3_wgrad_wino4_t(const float* dz, int64_t dz_bs, const float* a, i
                       G4_LDS * sizeof(float), stream, g);
     const int rc = aide_launch_status();
     if (rc != 0) return rc;
-    return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, stream);
+    return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, queue, stream);
 }
 
 int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
-                             int Co, int Ci, int H, int W, float* ws, hipStream_t stream) {
-    return aide_conv3x3_wgrad_wino4_t(dz, dz_bs, a, a_bs, dw, N, Co, Ci, H, W, ws, 0, stream);
+                             int Co, int Ci, int H, int W, float* ws, void* queue, hipStream_t stream) {
+    return aide_conv3x3_wgrad_wino4_t(dz, dz_bs, a, a_bs, dw, N, Co, Ci, H, W, ws, 0, queue, stream);
 }
 
 }  // extern "C"

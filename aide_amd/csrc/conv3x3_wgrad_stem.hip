@@ -21,7 +21,7 @@
 // the s_waitcnt and produced garbage -- the rounding is spelled out in integer arithmetic (rne_bf16) instead.
 #include "common.h"
 
-int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, hipStream_t stream);   // conv3x3_wgrad.hip
+int aide_wgrad_reduce_launch(const float* ws, int splits, int Co, int Ci, float* dw, void* queue, hipStream_t stream);   // conv3x3_wgrad.hip
 
 namespace {
 
@@ -180,7 +180,7 @@ extern "C" {
 
 // slabs (= workgroups per co tile) for an [N][.][H][W] problem: 4-row x 64-column tiles dealt round-robin
 int aide_conv3x3_wgrad_stem_splits(int N, int H, int W) {
-    static const long target = getenv("AIDE_STEM_SPLITS") ? atol(getenv("AIDE_STEM_SPLITS")) : 512;       // probe switch (512x512 x8: 256 -> 116 us, 512 -> 88, 1024 -> 93, 2048 -> 118)
+    const long target = 512;                     // (512x512 x8: 256 -> 116 us, 512 -> 88, 1024 -> 93, 2048 -> 118)
     const long tiles = (long)N * (H / ST_R) * (W / ST_C);
     long s = tiles / 4;                          // >= 4 tiles per workgroup: the next tile's loads fly under the MFMAs
     if (s < 256) s = 256;
@@ -199,7 +199,7 @@ int aide_conv3x3_wgrad_stem_supported(int Co, int Ci, int H, int W) {
 //   round_bf16 : operands rounded to bf16 when staged (the precision='bf16' contract); implied by dz_bf16
 int aide_conv3x3_wgrad_stem(const void* dz, int dz_bf16, int64_t dz_bs, const float* x, int64_t x_bs, float* dw,
                             int N, int Co, int Ci, int H, int W, float* ws, int splits, int round_bf16,
-                            hipStream_t stream) {
+                            void* queue, hipStream_t stream) {
     if (!dz || !x || !dw || !ws || N <= 0 || splits < 1 || !aide_conv3x3_wgrad_stem_supported(Co, Ci, H, W))
         return AIDE_ERR_ARG;
     if (dz_bs % (dz_bf16 ? 8 : 4)) return AIDE_ERR_ARG;
@@ -216,7 +216,7 @@ int aide_conv3x3_wgrad_stem(const void* dz, int dz_bf16, int64_t dz_bs, const fl
     else AIDE_LAUNCH_TIMED(AIDE_KT_WGRAD_STEM, fl, (wgrad_stem_kernel<false, false>), dim3(nb), dim3(256), 0, stream, g);
     const int rc = aide_launch_status();
     if (rc != 0) return rc;
-    return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, stream);
+    return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, queue, stream);
 }
 
 }  // extern "C"

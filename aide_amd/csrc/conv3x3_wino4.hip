@@ -41,7 +41,7 @@ struct W4Args {
     int pair;            // W == 16: a workgroup tile is 16 rows x (16 columns of image 2n | 16 columns of image 2n + 1)
     float* stats;        // optional [Cout][N * blocks_h * blocks_w][2]: per (channel, workgroup tile) sum / sum of squares of the
                          // pre-bias outputs -- the BatchNorm statistics of the forward pass without a pass over z
-    const float* scale;  // AFF variant (eval mode, aide_conv_epilogue_affine): y = relu?(acc * scale[co] + bias[co]) -- the
+    const float* scale;  // AFF variant (eval mode, epi_scale of aide_conv3x3_wino4): y = relu?(acc * scale[co] + bias[co]) -- the
     int relu;            // BatchNorm of running statistics folded into the epilogue, no separate pass over the conv output
 };
 
@@ -51,11 +51,7 @@ constexpr int F4_RCS = 775;                // raw channel stride: (41, 775) make
 constexpr int F4_RAW = 4 * F4_RCS;         // 3100 floats
 constexpr int F4_V = 36 * 32 * 4;          // V[p][2 channel pairs][32 tiles][2]
 constexpr int F4_SET = F4_RAW + F4_V;      // 7708 floats = 30832 B; two sets = 60.2 KB (filters never touch LDS)
-#if defined(AIDE_PROBE_4HALF) && !defined(AIDE_PROBE_4HALF_ONE)
-constexpr int F4_LDS = 2 * F4_SET;                       // (probe) two workgroups per CU; _ONE: the same kernel held at one
-#else
 constexpr int F4_LDS = 2 * F4_SET > 4 * 128 * 64 ? 2 * F4_SET : 4 * 128 * 64;   // epilogue swap needs 32768
-#endif
 
 // Position pairs: pair q = 3 i + t of transform row i holds columns (1,2), (3,4), (0,5) for t = 0, 1, 2 (the pairs the packed
 // input transform produces).  Accumulator slot 2 q + b <-> position F4_P(q, b); slot of column c in row i: F4_SLOT.
@@ -96,15 +92,7 @@ __device__ __forceinline__ float half_total_dpp(float v) {
 // 16 x 32: the 40 x 40 and 20 x 20 planes of the 320 x 320 workload fill 78 % of their tiles instead of 52 % / 39 %.  Only
 // the staging descriptors, the patch origin and the output address know the canvas; the main loop is the same code.
 template <int MODE, bool AFF = false>
-#ifdef AIDE_PROBE_4HALF
-// (timing probe, wrong results) half of the positions per workgroup -- 9 accumulators, 18 MFMAs per stage -- so that TWO
-// workgroups fit a CU (2 waves per SIMD): does a co-resident workgroup hide the fixed cost and the stalls of the other?
-#define F4_PROBE_KEEP(g, w) ((g) == 0 || (g) == 2 || (g) == 4 || (g) == 6)       /* 8 accumulators, 16 MFMAs per stage */
-__global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const W4Args a) {
-#else
-#define F4_PROBE_KEEP(g, w) true
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
-#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform (scalar) roles
@@ -284,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
 #pragma unroll
     for (int l = 0; l < 4; ++l) fetch(l, s_begin);
 #pragma unroll
-    for (int q = 0; q < 9; ++q) if (F4_PROBE_KEEP(q, 0)) fetch_u(q, s_begin, ua[0]);
+    for (int q = 0; q < 9; ++q) fetch_u(q, s_begin, ua[0]);
     if (pair) {                                            // the outer halo columns (-1 of A, 16 of B) of both sets, once
         for (int q = tid; q < 2 * 4 * 18 * 2; q += 256) {
             const int set = q / 144, rem = q - set * 144, c = rem / 36, rr = (rem % 36) >> 1, side = rem & 1;
@@ -314,77 +302,42 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
         // [tile][4] row layout measured 2-way bank conflicts on every fragment read, with or without swizzle)
         const float* lb = sc + F4_RAW + (9 * ph) * 256 + half * 128 + ((j * 4) ^ (half * 16));
         auto frag = [&](int q, int slot3) { fb[slot3] = *reinterpret_cast<const f32x4*>(lb + q * 256); };
-#ifndef AIDE_F4_EARLY_BARRIER
-        frag(0, 0); if (F4_PROBE_KEEP(1, 0)) frag(1, 1);
-#endif
+        frag(0, 0); frag(1, 1);
 #pragma unroll
         for (int st = 0; st < 36; ++st) {
-#ifdef AIDE_F4_EARLY_BARRIER
-            // (probe, no gain) The stage barrier BEFORE the last four MFMAs (they only use registers), followed at once by
-            // the first fragment reads of the NEXT stage.  All LDS stores of the stage are issued by slot 31.
-            if (st == 32) {
-                __syncthreads();
-                const float* lbn = sn + F4_RAW + (9 * ph) * 256 + half * 128 + ((j * 4) ^ (half * 16));
-#pragma unroll
-                for (int q = 0; q < 2; ++q) fb[q] = *reinterpret_cast<const f32x4*>(lbn + q * 256);
-            }
-#endif
             // slot order inside a position pair g: (2g,k0) (2g+1,k0) (2g,k1) (2g+1,k1)
             const int g = st >> 2, w = st & 3, pi = 2 * g + (w & 1), k = w >> 1;
             const int fs = g % 3;
-            if (w == 0 && g + 2 < 9 && F4_PROBE_KEEP(g + 2, 0)) frag(g + 2, (g + 2) % 3);   // fragments of a pair, two pairs (8 slots) ahead
+            if (w == 0 && g + 2 < 9) frag(g + 2, (g + 2) % 3);   // fragments of a pair, two pairs (8 slots) ahead
             // 18 x 16 accumulator registers exceed the 256 AGPRs: positions 16 and 17 are pinned to VGPRs,
             // and the register classes are spelled out (hipcc otherwise shuffles whole accumulators
             // between the two files every stage)
-            if (!F4_PROBE_KEEP(g, w)) {}
-            else if (pi < F4_NAGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pi]) : "v"(ua[kcur][g][(w & 1) * 2 + k]), "v"(fb[fs][k * 2 + (w & 1)]));
+            if (pi < F4_NAGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[pi]) : "v"(ua[kcur][g][(w & 1) * 2 + k]), "v"(fb[fs][k * 2 + (w & 1)]));
             else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[pi]) : "v"(ua[kcur][g][(w & 1) * 2 + k]), "v"(fb[fs][k * 2 + (w & 1)]));
             // staging schedule: only slot 20 carries vector-ALU work
             //   0..3 raw[s+2] global fetches, 4..21 U[s+1] fragment fetches;  0..17 patch reads (2 per slot)
             //   20 transform;  21..29 V stores (2 per slot);  31..35 raw stores (3 per slot)
-#ifndef AIDE_PROBE_4NOFETCH
             if (st < 4) fetch(st, s + 2);
-            else if (st < 22 && ((st - 4) & 1) == 0 && F4_PROBE_KEEP((st - 4) >> 1, 0)) fetch_u((st - 4) >> 1, s + 1, ua[1 - kcur]);
-#endif
-#ifdef AIDE_F4_EARLY_BARRIER
-            constexpr int XM = 18, XS = 19, PR = 27;        // transform slot, first V-store slot, first raw-store slot
-#else
+            else if (st < 22 && ((st - 4) & 1) == 0) fetch_u((st - 4) >> 1, s + 1, ua[1 - kcur]);
             constexpr int XM = 20, XS = 21, PR = 31;
-#endif
-#ifndef AIDE_PROBE_4NOXF
             if (st < 18) { xf_read(2 * st, kcur ? xr0 : xr1); xf_read(2 * st + 1, kcur ? xr0 : xr1); }
             if (st == XM) xf_math();
             if (st >= XS && st < XS + 9) xf_store(st - XS, sn + F4_RAW);
-#endif
-#ifndef AIDE_PROBE_4NOFETCH
             if (st >= PR && st < PR + 5) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
                     if (3 * (st - PR) + q < 13) put_raw(3 * (st - PR) + q, sc);
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
-#if !defined(AIDE_PROBE_4NOBAR) && !defined(AIDE_F4_EARLY_BARRIER)
         __syncthreads();
-#endif
     };
     // two stages per iteration, unconditionally (the host makes the stage count of a split even): with a
     // conditional second stage hipcc reconciles the accumulator registers of the two paths by copying them
-#ifdef AIDE_F4_EARLY_BARRIER
-    {   // first fragments of the first stage (every later stage gets them from its predecessor, after the barrier)
-        const float* lb0 = set0 + F4_RAW + (9 * ph) * 256 + half * 128 + ((j * 4) ^ (half * 16));
-#pragma unroll
-        for (int q = 0; q < 2; ++q) fb[q] = *reinterpret_cast<const f32x4*>(lb0 + q * 256);
-    }
-#endif
     for (int s = s_begin; s < s_end; s += 2) {
         stage(s, set0, set1, ic<0>{});
         stage(s + 1, set1, set0, ic<1>{});
     }
-#ifdef AIDE_F4_EARLY_BARRIER
-    __syncthreads();      // the epilogue reuses the staging buffers: every wave past its last fragment reads
-#endif
 
     // ---- output transform.  Partial over this wave's rows i = 3ph..3ph+2:
     //   T[i][b] = sum_c M[i][c] A[c][b];   Yp[a][b] = sum_i A^T[a][i] T[i][b]
@@ -481,11 +434,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
                         *reinterpret_cast<f32x2*>(a.stats + ((long)co * nparts + blk) * 2) = f32x2{s1, s2};
                     }
                 }
-#ifdef AIDE_PROBE_4NOSTORE
-                if (pok && co < a.Cout && a.N < 0) {             // (probe: everything but the output stores)
-#else
                 if (pok && co < a.Cout) {
-#endif
                     const float bv = bvs[2 * rp + e];
                     f32x4* const p0 = reinterpret_cast<f32x4*>(yn + (long)co * HW + (long)oh * a.W + ow);
                     f32x4 o[4];
@@ -516,19 +465,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             }
         }
     };
-#ifdef AIDE_PROBE_4NOEPI
-#pragma unroll
-    for (int p = 0; p < 18; ++p) { if (!F4_PROBE_KEEP(p >> 1, p & 1)) continue; if (p < F4_NAGPR) asm volatile("" :: "a"(acc[p])); else asm volatile("" :: "v"(acc[p])); }
-    (void)epilogue;
-#else
     if (ph == 0) epilogue(ic<0>{}); else epilogue(ic<1>{});
-#endif
     };   // run
     if (hs == 0) run(ic<0>{}); else run(ic<1>{});
 }
 
 // y[n][c][p] (+)= bias[c] + sum_s slab[s][n][c][p], 16 bytes per thread, fixed summation order.  scale != nullptr (eval mode,
-// aide_conv_epilogue_affine): y = relu?(sum * scale[c] + bias[c])
+// epi_scale): y = relu?(sum * scale[c] + bias[c])
 __global__ __launch_bounds__(256) void w4_splitk_reduce_kernel(const float* __restrict__ slabs, long split_stride,
                                                                int splitk, float* __restrict__ y, long y_bs, int C,
                                                                int HW, const float* __restrict__ bias, int accumulate,
@@ -655,17 +598,15 @@ int aide_conv3x3_wino4_supported(int Cin, int H, int W, int Cout) {
     // W == 16: two images per workgroup tile (the caller's N must be even: checked at launch and in aide_conv3x3_wino4_splitk).
     // 16 < W < 32 (the 20 x 20 bottleneck of the 320 x 320 workload): one tile column, its right part masked -- the same
     // 39 % tile use as F(2x2)'s 16 x 16 tiles there, at 2.25x fewer multiplies.
-    static const bool narrow = !(getenv("AIDE_W4_NARROW") && atoi(getenv("AIDE_W4_NARROW")) == 0);   // A-B switch
-    return (H % 4 == 0 && W % 4 == 0 && H >= 16 && (W >= 32 || W == 16 || (narrow && W > 16)) && Cout % 32 == 0 &&
+    return (H % 4 == 0 && W % 4 == 0 && H >= 16 && W >= 16 && Cout % 32 == 0 &&
             Cin % 8 == 0) ? 1 : 0;
 }
 
 // workgroup tile of a plane: 0 = 16 x 32 pixels, 1 = two 16-wide images side by side, 2 = the 20 x 20 canvas -- whichever
 // covers the plane with fewer tile slots (canvas: 25 of 32 slots used)
 static int f4_mode(int H, int W, int* bh, int* bw) {
-    static const bool canvas_on = !(getenv("AIDE_W4_CANVAS") && atoi(getenv("AIDE_W4_CANVAS")) == 0);      // A-B switch
     const int sh = (H + 15) / 16, sw = (W + 31) / 32, ch = (H + 19) / 20, cw = (W + 19) / 20;
-    const int mode = W == 16 ? 1 : (canvas_on && (long)ch * cw < (long)sh * sw) ? 2 : 0;     // (32 slots per workgroup either way)
+    const int mode = W == 16 ? 1 : ((long)ch * cw < (long)sh * sw) ? 2 : 0;     // (32 slots per workgroup either way)
     *bh = mode == 2 ? ch : sh;
     *bw = mode == 2 ? cw : sw;
     return mode;
@@ -676,13 +617,13 @@ int aide_conv3x3_wino4_splitk(int N, int Cin, int H, int W, int Cout) {
     f4_mode(H, W, &bh, &bw);
     const long nb = (long)bh * bw * (W == 16 ? N / 2 : N) * ((Cout + 63) / 64);
     const int pairs = Cin / 8;                             // a split gets a whole number of stage pairs
-    static const long target = getenv("AIDE_W4_SK_TARGET") ? atol(getenv("AIDE_W4_SK_TARGET")) : 200;     // probe switch
+    const long target = 200;                               // workgroups a split launch aims for (sweep: 200 ahead of 112 / 144 / 256)
     int s = 1;
     while (nb * s < target && pairs % (s * 2) == 0 && s * 2 <= pairs / 4) s *= 2;
     return s;
 }
 
-// partial-statistics entries per channel written by a forward launch when a sink is armed (aide_conv_stats_sink)
+// partial-statistics entries per channel written by a forward launch that is given a statistics sink (stats_parts of aide_conv3x3_wino4)
 int aide_conv3x3_wino4_stats_parts(int N, int H, int W) {
     int bh, bw;
     f4_mode(H, W, &bh, &bw);
@@ -697,8 +638,7 @@ int aide_conv3x3_wino4_pack_blocks(int Co, int Ci) {
 int aide_conv3x3_wino4_pack_multi(const void* descs, int n, int64_t total_blocks, hipStream_t stream) {
     if (!descs || n <= 0 || total_blocks <= 0) return AIDE_ERR_ARG;
     static_assert(sizeof(W4PackDesc) == 48, "descriptor layout");
-    static const long cap = getenv("AIDE_PACK_MAX_WGS") ? atol(getenv("AIDE_PACK_MAX_WGS")) : 0;      // 0: one workgroup per tile
-    const long grid = (cap > 0 && cap < total_blocks) ? cap : total_blocks;
+    const long grid = total_blocks;                       // one workgroup per tile (a capped grid-stride grid only got slower)
     hipLaunchKernelGGL(wino4_pack_multi_kernel, dim3((unsigned)grid), dim3(128), 0, stream,
                        (const W4PackDesc*)descs, n, (long)total_blocks);
     return aide_launch_status();
@@ -709,10 +649,9 @@ int aide_conv3x3_wino4_pack_multi(const void* descs, int n, int64_t total_blocks
 // of aide_conv3x3_ws_bytes(N, H, W, Cout, splitk) bytes.
 int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float* bias, float* y,
                        int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,
-                       float* ws, hipStream_t stream) {
-    int aff_relu = 0;
-    const float* aff = aide_conv_affine_take(&aff_relu);   // one-shot: armed by aide_conv_epilogue_affine for THIS launch (taken
-                                                            // before any early return: a refused launch must not leave it armed)
+                       float* ws, float* stats_parts, const float* epi_scale, int epi_relu, hipStream_t stream) {
+    const float* aff = epi_scale;
+    const int aff_relu = aff ? epi_relu : 0;
     if (!x || !u || !y || !aide_conv3x3_wino4_supported(Cin, H, W, Cout) || x_bs % 4 || y_bs % 4 || (W == 16 && N % 2))
         return AIDE_ERR_ARG;
     static bool attr_set = false;
@@ -730,7 +669,8 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
         attr_set = true;
     }
     W4Args a;
-    a.stats = (splitk <= 1 && accumulate == 0 && W >= 32) ? aide_conv_stats_take() : nullptr;
+    if (stats_parts && !(splitk <= 1 && accumulate == 0 && W >= 32)) return AIDE_ERR_ARG;   // only a launch that writes final outputs
+    a.stats = stats_parts;
     const int mode = f4_mode(H, W, &a.blocks_h, &a.blocks_w);
     if (aff && (accumulate != 0 || !bias || (mode == 1 && splitk <= 1))) return AIDE_ERR_ARG;
     a.scale = splitk > 1 ? nullptr : aff;           // a split launch leaves plain slabs: its reduce applies the epilogue
@@ -752,7 +692,6 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
     const long nb = (long)a.blocks_w * a.blocks_h * (a.pair ? N / 2 : N) * a.n_co_tiles * splitk;
     {   // tile group per XCD (nb / 8 consecutive logical blocks).  Memory-side reads of a launch: the filter pack once per
         // pixel-tile GROUP, the input (1.44x with its halo) once per co GROUP:  bytes ~ |U| P / gp + 1.44 |x| C / gc.
-        static const int force = getenv("AIDE_W4_RECT") ? atoi(getenv("AIDE_W4_RECT")) : 1;      // A-B switch (0: co-fastest order)
         const long P = (long)a.blocks_w * a.blocks_h * (a.pair ? N / 2 : N);
         const int C = a.n_co_tiles;
         const long per_xcd = nb / 8 > 0 ? nb / 8 : 1;
@@ -762,7 +701,7 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
         // (layer sweep, tools/bench_conv.py with AIDE_W4_RECT=0/1: the >= 19 GFLOP layers are level or 3-13 % faster with the
         // groups -- 512->512 @32x32 0.077 -> 0.067 ms -- the <= 5 GFLOP split-K layers 5-10 % slower, 32 workgroups of an XCD
         // then stream one small filter slice in step: they keep the co-fastest order)
-        const bool grouped = force == 2 || (force == 1 && AIDE_CONV_FLOPS(N, H, W, Cout, Cin) >= 8e9);
+        const bool grouped = AIDE_CONV_FLOPS(N, H, W, Cout, Cin) >= 8e9;
         for (long gp = 1; gp <= P && gp <= per_xcd && grouped; gp *= 2) {      // (powers of two: a handful of candidates per launch)
             if (P % gp) continue;
             for (int gc = 1; gc <= C; ++gc) {

@@ -213,19 +213,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
             //   slots  0..12 : global fetches of U[chunk+1] (8) and raw[chunk+2] (5)
             //   slots  4..19 : patch reads (2 LDS reads each);  slot 24 : the 32 packed transform adds
             //   slots 26..41 : V stores (2 each);  44..51 : U[chunk+1] stores;  52..56 : raw[chunk+2] stores
-#ifndef AIDE_PROBE_WNOFETCH
             if (st < NU) fetch_u(st, chunk + 1);
             else if (st < NU + NRB + NRC) fetch_raw(st - NU, chunk + 2);
-#endif
-#ifndef AIDE_PROBE_WNOXF
             if (st >= 4 && st < 20) xf_read(st - 4, sn);
             if (st == 24) xf_math();
             if (st >= 26 && st < 42) xf_store(st - 26, sn + RAWL);
-#endif
-#ifndef AIDE_PROBE_WNOFETCH
             if (st >= 44 && st < 44 + NU) put_u(st - 44, sn + RAWL + VL);
             if (st >= 52 && st < 52 + NRB + NRC) put_raw(st - 52, sc);
-#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         frag(0, a0A, b0A); frag(1, a1A, b1A);
@@ -236,9 +230,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
 #pragma unroll
             for (int k = 0; k < 8; ++k) slot(st + 8 + k, a0B, b0B, a1B, b1B, a0A, b0A, a1A, b1A);
         }
-#ifndef AIDE_PROBE_WNOBAR
         __syncthreads();
-#endif
         cur ^= 1;
     }
 

@@ -18,17 +18,7 @@ struct KTimer {
 } T;
 }  // namespace
 
-// one-shot sink for the BatchNorm statistics of the next eligible forward conv launch (see bn.hip / conv3x3_wino4.hip)
-static float* g_stats_sink = nullptr;
-float* aide_conv_stats_take() { float* p = g_stats_sink; g_stats_sink = nullptr; return p; }
-static const float* g_affine = nullptr;
-static int g_affine_relu = 0;
-const float* aide_conv_affine_take(int* relu) { const float* p = g_affine; g_affine = nullptr; *relu = p ? g_affine_relu : 0; return p; }
-
 extern "C" {
-
-int aide_conv_stats_sink(float* parts) { g_stats_sink = parts; return AIDE_OK; }
-int aide_conv_epilogue_affine(const float* scale, int relu) { g_affine = scale; g_affine_relu = relu; return AIDE_OK; }
 
 int aide_ktimer_slot(int family, double flops, hipEvent_t* e0, hipEvent_t* e1) {
     if (!(T.mask >> family & 1u)) return 0;
@@ -76,20 +66,6 @@ int aide_ktimer_read(int family, int64_t* launches, double* ms, double* flops, d
     *launches = n; *ms = t; *flops = f;
     if (max_ms) *max_ms = mx;
     return (int)(T.dropped > 0x7fffffff ? 0x7fffffff : T.dropped);
-}
-
-
-// A HIP stream whose kernels may only run on the compute units set in `mask` (`words` x 32 bits, bit i = CU i):
-// hipExtStreamCreateWithCUMask.  The engine puts the weight-gradient kernels of the backward pass on such a stream so that
-// a weight-gradient launch with >= 256 exclusive (144 KB LDS, 512 VGPR) workgroups can never occupy every CU and stall the
-// dependent chain on the main stream.  *stream receives the hipStream_t.
-int aide_stream_create_cumask(void** stream, const void* mask, int words) {
-    if (!stream || !mask || words <= 0) return AIDE_ERR_ARG;
-    hipStream_t st = nullptr;
-    const hipError_t rc = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, (const uint32_t*)mask);
-    if (rc != hipSuccess) return (int)rc;
-    *stream = (void*)st;
-    return AIDE_OK;
 }
 
 

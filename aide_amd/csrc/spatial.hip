@@ -531,8 +531,7 @@ int maxpool_bwd_t(const XT* x, int64_t x_bs, const GT* dy, int64_t dy_bs, DT* dx
 }
 template <typename XT, typename YT>
 int upsample_fwd_t(const XT* x, int64_t x_bs, YT* y, int64_t y_bs, int N, int C, int H, int W, hipStream_t stream) {
-    static const bool gather_only = getenv("AIDE_UPSAMPLE_GATHER") != nullptr;      // A-B switch
-    if (!gather_only && (2 * H) % UF_TR == 0 && (2 * W) % UF_TC == 0 && x_bs % 4 == 0 && y_bs % 8 == 0) {   // whole 32 x 128 output tiles
+    if ((2 * H) % UF_TR == 0 && (2 * W) % UF_TC == 0 && x_bs % 4 == 0 && y_bs % 8 == 0) {   // whole 32 x 128 output tiles
         const int tiles_w = 2 * W / UF_TC, tiles_h = 2 * H / UF_TR;
         hipLaunchKernelGGL((upsample2x_fwd_tiled_kernel<XT, YT>), dim3((unsigned)((long)tiles_w * tiles_h * N * C)), dim3(256),
                            0, stream, x, (long)x_bs, y, (long)y_bs, C, H, W, tiles_w, tiles_h,

@@ -22,22 +22,22 @@ import torch.distributed as dist
 # front of a bucket's all-reduce -- for the weight-gradient stream, which runs ~0.4 ms behind the main stream -- stalled the
 # main stream with it: C2 608 -> 567 images/s per rank before a single byte crosses xGMI, and with real peers the whole
 # all-reduce would sit in that queue.  More queues are no way out (GPU_MAX_HW_QUEUES=8 with RCCL: 363 images/s), nor are
-# high-priority streams for RCCL and the buckets (AIDE_RCCL_HIGH_PRIORITY=1: 452).  So the process keeps to FOUR streams:
-# main, second forward lane, weight gradients (which also carries the filter re-layout at the start of the forward pass:
-# engine.PACKS_ON_SIDE) and RCCL's own; a bucket's collective is issued FROM the weight-gradient stream (its tail is a
-# superset of what the bucket waits for; it only has to be ordered behind the main stream, which runs ahead of it).
-HIGH_PRIORITY = [os.environ.get('AIDE_RCCL_HIGH_PRIORITY', '0') != '0']     # A-B switch (measured: worse)
-# AIDE_COMM_FROM_SIDE=0: a dedicated bucket stream, as in round 2 (A-B switch)
-ISSUE_FROM_SIDE = [os.environ.get('AIDE_COMM_FROM_SIDE', '1') != '0']
-# AIDE_PICK_STREAMS=0: take the streams as the runtime hands them out (A-B switch; see aide_amd/streams.py)
+# high-priority streams for RCCL and the buckets (452).  So the process keeps to FOUR streams: main, second forward lane,
+# weight gradients (which also carries the filter re-layout at the start of the forward pass) and RCCL's own; a bucket's
+# collective is issued FROM the weight-gradient stream (its tail is a superset of what the bucket waits for; it only has to
+# be ordered behind the main stream, which runs ahead of it).
+# AIDE_PICK_STREAMS=0: take the streams as the runtime hands them out instead of measuring (aide_amd/streams.py)
 PICK_STREAMS = [os.environ.get('AIDE_PICK_STREAMS', '1') != '0']
+# RCCL / HIP-runtime tuning is NOT wrapped: RCCL reads its own environment (NCCL_MAX_NCHANNELS, NCCL_MIN_NCHANNELS,
+# NCCL_ALGO, NCCL_PROTO, RCCL_*), the runtime GPU_MAX_HW_QUEUES -- set them in the launcher's environment;
+# comm_environment() records what was set so that a bench line says under which settings it ran.
+_COMM_ENV_PREFIXES = ('NCCL_', 'RCCL_', 'GPU_MAX_HW_QUEUES', 'HSA_ENABLE_IPC_MODE_LEGACY', 'HIP_VISIBLE_DEVICES',
+                      'ROCR_VISIBLE_DEVICES')
 
 
-def nccl_options():
-    """process-group options for init_process_group('nccl', pg_options=...) (None: the defaults)"""
-    if not HIGH_PRIORITY[0]:
-        return None
-    return dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+def comm_environment():
+    """-> {name: value} of every RCCL / HIP-runtime variable set in this process that shapes the exchange"""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith(_COMM_ENV_PREFIXES)}
 
 
 def make_buckets(offsets, numels, bucket_elems):
@@ -95,7 +95,7 @@ def init_from_env(device_ids=None):
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    backend = os.environ.get('AIDE_DIST_BACKEND', os.environ.get('AIDE_BENCH_BACKEND', 'nccl'))
+    backend = os.environ.get('AIDE_DIST_BACKEND', 'nccl')
     if not torch.cuda.is_available():
         raise RuntimeError('aide_amd needs a HIP device (the product path has no CPU fallback)')
     if device_ids is not None:
@@ -112,7 +112,7 @@ def init_from_env(device_ids=None):
             if PICK_STREAMS[0]:
                 from . import streams
                 streams.reserve_queue(device)            # RCCL's stream then gets a hardware queue of its own (streams.py)
-            dist.init_process_group('nccl', device_id=device, pg_options=nccl_options())
+            dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(backend)
     return rank, world, device
@@ -135,6 +135,7 @@ def broadcast_module(module, src=0):
     # transformed filter copies are keyed on those, so tell it explicitly (any other `.data` edit of weights needs the same)
     from . import engine
     engine.PARAM_EPOCH[0] += 1
+    engine.STATS_EPOCH[0] += 1           # ... and the folded eval-mode BatchNorm coefficients on the running statistics
 
 
 class GradAllReduce(object):
@@ -148,7 +149,6 @@ class GradAllReduce(object):
         self.sched = None
         self.flat = None
         self.works = []
-        self.comm_stream = None
         self.time_exposed = False        # bench.py: event-time the main stream's wait for the communication stream
         self._exposed = []
         self.stream_plan = None
@@ -180,8 +180,6 @@ class GradAllReduce(object):
         self.sched.reset()
         self.flat = flat
         self.works = []
-        if flat.is_cuda and self.comm_stream is None and not ISSUE_FROM_SIDE[0]:
-            self.comm_stream = torch.cuda.Stream(device=flat.device, priority=-1 if HIGH_PRIORITY[0] else 0)
 
     def _launch(self, b):
         start, end, _ = self.sched.buckets[b]
@@ -189,27 +187,17 @@ class GradAllReduce(object):
         avg = dist.get_backend(self.pg) == 'nccl'          # RCCL averages in the collective itself: no extra pass
         if view.is_cuda:
             side = getattr(self.engine, 'side_stream', None)
-            lane = getattr(self.engine, 'lane_stream', None)
-            issue = side if (ISSUE_FROM_SIDE[0] and side is not None) else self.comm_stream
-            if issue is None:                              # no weight-gradient stream (single-stream schedule): in line
+            if side is None:                               # no weight-gradient stream (single-stream schedule): in line
                 self._reduce(view, avg)
                 return
-            # everything that writes this bucket has been enqueued: on the main stream, on the weight-gradient stream and
-            # (two-lane backward) on the second encoder's lane.  The collective is issued from the weight-gradient stream
-            # itself: RCCL's stream then waits for that stream's tail -- a superset of the bucket's weight gradients -- and
-            # the stream only has to be ordered behind the main stream (and the lane), which run ahead of it anyway.
+            # everything that writes this bucket has been enqueued, on the main stream and on the weight-gradient stream.
+            # The collective is issued from the weight-gradient stream itself: RCCL's stream then waits for that stream's
+            # tail -- a superset of the bucket's weight gradients -- and the stream only has to be ordered behind the main
+            # stream, which runs ahead of it anyway.
             ev = torch.cuda.Event()
             ev.record()
-            issue.wait_event(ev)
-            if lane is not None:
-                ev3 = torch.cuda.Event()
-                ev3.record(lane)
-                issue.wait_event(ev3)
-            if issue is not side and side is not None:
-                ev2 = torch.cuda.Event()
-                ev2.record(side)
-                issue.wait_event(ev2)
-            with torch.cuda.stream(issue):
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
                 self._reduce(view, avg)
         else:
             self._reduce(view, avg)
@@ -218,7 +206,7 @@ class GradAllReduce(object):
         if avg:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
         else:
-            # gloo (CPU unit tests; AIDE_BENCH_BACKEND=gloo dry runs of the N>1 bench on one GPU) has no AVG
+            # gloo (CPU unit tests; AIDE_DIST_BACKEND=gloo dry runs of the N>1 bench on one GPU) has no AVG
             view.div_(self.world)
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
@@ -252,8 +240,6 @@ class GradAllReduce(object):
             e0.record()
         for w in self.works:
             w.wait()
-        if flat.is_cuda and self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
         if timed:
             e1.record()
             self._exposed.append((e0, e1))
@@ -265,7 +251,6 @@ class GradAllReduce(object):
         sp = self.stream_plan
         return dict(buckets=len(self.sched.buckets),
                     bytes_per_step=int(sum(4 * (end - start) for start, end, _ in self.sched.buckets)),
-                    high_priority=bool(HIGH_PRIORITY[0]),
                     hw_queues=None if sp is None else dict(classes=sp['classes'], main=sp['main_class'], rccl=sp['rccl_class'],
                                                            side=sp['side'], lane=sp['lane']))
 

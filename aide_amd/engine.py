@@ -98,32 +98,20 @@ WGRAD_TAG = {0: 'conv3x3_wgrad_kernel', 2: 'conv3x3_wgrad_wino_kernel', 4: 'conv
 PRECISIONS = ('fp32', 'bf16')
 USE_WINOGRAD4 = [True]
 import os as _os
-HEAD_WGRAD_SIDE = [_os.environ.get('AIDE_HEAD_WGRAD_SIDE', '1') != '0']      # A-B switch
-STORE_BF16 = [True]            # precision='bf16': z / dz stored as bf16 (A-B switch)
+# In-process switches (module attributes, flipped by tests that prove a schedule or a storage choice changes nothing but
+# time -- tests/test_gpu_models.py, test_gpu_steps.py, test_gpu_bf16.py).  The only ENVIRONMENT switches of the package are
+# AIDE_HIP_LIB (library path), AIDE_DIST_BACKEND (dry-run backend), AIDE_PICK_STREAMS, AIDE_REPLAY and AIDE_DIRECT_GRADS;
+# every A-B switch whose alternative was measured and lost (DESIGN.md sections 4.6, 9.4, 9.7) is gone with its code path.
+STORE_BF16 = [True]            # precision='bf16': z / dz stored as bf16
 STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 where every reader / writer allows it
 STORE_G_BF16 = [True]          # ... and the gradients of those activations
-DEFER_WGRAD_REDUCE = [_os.environ.get('AIDE_DEFER_WGRAD_REDUCE', '1') != '0']     # A-B switch: batched slab reduce
-LATE_DGRAD_PACK = [_os.environ.get('AIDE_LATE_DGRAD_PACK', '0') != '0']   # A-B switch (measured: no effect, off)
-SIDE_CUMASK = ['']               # default CU mask of the weight-gradient stream ('' = none); see _side_stream
-REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch tapes (aide_amd/tape.py); A-B switch
-HP_CHAIN = [_os.environ.get('AIDE_HP_CHAIN', '0') != '0']            # A-B switch: backward chain on a high-priority stream
-EPILOGUE_STATS = [_os.environ.get('AIDE_EPILOGUE_STATS', '1') != '0']   # A-B switch: BN statistics from the conv epilogue
-SHARED_PACKS = [_os.environ.get('AIDE_SHARED_PACKS', '1') != '0']   # A-B switch: plans of an engine share packed filters; forward-only plans pack no dgrad direction
-FOLD_SPLITK = [_os.environ.get('AIDE_FOLD_SPLITK', '1') != '0']      # A-B switch: BatchNorm consumes the forward split-K slabs
-GROUP_STATS = [_os.environ.get('AIDE_GROUP_STATS', '1') != '0']    # A-B switch: epilogue BatchNorm statistics in grouped (stacked-batch) forwards
-F4_HALF_TILES = [_os.environ.get('AIDE_F4_HALF_TILES', '0') != '0']   # A-B switch: F(4x4) on layers whose Cout is 32 mod 64
-W16_PAIRS = [_os.environ.get('AIDE_W16_PAIRS', '0') != '0']      # F(4x4) on the 16-pixel-wide level (image pairs per tile): 11 % faster per launch than F(2x2), -0.6 % on the C2 step (larger filter pack, more slabs for BatchNorm to sum): off
-DUAL_BWD = [_os.environ.get('AIDE_DUAL_BWD', '0') != '0']        # ... and of the backward pass (measured +-0 beside the weight-gradient stream: off)
-DUAL_BWD_MAXLEVEL = [int(_os.environ.get('AIDE_DUAL_BWD_MAXLEVEL', '9'))]   # ... only for the ops of levels <= this (0: the tail of the pass, where nothing is left to overlap the second encoder's chain with)
-EARLY_FLUSH = [_os.environ.get('AIDE_EARLY_FLUSH', '0') != '0']   # A-B switch: the slab reduces still queued go out behind the LAST Winograd weight gradient, not behind the last kernel of the pass
-FOLD_EVAL_BN = [_os.environ.get('AIDE_FOLD_EVAL_BN', '1') != '0']   # A-B switch: eval-mode BatchNorm + ReLU in the F(4x4) conv epilogue (no pass over the conv output)
-TAIL_WG4_FULL = [_os.environ.get('AIDE_TAIL_WG4_FULL', '1') != '0']   # A-B switch: the last F(4x4) weight gradient of a single-encoder backward pass on 256 workgroups
-TAIL_WGRAD_MAIN = [_os.environ.get('AIDE_TAIL_WGRAD_MAIN', '1') != '0']   # A-B switch: the weight gradient of the LAST op of the backward pass (a stem conv: no data gradient) on the main stream, which has nothing left to do, beside the weight-gradient stream's backlog
-PACKS_ON_SIDE = [_os.environ.get('AIDE_PACKS_ON_SIDE', '1') != '0']   # A-B switch: the filter re-layout of a training plan on its weight-gradient stream (idle during the forward pass) instead of a stream of its own: one stream less per process (see distributed.py: hardware queues)
-DUAL_FWD = [_os.environ.get('AIDE_DUAL_FWD', '1') != '0']        # A-B switch: lane-1 chains of the forward pass on a second stream
-FREE_LANE = [_os.environ.get('AIDE_FREE_LANE', '1') != '0']      # A-B switch: lane 1 pools its own channels and runs ahead (no fork / join per level)
-FOLD_SPLITK_BWD = [_os.environ.get('AIDE_FOLD_SPLITK_BWD', '1') != '0']   # ... and BatchNorm backward the data-gradient slabs
-FLUSH_EVERY = int(_os.environ.get('AIDE_WGRAD_FLUSH_EVERY', '6'))      # layers per batched slab reduce
+REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch tapes (aide_amd/tape.py)
+SHARED_PACKS = [True]          # plans of an engine share packed filters; forward-only plans pack no dgrad direction
+FOLD_EVAL_BN = [True]          # eval-mode BatchNorm + ReLU in the conv epilogue (no pass over the conv output)
+TAIL_WGRAD_MAIN = [True]       # the weight gradient of the LAST op of the backward pass (a stem conv: no data gradient) on the main stream, which has nothing left to do, beside the weight-gradient stream's backlog
+DUAL_FWD = [True]              # lane-1 chains of the forward pass on a second stream
+FREE_LANE = [True]             # lane 1 pools its own channels and runs ahead (no fork / join per level)
+FLUSH_EVERY = 6                # layers per batched slab reduce
 
 
 def conv_mode(n, cin, h, w, cout):
@@ -131,10 +119,11 @@ def conv_mode(n, cin, h, w, cout):
     sweep (tools/bench_conv.py wino): F(4x4) wins on every layer of >= 8 GFLOP and on the >= 128x128-channel
     layers (1.3-1.5x over F(2x2) on the 19 / 39 GFLOP decoder layers); F(2x2) elsewhere; direct where neither
     is supported."""
-    if USE_WINOGRAD[0] and USE_WINOGRAD4[0] and lib.aide_conv3x3_wino4_supported(cin, h, w, cout) and \
-            not (w == 16 and (n % 2 or not W16_PAIRS[0])):         # 16-wide images go two per workgroup tile
+    if USE_WINOGRAD[0] and USE_WINOGRAD4[0] and lib.aide_conv3x3_wino4_supported(cin, h, w, cout) and w != 16:
+        # (w == 16: the kernel's image-pair tile is 11 % faster than F(2x2) there, the step 0.6 % slower -- 4x larger
+        # filter pack for the 8 M bottleneck parameters, twice the slabs for BatchNorm to sum)
         flops = 2.0 * n * h * w * cin * cout * 9
-        if cout % 64 and not F4_HALF_TILES[0]:   # trailing half block computed and dropped: 42 vs 52 us on 32->32 @256x256,
+        if cout % 64:                       # trailing half block computed and dropped: 42 vs 52 us on 32->32 @256x256,
             return 0                        # but the 4x larger filter pack eats the gain in the whole step
         if flops >= 8e9 or cin * cout >= 128 * 128:
             return 4
@@ -148,40 +137,22 @@ def use_winograd(n, cin, h, w, cout):
     return bool(USE_WINOGRAD[0] and lib.aide_conv3x3_wino_supported(cin, h, w, cout))
 
 
-SHARED_STREAMS = [_os.environ.get('AIDE_SHARED_STREAMS', '1') != '0']   # A-B switch: ONE weight-gradient stream and ONE lane / pack stream per device, shared by every plan of every engine
-
-
 def _preferred(dev):
-    """the per-device streams every plan should use instead of creating its own (a data-parallel rank's measured choice,
-    aide_amd/streams.py; or SHARED_STREAMS), or None"""
+    """the per-device streams every plan uses instead of creating its own: a data-parallel rank's measured choice
+    (aide_amd/streams.py), else ONE weight-gradient stream and ONE lane / pack stream per device shared by every plan of
+    every engine (the HIP runtime maps a process' streams onto 4 hardware queues: DESIGN.md 7a)"""
     from . import streams as _streams
     d = torch.device(dev)
     idx = d.index if d.index is not None else torch.cuda.current_device()
     pref = _streams.PREFERRED.get(idx)
-    if pref is None and SHARED_STREAMS[0]:
+    if pref is None:
         pref = _streams.PREFERRED[idx] = dict(side=torch.cuda.Stream(device=d), lane=torch.cuda.Stream(device=d))
     return pref
 
 
 def _side_stream(dev):
-    """Stream of the weight-gradient kernels.  AIDE_SIDE_CUMASK=<k>/<m> restricts it to k of every m compute units
-    (bit pattern repeated over the 256 CUs), e.g. 1/2 = every other CU."""
-    spec = _os.environ.get('AIDE_SIDE_CUMASK', SIDE_CUMASK[0])
-    if not spec:
-        pref = _preferred(dev)                    # a data-parallel rank measured which streams share a hardware queue
-        if pref is not None and pref.get('side') is not None:
-            return pref['side']
-        return torch.cuda.Stream(device=dev)
-    import ctypes
-    k, m = [int(v) for v in spec.split('/')]
-    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-    words = (ncu + 31) // 32
-    bits = [1 if (i % m) < k else 0 for i in range(words * 32)]
-    arr = (ctypes.c_uint32 * words)(*[sum(b << j for j, b in enumerate(bits[w * 32:(w + 1) * 32])) for w in range(words)])
-    out = ctypes.c_void_p()
-    with torch.cuda.device(dev):
-        _check(lib.aide_stream_create_cumask(ctypes.byref(out), arr, words), 'stream_create_cumask')
-    return torch.cuda.ExternalStream(out.value, device=dev)
+    """Stream of the weight-gradient kernels (shared per device, see _preferred)."""
+    return _preferred(dev)['side']
 
 
 class _Cover(object):
@@ -302,7 +273,7 @@ class Plan(object):
                     # else transposed F(2x2,3x3), else the direct kernel
                     if bf16 and lib.aide_conv3x3_wgrad_bf16_supported(cout, cin, hh, ww):
                         st['wino_w'] = BF16
-                        st['wg_bytes'] = lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, cout, cin, hh, ww)
+                        st['wg_bytes'] = lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, cout, cin, hh, ww, 0)
                     elif USE_WINOGRAD[0] and USE_WINOGRAD4[0] and cout % 64 == 0 and \
                             lib.aide_conv3x3_wgrad_wino4_supported(cout, cin, hh, ww):
                         # (a trailing half tile -- 32->32 @256x256 -- is 71 -> 56 us alone, but the 144 KB workgroups keep
@@ -311,7 +282,7 @@ class Plan(object):
                         # the LAST such launch of a backward pass whose dependent chain ends with it (every op before it in
                         # the graph is a stem conv without a data gradient -- the single-encoder U-Nets): nothing is left to
                         # share the chip with, so it takes all of it (the default leaves half to the dependent chain)
-                        if TAIL_WG4_FULL[0] and all(s0['kind'] == 'conv' and s0['src'].root.is_input for s0 in self.steps):
+                        if all(s0['kind'] == 'conv' and s0['src'].root.is_input for s0 in self.steps):
                             st['wg_target'] = 256
                         st['wg_bytes'] = lib.aide_conv3x3_wgrad_wino4_ws_bytes_t(n, cout, cin, hh, ww, st.get('wg_target', 0))
                     elif USE_WINOGRAD[0] and lib.aide_conv3x3_wgrad_wino_supported(cout, cin, hh, ww):
@@ -323,7 +294,7 @@ class Plan(object):
                     max_wg = max(max_wg, st['wg_bytes'])
                     # BatchNorm statistics from the conv epilogue (big planes, non-split F(4x4) forward, ungrouped training)
                     st['stats'] = None
-                    if training and (groups == 1 or GROUP_STATS[0]) and EPILOGUE_STATS[0] and (st['plan_f'] >> 8) <= 1 \
+                    if training and (st['plan_f'] >> 8) <= 1 \
                             and (hh * ww) % 4 == 0 and lib.aide_bn_two_pass(n // max(groups, 1), cout, hh, ww):
                         # F(4x4) forward only.  The same epilogue in the direct and F(2x2) kernels was built and measured: C2
                         # 575 -> 572 images/s (their epilogues are short and the butterflies cost more than the saved pass) and
@@ -399,29 +370,27 @@ class Plan(object):
             self.lane_b = pref['lane'] if (pref is not None and pref.get('lane') is not None) else torch.cuda.Stream(device=device)
             self.bn_ws_b = ops.bn_ws(max(max_bnc, 1), device)
             self.sk_ws_b = torch.empty(max(max_sk // 4, 1), **f32)
-            self.ev_lane_fork, self.ev_lane_join, self.ev_lane_acc = ops.new_event(), ops.new_event(), ops.new_event()
+            self.ev_lane_fork, self.ev_lane_join = ops.new_event(), ops.new_event()
             for st in self.steps:        # one event per split pooling op: "lane 1's half of this level is pooled"
                 if st['kind'] == 'pool' and st.get('lane_split'):
                     st['ev_b'] = ops.new_event()
         self._max_dz, self._max_wg = max_dz, max_wg
-        self.wg_ws = None
+        self.wg_ws = self.wg_queue = self._wq_active = None
         self._bwd_ready = False
         self.profiler = None             # set by Engine (bench.py's per-kernel HIP-event timing)
         self._pack_key, self._pack_tabs, self._pack_ids, self.side_fwd = None, {}, None, None
         # the weight-gradient stream of a plan that will run backward passes; it also carries the filter re-layout at the start
-        # of the forward pass (PACKS_ON_SIDE): the HIP runtime maps a process' streams onto 4 hardware queues, and the
+        # of the forward pass: the HIP runtime maps a process' streams onto 4 hardware queues, and the
         # data-parallel path needs one of them for RCCL's own stream (aide_amd/distributed.py)
         self.side = _side_stream(device) if (training and groups == 1) else None
         self._convs = self._conv_wslots = None
-        self._late_pending, self._late_inflight = None, False
         self._gate_conv = None           # the first conv that needs the side-stream filter packs
         self._tape_f = self._tape_b = None
-        self._coef_key, self._coef_tensors, self._coef_ok = None, None, False
+        self._coef_key, self._coef_tensors, self._coef_ok, self._coef_next, self._coef_bns = None, None, False, None, []
         self._fp = None
         self._fp_slots = self._fp_bns = None
         self.overlap = True              # weight gradients on a side stream (see backward)
         self.trace = None                # tools/phase_trace.py: callable(direction, step) before every op
-        self.hp = None                   # high-priority stream of the backward chain (HP_CHAIN)
         self.serial = 0                  # forwards run on this plan; _NetFunction.backward checks it still owns the buffers
         self.key = None
 
@@ -462,6 +431,7 @@ class Plan(object):
             if st['kind'] in ('conv', 'convT'):
                 st['wg_ws'] = self.wg_ws[st['wg_off']:st['wg_off'] + max(st['wg_bytes'] // 4, 1)]
         self.head_ws = torch.empty(max(self._max_wg // 4, 1), **f32)
+        self.wg_queue = ops.new_wgrad_queue()     # pending slab reduces of a backward pass (batched launches)
         sa = [st for st in self.steps if st['kind'] == 'sa']
         if sa:                      # small-channel gradient ping-pong buffers + the gate-backward workspace
             big = max(st['t1'].numel() for st in sa)
@@ -488,7 +458,7 @@ class Plan(object):
         for i, st in enumerate(self.steps):
             st['fold_dgrad'] = False
             sg = st.get('src_grad')
-            if i == 0 or st['kind'] != 'conv' or sg is None or sg['accumulate'] or sg['gaps'] or not FOLD_SPLITK_BWD[0]:
+            if i == 0 or st['kind'] != 'conv' or sg is None or sg['accumulate'] or sg['gaps']:
                 continue
             prod = self.steps[i - 1]
             src, dst = st['src'], prod.get('dst')
@@ -557,19 +527,13 @@ class Plan(object):
                         ops.bf16_pack_table(b16, self.dev) if b16 else None)
                 return tabs if any(t is not None for t in tabs) else None
             rest = convs[split:]
-            late = LATE_DGRAD_PACK[0] and self.training and len(rest) > 0
-            # the dgrad-direction packs of all but the first convs (half of the re-layout bytes) are needed only in the
-            # backward pass: they are launched when the decoder starts (first up-sampling / ConvT op), under its MFMA-bound
-            # convolutions, instead of next to the HBM-bound first level
-            ups = [st for st in self.steps if st['kind'] in ('up', 'convT')]
-            rest_tabs = tables(rest, True, not late) if rest else None
-            late_tabs = tables(rest, False, True) if late else None
-            cached = (tables(convs[:split]), rest_tabs, convs[split] if rest_tabs is not None else None, late_tabs,
-                      (ups[0] if ups else self.steps[-1]) if late_tabs is not None else None)
+            # (the dgrad-direction packs launched later, under the decoder forward, measured +-0 twice: one launch)
+            rest_tabs = tables(rest, True, True) if rest else None
+            cached = (tables(convs[:split]), rest_tabs, convs[split] if rest_tabs is not None else None)
             if len(self._pack_tabs) > 8:
                 self._pack_tabs.clear()
             self._pack_tabs[(ptrs, fresh)] = cached
-        first, rest, gate, late_tab, late_gate = cached
+        first, rest, gate = cached
         self._gate_conv = gate
 
         def launch(tabs):
@@ -599,13 +563,12 @@ class Plan(object):
         self._pack_key = key
         for i in mine:
             fresh_map[i] = key
-        self._late_pending = (late_tab, late_gate) if late_tab is not None else None
         if rest is None:
             self._shared['streams'] = (torch.cuda.current_stream(), None)
             return None
         if self.side_fwd is None:
             pref = _preferred(self.dev)
-            self.side_fwd = (self.side if (self.side is not None and PACKS_ON_SIDE[0]) else
+            self.side_fwd = (self.side if self.side is not None else
                              pref['lane'] if (pref is not None and pref.get('lane') is not None) else
                              torch.cuda.Stream(device=self.dev))
             self._side_fwd_ptr = ctypes.c_void_p(self.side_fwd.cuda_stream)
@@ -616,22 +579,10 @@ class Plan(object):
         self._shared['streams'] = (torch.cuda.current_stream(), self.side_fwd)
         return gate
 
-    def _late_pack(self, st):
-        """launch the deferred dgrad-direction packs on the side stream when the forward reaches their gate op"""
-        if self._late_pending is not None and (st is None or st is self._late_pending[1]):
-            tab = self._late_pending[0]
-            self._late_pending = None
-            main = torch.cuda.current_stream()
-            self.side_fwd.wait_stream(main)
-            with torch.cuda.stream(self.side_fwd):
-                self._launch_pack(tab)
-            self._late_inflight = True
-
     def _fingerprint(self):
         """addresses of every parameter and buffer the launch sequence bakes in (a tape is only valid for these)"""
         # ... and everything else a recorded sequence depends on: the runtime schedule switches and the BatchNorm scalars
-        fp = [DUAL_FWD[0], FREE_LANE[0], DUAL_BWD[0], DUAL_BWD_MAXLEVEL[0], EARLY_FLUSH[0], TAIL_WGRAD_MAIN[0], FOLD_SPLITK[0], FOLD_SPLITK_BWD[0], DEFER_WGRAD_REDUCE[0], FLUSH_EVERY,
-              HEAD_WGRAD_SIDE[0], EPILOGUE_STATS[0], self.overlap]
+        fp = [DUAL_FWD[0], FREE_LANE[0], TAIL_WGRAD_MAIN[0], self.overlap]
         # (this runs every forward: the tensors are looked up through the modules' own _parameters / _buffers dicts -- a
         # replaced parameter or buffer is seen -- without walking the module tree)
         slots = self._fp_slots
@@ -655,7 +606,7 @@ class Plan(object):
         return tuple(fp)
 
     def _tapeable(self):
-        return REPLAY[0] and self.profiler is None and self.trace is None and not LATE_DGRAD_PACK[0] and not HP_CHAIN[0]
+        return REPLAY[0] and self.profiler is None and self.trace is None
 
     def _coef_fresh(self):
         """eval mode: are the cached BatchNorm coefficients (scale, shift, folded bias per layer) those of the current
@@ -671,15 +622,23 @@ class Plan(object):
                     bn = st['bn']
                     tens += [st['conv'].bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
             tens = self._coef_tensors = [t for t in tens if t is not None]
-        key = (PARAM_EPOCH[0], STATS_EPOCH[0]) + tuple((t.data_ptr(), t._version) for t in tens)
-        fresh = key == self._coef_key
-        self._coef_key = key
-        return fresh
+            self._coef_bns = [st['bn'] for st in self.steps if st['kind'] in ('conv', 'convT')]
+        self._coef_eps = [bn.eps for bn in self._coef_bns]
+        key = (PARAM_EPOCH[0], STATS_EPOCH[0]) + tuple(self._coef_eps) + tuple((t.data_ptr(), t._version) for t in tens)
+        self._coef_next = key            # becomes _coef_key once the fold launches of this forward have been issued
+        return key == self._coef_key
 
     def forward(self, inputs, out):
         self.serial += 1                 # the saved activations of this plan now belong to THIS forward (any kind)
         gate = self._pack_filters()
         self._coef_ok = self._coef_fresh()
+        self._coef_key = None            # (a forward that dies between here and its fold launches leaves nothing marked fresh)
+        self._forward_any(inputs, out, gate)
+        if not self.training:
+            self._coef_key = self._coef_next
+        return out
+
+    def _forward_any(self, inputs, out, gate):
         if not self._tapeable():
             self._tape_f = self._tape_b = None
             return self._forward_impl(inputs, out, gate, None)
@@ -749,8 +708,6 @@ class Plan(object):
             kind = st['kind']
             if self.trace is not None:
                 self.trace('f', st)
-            if self._late_pending is not None:
-                self._late_pack(st)
             lane = st.get('lane', 0) if dual else 0
             if kind == 'conv' and st is self._gate_conv:      # (when) the remaining filters were re-packed on the side stream
                 wait = lambda: torch.cuda.current_stream().wait_stream(self.side_fwd)
@@ -800,8 +757,6 @@ class Plan(object):
                 self._forward_op(st, inputs, out, self.bn_ws, self.sk_ws)
         if pend or pooled:
             ops.order(self.ev_lane_join, bp, mp)
-        if self._late_pending is not None:
-            self._late_pack(None)
         return out
 
     def _forward_op(self, st, inputs, out, bn_ws, sk_ws):
@@ -815,26 +770,25 @@ class Plan(object):
                     prof.begin(FWD_TAG[st['wino_f']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_f']])
                 # training forward of a split-K layer: the conv leaves its slabs (accumulate = 2) and the BatchNorm that
                 # follows sums them itself -- no split-reduce launch, one pass over z less
-                slabs = self.training and FOLD_SPLITK[0] and (st['plan_f'] >> 8) > 1 and \
+                slabs = self.training and (st['plan_f'] >> 8) > 1 and \
                     (st['z'].shape[2] * st['z'].shape[3]) % 4 == 0          # (the slab loader reads 16 bytes)
                 acc = 2 if slabs else 0
                 if st.get('fold'):                 # eval: y = relu(acc * scale + folded bias) straight into the activation
-                    lib.aide_conv_epilogue_affine(ops.ptr(st['scale']), 1)
                     if st['wino_f'] == 4:
                         ops.conv3x3_wino4(x, st['uf'], st['fbias'], self.view(st['dst']), accumulate=0,
-                                          splitk=st['plan_f'] >> 8, ws=sk_ws)
+                                          splitk=st['plan_f'] >> 8, ws=sk_ws, epi_scale=st['scale'], epi_relu=True)
                     else:                          # direct kernel (the 32-channel first level, the stems), non-split
                         ops.conv3x3_igemm(x, st['wf'], st['fbias'], self.view(st['dst']), accumulate=0, plan=st['plan_f'],
-                                          ws=sk_ws)
+                                          ws=sk_ws, epi_scale=st['scale'], epi_relu=True)
                     if prof is not None:
                         prof.end()
                     return
-                if st['stats'] is not None:        # one-shot: this launch writes the BatchNorm statistics partials
-                    lib.aide_conv_stats_sink(ops.ptr(st['stats']))
                 if st['wino_f'] == BF16:
                     ops.conv3x3_bf16(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=sk_ws)
                 elif st['wino_f'] == 4:
-                    ops.conv3x3_wino4(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=sk_ws)
+                    # (st['stats']: this launch also writes the BatchNorm statistics partials of its output)
+                    ops.conv3x3_wino4(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=sk_ws,
+                                      stats=st['stats'])
                 elif st['wino_f']:
                     ops.conv3x3_wino(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=sk_ws)
                 else:
@@ -920,7 +874,7 @@ class Plan(object):
         # up-sampling backward); every weight-gradient kernel (MFMA-bound, off the critical path) goes to
         # a side stream as soon as its dz exists, so the HBM-bound kernels of the next layer run in
         # its shadow instead of between two MFMA kernels.
-        main = outer = torch.cuda.current_stream()
+        main = torch.cuda.current_stream()
         # (with a profiler attached the step runs on ONE stream: an event pair then brackets exactly one kernel's own time,
         # not its time under contention with the side stream -- bench.py instruments a single step for that reason)
         side = self.side if (self.overlap and self.profiler is None) else None
@@ -937,7 +891,8 @@ class Plan(object):
                 except BaseException:
                     # a replay that stops between the recorded defer(1) and defer(0) must not leave the library collecting
                     # slab reduces for ever (nor keep descriptors of this step)
-                    lib.load().aide_wgrad_reduce_discard()
+                    if self.wg_queue is not None:
+                        self.wg_queue.discard()
                     self._tape_b = None
                     raise
                 return
@@ -951,24 +906,9 @@ class Plan(object):
                 self._backward_streams(inputs, dlogits, gslot, main, side, cb)
             self._tape_b = tp.finish(dyn)
             return
-        if side is not None and HP_CHAIN[0]:
-            # the dependent chain on a HIGH-priority stream: when both streams have workgroups ready the dispatcher serves
-            # the chain first and the weight gradients soak up what is left
-            if self.hp is None:
-                self.hp = torch.cuda.Stream(device=self.dev, priority=-1)
-            self.hp.wait_stream(outer)
-            main = self.hp
-        if main is not outer:
-            with torch.cuda.stream(main):
-                self._backward_streams(inputs, dlogits, gslot, main, side, after_op)
-            outer.wait_stream(main)
-        else:
-            self._backward_streams(inputs, dlogits, gslot, main, side, after_op)
+        self._backward_streams(inputs, dlogits, gslot, main, side, after_op)
 
     def _backward_streams(self, inputs, dlogits, gslot, main, side, after_op):
-        if self._late_inflight:              # the dgrad-direction filter packs launched under the decoder forward
-            main.wait_stream(self.side_fwd)
-            self._late_inflight = False
         # raw stream handles: every fork / join below is a C-ABI call (ops.order) and every side-stream launch takes the
         # stream explicitly (ops.use_stream) -- nothing here depends on torch's stream context, so the whole sequence can be
         # recorded and re-issued by a launch tape
@@ -979,94 +919,52 @@ class Plan(object):
             ops.order(self.ev_fork, mp, sp)
         # The slab reduces of the weight gradients run batched, one launch per FLUSH_EVERY layers: fewer latency-bound
         # launches on the weight-gradient stream, and only the last (small, shallow-encoder) batch sits after the last kernel
-        # (bf16 mode: its weight-gradient slabs are several times larger and the batched reduce measured 1 % slower -> per layer)
-        defer = DEFER_WGRAD_REDUCE[0] and self.profiler is None and self.precision != 'bf16'
+        # (bf16 mode: its weight-gradient slabs are several times larger and the batched reduce measured 1 % slower -> per
+        # layer).  The queue of pending reduces is this plan's own object (ops.WgradQueue): the library keeps no state.
+        queue = self.wg_queue if (self.profiler is None and self.precision != 'bf16') else None
         waiting = []                          # ops whose after_op callback waits for the flush of their weight gradient
 
-        pending = lib.load().aide_wgrad_reduce_pending     # raw entry point: a host-state query decides WHERE the flushes go
-                                                           # while recording; a replayed tape has no use for it
-
         def flush():
-            if pending():
-                ops.check(lib.aide_wgrad_reduce_flush(sp if side is not None else mp), 'wgrad_reduce_flush')
+            # (pending(): a host-state query decides WHERE the flushes go while recording; a replayed tape re-issues them)
+            if queue.pending():
+                queue.flush(sp if side is not None else mp)
             if after_op is not None:
                 for w_st in waiting:          # their weight gradients are now enqueued in full
                     after_op(w_st)
             del waiting[:]
 
-        # the last op whose weight gradient leaves slabs of any size (Winograd kernels): what is still queued goes out right
-        # behind it, under the direct / stem weight gradients of the first level -- not as one more launch behind the
-        # last kernel of the pass (the tail of the step: 51 -> ~10 us on the FuseUNet step)
-        last_big = None
-        if defer and EARLY_FLUSH[0]:
-            for st in self.steps:
-                if st['kind'] == 'conv' and st.get('wino_w') in (2, 4):
-                    last_big = st
-                    break
         hook = after_op
-        if defer:
+        if queue is not None:
+            queue.discard()                   # (entries of a pass that died between its launches and its flush)
+
             def hook(w_st):
                 waiting.append(w_st)
-                if pending() >= FLUSH_EVERY or (w_st is last_big and pending()):
+                if queue.pending() >= FLUSH_EVERY:
                     flush()
-        if defer:
-            lib.aide_wgrad_reduce_defer(1)
-        done = False
+        self._wq_active = queue
         try:
             with ops.use_stream(mp):
                 self._backward_ops(inputs, dlogits, gslot, mp, sp, hook)
-            if defer:
+            if queue is not None:
                 flush()
-            done = True
-        finally:
-            if defer and done:
-                lib.aide_wgrad_reduce_defer(0)
-            elif defer:
-                # the pass died between its launches and its flush: the queued descriptors point into this step's arena
-                # and workspaces -- drop them and leave the deferred mode (never reduced through later)
-                lib.load().aide_wgrad_reduce_discard()
+        except BaseException:
+            if queue is not None:             # the queued descriptors point into this step's arena and workspaces
+                queue.discard()
+            raise
         if side is not None:
             ops.order(self.ev_join, sp, mp)
 
     def _backward_ops(self, inputs, dlogits, gslot, main, side, after_op):
-        """The backward launch sequence.  Two lanes as in the forward pass: the lane-1 chains (second encoder) run on their
-        own stream beside the lane-0 chain of the same level.  Lane 1 is released after every lane-0 op that is not a
-        conv (the pool / up-sampling backward that produces the level's skip gradient), waits for the main stream before a
-        data gradient that ACCUMULATES into a buffer lane 0 writes first, and is joined before the first main-stream op
-        that touches a gradient range it wrote (and at the end)."""
-        import ctypes
-        dual = self.lane_b is not None and DUAL_BWD[0] and side is not None and self.profiler is None and \
-            self.trace is None and not HP_CHAIN[0]
-        bp = ctypes.c_void_p(self.lane_b.cuda_stream) if dual else None
-        fold = [[0], [0]]                # per lane: split count of the data gradient the NEXT BatchNorm backward reads from its sk_ws
-        pend = []                        # gradient ranges lane 1 wrote since the last join
-
-        def overlaps(t):
-            return t is not None and any(r is t.root and c0 < t.c0 + t.C and t.c0 < c0 + c for r, c0, c in pend)
-        maxlev = DUAL_BWD_MAXLEVEL[0]
+        """The backward launch sequence: the dependent chain on `main`, every weight gradient on `side`.  (The second
+        encoder's chains on a stream of their own, as in the forward pass, measured +-0 beside the weight-gradient stream
+        -- DESIGN.md 3c -- and is not built in.)"""
+        fold = [0]                       # split count of the data gradient the NEXT BatchNorm backward reads from sk_ws
         for st in reversed(self.steps):
-            lane = st.get('lane', 0) if (dual and st['src'].level <= maxlev) else 0
-            sg = st.get('src_grad')
             if self.trace is not None:
                 self.trace('b', st)
-            if lane:
-                if sg is not None and (sg['accumulate'] or sg['gaps']):
-                    ops.order(self.ev_lane_acc, main, bp)      # lane 0 wrote (or zeroed) the buffer first
-                if sg is not None:
-                    pend.append((st['src'].root, st['src'].c0, st['src'].C))
-                with ops.use_stream(bp):
-                    self._backward_op(st, inputs, dlogits, gslot, bp, side, self.bn_ws_b, self.sk_ws_b, fold[1])
-            else:
-                if pend and (overlaps(st.get('dst')) or overlaps(st.get('src'))):
-                    ops.order(self.ev_lane_join, bp, main)
-                    del pend[:]
-                self._backward_op(st, inputs, dlogits, gslot, main, side, self.bn_ws, self.sk_ws, fold[0])
-                if dual and st['kind'] != 'conv' and st['src'].level <= maxlev:
-                    ops.order(self.ev_lane_fork, main, bp)     # the gradients this op wrote release lane 1
+            self._backward_op(st, inputs, dlogits, gslot, main, side, self.bn_ws, self.sk_ws, fold)
             if after_op is not None:
                 after_op(st)
-        if dual:
-            ops.order(self.ev_lane_join, bp, main)
 
     def _backward_op(self, st, inputs, dlogits, gslot, main, side, bn_ws, sk_ws, folded):
         """one op of the backward sequence on stream `main` (its lane's stream); folded: [split count] cell of the lane"""
@@ -1080,7 +978,7 @@ class Plan(object):
                 conv = st['conv']
                 k = conv.out_channels
                 assert sg is None or not sg['accumulate']
-                if side is not None and sg is not None and HEAD_WGRAD_SIDE[0]:
+                if side is not None and sg is not None:
                     # the head's weight gradient (one pass over the widest feature map) has no consumer until the
                     # optimizer: side stream, so that the dependent chain starts with the data gradient alone
                     with ops.use_stream(side):
@@ -1107,11 +1005,14 @@ class Plan(object):
                 x = self.view(st['src'], inputs)
                 if kind == 'conv':
                     prof = self.profiler
-                    wgrad = (ops.conv3x3_wgrad_bf16 if st['wino_w'] == BF16 else
-                             (lambda d_, x_, w_, ws=None: ops.conv3x3_wgrad_wino4(d_, x_, w_, ws=ws, target_wgs=256))
-                             if st.get('wg_target') else
-                             ops.conv3x3_wgrad_wino4 if st['wino_w'] == 4 else
-                             ops.conv3x3_wgrad_wino if st['wino_w'] else ops.conv3x3_wgrad)
+                    wq = self._wq_active
+                    wfn = (ops.conv3x3_wgrad_bf16 if st['wino_w'] == BF16 else
+                           (lambda d_, x_, w_, ws=None, queue=None: ops.conv3x3_wgrad_wino4(d_, x_, w_, ws=ws, target_wgs=256,
+                                                                                            queue=queue))
+                           if st.get('wg_target') else
+                           ops.conv3x3_wgrad_wino4 if st['wino_w'] == 4 else
+                           ops.conv3x3_wgrad_wino if st['wino_w'] else ops.conv3x3_wgrad)
+                    wgrad = lambda d_, x_, w_, ws=None: wfn(d_, x_, w_, ws=ws, queue=wq)
                     # the last op of the pass, when it has no data gradient (a stem conv): the dependent chain ends with its
                     # BatchNorm backward, so its weight gradient runs on that stream beside whatever the weight-gradient
                     # stream still has queued instead of behind it
@@ -1288,11 +1189,9 @@ class _NetFunction(torch.autograd.Function):
                     mode = 3
         flat = arena if mode == 1 else torch.empty(eng.flat_numel, device=dlogits.device, dtype=torch.float32)
         eng.side_stream = plan.side if (plan._bwd_ready and plan.overlap) else None
-        eng.lane_stream = plan.lane_b if (plan.overlap and DUAL_BWD[0]) else None
         if not plan._bwd_ready:
             plan._prepare_backward()
             eng.side_stream = plan.side if plan.overlap else None
-            eng.lane_stream = plan.lane_b if (plan.overlap and DUAL_BWD[0]) else None
         if eng.before_backward is not None:
             eng.before_backward(flat)
         plan.backward(ctx.inputs, dlogits, flat, eng.offsets, eng.after_backward_op)
@@ -1340,7 +1239,6 @@ class Engine(object):
         self.profiler = None             # object with begin(tag, flops) / end(): per-kernel HIP events
         self.before_backward = None      # callable(flat_grad) at the start of every backward
         self.side_stream = None          # stream carrying the weight-gradient kernels of the running backward
-        self.lane_stream = None          # ... and the stream of the lane-1 chains (second encoder), if any
         self.graph = None
         self._precision = 'fp32'
         self._arena = self._views = self._anchor = None
@@ -1406,6 +1304,12 @@ class Engine(object):
             self.plans = {}
             self._shared_packs = dict(buf={}, fresh={}, streams=None)
             self._arena = self._views = None
+
+    @staticmethod
+    def invalidate_coefficients():
+        """Call after editing BatchNorm running statistics or affine parameters through `.data` / raw pointers (no tensor
+        version changes): the folded eval-mode coefficients of every plan are recomputed by its next forward."""
+        STATS_EPOCH[0] += 1
 
     def plan_for(self, inputs, groups=1):
         self._refresh_params()

@@ -48,6 +48,38 @@ class Event(ctypes.c_void_p):
             pass
 
 
+class WgradQueue(ctypes.c_void_p):
+    """a caller-owned queue of weight-gradient slab reduces (aide_wgrad_queue_*): the wgrad wrappers given one only record
+    their reduce, flush(stream) runs everything recorded as one launch.  Host memory; destroyed with its owner."""
+
+    def __del__(self):
+        try:
+            if self.value:
+                lib.load().aide_wgrad_queue_destroy(ctypes.c_void_p(self.value))
+                self.value = None
+        except Exception:       # interpreter shutdown
+            pass
+
+    def pending(self):
+        return lib.load().aide_wgrad_queue_pending(self)      # (raw entry: a host-state query stays off the launch tape)
+
+    def flush(self, stream):
+        check(lib.aide_wgrad_queue_flush(self, stream), 'wgrad_queue_flush')
+
+    def discard(self):
+        return lib.load().aide_wgrad_queue_discard(self)
+
+
+def new_wgrad_queue():
+    q = WgradQueue()
+    check(lib.load().aide_wgrad_queue_create(ctypes.byref(q)), 'wgrad_queue_create')
+    return q
+
+
+def _qh(queue):
+    return queue if queue is not None else None
+
+
 def new_event():
     ev = Event()
     check(lib.aide_event_create(ctypes.byref(ev)), 'event_create')
@@ -145,8 +177,9 @@ def pack_weights_into(w, wf, wd):
           'conv3x3_pack_weights')
 
 
-def conv3x3_igemm(x, wp, bias, y, accumulate=False, plan=-1, ws=None):
-    """y (+)= conv3x3(x) with packed weights wp [cin_pad, 9, cout] (forward pack or dgrad pack)."""
+def conv3x3_igemm(x, wp, bias, y, accumulate=False, plan=-1, ws=None, epi_scale=None, epi_relu=True):
+    """y (+)= conv3x3(x) with packed weights wp [cin_pad, 9, cout] (forward pack or dgrad pack).
+    epi_scale [cout]: y = relu?(acc * epi_scale + bias) (eval-mode BatchNorm folded into the conv; non-split only)."""
     xp, xbs = planes(x)
     yp, ybs = planes(y)
     n, cin, h, w = x.shape
@@ -159,11 +192,14 @@ def conv3x3_igemm(x, wp, bias, y, accumulate=False, plan=-1, ws=None):
         ws = torch.empty(lib.aide_conv3x3_ws_bytes(n, h, w, cout, splitk) // 4, device=x.device,
                          dtype=torch.float32)
     check(lib.aide_conv3x3_igemm(xp, xbs, ptr(wp), cout, ptr(bias), yp, ybs, n, cin, h, w, cout,
-                                 int(accumulate), plan, ptr(ws), stream_ptr()), 'conv3x3_igemm')
+                                 int(accumulate), plan, ptr(ws), ptr(epi_scale), int(bool(epi_relu)), stream_ptr()),
+          'conv3x3_igemm')
     return y
 
 
-def conv3x3_wgrad(dz, a, dw, ws=None):
+def conv3x3_wgrad(dz, a, dw, ws=None, queue=None):
+    """queue (every weight-gradient wrapper): None = the slab reduce is launched behind the kernel, or a WgradQueue whose
+    flush() runs the reduces of several layers as one launch (ws must then stay untouched until that flush)"""
     dp, dbs = planes(dz)
     ap, abs_ = planes(a)
     n, co, h, w = dz.shape
@@ -172,7 +208,7 @@ def conv3x3_wgrad(dz, a, dw, ws=None):
     if ws is None:
         ws = torch.empty(lib.aide_conv3x3_wgrad_ws_bytes(n, co, ci, h, w) // 4, device=dz.device,
                          dtype=torch.float32)
-    check(lib.aide_conv3x3_wgrad(dp, dbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), stream_ptr()),
+    check(lib.aide_conv3x3_wgrad(dp, dbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), _qh(queue), stream_ptr()),
           'conv3x3_wgrad')
     return dw
 
@@ -245,7 +281,7 @@ def bn_train_fwd_slabs(slabs, splitk, split_stride, bias, z, a, gamma, beta, eps
 
 def bn_train_fwd_parts(z, a, parts, nparts, conv_bias, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean,
                        rstd, scale, shift, relu=True, first=0, stride=None):
-    """bn_train_fwd with the statistics emitted by the conv epilogue (lib.aide_conv_stats_sink): one pass over z.
+    """bn_train_fwd with the statistics emitted by the conv epilogue (conv3x3_wino4(..., stats=)): one pass over z.
     A group of a stacked batch: first = index of the group's first entry, nparts = its entry count, stride = entries per
     channel of the whole launch."""
     zp, zbs = planes(z, bf16_ok=True)
@@ -464,7 +500,9 @@ def wino4_pack(w, need_dgrad=True):
     return uf, ud
 
 
-def conv3x3_wino4(x, u, bias, y, accumulate=False, splitk=-1, ws=None):
+def conv3x3_wino4(x, u, bias, y, accumulate=False, splitk=-1, ws=None, stats=None, epi_scale=None, epi_relu=True):
+    """stats [cout * wino4_stats_parts * 2]: the launch also writes its BatchNorm statistics partials (non-split,
+    accumulate = 0, W >= 32); epi_scale [cout]: y = relu?(acc * epi_scale + bias) (eval-mode BatchNorm folded in)"""
     xp, xbs = planes(x)
     yp, ybs = planes(y)
     n, cin, h, w = x.shape
@@ -475,7 +513,7 @@ def conv3x3_wino4(x, u, bias, y, accumulate=False, splitk=-1, ws=None):
     if splitk > 1 and ws is None:
         ws = torch.empty(lib.aide_conv3x3_ws_bytes(n, h, w, cout, splitk) // 4, device=x.device, dtype=torch.float32)
     check(lib.aide_conv3x3_wino4(xp, xbs, ptr(u), ptr(bias), yp, ybs, n, cin, h, w, cout, int(accumulate), splitk,
-                                 ptr(ws), stream_ptr()), 'conv3x3_wino4')
+                                 ptr(ws), ptr(stats), ptr(epi_scale), int(bool(epi_relu)), stream_ptr()), 'conv3x3_wino4')
     return y
 
 
@@ -534,18 +572,19 @@ def wgrad_bf16_supported(co, ci, h, w):
     return bool(lib.aide_conv3x3_wgrad_bf16_supported(co, ci, h, w))
 
 
-def conv3x3_wgrad_bf16(dz, a, dw, ws=None):
-    """dw [Co,Ci,3,3] fp32 <- weight gradient on the bf16 MFMA path (dz fp32 or bf16-stored)."""
+def conv3x3_wgrad_bf16(dz, a, dw, ws=None, queue=None, co_blocks=0):
+    """dw [Co,Ci,3,3] fp32 <- weight gradient on the bf16 MFMA path (dz fp32 or bf16-stored).  co_blocks: 2 / 4 = the
+    64 / 128 co x 64 ci workgroup tile, 0 = the library's rule (ws is sized for the same choice)."""
     dzp, dzbs = planes(dz, bf16_ok=True)
     ap, abs_ = planes(a, bf16_ok=True)
     n, co, h, w = dz.shape
     ci = a.shape[1]
     assert tuple(dw.shape) == (co, ci, 3, 3) and dw.is_contiguous()
     if ws is None:
-        ws = torch.empty(lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, co, ci, h, w) // 4, device=dz.device,
+        ws = torch.empty(lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, co, ci, h, w, co_blocks) // 4, device=dz.device,
                          dtype=torch.float32)
     check(lib.aide_conv3x3_wgrad_bf16_mixed(dzp, int(is_bf16(dz)), dzbs, ap, int(is_bf16(a)), abs_, ptr(dw), n, co, ci,
-                                            h, w, ptr(ws), stream_ptr()), 'conv3x3_wgrad_bf16')
+                                            h, w, ptr(ws), co_blocks, _qh(queue), stream_ptr()), 'conv3x3_wgrad_bf16')
     return dw
 
 
@@ -553,7 +592,7 @@ def wgrad_wino4_supported(co, ci, h, w):
     return bool(lib.aide_conv3x3_wgrad_wino4_supported(co, ci, h, w))
 
 
-def conv3x3_wgrad_wino4(dz, a, dw, ws=None, target_wgs=0):
+def conv3x3_wgrad_wino4(dz, a, dw, ws=None, target_wgs=0, queue=None):
     """dw [Co,Ci,3,3] <- weight gradient via the transposed Winograd F(4x4,3x3) kernel.  target_wgs: workgroups of the
     launch (0: the library's default, half of the chip); ws must hold aide_conv3x3_wgrad_wino4_ws_bytes_t() for it."""
     dzp, dzbs = planes(dz)
@@ -565,8 +604,8 @@ def conv3x3_wgrad_wino4(dz, a, dw, ws=None, target_wgs=0):
                          dtype=torch.float32)
     elif target_wgs and ws.numel() * 4 < lib.load().aide_conv3x3_wgrad_wino4_ws_bytes_t(n, co, ci, h, w, target_wgs):   # (raw entry: a host-side size query stays off the launch tape)
         raise RuntimeError('aide_amd: weight-gradient workspace too small for %d workgroups' % target_wgs)
-    check(lib.aide_conv3x3_wgrad_wino4_t(dzp, dzbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), target_wgs, stream_ptr()),
-          'conv3x3_wgrad_wino4')
+    check(lib.aide_conv3x3_wgrad_wino4_t(dzp, dzbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), target_wgs, _qh(queue),
+                                         stream_ptr()), 'conv3x3_wgrad_wino4')
     return dw
 
 
@@ -574,7 +613,7 @@ def wgrad_wino_supported(co, ci, h, w):
     return bool(lib.aide_conv3x3_wgrad_wino_supported(co, ci, h, w))
 
 
-def conv3x3_wgrad_wino(dz, a, dw, ws=None):
+def conv3x3_wgrad_wino(dz, a, dw, ws=None, queue=None):
     dp, dbs = planes(dz)
     ap, abs_ = planes(a)
     n, co, h, w = dz.shape
@@ -583,7 +622,7 @@ def conv3x3_wgrad_wino(dz, a, dw, ws=None):
     if ws is None:
         ws = torch.empty(lib.aide_conv3x3_wgrad_wino_ws_bytes(n, co, ci, h, w) // 4, device=dz.device,
                          dtype=torch.float32)
-    check(lib.aide_conv3x3_wgrad_wino(dp, dbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), stream_ptr()),
+    check(lib.aide_conv3x3_wgrad_wino(dp, dbs, ap, abs_, ptr(dw), n, co, ci, h, w, ptr(ws), _qh(queue), stream_ptr()),
           'conv3x3_wgrad_wino')
     return dw
 

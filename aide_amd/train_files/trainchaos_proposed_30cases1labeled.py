@@ -46,11 +46,11 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
-# A-B switch.  The two networks of a step are independent until the cross-scored loss: network 2's forwards (the stacked
+# The two networks of a step are independent until the cross-scored loss: network 2's forwards (the stacked
 # augmentation pass, its reverse augmentation and pseudo labels, the training forward) and its backward run on a second
 # stream, so that the HBM-bound passes of one network (BatchNorm, pooling, up-sampling, reverse augmentation) overlap the
 # matrix-bound convolutions of the other and the launch gaps of one chain are filled by the other.
-TWO_NET_STREAMS = [os.environ.get('AIDE_COTEACH_STREAMS', '1') != '0']
+TWO_NET_STREAMS = [True]
 _NET2_STREAM = {}
 
 

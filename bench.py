@@ -64,23 +64,32 @@ def parse():
     ap.add_argument('--traffic-timeout', type=int, default=150)
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--allow-probes', action='store_true',
-                    help='run although AIDE_PROBE_* timing probes are set; the line is then marked INVALID (A-B tooling only)')
+                    help='run although AIDE_HIP_LIB selects another library build; the line is then marked INVALID (A-B tooling only)')
     return ap.parse_args()
 
 
+KNOWN_SWITCHES = ('AIDE_HIP_LIB', 'AIDE_DIST_BACKEND', 'AIDE_PICK_STREAMS', 'AIDE_REPLAY', 'AIDE_DIRECT_GRADS')
+
+
 def switches():
-    """every AIDE_* switch active in this process' environment (echoed in the line) and the probe switches among them.
-    AIDE_PROBE_* builds / runs skip work or use stale data: a bench line produced under one is not a measurement."""
+    """every AIDE_* variable in this process' environment (echoed in the line) and the ones that make the run something
+    other than the shipped product: AIDE_HIP_LIB selects another library build (tools/probes/mk_probe.py: ablation builds
+    skip work or compute wrong results).  The package reads exactly KNOWN_SWITCHES; anything else is a typo or a switch of
+    an older tree that would silently do nothing."""
     act = {k: v for k, v in sorted(os.environ.items()) if k.startswith('AIDE_')}
-    probes = sorted(k for k, v in act.items() if k.startswith('AIDE_PROBE_') and v not in ('', '0'))
-    return act, probes
+    unknown = sorted(k for k in act if k not in KNOWN_SWITCHES)
+    probes = sorted(k for k in act if k == 'AIDE_HIP_LIB' and act[k])
+    return act, probes, unknown
 
 
 def probe_guard(args):
-    act, probes = switches()
+    act, probes, unknown = switches()
+    if unknown:
+        raise SystemExit('bench.py: unknown switch(es) %s -- this tree reads only %s' % (', '.join(unknown), ', '.join(KNOWN_SWITCHES)))
     if probes and not args.allow_probes:
-        raise SystemExit('bench.py: refusing to run with timing probes set (%s): they skip work or use stale data, the '
-                         'line would not be a measurement (--allow-probes marks it INVALID instead)' % ', '.join(probes))
+        raise SystemExit('bench.py: refusing to run with %s set (a non-default library build: ablation builds skip work or '
+                         'compute wrong results, the line would not be a measurement; --allow-probes marks it INVALID instead)'
+                         % ', '.join(probes))
     return act, probes
 
 
@@ -378,7 +387,7 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img, act, probes)
                 final_loss=final, comm=comm_block(world, reducers, per_rank, args.steps), switches=act,
                 roofline=roof, kernels=kernels, cpu_baseline=cpu)
     if probes:
-        line['INVALID'] = 'timing probes active: %s' % ', '.join(probes)
+        line['INVALID'] = 'non-default library build: %s' % ', '.join(probes)
     print(json.dumps(line))
 
 
@@ -387,7 +396,7 @@ def self_launch(args):
     torch.distributed.run on 127.0.0.1 (what the driver does itself for N > 1).  The rank-0 child prints the JSON line."""
     import socket
     import subprocess
-    backend = os.environ.get('AIDE_DIST_BACKEND', os.environ.get('AIDE_BENCH_BACKEND', 'nccl'))
+    backend = os.environ.get('AIDE_DIST_BACKEND', 'nccl')
     ndev = torch.cuda.device_count()
     if backend == 'nccl' and ndev < args.gpus:
         raise SystemExit('bench.py: --gpus %d but only %d HIP device(s) visible (RCCL needs one device per rank; '
@@ -492,7 +501,7 @@ def main():
                     comm=comm_block(world, reducers, per_rank, args.steps), switches=act,
                     roofline=roof, kernels=kernels, cpu_baseline=cpu)
         if probes:
-            line['INVALID'] = 'timing probes active: %s' % ', '.join(probes)
+            line['INVALID'] = 'non-default library build: %s' % ', '.join(probes)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

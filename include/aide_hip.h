@@ -35,8 +35,11 @@ int aide_conv3x3_plan(int N, int Cin, int H, int W, int Cout);    /* variant | s
 size_t aide_conv3x3_ws_bytes(int N, int H, int W, int Cout, int splitk);
 int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, const float* bias,
                        float* y, int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate,
-                       int plan, float* ws, aide_stream_t stream);   /* forward and dgrad; any Cin, Cout, H, W
-                                                                        (partial channel tiles / chunks are masked) */
+                       int plan, float* ws, const float* epi_scale, int epi_relu,
+                       aide_stream_t stream);   /* forward and dgrad; any Cin, Cout, H, W (partial channel tiles / chunks are
+                                                   masked).  epi_scale != NULL (non-split, accumulate = 0, bias given): the
+                                                   epilogue writes y = relu?(acc * epi_scale[co] + bias[co]) -- eval-mode
+                                                   BatchNorm folded into the convolution (aide_bn_eval_fold) */
 /* Winograd F(2x2,3x3) variant of the same convolution (forward / dgrad) for even H, W % 4 == 0,
  * Cout % 64 == 0, Cin % 8 == 0.  Filters are pre-transformed (G g G^T), channel-blocked by 8:
  * uf [ci_pad/8][16][Co][8 ci], ud [co_pad/8][16][Ci][8 co] (the tensors are allocated as [pad][16][C]). */
@@ -52,9 +55,15 @@ int aide_conv3x3_wino4_supported(int Cin, int H, int W, int Cout);
 int aide_conv3x3_wino4_splitk(int N, int Cin, int H, int W, int Cout);
 int aide_conv3x3_wino4_pack_blocks(int Co, int Ci);
 int aide_conv3x3_wino4_pack_multi(const void* descs, int n, int64_t total_blocks, aide_stream_t stream);
+/* stats_parts (NULL, or parts[Cout][aide_conv3x3_wino4_stats_parts][2]; only a non-split launch with accumulate = 0 and
+ * W >= 32, AIDE_ERR_ARG otherwise): the epilogue also writes, per output channel and workgroup tile, the fp32 sum and sum
+ * of squares of its pre-bias outputs -- the BatchNorm statistics for aide_bn_train_fwd_parts (netblocks.py:25,27) without a
+ * pass over z.  epi_scale (NULL, or [Cout]; accumulate = 0 and bias given): y = relu?(acc * epi_scale[co] + bias[co]), the
+ * folded eval-mode BatchNorm of aide_bn_eval_fold (a split launch applies it in its slab reduce).  Both are plain
+ * arguments of THIS launch: the library keeps no state between calls. */
 int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float* bias, float* y, int64_t y_bs,
                        int N, int Cin, int H, int W, int Cout, int accumulate, int splitk, float* ws,
-                       aide_stream_t stream);
+                       float* stats_parts, const float* epi_scale, int epi_relu, aide_stream_t stream);
 /* descs as above with {w, uf, ud}; an entry occupies aide_conv3x3_wino_pack_blocks(Co, Ci) workgroups */
 int aide_conv3x3_wino_pack_blocks(int Co, int Ci);
 int aide_conv3x3_wino_pack_multi(const void* descs, int n, int64_t total_blocks, aide_stream_t stream);
@@ -63,9 +72,11 @@ int aide_conv3x3_wino(const float* x, int64_t x_bs, const float* u, const float*
                       float* ws, aide_stream_t stream);
 int aide_conv3x3_wgrad_splits(int N, int Co, int Ci, int H, int W);
 size_t aide_conv3x3_wgrad_ws_bytes(int N, int Co, int Ci, int H, int W);
+/* every weight-gradient entry point: `queue` = NULL (the slab reduce into dw is launched behind the kernel) or a
+ * caller-owned aide_wgrad_queue_* handle (the reduce is queued for the caller's batched launch; see below) */
 int aide_conv3x3_wgrad(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs,
                        float* dw /*[Co][Ci][3][3]*/, int N, int Co, int Ci, int H, int W, float* ws,
-                       aide_stream_t stream);
+                       void* queue, aide_stream_t stream);
 
 /* Winograd form of the weight gradient (16 instead of 36 MFMA-multiplies per tile, co, ci);
  * even H, W % 4 == 0, Co >= 64, Ci >= 64.  Same outputs as aide_conv3x3_wgrad. */
@@ -73,7 +84,7 @@ int aide_conv3x3_wgrad_wino_supported(int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_wino_splits(int N, int Co, int Ci, int H, int W);
 size_t aide_conv3x3_wgrad_wino_ws_bytes(int N, int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_wino(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
-                            int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
+                            int Co, int Ci, int H, int W, float* ws, void* queue, aide_stream_t stream);
 /* stem layers (Ci <= 3; H % 4 == 0, W % 64 == 0): the nine taps folded into the GEMM's N dimension, bound by reading dz once.
  * dz fp32 or bf16-stored (dz_bf16), x fp32; round_bf16: operands rounded to bf16 when staged (the bf16 mode's contract);
  * ws / splits as for aide_conv3x3_wgrad / aide_conv3x3_wgrad_bf16 (which dispatch here themselves).
@@ -82,20 +93,21 @@ int aide_conv3x3_wgrad_stem_supported(int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_stem_splits(int N, int H, int W);
 int aide_conv3x3_wgrad_stem(const void* dz, int dz_bf16, int64_t dz_bs, const float* x, int64_t x_bs, float* dw,
                             int N, int Co, int Ci, int H, int W, float* ws, int splits, int round_bf16,
-                            aide_stream_t stream);
+                            void* queue, aide_stream_t stream);
 /* transposed F(4x4,3x3) for the large layers: H % 4 == 0, W % 4 == 0, H >= 8, W >= 16, Co % 32 == 0 (a trailing half tile of 32
  * is computed and dropped), Ci % 32 == 0 */
 int aide_conv3x3_wgrad_wino4_supported(int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_wino4_splits(int N, int Co, int Ci, int H, int W);
 size_t aide_conv3x3_wgrad_wino4_ws_bytes(int N, int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
-                             int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
+                             int Co, int Ci, int H, int W, float* ws, void* queue, aide_stream_t stream);
 /* the same with the workgroup count of the launch as an argument (target_wgs <= 0: the default, half of the chip --
  * the kernel normally shares it with the dependent chain of the backward pass; 256 for a launch that has the chip alone) */
 int aide_conv3x3_wgrad_wino4_splits_t(int N, int Co, int Ci, int H, int W, int target_wgs);
 size_t aide_conv3x3_wgrad_wino4_ws_bytes_t(int N, int Co, int Ci, int H, int W, int target_wgs);
 int aide_conv3x3_wgrad_wino4_t(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
-                               int Co, int Ci, int H, int W, float* ws, int target_wgs, aide_stream_t stream);
+                               int Co, int Ci, int H, int W, float* ws, int target_wgs, void* queue,
+                               aide_stream_t stream);
 
 /* ---- bf16-MFMA mode of the same convolution (BASELINE config 5: "FuseUNet bf16 MFMA path") -------------------
  * replaces the same nn.Conv2d call sites (netblocks.py:17,24,26; UNet.py:12,19,21) when the engine runs with
@@ -119,12 +131,15 @@ int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint1
                             int y_bf16, int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,
                             float* ws, aide_stream_t stream);
 int aide_conv3x3_wgrad_bf16_supported(int Co, int Ci, int H, int W);
-int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W);
-size_t aide_conv3x3_wgrad_bf16_ws_bytes(int N, int Co, int Ci, int H, int W);
+/* co_blocks: output-channel blocks of 32 per workgroup tile -- 2 (64 co x 64 ci, 4 waves), 4 (128 co x 64 ci, 8 waves; needs
+ * Co % 128 == 0, else 2 is used) or 0 = the built-in rule (4 from 150 GFLOP per launch); the split count depends on it */
+int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W, int co_blocks);
+size_t aide_conv3x3_wgrad_bf16_ws_bytes(int N, int Co, int Ci, int H, int W, int co_blocks);
 int aide_conv3x3_wgrad_bf16(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
                             int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
 int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, const void* a, int a_bf16, int64_t a_bs,
-                                  float* dw, int N, int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
+                                  float* dw, int N, int Co, int Ci, int H, int W, float* ws, int co_blocks, void* queue,
+                                  aide_stream_t stream);
 
 /* ---- ConvTranspose2d(k=2, s=2) (learned_bilinear=True up path) ---------------------------------
  * replaces nn.ConvTranspose2d: netblocks.py:12, UNet.py:7 */
@@ -150,15 +165,13 @@ int aide_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, int
                        const float* scale, const float* shift, int relu, aide_stream_t stream);
 /* Eval-mode BatchNorm folded into the convolution before it (the per-case inference loop,
  * trainchaos_comparison_1case.py:233-273: net.eval(), running statistics): aide_bn_eval_fold also writes
- * fbias = conv_bias * scale + shift; aide_conv_epilogue_affine(scale, relu) arms a one-shot epilogue for the NEXT
- * aide_conv3x3_wino4 or aide_conv3x3_igemm launch (accumulate = 0, bias = fbias): y = relu?(acc * scale[co] + bias[co]),
- * written straight into the activation -- no separate BatchNorm pass over the conv output (a split-K aide_conv3x3_wino4
- * launch applies it in its slab reduce; aide_conv3x3_igemm only non-split).  A launch that cannot honour an armed
- * epilogue returns AIDE_ERR_ARG. */
+ * fbias = conv_bias * scale + shift; an aide_conv3x3_wino4 or aide_conv3x3_igemm launch given epi_scale = scale,
+ * bias = fbias (accumulate = 0) writes y = relu?(acc * scale[co] + bias[co]) straight into the activation -- no separate
+ * BatchNorm pass over the conv output (a split-K aide_conv3x3_wino4 launch applies it in its slab reduce;
+ * aide_conv3x3_igemm only non-split).  A launch that cannot honour the epilogue returns AIDE_ERR_ARG. */
 int aide_bn_eval_fold(int C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, const float* conv_bias, float* scale, float* shift,
                       float* fbias, aide_stream_t stream);
-int aide_conv_epilogue_affine(const float* scale, int relu);
 int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs, float* dz,
                      int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                      const float* scale, const float* shift, int relu, float* dgamma, float* dbeta,
@@ -185,13 +198,11 @@ int aide_bn_train_fwd_slabs(const float* slabs, int splitk, int64_t split_stride
                             const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                             float* running_var, long long* num_batches_tracked, float* mean, float* rstd, float* scale,
                             float* shift, int relu, void* ws, aide_stream_t stream);
-/* BatchNorm statistics from the convolution's epilogue.  aide_conv_stats_sink(parts) arms a one-shot sink: the NEXT
- * forward conv launch of a family that supports it (non-split, accumulate = 0; today: aide_conv3x3_wino4) writes, per output
- * channel and workgroup tile, the fp32 sum and sum of squares of its pre-bias outputs to parts[Cout][nparts][2]
- * (nparts = aide_conv3x3_wino4_stats_parts) and disarms it; aide_bn_train_fwd_parts then normalises with ONE pass over z
- * (replaces the statistics pass of nn.BatchNorm2d in train mode, netblocks.py:25,27).  aide_bn_two_pass tells whether the
- * plain aide_bn_train_fwd would need two launches for this shape. */
-int aide_conv_stats_sink(float* parts);
+/* BatchNorm statistics from the convolution's epilogue: a forward aide_conv3x3_wino4 launch given stats_parts writes, per
+ * output channel and workgroup tile, the fp32 sum and sum of squares of its pre-bias outputs to parts[Cout][nparts][2]
+ * (nparts = aide_conv3x3_wino4_stats_parts); aide_bn_train_fwd_parts then normalises with ONE pass over z (replaces the
+ * statistics pass of nn.BatchNorm2d in train mode, netblocks.py:25,27).  aide_bn_two_pass tells whether the plain
+ * aide_bn_train_fwd would need two launches for this shape. */
 int aide_conv3x3_wino4_stats_parts(int N, int H, int W);
 int aide_bn_two_pass(int N, int C, int H, int W);
 int aide_bn_train_fwd_parts(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C, int H,
@@ -266,25 +277,20 @@ int aide_stream_order(void* ev, aide_stream_t from, aide_stream_t to);
 int aide_event_record(void* ev, aide_stream_t from);
 int aide_stream_wait_event(aide_stream_t to, void* ev);
 
-/* ---- CU-masked stream (host pointers) ---------------------------------------------------------------------------
- * A HIP stream restricted to the compute units whose bits are set in mask[words] (hipExtStreamCreateWithCUMask).  The
- * backward pass runs its weight-gradient kernels on one: the dependent chain on the main stream then always finds free
- * CUs, whatever the grid of the weight-gradient launch. */
-int aide_stream_create_cumask(void** stream, const void* mask, int words);
-
-/* ---- deferred slab reduce of the weight gradients ------------------------------------------------------------------
- * Every aide_conv3x3_wgrad* call leaves per-split partial results ("slabs") in its workspace and reduces them into dw
- * with a small launch.  Between aide_wgrad_reduce_defer(1) and aide_wgrad_reduce_flush(stream) those reduces are
- * collected instead (each call then needs a workspace region of its own that stays untouched until the flush) and run
- * as ONE launch over all layers (fixed summation order per element: deterministic, identical results).
- * aide_wgrad_reduce_defer returns the previous mode; aide_wgrad_reduce_flush reduces everything pending (<= 512 layers)
- * on `stream`, which must be ordered after the weight-gradient kernels. */
-int aide_wgrad_reduce_defer(int on);
-int aide_wgrad_reduce_pending(void);
-int aide_wgrad_reduce_flush(aide_stream_t stream);
-/* Error path: drop every pending descriptor (they point into a pass that did not finish) and leave the deferred mode.
- * Returns the number of descriptors dropped.  aide_wgrad_reduce_defer(1) drops stale descriptors as well. */
-int aide_wgrad_reduce_discard(void);
+/* ---- batched slab reduce of the weight gradients (host pointers) ---------------------------------------------------
+ * Every aide_conv3x3_wgrad* call leaves per-split partial results ("slabs") in its workspace; with queue = NULL it reduces
+ * them into dw with a small launch of its own.  Given a caller-owned queue (aide_wgrad_queue_create) the reduce is only
+ * recorded there -- the call then needs a workspace region of its own that stays untouched until the flush -- and
+ * aide_wgrad_queue_flush(queue, stream) runs ONE launch over everything recorded (<= 512 layers; fixed summation order per
+ * element: deterministic, identical results) on `stream`, which must be ordered after the weight-gradient kernels.
+ * aide_wgrad_queue_pending: entries recorded and not yet flushed.  aide_wgrad_queue_discard: error path, drops them (they
+ * point into a pass that did not finish) and returns how many.  The queue is plain host memory owned by the caller: one
+ * per launch sequence (the engine keeps one per plan); the library has no global state besides the kernel timer. */
+int aide_wgrad_queue_create(void** queue);
+int aide_wgrad_queue_destroy(void* queue);
+int aide_wgrad_queue_pending(const void* queue);
+int aide_wgrad_queue_flush(void* queue, aide_stream_t stream);
+int aide_wgrad_queue_discard(void* queue);
 
 /* ---- kernel timer (measurement only; bench.py `roofline`) --------------------------------------------------------
  * While armed for a family, every launch of that family's MAIN kernel carries a start / stop HIP event pair on its own

@@ -202,24 +202,52 @@ def test_per_image_operand_limit():
         net.engine.plan_for((x, x))
 
 
-def test_bench_probe_guard_needs_no_gpu():
-    """bench.py refuses AIDE_PROBE_* switches before it touches a device (a probe run is not a measurement)"""
+def test_bench_switch_guard_needs_no_gpu():
+    """bench.py refuses unknown AIDE_* switches and non-default library builds before it touches a device"""
     import subprocess
     import sys
-    env = dict(os.environ, AIDE_PROBE_SKIP_WGRAD='1')
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1'], env=env, capture_output=True,
-                       text=True, timeout=300)
-    assert r.returncode != 0 and 'AIDE_PROBE_SKIP_WGRAD' in r.stderr and not r.stdout.strip()
+    for extra, word in ((dict(AIDE_PROBE_SKIP_WGRAD='1'), 'AIDE_PROBE_SKIP_WGRAD'), (dict(AIDE_HIP_LIB='/tmp/x.so'), 'AIDE_HIP_LIB')):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1'], env=env, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode != 0 and word in r.stderr and not r.stdout.strip()
 
 
-def test_wgrad_reduce_discard_and_event_destroy_exported(built):
-    """the error-path entry points of the deferred slab reduce (no launches: host state only)"""
+def test_runtime_switch_inventory():
+    """the package reads exactly the environment switches bench.py knows (<= 12 runtime switches)"""
+    import re
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    found = set()
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'aide_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                found |= set(re.findall(r"environ(?:\.get)?\(\s*['\"](AIDE_\w+)", src))
+                found |= set(re.findall(r"environ\[\s*['\"](AIDE_\w+)", src))
+                found |= set(re.findall(r'getenv\(\s*"(AIDE_\w+)"', src))
+                assert 'AIDE_PROBE_' not in src or f.endswith('.py'), 'probe macro in shipped source %s' % f
+    assert found <= set(bench.KNOWN_SWITCHES), sorted(found - set(bench.KNOWN_SWITCHES))
+    assert len(bench.KNOWN_SWITCHES) <= 12
+
+
+def test_wgrad_queue_is_caller_owned_host_state(built):
+    """the batched slab reduce works on a caller-owned queue handle (no launches here: host state only); the library has
+    no deferred-mode global any more"""
+    import ctypes
     from aide_amd._lib import lib
     dll = lib.load()
-    assert dll.aide_wgrad_reduce_defer(1) == 0
-    assert dll.aide_wgrad_reduce_pending() == 0
-    assert dll.aide_wgrad_reduce_discard() == 0          # nothing pending; leaves the deferred mode
-    assert dll.aide_wgrad_reduce_defer(0) == 0           # ... so the previous mode reads 0
+    q1, q2 = ctypes.c_void_p(), ctypes.c_void_p()
+    assert dll.aide_wgrad_queue_create(ctypes.byref(q1)) == 0 and q1.value
+    assert dll.aide_wgrad_queue_create(ctypes.byref(q2)) == 0 and q2.value and q2.value != q1.value
+    assert dll.aide_wgrad_queue_pending(q1) == 0 and dll.aide_wgrad_queue_pending(q2) == 0
+    assert dll.aide_wgrad_queue_discard(q1) == 0          # nothing pending
+    assert dll.aide_wgrad_queue_flush(q1, None) == 0      # an empty flush launches nothing
+    assert dll.aide_wgrad_queue_pending(None) < 0 and dll.aide_wgrad_queue_flush(None, None) < 0
+    assert dll.aide_wgrad_queue_destroy(q1) == 0 and dll.aide_wgrad_queue_destroy(q2) == 0
+    for gone in ('aide_wgrad_reduce_defer', 'aide_conv_stats_sink', 'aide_conv_epilogue_affine', 'aide_stream_create_cumask'):
+        assert not hasattr(dll, gone), '%s is still exported' % gone
 
 
 def test_keep_largest_connected_components():

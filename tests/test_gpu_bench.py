@@ -18,7 +18,7 @@ BENCH = os.path.join(ROOT, 'bench.py')
 
 def _run(extra, env=None, timeout=600):
     e = dict(os.environ)
-    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'AIDE_DIST_BACKEND', 'AIDE_BENCH_BACKEND'):
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'AIDE_DIST_BACKEND'):
         e.pop(k, None)
     e.update(env or {})
     return subprocess.run([sys.executable, BENCH] + extra, env=e, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
@@ -100,13 +100,17 @@ def test_bench_two_ranks(dev, workload):
     assert j['roofline'] is not None and j['roofline']['dropped_launches'] == 0
 
 
-def test_bench_refuses_probe_switches(dev):
-    r = _run(['--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--traffic', 'none'], env={'AIDE_PROBE_NO_OPTIM': '1'})
-    assert r.returncode != 0 and 'AIDE_PROBE_NO_OPTIM' in (r.stderr + r.stdout)
+def test_bench_refuses_probe_builds_and_unknown_switches(dev):
+    from aide_amd._lib import LIB_PATH
+    base = ['--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--traffic', 'none']
+    r = _run(base, env={'AIDE_DUAL_FWD': '1'})                  # a switch of an older tree: refused, not silently ignored
+    assert r.returncode != 0 and 'AIDE_DUAL_FWD' in (r.stderr + r.stdout)
+    r = _run(base, env={'AIDE_HIP_LIB': LIB_PATH})              # another library build: not a measurement of the product
+    assert r.returncode != 0 and 'AIDE_HIP_LIB' in (r.stderr + r.stdout)
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     r = _run(['--workload', 'tiny', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--traffic', 'none',
-              '--allow-probes'], env={'AIDE_PROBE_NO_OPTIM': '1', 'AIDE_DUAL_FWD': '1'})
+              '--allow-probes'], env={'AIDE_HIP_LIB': LIB_PATH, 'AIDE_REPLAY': '1'})
     assert r.returncode == 0, r.stderr[-2000:]
     j = _line(r)
-    assert 'AIDE_PROBE_NO_OPTIM' in j['INVALID']
-    assert j['switches'].get('AIDE_DUAL_FWD') == '1' and j['switches'].get('AIDE_PROBE_NO_OPTIM') == '1'
+    assert 'AIDE_HIP_LIB' in j['INVALID']
+    assert j['switches'].get('AIDE_REPLAY') == '1' and j['switches'].get('AIDE_HIP_LIB') == LIB_PATH

@@ -318,25 +318,23 @@ WGRAD_CASES = [
 
 
 @pytest.mark.parametrize('case', [(2, 256, 256, 32, 32), (1, 128, 64, 32, 96), (1, 128, 40, 8, 32)])
-def test_conv3x3_wgrad_bf16_wide_tile(dev, case, monkeypatch):
-    """the 128 co x 64 ci (8-wave) weight-gradient kernel, normally reserved for >= 150 GFLOP layers"""
-    monkeypatch.setenv('AIDE_BF16_WG_NWCO_MINFLOPS', '0')
-    test_conv3x3_wgrad_bf16(dev, case)
+def test_conv3x3_wgrad_bf16_wide_tile(dev, case):
+    """the 128 co x 64 ci (8-wave) weight-gradient kernel, normally reserved for >= 150 GFLOP layers (co_blocks = 4)"""
+    test_conv3x3_wgrad_bf16(dev, case, co_blocks=4)
     from aide_amd import ops
     n, co, ci, h, w = case
     g = torch.Generator().manual_seed(1)
     x16 = torch.randn(n, ci - ci % 8, h, w, generator=g).to(dev).bfloat16()
     dz16 = torch.randn(n, co, h, w, generator=g).to(dev).bfloat16()
     dw_wide = torch.empty(co, x16.shape[1], 3, 3, device=dev)
-    ops.conv3x3_wgrad_bf16(dz16, x16, dw_wide)                       # bf16-stored operands through the wide tile
-    monkeypatch.setenv('AIDE_BF16_WG_NWCO_MINFLOPS', '1e30')
+    ops.conv3x3_wgrad_bf16(dz16, x16, dw_wide, co_blocks=4)          # bf16-stored operands through the wide tile
     dw_ref = torch.empty_like(dw_wide)
-    ops.conv3x3_wgrad_bf16(dz16, x16, dw_ref)
+    ops.conv3x3_wgrad_bf16(dz16, x16, dw_ref, co_blocks=2)
     _close(dw_wide, dw_ref, 2e-5, 'wide vs 64x64 tile %s' % (case,))
 
 
 @pytest.mark.parametrize('case', WGRAD_CASES)
-def test_conv3x3_wgrad_bf16(dev, case):
+def test_conv3x3_wgrad_bf16(dev, case, co_blocks=0):
     from aide_amd import ops
     n, co, ci, h, w = case
     assert ops.wgrad_bf16_supported(co, ci, h, w)
@@ -351,11 +349,11 @@ def test_conv3x3_wgrad_bf16(dev, case):
     dw_exact = wgrad_ref(_rb(x), _rb(dy))
     dw_fp32 = wgrad_ref(x, dy)
     dw = torch.full((co, ci, 3, 3), float('nan'), device=dev)
-    ops.conv3x3_wgrad_bf16(dy.to(dev), x.to(dev), dw)
+    ops.conv3x3_wgrad_bf16(dy.to(dev), x.to(dev), dw, co_blocks=co_blocks)
     _close(dw, dw_exact, 5e-5, 'wgrad exact %s' % (case,))
     _close(dw, dw_fp32, 1e-2, 'wgrad vs fp32 %s' % (case,))
     dw2 = torch.empty_like(dw)
-    ops.conv3x3_wgrad_bf16(dy.to(dev), x.to(dev), dw2)
+    ops.conv3x3_wgrad_bf16(dy.to(dev), x.to(dev), dw2, co_blocks=co_blocks)
     assert torch.equal(dw, dw2), 'wgrad must be bit-reproducible'
     if ci <= 3:            # the stem layers read a bf16-STORED dz next to the fp32 image
         dw3 = torch.empty_like(dw)

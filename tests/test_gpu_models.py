@@ -394,7 +394,8 @@ def test_engine_assigned_gradients_keep_torch_contracts(dev):
 
 
 def test_two_lane_schedules_are_bit_identical(dev):
-    """The second encoder's chains on their own stream (forward: default on; backward: AIDE_DUAL_BWD) must give the single-lane
+    """The second encoder's chains on their own stream in the forward pass (engine.DUAL_FWD / FREE_LANE) and the last weight
+    gradient on the main stream (engine.TAIL_WGRAD_MAIN) must give the single-lane
     results bit for bit -- same kernels, own workspaces -- over several steps (also a race detector for the lane's
     BatchNorm / split-K workspaces and the fork / join points), with and without launch tapes' replays."""
     from aide_amd import engine, utils as U
@@ -403,20 +404,14 @@ def test_two_lane_schedules_are_bit_identical(dev):
     xs = [torch.randn(4, 3, 128, 128, generator=g).to(dev) for _ in range(2)]
     t = (torch.rand(4, 128, 128, generator=g) > 0.8).long().to(dev)
     w = torch.tensor([1.0, 1.0])
-    saved = (engine.DUAL_FWD[0], engine.DUAL_BWD[0], engine.FREE_LANE[0], engine.DUAL_BWD_MAXLEVEL[0], engine.EARLY_FLUSH[0],
-             engine.TAIL_WGRAD_MAIN[0])
+    saved = (engine.DUAL_FWD[0], engine.FREE_LANE[0], engine.TAIL_WGRAD_MAIN[0])
     results = []
     try:
         # (free: lane 1 pools its own channels and runs from level to level without a fork / join per level)
-        # (maxlev: the backward lanes only for the ops of levels <= maxlev; early: the queued slab reduces behind the last
-        # Winograd weight gradient instead of behind the last kernel)
         # tailm: the last op's weight gradient on the main stream instead of behind the weight-gradient stream's backlog
-        for fwd, bwd, free, maxlev, early, tailm in (
-                (False, False, False, 9, False, False), (True, False, False, 9, True, True), (True, False, True, 9, True, False),
-                (True, True, True, 9, True, True), (True, True, False, 0, False, False), (True, True, True, 0, True, True),
-                (True, False, True, 9, False, True)):
-            engine.DUAL_FWD[0], engine.DUAL_BWD[0], engine.FREE_LANE[0] = fwd, bwd, free
-            engine.DUAL_BWD_MAXLEVEL[0], engine.EARLY_FLUSH[0], engine.TAIL_WGRAD_MAIN[0] = maxlev, early, tailm
+        for fwd, free, tailm in ((False, False, False), (True, False, True), (True, True, False), (True, True, True),
+                                 (True, False, False)):
+            engine.DUAL_FWD[0], engine.FREE_LANE[0], engine.TAIL_WGRAD_MAIN[0] = fwd, free, tailm
             for plan in net.engine.plans.values():
                 plan._tape_f = plan._tape_b = None           # the recorded launch sequence bakes the schedule in
             outs = []
@@ -428,8 +423,7 @@ def test_two_lane_schedules_are_bit_identical(dev):
             results.append(outs[-1])
             torch.cuda.synchronize()
     finally:
-        (engine.DUAL_FWD[0], engine.DUAL_BWD[0], engine.FREE_LANE[0], engine.DUAL_BWD_MAXLEVEL[0],
-         engine.EARLY_FLUSH[0], engine.TAIL_WGRAD_MAIN[0]) = saved
+        engine.DUAL_FWD[0], engine.FREE_LANE[0], engine.TAIL_WGRAD_MAIN[0] = saved
     for other in results[1:]:
         for a, b in zip(results[0], other):
             assert torch.equal(a, b)
@@ -506,7 +500,7 @@ def test_eval_fold_tracks_parameters_and_statistics(dev):
     from aide_amd import engine, utils as U
     from aide_amd.optim import Adam
     if not engine.FOLD_EVAL_BN[0]:
-        pytest.skip('AIDE_FOLD_EVAL_BN=0: the folded epilogue is switched off')
+        pytest.skip('engine.FOLD_EVAL_BN is off: the folded epilogue is switched off')
     net, ref = build_pair('fuseunet', False, dev)
     g = torch.Generator().manual_seed(21)
     xs = [torch.randn(4, 3, 128, 128, generator=g) for _ in range(2)]

@@ -77,8 +77,8 @@ def test_proposed_coteaching_step(dev):
 
 
 def test_coteaching_two_streams_is_bit_identical(dev):
-    """Network 2 on its own stream (AIDE_COTEACH_STREAMS, the default) and packed filters shared between a network's plans
-    (AIDE_SHARED_PACKS, the default) are schedules, not different computations: three steps from the same initial state give
+    """Network 2 on its own stream (TWO_NET_STREAMS, the default) and packed filters shared between a network's plans
+    (engine.SHARED_PACKS, the default) are schedules, not different computations: three steps from the same initial state give
     bit-identical losses, selections and parameters of BOTH networks as the single-stream order with private packs -- any
     missing cross-stream dependency (inputs, optimizer update, engine-assigned gradients) or a stale shared pack would show
     here."""
@@ -163,14 +163,14 @@ def test_rccl_gradient_allreduce_single_rank(dev):
     import os
     import torch.distributed as dist
     from aide_amd import utils as U
-    from aide_amd.distributed import GradAllReduce, broadcast_module, nccl_options
+    from aide_amd.distributed import GradAllReduce, broadcast_module
     from aide_amd.models_twomodalinputs import fuseunet
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
     # (as init_from_env does it)
     from aide_amd import streams
     streams.reserve_queue(dev)
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, pg_options=nccl_options())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     try:
         torch.manual_seed(2)
         net = fuseunet(2).to(dev)
@@ -201,13 +201,13 @@ def test_gradient_allreduce_survives_plan_eviction(dev):
     import os
     import torch.distributed as dist
     from aide_amd import utils as U
-    from aide_amd.distributed import GradAllReduce, nccl_options
+    from aide_amd.distributed import GradAllReduce
     from aide_amd.models_twomodalinputs import fuseunet
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
     from aide_amd import streams
     streams.reserve_queue(dev)
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, pg_options=nccl_options())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     try:
         torch.manual_seed(2)
         net = fuseunet(2).to(dev)
@@ -270,7 +270,7 @@ def test_rank_streams_avoid_shared_hardware_queues(dev):
     import os
     import torch.distributed as dist
     from aide_amd import utils as U, streams
-    from aide_amd.distributed import GradAllReduce, broadcast_module, nccl_options
+    from aide_amd.distributed import GradAllReduce, broadcast_module
     from aide_amd.models_twomodalinputs import fuseunet
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29534')
@@ -286,7 +286,7 @@ def test_rank_streams_avoid_shared_hardware_queues(dev):
     saved = dict(streams.PREFERRED)
     streams.PREFERRED.clear()
     streams.reserve_queue(dev)
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, pg_options=nccl_options())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     try:
         torch.manual_seed(2)
         net = fuseunet(2).to(dev)

@@ -66,10 +66,10 @@ def main():
         else:
             row += '  %12s' % '-'
         if ops.wgrad_bf16_supported(co, ci, h, w):
-            ws = torch.empty(lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, co, ci, h, w) // 4, device=dev)
+            ws = torch.empty(lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, co, ci, h, w, 0) // 4, device=dev)
             t = timeit(lambda: ops.conv3x3_wgrad_bf16(dy, x, dw, ws=ws), reps)
             tot['wgrad'][0] += t; tot['wgrad'][1] += flops
-            row += '  %6.3f %5.0f (splits %d)' % (t, flops / t * 1e-9, lib.aide_conv3x3_wgrad_bf16_splits(n, co, ci, h, w))
+            row += '  %6.3f %5.0f (splits %d)' % (t, flops / t * 1e-9, lib.aide_conv3x3_wgrad_bf16_splits(n, co, ci, h, w, 0))
         print(row, flush=True)
         del x, dy, y, dx, wsf
     for k, (t, f) in tot.items():

@@ -1,7 +1,7 @@
 """What the data-parallel plumbing costs a rank's own step: the C2 step on ONE GPU with the bucketed gradient all-reduce
 installed on a single-rank RCCL group (the collectives are local, but the bucket hooks, the communication streams and RCCL's
 kernels are all there -- and so is the mapping of six streams onto the runtime's hardware queues).
-usage (GPU box): [AIDE_RCCL_HIGH_PRIORITY=0|1] python tools/bench_comm1.py [none|rccl] [workload] [steps]"""
+usage (GPU box): python tools/bench_comm1.py [none|rccl] [workload] [steps]"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,7 @@ import bench as B
 from aide_amd import utils as U
 from aide_amd.optim import Adam
 from aide_amd.synthetic import chaos_batch
-from aide_amd.distributed import GradAllReduce, broadcast_module, nccl_options, HIGH_PRIORITY
+from aide_amd.distributed import GradAllReduce, broadcast_module
 
 mode = sys.argv[1] if len(sys.argv) > 1 else 'rccl'
 wl = sys.argv[2] if len(sys.argv) > 2 else 'c2'
@@ -24,7 +24,7 @@ if mode == 'rccl':
         from aide_amd import streams
         streams.reserve_queue(dev)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29541')
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, pg_options=nccl_options())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 net = B.build(model, dev); net.train()
 net.engine.precision = B.WORKLOAD_PRECISION.get(wl, 'fp32')
 if mode == 'rccl':
@@ -42,7 +42,7 @@ for _ in range(5): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-print(json.dumps(dict(mode=mode, workload=wl, high_priority=bool(HIGH_PRIORITY[0]) if red else None,
+print(json.dumps(dict(mode=mode, workload=wl, 
                       images_per_s=round(batch / dt, 2), ms_per_step=round(dt * 1e3, 3),
                       exposed_ms=round(red.exposed_ms(), 4) if red else None,
                       buckets=red.describe()['buckets'] if red else None,

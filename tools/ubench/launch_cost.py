@@ -7,7 +7,7 @@ x = torch.zeros(1, 1, 4, 4, device='cuda')
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = ctypes.c_void_p(x.data_ptr())
 args = [p, ctypes.c_int64(16), ctypes.c_int(1), ctypes.c_int(1), ctypes.c_int(4), ctypes.c_int(4), s]
-f0 = dll.aide_wgrad_reduce_pending
+f0 = lambda: dll.aide_wgrad_queue_pending(None)
 f1 = dll.aide_fill_zero
 for f, a, name in ((f0, [], 'ctypes call, no launch'), (f1, args, 'ctypes call + 1 launch (fill_zero)')):
     for _ in range(200): f(*a)
