@@ -441,12 +441,12 @@ int aide_conv3x3_wgrad_wino4_t(const float* dz, int64_t dz_bs, const float* a, i
                                int Co, int Ci, int H, int W, float* ws, int target_wgs, void* queue, hipStream_t stream) {
     if (!dz || !a || !dw || !ws || N <= 0 || !aide_conv3x3_wgrad_wino4_supported(Co, Ci, H, W) || dz_bs % 4 || a_bs % 4)
         return AIDE_ERR_ARG;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const bool attr_set = [] {        // once per process, thread-safe (a function-local constant, not mutable state)
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   G4_LDS * (int)sizeof(float));
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     G4Args g;
     g.dz = dz; g.a = a; g.slabs = ws; g.dz_bs = dz_bs; g.a_bs = a_bs;
     g.N = N; g.Co = Co; g.Ci = Ci; g.H = H; g.W = W;

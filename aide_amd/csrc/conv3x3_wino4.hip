@@ -654,8 +654,7 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
     const int aff_relu = aff ? epi_relu : 0;
     if (!x || !u || !y || !aide_conv3x3_wino4_supported(Cin, H, W, Cout) || x_bs % 4 || y_bs % 4 || (W == 16 && N % 2))
         return AIDE_ERR_ARG;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const bool attr_set = [] {        // once per process, thread-safe (a function-local constant, not mutable state)
         hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             F4_LDS * (int)sizeof(float));
         hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -666,8 +665,9 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
                                   F4_LDS * (int)sizeof(float));
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   F4_LDS * (int)sizeof(float));
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     W4Args a;
     if (stats_parts && !(splitk <= 1 && accumulate == 0 && W >= 32)) return AIDE_ERR_ARG;   // only a launch that writes final outputs
     a.stats = stats_parts;

@@ -62,7 +62,10 @@ def parse():
                     help="roofline.traffic: 'live' = two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, separately, "
                          "--kernel-trace only) of this workload run as sub-processes after the timed region (rank 0, N=1)")
     ap.add_argument('--traffic-timeout', type=int, default=150)
-    ap.add_argument('--cpu-threads', type=int, default=32)
+    ap.add_argument('--cpu-threads', type=int, default=16,
+                    help='torch threads of the cpu_baseline leg: the fastest count of the sweep over 8 .. 256 threads on the '
+                         '256-thread host of the GPU box (tools/cpu_thread_sweep.py, profiles/r04_cpu_threads_c2.txt: 16 -> 2.46 '
+                         'images/s, 32 -> 2.02, 64 -> 1.10, 128 -> 0.63, 256 -> 125 s per step)')
     ap.add_argument('--allow-probes', action='store_true',
                     help='run although AIDE_HIP_LIB selects another library build; the line is then marked INVALID (A-B tooling only)')
     return ap.parse_args()
@@ -131,10 +134,30 @@ def timed_steps(step, args, world, device, timer, ev_steps):
     return elapsed, t_local, per_rank, out
 
 
-def comm_block(world, reducers, per_rank, steps):
-    """N > 1: what was exchanged and what of it the step had to wait for."""
+def replica_check(nets, reducers, world, device):
+    """N > 1, after the timed region (collectives on every rank): do all ranks hold the same bucket plan, and are the
+    replicas still bit-identical after the optimizer steps?  (exact: the parameters' bit patterns summed as integers)"""
     if world == 1:
-        return dict(backend=None, ranks=1)
+        return {}
+    plans = [tuple((s, e, tuple(i)) for s, e, i in r.sched.buckets) for r in reducers]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, plans)
+    sums = []
+    for net in nets:
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).view(torch.int32)
+        sums.append(flat.to(torch.int64).sum())
+    mine = torch.stack(sums).to(device)
+    allr = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    return dict(bucket_plan_identical=all(g == gathered[0] for g in gathered),
+                replicas_identical=all(bool(torch.equal(a, allr[0])) for a in allr))
+
+
+def comm_block(world, reducers, per_rank, steps, check=None):
+    """N > 1: what was exchanged and what of it the step had to wait for."""
+    from aide_amd.distributed import comm_environment
+    if world == 1:
+        return dict(backend=None, ranks=1, env=comm_environment())
     desc = [r.describe() for r in reducers]
     exposed = [r.exposed_ms() for r in reducers]
     try:
@@ -144,7 +167,7 @@ def comm_block(world, reducers, per_rank, steps):
     ms = [t / steps * 1e3 for t in per_rank]
     return dict(backend=dist.get_backend(), ranks=world, rccl_version=ver,
                 buckets=sum(d['buckets'] for d in desc), bytes_per_step=sum(d['bytes_per_step'] for d in desc),
-                high_priority_streams=all(d.get('high_priority') for d in desc),
+                env=comm_environment(), **(check or {}),
                 hw_queues=next((d['hw_queues'] for d in desc if d.get('hw_queues')), None),
                 exposed_ms=(round(sum(e for e in exposed if e is not None), 4)
                             if any(e is not None for e in exposed) else None),
@@ -173,12 +196,13 @@ def roofline_block(timer, ev_steps, steps, peak, args, precision, batch, world):
         tnote = 'measured at N=1 only'
     roof = dict(bound='mfma', kernel=dom[0], achieved=round(a['tflops'], 2),
                 peak=peak, unit='TFLOP/s',
-                frac=round(a['tflops'] / peak, 4), traffic=traffic, traffic_source=tnote,
-                # `achieved` counts ALGORITHMIC (direct-convolution) flop per launch, as the contract defines it;
-                # a Winograd F(4x4) launch executes 36/144 of those multiplies (F(2x2): 16/36), so `achieved`
-                # may exceed the MFMA peak.  `executed` is what the MFMA pipe really sustains.
-                executed=round(a['executed_tflops'], 2),
+                # `achieved` / `frac` count ALGORITHMIC (direct-convolution) flop per launch, as the contract defines it;
+                # a Winograd F(4x4) launch executes 36/144 of those multiplies (F(2x2): 16/36), so `frac` may exceed 1.
+                # `executed` / `executed_frac` is what the MFMA pipe really sustains: the hardware-utilisation number.
+                frac=round(a['tflops'] / peak, 4),
                 executed_frac=round(a['executed_tflops'] / peak, 4),
+                executed=round(a['executed_tflops'], 2),
+                traffic=traffic, traffic_source=tnote,
                 launches_per_step=round(a['launches'] / ev_steps, 2),
                 avg_launch_us=round(a['avg_ms'] * 1e3, 2),
                 alg_gflop_per_launch=round(a['flops'] / a['launches'] / 1e9, 3),
@@ -215,8 +239,9 @@ def build(model_name, device):
 
 def cpu_baseline(model_name, batch, size, steps, max_threads):
     """The oracle (plain aten, CPU) timed on the host cores on the SAME workload, bounded sample.
-    oneDNN stops scaling (and regresses badly) long before 256 threads on this shape, so the thread
-    count is capped; `cores` reports the threads actually used."""
+    oneDNN stops scaling (and regresses badly) long before 256 threads on this shape -- the sweep is in
+    profiles/r04_cpu_threads_c2.txt -- so the thread count is the fastest one measured; `cores` reports the
+    threads actually used, `host_cores` what the box has."""
     import oracle
     from aide_amd.synthetic import chaos_batch
     cores = min(os.cpu_count() or 1, max_threads)
@@ -365,6 +390,7 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img, act, probes)
     timer = None if args.no_kernel_events else DispatchTimer(capacity=1200 * ev_steps)
     el, _, per_rank, r = timed_steps(step, args, world, device, timer, ev_steps)
     final = [round(float(r['loss1']), 6), round(float(r['loss2']), 6)]
+    check = replica_check([n1, n2], reducers, world, device)
     if rank != 0:
         return
     value = batch * world * args.steps / el
@@ -383,8 +409,9 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img, act, probes)
                                      % (size, size, batch, precision),
                             global_batch=batch * world, parallelism='dp%d' % world, alg_gflop_per_image=gflop_img),
                 step_tflops=round(value * gflop_img / 1e3, 2),
-                step_mfma_frac=round(value * gflop_img / 1e3 / world / peak, 4),
-                final_loss=final, comm=comm_block(world, reducers, per_rank, args.steps), switches=act,
+                step_algorithmic_frac=round(value * gflop_img / 1e3 / world / peak, 4),
+                mfma_executed_frac=None if roof is None else roof['all_mfma_kernels']['executed_frac'],
+                final_loss=final, comm=comm_block(world, reducers, per_rank, args.steps, check), switches=act,
                 roofline=roof, kernels=kernels, cpu_baseline=cpu)
     if probes:
         line['INVALID'] = 'non-default library build: %s' % ', '.join(probes)
@@ -472,6 +499,7 @@ def main():
     timer = None if args.no_kernel_events else DispatchTimer(capacity=200 * ev_steps)
     elapsed, _, per_rank, loss = timed_steps(step, args, world, device, timer, ev_steps)
     final_loss = float(loss.item())
+    check = replica_check([net], reducers, world, device)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -495,10 +523,13 @@ def main():
                                             'bf16 conv operands / fp32 accumulate, fp32 BN+loss+Adam'),
                                 global_batch=batch * world, parallelism='dp%d' % world,
                                 alg_gflop_per_image=gflop_img),
+                    # algorithmic flop of the whole step / time / peak (> 1 is possible: Winograd executes 1/4 of them)
                     step_tflops=round(value * gflop_img / 1e3, 2),
-                    step_mfma_frac=round(value * gflop_img / 1e3 / world / peak, 4),
+                    step_algorithmic_frac=round(value * gflop_img / 1e3 / world / peak, 4),
+                    # executed multiplies of ALL MFMA conv dispatches / their summed dispatch time / peak: utilisation
+                    mfma_executed_frac=None if roof is None else roof['all_mfma_kernels']['executed_frac'],
                     final_loss=round(final_loss, 6),
-                    comm=comm_block(world, reducers, per_rank, args.steps), switches=act,
+                    comm=comm_block(world, reducers, per_rank, args.steps, check), switches=act,
                     roofline=roof, kernels=kernels, cpu_baseline=cpu)
         if probes:
             line['INVALID'] = 'non-default library build: %s' % ', '.join(probes)

@@ -48,6 +48,9 @@ def test_bench_line_and_dispatch_timer(dev):
     assert ks['conv3x3_wgrad4_kernel']['launches_per_step'] == 28
     assert ks['conv3x3_wino4_kernel']['launches_per_step'] == 38
     assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+    # the hardware-utilisation number sits at the top level next to the algorithmic one (Winograd: algorithmic may exceed 1)
+    assert j['mfma_executed_frac'] == roof['all_mfma_kernels']['executed_frac'] and 0 < j['mfma_executed_frac'] < 1
+    assert j['step_algorithmic_frac'] > j['mfma_executed_frac'] and list(roof).index('executed_frac') == list(roof).index('frac') + 1
     assert 20 < roof['avg_launch_us'] < 400
     # the dispatch times of all MFMA kernels of a step cannot exceed two streams' worth of the step
     assert roof['all_mfma_kernels']['sum_dispatch_ms_per_step'] < 2.0 * j['ms_per_step']
@@ -80,6 +83,35 @@ def _check_comm(j, world):
     rk = c['rank_ms_per_step']
     assert 0 < rk['min'] <= rk['max'] <= j['ms_per_step'] * 1.001
     assert isinstance(j['switches'], dict)
+    # checked on every rank after the timed region: one bucket plan, bit-identical replicas after the optimizer steps
+    assert c['bucket_plan_identical'] is True and c['replicas_identical'] is True
+    assert isinstance(c['env'], dict) and c['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
+
+
+@pytest.mark.parametrize('workload,steps', [('tiny', 3), ('c2', 2)])
+def test_bench_eight_ranks_rehearsal(dev, workload, steps):
+    """What can be rehearsed of the driver's N = 8 run on the hardware at hand: eight rank processes through the whole
+    bench flow (rank-0 broadcast, per-rank stream probe, bucketed reduces issued from the weight-gradient stream, barrier,
+    max-over-ranks timing, the line) -- over RCCL where eight devices are visible, else as a gloo dry run with all ranks
+    on the visible device(s).  Every rank must build the same bucket plan, the replicas must be bit-identical after the
+    optimizer steps, the spread of the per-rank step times is reported; the RCCL / runtime environment is recorded."""
+    eight = torch.cuda.device_count() >= 8
+    args = ['--gpus', '8', '--workload', workload, '--steps', str(steps), '--warmup', '1', '--event-steps', '1',
+            '--no-cpu-baseline', '--traffic', 'none']
+    env = {'GPU_MAX_HW_QUEUES': '4'}
+    if not eight:
+        env['AIDE_DIST_BACKEND'] = 'gloo'
+    r = _run(args, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r)
+    assert j['n_gpus'] == 8 and j['comm']['ranks'] == 8 and j['comm']['backend'] == ('nccl' if eight else 'gloo')
+    assert j['config']['parallelism'] == 'dp8' and j['config']['global_batch'] == 8 * (2 if workload == 'tiny' else 4)
+    c = j['comm']
+    assert c['ranks'] == 8 and c['buckets'] >= 1 and c['bucket_plan_identical'] is True and c['replicas_identical'] is True
+    assert c['env'].get('GPU_MAX_HW_QUEUES') == '4'
+    rk = c['rank_ms_per_step']
+    assert 0 < rk['min'] <= rk['max'] <= j['ms_per_step'] * 1.001
+    print('N=8 rehearsal %s: %.1f images/s, rank ms/step %.3f .. %.3f' % (workload, j['value'], rk['min'], rk['max']))
 
 
 @pytest.mark.parametrize('workload', ['c2', 'c3', 'c4', 'c5'])
