@@ -114,17 +114,20 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const ZT* __restrict__ z,
                                                        const SlabSrc sl) {
     __shared__ double sm[2 * 4];
     const int c = blockIdx.x % C, s = blockIdx.x / C;
+    // blockIdx.y: group of a stacked batch (aide_bn_train_fwd_groups; N = images per group, a plain launch has one group)
+    const int n0 = blockIdx.y * N;
+    partials += (long)blockIdx.y * C * splits * 2;
     const long total4 = (long)N * HW / V;
     const long per = (total4 + splits - 1) / splits;
     const long beg = s * per, end = min(beg + per, total4);
     const int hw4 = HW / V;
     double acc[2] = {0.0, 0.0};
-    const ZT* zc = z + (long)c * HW;
+    const ZT* zc = z + (long)n0 * z_bs + (long)c * HW;
 #pragma unroll 2
     for (PlaneCursor cur(beg, end, hw4); cur.left > 0; cur.next(hw4)) {
         float v[V];
         if constexpr (SLABS) {
-            slab_sum<V>(sl, (long)cur.n * sl.slab_bs + (long)c * HW + cur.p * V, c, v);
+            slab_sum<V>(sl, (long)(n0 + cur.n) * sl.slab_bs + (long)c * HW + cur.p * V, c, v);
             stv<V>(const_cast<ZT*>(zc) + (long)cur.n * z_bs + cur.p * V, v);
 #pragma unroll
             for (int k = 0; k < V; ++k) v[k] = as_stored(v[k], (const ZT*)nullptr);
@@ -163,41 +166,49 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(
     const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
     float* __restrict__ running_var, long long* __restrict__ nbt, float* __restrict__ mean_out,
     float* __restrict__ rstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out, int relu,
-    const float* __restrict__ fparts, int nparts, const float* __restrict__ cbias, int pstride) {
+    const float* __restrict__ fparts, int nparts, const float* __restrict__ cbias, int pstride, int ng, int groups) {
     __shared__ float coef[2];
     const int plane = blockIdx.y;                 // n*C + c
     const int n = plane / C, c = plane - n * C;
+    // Stacked batch (aide_bn_train_fwd_groups): `groups` runs of ng images, each normalised with ITS statistics (`count`
+    // = elements per channel of one group; partials [group][C][splits][2], the conv-epilogue entries of group g at
+    // [c][g * nparts ..]).  The publishing block of a channel walks the groups in order -- the running statistics after
+    // `groups` sequential forwards, bit for bit -- and leaves the last group's mean / rstd / scale / shift.
+    const int mine = n / ng;
+    const bool publisher = blockIdx.x == 0 && n == 0;
     if (threadIdx.x < 64) {
-        double s = 0.0, ss = 0.0;
-        if (fparts) {                             // statistics from the convolution's epilogue: [c][nparts][2], pre-bias
-            for (int i = threadIdx.x; i < nparts; i += 64) {
-                const f32x2 v = *reinterpret_cast<const f32x2*>(fparts + ((long)c * pstride + i) * 2);
-                s += (double)v[0];
-                ss += (double)v[1];
-            }
-        } else if ((int)threadIdx.x < splits) {
-            s = partials[((long)c * splits + threadIdx.x) * 2 + 0];
-            ss = partials[((long)c * splits + threadIdx.x) * 2 + 1];
-        }
-        s = wave_sum_d(s);
-        ss = wave_sum_d(ss);
-        if (threadIdx.x == 0) {
-            double mean = s / count;
-            double var = ss / count - mean * mean;
-            if (fparts && cbias) mean += (double)cbias[c];           // the sums are of z - bias
-            if (var < 0.0) var = 0.0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-            const float g = gamma ? gamma[c] : 1.0f, bb = beta ? beta[c] : 0.0f;
-            const float sc = g * rstd, sh = bb - (float)mean * sc;
-            coef[0] = sc; coef[1] = sh;
-            if (blockIdx.x == 0 && n == 0) {
-                mean_out[c] = (float)mean; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh;
-                if (running_mean) {
-                    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
-                    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+        for (int gi = publisher ? 0 : mine; gi <= (publisher ? groups - 1 : mine); ++gi) {
+            double s = 0.0, ss = 0.0;
+            if (fparts) {                             // statistics from the convolution's epilogue: [c][pstride][2], pre-bias
+                for (int i = threadIdx.x; i < nparts; i += 64) {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(fparts + ((long)c * pstride + (long)gi * nparts + i) * 2);
+                    s += (double)v[0];
+                    ss += (double)v[1];
                 }
-                if (c == 0 && nbt) *nbt += 1;
+            } else if ((int)threadIdx.x < splits) {
+                s = partials[(((long)gi * C + c) * splits + threadIdx.x) * 2 + 0];
+                ss = partials[(((long)gi * C + c) * splits + threadIdx.x) * 2 + 1];
+            }
+            s = wave_sum_d(s);
+            ss = wave_sum_d(ss);
+            if (threadIdx.x == 0) {
+                double mean = s / count;
+                double var = ss / count - mean * mean;
+                if (fparts && cbias) mean += (double)cbias[c];           // the sums are of z - bias
+                if (var < 0.0) var = 0.0;
+                const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+                const float g = gamma ? gamma[c] : 1.0f, bb = beta ? beta[c] : 0.0f;
+                const float sc = g * rstd, sh = bb - (float)mean * sc;
+                if (gi == mine) { coef[0] = sc; coef[1] = sh; }
+                if (publisher) {
+                    if (gi == groups - 1) { mean_out[c] = (float)mean; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh; }
+                    if (running_mean) {
+                        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+                        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+                    }
+                    if (c == 0 && nbt) *nbt += 1;
+                }
             }
         }
     }
@@ -391,60 +402,66 @@ __global__ __launch_bounds__(256) void bn_train_fused_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ scale_out,
-    float* __restrict__ shift_out, int relu, const SlabSrc sl) {
+    float* __restrict__ shift_out, int relu, const SlabSrc sl, int groups) {
     __shared__ double sm[2 * 4];
     __shared__ float coef[2];
     const int c = blockIdx.x, hw4 = HW / 4, total4 = N * hw4;
-    f32x4 v[BN_FQ];
-    double acc[2] = {0.0, 0.0};
+    // groups > 1 (aide_bn_train_fwd_groups): the stacked batch holds `groups` runs of N images; the channel's block takes
+    // them one after the other -- statistics, running-statistics update and normalisation per group, in order
+    for (int gi = 0; gi < groups; ++gi) {
+        const long n0 = (long)gi * N;
+        f32x4 v[BN_FQ];
+        double acc[2] = {0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < BN_FQ; ++k) {
-        const int i = threadIdx.x + k * 256;
-        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (i < total4) {
-            const int n = i / hw4, p = i - n * hw4;
-            float t4[4];
-            if constexpr (SLABS) {
-                slab_sum<4>(sl, (long)n * sl.slab_bs + (long)c * HW + p * 4, c, t4);
-                stv<4>(const_cast<ZT*>(z) + (long)n * z_bs + (long)c * HW + p * 4, t4);
+        for (int k = 0; k < BN_FQ; ++k) {
+            const int i = threadIdx.x + k * 256;
+            v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < total4) {
+                const int n = i / hw4, p = i - n * hw4;
+                float t4[4];
+                if constexpr (SLABS) {
+                    slab_sum<4>(sl, (n0 + n) * sl.slab_bs + (long)c * HW + p * 4, c, t4);
+                    stv<4>(const_cast<ZT*>(z) + (n0 + n) * z_bs + (long)c * HW + p * 4, t4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t4[e] = as_stored(t4[e], (const ZT*)nullptr);
-            } else {
-                ldv<4>(z + (long)n * z_bs + (long)c * HW + p * 4, t4);
+                    for (int e = 0; e < 4; ++e) t4[e] = as_stored(t4[e], (const ZT*)nullptr);
+                } else {
+                    ldv<4>(z + (n0 + n) * z_bs + (long)c * HW + p * 4, t4);
+                }
+                v[k] = f32x4{t4[0], t4[1], t4[2], t4[3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double d = (double)v[k][e]; acc[0] += d; acc[1] += d * d; }
             }
-            v[k] = f32x4{t4[0], t4[1], t4[2], t4[3]};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const double d = (double)v[k][e]; acc[0] += d; acc[1] += d * d; }
         }
-    }
-    block_sum_d<2>(acc, sm);
-    if (threadIdx.x == 0) {
-        const double mean = acc[0] / count;
-        double var = acc[1] / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[c] : 1.0f, bb = beta ? beta[c] : 0.0f;
-        const float sc = g * rstd, sh = bb - (float)mean * sc;
-        coef[0] = sc; coef[1] = sh;
-        mean_out[c] = (float)mean; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh;
-        if (running_mean) {
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
-            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+        if (gi > 0) __syncthreads();          // (the previous group's readers of sm / coef are done)
+        block_sum_d<2>(acc, sm);
+        if (threadIdx.x == 0) {
+            const double mean = acc[0] / count;
+            double var = acc[1] / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float g = gamma ? gamma[c] : 1.0f, bb = beta ? beta[c] : 0.0f;
+            const float sc = g * rstd, sh = bb - (float)mean * sc;
+            coef[0] = sc; coef[1] = sh;
+            if (gi == groups - 1) { mean_out[c] = (float)mean; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh; }
+            if (running_mean) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+            if (c == 0 && nbt) *nbt += 1;
         }
-        if (c == 0 && nbt) *nbt += 1;
-    }
-    __syncthreads();
-    const float sc = coef[0], sh = coef[1];
+        __syncthreads();
+        const float sc = coef[0], sh = coef[1];
 #pragma unroll
-    for (int k = 0; k < BN_FQ; ++k) {
-        const int i = threadIdx.x + k * 256;
-        if (i < total4) {
-            const int n = i / hw4, p = i - n * hw4;
-            float o[4];
+        for (int k = 0; k < BN_FQ; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < total4) {
+                const int n = i / hw4, p = i - n * hw4;
+                float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float y = fmaf(v[k][e], sc, sh); o[e] = relu ? fmaxf(y, 0.0f) : y; }
-            stv<4>(a + (long)n * a_bs + (long)c * HW + p * 4, o);
+                for (int e = 0; e < 4; ++e) { const float y = fmaf(v[k][e], sc, sh); o[e] = relu ? fmaxf(y, 0.0f) : y; }
+                stv<4>(a + (n0 + n) * a_bs + (long)c * HW + p * 4, o);
+            }
         }
     }
 }
@@ -531,23 +548,28 @@ size_t aide_bn_ws_bytes(int C) { return (size_t)C * 64 * 3 * sizeof(double); }
 
 namespace {
 
+// N: images per group; groups > 1: a stacked batch of `groups` runs of N images, each with its own batch statistics, the
+// running statistics updated once per group in order (one launch sequence instead of `groups`)
 template <typename ZT, typename AT, bool SLABS = false>
 int bn_train_fwd_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C, int H, int W,
                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
-                   float* scale, float* shift, int relu, void* ws, hipStream_t stream, SlabSrc sl = SlabSrc{}) {
+                   float* scale, float* shift, int relu, void* ws, hipStream_t stream, SlabSrc sl = SlabSrc{}, int groups = 1) {
     const int HW = H * W;
-    if (!z || !a || !ws) return AIDE_ERR_ARG;
+    if (!z || !a || !ws || groups < 1) return AIDE_ERR_ARG;
     const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && a_bs % 4 == 0;
     if (SLABS && (!sl.slabs || sl.splitk < 1 || !v4)) return AIDE_ERR_ARG;
-    const int splits = pick_splits(N, C, HW);
+    int splits = pick_splits(N, C, HW);
+    if (groups > 1 && splits > 96 / groups) splits = 96 / groups > 0 ? 96 / groups : 1;   // partials [group][C][splits][2] in C * 192 doubles
+    if ((long)groups * splits > 96) return AIDE_ERR_ARG;
     double* partials = (double*)ws;
     const double count = (double)N * HW;
     const int gx = max(1, min((HW / (v4 ? 4 : 1) + 255) / 256, 16));
+    const int NT = N * groups;
     if (v4 && bn_fused_ok(N, C, HW)) {
         hipLaunchKernelGGL((bn_train_fused_kernel<ZT, AT, SLABS>), dim3(C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, N, HW, count,
                            gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd,
-                           scale, shift, relu, sl);
+                           scale, shift, relu, sl, groups);
         return aide_launch_status();
     }
     // 8 values per lane: 16-byte accesses for the bf16-stored tensors of the precision='bf16' mode
@@ -555,20 +577,20 @@ int bn_train_fwd_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C,
     const bool v8 = v4 && !SLABS && HW % 8 == 0 && z_bs % 8 == 0 && a_bs % 8 == 0;
     if (v8) {
         const int gx8 = max(1, min((HW / 8 + 255) / 256, 16));
-        hipLaunchKernelGGL((bn_stats_kernel<8, ZT, false>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
-        hipLaunchKernelGGL((bn_train_apply_kernel<8, ZT, AT>), dim3(gx8, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+        hipLaunchKernelGGL((bn_stats_kernel<8, ZT, false>), dim3(C * splits, groups), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
+        hipLaunchKernelGGL((bn_train_apply_kernel<8, ZT, AT>), dim3(gx8, NT * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
-                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0);
+                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0, N, groups);
     } else if (v4) {
-        hipLaunchKernelGGL((bn_stats_kernel<4, ZT, SLABS>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
-        hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+        hipLaunchKernelGGL((bn_stats_kernel<4, ZT, SLABS>), dim3(C * splits, groups), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
+        hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, NT * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
-                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0);
+                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0, N, groups);
     } else {
-        hipLaunchKernelGGL((bn_stats_kernel<1, ZT, false>), dim3(C * splits), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
-        hipLaunchKernelGGL((bn_train_apply_kernel<1, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+        hipLaunchKernelGGL((bn_stats_kernel<1, ZT, false>), dim3(C * splits, groups), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
+        hipLaunchKernelGGL((bn_train_apply_kernel<1, ZT, AT>), dim3(gx, NT * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
-                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0);
+                           num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0, N, groups);
     }
     return aide_launch_status();
 }
@@ -660,6 +682,27 @@ int aide_bn_train_fwd_slabs(const float* slabs, int splitk, int64_t split_stride
 #undef AIDE_BN_FWD_S
 }
 
+// N images per group, `groups` groups stacked along the batch; group g's entries are parts[c][g * nparts .. (g + 1) * nparts)
+static int bn_parts_launch(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int groups, int C,
+                           int H, int W, const float* parts, int nparts, int parts_stride, const float* conv_bias,
+                           const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                           float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                           float* scale, float* shift, int relu, hipStream_t stream) {
+    const int HW = H * W;
+    if (!z || !a || !parts || nparts <= 0 || groups < 1 || parts_stride < nparts * groups || HW % 4 || z_bs % 4 || a_bs % 4)
+        return AIDE_ERR_ARG;
+    const double count = (double)N * HW;
+    const int gx = max(1, min((HW / 4 + 255) / 256, 16));
+#define AIDE_BN_PARTS(ZT, AT)                                                                                                  \
+    hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, N * groups * C), dim3(256), 0, stream, (const ZT*)z, (long)z_bs,    \
+                       (AT*)a, (long)a_bs, C, HW, (const double*)nullptr, 0, count, gamma, beta, eps, momentum, running_mean, \
+                       running_var, num_batches_tracked, mean, rstd, scale, shift, relu, parts, nparts, conv_bias, parts_stride, N, groups)
+    if (z_bf16) { if (a_bf16) AIDE_BN_PARTS(bf16_t, bf16_t); else AIDE_BN_PARTS(bf16_t, float); }
+    else { if (a_bf16) AIDE_BN_PARTS(float, bf16_t); else AIDE_BN_PARTS(float, float); }
+#undef AIDE_BN_PARTS
+    return aide_launch_status();
+}
+
 // BatchNorm(train)+ReLU whose statistics were emitted by the convolution's own epilogue (stats_parts of aide_conv3x3_wino4): parts
 // [C][nparts][2] fp32 = per channel and conv workgroup tile the sum and sum of squares of z - conv_bias.  One launch, one
 // read of z.  (H*W % 4 == 0 and 16-byte aligned batch strides.)
@@ -686,23 +729,46 @@ int aide_bn_train_fwd_parts_strided(const void* z, int z_bf16, int64_t z_bs, voi
                                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                                     float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
                                     float* scale, float* shift, int relu, hipStream_t stream) {
-    const int HW = H * W;
-    if (!z || !a || !parts || nparts <= 0 || parts_stride < nparts || HW % 4 || z_bs % 4 || a_bs % 4) return AIDE_ERR_ARG;
-    const double count = (double)N * HW;
-    const int gx = max(1, min((HW / 4 + 255) / 256, 16));
-#define AIDE_BN_PARTS(ZT, AT)                                                                                                  \
-    hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, (const ZT*)z, (long)z_bs,    \
-                       (AT*)a, (long)a_bs, C, HW, (const double*)nullptr, 0, count, gamma, beta, eps, momentum, running_mean, \
-                       running_var, num_batches_tracked, mean, rstd, scale, shift, relu, parts, nparts, conv_bias, parts_stride)
-    if (z_bf16) { if (a_bf16) AIDE_BN_PARTS(bf16_t, bf16_t); else AIDE_BN_PARTS(bf16_t, float); }
-    else { if (a_bf16) AIDE_BN_PARTS(float, bf16_t); else AIDE_BN_PARTS(float, float); }
-#undef AIDE_BN_PARTS
-    return aide_launch_status();
+    return bn_parts_launch(z, z_bf16, z_bs, a, a_bf16, a_bs, N, 1, C, H, W, parts, nparts, parts_stride, conv_bias, gamma, beta,
+                           eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd, scale, shift, relu,
+                           stream);
 }
 
 // two-pass (statistics kernel + apply kernel) or single small-plane kernel?  1 = two passes: only then do epilogue
 // statistics save a launch
 int aide_bn_two_pass(int N, int C, int H, int W) { return bn_fused_ok(N, C, H * W) ? 0 : 1; }
+
+// BatchNorm(train)+ReLU of a STACKED batch: `groups` independent batches of N images each, stacked along the batch
+// dimension of z / a (the four detached augmentation forwards of the co-teaching loop run as one pass,
+// trainchaos_proposed_30cases1labeled.py:265-269).  Every group is normalised with its own batch statistics and the
+// running statistics / num_batches_tracked are updated once per group, in order -- exactly `groups` sequential
+// train-mode forwards -- in one launch sequence instead of `groups`.  mean / rstd / scale / shift receive the LAST
+// group's values.  Input, one of: z as it is (slabs == parts == NULL); split-K slabs [splitk][N * groups][C][H][W] of the
+// conv before it (slabs, splitk, split_stride, slab_bias: as aide_bn_train_fwd_slabs; z is written); the conv epilogue's
+// statistics (parts [C][parts_stride][2] with group g's nparts entries at g * nparts, conv_bias: as
+// aide_bn_train_fwd_parts).  groups <= 96 / 2 (workspace: aide_bn_ws_bytes).
+int aide_bn_train_fwd_groups(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int groups,
+                             int C, int H, int W, const float* slabs, int splitk, int64_t split_stride,
+                             const float* slab_bias, const float* parts, int nparts, int parts_stride,
+                             const float* conv_bias, const float* gamma, const float* beta, float eps, float momentum,
+                             float* running_mean, float* running_var, long long* num_batches_tracked, float* mean,
+                             float* rstd, float* scale, float* shift, int relu, void* ws, hipStream_t stream) {
+    if (groups < 1 || N < 1 || (slabs && parts)) return AIDE_ERR_ARG;
+    if (parts)
+        return bn_parts_launch(z, z_bf16, z_bs, a, a_bf16, a_bs, N, groups, C, H, W, parts, nparts, parts_stride, conv_bias,
+                               gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd, scale,
+                               shift, relu, stream);
+    SlabSrc sl = SlabSrc{};
+    if (slabs) { sl.slabs = slabs; sl.bias = slab_bias; sl.split_stride = split_stride; sl.slab_bs = (long)C * H * W; sl.splitk = splitk; }
+#define AIDE_BN_FWD_G(ZT, AT)                                                                                                  \
+    (slabs ? bn_train_fwd_t<ZT, AT, true>((const ZT*)z, z_bs, (AT*)a, a_bs, N, C, H, W, gamma, beta, eps, momentum, running_mean, \
+                                          running_var, num_batches_tracked, mean, rstd, scale, shift, relu, ws, stream, sl, groups) \
+           : bn_train_fwd_t<ZT, AT, false>((const ZT*)z, z_bs, (AT*)a, a_bs, N, C, H, W, gamma, beta, eps, momentum, running_mean, \
+                                           running_var, num_batches_tracked, mean, rstd, scale, shift, relu, ws, stream, sl, groups))
+    if (z_bf16) return a_bf16 ? AIDE_BN_FWD_G(bf16_t, bf16_t) : AIDE_BN_FWD_G(bf16_t, float);
+    return a_bf16 ? AIDE_BN_FWD_G(float, bf16_t) : AIDE_BN_FWD_G(float, float);
+#undef AIDE_BN_FWD_G
+}
 
 int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
                              int H, int W, const float* scale, const float* shift, int relu, hipStream_t stream) {

@@ -279,6 +279,25 @@ def bn_train_fwd_slabs(slabs, splitk, split_stride, bias, z, a, gamma, beta, eps
     return a
 
 
+def bn_train_fwd_groups(z, a, groups, bn, mean, rstd, scale, shift, ws, relu=True, slabs=None, splitk=0, split_stride=0,
+                        slab_bias=None, parts=None, nparts=0, parts_stride=0, conv_bias=None):
+    """BatchNorm(train)+ReLU of a stacked batch: z / a hold `groups` runs of N / groups images; per-group statistics, the
+    running statistics updated once per group in order -- `groups` sequential forwards in one launch sequence.
+    Input: z, or the split-K slabs of the conv before it (slabs = pointer, z is written), or the conv epilogue's
+    statistics (parts: group g's nparts entries at g * nparts of every channel's parts_stride)."""
+    zp, zbs = planes(z, bf16_ok=True)
+    ap, abs_ = planes(a, bf16_ok=True)
+    n, c, h, w = z.shape
+    assert n % groups == 0
+    check(lib.aide_bn_train_fwd_groups(zp, int(is_bf16(z)), zbs, ap, int(is_bf16(a)), abs_, n // groups, groups, c, h, w,
+                                       slabs, splitk, split_stride, ptr(slab_bias), ptr(parts), nparts, parts_stride,
+                                       ptr(conv_bias), ptr(bn.weight), ptr(bn.bias), bn.eps, bn.momentum,
+                                       ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(mean),
+                                       ptr(rstd), ptr(scale), ptr(shift), int(relu), ptr(ws), stream_ptr()),
+          'bn_train_fwd_groups')
+    return a
+
+
 def bn_train_fwd_parts(z, a, parts, nparts, conv_bias, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean,
                        rstd, scale, shift, relu=True, first=0, stride=None):
     """bn_train_fwd with the statistics emitted by the conv epilogue (conv3x3_wino4(..., stats=)): one pass over z.

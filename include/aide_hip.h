@@ -217,6 +217,19 @@ int aide_bn_train_fwd_parts_strided(const void* z, int z_bf16, int64_t z_bs, voi
                                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                                     float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
                                     float* scale, float* shift, int relu, aide_stream_t stream);
+/* BatchNorm(train)+ReLU of a STACKED batch: `groups` independent batches of N images each, stacked along the batch dimension
+ * (the four detached augmentation forwards of the co-teaching loop as one pass, trainchaos_proposed_30cases1labeled.py:265-269).
+ * Every group is normalised with its own batch statistics; running statistics / num_batches_tracked are updated once per
+ * group, in order -- bit for bit what `groups` sequential train-mode forwards leave -- in ONE launch sequence; mean / rstd /
+ * scale / shift receive the last group's values.  Input, one of: z as it is (slabs == parts == NULL); the split-K slabs
+ * [splitk][N * groups][C][H][W] of the conv before it (as aide_bn_train_fwd_slabs; z is written); the conv epilogue's
+ * statistics parts[C][parts_stride][2], group g's nparts entries at g * nparts (as aide_bn_train_fwd_parts). */
+int aide_bn_train_fwd_groups(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int groups,
+                             int C, int H, int W, const float* slabs, int splitk, int64_t split_stride,
+                             const float* slab_bias, const float* parts, int nparts, int parts_stride,
+                             const float* conv_bias, const float* gamma, const float* beta, float eps, float momentum,
+                             float* running_mean, float* running_var, long long* num_batches_tracked, float* mean,
+                             float* rstd, float* scale, float* shift, int relu, void* ws, aide_stream_t stream);
 int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
                              int H, int W, const float* scale, const float* shift, int relu, aide_stream_t stream);
 int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz,
