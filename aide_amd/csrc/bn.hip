@@ -229,6 +229,46 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(
     }
 }
 
+// Statistics -> coefficients only (no pass over z): the conv epilogue's partial sums of a STACKED batch become, per group
+// and channel, the (scale, shift) pair of tab[group][tab_c][2] at channel offset tab_c0 -- the table the consumer
+// convolution's loader applies (conv3x3_wino4_kernel<.., BNIN>) -- and the running statistics move once per group, in order
+// (the arithmetic of bn_train_apply_kernel's publishing block, bit for bit).  One wave per channel.
+__global__ __launch_bounds__(64) void bn_finalize_groups_kernel(
+    const float* __restrict__ fparts, int nparts, int pstride, const float* __restrict__ cbias, double count, int groups,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
+    float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out,
+    float* __restrict__ tab, int tab_c, int tab_c0) {
+    const int c = blockIdx.x;
+    for (int gi = 0; gi < groups; ++gi) {
+        double s = 0.0, ss = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += 64) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(fparts + ((long)c * pstride + (long)gi * nparts + i) * 2);
+            s += (double)v[0];
+            ss += (double)v[1];
+        }
+        s = wave_sum_d(s);
+        ss = wave_sum_d(ss);
+        if (threadIdx.x == 0) {
+            double mean = s / count;
+            double var = ss / count - mean * mean;
+            if (cbias) mean += (double)cbias[c];                     // the sums are of z - bias
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float g = gamma ? gamma[c] : 1.0f, bb = beta ? beta[c] : 0.0f;
+            const float sc = g * rstd, sh = bb - (float)mean * sc;
+            *reinterpret_cast<f32x2*>(tab + ((long)gi * tab_c + tab_c0 + c) * 2) = f32x2{sc, sh};
+            if (gi == groups - 1) { mean_out[c] = (float)mean; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh; }
+            if (running_mean) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+            if (c == 0 && nbt) *nbt += 1;
+        }
+    }
+}
+
 // eval mode: scale/shift from running statistics
 __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
@@ -737,6 +777,23 @@ int aide_bn_train_fwd_parts_strided(const void* z, int z_bf16, int64_t z_bs, voi
 // two-pass (statistics kernel + apply kernel) or single small-plane kernel?  1 = two passes: only then do epilogue
 // statistics save a launch
 int aide_bn_two_pass(int N, int C, int H, int W) { return bn_fused_ok(N, C, H * W) ? 0 : 1; }
+
+// BatchNorm(train) WITHOUT its pass over z: from the conv epilogue's statistics of a stacked batch (parts as in
+// aide_bn_train_fwd_groups) to the per-group (scale, shift) table tab[groups][tab_C][2], entries [tab_c0, tab_c0 + C), that
+// the consumer convolution's loader applies (in_bn_tab of aide_conv3x3_wino4), plus the running-statistics updates of
+// `groups` sequential forwards.  N = images per group.
+int aide_bn_finalize_groups(int N, int groups, int C, int H, int W, const float* parts, int nparts, int parts_stride,
+                            const float* conv_bias, const float* gamma, const float* beta, float eps, float momentum,
+                            float* running_mean, float* running_var, long long* num_batches_tracked, float* mean,
+                            float* rstd, float* scale, float* shift, float* tab, int tab_C, int tab_c0, hipStream_t stream) {
+    if (!parts || !tab || N < 1 || groups < 1 || C < 1 || nparts < 1 || parts_stride < nparts * groups || tab_c0 < 0 ||
+        tab_c0 + C > tab_C || !mean || !rstd || !scale || !shift)
+        return AIDE_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_groups_kernel, dim3(C), dim3(64), 0, stream, parts, nparts, parts_stride, conv_bias,
+                       (double)N * H * W, groups, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+                       mean, rstd, scale, shift, tab, tab_C, tab_c0);
+    return aide_launch_status();
+}
 
 // BatchNorm(train)+ReLU of a STACKED batch: `groups` independent batches of N images each, stacked along the batch
 // dimension of z / a (the four detached augmentation forwards of the co-teaching loop run as one pass,

@@ -43,8 +43,12 @@ struct W4Args {
                          // pre-bias outputs -- the BatchNorm statistics of the forward pass without a pass over z
     const float* scale;  // AFF variant (eval mode, epi_scale of aide_conv3x3_wino4): y = relu?(acc * scale[co] + bias[co]) -- the
     int relu;            // BatchNorm of running statistics folded into the epilogue, no separate pass over the conv output
+    const float* in_tab; // BNIN variant (in_bn_tab of aide_conv3x3_wino4): [N / in_ng][Cin][2] = (scale, shift) per image group and
+    int in_ng;           // input channel -- the loader stages relu(x * scale + shift): the BatchNorm + ReLU of the producing
+                         // layer applied on the way in, its normalised output never materialised
 };
 
+constexpr int F4_BNIN_MAXC = 1024;         // BNIN variant: input channels whose (scale, shift) table + zero copy fit LDS beside the sets
 constexpr int F4_NAGPR = 16;               // accumulators (of 18) kept in the AGPR file; the rest are pinned to VGPRs
 constexpr int F4_RRS = 41;                 // raw row: [3 pad][-1][0..31][32][4 pad]; odd: conflict-free raw stores
 constexpr int F4_RCS = 775;                // raw channel stride: (41, 775) makes patch reads AND raw stores conflict-free
@@ -91,7 +95,13 @@ __device__ __forceinline__ float half_total_dpp(float v) {
 // MODE 2: the workgroup's 32 tile slots as a 5 x 5 canvas of 4x4 tiles = 20 x 20 pixels (25 slots used) instead of 4 x 8 =
 // 16 x 32: the 40 x 40 and 20 x 20 planes of the 320 x 320 workload fill 78 % of their tiles instead of 52 % / 39 %.  Only
 // the staging descriptors, the patch origin and the output address know the canvas; the main loop is the same code.
-template <int MODE, bool AFF = false>
+// BNIN: the input is the RAW conv output z of the layer before; the staging applies that layer's BatchNorm + ReLU
+// (per-channel scale / shift of the image's group, a table the caller derived from the statistics) before the raw tile goes to
+// LDS -- the forward-only augmentation passes of the co-teaching step save nothing for a backward pass, so the normalised
+// tensor need not exist (SURVEY 8b in_prologue{bn_relu}).  Zero padding must stay zero (BN(0) != 0): a unit that lies
+// outside the image reads its (scale, shift) from a ZERO copy of the table, so 0 * 0 + 0 = 0 without a select.  A separate
+// instantiation: the training kernels keep their code and register allocation.
+template <int MODE, bool AFF = false, bool BNIN = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -138,6 +148,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     // 440); raw edges: 4 x 18 x 2 dwords = 144 units (1 round; canvas 176); U: 2304 float4 (9 rounds)
     constexpr int NUI = 4 * NR * NI, NUE = 4 * NR * 2;
     unsigned offB[3], ldsB[3], offC, ldsC;
+    int tabB[3], tabC;                     // BNIN: float index of the unit's (scale, shift) entry for stage 0 (valid: table, else zero copy)
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
         int q = tid + e * 256;
@@ -148,6 +159,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
         const bool ok = ih >= 0 && ih < a.H && (pair || iw < a.W);
         offB[e] = ok ? (unsigned)((long)imgB * a.x_bs + c * HW + r * a.W + 1 + 4 * (pair ? (s4 & 3) : s4)) * 4u : BUF_OOB;
         ldsB[e] = (unsigned)(c * F4_RCS + r * RRS + 4 + 4 * s4 + 2 * imgB);
+        tabB[e] = F4_LDS + (ok ? 0 : 2 * a.Cin) + 2 * c;
     }
     {
         int q = tid;
@@ -155,6 +167,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
         const int c = q / (NR * 2), rem = q - c * (NR * 2), r = rem >> 1, side = rem & 1;
         const int ih = h0 - 1 + r, iw = side ? w0 + TPW : w0 - 1;
         const bool ok = !pair && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        tabC = F4_LDS + (ok ? 0 : 2 * a.Cin) + 2 * c;
         offC = ok ? (unsigned)(c * HW + r * a.W + (side ? TPW + 1 : 0)) * 4u : BUF_OOB;
         // (pair: every halo column is an image border; the edge units keep the two seam columns zero, the outer two are
         // zeroed once in the prologue)
@@ -192,6 +205,30 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
         if (w < 12) raw[ldsB[w >> 2] + (w & 3)] = rb[w >> 2][w & 3];
         else raw[ldsC] = rc;
     };
+    // BNIN: (scale, shift) of the four units' channels for one stage -> registers (bn_tab), then relu(x * scale + shift) on
+    // the 13 fetched values (bn_in) right before they go to LDS: 6 packed FMAs + 1 FMA + 13 max per stage
+    f32x2 tv[4];
+    auto bn_tab = [&](int stage) {
+        const int so = min(stage, s_end - 1) * 8;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) tv[e] = *reinterpret_cast<const f32x2*>(lds + tabB[e] + so);
+        tv[3] = *reinterpret_cast<const f32x2*>(lds + tabC + so);
+    };
+    auto bn_in = [&]() {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const f32x2 sc = f32x2{tv[e].x, tv[e].x}, sh = f32x2{tv[e].y, tv[e].y};
+            const f32x2 lo = f32x2{rb[e].x, rb[e].y} * sc + sh, hi = f32x2{rb[e].z, rb[e].w} * sc + sh;
+            rb[e] = f32x4{fmaxf(lo.x, 0.f), fmaxf(lo.y, 0.f), fmaxf(hi.x, 0.f), fmaxf(hi.y, 0.f)};
+        }
+        rc = fmaxf(__builtin_fmaf(rc, tv[3].x, tv[3].y), 0.f);
+    };
+    if constexpr (BNIN) {
+        float* tab = lds + F4_LDS;
+        const float* src = a.in_tab + (long)(n / a.in_ng) * 2 * a.Cin;
+        for (int i = tid; i < 2 * a.Cin; i += 256) { tab[i] = src[i]; tab[2 * a.Cin + i] = 0.f; }
+        __syncthreads();
+    }
 
     // ---- input transform: thread = (half hs, ci, tile) ----
     const int item = tid & 127, hs = wid >> 1;             // hs is wave-uniform
@@ -279,6 +316,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             lds[set * F4_SET + c * F4_RCS + rr * F4_RRS + (side ? 38 : 3)] = 0.f;
         }
     }
+    if constexpr (BNIN) { bn_tab(s_begin); bn_in(); }
 #pragma unroll
     for (int w = 0; w < 13; ++w) put_raw(w, set0);
 #pragma unroll
@@ -289,6 +327,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
     xf_math();
 #pragma unroll
     for (int m = 0; m < 9; ++m) xf_store(m, set0 + F4_RAW);
+    if constexpr (BNIN) { bn_tab(s_begin + 1); bn_in(); }
 #pragma unroll
     for (int w = 0; w < 13; ++w) put_raw(w, set1);
     __syncthreads();
@@ -323,6 +362,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
             if (st < 18) { xf_read(2 * st, kcur ? xr0 : xr1); xf_read(2 * st + 1, kcur ? xr0 : xr1); }
             if (st == XM) xf_math();
             if (st >= XS && st < XS + 9) xf_store(st - XS, sn + F4_RAW);
+            if constexpr (BNIN) {                     // the stage's second (and last) slot with vector-ALU work
+                if (st == 24) bn_tab(s + 2);
+                if (st == 30) bn_in();
+            }
             if (st >= PR && st < PR + 5) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
@@ -649,7 +692,8 @@ int aide_conv3x3_wino4_pack_multi(const void* descs, int n, int64_t total_blocks
 // of aide_conv3x3_ws_bytes(N, H, W, Cout, splitk) bytes.
 int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float* bias, float* y,
                        int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,
-                       float* ws, float* stats_parts, const float* epi_scale, int epi_relu, hipStream_t stream) {
+                       float* ws, float* stats_parts, const float* epi_scale, int epi_relu, const float* in_bn_tab,
+                       int in_bn_group_images, hipStream_t stream) {
     const float* aff = epi_scale;
     const int aff_relu = aff ? epi_relu : 0;
     if (!x || !u || !y || !aide_conv3x3_wino4_supported(Cin, H, W, Cout) || x_bs % 4 || y_bs % 4 || (W == 16 && N % 2))
@@ -665,6 +709,10 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
                                   F4_LDS * (int)sizeof(float));
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   F4_LDS * (int)sizeof(float));
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (F4_LDS + 4 * F4_BNIN_MAXC) * (int)sizeof(float));
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (F4_LDS + 4 * F4_BNIN_MAXC) * (int)sizeof(float));
         return true;
     }();
     (void)attr_set;
@@ -676,6 +724,9 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
     a.scale = splitk > 1 ? nullptr : aff;           // a split launch leaves plain slabs: its reduce applies the epilogue
     a.relu = aff_relu;
     a.pair = mode == 1 ? 1 : 0;
+    // input BatchNorm + ReLU in the loader: not with the image-pair tile or the folded epilogue (no caller needs either)
+    if (in_bn_tab && (mode == 1 || aff || Cin > F4_BNIN_MAXC || in_bn_group_images < 1 || N % in_bn_group_images)) return AIDE_ERR_ARG;
+    a.in_tab = in_bn_tab; a.in_ng = in_bn_tab ? in_bn_group_images : 1;
     a.x = x; a.u = u; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.n_co_tiles = (Cout + 63) / 64;
     a.stages_total = Cin / 4;
@@ -712,7 +763,16 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
         }
         a.gp = (int)bp; a.gc = bc;
     }
-    if (a.scale && mode == 2) {
+    if (a.in_tab) {
+        const size_t lds_bytes = (F4_LDS + 4 * (size_t)Cin) * sizeof(float);
+        if (mode == 2) {
+            AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), (conv3x3_wino4_kernel<2, false, true>),
+                              dim3((unsigned)nb), dim3(256), lds_bytes, stream, a);
+        } else {
+            AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), (conv3x3_wino4_kernel<0, false, true>),
+                              dim3((unsigned)nb), dim3(256), lds_bytes, stream, a);
+        }
+    } else if (a.scale && mode == 2) {
         AIDE_LAUNCH_TIMED(AIDE_KT_WINO4, AIDE_CONV_FLOPS(N, H, W, Cout, Cin), (conv3x3_wino4_kernel<2, true>), dim3((unsigned)nb),
                           dim3(256), F4_LDS * sizeof(float), stream, a);
     } else if (a.scale) {

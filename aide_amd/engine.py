@@ -112,6 +112,7 @@ TAIL_WGRAD_MAIN = [True]       # the weight gradient of the LAST op of the backw
 DUAL_FWD = [True]              # lane-1 chains of the forward pass on a second stream
 FREE_LANE = [True]             # lane 1 pools its own channels and runs ahead (no fork / join per level)
 FLUSH_EVERY = 6                # layers per batched slab reduce
+LAZY_BN = [True]               # forward-only stacked plans: BatchNorm + ReLU of a layer in its reader's loader (Plan._plan_lazy_bn)
 
 
 def conv_mode(n, cin, h, w, cout):
@@ -336,6 +337,7 @@ class Plan(object):
                 st['gate'] = torch.empty(n, hh, ww, **f32)
                 st['stat'] = torch.empty(2, **f32)
             self.steps.append(st)
+        self._plan_lazy_bn()
         # activation buffers.  bf16 mode stores an activation buffer as bf16 when everything that touches it can: written by
         # BatchNorm-apply / pooling / up-sampling, read by bf16 convolutions (forward AND weight gradient), pooling,
         # up-sampling or the head.  For a conv operand that is numerically free (the kernels round it anyway), max-pooling
@@ -393,6 +395,37 @@ class Plan(object):
         self.trace = None                # tools/phase_trace.py: callable(direction, step) before every op
         self.serial = 0                  # forwards run on this plan; _NetFunction.backward checks it still owns the buffers
         self.key = None
+
+    def _plan_lazy_bn(self):
+        """Forward-only stacked plans (the no-grad augmentation passes of the co-teaching step,
+        trainchaos_proposed_30cases1labeled.py:263-281): nothing is kept for a backward pass, so the BatchNorm + ReLU of a
+        layer whose ONLY reader is an F(4x4) convolution is applied in that convolution's loader (SURVEY 8b
+        in_prologue{bn_relu}) -- the producer writes its raw output z straight into the reader's input slot with the
+        statistics from its epilogue, a one-wave-per-channel launch turns them into the reader's per-group (scale, shift)
+        table, and the normalising pass over the tensor (one read + one write) never runs.  Channels of the reader's input
+        that are materialised activations (a skip half of a concat buffer) get (1, 0): ReLU of a non-negative value."""
+        self.lazy_bn = 0
+        if not (self.training and self.groups > 1) or not LAZY_BN[0]:
+            return
+        for st in self.steps:
+            if st['kind'] != 'conv' or st.get('stats') is None:
+                continue
+            dst = st['dst']
+            readers = [o for o in self.steps if o.get('src') is not None and o['src'].root is dst.root
+                       and o['src'].c0 < dst.c0 + dst.C and dst.c0 < o['src'].c0 + o['src'].C]
+            if len(readers) != 1:
+                continue
+            rd = readers[0]
+            src = rd['src']
+            if rd['kind'] != 'conv' or rd['wino_f'] != 4 or src.C > 1024 or not (src.c0 <= dst.c0 and dst.c0 + dst.C <= src.c0 + src.C):
+                continue
+            if rd.get('in_tab') is None:
+                tab = torch.zeros(self.groups, src.C, 2, device=self.dev, dtype=torch.float32)
+                tab[:, :, 0] = 1.0
+                rd['in_tab'] = tab
+            st['lazy_to'], st['tab_c0'] = rd, dst.c0 - src.c0
+            st['z'] = None                 # the raw output lives in the reader's input slot
+            self.lazy_bn += 1
 
     # ------------------------------------------------------------------ helpers
     def view(self, t, inputs=None):
@@ -783,19 +816,28 @@ class Plan(object):
                     if prof is not None:
                         prof.end()
                     return
+                lazy = st.get('lazy_to')
+                in_tab = st.get('in_tab')               # this conv applies the BatchNorm + ReLU of its input's producer(s)
                 if st['wino_f'] == BF16:
                     ops.conv3x3_bf16(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=sk_ws)
                 elif st['wino_f'] == 4:
                     # (st['stats']: this launch also writes the BatchNorm statistics partials of its output)
-                    ops.conv3x3_wino4(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=sk_ws,
-                                      stats=st['stats'])
+                    ops.conv3x3_wino4(x, st['uf'], conv.bias, self.view(st['dst']) if lazy is not None else st['z'],
+                                      accumulate=acc, splitk=st['plan_f'] >> 8, ws=sk_ws, stats=st['stats'],
+                                      in_tab=in_tab, in_group_images=(self.N // self.groups) if in_tab is not None else 0)
                 elif st['wino_f']:
                     ops.conv3x3_wino(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=sk_ws)
                 else:
                     ops.conv3x3_igemm(x, st['wf'], conv.bias, st['z'], accumulate=acc, plan=st['plan_f'], ws=sk_ws)
                 if prof is not None:
                     prof.end()
-                self._bn_apply(st, bn, conv.bias if slabs else None, (st['plan_f'] >> 8) if slabs else 0, bn_ws, sk_ws)
+                if lazy is not None:               # statistics -> the reader's (scale, shift) table; no pass over the tensor
+                    zz = self.view(st['dst'])
+                    ops.bn_finalize_groups(self.N // self.groups, self.groups, zz.shape[1], zz.shape[2], zz.shape[3], bn,
+                                           st['stats'], st['stats_parts'] // self.groups, st['stats_parts'], conv.bias,
+                                           st['mean'], st['rstd'], st['scale'], st['shift'], lazy['in_tab'], st['tab_c0'])
+                else:
+                    self._bn_apply(st, bn, conv.bias if slabs else None, (st['plan_f'] >> 8) if slabs else 0, bn_ws, sk_ws)
             elif kind == 'convT':
                 conv, bn = st['conv'], st['bn']
                 ops.convT2x2_fwd(self.view(st['src'], inputs), conv.weight, conv.bias, st['z'])

@@ -298,6 +298,17 @@ def bn_train_fwd_groups(z, a, groups, bn, mean, rstd, scale, shift, ws, relu=Tru
     return a
 
 
+def bn_finalize_groups(n_per_group, groups, c, h, w, bn, parts, nparts, parts_stride, conv_bias, mean, rstd, scale, shift,
+                       tab, tab_c0):
+    """statistics -> per-group (scale, shift) entries [tab_c0, tab_c0 + c) of tab [groups, tab_C, 2] + running statistics;
+    no pass over z (the consumer conv applies the table in its loader: conv3x3_wino4(..., in_tab=))"""
+    assert tab.dim() == 3 and tab.shape[0] == groups and tab.shape[2] == 2 and tab.is_contiguous()
+    check(lib.aide_bn_finalize_groups(n_per_group, groups, c, h, w, ptr(parts), nparts, parts_stride, ptr(conv_bias),
+                                      ptr(bn.weight), ptr(bn.bias), bn.eps, bn.momentum, ptr(bn.running_mean),
+                                      ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(mean), ptr(rstd), ptr(scale),
+                                      ptr(shift), ptr(tab), tab.shape[1], tab_c0, stream_ptr()), 'bn_finalize_groups')
+
+
 def bn_train_fwd_parts(z, a, parts, nparts, conv_bias, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean,
                        rstd, scale, shift, relu=True, first=0, stride=None):
     """bn_train_fwd with the statistics emitted by the conv epilogue (conv3x3_wino4(..., stats=)): one pass over z.
@@ -519,9 +530,11 @@ def wino4_pack(w, need_dgrad=True):
     return uf, ud
 
 
-def conv3x3_wino4(x, u, bias, y, accumulate=False, splitk=-1, ws=None, stats=None, epi_scale=None, epi_relu=True):
+def conv3x3_wino4(x, u, bias, y, accumulate=False, splitk=-1, ws=None, stats=None, epi_scale=None, epi_relu=True,
+                  in_tab=None, in_group_images=0):
     """stats [cout * wino4_stats_parts * 2]: the launch also writes its BatchNorm statistics partials (non-split,
-    accumulate = 0, W >= 32); epi_scale [cout]: y = relu?(acc * epi_scale + bias) (eval-mode BatchNorm folded in)"""
+    accumulate = 0, W >= 32); epi_scale [cout]: y = relu?(acc * epi_scale + bias) (eval-mode BatchNorm folded in);
+    in_tab [n / in_group_images, cin, 2]: x is the raw output of the layer before, the loader applies relu(x * scale + shift)"""
     xp, xbs = planes(x)
     yp, ybs = planes(y)
     n, cin, h, w = x.shape
@@ -532,7 +545,8 @@ def conv3x3_wino4(x, u, bias, y, accumulate=False, splitk=-1, ws=None, stats=Non
     if splitk > 1 and ws is None:
         ws = torch.empty(lib.aide_conv3x3_ws_bytes(n, h, w, cout, splitk) // 4, device=x.device, dtype=torch.float32)
     check(lib.aide_conv3x3_wino4(xp, xbs, ptr(u), ptr(bias), yp, ybs, n, cin, h, w, cout, int(accumulate), splitk,
-                                 ptr(ws), ptr(stats), ptr(epi_scale), int(bool(epi_relu)), stream_ptr()), 'conv3x3_wino4')
+                                 ptr(ws), ptr(stats), ptr(epi_scale), int(bool(epi_relu)), ptr(in_tab), int(in_group_images),
+                                 stream_ptr()), 'conv3x3_wino4')
     return y
 
 

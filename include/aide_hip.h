@@ -59,11 +59,17 @@ int aide_conv3x3_wino4_pack_multi(const void* descs, int n, int64_t total_blocks
  * W >= 32, AIDE_ERR_ARG otherwise): the epilogue also writes, per output channel and workgroup tile, the fp32 sum and sum
  * of squares of its pre-bias outputs -- the BatchNorm statistics for aide_bn_train_fwd_parts (netblocks.py:25,27) without a
  * pass over z.  epi_scale (NULL, or [Cout]; accumulate = 0 and bias given): y = relu?(acc * epi_scale[co] + bias[co]), the
- * folded eval-mode BatchNorm of aide_bn_eval_fold (a split launch applies it in its slab reduce).  Both are plain
- * arguments of THIS launch: the library keeps no state between calls. */
+ * folded eval-mode BatchNorm of aide_bn_eval_fold (a split launch applies it in its slab reduce).
+ * in_bn_tab (NULL, or [N / in_bn_group_images][Cin][2] = (scale, shift) per image group and INPUT channel; Cin <= 1024, not
+ * for W == 16): x is the RAW output z of the layer before and the loader stages relu(x * scale + shift) -- that layer's
+ * BatchNorm + ReLU applied on the way in (SURVEY 8b in_prologue{bn_relu}; netblocks.py:25-28), its normalised output never
+ * written: the forward-only augmentation passes of the co-teaching loop (trainchaos_proposed_30cases1labeled.py:263-281)
+ * keep nothing for a backward pass.  Channels that are already activations get (1, 0).  Table: aide_bn_finalize_groups.
+ * All of these are plain arguments of THIS launch: the library keeps no state between calls. */
 int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float* bias, float* y, int64_t y_bs,
                        int N, int Cin, int H, int W, int Cout, int accumulate, int splitk, float* ws,
-                       float* stats_parts, const float* epi_scale, int epi_relu, aide_stream_t stream);
+                       float* stats_parts, const float* epi_scale, int epi_relu, const float* in_bn_tab,
+                       int in_bn_group_images, aide_stream_t stream);
 /* descs as above with {w, uf, ud}; an entry occupies aide_conv3x3_wino_pack_blocks(Co, Ci) workgroups */
 int aide_conv3x3_wino_pack_blocks(int Co, int Ci);
 int aide_conv3x3_wino_pack_multi(const void* descs, int n, int64_t total_blocks, aide_stream_t stream);
@@ -230,6 +236,14 @@ int aide_bn_train_fwd_groups(const void* z, int z_bf16, int64_t z_bs, void* a, i
                              const float* conv_bias, const float* gamma, const float* beta, float eps, float momentum,
                              float* running_mean, float* running_var, long long* num_batches_tracked, float* mean,
                              float* rstd, float* scale, float* shift, int relu, void* ws, aide_stream_t stream);
+/* BatchNorm(train) WITHOUT its pass over z: the conv epilogue's statistics of a stacked batch (parts / nparts / parts_stride /
+ * conv_bias as above; N = images per group) become the per-group (scale, shift) entries [tab_c0, tab_c0 + C) of
+ * tab[groups][tab_C][2] -- the table the consumer convolution's loader applies (in_bn_tab of aide_conv3x3_wino4) -- and the
+ * running statistics / num_batches_tracked move once per group, in order. */
+int aide_bn_finalize_groups(int N, int groups, int C, int H, int W, const float* parts, int nparts, int parts_stride,
+                            const float* conv_bias, const float* gamma, const float* beta, float eps, float momentum,
+                            float* running_mean, float* running_var, long long* num_batches_tracked, float* mean,
+                            float* rstd, float* scale, float* shift, float* tab, int tab_C, int tab_c0, aide_stream_t stream);
 int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
                              int H, int W, const float* scale, const float* shift, int relu, aide_stream_t stream);
 int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz,

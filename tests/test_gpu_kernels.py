@@ -333,6 +333,46 @@ def test_conv3x3_winograd4_fwd_dgrad(dev, case):
         _close(dx, xr.grad + 1.0, rtol=1e-4, what='wino4 dgrad accumulate %s' % (case,))
 
 
+@pytest.mark.parametrize('case', [(4, 64, 64, 32, 32, 2), (2, 128, 64, 64, 64, 1), (6, 16, 128, 16, 32, 3), (4, 64, 128, 80, 80, 2),
+                                  (2, 96, 192, 40, 48, 2), (4, 64, 64, 40, 40, 4), (2, 64, 32, 60, 100, 1),      # canvas tiles
+                                  (3, 32, 96, 24, 28, 1), (2, 1024, 64, 16, 32, 2)])
+def test_conv3x3_winograd4_input_batchnorm(dev, case):
+    """F(4x4) forward whose loader applies relu(x * scale + shift) with a per-group, per-input-channel table (in_bn_tab:
+    the producing layer's BatchNorm + ReLU on the way in) == the convolution of the materialised activation, BIT FOR BIT
+    (same fmaf / max per element, same kernel after the staging) -- zero padding included: BN(0) != 0, the halo must stay 0.
+    Negative scales, split-K, both tile shapes, a 1024-channel input (the table limit), several image groups."""
+    from aide_amd import ops
+    n, ci, co, h, w, groups = case
+    g = torch.Generator().manual_seed(ci + 13 * co + h)
+    z = torch.randn(n, ci, h, w, generator=g).to(dev)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * (1.0 / (3.0 * ci ** 0.5))).to(dev)
+    b = torch.randn(co, generator=g).to(dev)
+    tab = torch.randn(groups, ci, 2, generator=g).to(dev)          # (scale, shift): both signs
+    tab[0, 0, 0] = 0.0
+    ng = n // groups
+    act = torch.empty_like(z)
+    for gi in range(groups):
+        sl = slice(gi * ng, (gi + 1) * ng)
+        # the apply kernel's arithmetic: fmaf(z, scale, shift), then max(., 0)
+        act[sl] = torch.clamp_min(torch.addcmul(tab[gi, :, 1].view(1, ci, 1, 1), z[sl], tab[gi, :, 0].view(1, ci, 1, 1)), 0.0)
+    from aide_amd import ops as O
+    a2 = torch.empty_like(z)                                       # ... through the library's own apply kernel, per group
+    for gi in range(groups):
+        sl = slice(gi * ng, (gi + 1) * ng)
+        O.bn_relu_apply(z[sl], a2[sl], tab[gi, :, 0].contiguous(), tab[gi, :, 1].contiguous(), True)
+    uf, _ = ops.wino4_pack(wt, need_dgrad=False)
+    for splitk in (1, 2):
+        if (ci // 8) % splitk:
+            continue
+        y_ref = torch.empty(n, co, h, w, device=dev)
+        ops.conv3x3_wino4(a2, uf, b, y_ref, splitk=splitk)
+        y = torch.full((n, co, h, w), 7.0, device=dev)
+        ops.conv3x3_wino4(z, uf, b, y, splitk=splitk, in_tab=tab, in_group_images=ng)
+        assert torch.equal(y, y_ref), 'input BatchNorm in the loader differs from the materialised form (splitk %d) %s' % (splitk, case)
+    yr = F.conv2d(act.cpu(), wt.cpu(), b.cpu(), padding=1)
+    _close(y, yr, rtol=1e-4, what='wino4 with input BatchNorm vs aten %s' % (case,))
+
+
 @pytest.mark.parametrize('case', [(2, 64, 64, 32, 32), (1, 128, 64, 64, 64), (2, 64, 128, 16, 16), (1, 256, 256, 16, 16),
                                   (1, 64, 128, 80, 80), (4, 512, 512, 16, 16), (1, 96, 160, 40, 24), (2, 64, 64, 6, 12)])
 def test_conv3x3_wgrad_winograd(dev, case):

@@ -263,6 +263,48 @@ def test_grouped_forward_equals_sequential(dev, kind):
         net.forward_groups([groups[0], tuple(t[:1] for t in groups[1])])
 
 
+@pytest.mark.parametrize('kind,size', [('fuseunet', 256), ('unet', 320)])
+def test_lazy_batchnorm_in_the_reader_is_bit_identical(dev, kind, size):
+    """Forward-only stacked passes apply the BatchNorm + ReLU of a layer whose only reader is an F(4x4) convolution in that
+    convolution's loader (engine.LAZY_BN; conv3x3_wino4 in_bn_tab) instead of a pass over the tensor: same arithmetic
+    element for element (fmaf, max), so outputs, running statistics and num_batches_tracked equal the materialised form
+    bit for bit -- also for border tiles (zero padding must stay zero after the affine map) and the 20 x 20 canvas tiles."""
+    import copy
+    from aide_amd import engine
+    from aide_amd.models_twomodalinputs import fuseunet
+    from aide_amd.models_singlemodalinput import UNet
+    torch.manual_seed(2)
+    net = (fuseunet(2) if kind == 'fuseunet' else UNet(2)).to(dev)
+    with torch.no_grad():                              # non-trivial affine parameters, negative scales included
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.randn(m.weight.shape, device=dev) * 0.5 + 0.75)
+                m.bias.copy_(torch.randn(m.bias.shape, device=dev) * 0.3)
+    ref = copy.deepcopy(net)
+    g = torch.Generator().manual_seed(9)
+    nin = 2 if kind == 'fuseunet' else 1
+    groups = [tuple(torch.randn(2, 3, size, size, generator=g).to(dev) for _ in range(nin)) for _ in range(4)]
+    net.train(); ref.train()
+    was = engine.LAZY_BN[0]
+    try:
+        engine.LAZY_BN[0] = True
+        outs = net.forward_groups(groups)
+        plan = [p for p in net.engine.plans.values() if p.groups == 4][0]
+        assert plan.lazy_bn >= 4, plan.lazy_bn
+        outs2 = net.forward_groups(groups)             # replayed tape, running statistics move on
+        engine.LAZY_BN[0] = False
+        refs = ref.forward_groups(groups)
+        assert [p for p in ref.engine.plans.values() if p.groups == 4][0].lazy_bn == 0
+        refs2 = ref.forward_groups(groups)
+    finally:
+        engine.LAZY_BN[0] = was
+    torch.cuda.synchronize()
+    for a, b in zip(outs + outs2, refs + refs2):
+        assert torch.equal(a, b)
+    for (k, p), (_, q) in zip(net.named_buffers(), ref.named_buffers()):
+        assert torch.equal(p, q), k
+
+
 def test_rank_streams_avoid_shared_hardware_queues(dev):
     """A data-parallel rank measures which streams share a hardware queue (aide_amd/streams.py) before its engine builds a
     plan: the weight-gradient stream it hands the engine runs beside the main stream AND beside RCCL's own stream, the lane
