@@ -537,7 +537,10 @@ struct BgArgs {
 
 // R = image rows of dz per stage (4, or 2: half the staging registers -> two workgroups per CU); NWCO = co blocks of 32
 // per workgroup: 2 (64 co x 64 ci, 4 waves) or 4 (128 co x 64 ci, 8 waves = two per SIMD: the four co blocks share one
-// x tile, halving the x bytes through L2 / L1 / LDS per MFMA, and a second wave per SIMD covers the other's stalls).
+// x tile, halving the x bytes through L2 / L1 / LDS per MFMA, and a second wave per SIMD covers the other's stalls), or
+// 1 (32 co x 64 ci, 2 waves, two workgroups per CU) for the 32-channel first-level layers: in the 64 x 64 tile three of four
+// waves multiplied zeros there (32->32 @512x512 x8: 0.195 ms for 268 MB of operands); a wave whose 32 input channels lie
+// beyond Ci skips its MFMAs, and the layer is bound by streaming dz and x once.
 //
 // Which operand carries the +-1 column shift of the taps (round 3): dW[kh][kw] = sum_q dz[q - (kw - 1)] x[q + (kh - 1) W], q
 // running over the ALIGNED pixels of the stage -- the shift sits on dz, whose shifted fragment serves all three kh, instead
@@ -546,7 +549,7 @@ struct BgArgs {
 // column -1 (one aligned 32-byte window per (row, k-step): kw = 2 is the window, kw = 1 four v_alignbit, kw = 0 a register
 // slice), zero where the neighbouring column lies outside the image, and the x rows are plain aligned copies with their row halo.
 template <int R, int NWCO> struct GCfg {
-    static constexpr int NT = 128 * NWCO;            // threads
+    static constexpr int NT = 64 * (NWCO == 1 ? 2 : 2 * NWCO);   // threads: NWCO co blocks x 2 ci blocks of 32
     static constexpr int TCO = 32 * NWCO;            // output channels per workgroup
     static constexpr int DZP = R * 5 + 1;            // slots per dz channel: R rows x 5 slots (columns -1 .. 38); odd: conflict-free
     static constexpr int XP = (R + 2) * 4 + 1;       // slots per x channel: R + 2 rows x 4 slots (columns 0 .. 31)
@@ -703,6 +706,8 @@ __global__ __launch_bounds__(128 * NWCO, (R == 2 && NWCO == 2) ? 2 : 1) void con
 
     const int la = (wco * 32 + j) * G::DZP + half;
     const int lb = G::DZS + (wci * 32 + j) * G::XP + half;
+    // (NWCO == 1) a wave whose whole ci block lies beyond Ci has nothing to multiply: it only stages
+    const bool mm = NWCO != 1 || ci0 + wci * 32 < g.Ci;
 
     set_chunk(c_begin);
 #pragma unroll
@@ -747,11 +752,13 @@ __global__ __launch_bounds__(128 * NWCO, (R == 2 && NWCO == 2) ? 2 : 1) void con
             s1[3] = __builtin_amdgcn_alignbit(w1v[0], w0v[3], 16);
             s0[0] = w0v[1]; s0[1] = w0v[2]; s0[2] = w0v[3]; s0[3] = w1v[0];   // kw = 0: dz[q+1 .. q+8]
             const bf16x8 a2 = __builtin_bit_cast(bf16x8, w0v), a1 = __builtin_bit_cast(bf16x8, s1), a0 = __builtin_bit_cast(bf16x8, s0);
+            if (mm) {
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, xf[kh], acc[kh * 3 + 0], 0, 0, 0);
-                acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xf[kh], acc[kh * 3 + 1], 0, 0, 0);
-                acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xf[kh], acc[kh * 3 + 2], 0, 0, 0);
+                for (int kh = 0; kh < 3; ++kh) {
+                    acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, xf[kh], acc[kh * 3 + 0], 0, 0, 0);
+                    acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xf[kh], acc[kh * 3 + 1], 0, 0, 0);
+                    acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xf[kh], acc[kh * 3 + 2], 0, 0, 0);
+                }
             }
             // staging: chunk + 1 registers -> the other buffer, then re-issue their loads for chunk + 2
 #pragma unroll
@@ -811,6 +818,7 @@ int launch_wgrad_bf16(BgArgs g, hipStream_t stream) {
 // 1024->512 @64x64 x8); below that it doubles the split count for nothing.  co_blocks: the caller's choice (2 or 4; 0 = this
 // rule).  (R = 2 rows per stage -- two workgroups per CU -- measured 3.5 % behind on the C5 step and is not instantiated.)
 int wgrad_bf16_nwco(int N, int Co, int Ci, int H, int W, int co_blocks) {
+    if (co_blocks == 1 || (co_blocks == 0 && Co <= 32)) return 1;
     if (co_blocks == 2 || Co % 128 != 0) return 2;
     if (co_blocks == 4) return 4;
     return 18.0 * N * H * W * (double)Co * Ci >= 1.5e11 ? 4 : 2;
@@ -914,7 +922,8 @@ int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W, int co_b
     const int tco = 32 * wgrad_bf16_nwco(N, Co, Ci, H, W, co_blocks);
     const long tiles = (long)((Co + tco - 1) / tco) * ((Ci + 63) / 64);
     const long chunks = (long)N * (H / 4) * (W / 32);
-    const long target = 192;
+    const long target = tco == 32 ? 512 : 192;   // (the 32-co tile: two workgroups per CU, and these first-level layers are the tail of
+                                                 // the backward pass -- nothing is left on the main stream to leave CUs to)
     long s = (target + tiles - 1) / tiles;       // fewer workgroups than CUs: the kernel runs on the side stream and leaves
                                                  // CUs to the dependent chain (same-box C5 step: 256 -> 439.9, 224 -> 442.9,
                                                  // 192 -> 444.4, 128 -> 428; 512 / 1024 measured 6 % / 16 % slower: twice the
@@ -934,7 +943,7 @@ int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, co
                                   float* dw, int N, int Co, int Ci, int H, int W, float* ws, int co_blocks, void* queue,
                                   hipStream_t stream) {
     if (!dz || !a || !dw || !ws || N <= 0 || !aide_conv3x3_wgrad_bf16_supported(Co, Ci, H, W)) return AIDE_ERR_ARG;
-    if (co_blocks != 0 && co_blocks != 2 && co_blocks != 4) return AIDE_ERR_ARG;
+    if (co_blocks != 0 && co_blocks != 1 && co_blocks != 2 && co_blocks != 4) return AIDE_ERR_ARG;
     if ((dz_bs % (dz_bf16 ? 8 : 4)) || (a_bs % (a_bf16 ? 8 : 4))) return AIDE_ERR_ARG;
     if (a_bf16 && aide_conv3x3_wgrad_stem_supported(Co, Ci, H, W)) return AIDE_ERR_ARG;   // stems read the fp32 images
     if (aide_conv3x3_wgrad_stem_supported(Co, Ci, H, W))                        // Ci <= 3
@@ -949,7 +958,9 @@ int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, co
     int rc;
 #define AIDE_WG(RR, NW) (dz_bf16 ? (a_bf16 ? launch_wgrad_bf16<RR, true, true, NW>(g, stream) : launch_wgrad_bf16<RR, true, false, NW>(g, stream)) \
                                  : (a_bf16 ? launch_wgrad_bf16<RR, false, true, NW>(g, stream) : launch_wgrad_bf16<RR, false, false, NW>(g, stream)))
-    if (wgrad_bf16_nwco(N, Co, Ci, H, W, co_blocks) == 4) rc = AIDE_WG(4, 4);
+    const int nwco = wgrad_bf16_nwco(N, Co, Ci, H, W, co_blocks);
+    if (nwco == 4) rc = AIDE_WG(4, 4);
+    else if (nwco == 1) rc = AIDE_WG(4, 1);
     else rc = AIDE_WG(4, 2);
 #undef AIDE_WG
     if (rc != 0) return rc;

@@ -137,8 +137,9 @@ int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint1
                             int y_bf16, int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,
                             float* ws, aide_stream_t stream);
 int aide_conv3x3_wgrad_bf16_supported(int Co, int Ci, int H, int W);
-/* co_blocks: output-channel blocks of 32 per workgroup tile -- 2 (64 co x 64 ci, 4 waves), 4 (128 co x 64 ci, 8 waves; needs
- * Co % 128 == 0, else 2 is used) or 0 = the built-in rule (4 from 150 GFLOP per launch); the split count depends on it */
+/* co_blocks: output-channel blocks of 32 per workgroup tile -- 1 (32 co x 64 ci, 2 waves, two workgroups per CU: the
+ * 32-channel first-level layers), 2 (64 co x 64 ci, 4 waves), 4 (128 co x 64 ci, 8 waves; needs Co % 128 == 0, else 2 is
+ * used) or 0 = the built-in rule (1 for Co <= 32, 4 from 150 GFLOP per launch); the split count depends on it */
 int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W, int co_blocks);
 size_t aide_conv3x3_wgrad_bf16_ws_bytes(int N, int Co, int Ci, int H, int W, int co_blocks);
 int aide_conv3x3_wgrad_bf16(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,

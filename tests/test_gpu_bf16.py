@@ -333,6 +333,23 @@ def test_conv3x3_wgrad_bf16_wide_tile(dev, case):
     _close(dw_wide, dw_ref, 2e-5, 'wide vs 64x64 tile %s' % (case,))
 
 
+@pytest.mark.parametrize('case', [(2, 32, 32, 32, 32), (1, 32, 64, 8, 64), (2, 32, 40, 16, 32), (1, 64, 32, 16, 64), (2, 96, 24, 8, 32)])
+def test_conv3x3_wgrad_bf16_narrow_tile(dev, case):
+    """the 32 co x 64 ci (2-wave) tile of the 32-channel first-level layers (co_blocks = 1; the default for Co <= 32), also
+    forced onto wider layers: several co tiles, a ci block that is skipped or partly masked"""
+    test_conv3x3_wgrad_bf16(dev, case, co_blocks=1)
+    from aide_amd import ops
+    n, co, ci, h, w = case
+    g = torch.Generator().manual_seed(3)
+    x16 = torch.randn(n, ci - ci % 8, h, w, generator=g).to(dev).bfloat16()
+    dz16 = torch.randn(n, co, h, w, generator=g).to(dev).bfloat16()
+    dw1 = torch.empty(co, x16.shape[1], 3, 3, device=dev)
+    ops.conv3x3_wgrad_bf16(dz16, x16, dw1, co_blocks=1)
+    dw2 = torch.empty_like(dw1)
+    ops.conv3x3_wgrad_bf16(dz16, x16, dw2, co_blocks=2)
+    _close(dw1, dw2, 2e-5, '32-co vs 64x64 tile %s' % (case,))
+
+
 @pytest.mark.parametrize('case', WGRAD_CASES)
 def test_conv3x3_wgrad_bf16(dev, case, co_blocks=0):
     from aide_amd import ops
