@@ -169,8 +169,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
     f32x2 tp[6][3];
     f32x2 tq[9];
     auto v_read = [&](int r, int xo) {                     // one 16-byte + one 8-byte read per patch row
-        const f32x4 q = *reinterpret_cast<const f32x4*>(lds + xo + r * G4_RS);
-        const f32x2 e = *reinterpret_cast<const f32x2*>(lds + xo + r * G4_RS + 4);
+        // (xo is a multiple of four floats by construction, but it travels through an opaque register: without the alignment
+        // spelled out hipcc emitted three ds_read2_b32 per row -- 18 per chunk, each 4-way bank-conflicted: the lanes' row
+        // starts are 16 bytes apart, i.e. 8 of the 32 dword banks -- where the layout was built for a conflict-free
+        // ds_read_b128 (G4_DS = 16 mod 64) plus one ds_read_b64)
+        const float* row = static_cast<const float*>(__builtin_assume_aligned(lds + xo + r * G4_RS, 16));
+        const f32x4 q = *reinterpret_cast<const f32x4*>(row);
+        const f32x2 e = *reinterpret_cast<const f32x2*>(row + 4);
         tp[r][0] = f32x2{q[0], q[1]}; tp[r][1] = f32x2{q[2], q[3]}; tp[r][2] = e;
     };
     auto v_math = [&](auto HS) {

@@ -27,8 +27,29 @@ WG_PUT = "                if (op < NOPS) put(op, nxt);\n"
 WG_FETCH = "                if (op < NOPS) fetch(op);\n"
 WG_BARRIER = "            __builtin_amdgcn_sched_barrier(0);\n        }\n        __syncthreads();\n        cur ^= 1;\n"
 
+# ---- conv3x3_wgrad4_kernel: which LDS access class carries the bank conflicts
+G4_PUT = """                    if (3 * (st - 31) + q < 14) put_d(3 * (st - 31) + q, rawc);
+"""
+G4_VSTORE = "            if (st >= 15 && st < 24) v_store(st - 15, 1 - kcur);\n"
+G4_ZSTORE = """                for (int q = 0; q < 2; ++q) z_store(2 * (st - 21) + q, 1 - kcur);
+"""
+G4_ZNONE = "                for (int q = 0; q < 2; ++q) { }\n"
+G4_VREAD = "            if (st >= 1 && st < 7) v_read(st - 1, kcur ? xr0 : xr1);\n"
+G4_FRAG = "            if (w == 0 && gq + 2 < 9) frag(gq + 2, (gq + 2) % 3);\n"
+
 # name -> (source file, [(old, new), ...])
 PROBES = {
+    'g4_noput': ('conv3x3_wgrad4.hip', [(G4_PUT, '                    { }\n')]),                 # no raw-tile stores (14 ds_write_b32)
+    'g4_novstore': ('conv3x3_wgrad4.hip', [(G4_VSTORE, '')]),                              # no V stores (9 ds_write_b64)
+    'g4_nozstore': ('conv3x3_wgrad4.hip', [(G4_ZSTORE, G4_ZNONE)]),          # no ZT stores (12 b64 + 12 b32)
+    'g4_novread': ('conv3x3_wgrad4.hip', [(G4_VREAD, '')]),                                # no patch reads (6 x b128 + b64)
+    'g4_nofrag': ('conv3x3_wgrad4.hip', [(G4_FRAG, '')]),                                  # fragment reads of the first two pairs only
+    # V stores as single ds_write_b64 (inline asm: hipcc cannot pair them into ds_write2st64_b64) -- are the conflicts the
+    # counter attributes to the V stores a property of the paired form (both halves of a pair hit the same banks)?
+    'g4_vunmerged': ('conv3x3_wgrad4.hip', [
+        ("    auto v_store = [&](int m, int set) { lds2[(set ? vb1 : vb0) + m * 128] = tq[m]; };\n",
+         "    auto v_store = [&](int m, int set) { asm volatile(\"ds_write_b64 %0, %1 offset:%2\" :: \"v\"((set ? vb1 : vb0) * 8), \"v\"(tq[m]), \"i\"(m * 1024) : \"memory\"); };\n")]),
+    'g4_nostores': ('conv3x3_wgrad4.hip', [(G4_PUT, '                    { }\n'), (G4_VSTORE, ''), (G4_ZSTORE, G4_ZNONE)]),
     'wg_nomfma': ('conv3x3_bf16.hip', [(WG_MFMA, WG_NOMFMA)]),
     'wg_nofetch': ('conv3x3_bf16.hip', [(WG_FETCH, '')]),
     'wg_noput': ('conv3x3_bf16.hip', [(WG_PUT, '')]),
