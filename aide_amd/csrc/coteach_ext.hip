@@ -102,6 +102,82 @@ __global__ __launch_bounds__(256) void region_ce_bwd_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------- region CE, any pooling window and class count
+// Coteachingloss_dropregionce(scale) pools logits (per class) and targets with MaxPool2d(kernel = stride = (KH, KW),
+// ceil_mode=True) (utils/coteach_loss.py:171-177): ceil(H / KH) x ceil(W / KW) regions, the last row / column of windows
+// clipped at the image border.  aux: C + 1 words per region -- the plane offset of every class' maximum (first maximum in
+// scan order, like max_pool2d) and (pooled target | ignored << 16).
+template <int MAXC>
+__global__ __launch_bounds__(256) void region_ce_win_kernel(const float* __restrict__ z, long zb,
+                                                            const long long* __restrict__ t, long tb, int C, int H, int W,
+                                                            int KH, int KW, int ignore_index, long total,
+                                                            float* __restrict__ loss, int* __restrict__ aux) {
+    const int Wp = (W + KW - 1) / KW, Hp = (H + KH - 1) / KH, P = Hp * Wp, HW = H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / P;
+        const int p = (int)(i - n * P), ph = p / Wp, pw = p - ph * Wp;
+        const int h0 = ph * KH, w0 = pw * KW, h1 = min(h0 + KH, H), w1 = min(w0 + KW, W);
+        float m[MAXC];
+        for (int c = 0; c < C; ++c) {
+            const float* q = z + n * zb + (long)c * HW;
+            float best = q[h0 * W + w0]; int at = h0 * W + w0;
+            for (int hh = h0; hh < h1; ++hh)
+                for (int ww = w0; ww < w1; ++ww) {
+                    const float v = q[hh * W + ww];
+                    if (v > best) { best = v; at = hh * W + ww; }
+                }
+            m[c] = best;
+            aux[i * (C + 1) + c] = at;
+        }
+        long long tp = t[n * tb + h0 * W + w0];
+        for (int hh = h0; hh < h1; ++hh)
+            for (int ww = w0; ww < w1; ++ww) { const long long v = t[n * tb + hh * W + ww]; tp = v > tp ? v : tp; }
+        const bool ign = tp == ignore_index;
+        float l = 0.f;
+        if (!ign) {                                   // lse(m) - m[tp], the arithmetic of log_softmax + nll_loss
+            float mx = m[0];
+            for (int c = 1; c < C; ++c) mx = fmaxf(mx, m[c]);
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s += expf(m[c] - mx);
+            l = (mx + logf(s)) - m[(int)tp];
+        }
+        loss[i] = l;
+        aux[i * (C + 1) + C] = (int)(ign ? 0 : tp) | (ign ? 1 << 16 : 0);
+    }
+}
+
+// dz = coeff * mask * dCE / d(pooled logits) at the arg-max positions, 0 everywhere else (the windows tile the plane)
+template <int MAXC>
+__global__ __launch_bounds__(256) void region_ce_win_bwd_kernel(const float* __restrict__ z, long zb,
+                                                                const int* __restrict__ aux,
+                                                                const unsigned char* __restrict__ mask,
+                                                                const float* __restrict__ coeff, int C, int H, int W, int KH,
+                                                                int KW, long total, float* __restrict__ dz, long db) {
+    const int Wp = (W + KW - 1) / KW, Hp = (H + KH - 1) / KH, P = Hp * Wp, HW = H * W;
+    const float cf = coeff[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / P;
+        const int p = (int)(i - n * P), ph = p / Wp, pw = p - ph * Wp;
+        const int h0 = ph * KH, w0 = pw * KW, h1 = min(h0 + KH, H), w1 = min(w0 + KW, W);
+        const int* a = aux + i * (C + 1);
+        const int tw = a[C], tp = tw & 0xffff;
+        const bool live = mask[i] && !(tw >> 16);
+        float m[MAXC], g[MAXC];
+        if (live) {
+            float mx = -3.4e38f;
+            for (int c = 0; c < C; ++c) { m[c] = z[n * zb + (long)c * HW + a[c]]; mx = fmaxf(mx, m[c]); }
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s += expf(m[c] - mx);
+            for (int c = 0; c < C; ++c) g[c] = cf * (expf(m[c] - mx) / s - (c == tp ? 1.f : 0.f));
+        }
+        for (int c = 0; c < C; ++c) {
+            float* d = dz + n * db + (long)c * HW;
+            for (int hh = h0; hh < h1; ++hh)
+                for (int ww = w0; ww < w1; ++ww) d[hh * W + ww] = (live && hh * W + ww == a[c]) ? g[c] : 0.f;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- k smallest of a segment (+ sum of a second array)
 __device__ __forceinline__ unsigned fkey(float v) {
     const unsigned b = __float_as_uint(v);
@@ -342,6 +418,25 @@ int aide_region_ce_bwd(const float* z, int64_t zb, const unsigned char* aux, con
     const long total = (long)N * (H / 2) * (W / 2);
     hipLaunchKernelGGL(region_ce_bwd_kernel, dim3(grid1(total)), dim3(256), 0, stream, z, (long)zb, aux, mask, coeff,
                        H, W, total, dz, (long)db);
+    return aide_launch_status();
+}
+
+int aide_region_ce_fwd_win(const float* z, int64_t zb, const long long* t, int64_t tb, int C, int N, int H, int W, int KH,
+                           int KW, int ignore_index, float* loss, int* aux, hipStream_t stream) {
+    if (!z || !t || !loss || !aux || N <= 0 || C < 2 || C > 8 || KH < 1 || KW < 1 || H < 1 || W < 1 || (long)H * W >= (1L << 31))
+        return AIDE_ERR_ARG;
+    const long total = (long)N * ((H + KH - 1) / KH) * ((W + KW - 1) / KW);
+    hipLaunchKernelGGL(region_ce_win_kernel<8>, dim3(grid1(total)), dim3(256), 0, stream, z, (long)zb, t, (long)tb, C, H, W, KH,
+                       KW, ignore_index, total, loss, aux);
+    return aide_launch_status();
+}
+
+int aide_region_ce_bwd_win(const float* z, int64_t zb, const int* aux, const unsigned char* mask, const float* coeff, int C,
+                           int N, int H, int W, int KH, int KW, float* dz, int64_t db, hipStream_t stream) {
+    if (!z || !aux || !mask || !coeff || !dz || N <= 0 || C < 2 || C > 8 || KH < 1 || KW < 1) return AIDE_ERR_ARG;
+    const long total = (long)N * ((H + KH - 1) / KH) * ((W + KW - 1) / KW);
+    hipLaunchKernelGGL(region_ce_win_bwd_kernel<8>, dim3(grid1(total)), dim3(256), 0, stream, z, (long)zb, aux, mask, coeff, C,
+                       H, W, KH, KW, total, dz, (long)db);
     return aide_launch_status();
 }
 

@@ -98,12 +98,13 @@ class _RegionCEFn(torch.autograd.Function):
     """mean over images and kept regions of the region CE of `z`, the kept set chosen by the OTHER net's losses."""
 
     @staticmethod
-    def forward(ctx, z, aux, loss_self, loss_other, keep):
+    def forward(ctx, z, aux, loss_self, loss_other, keep, win=None):
         n, _, h, w = z.shape
-        p = (h // 2) * (w // 2)
+        p = loss_self.numel() // n
         mask, sums, _ = _select(loss_other, loss_self, n, p, k_host=keep)
         ctx.save_for_backward(z, aux, mask)
         ctx.denom = float(n * keep)
+        ctx.win = win
         return (sums.sum() / ctx.denom).float() if keep > 0 else sums.sum().float() * float('nan')
 
     @staticmethod
@@ -112,23 +113,26 @@ class _RegionCEFn(torch.autograd.Function):
         n, c, h, w = z.shape
         coeff = (g.reshape(1).float() / ctx.denom).contiguous()
         dz = torch.empty_like(z)
-        if c == 2:
+        if ctx.win is not None:
+            check(lib.aide_region_ce_bwd_win(ptr(z), c * h * w, ptr(aux), ptr(mask), ptr(coeff), c, n, h, w, ctx.win[0],
+                                             ctx.win[1], ptr(dz), c * h * w, stream_ptr()), 'region_ce_bwd_win')
+        elif c == 2:
             check(lib.aide_region_ce_bwd(ptr(z), 2 * h * w, ptr(aux), ptr(mask), ptr(coeff), n, h, w, ptr(dz), 2 * h * w,
                                          stream_ptr()), 'region_ce_bwd')
         else:
             check(lib.aide_region_ce_bwd_mc(ptr(z), c * h * w, ptr(aux), ptr(mask), ptr(coeff), c, n, h, w, ptr(dz),
                                             c * h * w, stream_ptr()), 'region_ce_bwd_mc')
-        return dz, None, None, None, None
+        return dz, None, None, None, None, None
 
 
 class Coteachingloss_dropregionce(nn.Module):
-    """utils/coteach_loss.py:163-196.  Cross entropy on 2x2 max-pooled regions (logits per class, targets); per image
-    the `int((1 - forget_rate) * P)` regions with the smallest loss of the other net are kept; mean over all kept."""
+    """utils/coteach_loss.py:163-196.  Cross entropy on max-pooled regions (logits per class, targets): window = stride =
+    (int(H / int(H * scale)), int(W / int(W * scale))), ceil_mode (:171-174; the default scale 0.5 gives 2x2 windows, which
+    have kernels of their own); per image the `int((1 - forget_rate) * P)` regions with the smallest loss of the other net
+    are kept; mean over all kept."""
 
     def __init__(self, scale=0.5, reduction='none'):
         super(Coteachingloss_dropregionce, self).__init__()
-        if scale != 0.5:
-            raise NotImplementedError('aide_amd.Coteachingloss_dropregionce implements the reference default scale=0.5')
         if reduction != 'none':
             raise RuntimeError("Coteachingloss_dropregionce needs reduction='none' (the reference's .view(N, -1), "
                                "utils/coteach_loss.py:178, fails on a reduced loss)")
@@ -140,11 +144,25 @@ class Coteachingloss_dropregionce(nn.Module):
             raise RuntimeError('Coteachingloss_dropregionce: logits of different shapes')
         tg, t_bs = _seg._targets(targets, z1)
         n, c, h, w = z1.shape
-        if h % 2 or w % 2:
-            raise RuntimeError('Coteachingloss_dropregionce: H and W must be even')
+        ph_, pw_ = int(h * self.scale), int(w * self.scale)              # the reference's patch_w / patch_h (:172)
+        if ph_ < 1 or pw_ < 1:
+            raise ZeroDivisionError('Coteachingloss_dropregionce: scale %r leaves no patch (the reference divides by zero)' % (self.scale,))
+        kh, kw = int(h / ph_), int(w / pw_)
+        dev = z1.device
+        if (kh, kw) != (2, 2) or h % 2 or w % 2:
+            # any other window (and odd sizes, whose last window is clipped): the general kernels
+            p = ((h + kh - 1) // kh) * ((w + kw - 1) // kw)
+            keep = int((1 - forget_rate) * p)
+            with torch.no_grad():
+                l1, l2 = torch.empty(n * p, device=dev), torch.empty(n * p, device=dev)
+                a1 = torch.empty(n * p * (c + 1), device=dev, dtype=torch.int32)
+                a2 = torch.empty_like(a1)
+                for z, l, a in ((z1, l1, a1), (z2, l2, a2)):
+                    check(lib.aide_region_ce_fwd_win(ptr(z), c * h * w, ptr(tg), t_bs, c, n, h, w, kh, kw, 255, ptr(l), ptr(a),
+                                                     stream_ptr()), 'region_ce_fwd_win')
+            return (_RegionCEFn.apply(z1, a1, l1, l2, keep, (kh, kw)), _RegionCEFn.apply(z2, a2, l2, l1, keep, (kh, kw)))
         p = (h // 2) * (w // 2)
         keep = int((1 - forget_rate) * p)
-        dev = z1.device
         with torch.no_grad():
             l1, l2 = torch.empty(n * p, device=dev), torch.empty(n * p, device=dev)
             adt = torch.uint8 if c == 2 else torch.int32           # arg-max bookkeeping: a byte for two classes, a word for C

@@ -484,6 +484,13 @@ int aide_region_ce_fwd(const float* z, int64_t zb, const long long* t, int64_t t
                        int ignore_index, float* loss, unsigned char* aux, aide_stream_t stream);
 int aide_region_ce_bwd(const float* z, int64_t zb, const unsigned char* aux, const unsigned char* mask,
                        const float* coeff, int N, int H, int W, float* dz, int64_t db, aide_stream_t stream);
+/* the region cross entropy for any pooling window and class count: Coteachingloss_dropregionce(scale) pools with
+ * MaxPool2d(kernel = stride = (KH, KW), ceil_mode=True), KH = int(H / int(H * scale)) (utils/coteach_loss.py:171-177) --
+ * ceil(H / KH) x ceil(W / KW) regions, border windows clipped; C = 2 .. 8; aux: C + 1 words per region */
+int aide_region_ce_fwd_win(const float* z, int64_t zb, const long long* t, int64_t tb, int C, int N, int H, int W, int KH,
+                           int KW, int ignore_index, float* loss, int* aux, aide_stream_t stream);
+int aide_region_ce_bwd_win(const float* z, int64_t zb, const int* aux, const unsigned char* mask, const float* coeff, int C,
+                           int N, int H, int W, int KH, int KW, float* dz, int64_t db, aide_stream_t stream);
 int aide_select_smallest(const float* sel_vals, const float* sum_vals, int64_t seg_stride, int nseg, int M,
                          int64_t k_host, double rr, const long long* k_in, int only_positive, unsigned char* mask,
                          double* sums, long long* ks, aide_stream_t stream);

@@ -945,8 +945,50 @@ def g17_multiclass(ref_f, ref_u, ref_utils):
     print('g17 multiclass ok')
 
 
+def g18_dropregionce_scale(ref_utils):
+    """Coteachingloss_dropregionce for pooling windows other than the default 2 x 2 (utils/coteach_loss.py:163-196: window =
+    stride = int(H / int(H * scale)), ceil_mode): scale 0.25 (4 x 4 windows) and 0.3 (3 x 3, the last row / column of windows
+    clipped) on the two-class g3 logits, and a three-class case on a ragged plane.  Both losses, back-propagated
+    separately, with their gradients w.r.t. the own logits (the selection is not differentiated)."""
+    import oracle
+    g3 = np.load(os.path.join(OUT, 'g3_losses.npz'))
+    fx = {}
+    g = torch.Generator().manual_seed(77)
+    cases = {
+        'c2': (torch.from_numpy(g3['z1']), torch.from_numpy(g3['z2']), torch.from_numpy(g3['targets'])),      # [4, 2, 64, 64]
+        'c3': (torch.randn(2, 3, 36, 44, generator=g), torch.randn(2, 3, 36, 44, generator=g),
+               torch.randint(0, 3, (2, 36, 44), generator=g)),
+    }
+    for cname, (z1, z2, t) in cases.items():
+        if cname != 'c2':                      # (c2 = the inputs of g3_losses.npz)
+            fx[cname + '/z1'], fx[cname + '/z2'], fx[cname + '/targets'] = _np(z1), _np(z2), _np(t)
+        for scale in (0.25, 0.3):
+            for fr in (0.25, 0.5):
+                vals = {}
+                for tag, mod in (('ref', ref_utils), ('ora', oracle)):
+                    out = []
+                    for which in (0, 1):
+                        a1, a2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+                        ls = mod.Coteachingloss_dropregionce(scale=scale, reduction='none')(a1, a2, t, fr)
+                        ls[which].backward()
+                        own = a1 if which == 0 else a2
+                        out += [ls[which].detach(), own.grad.clone()]
+                    vals[tag] = out
+                for i in range(4):
+                    _same(vals['ref'][i], vals['ora'][i], 'dropregionce %s scale=%g fr=%g #%d' % (cname, scale, fr, i))
+                key = '%s/s%g/fr%g' % (cname, scale, fr)
+                r = vals['ref']
+                fx[key + '/loss1'], fx[key + '/grad1'], fx[key + '/loss2'], fx[key + '/grad2'] = (_np(x) for x in r)
+                print('g18', key, float(r[0]), float(r[2]), 'nonzero grads', int((r[1] != 0).sum()), int((r[3] != 0).sum()))
+    np.savez_compressed(os.path.join(OUT, 'g18_dropregionce_scale.npz'), **fx)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['g18']:
+        torch.set_num_threads(8)
+        ref_f, ref_u, ref_utils = _import_reference()
+        return g18_dropregionce_scale(ref_utils)
     if sys.argv[1:] == ['g8']:
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()
@@ -1009,6 +1051,7 @@ def main():
     g11_polylr(ref_utils)
     g12_metrics(ref_utils)
     g17_multiclass(ref_f, ref_u, ref_utils)
+    g18_dropregionce_scale(ref_utils)
     print('all golden fixtures written to', OUT)
 
 

@@ -233,6 +233,35 @@ def test_coteach_ext_g7(dev, cname):
         getattr(U, cname)(reduction='mean')
 
 
+def test_dropregionce_scale_g18(dev):
+    """Coteachingloss_dropregionce(scale) for the pooling windows the default kernels do not cover (scale 0.25: 4 x 4; scale
+    0.3: 3 x 3 with clipped border windows; two and three classes) vs the real reference (g18_dropregionce_scale.npz):
+    both losses and their gradients, forget rates 0.25 / 0.5.  (Round 3 raised NotImplementedError for scale != 0.5.)"""
+    from aide_amd import utils as U
+    g3, fx = np.load(os.path.join(GOLD, 'g3_losses.npz')), np.load(os.path.join(GOLD, 'g18_dropregionce_scale.npz'))
+    cases = {'c2': tuple(torch.from_numpy(g3[k]).to(dev) for k in ('z1', 'z2', 'targets')),
+             'c3': tuple(torch.from_numpy(fx['c3/' + k]).to(dev) for k in ('z1', 'z2', 'targets'))}
+    for cname, (z1, z2, t) in cases.items():
+        for scale in (0.25, 0.3):
+            for fr in (0.25, 0.5):
+                key = '%s/s%g/fr%g' % (cname, scale, fr)
+                for which in (0, 1):
+                    a1, a2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+                    ls = U.Coteachingloss_dropregionce(scale=scale, reduction='none')(a1, a2, t, fr)
+                    ref = float(fx[key + '/loss%d' % (which + 1)])
+                    assert abs(ls[which].item() - ref) < 1e-5 * abs(ref), (key, which, ls[which].item(), ref)
+                    ls[which].backward()
+                    gr = fx[key + '/grad%d' % (which + 1)]
+                    got = (a1 if which == 0 else a2).grad.cpu().numpy()
+                    # selections may differ from the reference only between values closer than fp32 noise
+                    bad = np.abs(got - gr) > 1e-4 * np.abs(gr).max() + 1e-12
+                    assert bad.mean() < 2e-4, (key, bad.sum(), np.abs(got - gr).max(), np.abs(gr).max())
+                    other = (a2 if which == 0 else a1).grad
+                    assert other is None or float(other.abs().max()) == 0.0
+    with pytest.raises(ZeroDivisionError):                        # the reference divides by int(H * scale) = 0
+        U.Coteachingloss_dropregionce(scale=0.001, reduction='none')(cases['c2'][0], cases['c2'][1], cases['c2'][2], 0.25)
+
+
 def test_select_smallest_ties_and_edges(dev):
     """aide_select_smallest: stable ties (lower index first), the > 0 candidate filter, k = int(rr * count),
     k handed over on the device, and the empty selection (-> nan mean like torch.mean of an empty tensor)."""

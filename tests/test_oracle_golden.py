@@ -252,6 +252,28 @@ def test_coteach_ext_g7():
                     close(torch.zeros_like(z1) if g is None else g, fx[key + gk], what=key + gk)
 
 
+def _g18_cases():
+    g3, fx = load('g3_losses.npz'), load('g18_dropregionce_scale.npz')
+    return fx, {'c2': tuple(torch.from_numpy(g3[k]) for k in ('z1', 'z2', 'targets')),
+                'c3': tuple(torch.from_numpy(fx['c3/' + k]) for k in ('z1', 'z2', 'targets'))}
+
+
+def test_dropregionce_scale_g18():
+    """Coteachingloss_dropregionce with pooling windows other than 2 x 2 (utils/coteach_loss.py:171-177: scale 0.25 -> 4 x 4,
+    scale 0.3 -> 3 x 3 with clipped border windows), two and three classes: the oracle restatement vs the reference's values."""
+    fx, cases = _g18_cases()
+    for cname, (z1, z2, t) in cases.items():
+        for scale in (0.25, 0.3):
+            for fr in (0.25, 0.5):
+                key = '%s/s%g/fr%g' % (cname, scale, fr)
+                for which in (0, 1):
+                    a1, a2 = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+                    ls = oracle.Coteachingloss_dropregionce(scale=scale, reduction='none')(a1, a2, t, fr)
+                    close(ls[which].detach(), fx[key + '/loss%d' % (which + 1)], what=key)
+                    ls[which].backward()
+                    close((a1 if which == 0 else a2).grad, fx[key + '/grad%d' % (which + 1)], what=key + ' grad')
+
+
 @pytest.mark.parametrize('cname', ['Pixelcoreg_Focalloss', 'Pixelcoreg_Focalloss_twomodel'])
 def test_pixelcoreg_g8(cname):
     """utils/reg_loss.py:58-193 restated in oracle/losses.py vs the reference's values (g8_pixelcoreg.npz)."""
