@@ -49,6 +49,10 @@ PROBES = {
     'g4_vunmerged': ('conv3x3_wgrad4.hip', [
         ("    auto v_store = [&](int m, int set) { lds2[(set ? vb1 : vb0) + m * 128] = tq[m]; };\n",
          "    auto v_store = [&](int m, int set) { asm volatile(\"ds_write_b64 %0, %1 offset:%2\" :: \"v\"((set ? vb1 : vb0) * 8), \"v\"(tq[m]), \"i\"(m * 1024) : \"memory\"); };\n")]),
+    # default workgroup count of the F(4x4) weight gradient (it shares the chip with the dependent chain)
+    'g4_t112': ('conv3x3_wgrad4.hip', [("target_wgs > 0 ? target_wgs : 128;", "target_wgs > 0 ? target_wgs : 112;")]),
+    'g4_t144': ('conv3x3_wgrad4.hip', [("target_wgs > 0 ? target_wgs : 128;", "target_wgs > 0 ? target_wgs : 144;")]),
+    'g4_t160': ('conv3x3_wgrad4.hip', [("target_wgs > 0 ? target_wgs : 128;", "target_wgs > 0 ? target_wgs : 160;")]),
     'g4_nostores': ('conv3x3_wgrad4.hip', [(G4_PUT, '                    { }\n'), (G4_VSTORE, ''), (G4_ZSTORE, G4_ZNONE)]),
     'wg_nomfma': ('conv3x3_bf16.hip', [(WG_MFMA, WG_NOMFMA)]),
     'wg_nofetch': ('conv3x3_bf16.hip', [(WG_FETCH, '')]),
