@@ -413,14 +413,21 @@ __global__ void bf16_splitk_reduce_kernel(const float* __restrict__ slabs, long 
 
 // ------------------------------------------------------------------------------------------ filter pack
 // w[Co][Ci][9] fp32 -> uf[ceil(Ci/16)][9][2][Co][8] bf16 (forward) and ud[ceil(Co/16)][9 reversed][2][Ci][8]
-// (dgrad: 180-degree rotation + channel transpose).  One thread per 16-byte slot; padding channels are zero.
+// (dgrad: 180-degree rotation + channel transpose); padding channels are zero.
+// A workgroup owns a 64 co x 16 ci block of one filter: its 64 x 144 floats are 64 contiguous 576-byte runs of w
+// (coalesced dword loads), they pass through LDS, and both packs leave as 16-byte slots in runs of 64 (forward: 1 KB per
+// (tap, channel group)) or 16 (dgrad: 256 B per (co chunk, tap, group)).  (One thread per slot gathering its eight
+// floats 36 bytes apart from global memory ran the re-layout of a FuseUNet at 1.2 TB/s: 181 us at the head of every
+// bf16 step, beside the two stem convolutions.)
 struct BfPackDesc {
     const float* w; uint16_t* uf; uint16_t* ud;
     int Co, Ci, r0, r1;
     long block_start;
 };
+constexpr int BP_CO = 64, BP_CI = 16, BP_ROW = BP_CI * 9 + 1;      // LDS row: 144 floats + 1 (odd stride: conflict-free columns)
 
 __global__ __launch_bounds__(256) void bf16_pack_multi_kernel(const BfPackDesc* __restrict__ descs, int n) {
+    __shared__ float tile[BP_CO * BP_ROW];
     const long blk = blockIdx.x;
     int lo = 0, hi = n - 1;
     while (lo < hi) {
@@ -428,39 +435,41 @@ __global__ __launch_bounds__(256) void bf16_pack_multi_kernel(const BfPackDesc* 
         if (descs[mid].block_start <= blk) lo = mid; else hi = mid - 1;
     }
     const BfPackDesc d = descs[lo];
-    const long nf = d.uf ? (long)((d.Ci + 15) / 16) * 18 * d.Co : 0;
-    const long nd = d.ud ? (long)((d.Co + 15) / 16) * 18 * d.Ci : 0;
-    const long i = (blk - d.block_start) * 256 + threadIdx.x;
-    float v[8];
-    if (i < nf) {
-        const int co = (int)(i % d.Co);
-        long r = i / d.Co;
-        const int g = (int)(r & 1); r >>= 1;
-        const int t = (int)(r % 9), chunk = (int)(r / 9);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int ci = chunk * 16 + g * 8 + c;
-            v[c] = ci < d.Ci ? d.w[((long)co * d.Ci + ci) * 9 + t] : 0.0f;
-        }
-    } else if (i < nf + nd) {
-        const long k = i - nf;
-        const int ci = (int)(k % d.Ci);
-        long r = k / d.Ci;
-        const int g = (int)(r & 1); r >>= 1;
-        const int t = (int)(r % 9), chunk = (int)(r / 9);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int co = chunk * 16 + g * 8 + c;
-            v[c] = co < d.Co ? d.w[((long)co * d.Ci + ci) * 9 + (8 - t)] : 0.0f;
-        }
-    } else {
-        return;
+    const int nci = (d.Ci + BP_CI - 1) / BP_CI;
+    const int lb = (int)(blk - d.block_start);
+    const int co0 = (lb / nci) * BP_CO, chunk = lb % nci, ci0 = chunk * BP_CI;
+    const int tid = threadIdx.x;
+    const int valid = min(BP_CI, d.Ci - ci0) * 9;                  // floats of a row that exist
+#pragma unroll 4
+    for (int e = tid; e < BP_CO * BP_CI * 9; e += 256) {
+        const int r = e / (BP_CI * 9), c = e - r * (BP_CI * 9);
+        tile[r * BP_ROW + c] = (co0 + r < d.Co && c < valid) ? d.w[((long)(co0 + r) * d.Ci + ci0) * 9 + c] : 0.0f;
     }
-    u32x4 s;
+    __syncthreads();
+    if (d.uf) {                                                    // slot = (tap, group, co): 8 input channels of one tap
+        for (int s = tid; s < 9 * 2 * BP_CO; s += 256) {
+            const int co = s % BP_CO, g = (s / BP_CO) & 1, t = s / (2 * BP_CO);
+            if (co0 + co >= d.Co) continue;
+            const float* p = tile + co * BP_ROW + g * 72 + t;
+            u32x4 v;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s[q] = pk_bf16(v[2 * q], v[2 * q + 1]);
-    u32x4* dst = reinterpret_cast<u32x4*>(i < nf ? d.uf : d.ud) + (i < nf ? i : i - nf);
-    *dst = s;
+            for (int q = 0; q < 4; ++q) v[q] = pk_bf16(p[18 * q], p[18 * q + 9]);
+            reinterpret_cast<u32x4*>(d.uf)[(((long)chunk * 9 + t) * 2 + g) * d.Co + co0 + co] = v;
+        }
+    }
+    if (d.ud) {                                                    // slot = (co chunk, tap', group, ci): 8 output channels, tap 8 - tap'
+        const int nchd = (d.Co + 15) / 16;
+        for (int s = tid; s < 4 * 9 * 2 * BP_CI; s += 256) {
+            const int ci = s % BP_CI, g = (s / BP_CI) & 1, t = (s / (2 * BP_CI)) % 9, cq = s / (2 * BP_CI * 9);
+            const int chd = co0 / 16 + cq;
+            if (ci0 + ci >= d.Ci || chd >= nchd) continue;
+            const float* p = tile + (cq * 16 + g * 8) * BP_ROW + ci * 9 + (8 - t);
+            u32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = pk_bf16(p[(2 * q) * BP_ROW], p[(2 * q + 1) * BP_ROW]);
+            reinterpret_cast<u32x4*>(d.ud)[(((long)chd * 9 + t) * 2 + g) * d.Ci + ci0 + ci] = v;
+        }
+    }
 }
 
 // 64-column tiles wherever the width allows (ahead by 3-10 % on every layer of the sweep from W = 64 up)
@@ -849,8 +858,11 @@ size_t aide_conv3x3_bf16_pack_elems(int Cout, int Cin) {    // bf16 elements of 
     return (size_t)((Cin + 15) / 16) * 18 * Cout * 8;
 }
 
-// descs: DEVICE array of n 48-byte records {const float* w; uint16* uf; uint16* ud (or 0); int32 Co, Ci, 0, 0;
-// int64 block_start}; an entry occupies ceil((slots_f + slots_d) / 256) workgroups, slots = pack_elems / 8.
+// workgroups of one filter in aide_conv3x3_bf16_pack_multi: 64 co x 16 ci blocks
+int aide_conv3x3_bf16_pack_blocks(int Cout, int Cin) { return ((Cout + BP_CO - 1) / BP_CO) * ((Cin + BP_CI - 1) / BP_CI); }
+
+// descs: DEVICE array of n 48-byte records {const float* w; uint16* uf (or 0); uint16* ud (or 0); int32 Co, Ci, 0, 0;
+// int64 block_start}; an entry occupies aide_conv3x3_bf16_pack_blocks(Co, Ci) workgroups.
 int aide_conv3x3_bf16_pack_multi(const void* descs, int n, int64_t total_blocks, hipStream_t stream) {
     if (!descs || n <= 0 || total_blocks <= 0) return AIDE_ERR_ARG;
     static_assert(sizeof(BfPackDesc) == 48, "descriptor layout");

@@ -568,8 +568,7 @@ def bf16_pack_table(entries, device):
         co, ci = w.shape[0], w.shape[1]
         rec += struct.pack('<QQQiiiiq', w.data_ptr(), uf.data_ptr() if uf is not None else 0,
                            ud.data_ptr() if ud is not None else 0, co, ci, 0, 0, start)
-        slots = ((uf.numel() if uf is not None else 0) + (ud.numel() if ud is not None else 0)) // 8
-        start += (slots + 255) // 256
+        start += lib.aide_conv3x3_bf16_pack_blocks(co, ci)
     return torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(device), len(entries), start
 
 

@@ -125,8 +125,9 @@ int aide_conv3x3_wgrad_wino4_t(const float* dz, int64_t dz_bs, const float* a, i
 int aide_conv3x3_bf16_supported(int Cin, int H, int W, int Cout);
 int aide_conv3x3_bf16_splitk(int N, int Cin, int H, int W, int Cout);
 size_t aide_conv3x3_bf16_pack_elems(int Cout, int Cin);          /* bf16 elements of one direction's pack */
-/* descs = DEVICE array of n 48-byte records {const float* w; uint16_t* uf; uint16_t* ud (or 0); int32 Co, Ci, 0, 0;
- * int64 block_start}; an entry occupies ceil((elems_f + elems_d) / 8 / 256) workgroups */
+/* descs = DEVICE array of n 48-byte records {const float* w; uint16_t* uf (or 0); uint16_t* ud (or 0); int32 Co, Ci, 0, 0;
+ * int64 block_start}; an entry occupies aide_conv3x3_bf16_pack_blocks(Co, Ci) workgroups (64 co x 16 ci blocks through LDS) */
+int aide_conv3x3_bf16_pack_blocks(int Cout, int Cin);
 int aide_conv3x3_bf16_pack_multi(const void* descs, int n, int64_t total_blocks, aide_stream_t stream);
 int aide_conv3x3_bf16(const float* x, int64_t x_bs, const uint16_t* u, const float* bias, float* y, int64_t y_bs,
                       int N, int Cin, int H, int W, int Cout, int accumulate, int splitk, float* ws,

