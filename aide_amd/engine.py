@@ -112,6 +112,7 @@ TAIL_WGRAD_MAIN = [True]       # the weight gradient of the LAST op of the backw
 DUAL_FWD = [True]              # lane-1 chains of the forward pass on a second stream
 FREE_LANE = [True]             # lane 1 pools its own channels and runs ahead (no fork / join per level)
 FLUSH_EVERY = 6                # layers per batched slab reduce
+GROUPED_BN = [True]            # stacked plans: BatchNorm of all groups in one launch sequence (aide_bn_train_fwd_groups)
 LAZY_BN = [True]               # forward-only stacked plans: BatchNorm + ReLU of a layer in its reader's loader (Plan._plan_lazy_bn)
 
 
@@ -875,7 +876,21 @@ class Plan(object):
         sk_ws = self.sk_ws if sk_ws is None else sk_ws
         ngroups = self.groups if (self.training and self.groups > 1) else 1
         m = self.N // ngroups
-        if self.training:
+        if self.training and ngroups > 1 and GROUPED_BN[0]:
+            # the stacked augmentation pass: every group's statistics / running-statistics update in ONE launch sequence
+            # (one launch sequence per group cost 3 x 2 x 32 small launches per co-teaching step)
+            if st.get('stats') is not None:
+                ops.bn_train_fwd_groups(z, a, ngroups, bn, st['mean'], st['rstd'], st['scale'], st['shift'], bn_ws,
+                                        parts=st['stats'], nparts=st['stats_parts'] // ngroups,
+                                        parts_stride=st['stats_parts'], conv_bias=st['conv'].bias)
+            elif splitk > 0:
+                import ctypes
+                ops.bn_train_fwd_groups(z, a, ngroups, bn, st['mean'], st['rstd'], st['scale'], st['shift'], bn_ws,
+                                        slabs=ctypes.c_void_p(sk_ws.data_ptr()), splitk=splitk, split_stride=z.numel(),
+                                        slab_bias=slab_bias)
+            else:
+                ops.bn_train_fwd_groups(z, a, ngroups, bn, st['mean'], st['rstd'], st['scale'], st['shift'], bn_ws)
+        elif self.training:
             stride = z.numel()                              # elements of one slab
             per_img = stride // self.N
             for gi in range(ngroups):

@@ -263,6 +263,48 @@ def test_grouped_forward_equals_sequential(dev, kind):
         net.forward_groups([groups[0], tuple(t[:1] for t in groups[1])])
 
 
+@pytest.mark.parametrize('kind', ['fuseunet', 'unetsa'])
+def test_grouped_batchnorm_launches_equal_per_group_launches(dev, kind, monkeypatch):
+    """The stacked pass normalises all groups of a layer in one launch sequence (engine.GROUPED_BN,
+    aide_bn_train_fwd_groups: plain / split-K-slab / epilogue-statistics input, the small-plane single-kernel form and
+    the two-pass form) == one launch sequence per group: outputs, running statistics (updated in group order),
+    num_batches_tracked.  (The two-pass form sums its partials in fewer splits: 1e-6, not bitwise.)"""
+    import copy
+    from aide_amd import engine, ops
+    from aide_amd.models_twomodalinputs import fuseunet
+    from aide_amd.models_singlemodalinput import UNetsa
+    torch.manual_seed(2)
+    net = (fuseunet(2) if kind == 'fuseunet' else UNetsa(2)).to(dev)
+    ref = copy.deepcopy(net)
+    g = torch.Generator().manual_seed(6)
+    nin = 2 if kind == 'fuseunet' else 1
+    groups = [tuple(torch.randn(2, 3, 128, 160, generator=g).to(dev) for _ in range(nin)) for _ in range(4)]
+    net.train(); ref.train()
+    calls = []
+    real = ops.bn_train_fwd_groups
+    monkeypatch.setattr(ops, 'bn_train_fwd_groups', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    was = (engine.GROUPED_BN[0], engine.LAZY_BN[0])
+    try:
+        engine.LAZY_BN[0] = False
+        engine.GROUPED_BN[0] = True
+        outs = net.forward_groups(groups) + net.forward_groups(groups)
+        assert len(calls) >= 20, len(calls)               # (the second pass replays the launch tape)
+        engine.GROUPED_BN[0] = False
+        n0 = len(calls)
+        refs = ref.forward_groups(groups) + ref.forward_groups(groups)
+        assert len(calls) == n0
+    finally:
+        engine.GROUPED_BN[0], engine.LAZY_BN[0] = was
+    torch.cuda.synchronize()
+    for a, b in zip(outs, refs):
+        assert (a - b).abs().max().item() <= 1e-6 * b.abs().max().item()
+    for (k, p), (_, q) in zip(net.named_buffers(), ref.named_buffers()):
+        if 'num_batches_tracked' in k:
+            assert int(p) == int(q) == 8
+        else:
+            assert (p - q).abs().max().item() <= 1e-6 * (q.abs().max().item() + 1e-12), k
+
+
 @pytest.mark.parametrize('kind,size', [('fuseunet', 256), ('unet', 320)])
 def test_lazy_batchnorm_in_the_reader_is_bit_identical(dev, kind, size):
     """Forward-only stacked passes apply the BatchNorm + ReLU of a layer whose only reader is an F(4x4) convolution in that
