@@ -8,6 +8,6 @@ def run(flag):
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=os.environ['GRAFT_REPO_ROOT'])
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     return j['value'], j['ms_per_step']
-for i in range(3):
+for i in range(2):
     print('c3 grouped', run('True'), ' per-group', run('False'))
 PY
