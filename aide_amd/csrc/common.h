@@ -68,7 +68,8 @@ static inline int aide_launch_status() { return (int)hipGetLastError(); }
 // ---- optional per-kernel timing (ktimer.hip; include/aide_hip.h "kernel timer"): a launch of an armed family carries
 // a start / stop event pair that receives the dispatch's own begin / end timestamps
 enum { AIDE_KT_IGEMM = 0, AIDE_KT_WINO2 = 1, AIDE_KT_WINO4 = 2, AIDE_KT_WGRAD = 3, AIDE_KT_WGRAD_WINO2 = 4,
-       AIDE_KT_WGRAD4 = 5, AIDE_KT_WGRAD_STEM = 6, AIDE_KT_BF16 = 7, AIDE_KT_WGRAD_BF16 = 8, AIDE_KT_CONVT = 9 };
+       AIDE_KT_WGRAD4 = 5, AIDE_KT_WGRAD_STEM = 6, AIDE_KT_BF16 = 7, AIDE_KT_WGRAD_BF16 = 8, AIDE_KT_CONVT = 9,
+       AIDE_KT_STEM_FWD = 10 };
 extern "C" int aide_ktimer_slot(int family, double flops, hipEvent_t* e0, hipEvent_t* e1);
 #define AIDE_LAUNCH_TIMED(FAM, FLOPS, kernel, grid, block, lds, stream, ...)                                  \
     do {                                                                                                      \

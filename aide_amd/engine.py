@@ -90,9 +90,11 @@ USE_WINOGRAD_DGRAD = [True]    # ... for the dgrad direction only
 # multiplies a launch executes per algorithmic (direct-convolution) multiply, by conv mode
 WINO_EXEC = 16.0 / 36.0
 BF16 = 16                      # conv mode id of the bf16-MFMA kernels (conv3x3_bf16.hip)
-EXEC_FRAC = {0: 1.0, 2: 16.0 / 36.0, 4: 36.0 / 144.0, BF16: 1.0}
+STEM = 32                      # forward mode id of the stem kernel (conv3x3_stem.hip: Cin <= 3, taps folded into K, no filter pack)
+EXEC_FRAC = {0: 1.0, 2: 16.0 / 36.0, 4: 36.0 / 144.0, BF16: 1.0, STEM: 28.0 / 27.0}
 # profiler tags = the kernel that does the work of one conv operator call (its split reduce rides along)
-FWD_TAG = {0: 'conv3x3_mfma_kernel', 2: 'conv3x3_wino_kernel', 4: 'conv3x3_wino4_kernel', BF16: 'conv3x3_bf16_kernel'}
+FWD_TAG = {0: 'conv3x3_mfma_kernel', 2: 'conv3x3_wino_kernel', 4: 'conv3x3_wino4_kernel', BF16: 'conv3x3_bf16_kernel',
+           STEM: 'conv3x3_stem_fwd_kernel'}
 WGRAD_TAG = {0: 'conv3x3_wgrad_kernel', 2: 'conv3x3_wgrad_wino_kernel', 4: 'conv3x3_wgrad4_kernel',
              BF16: 'conv3x3_wgrad_bf16_kernel'}
 PRECISIONS = ('fp32', 'bf16')
@@ -107,6 +109,7 @@ STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 wh
 STORE_G_BF16 = [True]          # ... and the gradients of those activations
 REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch tapes (aide_amd/tape.py)
 SHARED_PACKS = [True]          # plans of an engine share packed filters; forward-only plans pack no dgrad direction
+STEM_FWD = [True]              # fp32 3->32 stem convs forward on conv3x3_stem.hip (taps folded into K, filters from the master weights)
 FOLD_EVAL_BN = [True]          # eval-mode BatchNorm + ReLU in the conv epilogue (no pass over the conv output)
 TAIL_WGRAD_MAIN = [True]       # the weight gradient of the LAST op of the backward pass (a stem conv: no data gradient) on the main stream, which has nothing left to do, beside the weight-gradient stream's backlog
 DUAL_FWD = [True]              # lane-1 chains of the forward pass on a second stream
@@ -243,9 +246,17 @@ class Plan(object):
                         st['wino_f'] = BF16
                     if bf16 and need_dg and lib.aide_conv3x3_bf16_supported(cout, hh, ww, cin):
                         st['wino_d'] = BF16
+                    # the 3->32 stem layers in fp32: their own forward kernel straight from the master weights (measured alone
+                    # against the general kernels, tools/bench_stem.py: 3->32 x4 @256 14.3 vs 15.5 us, x8 @512 77.5 vs 84.3;
+                    # level with them for 3->64, and behind the bf16 kernel where z is stored narrow: 63 vs 56 us)
+                    if STEM_FWD[0] and not bf16 and cout == 32 and lib.aide_conv3x3_stem_fwd_supported(cin, hh, ww, cout):
+                        st['wino_f'] = STEM
+                        st['round_bf16'] = bf16
                     st['wf'] = st['wd'] = st['uf'] = st['ud'] = None
                     st['plan_f'] = st['plan_d'] = 0
-                    if st['wino_f'] == BF16:
+                    if st['wino_f'] == STEM:
+                        pass                                      # no pack, no split
+                    elif st['wino_f'] == BF16:
                         st['uf'] = pack_buf(conv, 'f', BF16, lambda: ops.bf16_pack_alloc(cout, cin, device))
                         st['plan_f'] = lib.aide_conv3x3_bf16_splitk(n, cin, hh, ww, cout) << 8
                     elif st['wino_f'] == 4:
@@ -310,7 +321,7 @@ class Plan(object):
                     # eval mode (the per-case inference loop): BatchNorm of the running statistics + ReLU as the epilogue of the
                     # F(4x4) forward kernel -- the conv writes the activation, z is never materialised
                     st['fold'] = not training and FOLD_EVAL_BN[0] and (
-                        (st['wino_f'] == 4 and ww != 16) or (st['wino_f'] == 0 and (st['plan_f'] >> 8) <= 1))
+                        (st['wino_f'] == 4 and ww != 16) or (st['wino_f'] == 0 and (st['plan_f'] >> 8) <= 1) or st['wino_f'] == STEM)
                     st['pack_key'] = None
                     st['flops'] = 2.0 * n * hh * ww * cout * cin * 9      # algorithmic, per launch
                     # bf16 mode keeps the conv output z (read only by BatchNorm) and its gradient dz (read only by the
@@ -318,7 +329,7 @@ class Plan(object):
                     # numerically) in HBM as bf16: half the bytes of the conv-output write, of four BatchNorm reads and
                     # of the dz write + two reads
                     st['dz_bf16'] = (st['wino_w'] == BF16 and (not need_dg or st['wino_d'] == BF16) and STORE_BF16[0])
-                    if st['wino_f'] == BF16 and STORE_BF16[0]:
+                    if (st['wino_f'] == BF16 or (st['wino_f'] == STEM and bf16)) and STORE_BF16[0]:
                         st['z'] = torch.empty(n, cout, hh, ww, device=device, dtype=torch.bfloat16)
                 else:
                     cin = src.C
@@ -348,7 +359,7 @@ class Plan(object):
         for st in self.steps:
             kind = st['kind']
             if kind == 'conv':
-                if not (st['wino_f'] == BF16 and st['wino_w'] == BF16):
+                if not (st['wino_f'] in (BF16, STEM) and st['wino_w'] == BF16):
                     narrow[id(st['src'].root)] = False
             elif kind in ('convT', 'sa'):
                 narrow[id(st['src'].root)] = False
@@ -808,7 +819,10 @@ class Plan(object):
                     (st['z'].shape[2] * st['z'].shape[3]) % 4 == 0          # (the slab loader reads 16 bytes)
                 acc = 2 if slabs else 0
                 if st.get('fold'):                 # eval: y = relu(acc * scale + folded bias) straight into the activation
-                    if st['wino_f'] == 4:
+                    if st['wino_f'] == STEM:
+                        ops.conv3x3_stem_fwd(x, conv.weight, st['fbias'], self.view(st['dst']), round_bf16=st['round_bf16'],
+                                             epi_scale=st['scale'], epi_relu=True)
+                    elif st['wino_f'] == 4:
                         ops.conv3x3_wino4(x, st['uf'], st['fbias'], self.view(st['dst']), accumulate=0,
                                           splitk=st['plan_f'] >> 8, ws=sk_ws, epi_scale=st['scale'], epi_relu=True)
                     else:                          # direct kernel (the 32-channel first level, the stems), non-split
@@ -819,7 +833,9 @@ class Plan(object):
                     return
                 lazy = st.get('lazy_to')
                 in_tab = st.get('in_tab')               # this conv applies the BatchNorm + ReLU of its input's producer(s)
-                if st['wino_f'] == BF16:
+                if st['wino_f'] == STEM:
+                    ops.conv3x3_stem_fwd(x, conv.weight, conv.bias, st['z'], round_bf16=st['round_bf16'])
+                elif st['wino_f'] == BF16:
                     ops.conv3x3_bf16(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=sk_ws)
                 elif st['wino_f'] == 4:
                     # (st['stats']: this launch also writes the BatchNorm statistics partials of its output)
