@@ -55,9 +55,11 @@ def parse():
                     help='oracle steps timed for cpu_baseline (default: 5 for c2 = about 10 s of CPU work, 2 for the larger workloads)')
     ap.add_argument('--no-kernel-events', action='store_true',
                     help='do not time the MFMA conv dispatches with HIP events (roofline -> null)')
-    ap.add_argument('--event-steps', type=int, default=8,
+    ap.add_argument('--event-steps', type=int, default=3,
                     help='how many of the timed steps (the last ones) carry dispatch start/stop events: a launch with '
-                         'events costs ~4 us more than a plain one (4.5 %% of the C2 step if every step is timed)')
+                         'events opens a ~7 us gap in its queue (the kernel durations themselves are unchanged), an '
+                         'instrumented C2 step runs ~6 %% longer: 3 of 50 steps cost the line 0.2-0.3 %%, the 8 of '
+                         'rounds 2-4 cost 0.7-1.0 %% (same-box A/B, DESIGN 11.7)')
     ap.add_argument('--traffic', default='live', choices=('live', 'none'),
                     help="roofline.traffic: 'live' = two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, separately, "
                          "--kernel-trace only) of this workload run as sub-processes after the timed region (rank 0, N=1)")
