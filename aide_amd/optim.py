@@ -100,7 +100,7 @@ class Adam(torch.optim.Optimizer):
                     for st in fast['states']:
                         st['step'] = step
                     self._launch(fast['tab'], fast['gtab'], fast['n'], group, step)
-                    self._keep = (fast['gtab'], grads)
+                    self._keep = (fast['gtab'], None)
                     continue
                 self._fast.pop(gi, None)
             plist = [p for p in group['params'] if p.grad is not None]
@@ -141,7 +141,10 @@ class Adam(torch.optim.Optimizer):
             for p in plist:
                 self.state[p]['step'] = step
             self._launch(tab, gtab, len(plist), group, step)
-            self._keep = (gtab, grads)            # keep alive until the next step (async launch)
+            # keep alive until the next step (async launch): the pointer table and the contiguous COPIES made above -- not
+            # the parameters' own gradient tensors: a reference held here makes the engine's next backward pass take them
+            # for gradients the caller still wants (it then leaves that arena alone and fills a new one, every step)
+            self._keep = (gtab, [g for g, p in zip(grads, plist) if g is not p.grad])
             if len(plist) == len(group['params']) and all(g is p.grad for g, p in zip(grads, plist)):
                 self._fast[gi] = dict(params=group['params'], n=len(plist), gkey=gkey,
                                       pkey=tuple(p.data_ptr() for p in plist), amsgrad=bool(group['amsgrad']),

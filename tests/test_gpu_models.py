@@ -402,6 +402,19 @@ def test_engine_assigned_gradients_keep_torch_contracts(dev):
     net.zero_grad()
     crit(net(*xs2), t2).backward()
     assert net.engine._arena is a0
+    # ... and the reference's own loop (zero_grad, forward, backward, optimizer.step) holds nothing either: one arena for
+    # all steps, the optimizer on its steady-state path (no pointer-table upload), no 100 MB zero fill per step
+    from aide_amd.optim import Adam
+    opt = Adam(net.parameters(), lr=1e-4, amsgrad=True)
+    arenas, fast_steps = set(), []
+    for _ in range(5):
+        opt.zero_grad()
+        crit(net(*xs2), t2).backward()
+        opt.step()
+        arenas.add(net.engine._arena.data_ptr())
+        fast_steps.append((id(opt._fast[0]), opt._fast[0]['step']) if opt._fast else None)      # (the slow path builds a new record)
+    assert len(arenas) == 1 and len(set(f[0] for f in fast_steps)) == 1 and [f[1] for f in fast_steps] == [1, 2, 3, 4, 5], \
+        (arenas, fast_steps)
     # (2) parameter hooks
     ref, _ = build_pair('fuseunet', False, dev)
     hk, _ = build_pair('fuseunet', False, dev)
