@@ -649,7 +649,7 @@ int bn_relu_apply_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C
 template <typename ZT, typename DT, typename GT>
 int bn_relu_bwd_t(const GT* dA, int64_t d_bs, const ZT* z, int64_t z_bs, DT* dz, int64_t dz_bs,
                   int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
-                  const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws,
+                  const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws, void* done,
                   hipStream_t stream) {
     const int HW = H * W;
     if (!ws) return AIDE_ERR_ARG;
@@ -658,20 +658,20 @@ int bn_relu_bwd_t(const GT* dA, int64_t d_bs, const ZT* z, int64_t z_bs, DT* dz,
     double* partials = (double*)ws;
     const double count = (double)N * HW;
     if (v4 && bn_fused_ok(N, C, HW)) {
-        hipLaunchKernelGGL((bn_bwd_fused_kernel<ZT, DT, GT>), dim3(C), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs,
-                           N, HW, count, mean, rstd, scale, shift, relu, dgamma, dbeta, dbias, SlabSrc{});
+        AIDE_LAUNCH_DONE(done, (bn_bwd_fused_kernel<ZT, DT, GT>), dim3(C), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs,
+                         N, HW, count, mean, rstd, scale, shift, relu, dgamma, dbeta, dbias, SlabSrc{});
         return aide_launch_status();
     }
     const bool v8 = v4 && HW % 8 == 0 && z_bs % 8 == 0 && d_bs % 8 == 0 && dz_bs % 8 == 0;
     if (v8) {
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<8, ZT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<8, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
+        AIDE_LAUNCH_DONE(done, (bn_bwd_apply_kernel<8, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
     } else if (v4) {
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, ZT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<4, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
+        AIDE_LAUNCH_DONE(done, (bn_bwd_apply_kernel<4, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
     } else {
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, ZT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<1, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
+        AIDE_LAUNCH_DONE(done, (bn_bwd_apply_kernel<1, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
     }
     return aide_launch_status();
 }
@@ -838,9 +838,9 @@ int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, i
 int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz,
                            int dz_bf16, int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                            const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
-                           void* ws, hipStream_t stream) {
+                           void* ws, void* done, hipStream_t stream) {
 #define AIDE_BN_BWD(ZT, DT, GT) bn_relu_bwd_t<ZT, DT, GT>((const GT*)dA, d_bs, (const ZT*)z, z_bs, (DT*)dz, dz_bs, N, C, H, W, \
-                                                          mean, rstd, scale, shift, relu, dgamma, dbeta, dbias, ws, stream)
+                                                          mean, rstd, scale, shift, relu, dgamma, dbeta, dbias, ws, done, stream)
 #define AIDE_BN_BWD_G(ZT, DT) (dA_bf16 ? AIDE_BN_BWD(ZT, DT, bf16_t) : AIDE_BN_BWD(ZT, DT, float))
     if (z_bf16) return dz_bf16 ? AIDE_BN_BWD_G(bf16_t, bf16_t) : AIDE_BN_BWD_G(bf16_t, float);
     return dz_bf16 ? AIDE_BN_BWD_G(float, bf16_t) : AIDE_BN_BWD_G(float, float);
@@ -853,15 +853,15 @@ int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void
 int aide_bn_relu_bwd_slabs(const float* slabs, int splitk, int64_t split_stride, const float* z, int64_t z_bs, float* dz,
                            int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                            const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
-                           hipStream_t stream) {
+                           void* done, hipStream_t stream) {
     const int HW = H * W;
     if (!slabs || splitk < 1 || !z || !dz || HW % 4 || z_bs % 4 || dz_bs % 4 || split_stride % 4 || !bn_fused_ok(N, C, HW))
         return AIDE_ERR_ARG;
     SlabSrc sl;
     sl.slabs = slabs; sl.bias = nullptr; sl.split_stride = split_stride; sl.slab_bs = (long)C * HW; sl.splitk = splitk;
-    hipLaunchKernelGGL((bn_bwd_fused_kernel<float, float, float, true>), dim3(C), dim3(256), 0, stream, (const float*)nullptr, 0L,
-                       z, (long)z_bs, dz, (long)dz_bs, N, HW, (double)N * HW, mean, rstd, scale, shift, relu, dgamma, dbeta,
-                       dbias, sl);
+    AIDE_LAUNCH_DONE(done, (bn_bwd_fused_kernel<float, float, float, true>), dim3(C), dim3(256), 0, stream, (const float*)nullptr, 0L,
+                     z, (long)z_bs, dz, (long)dz_bs, N, HW, (double)N * HW, mean, rstd, scale, shift, relu, dgamma, dbeta,
+                     dbias, sl);
     return aide_launch_status();
 }
 
@@ -889,10 +889,10 @@ int aide_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, int
 // Backward of relu(bn(z)): dA -> dz, dgamma, dbeta, and the (mathematically zero) conv-bias grad.
 int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs, float* dz, int64_t dz_bs,
                      int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
-                     const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws,
+                     const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws, void* done,
                      hipStream_t stream) {
     return bn_relu_bwd_t<float, float, float>(dA, d_bs, z, z_bs, dz, dz_bs, N, C, H, W, mean, rstd, scale, shift, relu, dgamma,
-                                       dbeta, dbias, ws, stream);
+                                       dbeta, dbias, ws, done, stream);
 }
 
 }  // extern "C"

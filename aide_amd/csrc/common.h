@@ -79,6 +79,14 @@ extern "C" int aide_ktimer_slot(int family, double flops, hipEvent_t* e0, hipEve
         else                                                                                                  \
             hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                \
     } while (0)
+// launch with an optional completion event (aide_event_create) attached to the DISPATCH itself: the hand-over to another
+// stream then costs the launching queue ~1.4 us instead of the ~5 us hole of a separate record packet
+// (tools/ubench/handover_cost.hip)
+#define AIDE_LAUNCH_DONE(DONE, kernel, grid, block, lds, stream, ...)                                                 \
+    do {                                                                                                              \
+        if (DONE) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, (hipEvent_t)(DONE), 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                      \
+    } while (0)
 #define AIDE_CONV_FLOPS(N, H, W, Co, Ci) (2.0 * (double)(N) * (double)(H) * (double)(W) * (double)(Co) * (double)(Ci) * 9.0)
 
 // XCD-aware bijective remap of a 1-D block id: the hardware dispatches block b to XCD b % 8;

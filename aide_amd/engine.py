@@ -114,6 +114,7 @@ FOLD_EVAL_BN = [True]          # eval-mode BatchNorm + ReLU in the conv epilogue
 TAIL_WGRAD_MAIN = [True]       # the weight gradient of the LAST op of the backward pass (a stem conv: no data gradient) on the main stream, which has nothing left to do, beside the weight-gradient stream's backlog
 DUAL_FWD = [True]              # lane-1 chains of the forward pass on a second stream
 FREE_LANE = [True]             # lane 1 pools its own channels and runs ahead (no fork / join per level)
+HANDOVER_ON_KERNEL = [True]    # the dz hand-over event of a layer rides on its BatchNorm backward's last dispatch (hipExtLaunchKernelGGL stop event)
 FLUSH_EVERY = 6                # layers per batched slab reduce
 WGRAD_HANDOVER = [6, 2, 2e10]  # main -> side hand-overs of dz: the first 6 conv layers of a backward pass each, then every 2nd among the layers of <= 20 GFLOP (Plan._prepare_backward)
 GROUPED_BN = [True]            # stacked plans: BatchNorm of all groups in one launch sequence (aide_bn_train_fwd_groups)
@@ -1090,14 +1091,20 @@ class Plan(object):
                 conv, bn = st['conv'], st['bn']
                 z = st['z']
                 dz = st['dz']
+                # a layer that hands its dz over to the weight-gradient stream right away: the event rides on the
+                # BatchNorm backward's last dispatch (done=) and the other stream only waits for it -- no record packet
+                # between this launch and the data-gradient convolution on this queue
+                tail_ = TAIL_WGRAD_MAIN[0] and st is self.steps[0] and sg is None and self.profiler is None
+                done = st['ev'] if (side is not None and not tail_ and HANDOVER_ON_KERNEL[0]
+                                    and not (self.profiler is None and st.get('wg_defer'))) else None
                 if folded[0]:                  # dA is still in the split-K slabs of the conv after this one
                     ops.bn_relu_bwd_slabs(sk_ws, folded[0], z, dz, st['mean'], st['rstd'], st['scale'], st['shift'],
-                                          gslot(bn.weight), gslot(bn.bias), gslot(conv.bias), True)
+                                          gslot(bn.weight), gslot(bn.bias), gslot(conv.bias), True, done=done)
                     folded[0] = 0
                 else:
                     ops.bn_relu_bwd(self.gview(st['dst']), z, dz, st['mean'], st['rstd'], st['scale'],
                                     st['shift'], gslot(bn.weight), gslot(bn.bias), gslot(conv.bias),
-                                    bn_ws, True)
+                                    bn_ws, True, done=done)
                 x = self.view(st['src'], inputs)
                 if kind == 'conv':
                     prof = self.profiler
@@ -1119,7 +1126,10 @@ class Plan(object):
                         self._wg_pending.append((st, lambda dz=dz, x=x, w_=gslot(conv.weight), ws=st['wg_ws']:
                                                  wgrad(dz, x, w_, ws=ws)))
                     elif side is not None and not tail:
-                        ops.order(st['ev'], main, side)
+                        if done is not None:
+                            ops.wait(side, done)
+                        else:
+                            ops.order(st['ev'], main, side)
                         with ops.use_stream(side):
                             for _, launch in self._wg_pending:
                                 launch()
@@ -1166,7 +1176,10 @@ class Plan(object):
                     # stream still has queued instead of behind it
                     tail = TAIL_WGRAD_MAIN[0] and st is self.steps[0] and sg is None and prof is None
                     if side is not None and not tail:
-                        ops.order(st['ev'], main, side)
+                        if done is not None:
+                            ops.wait(side, done)
+                        else:
+                            ops.order(st['ev'], main, side)
                         with ops.use_stream(side):
                             for _, launch in self._wg_pending:
                                 launch()

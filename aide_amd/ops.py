@@ -362,25 +362,26 @@ def bn_relu_apply(z, a, scale, shift, relu=True):
     return a
 
 
-def bn_relu_bwd(dA, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, relu=True):
+def bn_relu_bwd(dA, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, relu=True, done=None):
+    """done: event recorded when dz is complete (attached to the last dispatch; pair with wait(stream, done))"""
     gp, gbs = planes(dA, bf16_ok=True)
     zp, zbs = planes(z, bf16_ok=True)
     dp, dbs = planes(dz, bf16_ok=True)
     n, c, h, w = z.shape
     check(lib.aide_bn_relu_bwd_mixed(gp, int(is_bf16(dA)), gbs, zp, int(is_bf16(z)), zbs, dp, int(is_bf16(dz)), dbs, n, c, h, w,
                                      ptr(mean), ptr(rstd), ptr(scale), ptr(shift), int(relu), ptr(dgamma), ptr(dbeta),
-                                     ptr(dbias), ptr(ws), stream_ptr()), 'bn_relu_bwd')
+                                     ptr(dbias), ptr(ws), done, stream_ptr()), 'bn_relu_bwd')
     return dz
 
 
-def bn_relu_bwd_slabs(slabs, splitk, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, relu=True):
+def bn_relu_bwd_slabs(slabs, splitk, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, relu=True, done=None):
     """bn_relu_bwd whose dA is the split-K slabs [splitk][N][C][H][W] (fp32 tensor `slabs`, at its start) left by the
     data-gradient convolution (accumulate=2); fp32 z / dz, small planes (lib.aide_bn_two_pass(...) == 0)."""
     zp, zbs = planes(z)
     dp, dbs = planes(dz)
     n, c, h, w = z.shape
     check(lib.aide_bn_relu_bwd_slabs(ptr(slabs), splitk, n * c * h * w, zp, zbs, dp, dbs, n, c, h, w, ptr(mean), ptr(rstd),
-                                     ptr(scale), ptr(shift), int(relu), ptr(dgamma), ptr(dbeta), ptr(dbias), stream_ptr()),
+                                     ptr(scale), ptr(shift), int(relu), ptr(dgamma), ptr(dbeta), ptr(dbias), done, stream_ptr()),
           'bn_relu_bwd_slabs')
     return dz
 

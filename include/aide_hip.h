@@ -192,7 +192,10 @@ int aide_bn_eval_fold(int C, const float* gamma, const float* beta, const float*
 int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs, float* dz,
                      int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                      const float* scale, const float* shift, int relu, float* dgamma, float* dbeta,
-                     float* dbias, void* ws, aide_stream_t stream);
+                     float* dbias, void* ws, void* done, aide_stream_t stream);
+/* `done` (the three aide_bn_relu_bwd* calls): NULL, or an event of aide_event_create that is recorded when dz is complete --
+ * attached to the call's last dispatch instead of a record packet of its own: aide_stream_wait_event(other, done) then
+ * orders another stream behind dz at ~1.4 us of this queue's time (aide_stream_order: ~5 us; tools/ubench/handover_cost.hip) */
 /* aide_bn_relu_bwd with dA still in the split-K slabs [splitk][N][C][H][W] (fp32, split_stride elements apart) of the
  * data-gradient convolution that produced it (aide_conv3x3_wino4 / aide_conv3x3_wino launched with accumulate = 2): the
  * kernel sums the slabs itself, in the order of the split reduce, so that launch and one pass over dA disappear.  Small
@@ -200,7 +203,7 @@ int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs
 int aide_bn_relu_bwd_slabs(const float* slabs, int splitk, int64_t split_stride, const float* z, int64_t z_bs, float* dz,
                            int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                            const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
-                           aide_stream_t stream);
+                           void* done, aide_stream_t stream);
 /* the same three operators on bf16-STORED z / a / dz (precision='bf16'): z_bf16 / a_bf16 / dz_bf16 give the element type behind the
  * untyped pointers; the arithmetic (fp32 per element, fp64 reductions) is unchanged, widening is exact, dz is narrowed RNE */
 int aide_bn_train_fwd_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
@@ -260,7 +263,7 @@ int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, i
 int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz,
                            int dz_bf16, int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                            const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
-                           void* ws, aide_stream_t stream);
+                           void* ws, void* done, aide_stream_t stream);
 
 /* ---- MaxPool2d(2,2), bilinear x2 (align_corners=True) -------------------------------------------
  * replaces nn.MaxPool2d: fuseunet.py:13-31 (calls :51-78), UNet.py:114 ;

@@ -170,6 +170,43 @@ def test_bn_relu_fwd_bwd(dev, shape):
     assert dbias.abs().max().item() < 1e-3      # mathematically zero (dead conv bias)
 
 
+@pytest.mark.parametrize('shape', [(8, 64, 256, 256), (4, 128, 64, 64), (3, 8, 20, 20)])
+def test_bn_relu_bwd_completion_event(dev, shape):
+    """`done` of aide_bn_relu_bwd*: an event recorded when dz is complete, attached to the call's last dispatch (two-pass,
+    single-kernel and scalar forms).  Another stream that waits for it must see all of dz: the consumer copies a NaN-primed
+    dz while the producing stream goes on to overwrite the inputs; ten rounds back to back."""
+    import ctypes
+    from aide_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h)
+    z = (torch.randn(n, c, h, w, generator=g) * 2.0).to(dev)
+    dA = torch.randn(n, c, h, w, generator=g).to(dev)
+    mean, rstd, scale, shift = (torch.empty(c, device=dev) for _ in range(4))
+    ws = ops.bn_ws(c, dev)
+    ops.bn_train_fwd(z, torch.empty_like(z), torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.3, 1e-5, 0.1,
+                     torch.zeros(c, device=dev), torch.ones(c, device=dev), torch.zeros((), dtype=torch.int64, device=dev),
+                     mean, rstd, scale, shift, ws, True)
+    dg, db, dbias = (torch.empty(c, device=dev) for _ in range(3))
+    ref = torch.empty_like(z)
+    ops.bn_relu_bwd(dA, z, ref, mean, rstd, scale, shift, dg, db, dbias, ws, True)
+    side = torch.cuda.Stream(device=dev)
+    ev = ops.new_event()
+    dz = torch.empty_like(z)
+    outs = []
+    torch.cuda.synchronize()
+    for _ in range(10):
+        dz.fill_(float('nan'))
+        side.wait_stream(torch.cuda.current_stream())          # (the consumer's previous copy is done before the fill: separate check)
+        ops.bn_relu_bwd(dA, z, dz, mean, rstd, scale, shift, dg, db, dbias, ws, True, done=ev)
+        ops.wait(ctypes.c_void_p(side.cuda_stream), ev)
+        with torch.cuda.stream(side):
+            outs.append(dz.clone())
+        torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, ref)
+
+
 @pytest.mark.parametrize('case', [(4, 512, 16, 16, 8), (4, 256, 32, 32, 4), (2, 128, 64, 64, 2)])
 def test_bn_relu_bwd_from_splitk_slabs(dev, case):
     """BatchNorm backward that reads its dA from the split-K slabs of the data-gradient convolution (the engine's
