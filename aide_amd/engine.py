@@ -116,7 +116,6 @@ DUAL_FWD = [True]              # lane-1 chains of the forward pass on a second s
 FREE_LANE = [True]             # lane 1 pools its own channels and runs ahead (no fork / join per level)
 HANDOVER_ON_KERNEL = [True]    # the dz hand-over event of a layer rides on its BatchNorm backward's last dispatch (hipExtLaunchKernelGGL stop event)
 FLUSH_EVERY = 6                # layers per batched slab reduce
-WGRAD_HANDOVER = [6, 2, 2e10]  # main -> side hand-overs of dz: the first 6 conv layers of a backward pass each, then every 2nd among the layers of <= 20 GFLOP (Plan._prepare_backward)
 GROUPED_BN = [True]            # stacked plans: BatchNorm of all groups in one launch sequence (aide_bn_train_fwd_groups)
 LAZY_BN = [True]               # forward-only stacked plans: BatchNorm + ReLU of a layer in its reader's loader (Plan._plan_lazy_bn)
 
@@ -479,17 +478,6 @@ class Plan(object):
                 st['wg_ws'] = self.wg_ws[st['wg_off']:st['wg_off'] + max(st['wg_bytes'] // 4, 1)]
         self.head_ws = torch.empty(max(self._max_wg // 4, 1), **f32)
         self.wg_queue = ops.new_wgrad_queue()     # pending slab reduces of a backward pass (batched launches)
-        # main -> side hand-overs of the weight gradients (WGRAD_HANDOVER = (first, every)): the first `first` conv layers of
-        # the backward pass hand their dz over at once (the weight-gradient stream is waiting for them), after that only
-        # every `every`-th layer does and the layers between ride with it; the last two always do (the tail of the pass).
-        # Only layers of <= max_flop: a held-back weight gradient starts one layer late, which costs more than the two ~6 us
-        # holes it saves once the layers are long (same-box A/B, tools/r4/gpu_x.sh: C2 +1.0 % at 20 GFLOP, +1.4 % at 40 or
-        # without a bound; C4 +0.1 / -0.4 / -0.7 %; C3 +0.5 %; C5 within its noise)
-        first, every, max_flop = WGRAD_HANDOVER
-        convs_b = [st for st in reversed(self.steps) if st['kind'] in ('conv', 'convT')]
-        for k, st in enumerate(convs_b):
-            st['wg_defer'] = (st['kind'] == 'conv' and self.side is not None and every > 1 and first <= k < len(convs_b) - 2
-                              and (k - first) % every != every - 1 and st['flops'] <= max_flop)
         sa = [st for st in self.steps if st['kind'] == 'sa']
         if sa:                      # small-channel gradient ping-pong buffers + the gate-backward workspace
             big = max(st['t1'].numel() for st in sa)
@@ -1045,23 +1033,12 @@ class Plan(object):
         encoder's chains on a stream of their own, as in the forward pass, measured +-0 beside the weight-gradient stream
         -- DESIGN.md 3c -- and is not built in.)"""
         fold = [0]                       # split count of the data gradient the NEXT BatchNorm backward reads from sk_ws
-        self._wg_pending = []            # weight gradients held back for the next main -> side hand-over (WGRAD_HANDOVER)
-        held = []
         for st in reversed(self.steps):
             if self.trace is not None:
                 self.trace('b', st)
             self._backward_op(st, inputs, dlogits, gslot, main, side, self.bn_ws, self.sk_ws, fold)
-            if self._wg_pending and self._wg_pending[-1][0] is st:
-                held.append(st)          # its weight gradient is not launched yet: after_op once it is
-                continue
-            if st['kind'] in ('conv', 'convT'):
-                if after_op is not None:
-                    for h in held:
-                        after_op(h)
-                del held[:]
             if after_op is not None:
                 after_op(st)
-        assert not self._wg_pending and not held
 
     def _backward_op(self, st, inputs, dlogits, gslot, main, side, bn_ws, sk_ws, folded):
         """one op of the backward sequence on stream `main` (its lane's stream); folded: [split count] cell of the lane"""
@@ -1095,8 +1072,7 @@ class Plan(object):
                 # BatchNorm backward's last dispatch (done=) and the other stream only waits for it -- no record packet
                 # between this launch and the data-gradient convolution on this queue
                 tail_ = TAIL_WGRAD_MAIN[0] and st is self.steps[0] and sg is None and self.profiler is None
-                done = st['ev'] if (side is not None and not tail_ and HANDOVER_ON_KERNEL[0]
-                                    and not (self.profiler is None and st.get('wg_defer'))) else None
+                done = st['ev'] if (side is not None and not tail_ and HANDOVER_ON_KERNEL[0]) else None
                 if folded[0]:                  # dA is still in the split-K slabs of the conv after this one
                     ops.bn_relu_bwd_slabs(sk_ws, folded[0], z, dz, st['mean'], st['rstd'], st['scale'], st['shift'],
                                           gslot(bn.weight), gslot(bn.bias), gslot(conv.bias), True, done=done)
@@ -1120,20 +1096,12 @@ class Plan(object):
                     # BatchNorm backward, so its weight gradient runs on that stream beside whatever the weight-gradient
                     # stream still has queued instead of behind it
                     tail = TAIL_WGRAD_MAIN[0] and st is self.steps[0] and sg is None and prof is None
-                    if side is not None and not tail and prof is None and st.get('wg_defer'):
-                        # no hand-over of its own: launched behind the next layer's (every record / wait pair is a ~6 us
-                        # hole in BOTH queues, and past the first layers the weight-gradient stream runs behind anyway)
-                        self._wg_pending.append((st, lambda dz=dz, x=x, w_=gslot(conv.weight), ws=st['wg_ws']:
-                                                 wgrad(dz, x, w_, ws=ws)))
-                    elif side is not None and not tail:
+                    if side is not None and not tail:
                         if done is not None:
                             ops.wait(side, done)
                         else:
                             ops.order(st['ev'], main, side)
                         with ops.use_stream(side):
-                            for _, launch in self._wg_pending:
-                                launch()
-                            del self._wg_pending[:]
                             if prof is not None:
                                 prof.begin(WGRAD_TAG[st['wino_w']], st['flops'], st['flops'] * EXEC_FRAC[st['wino_w']])
                             wgrad(dz, x, gslot(conv.weight), ws=st['wg_ws'])
@@ -1181,9 +1149,6 @@ class Plan(object):
                         else:
                             ops.order(st['ev'], main, side)
                         with ops.use_stream(side):
-                            for _, launch in self._wg_pending:
-                                launch()
-                            del self._wg_pending[:]
                             ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=st['wg_ws'])
                     else:
                         ops.convT2x2_wgrad(x, dz, gslot(conv.weight), ws=st['wg_ws'])

@@ -280,45 +280,6 @@ def test_side_stream_wgrad_is_bit_identical(dev):
             assert torch.equal(a, b) and torch.equal(a, c)
 
 
-def test_held_back_weight_gradients_are_a_schedule(dev):
-    """engine.WGRAD_HANDOVER: past the first layers of a backward pass only every n-th conv hands its dz over to the
-    weight-gradient stream and the layers between ride with it.  Same launches, another order on the side stream: gradients
-    bit-identical to one hand-over per layer, and the per-op callback of a held-back layer (the gradient all-reduce marks
-    the op's parameters complete there) only fires once its weight gradient has been issued."""
-    from aide_amd import engine, utils as U
-    was = list(engine.WGRAD_HANDOVER)
-    w = torch.tensor([1.0, 1.0])
-    try:
-        for kind in ('fuseunet', 'unet'):
-            g = torch.Generator().manual_seed(11)
-            xs = [torch.randn(2, 3, 64, 64, generator=g).to(dev) for _ in range(2 if kind == 'fuseunet' else 1)]
-            t = (torch.rand(2, 64, 64, generator=g) > 0.8).long().to(dev)
-            grads, held = [], []
-            for handover in ([0, 1, 1e30], [2, 3, 1e30], [0, 2, 1e30]):
-                engine.WGRAD_HANDOVER[:] = handover
-                net, _ = build_pair(kind, False, dev)
-                order = []
-                net.engine.after_backward_op = lambda st, net=net, order=order: order.append(
-                    (st['kind'], bool(st.get('wg_defer')),
-                     any(p[0] is st for p in list(net.engine.plans.values())[0]._wg_pending)))
-                for rep in range(3):                       # recorded, then replayed from the launch tape
-                    net.zero_grad()
-                    out = net(*xs)
-                    plan = list(net.engine.plans.values())[0]
-                    del order[:]
-                    U.CEMDiceLoss(w, w, w)(out, t).backward()
-                    assert not any(pending for _, _, pending in order), order
-                net.engine.after_backward_op = None
-                grads.append([p.grad.clone() for p in net.parameters()])
-                held.append(sum(1 for k, d, _ in order if d))
-                assert len(order) == len(plan.steps)
-            assert held[0] == 0 and held[1] >= 8 and held[2] >= 8, held
-            for a, b, c in zip(*grads):
-                assert torch.equal(a, b) and torch.equal(a, c)
-    finally:
-        engine.WGRAD_HANDOVER[:] = was
-
-
 def test_engine_assigned_gradients_follow_autograd_semantics(dev):
     """Parameter gradients are assigned by the engine (one autograd anchor, persistent arena): the values equal the plain
     autograd form bit for bit, a second backward ACCUMULATES (as AccumulateGrad does), zero_grad(set_to_none=False) keeps
