@@ -109,7 +109,7 @@ STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 wh
 STORE_G_BF16 = [True]          # ... and the gradients of those activations
 REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch tapes (aide_amd/tape.py)
 SHARED_PACKS = [True]          # plans of an engine share packed filters; forward-only plans pack no dgrad direction
-STEM_FWD = [True]              # fp32 3->32 stem convs forward on conv3x3_stem.hip (taps folded into K, filters from the master weights)
+STEM_FWD = [False]             # fp32 3->32 stem convs forward on conv3x3_stem.hip (taps folded into K, filters from the master weights): level in the step, off
 FOLD_EVAL_BN = [True]          # eval-mode BatchNorm + ReLU in the conv epilogue (no pass over the conv output)
 TAIL_WGRAD_MAIN = [True]       # the weight gradient of the LAST op of the backward pass (a stem conv: no data gradient) on the main stream, which has nothing left to do, beside the weight-gradient stream's backlog
 DUAL_FWD = [True]              # lane-1 chains of the forward pass on a second stream
