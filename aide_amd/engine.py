@@ -115,6 +115,7 @@ TAIL_WGRAD_MAIN = [True]       # the weight gradient of the LAST op of the backw
 DUAL_FWD = [True]              # lane-1 chains of the forward pass on a second stream
 FREE_LANE = [True]             # lane 1 pools its own channels and runs ahead (no fork / join per level)
 HANDOVER_ON_KERNEL = [True]    # the dz hand-over event of a layer rides on its BatchNorm backward's last dispatch (hipExtLaunchKernelGGL stop event)
+W4_HALF_TILE = [True]          # F(4x4) weight gradient also for Co = 32 layers (a trailing half tile computed and dropped): the 32->32 layers at the END of the backward pass
 FLUSH_EVERY = 6                # layers per batched slab reduce
 GROUPED_BN = [True]            # stacked plans: BatchNorm of all groups in one launch sequence (aide_bn_train_fwd_groups)
 LAZY_BN = [True]               # forward-only stacked plans: BatchNorm + ReLU of a layer in its reader's loader (Plan._plan_lazy_bn)
@@ -288,10 +289,12 @@ class Plan(object):
                     if bf16 and lib.aide_conv3x3_wgrad_bf16_supported(cout, cin, hh, ww):
                         st['wino_w'] = BF16
                         st['wg_bytes'] = lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, cout, cin, hh, ww, 0)
-                    elif USE_WINOGRAD[0] and USE_WINOGRAD4[0] and cout % 64 == 0 and \
+                    elif USE_WINOGRAD[0] and USE_WINOGRAD4[0] and (cout % 64 == 0 or W4_HALF_TILE[0]) and \
                             lib.aide_conv3x3_wgrad_wino4_supported(cout, cin, hh, ww):
-                        # (a trailing half tile -- 32->32 @256x256 -- is 71 -> 56 us alone, but the 144 KB workgroups keep
-                        # the main stream's kernels off the CUs: the step lost 0.5 %, so those layers stay on the direct kernel)
+                        # (a trailing half tile -- 32->32 @256x256 -- is 71 -> 56 us alone.  In round 2 the step lost 0.5 % with it:
+                        # the 144 KB workgroups kept the main stream's kernels off the CUs; with the backward pass as it is now
+                        # these layers are the last thing the weight-gradient stream does and the step gains: C2 621.9 / 620.9,
+                        # 621.8 / 620.7, 621.2 / 619.6 same box, C3 level -- W4_HALF_TILE)
                         st['wino_w'] = 4
                         # the LAST such launch of a backward pass whose dependent chain ends with it (every op before it in
                         # the graph is a stem conv without a data gradient -- the single-encoder U-Nets): nothing is left to
