@@ -130,8 +130,8 @@ def conv_mode(n, cin, h, w, cout):
         # (w == 16: the kernel's image-pair tile is 11 % faster than F(2x2) there, the step 0.6 % slower -- 4x larger
         # filter pack for the 8 M bottleneck parameters, twice the slabs for BatchNorm to sum)
         flops = 2.0 * n * h * w * cin * cout * 9
-        if cout % 64:                       # trailing half block computed and dropped: 42 vs 52 us on 32->32 @256x256,
-            return 0                        # but the 4x larger filter pack eats the gain in the whole step
+        if cout % 64:                       # trailing half block computed and dropped: 42 vs 52 us on 32->32 @256x256 alone,
+            return 0                        # level in the step (round 4 again: C2 620.2 / 620.4, C3 155.2 / 155.4)
         if flops >= 8e9 or cin * cout >= 128 * 128:
             return 4
     return 2 if use_winograd(n, cin, h, w, cout) else 0
