@@ -63,10 +63,21 @@ def _net2_stream(device):
     return s
 
 
+def join_networks():
+    """after a run of coteach_step(..., pipeline=True): order the caller's stream behind network 2's stream (its last
+    backward pass and optimizer step) before anything else touches network 2 -- evaluation, checkpoints, .item() on its state"""
+    for dev, s in _NET2_STREAM.items():
+        torch.cuda.current_stream(dev).wait_stream(s)
+
+
 def coteach_step(net1, net2, opt1, opt2, loss_op, inphase, outphase, aug_pairs, targets1, targets2, rate,
-                 temperature=1.0, augset=None):
+                 temperature=1.0, augset=None, pipeline=False):
     """One step of trainchaos_proposed_30cases1labeled.py:260-325 on device tensors. `augset` (the
-    loader's dict with 'augno', 'hflip{k}', 'degree{k}') triggers the on-device reverseaug (:271-272)."""
+    loader's dict with 'augno', 'hflip{k}', 'degree{k}') triggers the on-device reverseaug (:271-272).
+    pipeline: network 2's backward pass and optimizer step (:324-325) stay on network 2's stream and the call returns
+    with the caller's stream free after network 1's update -- the NEXT step's network-1 forwards (:265-269, which need
+    only network 1's new weights) then run beside them.  Same arithmetic, same order per network; the caller owes a
+    join_networks() before it reads network 2 outside this function."""
     from aide_amd.utils import pseudo_label_ensemble, reverseaug
     cur = torch.cuda.current_stream(inphase.device)
     two = TWO_NET_STREAMS[0]
@@ -94,10 +105,15 @@ def coteach_step(net1, net2, opt1, opt2, loss_op, inphase, outphase, aug_pairs, 
     loss1, loss2, indx1, indx2 = loss_op(o1, o2, targets1, targets2, pl1, wm1, pl2, wm2, rate)   # :303-321
     loss1.backward()                                              # :322-325 (graphs are disjoint)
     opt1.step()
-    loss2.backward()                                              # (network 2's node runs on the stream of its forward)
-    if two:
-        cur.wait_stream(s2)
-    opt2.step()
+    if two and pipeline:
+        with torch.cuda.stream(s2):                               # (autograd's end-of-pass join then lands on s2, not on cur)
+            loss2.backward()
+            opt2.step()
+    else:
+        loss2.backward()                                          # (network 2's node runs on the stream of its forward)
+        if two:
+            cur.wait_stream(s2)
+        opt2.step()
     return dict(outputs1=o1.detach(), outputs2=o2.detach(), loss1=loss1.detach(), loss2=loss2.detach(),
                 indx1=indx1, indx2=indx2, extra=loss_op.last)
 
@@ -149,9 +165,11 @@ def Train(args=None):
                 augset['hflip%d' % (k + 1)] = [int(torch.randint(0, 2, (1,), generator=g)) for _ in range(args.batch_size)]
                 augset['degree%d' % (k + 1)] = [float((torch.rand(1, generator=g) * 2 - 1) * args.rotation)
                                                 for _ in range(args.batch_size)]
-            r = coteach_step(net1, net2, opt1, opt2, loss_op, xin, xout, augs, t, t, rate, args.temperature, augset=augset)
+            r = coteach_step(net1, net2, opt1, opt2, loss_op, xin, xout, augs, t, t, rate, args.temperature, augset=augset,
+                             pipeline=True)
             l1 += r['loss1']
             l2 += r['loss2']
+        join_networks()
         if sch1 is not None:
             sch1.step()
             sch2.step()

@@ -357,6 +357,9 @@ def cpu_baseline_coteach(batch, size, steps, max_threads, augset):
                 sec_per_step=dt)
 
 
+PIPELINE_C3 = [True]       # coteach_step(pipeline=True): the train script's own setting (train_files/trainchaos_proposed_30cases1labeled.py Train)
+
+
 def main_coteach(args, rank, world, device, batch, size, gflop_img, act, probes):
     """BASELINE config 3 (not the headline): the AIDE proposed step; N>1 = data-parallel replicas with per-replica
     BatchNorm statistics and small-loss selection, both networks' gradients mean-all-reduced."""
@@ -387,7 +390,7 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img, act, probes)
         augset['degree%d' % (k + 1)] = [15.0 * (k + 1) - 7.0 * b for b in range(batch)]
 
     def step():
-        return coteach_step(n1, n2, o1, o2, op, xin, xout, augs, t, t, 0.25, augset=augset)
+        return coteach_step(n1, n2, o1, o2, op, xin, xout, augs, t, t, 0.25, augset=augset, pipeline=PIPELINE_C3[0])
     ev_steps = max(1, min(args.event_steps, args.steps))
     timer = None if args.no_kernel_events else DispatchTimer(capacity=1200 * ev_steps)
     el, _, per_rank, r = timed_steps(step, args, world, device, timer, ev_steps)

@@ -98,9 +98,9 @@ def test_coteaching_two_streams_is_bit_identical(dev):
     from aide_amd import engine as E
     old, old_sp = M.TWO_NET_STREAMS[0], E.SHARED_PACKS[0]
     try:
-        for two in (False, True):
-            M.TWO_NET_STREAMS[0] = two
-            E.SHARED_PACKS[0] = two          # ... and with every plan packing its own filters (both directions) vs shared packs
+        for two in (False, True, 'pipelined'):
+            M.TWO_NET_STREAMS[0] = bool(two)
+            E.SHARED_PACKS[0] = bool(two)    # ... and with every plan packing its own filters (both directions) vs shared packs
             torch.manual_seed(2)
             n1, n2 = fuseunet(2).to(dev), fuseunet(2).to(dev)
             n1.train(); n2.train()
@@ -108,17 +108,22 @@ def test_coteaching_two_streams_is_bit_identical(dev):
             op = CoTeachingProposedLoss(cediceweight=[1.0, 1.0], ceclassweight=[1.0, 1.0], segcor_weight=[1.0, 10.0])
             trace = []
             for _ in range(3):
-                r = M.coteach_step(n1, n2, o1, o2, op, T('xin'), T('xout'), augs, T('t1'), T('t2'), 0.25, augset=augset)
+                # 'pipelined': network 2's backward pass and optimizer step stay on its stream, the next step's network-1
+                # forwards run beside them (coteach_step(pipeline=True), what the train script and bench.py use)
+                r = M.coteach_step(n1, n2, o1, o2, op, T('xin'), T('xout'), augs, T('t1'), T('t2'), 0.25, augset=augset,
+                                   pipeline=(two == 'pipelined'))
                 trace.append((r['loss1'].clone(), r['loss2'].clone(), r['indx1'].clone(), r['indx2'].clone()))
+            M.join_networks()
             torch.cuda.synchronize()
             res[two] = (trace, [p.detach().clone() for p in list(n1.parameters()) + list(n2.parameters())],
                         [b.detach().clone() for b in list(n1.buffers()) + list(n2.buffers())])
     finally:
         M.TWO_NET_STREAMS[0], E.SHARED_PACKS[0] = old, old_sp
-    for a, b in zip(res[False][0], res[True][0]):
-        assert all(torch.equal(x, y) for x, y in zip(a, b))
-    assert all(torch.equal(x, y) for x, y in zip(res[False][1], res[True][1]))
-    assert all(torch.equal(x, y) for x, y in zip(res[False][2], res[True][2]))
+    for other in (True, 'pipelined'):
+        for a, b in zip(res[False][0], res[other][0]):
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
+        assert all(torch.equal(x, y) for x, y in zip(res[False][1], res[other][1]))
+        assert all(torch.equal(x, y) for x, y in zip(res[False][2], res[other][2]))
 
 
 def test_cli_smoke(dev, tmp_path):
