@@ -55,11 +55,11 @@ def parse():
                     help='oracle steps timed for cpu_baseline (default: 5 for c2 = about 10 s of CPU work, 2 for the larger workloads)')
     ap.add_argument('--no-kernel-events', action='store_true',
                     help='do not time the MFMA conv dispatches with HIP events (roofline -> null)')
-    ap.add_argument('--event-steps', type=int, default=3,
+    ap.add_argument('--event-steps', type=int, default=None,
                     help='how many of the timed steps (the last ones) carry dispatch start/stop events: a launch with '
                          'events opens a ~7 us gap in its queue (the kernel durations themselves are unchanged), an '
                          'instrumented C2 step runs ~6 %% longer: 3 of 50 steps cost the line 0.2-0.3 %%, the 8 of '
-                         'rounds 2-4 cost 0.7-1.0 %% (same-box A/B, DESIGN 11.7)')
+                         'rounds 2-4 cost 0.7-1.0 %% (same-box A/B, DESIGN 11.7).  Default: 3, but at most one timed step in ten')
     ap.add_argument('--traffic', default='live', choices=('live', 'none'),
                     help="roofline.traffic: 'live' = two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, separately, "
                          "--kernel-trace only) of this workload run as sub-processes after the timed region (rank 0, N=1)")
@@ -96,6 +96,14 @@ def probe_guard(args):
                          'compute wrong results, the line would not be a measurement; --allow-probes marks it INVALID instead)'
                          % ', '.join(probes))
     return act, probes
+
+
+def event_steps(args):
+    """how many of the timed steps carry dispatch events: --event-steps, but (unless given explicitly) at most one step in
+    ten -- an instrumented step runs ~6 % longer, and a short run should not pay for its own measurement"""
+    if args.event_steps is not None:
+        return max(1, min(args.event_steps, args.steps))
+    return max(1, min(3, args.steps // 10))
 
 
 def timed_steps(step, args, world, device, timer, ev_steps):
@@ -391,7 +399,7 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img, act, probes)
 
     def step():
         return coteach_step(n1, n2, o1, o2, op, xin, xout, augs, t, t, 0.25, augset=augset, pipeline=PIPELINE_C3[0])
-    ev_steps = max(1, min(args.event_steps, args.steps))
+    ev_steps = event_steps(args)
     timer = None if args.no_kernel_events else DispatchTimer(capacity=1200 * ev_steps)
     el, _, per_rank, r = timed_steps(step, args, world, device, timer, ev_steps)
     final = [round(float(r['loss1']), 6), round(float(r['loss2']), 6)]
@@ -500,7 +508,7 @@ def main():
 
     # every launch of every MFMA conv kernel in the timed steps carries a start / stop event pair holding the dispatch's
     # own begin / end timestamps (C ABI kernel timer): the steps keep their multi-stream schedule, nothing is serialised
-    ev_steps = max(1, min(args.event_steps, args.steps))
+    ev_steps = event_steps(args)
     timer = None if args.no_kernel_events else DispatchTimer(capacity=200 * ev_steps)
     elapsed, _, per_rank, loss = timed_steps(step, args, world, device, timer, ev_steps)
     final_loss = float(loss.item())
