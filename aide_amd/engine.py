@@ -116,7 +116,7 @@ DUAL_FWD = [True]              # lane-1 chains of the forward pass on a second s
 FREE_LANE = [True]             # lane 1 pools its own channels and runs ahead (no fork / join per level)
 HANDOVER_ON_KERNEL = [True]    # the dz hand-over event of a layer rides on its BatchNorm backward's last dispatch (hipExtLaunchKernelGGL stop event)
 W4_HALF_TILE = [True]          # F(4x4) weight gradient also for Co = 32 layers (a trailing half tile computed and dropped): the 32->32 layers at the END of the backward pass
-FLUSH_EVERY = 6                # layers per batched slab reduce
+FLUSH_EVERY = 4                # layers per batched slab reduce (re-measured at the end of round 4: 6 -> 4 C2 +0.5 / +0.8 % on two boxes, C4 +0.2 %, C3 +0.1 %; 2, 3, 5, 8, 12 and one flush at the end all behind 4)
 GROUPED_BN = [True]            # stacked plans: BatchNorm of all groups in one launch sequence (aide_bn_train_fwd_groups)
 LAZY_BN = [True]               # forward-only stacked plans: BatchNorm + ReLU of a layer in its reader's loader (Plan._plan_lazy_bn)
 
