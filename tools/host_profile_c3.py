@@ -15,7 +15,7 @@ augset = {'augno': [4] * 4}
 for k in range(4):
     augset['hflip%d' % (k + 1)] = [(k + b) % 2 for b in range(4)]
     augset['degree%d' % (k + 1)] = [15.0 * (k + 1) - 7.0 * b for b in range(4)]
-step = lambda: coteach_step(n1, n2, o1, o2, op, xin, xout, augs, t, t, 0.25, augset=augset)
+step = lambda: coteach_step(n1, n2, o1, o2, op, xin, xout, augs, t, t, 0.25, augset=augset, pipeline=True)
 for _ in range(5): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
