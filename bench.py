@@ -418,8 +418,9 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img, act, probes)
                 ms_per_step=round(el / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
                 vs_baseline=None, dtype='f32' if precision == 'fp32' else 'bf16', data='synthetic',
                 config=dict(workload='c3 two fuseunet co-teaching step (4 aug fwd + fwd + bwd + Adam per net, '
-                                     'on-device reverseaug, fused selection), %dx%d, bs=%d/GPU, %s'
-                                     % (size, size, batch, precision),
+                                     'on-device reverseaug, fused selection%s), %dx%d, bs=%d/GPU, %s'
+                                     % (', network 2 pipelined across the step boundary' if PIPELINE_C3[0] else '',
+                                        size, size, batch, precision),
                             global_batch=batch * world, parallelism='dp%d' % world, alg_gflop_per_image=gflop_img),
                 step_tflops=round(value * gflop_img / 1e3, 2),
                 step_algorithmic_frac=round(value * gflop_img / 1e3 / world / peak, 4),
