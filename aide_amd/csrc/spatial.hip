@@ -240,7 +240,12 @@ __device__ __forceinline__ int up_bwd_weights(int i, int in_size, int out_size, 
 // global loads and the six-tap column pass touch consecutive LDS words per lane (the interleaved layout was 2-way
 // bank-conflicted on every access); the tap weights live in registers (a thread's source column, and its four source
 // rows, are fixed for the whole workgroup), not in LDS tables: 6 + 6 LDS reads per source pixel instead of 13 + 12.
-template <typename GT, typename DT>
+// FAST (destination rows 16-byte aligned: pointer, batch stride and 2 W elements): the window comes in as aligned 16-byte
+// pieces of a slightly wider column range (it starts 2 W0 - 8 / 2 W0 - 4 pixels into the row for bf16 / fp32 instead of
+// 2 W0 - 2) -- 3 / 5 loads per thread instead of ten 4- / 8-byte ones, and one ds_write_b128 / two ds_write_b64 each: the
+// kernel is a stream of the destination tensor and spends most of its life beside the weight gradient on a quarter of the
+// CUs, where the bytes a wave has in flight are what it gets done.
+template <typename GT, typename DT, bool FAST>
 __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const GT* __restrict__ dy, long dy_bs,
                                                                    DT* __restrict__ dx, long dx_bs, int C, int H,
                                                                    int W, int tiles_w, int accumulate) {
@@ -249,8 +254,14 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const GT* __r
     // 21 KB of LDS per workgroup instead of 31 KB, i.e. seven resident workgroups per CU instead of five (and more of them
     // beside the weight-gradient workgroups of the side stream, where this kernel ran at 1.3 TB/s)
     constexpr bool PK = sizeof(GT) == 2;
-    __shared__ float te[PK ? 1 : UB_RH][HW2 + 1], to[PK ? 1 : UB_RH][HW2 + 1];
-    __shared__ unsigned tp[PK ? UB_RH : 1][HW2 + 1];
+    constexpr int CPX = PK ? 8 : 4;                         // FAST: pixels per 16-byte piece
+    constexpr int LEAD = PK ? 6 : 2;                        //       the aligned range starts LEAD pixels left of the window
+    constexpr int NCHK = PK ? 18 : 34;                      //       pieces per window row (144 / 136 pixels)
+    constexpr int TES = FAST ? 68 : HW2 + 1, TPS = FAST ? 72 : HW2 + 1;      // row strides (dwords)
+    constexpr int QL = FAST ? LEAD / 2 : 0;                 // pair index of window column 0 in a stored row
+    __shared__ __attribute__((aligned(16))) float te[PK ? 1 : UB_RH][TES];
+    __shared__ __attribute__((aligned(16))) float to[PK ? 1 : UB_RH][TES];
+    __shared__ __attribute__((aligned(16))) unsigned tp[PK ? UB_RH : 1][TPS];
     __shared__ float hp[UB_RH][UB_TW + 1];
     const int Ho = 2 * H, Wo = 2 * W;
     const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
@@ -277,7 +288,32 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const GT* __r
     // all ten loads of a thread are issued before the first LDS store (a load -> wait -> store loop exposed the full
     // memory latency ten times per workgroup: 0.9 TB/s); out-of-plane elements read a clamped address and are zeroed
     constexpr int NLD = (UB_RH * HW2 + 255) / 256;
-    if constexpr (PK) {
+    if constexpr (FAST) {
+        constexpr int NLF = (UB_RH * NCHK + 255) / 256;
+        u32x4 v[NLF];
+#pragma unroll
+        for (int k = 0; k < NLF; ++k) {
+            const int e = tid + k * 256;
+            const int r = e / NCHK, ck = e - r * NCHK;
+            const int oh = R0 + r, ow = C0 - LEAD + ck * CPX;          // (a multiple of CPX, as Wo is: a piece is all in or all out)
+            const bool ok = e < UB_RH * NCHK && oh >= 0 && oh < Ho && ow >= 0 && ow + CPX <= Wo;
+            const u32x4 t = *reinterpret_cast<const u32x4*>(g + (ok ? (long)oh * Wo + ow : 0L));
+            v[k] = ok ? t : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int k = 0; k < NLF; ++k) {
+            const int e = tid + k * 256;
+            if (e < UB_RH * NCHK) {
+                const int r = e / NCHK, ck = e - r * NCHK;
+                if constexpr (PK) {
+                    *reinterpret_cast<u32x4*>(&tp[r][ck * 4]) = v[k];
+                } else {                                    // (e0, o0, e1, o1) -> even / odd column arrays
+                    *reinterpret_cast<u32x2*>(&te[r][ck * 2]) = u32x2{v[k][0], v[k][2]};
+                    *reinterpret_cast<u32x2*>(&to[r][ck * 2]) = u32x2{v[k][1], v[k][3]};
+                }
+            }
+        }
+    } else if constexpr (PK) {
         unsigned v[NLD];
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
@@ -319,7 +355,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const GT* __r
     for (int k = 0; k < 6; ++k) wc[k] = wtab[UB_TH + x][k];
     const int oc = otab[UB_TH + x];                         // first candidate column inside the window
     // column pass: hp[r][x] = sum_l wc[l] * window[r][oc + l]; window column q lives in (q & 1 ? to : te)[r][q >> 1]
-    const int q0 = oc >> 1;                                 // oc is even: candidates start at max(0, 2 i - 2), C0 is even
+    const int q0 = (oc >> 1) + QL;                          // oc is even: candidates start at max(0, 2 i - 2), C0 is even
     for (int r = rq; r < UB_RH; r += 4) {
         if constexpr (PK) {
             const unsigned a = tp[r][q0], b = tp[r][q0 + 1], d = tp[r][q0 + 2];       // (even | odd << 16) column pairs
@@ -593,6 +629,12 @@ int aide_maxpool2x2_bwd_mixed(const void* x, int x_bf16, int64_t x_bs, const voi
 #undef AIDE_PB
 }
 
+// may the tiled up-sampling backward read its destination rows as aligned 16-byte pieces?  (es = bytes per element)
+static inline bool ub_fast(const void* dy, int64_t dy_bs, int W, int es) {
+    const int per = 16 / es;
+    return (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (dy_bs % per) == 0 && ((2 * W) % per) == 0;
+}
+
 int aide_upsample2x_bilinear_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int N, int C, int H,
                                  int W, hipStream_t stream) {
     const long total = (long)N * C * 4 * H * W;
@@ -617,8 +659,12 @@ int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int6
     const long total = (long)N * C * H * W;
     if (dy_bs % 2 == 0 && (long)N * C <= 65535) {          // 8-byte loads of the destination rows
         const int tw = (W + UB_TW - 1) / UB_TW, th = (H + UB_TH - 1) / UB_TH;
-        hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<float, float>), dim3(tw * th, N * C), dim3(256), 0, stream, dy,
-                           (long)dy_bs, dx, (long)dx_bs, C, H, W, tw, accumulate);
+        if (ub_fast(dy, dy_bs, W, 4))
+            hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<float, float, true>), dim3(tw * th, N * C), dim3(256), 0, stream, dy,
+                               (long)dy_bs, dx, (long)dx_bs, C, H, W, tw, accumulate);
+        else
+            hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<float, float, false>), dim3(tw * th, N * C), dim3(256), 0, stream, dy,
+                               (long)dy_bs, dx, (long)dx_bs, C, H, W, tw, accumulate);
         return aide_launch_status();
     }
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, (long)dy_bs,
@@ -631,8 +677,14 @@ int aide_upsample2x_bilinear_bwd_mixed(const void* dy, int dy_bf16, int64_t dy_b
                                        int N, int C, int H, int W, int accumulate, hipStream_t stream) {
     if (dy_bs % 2 || (long)N * C > 65535) return AIDE_ERR_ARG;
     const int tw = (W + UB_TW - 1) / UB_TW, th = (H + UB_TH - 1) / UB_TH;
-#define AIDE_UB(GT, DT) hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<GT, DT>), dim3(tw * th, N * C), dim3(256), 0, stream, \
-                                           (const GT*)dy, (long)dy_bs, (DT*)dx, (long)dx_bs, C, H, W, tw, accumulate)
+    const bool fast = ub_fast(dy, dy_bs, W, dy_bf16 ? 2 : 4);
+#define AIDE_UB(GT, DT)                                                                                                          \
+    do {                                                                                                                         \
+        if (fast) hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<GT, DT, true>), dim3(tw * th, N * C), dim3(256), 0, stream,      \
+                                     (const GT*)dy, (long)dy_bs, (DT*)dx, (long)dx_bs, C, H, W, tw, accumulate);                   \
+        else hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<GT, DT, false>), dim3(tw * th, N * C), dim3(256), 0, stream,         \
+                                (const GT*)dy, (long)dy_bs, (DT*)dx, (long)dx_bs, C, H, W, tw, accumulate);                        \
+    } while (0)
     if (dy_bf16) { if (dx_bf16) AIDE_UB(bf16_store_t, bf16_store_t); else AIDE_UB(bf16_store_t, float); }
     else { if (dx_bf16) AIDE_UB(float, bf16_store_t); else AIDE_UB(float, float); }
 #undef AIDE_UB
