@@ -631,7 +631,7 @@ class Plan(object):
     def _fingerprint(self):
         """addresses of every parameter and buffer the launch sequence bakes in (a tape is only valid for these)"""
         # ... and everything else a recorded sequence depends on: the runtime schedule switches and the BatchNorm scalars
-        fp = [DUAL_FWD[0], FREE_LANE[0], TAIL_WGRAD_MAIN[0], self.overlap]
+        fp = [DUAL_FWD[0], FREE_LANE[0], TAIL_WGRAD_MAIN[0], HANDOVER_ON_KERNEL[0], FLUSH_EVERY, self.overlap]
         # (this runs every forward: the tensors are looked up through the modules' own _parameters / _buffers dicts -- a
         # replaced parameter or buffer is seen -- without walking the module tree)
         slots = self._fp_slots
