@@ -62,7 +62,8 @@ def reverseaug(augset, augoutput, classno):
     """Drop-in for the reference function: augoutput[k] is the [N,classno,H,W] output of augmented pass k;
     augset carries 'augno', 'hflip{k}', 'degree{k}' per batch element (datasetchaos_proposed/dataset.py)."""
     nb = len(augset['augno'])
-    naug = int(augset['augno'][0])
+    # (the reference walks range(augno[b]) per element, :82-83; its caller makes augno[0] passes, :265)
+    naug = min(len(augoutput), max(int(a) for a in augset['augno']))
     if naug == 0:
         return augoutput
     h, w = augoutput[0].shape[2], augoutput[0].shape[3]

@@ -983,8 +983,80 @@ def g18_dropregionce_scale(ref_utils):
     np.savez_compressed(os.path.join(OUT, 'g18_dropregionce_scale.npz'), **fx)
 
 
+def _ref_functions(path, names, glb):
+    """The named top-level functions of a reference script that cannot be imported (the train scripts import skimage / pydicom
+    and run argparse / mkdir at module top): their definitions are taken out of the script's syntax tree and compiled
+    IN MEMORY from the reference's own text -- nothing of it is written anywhere."""
+    import ast
+    tree = ast.parse(open(path).read(), filename=path)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in body) == sorted(names), (path, [n.name for n in body])
+    ns = dict(glb)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, 'exec'), ns)
+    return [ns[n] for n in names]
+
+
+def g19_reverseaug():
+    """Pins the LOOP-LEVEL restatements to the reference's own function text: `reverseaug` and `sharpen` of
+    train_files/trainchaos_proposed_30cases1labeled.py:81-101 and the p^(1/T) `sharpen` of
+    train_files/trainkidney_proposed_mask1.py:113-117 are executed here (see _ref_functions) on non-identity flips / rotations
+    (PIL's 0 / 90 / 180 / 270 fast paths, square and non-square planes, augno < 4) and oracle.steps.reverseaug /
+    oracle.losses.sharpen / sharpen_root must reproduce them bit for bit."""
+    import warnings
+    from PIL import Image
+    from oracle import steps, losses
+    glb = dict(torch=torch, np=np, Image=Image)
+    chaos = os.path.join(REF, 'train_files', 'trainchaos_proposed_30cases1labeled.py')
+    kidney = os.path.join(REF, 'train_files', 'trainkidney_proposed_mask1.py')
+    ref_rev, ref_sharpen = _ref_functions(chaos, ['reverseaug', 'sharpen'], glb)
+    kid_rev, kid_sharpen = _ref_functions(kidney, ['reverseaugbatch', 'sharpen'], glb)     # (:97-111: the batched form this step calls, :274-275)
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    augsets = [
+        {'augno': [4, 4, 4, 3],
+         'hflip1': [0, 1, 0, 1], 'degree1': [0.0, 37.5, -60.0, 12.25],
+         'hflip2': [1, 0, 1, 0], 'degree2': [90.0, 180.0, 270.0, -90.0],
+         'hflip3': [0, 0, 1, 1], 'degree3': [59.99, -0.5, 360.0, 45.0],
+         'hflip4': [1, 1, 0, 0], 'degree4': [-33.0, 5.0, 120.0, 77.0]},
+        {'augno': [2, 4, 1, 4],
+         'hflip1': [1, 1, 0, 0], 'degree1': [-90.0, 60.0, 180.0, -17.0],
+         'hflip2': [0, 1, 1, 0], 'degree2': [23.0, -180.0, 3.0, 270.0],
+         'hflip3': [1, 0, 0, 1], 'degree3': [1.0, 90.0, 2.0, -45.0],
+         'hflip4': [0, 0, 1, 1], 'degree4': [9.0, 0.0, 4.0, 33.3]}]
+    case = 0
+    for (h, w) in ((16, 16), (12, 20), (20, 12)):
+        for augset in augsets:
+            outs = [torch.randn(4, 2, h, w, generator=g) for _ in range(4)]
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                ref = ref_rev(augset, [o.clone() for o in outs], 2)
+                kid = kid_rev(augset, [o.clone() for o in outs], 2)
+                ora = steps.reverseaug(augset, [o.clone() for o in outs], 2)
+            for k in range(4):
+                _same(ora[k], ref[k], 'reverseaug case %d pass %d' % (case, k))
+                _same(kid[k], ref[k], 'kidney reverseaug case %d pass %d' % (case, k))
+                out['rev%d/in%d' % (case, k)] = _np(outs[k])
+                out['rev%d/out%d' % (case, k)] = _np(ref[k])
+            for key, v in augset.items():
+                out['rev%d/%s' % (case, key)] = np.asarray(v, dtype=np.float64)
+            case += 1
+    out['rev_cases'] = np.asarray(case)
+    p = torch.softmax(torch.randn(4, 2, 16, 16, generator=g) * 2.0, dim=1)
+    out['sharpen/p'] = _np(p)
+    for T in (0.5, 1.0, 2.0):
+        a, b = ref_sharpen(p.clone(), T), kid_sharpen(p.clone(), T)
+        _same(losses.sharpen(p.clone(), T), a, 'sharpen p^T, T = %g' % T)
+        _same(losses.sharpen_root(p.clone(), T), b, 'sharpen p^(1/T), T = %g' % T)
+        out['sharpen/pow_T_%g' % T] = _np(a)
+        out['sharpen/pow_invT_%g' % T] = _np(b)
+    np.savez_compressed(os.path.join(OUT, 'g19_reverseaug.npz'), **out)
+    print('g19_reverseaug.npz: %d reverseaug cases and both sharpen flavours reproduced bit for bit by the oracle' % case)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['g19']:
+        return g19_reverseaug()
     if sys.argv[1:] == ['g18']:
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()
@@ -1052,6 +1124,7 @@ def main():
     g12_metrics(ref_utils)
     g17_multiclass(ref_f, ref_u, ref_utils)
     g18_dropregionce_scale(ref_utils)
+    g19_reverseaug()
     print('all golden fixtures written to', OUT)
 
 

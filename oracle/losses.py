@@ -398,4 +398,11 @@ class CEDiceLoss(nn.Module):
 def sharpen(mask, temperature):
     """trainchaos_proposed_30cases1labeled.py:97-101 — p^T / sum_c p^T."""
     m = torch.pow(mask, temperature)
-    return m / m.sum(dim=1, keepdim=True)
+    return m / m.sum(dim=1).unsqueeze(dim=1)
+
+
+def sharpen_root(mask, temperature):
+    """trainkidney_proposed_mask1.py:113-117 (and the breast scripts) — p^(1/T) / sum_c p^(1/T): the flavour of the eight
+    UNet `*_proposed_*` scripts."""
+    m = torch.pow(mask, 1.0 / temperature)
+    return m / m.sum(dim=1).unsqueeze(dim=1)

@@ -167,11 +167,22 @@ def test_full_size_properties(dev):
 
 
 def test_reverseaug_matches_pil(dev):
-    """GPU reverseaug vs the PIL round trip of the reference (oracle.steps.reverseaug), incl. PIL's exact
-    fast paths (0/90/180/270 degrees) and non-square planes."""
+    """GPU reverseaug vs the reference's own reverseaug (fixture g19_reverseaug.npz: the function text of
+    trainchaos_proposed_30cases1labeled.py:81-95 executed in the build container), incl. PIL's exact fast paths
+    (0 / 90 / 180 / 270 degrees), non-square planes and augno < 4 -- and, on larger planes than the fixture holds, vs the
+    oracle restatement that the fixture pins bit for bit."""
     import warnings
     from aide_amd import utils as U
     from oracle import steps
+    from test_oracle_golden import g19_cases
+    fx = np.load(os.path.join(GOLD, 'g19_reverseaug.npz'))
+    for c, (augset, ins, outs) in enumerate(g19_cases(fx)):
+        got = U.reverseaug(augset, [t.to(dev) for t in ins], 2)
+        for k in range(4):
+            assert (got[k].cpu() - outs[k]).abs().max().item() < 2e-6, (c, k)
+        for b in range(4):                       # the passes k >= augno[b] of an element are left untouched
+            for k in range(augset['augno'][b], 4):
+                assert torch.equal(got[k][b].cpu(), ins[k][b]), (c, b, k)
     g = torch.Generator().manual_seed(21)
     for (h, w) in ((32, 32), (48, 64)):
         nb = 4

@@ -379,3 +379,36 @@ def test_g17_multiclass_models(name, ctor, C, nin):
     grads = dict((k, p.grad) for k, p in net.named_parameters())
     for k in ('last_conv1.weight', 'last_conv1.bias'):
         close(grads[k], fx['%s/grad/%s' % (name, k)], rtol=1e-4, what=k)
+
+
+def g19_cases(fx):
+    """(augset dict, list of 4 input tensors, list of 4 reference outputs) per case of g19_reverseaug.npz"""
+    for c in range(int(fx['rev_cases'])):
+        augset = {'augno': [int(v) for v in fx['rev%d/augno' % c]]}
+        for k in range(1, 5):
+            augset['hflip%d' % k] = [int(v) for v in fx['rev%d/hflip%d' % (c, k)]]
+            augset['degree%d' % k] = [float(v) for v in fx['rev%d/degree%d' % (c, k)]]
+        yield (augset, [torch.from_numpy(fx['rev%d/in%d' % (c, k)]) for k in range(4)],
+               [torch.from_numpy(fx['rev%d/out%d' % (c, k)]) for k in range(4)])
+
+
+def test_g19_reverseaug_and_sharpen_pinned_to_reference_text():
+    """oracle.steps.reverseaug / oracle.losses.sharpen / sharpen_root against what the reference's OWN function text produced
+    (gen_golden.g19_reverseaug executes `reverseaug`, `reverseaugbatch` and both `sharpen` flavours out of the train scripts'
+    syntax trees: trainchaos_proposed_30cases1labeled.py:81-101, trainkidney_proposed_mask1.py:97-117): bit for bit."""
+    import warnings
+    from oracle import losses
+    fx = load('g19_reverseaug.npz')
+    n = 0
+    for augset, ins, outs in g19_cases(fx):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            got = steps.reverseaug(augset, [t.clone() for t in ins], 2)
+        for k in range(4):
+            assert torch.equal(got[k], outs[k]), (n, k)
+        n += 1
+    assert n == 6
+    p = torch.from_numpy(fx['sharpen/p'])
+    for T in (0.5, 1.0, 2.0):
+        assert torch.equal(losses.sharpen(p.clone(), T), torch.from_numpy(fx['sharpen/pow_T_%g' % T]))
+        assert torch.equal(losses.sharpen_root(p.clone(), T), torch.from_numpy(fx['sharpen/pow_invT_%g' % T]))
