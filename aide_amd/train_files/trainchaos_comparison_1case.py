@@ -87,7 +87,7 @@ def Train(args=None):
     optimizer = Adam(net.parameters(), lr=args.lr, amsgrad=True)
     scheduler = make_scheduler(args.lr_policy, optimizer, args.num_epoch)
     single = not args.model_name.startswith('fuseunet')
-    history = {'train_loss': [], 'train_dice': []}
+    history = {'train_loss': [], 'train_dice': [], 'step_loss': []}
     best_casedice = 0.0                      # :188 (a case Dice of 0 never saves, as in the reference)
     for epoch in range(args.num_epoch):
         ts = time.time()
@@ -95,6 +95,7 @@ def Train(args=None):
         loss_sum = torch.zeros((), device=device)
         dice_sum = torch.zeros((), device=device)
         count = 0
+        step_losses = []                                      # device scalars, read once per epoch
         for it in range(args.steps_per_epoch):
             inphase, outphase, targets = chaos_batch(args.batch_size, args.img_size,
                                                      seed=(args.torch_seed * 100003 + epoch * 1009 + it) * world + rank,
@@ -106,11 +107,13 @@ def Train(args=None):
             loss.backward()
             optimizer.step()
             count += inphase.shape[0]
+            step_losses.append(loss.detach())
             loss_sum += loss.detach() * inphase.shape[0]      # device-side accumulation: one host
             dice_sum += U.Dice_fn(outputs, targets)           # sync per epoch instead of two per step
         if scheduler is not None:
             scheduler.step()
         history['train_loss'].append(float(loss_sum) / count)
+        history['step_loss'] += [float(v) for v in torch.stack(step_losses).cpu()]
         history['train_dice'].append(float(dice_sum) / count)
         # per-case evaluation (reference :232-315: every slice of a case through the eval-mode net, 3-D Dice of the label
         # volume) on a synthetic case, and the best-checkpoint rule of :329-345 ({'net': state_dict, ...})

@@ -71,35 +71,53 @@ def join_networks():
 
 
 def coteach_step(net1, net2, opt1, opt2, loss_op, inphase, outphase, aug_pairs, targets1, targets2, rate,
-                 temperature=1.0, augset=None, pipeline=False):
+                 temperature=1.0, augset=None, pipeline=False, eval_aug=False, sharpen='pow'):
     """One step of trainchaos_proposed_30cases1labeled.py:260-325 on device tensors. `augset` (the
     loader's dict with 'augno', 'hflip{k}', 'degree{k}') triggers the on-device reverseaug (:271-272).
+    The single-modal form of the eight UNet `*_proposed_*` scripts: outphase=None, aug_pairs a list of tensors (or 1-tuples),
+    eval_aug=True (the nets are in eval() for the augmentation passes and back in train() for the step:
+    trainkidney_proposed_mask1.py:265-266,290-291), sharpen='root' (p^(1/T), :113-117); the keep count is the loss
+    operator's (`CoTeachingProposedLoss(keep=...)`: 2, or int(batch_size / 2) in the breast scripts,
+    trainbreast_dataset3_proposed_272cases25labeled.py:304).
     pipeline: network 2's backward pass and optimizer step (:324-325) stay on network 2's stream and the call returns
     with the caller's stream free after network 1's update -- the NEXT step's network-1 forwards (:265-269, which need
     only network 1's new weights) then run beside them.  Same arithmetic, same order per network; the caller owes a
     join_networks() before it reads network 2 outside this function."""
     from aide_amd.utils import pseudo_label_ensemble, reverseaug
+    if sharpen not in ('pow', 'root'):
+        raise ValueError("sharpen must be 'pow' (p^T) or 'root' (p^(1/T))")
+    expo = float(temperature) if sharpen == 'pow' else 1.0 / float(temperature)
+
+    def fwd(net, x, y):
+        return net(x, y) if y is not None else net(x)
     cur = torch.cuda.current_stream(inphase.device)
     two = TWO_NET_STREAMS[0]
     s2 = _net2_stream(inphase.device) if two else cur
     if two:
         s2.wait_stream(cur)                                       # the inputs (and last step's optimizer) are cur's work
-    # :265-269 -- the four augmented forwards of a network as ONE stacked pass (per-group BatchNorm statistics and
-    # running-stat updates, in order: the semantics of the sequential forwards; 4x the pixels per conv launch)
+    if eval_aug:
+        net1.eval()
+        net2.eval()
+    # :265-269 -- the four augmented forwards of a network as ONE stacked pass (train mode: per-group BatchNorm statistics and
+    # running-stat updates, in order: the semantics of the sequential forwards; eval mode: running statistics, nothing
+    # updated; either way 4x the pixels per conv launch)
     a1 = net1.forward_groups(aug_pairs)
     with torch.cuda.stream(s2):
         a2 = net2.forward_groups(aug_pairs)
         if augset is not None:
-            a2 = reverseaug(augset, a2, 2)                        # :271-272, no host round trip
-        pl2, wm2 = pseudo_label_ensemble(a2, temperature)         # :274-292
+            a2 = reverseaug(augset, a2, a2[0].shape[1])           # :271-272, no host round trip
+        pl2, wm2 = pseudo_label_ensemble(a2, expo)                # :274-292
     if augset is not None:
-        a1 = reverseaug(augset, a1, 2)
-    pl1, wm1 = pseudo_label_ensemble(a1, temperature)
+        a1 = reverseaug(augset, a1, a1[0].shape[1])
+    pl1, wm1 = pseudo_label_ensemble(a1, expo)
+    if eval_aug:
+        net1.train()
+        net2.train()
     opt1.zero_grad()
     opt2.zero_grad()
-    o1 = net1(inphase, outphase)                                  # :301-302
+    o1 = fwd(net1, inphase, outphase)                             # :301-302
     with torch.cuda.stream(s2):
-        o2 = net2(inphase, outphase)
+        o2 = fwd(net2, inphase, outphase)
     if two:
         cur.wait_stream(s2)
     loss1, loss2, indx1, indx2 = loss_op(o1, o2, targets1, targets2, pl1, wm1, pl2, wm2, rate)   # :303-321
@@ -115,19 +133,34 @@ def coteach_step(net1, net2, opt1, opt2, loss_op, inphase, outphase, aug_pairs, 
             cur.wait_stream(s2)
         opt2.step()
     return dict(outputs1=o1.detach(), outputs2=o2.detach(), loss1=loss1.detach(), loss2=loss2.detach(),
-                indx1=indx1, indx2=indx2, extra=loss_op.last)
+                indx1=indx1, indx2=indx2, extra=loss_op.last, pl1=pl1, pl2=pl2, wm1=wm1, wm2=wm2)
 
 
-def Train(args=None):
-    from aide_amd.models_twomodalinputs import fuseunet
+# The three forms of the reference's nine `*_proposed_*` scripts (oracle.steps.proposed_step; fixture g20 executes their loop bodies)
+VARIANTS = {
+    'chaos': dict(two_modal=True, eval_aug=False, sharpen='pow', keep=lambda bs: min(2, bs)),
+    'kidney': dict(two_modal=False, eval_aug=True, sharpen='root', keep=lambda bs: min(2, bs)),        # also prostate
+    'breast': dict(two_modal=False, eval_aug=True, sharpen='root', keep=lambda bs: int(bs / 2)),
+}
+
+
+def Train(args=None, variant='chaos'):
     from aide_amd.optim import Adam
     from aide_amd.synthetic import chaos_batch
     from aide_amd.utils import CoTeachingProposedLoss
     from aide_amd.utils.poly_lr_scheduler import make_scheduler
     from aide_amd.distributed import init_from_env, attach
+    from aide_amd.train_files.trainchaos_comparison_1case import build_model, evaluate_case
     args = args or parse_args()
-    if args.model_name != 'fuseunet':
-        raise ValueError('Model not implemented')
+    var = VARIANTS[variant]
+    if var['two_modal']:
+        if args.model_name != 'fuseunet':                                # :75-78
+            raise ValueError('Model not implemented')
+        names = (args.model_name, args.model_name)
+    else:
+        names = (args.model1_name, args.model2_name)
+        if any(nm not in ('UNet', 'UNetsa') for nm in names):            # trainkidney_proposed_mask1.py:73-80
+            raise ValueError('Model not implemented')
     torch.manual_seed(args.torch_seed)
     torch.cuda.manual_seed_all(args.torch_seed)
     np.random.seed(args.torch_seed)
@@ -135,15 +168,16 @@ def Train(args=None):
     # reference: nn.DataParallel over --gpu_order (:183-186); here one process per GPU, rank r on gpu_order[r], per-replica
     # BatchNorm statistics and small-loss selection, both networks' gradients mean-all-reduced over RCCL
     rank, world, device = init_from_env([int(d) for d in args.gpu_order.split(',')])
-    net1, net2 = fuseunet(2).to(device), fuseunet(2).to(device)
+    net1, net2 = build_model(names[0], 2).to(device), build_model(names[1], 2).to(device)
     reducers = (attach(net1), attach(net2))          # noqa: F841
     loss_op = CoTeachingProposedLoss(cediceweight=args.cedice_weight, ceclassweight=args.ceclass_weight,
-                                     segcor_weight=args.segcor_weight, keep=min(2, args.batch_size))
+                                     segcor_weight=args.segcor_weight, keep=var['keep'](args.batch_size))
     opt1 = Adam(net1.parameters(), lr=args.lr, amsgrad=True)
     opt2 = Adam(net2.parameters(), lr=args.lr, amsgrad=True)
     sch1 = make_scheduler(args.lr_policy, opt1, args.num_epoch)        # :236-240
     sch2 = make_scheduler(args.lr_policy, opt2, args.num_epoch)
     g = torch.Generator(device='cpu').manual_seed(args.torch_seed)
+    single = not var['two_modal']
     best = 0.0                                                        # :244
     for epoch in range(args.num_epoch):
         ts = time.time()
@@ -155,9 +189,13 @@ def Train(args=None):
         for it in range(args.steps_per_epoch):
             xin, xout, t = chaos_batch(args.batch_size, args.img_size,
                                        seed=(args.torch_seed * 100003 + epoch * 1009 + it) * world + rank)
-            augs = [((xin * (1 + 0.1 * torch.randn(1, generator=g))).to(device),
-                     (xout * (1 + 0.1 * torch.randn(1, generator=g))).to(device)) for _ in range(4)]
-            xin, xout, t = xin.to(device), xout.to(device), t.to(device)
+            if single:
+                augs = [(xin * (1 + 0.1 * torch.randn(1, generator=g))).to(device) for _ in range(4)]
+                xin, xout, t = xin.to(device), None, t.to(device)
+            else:
+                augs = [((xin * (1 + 0.1 * torch.randn(1, generator=g))).to(device),
+                         (xout * (1 + 0.1 * torch.randn(1, generator=g))).to(device)) for _ in range(4)]
+                xin, xout, t = xin.to(device), xout.to(device), t.to(device)
             # augmentation bookkeeping as the loader's dict (:81-95): 4 augmentations per sample, random flips and rotations
             # within +-args.rotation; the logits are mapped back on the device (aide_reverse_aug)
             augset = {'augno': [4] * args.batch_size}
@@ -166,7 +204,7 @@ def Train(args=None):
                 augset['degree%d' % (k + 1)] = [float((torch.rand(1, generator=g) * 2 - 1) * args.rotation)
                                                 for _ in range(args.batch_size)]
             r = coteach_step(net1, net2, opt1, opt2, loss_op, xin, xout, augs, t, t, rate, args.temperature, augset=augset,
-                             pipeline=True)
+                             pipeline=True, eval_aug=var['eval_aug'], sharpen=var['sharpen'])
             l1 += r['loss1']
             l2 += r['loss2']
         join_networks()
@@ -174,9 +212,8 @@ def Train(args=None):
             sch1.step()
             sch2.step()
         # per-case evaluation of both networks and the best-checkpoint rule of :495-526 (average of the two case Dice values)
-        from aide_amd.train_files.trainchaos_comparison_1case import evaluate_case
-        cd1 = evaluate_case(net1, args, device, False, epoch)
-        cd2 = evaluate_case(net2, args, device, False, epoch)
+        cd1 = evaluate_case(net1, args, device, single, epoch)
+        cd2 = evaluate_case(net2, args, device, single, epoch)
         if rank == 0:
             logging.info('epoch %d loss1 %.4f loss2 %.4f traincase_dice %.3f %.3f time %.1fs', epoch + 1,
                          float(l1) / args.steps_per_epoch, float(l2) / args.steps_per_epoch, cd1, cd2, time.time() - ts)
@@ -185,7 +222,7 @@ def Train(args=None):
                 os.makedirs(args.checkpoint, exist_ok=True)
                 # file names of :178-179, :512-513, :524-525 -- including the reference's own spelling of the second one
                 # ('..._net2_besttraincasedicde.pkl'), which its test scripts open
-                stem = '%s_temp%s_r%d' % (args.model_name, args.temperature, args.repetition)
+                stem = '%s_temp%s_r%d' % (names[0], args.temperature, args.repetition)
                 for k, net, suffix in ((1, net1, 'besttraincasedice'), (2, net2, 'besttraincasedicde')):
                     torch.save({'net': net.state_dict(), 'loss': float(l1 if k == 1 else l2) / args.steps_per_epoch,
                                 'epoch': epoch + 1},

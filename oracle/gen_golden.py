@@ -1053,8 +1053,151 @@ def g19_reverseaug():
     print('g19_reverseaug.npz: %d reverseaug cases and both sharpen flavours reproduced bit for bit by the oracle' % case)
 
 
+def _ref_train_loop_body(path):
+    """The statements of the TRAINING loop body of a reference `*_proposed_*` script -- the first `for batch_idx, (...) in
+    tqdm(enumerate(train_loader), ...)` inside its `for epoch in ...` loop -- compiled in memory from the script's own syntax
+    tree, to be exec'd in a namespace that supplies what the surrounding function would (nets, criteria, optimizers, a batch)."""
+    import ast
+    tree = ast.parse(open(path).read(), filename=path)
+    epoch_loop = next(n for n in ast.walk(tree) if isinstance(n, ast.For) and isinstance(n.target, ast.Name) and n.target.id == 'epoch')
+    inner = next(n for n in epoch_loop.body if isinstance(n, ast.For) and 'train_loader' in ast.dump(n.iter))
+    first, last = inner.body[0].lineno, inner.body[-1].end_lineno
+    return compile(ast.Module(body=inner.body, type_ignores=[]), path, 'exec'), (first, last)
+
+
+def g20_proposed_variants(ref_f, ref_u, ref_utils):
+    """The co-teaching step in the three forms of the reference's `*_proposed_*` scripts, each produced by EXECUTING the
+    script's own training-loop body (see _ref_train_loop_body) with the imported reference modules, non-identity flips /
+    rotations through its own reverseaug / reverseaugbatch and its own sharpen:
+      chaos   trainchaos_proposed_30cases1labeled.py:262-330   fuseunet, bs 4, train-mode passes, p^T, keep 2
+      kidney  trainkidney_proposed_mask1.py:266-338            UNet, bs 4, eval-mode passes, p^(1/T), keep 2
+      breast  trainbreast_dataset3_proposed_272cases25labeled.py:258-336   UNet, bs 8, eval-mode passes, p^(1/T), keep 4
+    and oracle.steps.proposed_step (oracle nets and losses, same seeds) must reproduce loss / indices / gradients bit for bit."""
+    import types
+    import warnings
+    import oracle
+    from PIL import Image
+    from oracle import steps, losses
+    tf = os.path.join(REF, 'train_files')
+    cases = [('chaos', os.path.join(tf, 'trainchaos_proposed_30cases1labeled.py'), 'reverseaug', True, 4, 0.5, 2, False, losses.sharpen),
+             ('kidney', os.path.join(tf, 'trainkidney_proposed_mask1.py'), 'reverseaugbatch', False, 4, 0.5, 2, True, losses.sharpen_root),
+             ('breast', os.path.join(tf, 'trainbreast_dataset3_proposed_272cases25labeled.py'), 'reverseaugbatch', False, 8, 2.0, 4, True,
+              losses.sharpen_root)]
+    fx = {}
+    s = 32
+    w = torch.tensor([1.0, 1.0])
+    for name, path, revname, two_modal, n, temp, keep, eval_aug, sharpen_fn in cases:
+        body, lines = _ref_train_loop_body(path)
+        rev, shp = _ref_functions(path, [revname, 'sharpen'], dict(torch=torch, np=np, Image=Image))
+        g = torch.Generator().manual_seed(977 + n)
+        nin = 2 if two_modal else 1
+        xs = [torch.randn(n, 3, s, s, generator=g) for _ in range(nin)]
+        t1 = (torch.rand(n, s, s, generator=g) > 0.7).long()
+        t2 = (torch.rand(n, s, s, generator=g) > 0.65).long()
+        augs = [[x + 0.05 * torch.randn(n, 3, s, s, generator=g) for x in xs] for _ in range(4)]
+        augset = {'augno': [4] * n}
+        for k in range(4):
+            augset['hflip%d' % (k + 1)] = [int(v) for v in torch.randint(0, 2, (n,), generator=g)]
+            deg = (torch.rand(n, generator=g) * 120.0 - 60.0).tolist()
+            if k == 1:
+                deg[0], deg[1] = 90.0, 180.0                     # PIL's exact fast paths, too
+            augset['degree%d' % (k + 1)] = [float(d) for d in deg]
+        rate = 0.36                                               # (epoch 12 of a 20-epoch warm-up)
+        key = name + '/'
+        for i, x in enumerate(xs):
+            fx[key + 'x%d' % i] = _np(x)
+        fx[key + 't1'], fx[key + 't2'] = _np(t1), _np(t2)
+        for k in range(4):
+            for i in range(nin):
+                fx[key + 'aug%d_%d' % (k, i)] = _np(augs[k][i])
+            fx[key + 'hflip%d' % (k + 1)] = np.asarray(augset['hflip%d' % (k + 1)], dtype=np.float64)
+            fx[key + 'degree%d' % (k + 1)] = np.asarray(augset['degree%d' % (k + 1)], dtype=np.float64)
+        fx[key + 'meta'] = np.asarray([n, temp, keep, int(eval_aug), rate, nin], dtype=np.float64)
+
+        def nets(fmod, umod):
+            torch.manual_seed(2)
+            ctor = fmod.fuseunet if two_modal else umod.UNet
+            a, b = ctor(2), ctor(2)
+            a.train(), b.train()
+            return a, b
+
+        # ---- the reference: its own loop body, its own modules ----
+        net1, net2 = nets(ref_f, ref_u)
+        ns = dict(torch=torch, np=np, Image=Image, device=torch.device('cpu'), num_classes=2, net1=net1, net2=net2,
+                  criterion=ref_utils.CEMDiceLossImage(cediceweight=w, ceclassweight=w, diceclassweight=w),
+                  corrlosscriterion=ref_utils.MulticlassMSELoss(reduction='none'),
+                  optimizer1=torch.optim.Adam(net1.parameters(), lr=1e-4, amsgrad=True),
+                  optimizer2=torch.optim.Adam(net2.parameters(), lr=1e-4, amsgrad=True),
+                  args=types.SimpleNamespace(batch_size=n, temperature=temp, segcor_weight=[1.0, 10.0]),
+                  rate_schedule=np.full(20, rate), epoch=12, Dice_fn=ref_utils.Dice_fn, sharpen=shp,
+                  train_count=0, train_loss1=0., train_loss2=0., train_dice1=0., train_dice2=0., batch_idx=0)
+        ns[revname] = rev
+        aug_ns = dict((kk, list(v)) for kk, v in augset.items())
+        for k in range(4):
+            if two_modal:
+                aug_ns['imgmodal1%d' % (k + 1)], aug_ns['imgmodal2%d' % (k + 1)] = augs[k][0].clone(), augs[k][1].clone()
+            else:
+                aug_ns['img%d' % (k + 1)] = augs[k][0].clone()
+        ns['augset'] = aug_ns
+        if two_modal:          # the CHAOS loader hands one-hot targets; the loop takes channel 1 (:294-295)
+            oh = lambda t: torch.stack([1 - t, t], 1)
+            ns.update(inphase=xs[0].clone(), outphase=xs[1].clone(), targets=oh(t1), targets1=oh(t1), targets2=oh(t2))
+        else:
+            ns.update(inputs=xs[0].clone(), targets=t1.clone(), targets1=t1.clone(), targets2=t2.clone())
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            exec(body, ns)
+        ref = dict(loss1=ns['loss1'].detach(), loss2=ns['loss2'].detach(), indx1=ns['indx1'], indx2=ns['indx2'],
+                   loss1_pre=ns['loss1_segpre'].detach(), loss2_pre=ns['loss2_segpre'].detach(),
+                   outputs1=ns['outputs1'].detach(), outputs2=ns['outputs2'].detach(),
+                   pl1=ns['pseudo_label1'], pl2=ns['pseudo_label2'], wm1=ns['weightmap1'], wm2=ns['weightmap2'],
+                   g1=torch.stack([p.grad.double().norm() for p in net1.parameters()]),
+                   g2=torch.stack([p.grad.double().norm() for p in net2.parameters()]),
+                   head1=net1.last_conv1.weight.detach().clone(), head2=net2.last_conv1.weight.detach().clone())
+        bn_ref = [m for m in net1.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
+        ref['nbt'] = bn_ref.num_batches_tracked.clone()
+        ref['rm'] = bn_ref.running_mean.clone()
+        assert net1.training and net2.training
+        assert ns['train_count'] == n
+
+        # ---- the oracle restatement ----
+        o1n, o2n = nets(oracle, oracle)
+        crit = oracle.CEMDiceLossImage(cediceweight=w, ceclassweight=w, diceclassweight=w)
+        corr = oracle.MulticlassMSELoss(reduction='none')
+        oa = torch.optim.Adam(o1n.parameters(), lr=1e-4, amsgrad=True)
+        ob = torch.optim.Adam(o2n.parameters(), lr=1e-4, amsgrad=True)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            r = steps.proposed_step(o1n, o2n, crit, corr, oa, ob, xs[0], xs[1] if two_modal else None,
+                                    [tuple(a) for a in augs], t1, t2, rate, temperature=temp,
+                                    reverse=lambda lst: steps.reverseaug(augset, lst, 2), keep=keep, eval_aug=eval_aug,
+                                    sharpen_fn=sharpen_fn)
+        r['g1'] = torch.stack([p.grad.double().norm() for p in o1n.parameters()])
+        r['g2'] = torch.stack([p.grad.double().norm() for p in o2n.parameters()])
+        r['head1'], r['head2'] = o1n.last_conv1.weight.detach().clone(), o2n.last_conv1.weight.detach().clone()
+        bn_o = [m for m in o1n.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
+        r['nbt'], r['rm'] = bn_o.num_batches_tracked.clone(), bn_o.running_mean.clone()
+        for k in ('outputs1', 'outputs2', 'loss1', 'loss2', 'indx1', 'indx2', 'loss1_pre', 'loss2_pre', 'pl1', 'pl2', 'wm1', 'wm2',
+                  'g1', 'g2', 'head1', 'head2', 'nbt', 'rm'):
+            _same(r[k], ref[k], 'g20 %s %s' % (name, k))
+        for k in ('loss1', 'loss2', 'indx1', 'indx2', 'loss1_pre', 'loss2_pre', 'g1', 'g2', 'head1', 'head2', 'nbt', 'rm'):
+            fx[key + k] = _np(ref[k])
+        for k in ('outputs1', 'outputs2', 'pl1', 'pl2', 'wm1', 'wm2'):
+            fx[key + k] = _sub(ref[k], 2048)
+        fx[key + 'min_gap1'] = np.diff(np.sort(_np(ref['loss1_pre']))).min()
+        fx[key + 'min_gap2'] = np.diff(np.sort(_np(ref['loss2_pre']))).min()
+        print('g20 %-6s (loop body lines %d-%d executed) loss %.6f %.6f indx %s %s gaps %.3g %.3g nbt %d' % (
+            name, lines[0], lines[1], float(ref['loss1']), float(ref['loss2']), ref['indx1'].tolist(), ref['indx2'].tolist(),
+            fx[key + 'min_gap1'], fx[key + 'min_gap2'], int(ref['nbt'])))
+    np.savez_compressed(os.path.join(OUT, 'g20_proposed_variants.npz'), **fx)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['g20']:
+        torch.set_num_threads(8)
+        ref_f, ref_u, ref_utils = _import_reference()
+        return g20_proposed_variants(ref_f, ref_u, ref_utils)
     if sys.argv[1:] == ['g19']:
         return g19_reverseaug()
     if sys.argv[1:] == ['g18']:
@@ -1125,6 +1268,7 @@ def main():
     g17_multiclass(ref_f, ref_u, ref_utils)
     g18_dropregionce_scale(ref_utils)
     g19_reverseaug()
+    g20_proposed_variants(ref_f, ref_u, ref_utils)
     print('all golden fixtures written to', OUT)
 
 

@@ -44,14 +44,15 @@ def reverseaug(augset, augoutput, classno):
     return augoutput
 
 
-def pseudo_labels(aug_logits, temperature):
+def pseudo_labels(aug_logits, temperature, sharpen_fn=None):
     """trainchaos_proposed_30cases1labeled.py:274-292 — mean softmax over the (already
-    reverse-augmented) passes, sharpen, weightmap = 1 - 4 p0 p1."""
+    reverse-augmented) passes, sharpen, weightmap = 1 - 4 p0 p1.  sharpen_fn: losses.sharpen (p^T, the CHAOS script) or
+    losses.sharpen_root (p^(1/T), trainkidney_proposed_mask1.py:113-117 and the other UNet scripts)."""
     acc = None
     for lg in aug_logits:
         sm = F.softmax(lg, dim=1)
         acc = sm if acc is None else acc + sm
-    pl = sharpen(acc / float(len(aug_logits)), temperature)
+    pl = (sharpen_fn or sharpen)(acc / float(len(aug_logits)), temperature)
     wm = (1.0 - 4.0 * pl[:, 0] * pl[:, 1]).unsqueeze(1)
     return pl, wm
 
@@ -59,7 +60,9 @@ def pseudo_labels(aug_logits, temperature):
 def proposed_losses(criterion, corr, outputs1, outputs2, targets1, targets2,
                     pl1, wm1, pl2, wm2, rate, segcor_weight=(1.0, 10.0), keep=2):
     """trainchaos_proposed_30cases1labeled.py:303-321. ``criterion`` = CEMDiceLossImage,
-    ``corr`` = MulticlassMSELoss('none'). Returns (loss1, loss2, indx1, indx2, seg1pre, seg2pre)."""
+    ``corr`` = MulticlassMSELoss('none'). Returns (loss1, loss2, indx1, indx2, seg1pre, seg2pre).
+    keep: 2 in the CHAOS / kidney scripts (:307-310), int(batch_size / 2) in the breast scripts
+    (trainbreast_dataset3_proposed_272cases25labeled.py:303-312)."""
     l1pre = criterion(outputs1, targets2)          # net1 scored against net2's labels (:303)
     l2pre = criterion(outputs2, targets1)
     _, indx1 = l1pre.sort()
@@ -78,30 +81,45 @@ def proposed_losses(criterion, corr, outputs1, outputs2, targets1, targets2,
 
 def proposed_step(net1, net2, criterion, corr, opt1, opt2, inphase, outphase, aug_pairs,
                   targets1, targets2, rate, temperature=1.0, segcor_weight=(1.0, 10.0),
-                  reverse=None):
-    """One AIDE co-teaching step. ``aug_pairs`` = list of (imgmodal1_k, imgmodal2_k);
-    ``reverse`` = callable(list_of_logits)->list_of_logits (identity when None; the PIL
-    reverse-augmentation of :81-95 is outside the hot path for parity runs)."""
+                  reverse=None, keep=2, eval_aug=False, sharpen_fn=None):
+    """One AIDE co-teaching step. ``aug_pairs`` = list of (imgmodal1_k, imgmodal2_k) -- or of single tensors / 1-tuples for a
+    single-modal net (``outphase=None``); ``reverse`` = callable(list_of_logits)->list_of_logits (identity when None).
+    The three forms the reference's nine ``*_proposed_*`` scripts take (pinned by fixture g20, which EXECUTES their loop bodies):
+      CHAOS (trainchaos_proposed_30cases1labeled.py:260-325): fuseunet, train-mode augmentation passes, sharpen p^T, keep 2;
+      kidney / prostate (trainkidney_proposed_mask1.py:262-333): UNet, nets in eval() for the augmentation passes (:265-266)
+        and back to train() (:290-291), sharpen p^(1/T), keep 2;
+      breast (trainbreast_dataset3_proposed_272cases25labeled.py:258-331): as kidney with keep = int(batch_size / 2) (:304)."""
+    def fwd(net, x, y):
+        return net(x, y) if y is not None else net(x)
+    if eval_aug:
+        net1.eval()
+        net2.eval()
     a1, a2 = [], []
-    for xin, xout in aug_pairs:                                   # :265-269 (train-mode BN!)
-        a1.append(net1(xin, xout).detach())
-        a2.append(net2(xin, xout).detach())
+    for pair in aug_pairs:
+        pair = tuple(pair) if isinstance(pair, (tuple, list)) else (pair,)
+        xin, xout = pair[0], (pair[1] if len(pair) > 1 else None)
+        a1.append(fwd(net1, xin, xout).detach())
+        a2.append(fwd(net2, xin, xout).detach())
     if reverse is not None:
         a1, a2 = reverse(a1), reverse(a2)
-    pl1, wm1 = pseudo_labels(a1, temperature)
-    pl2, wm2 = pseudo_labels(a2, temperature)
+    pl1, wm1 = pseudo_labels(a1, temperature, sharpen_fn)
+    pl2, wm2 = pseudo_labels(a2, temperature, sharpen_fn)
+    if eval_aug:
+        net1.train()
+        net2.train()
     opt1.zero_grad()
     opt2.zero_grad()
-    o1 = net1(inphase, outphase)
-    o2 = net2(inphase, outphase)
+    o1 = fwd(net1, inphase, outphase)
+    o2 = fwd(net2, inphase, outphase)
     loss1, loss2, indx1, indx2, l1pre, l2pre = proposed_losses(
-        criterion, corr, o1, o2, targets1, targets2, pl1, wm1, pl2, wm2, rate, segcor_weight)
+        criterion, corr, o1, o2, targets1, targets2, pl1, wm1, pl2, wm2, rate, segcor_weight, keep)
     loss1.backward(retain_graph=True)                             # :322-325
     opt1.step()
     loss2.backward()
     opt2.step()
     return dict(outputs1=o1.detach(), outputs2=o2.detach(), loss1=loss1.detach(),
-                loss2=loss2.detach(), indx1=indx1, indx2=indx2, loss1_pre=l1pre, loss2_pre=l2pre)
+                loss2=loss2.detach(), indx1=indx1, indx2=indx2, loss1_pre=l1pre, loss2_pre=l2pre,
+                pl1=pl1, pl2=pl2, wm1=wm1, wm2=wm2)
 
 
 def predict_case(net, inphase, outphase=None):

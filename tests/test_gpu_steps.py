@@ -76,6 +76,79 @@ def test_proposed_coteaching_step(dev):
         assert np.median(np.abs(gn[live] - fx[key + 'g1'][live]) / fx[key + 'g1'][live]) < 1e-3
 
 
+@pytest.mark.parametrize('name', ['chaos', 'kidney', 'breast'])
+def test_proposed_step_variants_g20(dev, name):
+    """The co-teaching step in the three forms of the reference's nine `*_proposed_*` scripts against fixture g20, which was
+    produced by EXECUTING the scripts' own loop bodies (oracle/gen_golden.py::g20_proposed_variants):
+      chaos   fuseunet, bs 4, train-mode augmentation passes, p^T, keep 2     (trainchaos_proposed_30cases1labeled.py:262-330)
+      kidney  UNet, bs 4, eval-mode passes, p^(1/T), keep 2                    (trainkidney_proposed_mask1.py:266-338)
+      breast  UNet, bs 8, eval-mode passes, p^(1/T), keep int(bs / 2) = 4      (trainbreast_dataset3_proposed_272cases25labeled.py:258-336)
+    with non-identity flips / rotations through the on-device reverse augmentation.  Index vectors bit-exact (the recorded
+    adjacent-loss gaps exceed the per-image loss error tenfold), losses / pseudo labels / weight maps / gradient norms <= 1e-3."""
+    from aide_amd.models_twomodalinputs import fuseunet
+    from aide_amd.models_singlemodalinput import UNet
+    from aide_amd.optim import Adam
+    from aide_amd.utils import CoTeachingProposedLoss
+    from aide_amd.train_files.trainchaos_proposed_30cases1labeled import coteach_step, join_networks, VARIANTS
+    from test_oracle_golden import g20_case, sub
+    fx = np.load(os.path.join(GOLD, 'g20_proposed_variants.npz'))
+    c = g20_case(fx, name)
+    key = name + '/'
+    var = VARIANTS[name]
+    assert var['two_modal'] == c['two_modal'] and var['eval_aug'] == c['eval_aug'] and var['keep'](c['n']) == c['keep']
+    D = lambda t: t.to(dev)
+    torch.manual_seed(2)
+    ctor = fuseunet if c['two_modal'] else UNet
+    n1, n2 = ctor(2).to(dev), ctor(2).to(dev)
+    n1.train(); n2.train()
+    o1, o2 = Adam(n1.parameters(), lr=1e-4, amsgrad=True), Adam(n2.parameters(), lr=1e-4, amsgrad=True)
+    op = CoTeachingProposedLoss(cediceweight=[1.0, 1.0], ceclassweight=[1.0, 1.0], segcor_weight=[1.0, 10.0], keep=c['keep'])
+    augs = [tuple(D(a) for a in pair) for pair in c['augs']]
+    r = coteach_step(n1, n2, o1, o2, op, D(c['xs'][0]), D(c['xs'][1]) if c['two_modal'] else None, augs, D(c['t1']), D(c['t2']),
+                     c['rate'], temperature=c['temp'], augset=c['augset'], eval_aug=var['eval_aug'], sharpen=var['sharpen'])
+    join_networks()
+    assert n1.training and n2.training
+    pre1, pre2 = r['extra']['per_image1'].cpu().numpy(), r['extra']['per_image2'].cpu().numpy()
+    err = max(np.abs(pre1 - fx[key + 'loss1_pre']).max(), np.abs(pre2 - fx[key + 'loss2_pre']).max())
+    assert err < 1e-3 * np.abs(fx[key + 'loss1_pre']).max()
+    assert err * 10 < min(float(fx[key + 'min_gap1']), float(fx[key + 'min_gap2'])), (err, fx[key + 'min_gap1'], fx[key + 'min_gap2'])
+    assert r['indx1'].cpu().tolist() == fx[key + 'indx1'].tolist()              # bit-exact selection, bs 8 / keep 4 included
+    assert r['indx2'].cpu().tolist() == fx[key + 'indx2'].tolist()
+    for k in ('loss1', 'loss2'):
+        assert abs(r[k].item() - float(fx[key + k])) < 1e-3 * abs(float(fx[key + k])), k
+    for k in ('pl1', 'pl2', 'wm1', 'wm2'):
+        assert np.abs(sub(r[k].cpu().numpy(), 2048) - fx[key + k]).max() < 1e-3, k
+    bn = [m for m in n1.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
+    assert int(bn.num_batches_tracked) == int(fx[key + 'nbt']) == (5 if name == 'chaos' else 1)
+    assert np.abs(bn.running_mean.cpu().numpy() - fx[key + 'rm']).max() < 1e-5
+    for net, gk in ((n1, 'g1'), (n2, 'g2')):
+        live = fx[key + gk] > 1e-5
+        gn = np.array([p.grad.double().norm().item() for p in net.parameters()])
+        assert np.median(np.abs(gn[live] - fx[key + gk][live]) / fx[key + gk][live]) < 1e-3, gk
+    assert np.abs(n1.last_conv1.weight.detach().cpu().numpy() - fx[key + 'head1']).max() < 1e-5
+
+
+def test_grouped_forward_in_eval_mode(dev):
+    """forward_groups under net.eval() (the augmentation passes of the UNet co-teaching scripts, trainkidney_proposed_mask1.py:
+    265-272): the stacked pass uses the running statistics, updates nothing and equals the sequential eval-mode forwards."""
+    from aide_amd.models_singlemodalinput import UNet
+    torch.manual_seed(2)
+    net = UNet(2).to(dev)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(2, 3, 64, 64, generator=g).to(dev) for _ in range(4)]
+    net.train()
+    with torch.no_grad():
+        net(xs[0])                                 # running statistics that are not the initial (0, 1)
+    net.eval()
+    bufs = [b.clone() for b in net.buffers()]
+    with torch.no_grad():
+        seq = [net(x).clone() for x in xs]
+    grp = net.forward_groups(xs)
+    for a, b in zip(seq, grp):
+        assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
+    assert all(torch.equal(a, b) for a, b in zip(bufs, net.buffers()))
+
+
 def test_coteaching_two_streams_is_bit_identical(dev):
     """Network 2 on its own stream (TWO_NET_STREAMS, the default) and packed filters shared between a network's plans
     (engine.SHARED_PACKS, the default) are schedules, not different computations: three steps from the same initial state give
@@ -146,6 +219,56 @@ def test_cli_smoke(dev, tmp_path):
     build_model('fuseunet', 2).load_state_dict(state['net'])
     with pytest.raises(ValueError, match='Model not implemented'):
         build_model('resnet', 2)
+
+
+def test_cli_smoke_default_size(dev):
+    """BASELINE config 1 literally: `--model_name fuseunet --batch_size 4` at the script's default 256 x 256
+    (trainchaos_comparison_1case.py:21-49,186-202), three steps through the CLI on the device; the loss trajectory against the
+    oracle's comparison_step (the restated :195-199 on aten CPU ops) run on the SAME chaos_batch seeds the CLI draws."""
+    import oracle
+    from oracle import steps
+    from aide_amd.synthetic import chaos_batch
+    from aide_amd.train_files.trainchaos_comparison_1case import parse_args, Train
+    args = parse_args(['--model_name', 'fuseunet', '--batch_size', '4', '--img_size', '256', '--num_epoch', '1',
+                       '--steps_per_epoch', '3', '--checkpoint', ''])
+    assert args.img_size == parse_args([]).img_size == 256 and args.batch_size == parse_args([]).batch_size == 4
+    net, hist = Train(args)
+    got = hist['step_loss']
+    assert len(got) == 3
+    torch.manual_seed(args.torch_seed)
+    ref_net = oracle.fuseunet(2)
+    ref_net.train()
+    w = torch.tensor([1.0, 1.0])
+    crit = oracle.CEMDiceLoss(cediceweight=w, ceclassweight=w, diceclassweight=w)
+    opt = torch.optim.Adam(ref_net.parameters(), lr=args.lr, amsgrad=True)
+    want = []
+    for it in range(3):
+        xin, xout, t = chaos_batch(4, 256, seed=args.torch_seed * 100003 + it)
+        _, loss = steps.comparison_step(ref_net, crit, opt, xin, xout, t)
+        want.append(float(loss))
+    rel = np.abs(np.array(got) - np.array(want)) / np.array(want)
+    # step 1 sees identical weights; later steps inherit Adam's lr * sign(g) amplification of rounding differences (see
+    # test_comparison_three_steps and tests/test_oracle_golden.py::test_trajectory_noise_floor)
+    assert rel[0] < 1e-4 and rel[1] < 1e-3 and rel[2] < 3e-3, (got, want)
+
+
+def test_cli_unet_proposed_smoke(dev, tmp_path):
+    """The single-modal co-teaching CLIs (flag tables of trainkidney_proposed_mask1.py:28-60 and
+    trainbreast_dataset3_proposed_272cases25labeled.py): --model1_name / --model2_name, eval-mode augmentation passes,
+    p^(1/T), keep 2 resp. int(batch_size / 2)."""
+    from aide_amd.train_files import trainkidney_proposed_mask1 as K, trainbreast_dataset3_proposed_272cases25labeled as B
+    a = K.parse_args([])
+    assert (a.model1_name, a.model2_name, a.img_size, a.lr, a.repetition) == ('UNet', 'UNet', 512, 1e-5, 100)
+    b = B.parse_args([])
+    assert (b.img_size, b.repetition, b.checkpoint) == (384, 1, 'checkpoint_breastdata3_proposed272cases25labels')
+    for mod, bs in ((K, 2), (B, 4)):
+        args = mod.parse_args(['--batch_size', str(bs), '--img_size', '64', '--num_epoch', '2', '--steps_per_epoch', '2',
+                               '--warmup_epoch', '2', '--temperature', '0.5', '--checkpoint', str(tmp_path / mod.__name__)])
+        n1, n2 = mod.Train(args)
+        assert all(torch.isfinite(p).all() for p in list(n1.parameters()) + list(n2.parameters()))
+        assert n1.training and n2.training
+    with pytest.raises(ValueError, match='Model not implemented'):
+        K.Train(K.parse_args(['--model1_name', 'fuseunet']))
 
 
 def test_cli_proposed_smoke(dev, tmp_path):

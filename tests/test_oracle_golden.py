@@ -412,3 +412,57 @@ def test_g19_reverseaug_and_sharpen_pinned_to_reference_text():
     for T in (0.5, 1.0, 2.0):
         assert torch.equal(losses.sharpen(p.clone(), T), torch.from_numpy(fx['sharpen/pow_T_%g' % T]))
         assert torch.equal(losses.sharpen_root(p.clone(), T), torch.from_numpy(fx['sharpen/pow_invT_%g' % T]))
+
+
+G20 = {'chaos': (True, None), 'kidney': (False, None), 'breast': (False, None)}
+
+
+def g20_case(fx, name):
+    """-> dict(xs, t1, t2, augs (list of tuples), augset, n, temp, keep, eval_aug, rate) of one variant of g20_proposed_variants.npz"""
+    key = name + '/'
+    n, temp, keep, eval_aug, rate, nin = [float(v) for v in fx[key + 'meta']]
+    n, keep, nin = int(n), int(keep), int(nin)
+    augset = {'augno': [4] * n}
+    for k in range(1, 5):
+        augset['hflip%d' % k] = [int(v) for v in fx[key + 'hflip%d' % k]]
+        augset['degree%d' % k] = [float(v) for v in fx[key + 'degree%d' % k]]
+    return dict(xs=[torch.from_numpy(fx[key + 'x%d' % i]) for i in range(nin)], t1=torch.from_numpy(fx[key + 't1']),
+                t2=torch.from_numpy(fx[key + 't2']),
+                augs=[tuple(torch.from_numpy(fx[key + 'aug%d_%d' % (k, i)]) for i in range(nin)) for k in range(4)],
+                augset=augset, n=n, temp=temp, keep=keep, eval_aug=bool(eval_aug), rate=rate, two_modal=nin == 2)
+
+
+@pytest.mark.parametrize('name', ['chaos', 'kidney', 'breast'])
+def test_g20_proposed_step_variants(name):
+    """oracle.steps.proposed_step in the three forms of the reference's `*_proposed_*` scripts against what the scripts' OWN
+    loop bodies produced (gen_golden.g20_proposed_variants executes them from the syntax tree with the imported reference
+    modules): fuseunet / train-mode passes / p^T / keep 2; UNet / eval-mode passes / p^(1/T) / keep 2; UNet, bs 8, keep 4."""
+    import warnings
+    from oracle import losses
+    fx = load('g20_proposed_variants.npz')
+    c = g20_case(fx, name)
+    key = name + '/'
+    w = torch.tensor([1.0, 1.0])
+    torch.manual_seed(2)
+    ctor = oracle.fuseunet if c['two_modal'] else oracle.UNet
+    n1, n2 = ctor(2), ctor(2)
+    n1.train(), n2.train()
+    o1 = torch.optim.Adam(n1.parameters(), lr=1e-4, amsgrad=True)
+    o2 = torch.optim.Adam(n2.parameters(), lr=1e-4, amsgrad=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        r = steps.proposed_step(n1, n2, oracle.CEMDiceLossImage(w, w, w), oracle.MulticlassMSELoss('none'), o1, o2,
+                                c['xs'][0], c['xs'][1] if c['two_modal'] else None, c['augs'], c['t1'], c['t2'], c['rate'],
+                                temperature=c['temp'], reverse=lambda lst: steps.reverseaug(c['augset'], lst, 2),
+                                keep=c['keep'], eval_aug=c['eval_aug'],
+                                sharpen_fn=losses.sharpen if name == 'chaos' else losses.sharpen_root)
+    assert r['indx1'].tolist() == fx[key + 'indx1'].tolist()
+    assert r['indx2'].tolist() == fx[key + 'indx2'].tolist()
+    close(r['loss1'], fx[key + 'loss1'], rtol=1e-4)
+    close(r['loss2'], fx[key + 'loss2'], rtol=1e-4)
+    close(r['loss1_pre'], fx[key + 'loss1_pre'], rtol=1e-4)
+    close(sub(r['pl1'], 2048), fx[key + 'pl1'], rtol=1e-4)
+    close(sub(r['wm2'], 2048), fx[key + 'wm2'], rtol=1e-4)
+    bn = [m for m in n1.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
+    assert int(bn.num_batches_tracked) == int(fx[key + 'nbt']) == (5 if name == 'chaos' else 1)   # eval-mode passes update nothing
+    assert n1.training and n2.training
