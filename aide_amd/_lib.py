@@ -41,6 +41,18 @@ def parse_header(path=HEADER):
 
 
 TAPE = [None]          # the Tape that records the calls of the running forward / backward (aide_amd/tape.py), or None
+# AIDE_ABI_COVERAGE=<file>: which entry points of the C ABI a process reaches (tools/abi_coverage.py merges the files of a test /
+# bench run into profiles/rNN_abi_coverage.md); a measurement aid, off by default
+COVER = {} if os.environ.get('AIDE_ABI_COVERAGE') else None
+if COVER is not None:
+    import atexit
+    import json
+
+    def _dump_cover():
+        path = '%s.%d' % (os.environ['AIDE_ABI_COVERAGE'], os.getpid())
+        with open(path, 'w') as f:
+            json.dump(COVER, f)
+    atexit.register(_dump_cover)
 
 
 class _Fn(object):
@@ -53,6 +65,8 @@ class _Fn(object):
         self.cfn, self.argtypes, self.name = cfn, argtypes, name
 
     def __call__(self, *args):
+        if COVER is not None:
+            COVER[self.name] = COVER.get(self.name, 0) + 1
         tape = TAPE[0]
         if tape is None:
             return self.cfn(*args)

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libaide_hip.so')
-SOURCES = ['conv3x3.hip', 'conv3x3_winograd.hip', 'conv3x3_wino4.hip', 'conv3x3_wgrad.hip', 'conv3x3_wgrad4.hip', 'conv3x3_wgrad_stem.hip', 'conv3x3_stem.hip', 'conv3x3_bf16.hip', 'bn.hip', 'spatial.hip', 'loss.hip', 'loss_mc.hip', 'coteach_ext.hip', 'head_adam.hip',
+SOURCES = ['conv3x3.hip', 'conv3x3_winograd.hip', 'conv3x3_wino4.hip', 'conv3x3_wgrad.hip', 'conv3x3_wgrad4.hip', 'conv3x3_wgrad_stem.hip', 'conv3x3_bf16.hip', 'bn.hip', 'spatial.hip', 'loss.hip', 'loss_mc.hip', 'coteach_ext.hip', 'head_adam.hip',
            'convt.hip', 'attention.hip', 'ktimer.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast']
 

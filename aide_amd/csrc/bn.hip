@@ -168,14 +168,16 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(
     float* __restrict__ rstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out, int relu,
     const float* __restrict__ fparts, int nparts, const float* __restrict__ cbias, int pstride, int ng, int groups) {
     __shared__ float coef[2];
-    const int plane = blockIdx.y;                 // n*C + c
+    // grid = (planes, chunks of a plane): the plane index rides on gridDim.x (limit 2^31 - 1) -- a stacked batch of 4 groups x 32
+    // images at C = 512 is 65 536 planes, one more than gridDim.y may hold
+    const int plane = blockIdx.x;                 // n*C + c
     const int n = plane / C, c = plane - n * C;
     // Stacked batch (aide_bn_train_fwd_groups): `groups` runs of ng images, each normalised with ITS statistics (`count`
     // = elements per channel of one group; partials [group][C][splits][2], the conv-epilogue entries of group g at
     // [c][g * nparts ..]).  The publishing block of a channel walks the groups in order -- the running statistics after
     // `groups` sequential forwards, bit for bit -- and leaves the last group's mean / rstd / scale / shift.
     const int mine = n / ng;
-    const bool publisher = blockIdx.x == 0 && n == 0;
+    const bool publisher = blockIdx.y == 0 && n == 0;
     if (threadIdx.x < 64) {
         for (int gi = publisher ? 0 : mine; gi <= (publisher ? groups - 1 : mine); ++gi) {
             double s = 0.0, ss = 0.0;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(
     const ZT* zp = z + (long)n * z_bs + (long)c * HW;
     AT* ap = a + (long)n * a_bs + (long)c * HW;
     const int hw4 = HW / V;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw4; i += gridDim.x * 256) {
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < hw4; i += gridDim.y * 256) {
         float v[V];
         ldv<V>(zp + i * V, v);
 #pragma unroll
@@ -302,13 +304,13 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ZT* __restrict
                                                             AT* __restrict__ a, long a_bs, int C, int HW,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int relu) {
-    const int plane = blockIdx.y;                 // n*C + c
+    const int plane = blockIdx.x;                 // n*C + c (grid = (planes, chunks): see bn_train_apply_kernel)
     const int n = plane / C, c = plane - n * C;
     const float sc = scale[c], sh = shift[c];
     const ZT* zp = z + (long)n * z_bs + (long)c * HW;
     AT* ap = a + (long)n * a_bs + (long)c * HW;
     const int hw4 = HW / V;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw4; i += gridDim.x * 256) {
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < hw4; i += gridDim.y * 256) {
         float v[V];
         ldv<V>(zp + i * V, v);
 #pragma unroll
@@ -618,17 +620,17 @@ int bn_train_fwd_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C,
     if (v8) {
         const int gx8 = max(1, min((HW / 8 + 255) / 256, 16));
         hipLaunchKernelGGL((bn_stats_kernel<8, ZT, false>), dim3(C * splits, groups), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
-        hipLaunchKernelGGL((bn_train_apply_kernel<8, ZT, AT>), dim3(gx8, NT * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+        hipLaunchKernelGGL((bn_train_apply_kernel<8, ZT, AT>), dim3(NT * C, gx8), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
                            num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0, N, groups);
     } else if (v4) {
         hipLaunchKernelGGL((bn_stats_kernel<4, ZT, SLABS>), dim3(C * splits, groups), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
-        hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, NT * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+        hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(NT * C, gx), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
                            num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0, N, groups);
     } else {
         hipLaunchKernelGGL((bn_stats_kernel<1, ZT, false>), dim3(C * splits, groups), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
-        hipLaunchKernelGGL((bn_train_apply_kernel<1, ZT, AT>), dim3(gx, NT * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+        hipLaunchKernelGGL((bn_train_apply_kernel<1, ZT, AT>), dim3(NT * C, gx), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
                            num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0, N, groups);
     }
@@ -641,8 +643,8 @@ int bn_relu_apply_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C
     const int HW = H * W;
     const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && a_bs % 4 == 0;
     const int gx = max(1, min((HW / (v4 ? 4 : 1) + 255) / 256, 16));
-    if (v4) hipLaunchKernelGGL((bn_relu_apply_kernel<4, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
-    else hipLaunchKernelGGL((bn_relu_apply_kernel<1, ZT, AT>), dim3(gx, N * C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
+    if (v4) hipLaunchKernelGGL((bn_relu_apply_kernel<4, ZT, AT>), dim3(N * C, gx), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
+    else hipLaunchKernelGGL((bn_relu_apply_kernel<1, ZT, AT>), dim3(N * C, gx), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
     return aide_launch_status();
 }
 
@@ -734,7 +736,7 @@ static int bn_parts_launch(const void* z, int z_bf16, int64_t z_bs, void* a, int
     const double count = (double)N * HW;
     const int gx = max(1, min((HW / 4 + 255) / 256, 16));
 #define AIDE_BN_PARTS(ZT, AT)                                                                                                  \
-    hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(gx, N * groups * C), dim3(256), 0, stream, (const ZT*)z, (long)z_bs,    \
+    hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(N * groups * C, gx), dim3(256), 0, stream, (const ZT*)z, (long)z_bs,    \
                        (AT*)a, (long)a_bs, C, HW, (const double*)nullptr, 0, count, gamma, beta, eps, momentum, running_mean, \
                        running_var, num_batches_tracked, mean, rstd, scale, shift, relu, parts, nparts, conv_bias, parts_stride, N, groups)
     if (z_bf16) { if (a_bf16) AIDE_BN_PARTS(bf16_t, bf16_t); else AIDE_BN_PARTS(bf16_t, float); }

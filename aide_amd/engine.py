@@ -90,11 +90,9 @@ USE_WINOGRAD_DGRAD = [True]    # ... for the dgrad direction only
 # multiplies a launch executes per algorithmic (direct-convolution) multiply, by conv mode
 WINO_EXEC = 16.0 / 36.0
 BF16 = 16                      # conv mode id of the bf16-MFMA kernels (conv3x3_bf16.hip)
-STEM = 32                      # forward mode id of the stem kernel (conv3x3_stem.hip: Cin <= 3, taps folded into K, no filter pack)
-EXEC_FRAC = {0: 1.0, 2: 16.0 / 36.0, 4: 36.0 / 144.0, BF16: 1.0, STEM: 28.0 / 27.0}
+EXEC_FRAC = {0: 1.0, 2: 16.0 / 36.0, 4: 36.0 / 144.0, BF16: 1.0}
 # profiler tags = the kernel that does the work of one conv operator call (its split reduce rides along)
-FWD_TAG = {0: 'conv3x3_mfma_kernel', 2: 'conv3x3_wino_kernel', 4: 'conv3x3_wino4_kernel', BF16: 'conv3x3_bf16_kernel',
-           STEM: 'conv3x3_stem_fwd_kernel'}
+FWD_TAG = {0: 'conv3x3_mfma_kernel', 2: 'conv3x3_wino_kernel', 4: 'conv3x3_wino4_kernel', BF16: 'conv3x3_bf16_kernel'}
 WGRAD_TAG = {0: 'conv3x3_wgrad_kernel', 2: 'conv3x3_wgrad_wino_kernel', 4: 'conv3x3_wgrad4_kernel',
              BF16: 'conv3x3_wgrad_bf16_kernel'}
 PRECISIONS = ('fp32', 'bf16')
@@ -109,7 +107,6 @@ STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 wh
 STORE_G_BF16 = [True]          # ... and the gradients of those activations
 REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch tapes (aide_amd/tape.py)
 SHARED_PACKS = [True]          # plans of an engine share packed filters; forward-only plans pack no dgrad direction
-STEM_FWD = [False]             # fp32 3->32 stem convs forward on conv3x3_stem.hip (taps folded into K, filters from the master weights): level in the step, off
 FOLD_EVAL_BN = [True]          # eval-mode BatchNorm + ReLU in the conv epilogue (no pass over the conv output)
 TAIL_WGRAD_MAIN = [True]       # the weight gradient of the LAST op of the backward pass (a stem conv: no data gradient) on the main stream, which has nothing left to do, beside the weight-gradient stream's backlog
 DUAL_FWD = [True]              # lane-1 chains of the forward pass on a second stream
@@ -248,17 +245,9 @@ class Plan(object):
                         st['wino_f'] = BF16
                     if bf16 and need_dg and lib.aide_conv3x3_bf16_supported(cout, hh, ww, cin):
                         st['wino_d'] = BF16
-                    # the 3->32 stem layers in fp32: their own forward kernel straight from the master weights (measured alone
-                    # against the general kernels, tools/bench_stem.py: 3->32 x4 @256 14.3 vs 15.5 us, x8 @512 77.5 vs 84.3;
-                    # level with them for 3->64, and behind the bf16 kernel where z is stored narrow: 63 vs 56 us)
-                    if STEM_FWD[0] and not bf16 and cout == 32 and lib.aide_conv3x3_stem_fwd_supported(cin, hh, ww, cout):
-                        st['wino_f'] = STEM
-                        st['round_bf16'] = bf16
                     st['wf'] = st['wd'] = st['uf'] = st['ud'] = None
                     st['plan_f'] = st['plan_d'] = 0
-                    if st['wino_f'] == STEM:
-                        pass                                      # no pack, no split
-                    elif st['wino_f'] == BF16:
+                    if st['wino_f'] == BF16:
                         st['uf'] = pack_buf(conv, 'f', BF16, lambda: ops.bf16_pack_alloc(cout, cin, device))
                         st['plan_f'] = lib.aide_conv3x3_bf16_splitk(n, cin, hh, ww, cout) << 8
                     elif st['wino_f'] == 4:
@@ -325,7 +314,7 @@ class Plan(object):
                     # eval mode (the per-case inference loop): BatchNorm of the running statistics + ReLU as the epilogue of the
                     # F(4x4) forward kernel -- the conv writes the activation, z is never materialised
                     st['fold'] = not training and FOLD_EVAL_BN[0] and (
-                        (st['wino_f'] == 4 and ww != 16) or (st['wino_f'] == 0 and (st['plan_f'] >> 8) <= 1) or st['wino_f'] == STEM)
+                        (st['wino_f'] == 4 and ww != 16) or (st['wino_f'] == 0 and (st['plan_f'] >> 8) <= 1))
                     st['pack_key'] = None
                     st['flops'] = 2.0 * n * hh * ww * cout * cin * 9      # algorithmic, per launch
                     # bf16 mode keeps the conv output z (read only by BatchNorm) and its gradient dz (read only by the
@@ -333,7 +322,7 @@ class Plan(object):
                     # numerically) in HBM as bf16: half the bytes of the conv-output write, of four BatchNorm reads and
                     # of the dz write + two reads
                     st['dz_bf16'] = (st['wino_w'] == BF16 and (not need_dg or st['wino_d'] == BF16) and STORE_BF16[0])
-                    if (st['wino_f'] == BF16 or (st['wino_f'] == STEM and bf16)) and STORE_BF16[0]:
+                    if st['wino_f'] == BF16 and STORE_BF16[0]:
                         st['z'] = torch.empty(n, cout, hh, ww, device=device, dtype=torch.bfloat16)
                 else:
                     cin = src.C
@@ -363,7 +352,7 @@ class Plan(object):
         for st in self.steps:
             kind = st['kind']
             if kind == 'conv':
-                if not (st['wino_f'] in (BF16, STEM) and st['wino_w'] == BF16):
+                if not (st['wino_f'] == BF16 and st['wino_w'] == BF16):
                     narrow[id(st['src'].root)] = False
             elif kind in ('convT', 'sa'):
                 narrow[id(st['src'].root)] = False
@@ -823,10 +812,7 @@ class Plan(object):
                     (st['z'].shape[2] * st['z'].shape[3]) % 4 == 0          # (the slab loader reads 16 bytes)
                 acc = 2 if slabs else 0
                 if st.get('fold'):                 # eval: y = relu(acc * scale + folded bias) straight into the activation
-                    if st['wino_f'] == STEM:
-                        ops.conv3x3_stem_fwd(x, conv.weight, st['fbias'], self.view(st['dst']), round_bf16=st['round_bf16'],
-                                             epi_scale=st['scale'], epi_relu=True)
-                    elif st['wino_f'] == 4:
+                    if st['wino_f'] == 4:
                         ops.conv3x3_wino4(x, st['uf'], st['fbias'], self.view(st['dst']), accumulate=0,
                                           splitk=st['plan_f'] >> 8, ws=sk_ws, epi_scale=st['scale'], epi_relu=True)
                     else:                          # direct kernel (the 32-channel first level, the stems), non-split
@@ -837,9 +823,7 @@ class Plan(object):
                     return
                 lazy = st.get('lazy_to')
                 in_tab = st.get('in_tab')               # this conv applies the BatchNorm + ReLU of its input's producer(s)
-                if st['wino_f'] == STEM:
-                    ops.conv3x3_stem_fwd(x, conv.weight, conv.bias, st['z'], round_bf16=st['round_bf16'])
-                elif st['wino_f'] == BF16:
+                if st['wino_f'] == BF16:
                     ops.conv3x3_bf16(x, st['uf'], conv.bias, st['z'], accumulate=acc, splitk=st['plan_f'] >> 8, ws=sk_ws)
                 elif st['wino_f'] == 4:
                     # (st['stats']: this launch also writes the BatchNorm statistics partials of its output)
@@ -1214,10 +1198,22 @@ def _max_refs(views):
 _REF_BASE = _max_refs([object()])               # what a list element nobody else holds shows inside that loop
 
 
-def _views_held_elsewhere(views):
-    """does anybody besides the engine's own list still hold one of the arena's gradient views (a caller that kept
-    `p.grad` across zero_grad(): a snapshot, manual accumulation, gradient statistics)?"""
-    return _max_refs(views) > _REF_BASE
+_STORAGE_USES = getattr(torch._C, '_storage_Use_Count', None)
+
+
+def _storage_uses(t):
+    """tensors sharing t's storage (+1 for the temporary storage wrapper), or -1 where torch does not expose the count"""
+    return _STORAGE_USES(t.untyped_storage()._cdata) if _STORAGE_USES is not None else -1
+
+
+def _views_held_elsewhere(views, arena=None, base_uses=-1):
+    """does anybody besides the engine still hold a gradient of the last pass across zero_grad() (a snapshot, manual
+    accumulation, gradient statistics)?  Either one of the arena's view OBJECTS (Python reference counts), or any other
+    tensor on the arena's storage -- `p.grad.detach()`, `.data`, `.view(-1)`, a slice (the storage's use count against what
+    the engine's own tensors account for; torch builds without that counter see only the first kind: keep a .clone())."""
+    if _max_refs(views) > _REF_BASE:
+        return True
+    return arena is not None and base_uses >= 0 and _storage_uses(arena) > base_uses
 
 
 class _NetFunction(torch.autograd.Function):
@@ -1266,7 +1262,7 @@ class _NetFunction(torch.autograd.Function):
             have = [p.grad for p in params]
             if all(g is None for g in have):
                 mode = 1
-                if _views_held_elsewhere(views):
+                if _views_held_elsewhere(views, arena, eng._arena_uses):
                     # torch semantics: `p.grad = None` leaves a gradient tensor the caller still holds intact.  The arena
                     # is about to be overwritten in place, so those tensors keep the OLD arena and this pass gets a new one.
                     arena, views = eng.grad_arena(dlogits.device, fresh=True)
@@ -1310,7 +1306,12 @@ class _NetFunction(torch.autograd.Function):
         # the caller's current stream behind it.  Without it a forward issued on a non-current stream (network 2 of the
         # co-teaching step) leaves `optimizer.step()` on the caller's stream racing this backward: the engine assigns the
         # parameter gradients itself, so autograd's leaf-stream synchronisation never saw them.
-        return (None,) * (3 + ctx.ntensors - 1) + (torch.empty(1, device=dlogits.device),)
+        # (a cached zero, not torch.empty: uninitialised bits may be a NaN pattern -- detect_anomaly would flag it -- and a second
+        # backward before anchor.grad is cleared accumulates it)
+        z = eng._anchor_zero
+        if z is None or z.device != dlogits.device:
+            z = eng._anchor_zero = torch.zeros(1, device=dlogits.device)
+        return (None,) * (3 + ctx.ntensors - 1) + (z,)
 
 
 class Engine(object):
@@ -1331,7 +1332,8 @@ class Engine(object):
         self.side_stream = None          # stream carrying the weight-gradient kernels of the running backward
         self.graph = None
         self._precision = 'fp32'
-        self._arena = self._views = self._anchor = None
+        self._arena = self._views = self._anchor = self._anchor_zero = None
+        self._arena_uses = -1
         self._pslots = None
 
     def grad_arena(self, device, fresh=False):
@@ -1342,6 +1344,7 @@ class Engine(object):
         if fresh or a is None or a.numel() != self.flat_numel or a.device != device:
             a = self._arena = torch.zeros(self.flat_numel, device=device, dtype=torch.float32)
             self._views = [a[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
+            self._arena_uses = _storage_uses(a)      # the arena and its views: anything above this is a caller's alias
         return a, self._views
 
     @property

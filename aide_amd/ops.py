@@ -197,22 +197,6 @@ def conv3x3_igemm(x, wp, bias, y, accumulate=False, plan=-1, ws=None, epi_scale=
     return y
 
 
-def conv3x3_stem_fwd(x, weight, bias, y, round_bf16=False, epi_scale=None, epi_relu=True):
-    """y = conv3x3(x) of a stem layer (Cin <= 3) straight from the master weights [cout, cin, 3, 3] (no pack); y fp32 or
-    bf16 storage; round_bf16: x and the filters rounded to bf16 when staged (the precision='bf16' operand contract);
-    epi_scale [cout]: y = relu?(acc * epi_scale + bias)."""
-    xp, xbs = planes(x)
-    yp, ybs = planes(y, bf16_ok=True)
-    n, cin, h, w = x.shape
-    cout = y.shape[1]
-    assert tuple(weight.shape) == (cout, cin, 3, 3) and weight.is_contiguous() and weight.dtype == torch.float32
-    assert y.shape[0] == n and y.shape[2:] == x.shape[2:]
-    check(lib.aide_conv3x3_stem_fwd(xp, xbs, ptr(weight), ptr(bias), yp, int(y.dtype == torch.bfloat16), ybs, n, cin, h, w,
-                                    cout, int(bool(round_bf16)), ptr(epi_scale), int(bool(epi_relu)), stream_ptr()),
-          'conv3x3_stem_fwd')
-    return y
-
-
 def conv3x3_wgrad(dz, a, dw, ws=None, queue=None):
     """queue (every weight-gradient wrapper): None = the slab reduce is launched behind the kernel, or a WgradQueue whose
     flush() runs the reduces of several layers as one launch (ws must then stay untouched until that flush)"""

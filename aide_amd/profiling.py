@@ -57,7 +57,7 @@ KT_FAMILIES = {
     0: ('conv3x3_mfma_kernel', 1.0), 1: ('conv3x3_wino_kernel', 16.0 / 36.0), 2: ('conv3x3_wino4_kernel', 36.0 / 144.0),
     3: ('conv3x3_wgrad_kernel', 1.0), 4: ('conv3x3_wgrad_wino_kernel', 16.0 / 36.0),
     5: ('conv3x3_wgrad4_kernel', 36.0 / 144.0), 6: ('wgrad_stem_kernel', 1.0), 7: ('conv3x3_bf16_kernel', 1.0),
-    8: ('conv3x3_wgrad_bf16_kernel', 1.0), 10: ('conv3x3_stem_fwd_kernel', 28.0 / 27.0),
+    8: ('conv3x3_wgrad_bf16_kernel', 1.0),
 }
 
 

@@ -73,7 +73,7 @@ def parse():
     return ap.parse_args()
 
 
-KNOWN_SWITCHES = ('AIDE_HIP_LIB', 'AIDE_DIST_BACKEND', 'AIDE_PICK_STREAMS', 'AIDE_REPLAY', 'AIDE_DIRECT_GRADS')
+KNOWN_SWITCHES = ('AIDE_HIP_LIB', 'AIDE_DIST_BACKEND', 'AIDE_PICK_STREAMS', 'AIDE_REPLAY', 'AIDE_DIRECT_GRADS', 'AIDE_ABI_COVERAGE')
 
 
 def switches():

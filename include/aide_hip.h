@@ -100,15 +100,6 @@ int aide_conv3x3_wgrad_stem_splits(int N, int H, int W);
 int aide_conv3x3_wgrad_stem(const void* dz, int dz_bf16, int64_t dz_bs, const float* x, int64_t x_bs, float* dw,
                             int N, int Co, int Ci, int H, int W, float* ws, int splits, int round_bf16,
                             void* queue, aide_stream_t stream);
-/* stem layers, forward (Cin <= 3, Cout 32 or 64, W % 64 == 0): the nine taps folded into the GEMM's K dimension (K = 27), filters
- * read from the MASTER weights w[Cout][Cin][3][3] (no pack), bound by writing y once.  y fp32 or bf16 storage (y_bf16; y_bs in
- * elements); round_bf16: x and w rounded to bf16 when staged (the bf16 mode's operand contract); epi_scale NULL or [Cout]:
- * y = relu?(acc * epi_scale[co] + bias[co]).
- * Replaces nn.Conv2d(3, C, 3, padding=1).forward (netblocks.py:24 in modal*_downblock1, UNet.py:19). */
-int aide_conv3x3_stem_fwd_supported(int Cin, int H, int W, int Cout);
-int aide_conv3x3_stem_fwd(const float* x, int64_t x_bs, const float* w, const float* bias, void* y, int y_bf16, int64_t y_bs,
-                          int N, int Cin, int H, int W, int Cout, int round_bf16, const float* epi_scale, int epi_relu,
-                          aide_stream_t stream);
 /* transposed F(4x4,3x3) for the large layers: H % 4 == 0, W % 4 == 0, H >= 8, W >= 16, Co % 32 == 0 (a trailing half tile of 32
  * is computed and dropped), Ci % 32 == 0 */
 int aide_conv3x3_wgrad_wino4_supported(int Co, int Ci, int H, int W);
@@ -240,7 +231,9 @@ int aide_bn_train_fwd_parts_strided(const void* z, int z_bf16, int64_t z_bs, voi
 /* BatchNorm(train)+ReLU of a STACKED batch: `groups` independent batches of N images each, stacked along the batch dimension
  * (the four detached augmentation forwards of the co-teaching loop as one pass, trainchaos_proposed_30cases1labeled.py:265-269).
  * Every group is normalised with its own batch statistics; running statistics / num_batches_tracked are updated once per
- * group, in order -- bit for bit what `groups` sequential train-mode forwards leave -- in ONE launch sequence; mean / rstd /
+ * group, in order -- what `groups` sequential train-mode forwards leave (bit for bit in the fused single-launch and the
+ * conv-epilogue-parts forms; the two-pass form sums at most 96 / groups partials per channel instead of a launch's own split
+ * count, so its statistics agree to rounding, <= 1e-6 relative) -- in ONE launch sequence; mean / rstd /
  * scale / shift receive the last group's values.  Input, one of: z as it is (slabs == parts == NULL); the split-K slabs
  * [splitk][N * groups][C][H][W] of the conv before it (as aide_bn_train_fwd_slabs; z is written); the conv epilogue's
  * statistics parts[C][parts_stride][2], group g's nparts entries at g * nparts (as aide_bn_train_fwd_parts). */
@@ -340,7 +333,7 @@ int aide_wgrad_queue_discard(void* queue);
  * measured as it runs.  Families (bit ids of `family_mask`): 0 conv3x3_mfma_kernel, 1 conv3x3_wino_kernel,
  * 2 conv3x3_wino4_kernel, 3 conv3x3_wgrad_kernel, 4 conv3x3_wgrad_wino_kernel, 5 conv3x3_wgrad4_kernel,
  * 6 wgrad_stem_kernel, 7 conv3x3_bf16_kernel, 8 conv3x3_wgrad_bf16_kernel, 9 convT kernels,
- * 10 conv3x3_stem_fwd_kernel.
+ * (family 10 is unused).
  * aide_ktimer_start creates the events (call it outside the timed region); aide_ktimer_read needs an idle device and
  * returns the number of launches that found no free slot (>= 0) or an error (< 0).  `flops` = algorithmic
  * (direct-convolution) flop, 2 N H W Co Ci 9 per launch. */

@@ -87,48 +87,6 @@ def test_conv3x3_channel_slices(dev):
     assert (big_out[:, :64] == 7.0).all() and (big_out[:, 128:] == 7.0).all()
 
 
-@pytest.mark.parametrize('case', [(2, 3, 32, 64, 64), (1, 3, 64, 13, 128), (3, 2, 32, 4, 64), (1, 1, 64, 12, 192),
-                                  (4, 3, 32, 128, 128), (1, 3, 64, 1, 64)])
-def test_conv3x3_stem_forward(dev, case):
-    """The stem kernel (Ci <= 3, taps folded into K, filters from the master weights): fp32 and bf16-stored outputs, the
-    bf16 mode's operand rounding, the folded eval epilogue, ragged heights, a batch-strided (channel-slice) output."""
-    from aide_amd import ops
-    from aide_amd._lib import lib
-    n, ci, co, h, w = case
-    assert lib.aide_conv3x3_stem_fwd_supported(ci, h, w, co)
-    g = torch.Generator().manual_seed(ci * 17 + co + h)
-    x = torch.randn(n, ci, h, w, generator=g)
-    wt = torch.randn(co, ci, 3, 3, generator=g) * (1.0 / (3.0 * ci ** 0.5))
-    b = torch.randn(co, generator=g)
-    sc = torch.randn(co, generator=g)
-    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
-    xd, wd_, bd, scd = x.to(dev), wt.to(dev), b.to(dev), sc.to(dev)
-    big = torch.full((n, co + 8, h, w), 7.0, device=dev)
-    y = big[:, 4:4 + co]
-    ops.conv3x3_stem_fwd(xd, wd_, bd, y)
-    _close(y, ref, what='stem fwd %s' % (case,))
-    assert (big[:, :4] == 7.0).all() and (big[:, 4 + co:] == 7.0).all()
-    ops.conv3x3_stem_fwd(xd, wd_, None, y)
-    _close(y, ref - b.double().view(1, -1, 1, 1), what='stem fwd, no bias %s' % (case,))
-    # eval epilogue: relu(acc * scale + bias)
-    ops.conv3x3_stem_fwd(xd, wd_, bd, y, epi_scale=scd, epi_relu=True)
-    nb = F.conv2d(x.double(), wt.double(), None, padding=1)
-    _close(y, F.relu(nb * sc.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)), what='stem fwd epilogue %s' % (case,))
-    # bf16 mode: operands rounded to bf16 (products exact in fp32), output stored as bf16
-    xr, wr = x.bfloat16().double(), wt.bfloat16().double()
-    ref16 = F.conv2d(xr, wr, b.double(), padding=1)
-    y32 = torch.empty(n, co, h, w, device=dev)
-    ops.conv3x3_stem_fwd(xd, wd_, bd, y32, round_bf16=True)
-    _close(y32, ref16, what='stem fwd rounded operands %s' % (case,))
-    y16 = torch.full((n, co + 2, h, w), 7.0, device=dev, dtype=torch.bfloat16)
-    ops.conv3x3_stem_fwd(xd, wd_, bd, y16[:, 2:], round_bf16=True)
-    assert torch.equal(y16[:, 2:], y32.bfloat16()), 'bf16 storage = RNE of the fp32 result'
-    assert (y16[:, :2] == 7.0).all()
-    with pytest.raises(RuntimeError):
-        ops.conv3x3_stem_fwd(torch.randn(1, 4, 8, 64, device=dev), torch.randn(32, 4, 3, 3, device=dev), None,
-                             torch.empty(1, 32, 8, 64, device=dev))
-
-
 @pytest.mark.parametrize('shape', [(4, 32, 64, 64), (2, 64, 16, 16), (3, 8, 20, 20)])
 def test_bn_relu_fwd_bwd(dev, shape):
     from aide_amd import ops

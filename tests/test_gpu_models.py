@@ -357,6 +357,14 @@ def test_engine_assigned_gradients_keep_torch_contracts(dev):
     assert all(p.grad is not h for p, h in zip(params, held))
     assert any(not torch.equal(p.grad, h) for p, h in zip(params, held))
     del held
+    # ... and so does an ALIAS of one (detach / view / slice share the arena's storage; round-4 advisor finding)
+    alias = [params[0].grad.detach(), params[3].grad.view(-1)[:5], params[7].grad.data]
+    snap = [a.clone() for a in alias]
+    net.zero_grad()
+    crit(net(*xs), t).backward()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(alias, snap)), 'an alias of a held gradient was overwritten'
+    del alias
     net.zero_grad()
     crit(net(*xs2), t2).backward()                     # nobody holds the views any more: the arena is reused in place
     a0 = net.engine._arena
