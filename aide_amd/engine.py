@@ -83,10 +83,6 @@ class Graph(object):
         self.ops.append(dict(kind='sa', src=src, dst=dst, mod=mod))
 
 
-USE_WINOGRAD = [True]          # global switch (tests / A-B runs)
-USE_WINOGRAD_DGRAD = [True]    # ... for the dgrad direction only
-
-
 # multiplies a launch executes per algorithmic (direct-convolution) multiply, by conv mode
 WINO_EXEC = 16.0 / 36.0
 BF16 = 16                      # conv mode id of the bf16-MFMA kernels (conv3x3_bf16.hip)
@@ -96,34 +92,64 @@ FWD_TAG = {0: 'conv3x3_mfma_kernel', 2: 'conv3x3_wino_kernel', 4: 'conv3x3_wino4
 WGRAD_TAG = {0: 'conv3x3_wgrad_kernel', 2: 'conv3x3_wgrad_wino_kernel', 4: 'conv3x3_wgrad4_kernel',
              BF16: 'conv3x3_wgrad_bf16_kernel'}
 PRECISIONS = ('fp32', 'bf16')
-USE_WINOGRAD4 = [True]
 import os as _os
-# In-process switches (module attributes, flipped by tests that prove a schedule or a storage choice changes nothing but
-# time -- tests/test_gpu_models.py, test_gpu_steps.py, test_gpu_bf16.py).  The only ENVIRONMENT switches of the package are
-# AIDE_HIP_LIB (library path), AIDE_DIST_BACKEND (dry-run backend), AIDE_PICK_STREAMS, AIDE_REPLAY and AIDE_DIRECT_GRADS;
-# every A-B switch whose alternative was measured and lost (DESIGN.md sections 4.6, 9.4, 9.7) is gone with its code path.
-STORE_BF16 = [True]            # precision='bf16': z / dz stored as bf16
-STORE_A_BF16 = [True]          # precision='bf16': activations stored as bf16 where every reader / writer allows it
-STORE_G_BF16 = [True]          # ... and the gradients of those activations
-REPLAY = [_os.environ.get('AIDE_REPLAY', '1') != '0']                # launch tapes (aide_amd/tape.py)
-SHARED_PACKS = [True]          # plans of an engine share packed filters; forward-only plans pack no dgrad direction
-FOLD_EVAL_BN = [True]          # eval-mode BatchNorm + ReLU in the conv epilogue (no pass over the conv output)
-TAIL_WGRAD_MAIN = [True]       # the weight gradient of the LAST op of the backward pass (a stem conv: no data gradient) on the main stream, which has nothing left to do, beside the weight-gradient stream's backlog
-DUAL_FWD = [True]              # lane-1 chains of the forward pass on a second stream
-FREE_LANE = [True]             # lane 1 pools its own channels and runs ahead (no fork / join per level)
-HANDOVER_ON_KERNEL = [True]    # the dz hand-over event of a layer rides on its BatchNorm backward's last dispatch (hipExtLaunchKernelGGL stop event)
-W4_HALF_TILE = [True]          # F(4x4) weight gradient also for Co = 32 layers (a trailing half tile computed and dropped): the 32->32 layers at the END of the backward pass
-FLUSH_EVERY = 4                # layers per batched slab reduce (re-measured at the end of round 4: 6 -> 4 C2 +0.5 / +0.8 % on two boxes, C4 +0.2 %, C3 +0.1 %; 2, 3, 5, 8, 12 and one flush at the end all behind 4)
-GROUPED_BN = [True]            # stacked plans: BatchNorm of all groups in one launch sequence (aide_bn_train_fwd_groups)
-LAZY_BN = [True]               # forward-only stacked plans: BatchNorm + ReLU of a layer in its reader's loader (Plan._plan_lazy_bn)
 
 
-def conv_mode(n, cin, h, w, cout):
+class EngineConfig(object):
+    """The in-process switches of ONE Engine (`net.engine.config`).  Every alternative is the same computation on another
+    schedule, storage form or kernel family: the tests that prove it flip a switch on their own network
+    (tests/test_gpu_models.py, test_gpu_steps.py, test_gpu_bf16.py, test_gpu_fullsize.py).  Assigning a switch drops the
+    engine's plans, launch tapes and shared filter packs, so the next forward is built under the new setting -- nothing
+    replays an old launch sequence, and no other engine is affected.  The only ENVIRONMENT switches of the package are
+    AIDE_HIP_LIB (library path), AIDE_DIST_BACKEND (dry-run backend), AIDE_PICK_STREAMS, AIDE_REPLAY, AIDE_DIRECT_GRADS and the
+    measurement aid AIDE_ABI_COVERAGE; every A-B switch whose alternative was measured and lost is gone with its code path."""
+    DEFAULTS = dict(
+        use_winograd=True,          # Winograd kernels at all (False: direct implicit GEMM everywhere)
+        use_winograd_dgrad=True,    # ... for the dgrad direction
+        use_winograd4=True,         # F(4x4) where the layer rule picks it (False: F(2x2) / direct)
+        store_bf16=True,            # precision='bf16': z / dz stored as bf16
+        store_a_bf16=True,          # precision='bf16': activations stored as bf16 where every reader / writer allows it
+        store_g_bf16=True,          # ... and the gradients of those activations
+        replay=_os.environ.get('AIDE_REPLAY', '1') != '0',     # launch tapes (aide_amd/tape.py)
+        shared_packs=True,          # plans of an engine share packed filters; forward-only plans pack no dgrad direction
+        fold_eval_bn=True,          # eval-mode BatchNorm + ReLU in the conv epilogue (no pass over the conv output)
+        tail_wgrad_main=True,       # the weight gradient of the LAST op of the backward pass on the main stream
+        dual_fwd=True,              # lane-1 chains of the forward pass on a second stream
+        free_lane=True,             # lane 1 pools its own channels and runs ahead (no fork / join per level)
+        handover_on_kernel=True,    # the dz hand-over event of a layer rides on its BatchNorm backward's last dispatch
+        w4_half_tile=True,          # F(4x4) weight gradient also for Co = 32 layers (trailing half tile computed and dropped)
+        grouped_bn=True,            # stacked plans: BatchNorm of all groups in one launch sequence
+        lazy_bn=True,               # forward-only stacked plans: BatchNorm + ReLU of a layer in its reader's loader
+        direct_grads=_os.environ.get('AIDE_DIRECT_GRADS', '1') != '0',   # parameter gradients assigned by the engine
+    )
+
+    def __init__(self, on_change=None):
+        object.__setattr__(self, '_on_change', on_change)
+        for k, v in self.DEFAULTS.items():
+            object.__setattr__(self, k, v)
+
+    def __setattr__(self, k, v):
+        if k not in self.DEFAULTS:
+            raise AttributeError('aide_amd: the engine has no switch %r (switches: %s)' % (k, ', '.join(sorted(self.DEFAULTS))))
+        v = bool(v)
+        if getattr(self, k) != v:
+            object.__setattr__(self, k, v)
+            if self._on_change is not None:
+                self._on_change()
+
+    def snapshot(self):
+        return tuple(getattr(self, k) for k in sorted(self.DEFAULTS))
+
+
+FLUSH_EVERY = 4                # layers per batched slab reduce (a constant: 6 -> 4 C2 +0.5 / +0.8 % on two boxes, C4 +0.2 %, C3 +0.1 %; 2, 3, 5, 8, 12 and one flush at the end all behind 4)
+
+
+def conv_mode(cfg, n, cin, h, w, cout):
     """0 = direct implicit GEMM, 2 = Winograd F(2x2,3x3), 4 = Winograd F(4x4,3x3).  Static rule from the layer
     sweep (tools/bench_conv.py wino): F(4x4) wins on every layer of >= 8 GFLOP and on the >= 128x128-channel
     layers (1.3-1.5x over F(2x2) on the 19 / 39 GFLOP decoder layers); F(2x2) elsewhere; direct where neither
     is supported."""
-    if USE_WINOGRAD[0] and USE_WINOGRAD4[0] and lib.aide_conv3x3_wino4_supported(cin, h, w, cout) and w != 16:
+    if cfg.use_winograd and cfg.use_winograd4 and lib.aide_conv3x3_wino4_supported(cin, h, w, cout) and w != 16:
         # (w == 16: the kernel's image-pair tile is 11 % faster than F(2x2) there, the step 0.6 % slower -- 4x larger
         # filter pack for the 8 M bottleneck parameters, twice the slabs for BatchNorm to sum)
         flops = 2.0 * n * h * w * cin * cout * 9
@@ -131,14 +157,14 @@ def conv_mode(n, cin, h, w, cout):
             return 0                        # level in the step (round 4 again: C2 620.2 / 620.4, C3 155.2 / 155.4)
         if flops >= 8e9 or cin * cout >= 128 * 128:
             return 4
-    return 2 if use_winograd(n, cin, h, w, cout) else 0
+    return 2 if use_winograd(cfg, n, cin, h, w, cout) else 0
 
 
-def use_winograd(n, cin, h, w, cout):
+def use_winograd(cfg, n, cin, h, w, cout):
     """Static (deterministic) choice between the Winograd and the direct conv kernel: the layer sweep
     (tools/bench_conv.py all) has Winograd ahead on every layer shape it supports (1.2x-1.9x; the one
     exception, 64->128 @64x64 forward, loses 4 us), so it is used wherever it is supported."""
-    return bool(USE_WINOGRAD[0] and lib.aide_conv3x3_wino_supported(cin, h, w, cout))
+    return bool(cfg.use_winograd and lib.aide_conv3x3_wino_supported(cin, h, w, cout))
 
 
 def _preferred(dev):
@@ -194,8 +220,9 @@ class _Cover(object):
 
 
 class Plan(object):
-    def __init__(self, graph, params, n, h, w, device, training, precision='fp32', groups=1, shared=None):
+    def __init__(self, graph, params, n, h, w, device, training, precision='fp32', groups=1, shared=None, cfg=None):
         self.g, self.N, self.H, self.W, self.dev, self.training = graph, n, h, w, device, training
+        cfg = self.cfg = cfg if cfg is not None else EngineConfig()
         self.precision = precision
         # Packed filters are a function of (layer, direction, kernel family) only: the plans of one engine (the stacked
         # augmentation pass, the training batch, an evaluation batch) share them, and a plan that finds a pack already
@@ -209,7 +236,7 @@ class Plan(object):
         bf16 = precision == 'bf16'
         self.pindex = {id(p): i for i, p in enumerate(params)}
         f32 = dict(device=device, dtype=torch.float32)
-        forward_only = (groups > 1 or not training) and SHARED_PACKS[0]   # no backward pass will ever run on this plan: no dgrad-direction packs
+        forward_only = (groups > 1 or not training) and cfg.shared_packs   # no backward pass will ever run on this plan: no dgrad-direction packs
 
         def pack_buf(conv, direction, mode, make):
             key = (id(conv), direction, mode, device.index)
@@ -237,8 +264,8 @@ class Plan(object):
                     need_dg = not src.root.is_input and not forward_only
                     # Winograd F(2x2,3x3) where it is supported and measured faster (16 MFMA-multiplies
                     # per output instead of 36); the direct implicit GEMM otherwise
-                    st['wino_f'] = conv_mode(n, cin, hh, ww, cout)
-                    st['wino_d'] = conv_mode(n, cout, hh, ww, cin) if (need_dg and USE_WINOGRAD_DGRAD[0]) else 0
+                    st['wino_f'] = conv_mode(cfg, n, cin, hh, ww, cout)
+                    st['wino_d'] = conv_mode(cfg, n, cout, hh, ww, cin) if (need_dg and cfg.use_winograd_dgrad) else 0
                     # precision='bf16': bf16 operands / fp32 accumulation wherever the bf16 kernels cover the
                     # layer shape, the fp32 kernels elsewhere (narrow deep levels of small inputs)
                     if bf16 and lib.aide_conv3x3_bf16_supported(cin, hh, ww, cout):
@@ -278,12 +305,12 @@ class Plan(object):
                     if bf16 and lib.aide_conv3x3_wgrad_bf16_supported(cout, cin, hh, ww):
                         st['wino_w'] = BF16
                         st['wg_bytes'] = lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, cout, cin, hh, ww, 0)
-                    elif USE_WINOGRAD[0] and USE_WINOGRAD4[0] and (cout % 64 == 0 or W4_HALF_TILE[0]) and \
+                    elif cfg.use_winograd and cfg.use_winograd4 and (cout % 64 == 0 or cfg.w4_half_tile) and \
                             lib.aide_conv3x3_wgrad_wino4_supported(cout, cin, hh, ww):
                         # (a trailing half tile -- 32->32 @256x256 -- is 71 -> 56 us alone.  In round 2 the step lost 0.5 % with it:
                         # the 144 KB workgroups kept the main stream's kernels off the CUs; with the backward pass as it is now
                         # these layers are the last thing the weight-gradient stream does and the step gains: C2 621.9 / 620.9,
-                        # 621.8 / 620.7, 621.2 / 619.6 same box, C3 level -- W4_HALF_TILE)
+                        # 621.8 / 620.7, 621.2 / 619.6 same box, C3 level -- config.w4_half_tile)
                         st['wino_w'] = 4
                         # the LAST such launch of a backward pass whose dependent chain ends with it (every op before it in
                         # the graph is a stem conv without a data gradient -- the single-encoder U-Nets): nothing is left to
@@ -291,7 +318,7 @@ class Plan(object):
                         if all(s0['kind'] == 'conv' and s0['src'].root.is_input for s0 in self.steps):
                             st['wg_target'] = 256
                         st['wg_bytes'] = lib.aide_conv3x3_wgrad_wino4_ws_bytes_t(n, cout, cin, hh, ww, st.get('wg_target', 0))
-                    elif USE_WINOGRAD[0] and lib.aide_conv3x3_wgrad_wino_supported(cout, cin, hh, ww):
+                    elif cfg.use_winograd and lib.aide_conv3x3_wgrad_wino_supported(cout, cin, hh, ww):
                         st['wino_w'] = 2
                         st['wg_bytes'] = lib.aide_conv3x3_wgrad_wino_ws_bytes(n, cout, cin, hh, ww)
                     else:
@@ -313,7 +340,7 @@ class Plan(object):
                             st['stats'] = torch.empty(cout * parts * 2, **f32)
                     # eval mode (the per-case inference loop): BatchNorm of the running statistics + ReLU as the epilogue of the
                     # F(4x4) forward kernel -- the conv writes the activation, z is never materialised
-                    st['fold'] = not training and FOLD_EVAL_BN[0] and (
+                    st['fold'] = not training and cfg.fold_eval_bn and (
                         (st['wino_f'] == 4 and ww != 16) or (st['wino_f'] == 0 and (st['plan_f'] >> 8) <= 1))
                     st['pack_key'] = None
                     st['flops'] = 2.0 * n * hh * ww * cout * cin * 9      # algorithmic, per launch
@@ -321,8 +348,8 @@ class Plan(object):
                     # bf16 dgrad / wgrad kernels, which round it to bf16 anyway -- storing it narrow changes nothing
                     # numerically) in HBM as bf16: half the bytes of the conv-output write, of four BatchNorm reads and
                     # of the dz write + two reads
-                    st['dz_bf16'] = (st['wino_w'] == BF16 and (not need_dg or st['wino_d'] == BF16) and STORE_BF16[0])
-                    if st['wino_f'] == BF16 and STORE_BF16[0]:
+                    st['dz_bf16'] = (st['wino_w'] == BF16 and (not need_dg or st['wino_d'] == BF16) and cfg.store_bf16)
+                    if st['wino_f'] == BF16 and cfg.store_bf16:
                         st['z'] = torch.empty(n, cout, hh, ww, device=device, dtype=torch.bfloat16)
                 else:
                     cin = src.C
@@ -348,7 +375,7 @@ class Plan(object):
         # up-sampling or the head.  For a conv operand that is numerically free (the kernels round it anyway), max-pooling
         # commutes with the rounding; up-sampling and the head then see rounded inputs (what torch.autocast gives them).
         # Gradients of activations stay fp32.
-        narrow = {id(t): bf16 and STORE_A_BF16[0] for t in graph.roots}
+        narrow = {id(t): bf16 and cfg.store_a_bf16 for t in graph.roots}
         for st in self.steps:
             kind = st['kind']
             if kind == 'conv':
@@ -365,7 +392,7 @@ class Plan(object):
         # runs its dgrad on the bf16 kernel (the other writers / readers -- pooling, up-sampling, head, BatchNorm backward --
         # are storage-generic).  Writers after the first accumulate in fp32 and round once per write (torch.autocast's
         # bf16 activation gradients accumulate the same way).
-        self.narrow_grad = {k: v and STORE_G_BF16[0] for k, v in narrow.items()}
+        self.narrow_grad = {k: v and cfg.store_g_bf16 for k, v in narrow.items()}
         for st in self.steps:
             if st['kind'] == 'conv' and not st['src'].root.is_input and st['wino_d'] != BF16:
                 self.narrow_grad[id(st['src'].root)] = False
@@ -410,7 +437,7 @@ class Plan(object):
         table, and the normalising pass over the tensor (one read + one write) never runs.  Channels of the reader's input
         that are materialised activations (a skip half of a concat buffer) get (1, 0): ReLU of a non-negative value."""
         self.lazy_bn = 0
-        if not (self.training and self.groups > 1) or not LAZY_BN[0]:
+        if not (self.training and self.groups > 1) or not self.cfg.lazy_bn:
             return
         for st in self.steps:
             if st['kind'] != 'conv' or st.get('stats') is None:
@@ -620,7 +647,7 @@ class Plan(object):
     def _fingerprint(self):
         """addresses of every parameter and buffer the launch sequence bakes in (a tape is only valid for these)"""
         # ... and everything else a recorded sequence depends on: the runtime schedule switches and the BatchNorm scalars
-        fp = [DUAL_FWD[0], FREE_LANE[0], TAIL_WGRAD_MAIN[0], HANDOVER_ON_KERNEL[0], FLUSH_EVERY, self.overlap]
+        fp = [self.cfg.snapshot(), FLUSH_EVERY, self.overlap]
         # (this runs every forward: the tensors are looked up through the modules' own _parameters / _buffers dicts -- a
         # replaced parameter or buffer is seen -- without walking the module tree)
         slots = self._fp_slots
@@ -644,7 +671,7 @@ class Plan(object):
         return tuple(fp)
 
     def _tapeable(self):
-        return REPLAY[0] and self.profiler is None and self.trace is None
+        return self.cfg.replay and self.profiler is None and self.trace is None
 
     def _coef_fresh(self):
         """eval mode: are the cached BatchNorm coefficients (scale, shift, folded bias per layer) those of the current
@@ -706,15 +733,15 @@ class Plan(object):
         # conv -> BN chain per level) run on a second stream, beside the lane-0 chain of the same level -- one chain's
         # HBM-bound BatchNorm and launch boundaries under the other's convolutions.  Fork: lane 1 waits for everything
         # enqueued on the main stream so far; join: before the first main-stream op that touches channels lane 1 wrote.
-        dual = self.lane_b is not None and DUAL_FWD[0] and self.profiler is None and self.trace is None
+        dual = self.lane_b is not None and self.cfg.dual_fwd and self.profiler is None and self.trace is None
         mp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         bp = ctypes.c_void_p(self.lane_b.cuda_stream) if dual else None
-        # Free-running lane 1 (FREE_LANE): a pooling op whose source holds lane-0 channels [0, c) and lane-1 channels [c, C)
+        # Free-running lane 1 (config.free_lane): a pooling op whose source holds lane-0 channels [0, c) and lane-1 channels [c, C)
         # runs as two launches, each on the stream that produced its channels.  Lane 1 then never waits for lane 0 after the
         # first fork (its next level reads only what it pooled itself), and lane 0 waits for lane 1 exactly where it reads
         # lane 1's pooled channels -- on an event recorded right behind that pooling launch, not on lane 1's tail.  (With one
         # pooling launch per level on the main stream each level cost a join + a fork: ~35 us of idle time per lane and level.)
-        free = dual and FREE_LANE[0]
+        free = dual and self.cfg.free_lane
         on_b, pend = False, []
         forked = False        # free: lane 1 has been ordered behind the main stream (since the last event that needs it again)
         touched = []          # free: ranges lane-0 ops read or wrote since the last fork
@@ -880,7 +907,7 @@ class Plan(object):
         sk_ws = self.sk_ws if sk_ws is None else sk_ws
         ngroups = self.groups if (self.training and self.groups > 1) else 1
         m = self.N // ngroups
-        if self.training and ngroups > 1 and GROUPED_BN[0]:
+        if self.training and ngroups > 1 and self.cfg.grouped_bn:
             # the stacked augmentation pass: every group's statistics / running-statistics update in ONE launch sequence
             # (one launch sequence per group cost 3 x 2 x 32 small launches per co-teaching step)
             if st.get('stats') is not None:
@@ -1058,8 +1085,8 @@ class Plan(object):
                 # a layer that hands its dz over to the weight-gradient stream right away: the event rides on the
                 # BatchNorm backward's last dispatch (done=) and the other stream only waits for it -- no record packet
                 # between this launch and the data-gradient convolution on this queue
-                tail_ = TAIL_WGRAD_MAIN[0] and st is self.steps[0] and sg is None and self.profiler is None
-                done = st['ev'] if (side is not None and not tail_ and HANDOVER_ON_KERNEL[0]) else None
+                tail_ = self.cfg.tail_wgrad_main and st is self.steps[0] and sg is None and self.profiler is None
+                done = st['ev'] if (side is not None and not tail_ and self.cfg.handover_on_kernel) else None
                 if folded[0]:                  # dA is still in the split-K slabs of the conv after this one
                     ops.bn_relu_bwd_slabs(sk_ws, folded[0], z, dz, st['mean'], st['rstd'], st['scale'], st['shift'],
                                           gslot(bn.weight), gslot(bn.bias), gslot(conv.bias), True, done=done)
@@ -1082,7 +1109,7 @@ class Plan(object):
                     # the last op of the pass, when it has no data gradient (a stem conv): the dependent chain ends with its
                     # BatchNorm backward, so its weight gradient runs on that stream beside whatever the weight-gradient
                     # stream still has queued instead of behind it
-                    tail = TAIL_WGRAD_MAIN[0] and st is self.steps[0] and sg is None and prof is None
+                    tail = self.cfg.tail_wgrad_main and st is self.steps[0] and sg is None and prof is None
                     if side is not None and not tail:
                         if done is not None:
                             ops.wait(side, done)
@@ -1131,7 +1158,7 @@ class Plan(object):
                     # the last op of the pass, when it has no data gradient (a stem conv): the dependent chain ends with its
                     # BatchNorm backward, so its weight gradient runs on that stream beside whatever the weight-gradient
                     # stream still has queued instead of behind it
-                    tail = TAIL_WGRAD_MAIN[0] and st is self.steps[0] and sg is None and prof is None
+                    tail = self.cfg.tail_wgrad_main and st is self.steps[0] and sg is None and prof is None
                     if side is not None and not tail:
                         if done is not None:
                             ops.wait(side, done)
@@ -1173,7 +1200,6 @@ class Plan(object):
                                        accumulate=sg['accumulate'])
 
 
-DIRECT_GRADS = [_os.environ.get('AIDE_DIRECT_GRADS', '1') != '0']    # A-B switch: parameter gradients assigned by the engine
 
 
 def _has_param_hooks(params):
@@ -1332,9 +1358,16 @@ class Engine(object):
         self.side_stream = None          # stream carrying the weight-gradient kernels of the running backward
         self.graph = None
         self._precision = 'fp32'
+        self.config = EngineConfig(self._config_changed)
         self._arena = self._views = self._anchor = self._anchor_zero = None
         self._arena_uses = -1
         self._pslots = None
+
+    def _config_changed(self):
+        """a switch of self.config was assigned: plans (with their launch tapes) and shared filter packs were built under the old
+        setting -- drop them; the next forward compiles under the new one"""
+        self.plans = {}
+        self._shared_packs = dict(buf={}, fresh={}, streams=None)
 
     def grad_arena(self, device, fresh=False):
         """the persistent flat gradient arena of this module and the per-parameter views into it (offsets: _refresh_params).
@@ -1420,7 +1453,7 @@ class Engine(object):
                         raise RuntimeError('aide_amd: %dx%d is too large: %d channels of %s exceed the 2 GiB per-image '
                                            'operand limit of the kernels' % (h, w, t.C, t.name))
             plan = Plan(self.graph, self.params, n, h, w, x.device, bool(self.module.training), self._precision,
-                        groups, shared=self._shared_packs if SHARED_PACKS[0] else None)
+                        groups, shared=self._shared_packs if self.config.shared_packs else None, cfg=self.config)
             plan.key = key
             self.plans[key] = plan
             # a plan owns full activation (+ gradient) buffers: ragged last batches / many input shapes must not pile
@@ -1471,7 +1504,7 @@ class Engine(object):
         for p in self.params:
             if not p.is_cuda:
                 raise RuntimeError('aide_amd: module parameters are on %s; call .to(device) first' % p.device)
-        if DIRECT_GRADS[0] and torch.is_grad_enabled() and any(p.requires_grad for p in self.params) and \
+        if self.config.direct_grads and torch.is_grad_enabled() and any(p.requires_grad for p in self.params) and \
                 not _has_param_hooks(self.params):
             if self._anchor is None or self._anchor.device != ins[0].device:
                 self._anchor = torch.zeros(1, device=ins[0].device, requires_grad=True)

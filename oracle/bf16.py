@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 
-STORE_Z_BF16 = [True]       # False: emulate the A-B mode with an fp32-stored conv output (engine.STORE_BF16)
+STORE_Z_BF16 = [True]       # False: emulate the A-B mode with an fp32-stored conv output (engine config.store_bf16)
 STORE_A_BF16 = [True]       # False: ... with fp32-stored activations (engine.STORE_A_BF16)
 
 

@@ -132,18 +132,14 @@ def test_config2_fuseunet_256_elementwise(dev):
 def test_config2_direct_kernels(dev):
     """The same check with the Winograd kernels switched off (direct implicit-GEMM MFMA kernels only: an exact fp32 fmaf
     chain like the reference's)."""
-    from aide_amd import engine as E
     from aide_amd.synthetic import chaos_batch
     from aide_amd.models_twomodalinputs import fuseunet
     fx = np.load(os.path.join(GOLD, 'g2_config2.npz'))
     xin, xout, t = chaos_batch(4, 256, seed=int(fx['seed']))
     torch.manual_seed(2)
     net = fuseunet(2).to(dev)
-    E.USE_WINOGRAD[0] = False
-    try:
-        _check_config(dev, net, _oracle('fuseunet'), (xin, xout), t, fx, 'C2 (direct kernels)')
-    finally:
-        E.USE_WINOGRAD[0] = True
+    net.engine.config.use_winograd = False          # this network's engine only
+    _check_config(dev, net, _oracle('fuseunet'), (xin, xout), t, fx, 'C2 (direct kernels)')
 
 
 def test_config4_unet_320(dev):

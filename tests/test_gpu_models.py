@@ -293,26 +293,22 @@ def test_engine_assigned_gradients_follow_autograd_semantics(dev):
     crit = U.CEMDiceLoss(w, w, w)
 
     def grads_of(direct, passes=1, zero_in_place=False, freeze=False):
-        was = E.DIRECT_GRADS[0]
-        E.DIRECT_GRADS[0] = direct
-        try:
-            net, _ = build_pair('fuseunet', False, dev)
-            params = list(net.parameters())
-            if freeze:
-                params[5].requires_grad_(False)
-            opt = Adam([p for p in params if p.requires_grad], lr=1e-3, amsgrad=True)
-            if zero_in_place:                       # gradients exist and are zero: the backward must add into them
-                crit(net(*xs), t).backward()
-                opt.zero_grad(set_to_none=False)
-                assert all(float(p.grad.abs().max()) == 0.0 for p in params if p.requires_grad)
-            for _ in range(passes):
-                crit(net(*xs), t).backward()
-            out = [None if p.grad is None else p.grad.clone() for p in params]
-            opt.step()
-            torch.cuda.synchronize()
-            return out, [p.detach().clone() for p in params]
-        finally:
-            E.DIRECT_GRADS[0] = was
+        net, _ = build_pair('fuseunet', False, dev)
+        net.engine.config.direct_grads = direct
+        params = list(net.parameters())
+        if freeze:
+            params[5].requires_grad_(False)
+        opt = Adam([p for p in params if p.requires_grad], lr=1e-3, amsgrad=True)
+        if zero_in_place:                       # gradients exist and are zero: the backward must add into them
+            crit(net(*xs), t).backward()
+            opt.zero_grad(set_to_none=False)
+            assert all(float(p.grad.abs().max()) == 0.0 for p in params if p.requires_grad)
+        for _ in range(passes):
+            crit(net(*xs), t).backward()
+        out = [None if p.grad is None else p.grad.clone() for p in params]
+        opt.step()
+        torch.cuda.synchronize()
+        return out, [p.detach().clone() for p in params]
     ref, pref = grads_of(False)
     got, pgot = grads_of(True)
     assert all(torch.equal(a, b) for a, b in zip(ref, got)), 'engine-assigned gradients differ from the autograd form'
@@ -415,8 +411,8 @@ def test_engine_assigned_gradients_keep_torch_contracts(dev):
 
 
 def test_two_lane_schedules_are_bit_identical(dev):
-    """The second encoder's chains on their own stream in the forward pass (engine.DUAL_FWD / FREE_LANE) and the last weight
-    gradient on the main stream (engine.TAIL_WGRAD_MAIN) must give the single-lane
+    """The second encoder's chains on their own stream in the forward pass (config.dual_fwd / free_lane) and the last weight
+    gradient on the main stream (config.tail_wgrad_main) must give the single-lane
     results bit for bit -- same kernels, own workspaces -- over several steps (also a race detector for the lane's
     BatchNorm / split-K workspaces and the fork / join points), with and without launch tapes' replays."""
     from aide_amd import engine, utils as U
@@ -425,26 +421,21 @@ def test_two_lane_schedules_are_bit_identical(dev):
     xs = [torch.randn(4, 3, 128, 128, generator=g).to(dev) for _ in range(2)]
     t = (torch.rand(4, 128, 128, generator=g) > 0.8).long().to(dev)
     w = torch.tensor([1.0, 1.0])
-    saved = (engine.DUAL_FWD[0], engine.FREE_LANE[0], engine.TAIL_WGRAD_MAIN[0])
+    cfg = net.engine.config
     results = []
-    try:
-        # (free: lane 1 pools its own channels and runs from level to level without a fork / join per level)
-        # tailm: the last op's weight gradient on the main stream instead of behind the weight-gradient stream's backlog
-        for fwd, free, tailm in ((False, False, False), (True, False, True), (True, True, False), (True, True, True),
-                                 (True, False, False)):
-            engine.DUAL_FWD[0], engine.FREE_LANE[0], engine.TAIL_WGRAD_MAIN[0] = fwd, free, tailm
-            for plan in net.engine.plans.values():
-                plan._tape_f = plan._tape_b = None           # the recorded launch sequence bakes the schedule in
-            outs = []
-            for _ in range(3):                                 # recorded pass + two replays (BatchNorm running stats move on)
-                net.zero_grad()
-                out = net(*xs)
-                U.CEMDiceLoss(w, w, w)(out, t).backward()
-                outs.append([out.detach().clone()] + [p.grad.clone() for p in net.parameters()])
-            results.append(outs[-1])
-            torch.cuda.synchronize()
-    finally:
-        engine.DUAL_FWD[0], engine.FREE_LANE[0], engine.TAIL_WGRAD_MAIN[0] = saved
+    # (free: lane 1 pools its own channels and runs from level to level without a fork / join per level)
+    # tailm: the last op's weight gradient on the main stream instead of behind the weight-gradient stream's backlog
+    for fwd, free, tailm in ((False, False, False), (True, False, True), (True, True, False), (True, True, True),
+                             (True, False, False)):
+        cfg.dual_fwd, cfg.free_lane, cfg.tail_wgrad_main = fwd, free, tailm    # (an assignment drops the engine's plans and tapes)
+        outs = []
+        for _ in range(3):                                 # recorded pass + two replays (BatchNorm running stats move on)
+            net.zero_grad()
+            out = net(*xs)
+            U.CEMDiceLoss(w, w, w)(out, t).backward()
+            outs.append([out.detach().clone()] + [p.grad.clone() for p in net.parameters()])
+        results.append(outs[-1])
+        torch.cuda.synchronize()
     for other in results[1:]:
         for a, b in zip(results[0], other):
             assert torch.equal(a, b)
@@ -520,8 +511,6 @@ def test_eval_fold_tracks_parameters_and_statistics(dev):
     load_state_dict -- over recorded and replayed launch tapes."""
     from aide_amd import engine, utils as U
     from aide_amd.optim import Adam
-    if not engine.FOLD_EVAL_BN[0]:
-        pytest.skip('engine.FOLD_EVAL_BN is off: the folded epilogue is switched off')
     net, ref = build_pair('fuseunet', False, dev)
     g = torch.Generator().manual_seed(21)
     xs = [torch.randn(4, 3, 128, 128, generator=g) for _ in range(2)]
@@ -540,16 +529,15 @@ def test_eval_fold_tracks_parameters_and_statistics(dev):
         return outs[0]
 
     def unfolded():
-        saved = engine.FOLD_EVAL_BN[0]
-        keep = dict(net.engine.plans)
+        eng = net.engine
+        keep, keep_packs = dict(eng.plans), eng._shared_packs
         try:
-            engine.FOLD_EVAL_BN[0] = False
-            net.engine.plans.clear()                               # the choice is made when a plan is built
+            eng.config.fold_eval_bn = False                        # (drops the plans: the choice is made when a plan is built)
             with torch.no_grad():
                 return net(*xd).clone()
         finally:
-            engine.FOLD_EVAL_BN[0] = saved
-            net.engine.plans.clear(); net.engine.plans.update(keep)
+            eng.config.fold_eval_bn = True
+            eng.plans, eng._shared_packs = keep, keep_packs        # back to the plans whose cached coefficients are under test
 
     a0 = evals()
     plan = [p for p in net.engine.plans.values() if not p.training][0]

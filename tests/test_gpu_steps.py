@@ -151,7 +151,7 @@ def test_grouped_forward_in_eval_mode(dev):
 
 def test_coteaching_two_streams_is_bit_identical(dev):
     """Network 2 on its own stream (TWO_NET_STREAMS, the default) and packed filters shared between a network's plans
-    (engine.SHARED_PACKS, the default) are schedules, not different computations: three steps from the same initial state give
+    (config.shared_packs, the default) are schedules, not different computations: three steps from the same initial state give
     bit-identical losses, selections and parameters of BOTH networks as the single-stream order with private packs -- any
     missing cross-stream dependency (inputs, optimizer update, engine-assigned gradients) or a stale shared pack would show
     here."""
@@ -168,14 +168,13 @@ def test_coteaching_two_streams_is_bit_identical(dev):
         augset['hflip%d' % (k + 1)] = [(k + b) % 2 for b in range(n)]
         augset['degree%d' % (k + 1)] = [15.0 * (k + 1) - 7.0 * b for b in range(n)]
     res = {}
-    from aide_amd import engine as E
-    old, old_sp = M.TWO_NET_STREAMS[0], E.SHARED_PACKS[0]
+    old = M.TWO_NET_STREAMS[0]
     try:
         for two in (False, True, 'pipelined'):
             M.TWO_NET_STREAMS[0] = bool(two)
-            E.SHARED_PACKS[0] = bool(two)    # ... and with every plan packing its own filters (both directions) vs shared packs
             torch.manual_seed(2)
             n1, n2 = fuseunet(2).to(dev), fuseunet(2).to(dev)
+            n1.engine.config.shared_packs = n2.engine.config.shared_packs = bool(two)   # ... and with every plan packing its own filters (both directions) vs shared packs
             n1.train(); n2.train()
             o1, o2 = Adam(n1.parameters(), lr=1e-3, amsgrad=True), Adam(n2.parameters(), lr=1e-3, amsgrad=True)
             op = CoTeachingProposedLoss(cediceweight=[1.0, 1.0], ceclassweight=[1.0, 1.0], segcor_weight=[1.0, 10.0])
@@ -191,7 +190,7 @@ def test_coteaching_two_streams_is_bit_identical(dev):
             res[two] = (trace, [p.detach().clone() for p in list(n1.parameters()) + list(n2.parameters())],
                         [b.detach().clone() for b in list(n1.buffers()) + list(n2.buffers())])
     finally:
-        M.TWO_NET_STREAMS[0], E.SHARED_PACKS[0] = old, old_sp
+        M.TWO_NET_STREAMS[0] = old
     for other in (True, 'pipelined'):
         for a, b in zip(res[False][0], res[other][0]):
             assert all(torch.equal(x, y) for x, y in zip(a, b))
@@ -393,7 +392,7 @@ def test_grouped_forward_equals_sequential(dev, kind):
 
 @pytest.mark.parametrize('kind', ['fuseunet', 'unetsa'])
 def test_grouped_batchnorm_launches_equal_per_group_launches(dev, kind, monkeypatch):
-    """The stacked pass normalises all groups of a layer in one launch sequence (engine.GROUPED_BN,
+    """The stacked pass normalises all groups of a layer in one launch sequence (config.grouped_bn,
     aide_bn_train_fwd_groups: plain / split-K-slab / epilogue-statistics input, the small-plane single-kernel form and
     the two-pass form) == one launch sequence per group: outputs, running statistics (updated in group order),
     num_batches_tracked.  (The two-pass form sums its partials in fewer splits: 1e-6, not bitwise.)"""
@@ -411,18 +410,14 @@ def test_grouped_batchnorm_launches_equal_per_group_launches(dev, kind, monkeypa
     calls = []
     real = ops.bn_train_fwd_groups
     monkeypatch.setattr(ops, 'bn_train_fwd_groups', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
-    was = (engine.GROUPED_BN[0], engine.LAZY_BN[0])
-    try:
-        engine.LAZY_BN[0] = False
-        engine.GROUPED_BN[0] = True
-        outs = net.forward_groups(groups) + net.forward_groups(groups)
-        assert len(calls) >= 20, len(calls)               # (the second pass replays the launch tape)
-        engine.GROUPED_BN[0] = False
-        n0 = len(calls)
-        refs = ref.forward_groups(groups) + ref.forward_groups(groups)
-        assert len(calls) == n0
-    finally:
-        engine.GROUPED_BN[0], engine.LAZY_BN[0] = was
+    net.engine.config.lazy_bn = ref.engine.config.lazy_bn = False
+    net.engine.config.grouped_bn = True
+    outs = net.forward_groups(groups) + net.forward_groups(groups)
+    assert len(calls) >= 20, len(calls)               # (the second pass replays the launch tape)
+    ref.engine.config.grouped_bn = False
+    n0 = len(calls)
+    refs = ref.forward_groups(groups) + ref.forward_groups(groups)
+    assert len(calls) == n0
     torch.cuda.synchronize()
     for a, b in zip(outs, refs):
         assert (a - b).abs().max().item() <= 1e-6 * b.abs().max().item()
@@ -436,7 +431,7 @@ def test_grouped_batchnorm_launches_equal_per_group_launches(dev, kind, monkeypa
 @pytest.mark.parametrize('kind,size', [('fuseunet', 256), ('unet', 320)])
 def test_lazy_batchnorm_in_the_reader_is_bit_identical(dev, kind, size):
     """Forward-only stacked passes apply the BatchNorm + ReLU of a layer whose only reader is an F(4x4) convolution in that
-    convolution's loader (engine.LAZY_BN; conv3x3_wino4 in_bn_tab) instead of a pass over the tensor: same arithmetic
+    convolution's loader (config.lazy_bn; conv3x3_wino4 in_bn_tab) instead of a pass over the tensor: same arithmetic
     element for element (fmaf, max), so outputs, running statistics and num_batches_tracked equal the materialised form
     bit for bit -- also for border tiles (zero padding must stay zero after the affine map) and the 20 x 20 canvas tiles."""
     import copy
@@ -455,19 +450,15 @@ def test_lazy_batchnorm_in_the_reader_is_bit_identical(dev, kind, size):
     nin = 2 if kind == 'fuseunet' else 1
     groups = [tuple(torch.randn(2, 3, size, size, generator=g).to(dev) for _ in range(nin)) for _ in range(4)]
     net.train(); ref.train()
-    was = engine.LAZY_BN[0]
-    try:
-        engine.LAZY_BN[0] = True
-        outs = net.forward_groups(groups)
-        plan = [p for p in net.engine.plans.values() if p.groups == 4][0]
-        assert plan.lazy_bn >= 4, plan.lazy_bn
-        outs2 = net.forward_groups(groups)             # replayed tape, running statistics move on
-        engine.LAZY_BN[0] = False
-        refs = ref.forward_groups(groups)
-        assert [p for p in ref.engine.plans.values() if p.groups == 4][0].lazy_bn == 0
-        refs2 = ref.forward_groups(groups)
-    finally:
-        engine.LAZY_BN[0] = was
+    net.engine.config.lazy_bn = True
+    outs = net.forward_groups(groups)
+    plan = [p for p in net.engine.plans.values() if p.groups == 4][0]
+    assert plan.lazy_bn >= 4, plan.lazy_bn
+    outs2 = net.forward_groups(groups)             # replayed tape, running statistics move on
+    ref.engine.config.lazy_bn = False
+    refs = ref.forward_groups(groups)
+    assert [p for p in ref.engine.plans.values() if p.groups == 4][0].lazy_bn == 0
+    refs2 = ref.forward_groups(groups)
     torch.cuda.synchronize()
     for a, b in zip(outs + outs2, refs + refs2):
         assert torch.equal(a, b)

@@ -6,8 +6,8 @@ from aide_amd import engine, utils as U
 from test_gpu_models import build_pair, forced_relu_masks
 dev = torch.device('cuda:0')
 def run(kind, shape, wino, dbl=False):
-    engine.USE_WINOGRAD[0] = wino
     net, ref = build_pair(kind, False, dev)
+    net.engine.config.use_winograd = bool(wino)
     g = torch.Generator().manual_seed(9)
     n, h, w = shape
     xs = [torch.randn(n, 3, h, w, generator=g) for _ in range(2 if kind == 'fuseunet' else 1)]
