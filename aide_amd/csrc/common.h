@@ -65,11 +65,31 @@ __device__ __forceinline__ void st1(bf16_store_t* p, float v) { *p = (bf16_store
 
 static inline int aide_launch_status() { return (int)hipGetLastError(); }
 
+// Dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) of a launcher's kernels: once per DEVICE -- the attribute
+// is set for the function on the device that is current at the time, so a process that drives several devices needs it on
+// each -- and with its status returned to the caller (a refused opt-in would otherwise surface as a failed launch later).
+//   static AideLdsOptIn lds;  if (int rc = lds.ensure([] { return hipFuncSetAttribute(...); })) return rc;
+#include <atomic>
+struct AideLdsOptIn {
+    std::atomic<unsigned long long> done{0ull};
+    template <class F>
+    int ensure(F&& set_all) {
+        int dev = 0;
+        const hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return 0;
+        const hipError_t rc = set_all();           // (idempotent: two threads racing here both set the same values)
+        if (rc != hipSuccess) return (int)rc;
+        done.fetch_or(bit, std::memory_order_release);
+        return 0;
+    }
+};
+
 // ---- optional per-kernel timing (ktimer.hip; include/aide_hip.h "kernel timer"): a launch of an armed family carries
 // a start / stop event pair that receives the dispatch's own begin / end timestamps
 enum { AIDE_KT_IGEMM = 0, AIDE_KT_WINO2 = 1, AIDE_KT_WINO4 = 2, AIDE_KT_WGRAD = 3, AIDE_KT_WGRAD_WINO2 = 4,
-       AIDE_KT_WGRAD4 = 5, AIDE_KT_WGRAD_STEM = 6, AIDE_KT_BF16 = 7, AIDE_KT_WGRAD_BF16 = 8, AIDE_KT_CONVT = 9,
-       AIDE_KT_STEM_FWD = 10 };
+       AIDE_KT_WGRAD4 = 5, AIDE_KT_WGRAD_STEM = 6, AIDE_KT_BF16 = 7, AIDE_KT_WGRAD_BF16 = 8, AIDE_KT_CONVT = 9 };
 extern "C" int aide_ktimer_slot(int family, double flops, hipEvent_t* e0, hipEvent_t* e1);
 #define AIDE_LAUNCH_TIMED(FAM, FLOPS, kernel, grid, block, lds, stream, ...)                                  \
     do {                                                                                                      \

@@ -480,12 +480,11 @@ int launch_bf16_t(BfArgs a, hipStream_t stream) {
     constexpr int WAVES_N = NW / WAVES_M, TCO = 32 * WM * WAVES_M, TH = WAVES_N * WN / (TW / 32);
     constexpr int BUF = 2 * (TH + 2) * (TW + 4) + 18 * TCO + 2;
     constexpr int LDS_BYTES = 2 * BUF * 16 + TCO * 4;
-    static const bool attr_set = [] {        // once per process, thread-safe (a function-local constant, not mutable state)
-        (void)hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, TW, NW>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        return true;
-    }();
-    (void)attr_set;
+    static AideLdsOptIn lds_opt;             // per device, status checked (common.h)
+    if (int rc = lds_opt.ensure([] {
+            return hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<WM, WAVES_M, WN, OCC, RAGGED, IN_BF16, OUT_BF16, TW, NW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        })) return rc;
     a.tiles_w = a.W / TW;
     a.tiles_h = (a.H + TH - 1) / TH;
     a.n_co_tiles = a.Cout / TCO;
@@ -807,12 +806,11 @@ __global__ __launch_bounds__(128 * NWCO, (R == 2 && NWCO == 2) ? 2 : 1) void con
 template <int R, bool DZ_BF16, bool X_BF16, int NWCO>
 int launch_wgrad_bf16(BgArgs g, hipStream_t stream) {
     constexpr int LDS_BYTES = 2 * GCfg<R, NWCO>::BUF * 16;
-    static const bool attr_set = [] {        // once per process, thread-safe (a function-local constant, not mutable state)
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<R, DZ_BF16, X_BF16, NWCO>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        return true;
-    }();
-    (void)attr_set;
+    static AideLdsOptIn lds_opt;             // per device, status checked (common.h)
+    if (int rc = lds_opt.ensure([] {
+            return hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<R, DZ_BF16, X_BF16, NWCO>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        })) return rc;
     g.bands_h = g.H / R;
     g.chunks_total = g.N * g.segs_w * g.bands_h;
     g.n_co_tiles = (g.Co + 32 * NWCO - 1) / (32 * NWCO);

@@ -922,12 +922,11 @@ int aide_conv3x3_wgrad_wino(const float* dz, int64_t dz_bs, const float* a, int6
                             int Co, int Ci, int H, int W, float* ws, void* queue, hipStream_t stream) {
     if (!dz || !a || !dw || !ws || !aide_conv3x3_wgrad_wino_supported(Co, Ci, H, W) || dz_bs % 4 || a_bs % 4)
         return AIDE_ERR_ARG;
-    static const bool attr_set = [] {        // once per process, thread-safe (a function-local constant, not mutable state)
-        hipFuncSetAttribute((const void*)conv3x3_wgrad_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            WW_LDS * (int)sizeof(float));
-        return true;
-    }();
-    (void)attr_set;
+    static AideLdsOptIn lds_opt;             // per device, status checked (common.h)
+    if (int rc = lds_opt.ensure([] {
+            return hipFuncSetAttribute((const void*)conv3x3_wgrad_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       WW_LDS * (int)sizeof(float));
+        })) return rc;
     WWArgs g;
     g.dz = dz; g.a = a; g.slabs = ws; g.dz_bs = dz_bs; g.a_bs = a_bs;
     g.N = N; g.Co = Co; g.Ci = Ci; g.H = H; g.W = W;

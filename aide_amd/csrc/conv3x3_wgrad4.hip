@@ -446,12 +446,11 @@ int aide_conv3x3_wgrad_wino4_t(const float* dz, int64_t dz_bs, const float* a, i
                                int Co, int Ci, int H, int W, float* ws, int target_wgs, void* queue, hipStream_t stream) {
     if (!dz || !a || !dw || !ws || N <= 0 || !aide_conv3x3_wgrad_wino4_supported(Co, Ci, H, W) || dz_bs % 4 || a_bs % 4)
         return AIDE_ERR_ARG;
-    static const bool attr_set = [] {        // once per process, thread-safe (a function-local constant, not mutable state)
-        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  G4_LDS * (int)sizeof(float));
-        return true;
-    }();
-    (void)attr_set;
+    static AideLdsOptIn lds_opt;             // per device, status checked (common.h)
+    if (int rc = lds_opt.ensure([] {
+            return hipFuncSetAttribute((const void*)conv3x3_wgrad4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       G4_LDS * (int)sizeof(float));
+        })) return rc;
     G4Args g;
     g.dz = dz; g.a = a; g.slabs = ws; g.dz_bs = dz_bs; g.a_bs = a_bs;
     g.N = N; g.Co = Co; g.Ci = Ci; g.H = H; g.W = W;

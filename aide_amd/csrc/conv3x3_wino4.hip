@@ -698,24 +698,20 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
     const int aff_relu = aff ? epi_relu : 0;
     if (!x || !u || !y || !aide_conv3x3_wino4_supported(Cin, H, W, Cout) || x_bs % 4 || y_bs % 4 || (W == 16 && N % 2))
         return AIDE_ERR_ARG;
-    static const bool attr_set = [] {        // once per process, thread-safe (a function-local constant, not mutable state)
-        hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            F4_LDS * (int)sizeof(float));
-        hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            F4_LDS * (int)sizeof(float));
-        hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            F4_LDS * (int)sizeof(float));
-        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  F4_LDS * (int)sizeof(float));
-        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  F4_LDS * (int)sizeof(float));
-        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (F4_LDS + 4 * F4_BNIN_MAXC) * (int)sizeof(float));
-        (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (F4_LDS + 4 * F4_BNIN_MAXC) * (int)sizeof(float));
-        return true;
-    }();
-    (void)attr_set;
+    static AideLdsOptIn lds_opt;             // per device, status checked (common.h)
+    if (int rc = lds_opt.ensure([] {
+            constexpr int plain = F4_LDS * (int)sizeof(float), bnin = (F4_LDS + 4 * F4_BNIN_MAXC) * (int)sizeof(float);
+            const struct { const void* fn; int bytes; } ks[] = {
+                {(const void*)conv3x3_wino4_kernel<0>, plain}, {(const void*)conv3x3_wino4_kernel<1>, plain},
+                {(const void*)conv3x3_wino4_kernel<2>, plain}, {(const void*)conv3x3_wino4_kernel<0, true>, plain},
+                {(const void*)conv3x3_wino4_kernel<2, true>, plain}, {(const void*)conv3x3_wino4_kernel<0, false, true>, bnin},
+                {(const void*)conv3x3_wino4_kernel<2, false, true>, bnin}};
+            for (const auto& k : ks) {
+                const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        })) return rc;
     W4Args a;
     if (stats_parts && !(splitk <= 1 && accumulate == 0 && W >= 32)) return AIDE_ERR_ARG;   // only a launch that writes final outputs
     a.stats = stats_parts;

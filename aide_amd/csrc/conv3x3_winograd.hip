@@ -419,12 +419,11 @@ int aide_conv3x3_wino(const float* x, int64_t x_bs, const float* u, const float*
                       float* ws, hipStream_t stream) {
     if (!x || !u || !y || !aide_conv3x3_wino_supported(Cin, H, W, Cout) || x_bs % 4 || y_bs % 2)
         return AIDE_ERR_ARG;
-    static const bool attr_set = [] {        // once per process, thread-safe (a function-local constant, not mutable state)
-        hipFuncSetAttribute((const void*)conv3x3_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            2 * WBUF * (int)sizeof(float));
-        return true;
-    }();
-    (void)attr_set;
+    static AideLdsOptIn lds_opt;             // per device, status checked (common.h)
+    if (int rc = lds_opt.ensure([] {
+            return hipFuncSetAttribute((const void*)conv3x3_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * WBUF * (int)sizeof(float));
+        })) return rc;
     WinoArgs a;
     a.x = x; a.u = u; a.x_bs = x_bs; a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.tiles_w = (W + 15) / 16; a.tiles_h = (H + 15) / 16; a.n_co_tiles = Cout / WTCO;

@@ -40,6 +40,46 @@ def comm_environment():
     return {k: v for k, v in sorted(os.environ.items()) if k.startswith(_COMM_ENV_PREFIXES)}
 
 
+_RCCL_LOG = [None]          # file RCCL's INFO log of this rank goes to (set by init_from_env when nobody else configured NCCL_DEBUG)
+
+
+def first_contact(device=None, topo=True):
+    """What a first run on real peers should leave on record (bench.py `comm.first_contact`, rank 0, N > 1): the link topology as
+    `rocm-smi --showtopo` prints it, the channel count RCCL chose for this communicator (parsed from its own INFO log: the
+    workgroups its kernels take from the CUs the 144 KB-LDS convolution kernels want), and whether streams.pick() found a
+    hardware queue free of both the main stream and RCCL -- if not, the documented fallback is AIDE_PICK_STREAMS=0 (streams as the
+    runtime hands them out) and the record says so.  Everything here is best effort: a missing tool or log yields None."""
+    import re
+    import subprocess
+    out = dict(topology=None, rccl_channels=None, rccl_log=None, streams_fallback=None)
+    if topo:
+        try:
+            r = subprocess.run(['rocm-smi', '--showtopo'], capture_output=True, text=True, timeout=30)
+            lines = [ln.rstrip() for ln in r.stdout.splitlines() if ln.strip() and not set(ln.strip()) <= set('=-')]
+            out['topology'] = lines[:120]
+        except Exception as e:                      # noqa: BLE001  (tool missing / timeout: recorded, not fatal)
+            out['topology'] = 'unavailable: %s' % (e,)
+    path = _RCCL_LOG[0]
+    if path and os.path.exists(path):
+        try:
+            txt = open(path, errors='replace').read()
+            m = re.findall(r'(\d+) coll channels', txt)
+            ch = re.findall(r'Channel (\d+)/(\d+)', txt)
+            out['rccl_channels'] = int(m[-1]) if m else (int(ch[-1][1]) if ch else None)
+            out['rccl_log'] = [ln for ln in txt.splitlines() if 'channels' in ln or 'Init COMPLETE' in ln or 'Using network' in ln][-6:]
+        except Exception as e:                      # noqa: BLE001
+            out['rccl_log'] = 'unreadable: %s' % (e,)
+    if not PICK_STREAMS[0]:
+        out['streams_fallback'] = 'AIDE_PICK_STREAMS=0: streams as the runtime hands them out (no hardware-queue measurement)'
+    else:
+        from . import streams
+        idx = device.index if device is not None and device.index is not None else torch.cuda.current_device()
+        if idx not in streams.PREFERRED:
+            out['streams_fallback'] = ('streams.pick() found no hardware queue free of the main stream and RCCL (or did not run): the '
+                                       'engine uses streams as the runtime hands them out; AIDE_PICK_STREAMS=0 makes that explicit')
+    return out
+
+
 def make_buckets(offsets, numels, bucket_elems):
     """Greedy contiguous buckets over the flat arena, walked in arena (offset) order -- the engine lays the arena out
     in backward-completion order, so bucket k is complete before bucket k+1. -> list of (start, end, [param indices])."""
@@ -112,6 +152,13 @@ def init_from_env(device_ids=None):
             if PICK_STREAMS[0]:
                 from . import streams
                 streams.reserve_queue(device)            # RCCL's stream then gets a hardware queue of its own (streams.py)
+            if rank == 0 and 'NCCL_DEBUG' not in os.environ and 'NCCL_DEBUG_FILE' not in os.environ:
+                # rank 0 keeps RCCL's own account of the communicator (channel count, transport) for first_contact()
+                import tempfile
+                _RCCL_LOG[0] = os.path.join(tempfile.gettempdir(), 'aide_rccl_rank0_%d.log' % os.getpid())
+                os.environ['NCCL_DEBUG'] = 'INFO'
+                os.environ['NCCL_DEBUG_SUBSYS'] = 'INIT'
+                os.environ['NCCL_DEBUG_FILE'] = _RCCL_LOG[0]
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(backend)

@@ -165,7 +165,7 @@ def replica_check(nets, reducers, world, device):
 
 def comm_block(world, reducers, per_rank, steps, check=None):
     """N > 1: what was exchanged and what of it the step had to wait for."""
-    from aide_amd.distributed import comm_environment
+    from aide_amd.distributed import comm_environment, first_contact
     if world == 1:
         return dict(backend=None, ranks=1, env=comm_environment())
     desc = [r.describe() for r in reducers]
@@ -178,6 +178,8 @@ def comm_block(world, reducers, per_rank, steps, check=None):
     return dict(backend=dist.get_backend(), ranks=world, rccl_version=ver,
                 buckets=sum(d['buckets'] for d in desc), bytes_per_step=sum(d['bytes_per_step'] for d in desc),
                 env=comm_environment(), **(check or {}),
+                # link topology, RCCL's channel count, stream fallback (multi-GPU: first contact with real peers)
+                first_contact=first_contact() if dist.get_rank() == 0 else None,
                 hw_queues=next((d['hw_queues'] for d in desc if d.get('hw_queues')), None),
                 exposed_ms=(round(sum(e for e in exposed if e is not None), 4)
                             if any(e is not None for e in exposed) else None),

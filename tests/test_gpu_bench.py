@@ -119,6 +119,11 @@ def test_bench_eight_ranks_rehearsal(dev, workload, steps):
     assert c['env'].get('GPU_MAX_HW_QUEUES') == env['GPU_MAX_HW_QUEUES']
     rk = c['rank_ms_per_step']
     assert 0 < rk['min'] <= rk['max'] <= j['ms_per_step'] * 1.001
+    # first-contact record: link topology as rocm-smi prints it, RCCL's channel count (None under gloo), the stream fallback
+    fc = c['first_contact']
+    assert set(fc) >= {'topology', 'rccl_channels', 'rccl_log', 'streams_fallback'} and fc['topology']
+    assert eight or fc['rccl_channels'] is None
+    assert not eight or (isinstance(fc['rccl_channels'], int) and fc['rccl_channels'] > 0)
     print('N=8 rehearsal %s: %.1f images/s, rank ms/step %.3f .. %.3f' % (workload, j['value'], rk['min'], rk['max']))
 
 
