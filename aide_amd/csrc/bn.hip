@@ -684,14 +684,6 @@ extern "C" {
 
 // Training-mode forward of relu(bn(z)): batch statistics (pass 1), then finalize + apply (pass 2).
 // Outputs mean/rstd/scale/shift [C] are kept by the caller for the backward.
-int aide_bn_train_fwd(const float* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
-                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                      float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
-                      float* scale, float* shift, int relu, void* ws, hipStream_t stream) {
-    return bn_train_fwd_t<float, float>(z, z_bs, a, a_bs, N, C, H, W, gamma, beta, eps, momentum, running_mean,
-                                        running_var, num_batches_tracked, mean, rstd, scale, shift, relu, ws, stream);
-}
-
 // the same operators on bf16-stored conv outputs / conv-output gradients (precision='bf16'); z_bf16 / dz_bf16 select
 // the storage type of the untyped pointers, everything else is unchanged
 int aide_bn_train_fwd_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
@@ -755,16 +747,6 @@ int aide_bn_train_fwd_parts_strided(const void* z, int z_bf16, int64_t z_bs, voi
                                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                                     float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
                                     float* scale, float* shift, int relu, hipStream_t stream);
-
-int aide_bn_train_fwd_parts(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C, int H,
-                            int W, const float* parts, int nparts, const float* conv_bias, const float* gamma,
-                            const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                            long long* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift,
-                            int relu, hipStream_t stream) {
-    return aide_bn_train_fwd_parts_strided(z, z_bf16, z_bs, a, a_bf16, a_bs, N, C, H, W, parts, nparts, nparts, conv_bias, gamma,
-                                           beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd,
-                                           scale, shift, relu, stream);
-}
 
 int aide_bn_train_fwd_parts_strided(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
                                     int H, int W, const float* parts, int nparts, int parts_stride, const float* conv_bias,
@@ -883,18 +865,5 @@ int aide_bn_eval_fold(int C, const float* gamma, const float* beta, const float*
     return aide_launch_status();
 }
 
-int aide_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
-                       const float* scale, const float* shift, int relu, hipStream_t stream) {
-    return bn_relu_apply_t<float, float>(z, z_bs, a, a_bs, N, C, H, W, scale, shift, relu, stream);
-}
-
 // Backward of relu(bn(z)): dA -> dz, dgamma, dbeta, and the (mathematically zero) conv-bias grad.
-int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs, float* dz, int64_t dz_bs,
-                     int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
-                     const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws, void* done,
-                     hipStream_t stream) {
-    return bn_relu_bwd_t<float, float, float>(dA, d_bs, z, z_bs, dz, dz_bs, N, C, H, W, mean, rstd, scale, shift, relu, dgamma,
-                                       dbeta, dbias, ws, done, stream);
-}
-
 }  // extern "C"

@@ -914,12 +914,6 @@ int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint1
     return rc;
 }
 
-int aide_conv3x3_bf16(const float* x, int64_t x_bs, const uint16_t* u, const float* bias, float* y, int64_t y_bs,
-                      int N, int Cin, int H, int W, int Cout, int accumulate, int splitk, float* ws,
-                      hipStream_t stream) {
-    return aide_conv3x3_bf16_mixed(x, 0, x_bs, u, bias, y, 0, y_bs, N, Cin, H, W, Cout, accumulate, splitk, ws, stream);
-}
-
 int aide_conv3x3_wgrad_bf16_supported(int Co, int Ci, int H, int W) {
     // any Ci: input channels beyond Ci are masked in the loaders and in the slab store (the 3-channel network inputs
     // cost a mostly idle 64-wide ci tile, but that layer is bound by streaming dz, not by the MFMAs)
@@ -975,11 +969,6 @@ int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, co
 #undef AIDE_WG
     if (rc != 0) return rc;
     return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, queue, stream);
-}
-
-int aide_conv3x3_wgrad_bf16(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N, int Co,
-                            int Ci, int H, int W, float* ws, hipStream_t stream) {
-    return aide_conv3x3_wgrad_bf16_mixed(dz, 0, dz_bs, a, 0, a_bs, dw, N, Co, Ci, H, W, ws, 0, nullptr, stream);
 }
 
 }  // extern "C"

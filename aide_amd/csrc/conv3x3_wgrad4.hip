@@ -422,7 +422,7 @@ int aide_conv3x3_wgrad_wino4_supported(int Co, int Ci, int H, int W) {
 int aide_conv3x3_wgrad_wino4_splits_t(int N, int Co, int Ci, int H, int W, int target_wgs) {
     const long blocks = (long)((Co + 63) / 64) * (Ci / 32);
     const long chunks = (long)N * (H / 4) * ((W + 15) / 16);
-    const long target = target_wgs > 0 ? target_wgs : 128;      // default: half of the chip
+    const long target = target_wgs > 0 ? target_wgs : 128;      // default: half of the chip (HISTORY §4.6)
     long s = (target + blocks - 1) / blocks;
     if (s > chunks / 2) s = chunks / 2;
     if (s < 1) s = 1;
@@ -482,11 +482,6 @@ int aide_conv3x3_wgrad_wino4_t(const float* dz, int64_t dz_bs, const float* a, i
     const int rc = aide_launch_status();
     if (rc != 0) return rc;
     return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, queue, stream);
-}
-
-int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
-                             int Co, int Ci, int H, int W, float* ws, void* queue, hipStream_t stream) {
-    return aide_conv3x3_wgrad_wino4_t(dz, dz_bs, a, a_bs, dw, N, Co, Ci, H, W, ws, 0, queue, stream);
 }
 
 }  // extern "C"

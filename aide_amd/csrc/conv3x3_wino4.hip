@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_kernel(const W4Args a) {
         // The eight bias values of this lane's output rows are fetched up front.  (Read next to their use they were eight
         // dependent global_load -> s_waitcnt vmcnt(0) round trips per wave, each of which also waited for the output stores
         // issued before it to be acknowledged -- stores count in vmcnt on gfx9: most of the "3.5 us of output stores" of
-        // DESIGN 4.8.)
+        // HISTORY §4.8.)
         float bvs[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {

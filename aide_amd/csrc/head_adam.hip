@@ -238,18 +238,9 @@ int head_bwd_t(const float* dy, int64_t dy_bs, const XT* x, int64_t x_bs, const 
 
 extern "C" {
 
-int aide_head1x1_fwd(const float* x, int64_t x_bs, const float* w, const float* b, float* y, int64_t y_bs,
-                     int N, int C, int K, int H, int W, hipStream_t stream) {
-    return head_fwd_t<float>(x, x_bs, w, b, y, y_bs, N, C, K, H, W, stream);
-}
 size_t aide_head1x1_ws_bytes(int C, int K) { return (size_t)HEAD_WG_BLOCKS * (K * C + K) * sizeof(double); }
 
 // dy: [N][K][HW] -> dx [N][C][HW] (may be NULL), dw [K][C] + db [K] (dw may be NULL: data gradient only)
-int aide_head1x1_bwd(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, const float* w, float* dx,
-                     int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W, void* ws,
-                     hipStream_t stream) {
-    return head_bwd_t<float, float>(dy, dy_bs, x, x_bs, w, dx, dx_bs, dw, db, N, C, K, H, W, ws, stream);
-}
 // the head on a bf16-stored feature map (precision='bf16'); logits and every gradient stay fp32
 int aide_head1x1_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, const float* w, const float* b, float* y,
                            int64_t y_bs, int N, int C, int K, int H, int W, hipStream_t stream) {

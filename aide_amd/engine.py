@@ -170,7 +170,7 @@ def use_winograd(cfg, n, cin, h, w, cout):
 def _preferred(dev):
     """the per-device streams every plan uses instead of creating its own: a data-parallel rank's measured choice
     (aide_amd/streams.py), else ONE weight-gradient stream and ONE lane / pack stream per device shared by every plan of
-    every engine (the HIP runtime maps a process' streams onto 4 hardware queues: DESIGN.md 7a)"""
+    every engine (the HIP runtime maps a process' streams onto 4 hardware queues: HISTORY §7a)"""
     from . import streams as _streams
     d = torch.device(dev)
     idx = d.index if d.index is not None else torch.cuda.current_device()
@@ -1045,7 +1045,7 @@ class Plan(object):
     def _backward_ops(self, inputs, dlogits, gslot, main, side, after_op):
         """The backward launch sequence: the dependent chain on `main`, every weight gradient on `side`.  (The second
         encoder's chains on a stream of their own, as in the forward pass, measured +-0 beside the weight-gradient stream
-        -- DESIGN.md 3c -- and is not built in.)"""
+        -- HISTORY §3c -- and is not built in.)"""
         fold = [0]                       # split count of the data gradient the NEXT BatchNorm backward reads from sk_ws
         for st in reversed(self.steps):
             if self.trace is not None:

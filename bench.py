@@ -59,7 +59,7 @@ def parse():
                     help='how many of the timed steps (the last ones) carry dispatch start/stop events: a launch with '
                          'events opens a ~7 us gap in its queue (the kernel durations themselves are unchanged), an '
                          'instrumented C2 step runs ~6 %% longer: 3 of 50 steps cost the line 0.2-0.3 %%, the 8 of '
-                         'rounds 2-4 cost 0.7-1.0 %% (same-box A/B, DESIGN 11.7).  Default: 3, but at most one timed step in ten')
+                         'rounds 2-4 cost 0.7-1.0 %% (same-box A/B, HISTORY §11.7).  Default: 3, but at most one timed step in ten')
     ap.add_argument('--traffic', default='live', choices=('live', 'none'),
                     help="roofline.traffic: 'live' = two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, separately, "
                          "--kernel-trace only) of this workload run as sub-processes after the timed region (rank 0, N=1)")
@@ -189,7 +189,7 @@ def comm_block(world, reducers, per_rank, steps, check=None):
 
 
 def roofline_block(timer, ev_steps, steps, peak, args, precision, batch, world):
-    """`roofline` + per-family `kernels` from the dispatch timer (see DESIGN.md 6)."""
+    """`roofline` + per-family `kernels` from the dispatch timer (see DESIGN.md §7)."""
     agg = timer.summary()
     kernels = {}
     for k, a in agg.items():

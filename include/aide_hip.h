@@ -105,10 +105,9 @@ int aide_conv3x3_wgrad_stem(const void* dz, int dz_bf16, int64_t dz_bs, const fl
 int aide_conv3x3_wgrad_wino4_supported(int Co, int Ci, int H, int W);
 int aide_conv3x3_wgrad_wino4_splits(int N, int Co, int Ci, int H, int W);
 size_t aide_conv3x3_wgrad_wino4_ws_bytes(int N, int Co, int Ci, int H, int W);
-int aide_conv3x3_wgrad_wino4(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
-                             int Co, int Ci, int H, int W, float* ws, void* queue, aide_stream_t stream);
-/* the same with the workgroup count of the launch as an argument (target_wgs <= 0: the default, half of the chip --
- * the kernel normally shares it with the dependent chain of the backward pass; 256 for a launch that has the chip alone) */
+/* dw [Co][Ci][3][3] = sum over images and pixels; the workgroup count of the launch is an argument (target_wgs <= 0: the
+ * default, half of the chip -- the kernel normally shares it with the dependent chain of the backward pass; 256 for a launch
+ * that has the chip alone); ws: aide_conv3x3_wgrad_wino4_ws_bytes_t() bytes; queue: NULL or a batched-reduce queue */
 int aide_conv3x3_wgrad_wino4_splits_t(int N, int Co, int Ci, int H, int W, int target_wgs);
 size_t aide_conv3x3_wgrad_wino4_ws_bytes_t(int N, int Co, int Ci, int H, int W, int target_wgs);
 int aide_conv3x3_wgrad_wino4_t(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
@@ -129,11 +128,9 @@ size_t aide_conv3x3_bf16_pack_elems(int Cout, int Cin);          /* bf16 element
  * int64 block_start}; an entry occupies aide_conv3x3_bf16_pack_blocks(Co, Ci) workgroups (64 co x 16 ci blocks through LDS) */
 int aide_conv3x3_bf16_pack_blocks(int Cout, int Cin);
 int aide_conv3x3_bf16_pack_multi(const void* descs, int n, int64_t total_blocks, aide_stream_t stream);
-int aide_conv3x3_bf16(const float* x, int64_t x_bs, const uint16_t* u, const float* bias, float* y, int64_t y_bs,
-                      int N, int Cin, int H, int W, int Cout, int accumulate, int splitk, float* ws,
-                      aide_stream_t stream);                     /* forward and dgrad */
-/* the same with bf16 STORAGE of the conv output z (forward: y_bf16) or of its gradient dz (dgrad: x_bf16) -- the
- * engine's precision='bf16' mode keeps z and dz in HBM as bf16 (they are only read by BatchNorm / by these kernels) */
+/* forward and dgrad; x_bf16 / y_bf16 = 0: fp32 tensors; 1: bf16 STORAGE of the conv output z (forward: y_bf16) or of its
+ * gradient dz (dgrad: x_bf16) -- the engine's precision='bf16' mode keeps z and dz in HBM as bf16 (they are only read by
+ * BatchNorm / by these kernels) */
 int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint16_t* u, const float* bias, void* y,
                             int y_bf16, int64_t y_bs, int N, int Cin, int H, int W, int Cout, int accumulate, int splitk,
                             float* ws, aide_stream_t stream);
@@ -143,8 +140,6 @@ int aide_conv3x3_wgrad_bf16_supported(int Co, int Ci, int H, int W);
  * used) or 0 = the built-in rule (1 for Co <= 32, 4 from 150 GFLOP per launch); the split count depends on it */
 int aide_conv3x3_wgrad_bf16_splits(int N, int Co, int Ci, int H, int W, int co_blocks);
 size_t aide_conv3x3_wgrad_bf16_ws_bytes(int N, int Co, int Ci, int H, int W, int co_blocks);
-int aide_conv3x3_wgrad_bf16(const float* dz, int64_t dz_bs, const float* a, int64_t a_bs, float* dw, int N,
-                            int Co, int Ci, int H, int W, float* ws, aide_stream_t stream);
 int aide_conv3x3_wgrad_bf16_mixed(const void* dz, int dz_bf16, int64_t dz_bs, const void* a, int a_bf16, int64_t a_bs,
                                   float* dw, int N, int Co, int Ci, int H, int W, float* ws, int co_blocks, void* queue,
                                   aide_stream_t stream);
@@ -162,15 +157,9 @@ int aide_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t d
 /* ---- BatchNorm2d (+ReLU) -----------------------------------------------------------------------
  * replaces nn.BatchNorm2d + nn.ReLU: netblocks.py:25,27,28,18 ; UNet.py:20,22,23,13 */
 size_t aide_bn_ws_bytes(int C);
-int aide_bn_train_fwd(const float* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
-                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                      float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
-                      float* scale, float* shift, int relu, void* ws, aide_stream_t stream);
 int aide_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift,
                        aide_stream_t stream);
-int aide_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, int N, int C, int H, int W,
-                       const float* scale, const float* shift, int relu, aide_stream_t stream);
 /* Eval-mode BatchNorm folded into the convolution before it (the per-case inference loop,
  * trainchaos_comparison_1case.py:233-273: net.eval(), running statistics): aide_bn_eval_fold also writes
  * fbias = conv_bias * scale + shift; an aide_conv3x3_wino4 or aide_conv3x3_igemm launch given epi_scale = scale,
@@ -180,10 +169,6 @@ int aide_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, int
 int aide_bn_eval_fold(int C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, const float* conv_bias, float* scale, float* shift,
                       float* fbias, aide_stream_t stream);
-int aide_bn_relu_bwd(const float* dA, int64_t d_bs, const float* z, int64_t z_bs, float* dz,
-                     int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
-                     const float* scale, const float* shift, int relu, float* dgamma, float* dbeta,
-                     float* dbias, void* ws, void* done, aide_stream_t stream);
 /* `done` (the three aide_bn_relu_bwd* calls): NULL, or an event of aide_event_create that is recorded when dz is complete --
  * attached to the call's last dispatch instead of a record packet of its own: aide_stream_wait_event(other, done) then
  * orders another stream behind dz at ~1.4 us of this queue's time (aide_stream_order: ~5 us; tools/ubench/handover_cost.hip) */
@@ -195,8 +180,11 @@ int aide_bn_relu_bwd_slabs(const float* slabs, int splitk, int64_t split_stride,
                            int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                            const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
                            void* done, aide_stream_t stream);
-/* the same three operators on bf16-STORED z / a / dz (precision='bf16'): z_bf16 / a_bf16 / dz_bf16 give the element type behind the
- * untyped pointers; the arithmetic (fp32 per element, fp64 reductions) is unchanged, widening is exact, dz is narrowed RNE */
+/* Training-mode forward a = relu?(bn(z)) (batch statistics, running-statistics update; mean / rstd / scale / shift [C] are kept
+ * by the caller for the backward), the plain apply a = relu?(z * scale + shift), and the backward dA -> dz, dgamma, dbeta (+ the
+ * mathematically zero conv-bias gradient).  z_bf16 / a_bf16 / dz_bf16 give the element type behind the untyped pointers (0 = fp32;
+ * 1 = bf16 STORAGE, precision='bf16'); the arithmetic (fp32 per element, fp64 reductions) is the same, widening is exact, dz is
+ * narrowed RNE */
 int aide_bn_train_fwd_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
                             int H, int W, const float* gamma, const float* beta, float eps, float momentum,
                             float* running_mean, float* running_var, long long* num_batches_tracked, float* mean,
@@ -213,14 +201,9 @@ int aide_bn_train_fwd_slabs(const float* slabs, int splitk, int64_t split_stride
  * output channel and workgroup tile, the fp32 sum and sum of squares of its pre-bias outputs to parts[Cout][nparts][2]
  * (nparts = aide_conv3x3_wino4_stats_parts); aide_bn_train_fwd_parts then normalises with ONE pass over z (replaces the
  * statistics pass of nn.BatchNorm2d in train mode, netblocks.py:25,27).  aide_bn_two_pass tells whether the plain
- * aide_bn_train_fwd would need two launches for this shape. */
+ * aide_bn_train_fwd_mixed would need two launches for this shape. */
 int aide_conv3x3_wino4_stats_parts(int N, int H, int W);
 int aide_bn_two_pass(int N, int C, int H, int W);
-int aide_bn_train_fwd_parts(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C, int H,
-                            int W, const float* parts, int nparts, const float* conv_bias, const float* gamma,
-                            const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                            long long* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift,
-                            int relu, aide_stream_t stream);
 /* the same for ONE group of a stacked batch (Engine.run_groups): `parts` points at the group's first entry of channel 0,
  * nparts counts the group's entries, parts_stride the entries per channel of the whole launch */
 int aide_bn_train_fwd_parts_strided(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
@@ -376,19 +359,13 @@ int aide_sa_gate_bwd(const float* dout, int64_t dout_bs, const float* y, int64_t
 
 /* ---- 1x1 head convolution -----------------------------------------------------------------------
  * replaces last_conv1 = nn.Conv2d(64, num_classes, 1): fuseunet.py:41,89 ; UNet.py:150,164.  K = num_classes, 1 .. 8 */
-int aide_head1x1_fwd(const float* x, int64_t x_bs, const float* w, const float* b, float* y, int64_t y_bs,
-                     int N, int C, int K, int H, int W, aide_stream_t stream);
 size_t aide_head1x1_ws_bytes(int C, int K);
-/* the head on a bf16-stored feature map (precision='bf16'); logits and every gradient stay fp32 */
+/* x_bf16 / dx_bf16 = 1: the head on a bf16-stored feature map (precision='bf16'); logits and every gradient stay fp32 */
 int aide_head1x1_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, const float* w, const float* b, float* y,
                            int64_t y_bs, int N, int C, int K, int H, int W, aide_stream_t stream);
 int aide_head1x1_bwd_mixed(const float* dy, int64_t dy_bs, const void* x, int x_bf16, int64_t x_bs, const float* w,
                            void* dx, int dx_bf16, int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W,
                            void* ws, aide_stream_t stream);
-int aide_head1x1_bwd(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, const float* w,
-                     float* dx, int64_t dx_bs, float* dw, float* db, int N, int C, int K, int H, int W,
-                     void* ws, aide_stream_t stream);
-
 /* ---- fused segmentation losses / co-teaching selection -----------------------------------------
  * replaces utils/loss2d.py:5-154, utils/coteach_loss.py:94-161, utils/metrics2d.py:8-29 and the
  * inline selection of train_files/trainchaos_proposed_30cases1labeled.py:274-321 */

@@ -8,7 +8,7 @@ The oracle is a plain-PyTorch (stock aten, CPU, fp32) restatement of the
 reference algorithm.  Each function cites the reference file:line it follows.
 It is pinned by ``tests/golden/*.npz`` which were produced by importing the
 real reference (``oracle/gen_golden.py``, run in the build container where
-``/root/reference`` exists); see DESIGN.md "Oracle pinning".
+``/root/reference`` exists); see DESIGN.md §2.
 """
 from .nets import (fuseunet, UNet, fuseunetsa, UNetsa, Spatial_Attention, fuseunetsaseparate,  # noqa: F401
                    UNet128, UNet32, UNet16, UNet8, UNet4, UNet2)

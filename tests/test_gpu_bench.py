@@ -44,7 +44,7 @@ def test_bench_line_and_dispatch_timer(dev):
     assert roof['bound'] == 'mfma' and roof['unit'] == 'TFLOP/s' and roof['peak'] == 157.3
     assert roof['dropped_launches'] == 0
     # 30 F(4x4) weight gradients (28 layers of >= 64 output channels + the two 32->32 layers as half tiles) and 38 F(4x4)
-    # forward / dgrad launches per FuseUNet step at 256x256 (DESIGN.md 4)
+    # forward / dgrad launches per FuseUNet step at 256x256 (DESIGN.md §4)
     ks = j['kernels']
     assert ks['conv3x3_wgrad4_kernel']['launches_per_step'] == 30
     assert ks['conv3x3_wino4_kernel']['launches_per_step'] == 38

@@ -455,7 +455,7 @@ def _network_vs_oracle(dev, kind, LOGIT_TOL, LOSS_TOL, GRAD_TOL, store=True):
     worst = 0.0
     for (name, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         if name.endswith('conv1.bias') or name.endswith('conv2.bias') or '.bilinear_up.' in name and name.endswith('.1.bias'):
-            continue                                   # biases feeding a BatchNorm: zero true gradient
+            continue                                   # biases feeding a BatchNorm: zero true gradient (HISTORY §5)
         scale = q.grad.abs().max().item()
         if scale < 1e-7:
             continue

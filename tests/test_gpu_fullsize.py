@@ -96,7 +96,7 @@ def _check_config(dev, net, ref, inputs, t, fx, tag):
                 and not k.startswith('last_conv'):
             # a 3x3 / transposed conv bias feeding a BatchNorm: zero true gradient, both sides hold rounding noise of their
             # own summation order (aten's is thread-schedule dependent: its magnitude straddled a 1e-6 cut-off from run to
-            # run) -- both must be negligible beside the same conv's weight gradient
+            # run) -- both must be negligible beside the same conv's weight gradient (HISTORY.md section 5)
             wscale = named[k[:-5] + '.weight'].grad.abs().max().item()
             assert max(scale, p.grad.abs().max().item()) <= 1e-4 * wscale + 1e-12, (k, scale, p.grad.abs().max().item(), wscale)
             continue

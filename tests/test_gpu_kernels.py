@@ -474,9 +474,9 @@ FULL_LAYERS = [(1024, 512, 32), (512, 256, 64), (256, 128, 128), (128, 64, 256),
 
 @pytest.mark.parametrize('layer', FULL_LAYERS)
 def test_full_size_layers_winograd_vs_direct(dev, layer):
-    """BASELINE config 2 layer sizes (N = 4), too large for the CPU oracle in a unit test: the three independent
-    implementations of the same operator — F(4x4,3x3), F(2x2,3x3) and the direct implicit GEMM — must agree
-    (forward, dgrad, wgrad; 1e-4 of the result scale), and the F(4x4) kernels must be linear in their input."""
+    """BASELINE config 2 layer sizes (N = 4): the three independent implementations of the same operator — F(4x4,3x3),
+    F(2x2,3x3) and the direct implicit GEMM — must agree (forward, dgrad, wgrad; 1e-4 of the result scale), the F(4x4) kernels
+    must be linear in their input, and image 0 of every direction is held to aten's float64 convolution on the CPU."""
     from aide_amd import ops
     ci, co, h = layer
     n = 4
@@ -510,3 +510,14 @@ def test_full_size_layers_winograd_vs_direct(dev, layer):
     # determinism: a second launch is bit-identical (fixed-order split reductions, no atomics)
     assert torch.equal(ops.conv3x3_wgrad_wino4(dy, x, torch.empty_like(w)), g4)
     assert torch.equal(ops.conv3x3_wino4(x, u4f, b, torch.empty_like(y0)), y4)
+    # ... and an anchor OUTSIDE this library, so that the comparison above is not a self-comparison: image 0 of the forward, the
+    # data gradient and the weight gradient against aten's float64 convolution on the CPU (one image bounds the CPU time)
+    xc, wc, bc, dyc = x[:1].double().cpu(), w.double().cpu(), b.double().cpu(), dy[:1].double().cpu()
+    ry = F.conv2d(xc, wc, bc, padding=1)
+    _close(y4[:1], ry, rtol=1e-4, what='F4 vs aten float64 fwd %s' % (layer,))
+    _close(y0[:1], ry, rtol=2e-5, what='direct vs aten float64 fwd %s' % (layer,))
+    rd = torch.nn.grad.conv2d_input(xc.shape, wc, dyc, padding=1)
+    _close(d4[:1], rd, rtol=1e-4, what='F4 vs aten float64 dgrad %s' % (layer,))
+    rg = torch.nn.grad.conv2d_weight(xc, wc.shape, dyc, padding=1)
+    g4_1 = ops.conv3x3_wgrad_wino4(dy[:1], x[:1], torch.empty_like(w))
+    _close(g4_1, rg, rtol=1e-4, what='F4 vs aten float64 wgrad %s' % (layer,))

@@ -1,4 +1,4 @@
-// Facts for an fp32-by-split-bf16 F(4x4) kernel: sustained rate of the bf16 MFMA shapes at one wave per SIMD with
+// Facts for an fp32-by-split-bf16 F(4x4) kernel (HISTORY §8): sustained rate of the bf16 MFMA shapes at one wave per SIMD with
 // independent accumulators, alone and with K filler VALU instructions per MFMA -- is a VALU instruction paid in bf16-MFMA
 // time as it is in fp32-MFMA time?
 #include <hip/hip_runtime.h>

@@ -1,4 +1,4 @@
-"""What do split-bf16 products cost an F(4x4,3x3) convolution in accuracy?  (CPU, numpy)
+"""What do split-bf16 products cost an F(4x4,3x3) convolution in accuracy?  (CPU, numpy; HISTORY §10-6)
 
 The transform-domain operands U = G g G^T (filters) and V = B^T d B (data) are fp32.  On the bf16 matrix pipe each is written as a
 sum of bf16 terms (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)) and the element-wise product U (.) V summed over
