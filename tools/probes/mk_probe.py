@@ -39,6 +39,10 @@ G4_FRAG = "            if (w == 0 && gq + 2 < 9) frag(gq + 2, (gq + 2) % 3);\n"
 
 # name -> (source file, [(old, new), ...])
 PROBES = {
+    # hand-over events with a device-scope release instead of the default (round 5: the 5-7 us hole behind every kernel that carries a
+    # completion event in the backward pass -- is it the system-scope fence of the event?)
+    'ev_device': ('ktimer.hip', [("hipEventCreateWithFlags(&e, hipEventDisableTiming);", "hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice);")]),
+    'ev_nofence': ('ktimer.hip', [("hipEventCreateWithFlags(&e, hipEventDisableTiming);", "hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);")]),
     'g4_noput': ('conv3x3_wgrad4.hip', [(G4_PUT, '                    { }\n')]),                 # no raw-tile stores (14 ds_write_b32)
     'g4_novstore': ('conv3x3_wgrad4.hip', [(G4_VSTORE, '')]),                              # no V stores (9 ds_write_b64)
     'g4_nozstore': ('conv3x3_wgrad4.hip', [(G4_ZSTORE, G4_ZNONE)]),          # no ZT stores (12 b64 + 12 b32)
