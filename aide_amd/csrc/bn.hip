@@ -271,18 +271,6 @@ __global__ __launch_bounds__(64) void bn_finalize_groups_kernel(
     }
 }
 
-// eval mode: scale/shift from running statistics
-__global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                     const float* __restrict__ rm, const float* __restrict__ rv, float eps,
-                                     float* __restrict__ scale_out, float* __restrict__ shift_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float rstd = 1.0f / sqrtf(rv[c] + eps);
-    const float sc = (gamma ? gamma[c] : 1.0f) * rstd;
-    scale_out[c] = sc;
-    shift_out[c] = (beta ? beta[c] : 0.0f) - rm[c] * sc;
-}
-
 // eval mode with the BatchNorm folded into the convolution's epilogue: a = relu(acc * scale + fbias), fbias = conv_bias * scale + shift
 __global__ void bn_eval_fold_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ rm, const float* __restrict__ rv, float eps,
@@ -846,13 +834,6 @@ int aide_bn_relu_bwd_slabs(const float* slabs, int splitk, int64_t split_stride,
     AIDE_LAUNCH_DONE(done, (bn_bwd_fused_kernel<float, float, float, true>), dim3(C), dim3(256), 0, stream, (const float*)nullptr, 0L,
                      z, (long)z_bs, dz, (long)dz_bs, N, HW, (double)N * HW, mean, rstd, scale, shift, relu, dgamma, dbeta,
                      dbias, sl);
-    return aide_launch_status();
-}
-
-int aide_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean,
-                       const float* running_var, float eps, float* scale, float* shift, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, C, gamma, beta,
-                       running_mean, running_var, eps, scale, shift);
     return aide_launch_status();
 }
 

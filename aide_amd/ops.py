@@ -325,12 +325,6 @@ def bn_train_fwd_parts(z, a, parts, nparts, conv_bias, gamma, beta, eps, momentu
     return a
 
 
-def bn_eval_coeff(gamma, beta, running_mean, running_var, eps, scale, shift):
-    check(lib.aide_bn_eval_coeff(scale.numel(), ptr(gamma), ptr(beta), ptr(running_mean),
-                                 ptr(running_var), eps, ptr(scale), ptr(shift), stream_ptr()),
-          'bn_eval_coeff')
-
-
 def bn_eval_fold(bn, conv_bias, scale, shift, fbias):
     """eval-mode coefficients of `bn` and the bias of the convolution before it folded through them"""
     check(lib.aide_bn_eval_fold(scale.numel(), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),

@@ -157,9 +157,6 @@ int aide_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t d
 /* ---- BatchNorm2d (+ReLU) -----------------------------------------------------------------------
  * replaces nn.BatchNorm2d + nn.ReLU: netblocks.py:25,27,28,18 ; UNet.py:20,22,23,13 */
 size_t aide_bn_ws_bytes(int C);
-int aide_bn_eval_coeff(int C, const float* gamma, const float* beta, const float* running_mean,
-                       const float* running_var, float eps, float* scale, float* shift,
-                       aide_stream_t stream);
 /* Eval-mode BatchNorm folded into the convolution before it (the per-case inference loop,
  * trainchaos_comparison_1case.py:233-273: net.eval(), running statistics): aide_bn_eval_fold also writes
  * fbias = conv_bias * scale + shift; an aide_conv3x3_wino4 or aide_conv3x3_igemm launch given epi_scale = scale,
