@@ -1359,9 +1359,22 @@ class Engine(object):
         self.graph = None
         self._precision = 'fp32'
         self.config = EngineConfig(self._config_changed)
+        self.pending_stream = None       # a stream still carrying this module's last backward / optimizer step (set by a caller
+                                         # that leaves them there: coteach_step(pipeline=True)); see _join_pending
         self._arena = self._views = self._anchor = self._anchor_zero = None
         self._arena_uses = -1
         self._pslots = None
+
+    def _join_pending(self):
+        """a forward issued on ANOTHER stream than the one that still carries this module's last backward pass / optimizer
+        step (evaluation, a plain forward after a pipelined co-teaching loop) is ordered behind it; a forward on that same
+        stream -- the next pipelined step -- needs no wait and keeps the overlap"""
+        s = self.pending_stream
+        if s is not None:
+            cur = torch.cuda.current_stream(s.device)
+            if cur != s:
+                cur.wait_stream(s)
+                self.pending_stream = None
 
     def _config_changed(self):
         """a switch of self.config was assigned: plans (with their launch tapes) and shared filter packs were built under the old
@@ -1470,6 +1483,7 @@ class Engine(object):
         layers need no split-K and fill the chip), every BatchNorm normalises and updates its running statistics per
         group, in order -- exactly what the sequential forwards of the co-teaching loop's augmentation passes do
         (trainchaos_proposed_30cases1labeled.py:265-269).  Forward only (no autograd graph)."""
+        self._join_pending()
         groups = len(input_groups)
         nin = len(input_groups[0])
         ins = []
@@ -1491,6 +1505,7 @@ class Engine(object):
         return [out[g * m:(g + 1) * m] for g in range(groups)]
 
     def run(self, *inputs):
+        self._join_pending()
         ins = []
         for x in inputs:
             if not isinstance(x, torch.Tensor) or not x.is_cuda:

@@ -65,9 +65,25 @@ def _net2_stream(device):
 
 def join_networks():
     """after a run of coteach_step(..., pipeline=True): order the caller's stream behind network 2's stream (its last
-    backward pass and optimizer step) before anything else touches network 2 -- evaluation, checkpoints, .item() on its state"""
+    backward pass and optimizer step) before anything else touches network 2.  Forwards of network 2 (evaluation) and its
+    `state_dict()` (checkpoints) do this by themselves -- the engine orders a forward issued on another stream behind the
+    pending one, a state-dict pre-hook joins -- so the explicit call is only needed before raw reads of its parameters
+    (`p.data`, `.item()` on a buffer)."""
     for dev, s in _NET2_STREAM.items():
         torch.cuda.current_stream(dev).wait_stream(s)
+
+
+def _guard_pipelined(net, stream):
+    """network `net` keeps its backward pass / optimizer step on `stream` past the end of coteach_step: mark its engine (a
+    forward on any other stream waits first) and make state_dict() join"""
+    net.engine.pending_stream = stream
+    if not getattr(net, '_aide_join_hook', False):
+        def _join(module, prefix, keep_vars):
+            s = module.engine.pending_stream
+            if s is not None:
+                torch.cuda.current_stream(s.device).wait_stream(s)
+        net.register_state_dict_pre_hook(_join)
+        net._aide_join_hook = True
 
 
 def coteach_step(net1, net2, opt1, opt2, loss_op, inphase, outphase, aug_pairs, targets1, targets2, rate,
@@ -127,6 +143,7 @@ def coteach_step(net1, net2, opt1, opt2, loss_op, inphase, outphase, aug_pairs, 
         with torch.cuda.stream(s2):                               # (autograd's end-of-pass join then lands on s2, not on cur)
             loss2.backward()
             opt2.step()
+        _guard_pipelined(net2, s2)
     else:
         loss2.backward()                                          # (network 2's node runs on the stream of its forward)
         if two:

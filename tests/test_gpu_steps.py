@@ -198,6 +198,38 @@ def test_coteaching_two_streams_is_bit_identical(dev):
         assert all(torch.equal(x, y) for x, y in zip(res[False][2], res[other][2]))
 
 
+def test_pipelined_network2_reads_join_by_themselves(dev):
+    """coteach_step(pipeline=True) returns with network 2's backward pass and optimizer step still running on its own stream
+    (round-4 advisor finding: every caller had to remember join_networks()).  A forward of network 2 on the caller's stream
+    and its state_dict() now order themselves behind that stream: what they see equals what a full device synchronisation
+    shows afterwards."""
+    from aide_amd.models_twomodalinputs import fuseunet
+    from aide_amd.optim import Adam
+    from aide_amd.utils import CoTeachingProposedLoss
+    from aide_amd.train_files import trainchaos_proposed_30cases1labeled as M
+    fx = np.load(os.path.join(GOLD, 'g4_proposed.npz'))
+    T = lambda k: torch.from_numpy(fx[k]).to(dev)
+    augs = [(T('aug%d_in' % i), T('aug%d_out' % i)) for i in range(4)]
+    torch.manual_seed(2)
+    n1, n2 = fuseunet(2).to(dev), fuseunet(2).to(dev)
+    n1.train(); n2.train()
+    o1, o2 = Adam(n1.parameters(), lr=1e-3, amsgrad=True), Adam(n2.parameters(), lr=1e-3, amsgrad=True)
+    op = CoTeachingProposedLoss(cediceweight=[1.0, 1.0], ceclassweight=[1.0, 1.0], segcor_weight=[1.0, 10.0])
+    for _ in range(3):
+        M.coteach_step(n1, n2, o1, o2, op, T('xin'), T('xout'), augs, T('t1'), T('t2'), 0.25, pipeline=True)
+    assert n2.engine.pending_stream is not None
+    early = {k: v.clone() for k, v in n2.state_dict().items()}          # no join_networks(), no synchronize
+    n2.eval()
+    with torch.no_grad():
+        out_early = n2(T('xin'), T('xout')).clone()                       # a forward on the caller's stream
+    torch.cuda.synchronize()
+    late = n2.state_dict()
+    assert all(torch.equal(early[k], late[k]) for k in late), 'state_dict() read network 2 before its optimizer step had finished'
+    with torch.no_grad():
+        assert torch.equal(out_early, n2(T('xin'), T('xout')))
+    assert n2.engine.pending_stream is None
+
+
 def test_cli_smoke(dev, tmp_path):
     """The restated CLI (--model_name / --batch_size as in README.md:32) trains, the loss falls, every epoch evaluates a
     case and the best checkpoint is written in the reference's format ({'net': state_dict, ...}, :329-345) and loads back."""
