@@ -285,3 +285,20 @@ def test_class_weight_host_logic():
         _seg.class_w_array(1.0, 3.0, 3)                                             # a 2-class pair on 3 classes
     with pytest.raises(NotImplementedError):
         _seg.class_weights([1.0] * 9)
+
+
+def test_engine_config_is_per_engine_and_drops_plans():
+    """EngineConfig (net.engine.config): unknown switches raise, assigning a NEW value calls the owner's invalidation hook once,
+    re-assigning the same value does not, the snapshot (part of every launch tape's key) follows, two configs are independent."""
+    from aide_amd.engine import EngineConfig
+    calls = []
+    a, b = EngineConfig(lambda: calls.append('a')), EngineConfig(lambda: calls.append('b'))
+    s0 = a.snapshot()
+    assert s0 == b.snapshot() and len(s0) == len(EngineConfig.DEFAULTS)
+    a.use_winograd = False
+    a.use_winograd = False
+    assert calls == ['a'] and a.snapshot() != s0 and b.snapshot() == s0 and b.use_winograd is True
+    a.use_winograd = True
+    assert calls == ['a', 'a'] and a.snapshot() == s0
+    with pytest.raises(AttributeError, match='no switch'):
+        a.use_winogard = False
