@@ -13,6 +13,7 @@
 // Reductions: fp64 accumulation per thread -> fixed-order tree -> per-(channel,split) partials ->
 // finalize in channel order.  No atomics: results are bit-reproducible run to run.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -61,6 +62,15 @@ template <int V> __device__ __forceinline__ void stv(bf16_t* p, const float (&o)
     } else if constexpr (V == 4) { *reinterpret_cast<u32x2*>(p) = u32x2{bn_pk_bf16(o[0], o[1]), bn_pk_bf16(o[2], o[3])}; }
     else { p[0] = (bf16_t)(bn_pk_bf16(o[0], 0.f) & 0xffffu); }
 }
+
+// Workspace (aide_bn_ws_bytes): one block of BN_WS_STRIDE doubles per channel, at the same address whatever the C of the call
+// (an engine shares one workspace between its layers): [0] epoch (int64: generations completed on this channel), [1] broadcast
+// values (two floats), [2] broadcast generation (int64), then BN_SLOTS slots of {v0, v1, v2, generation (int64)}.
+constexpr int BN_SLOTS = 256, BN_WS_HDR = 8, BN_WS_STRIDE = BN_WS_HDR + 4 * BN_SLOTS;
+__device__ __forceinline__ double* ws_chan(double* ws, int c) { return ws + (long)c * BN_WS_STRIDE; }
+__device__ __forceinline__ const double* ws_chan(const double* ws, int c) { return ws + (long)c * BN_WS_STRIDE; }
+__device__ __forceinline__ double* ws_slot(double* ws, int c, int slot) { return ws_chan(ws, c) + BN_WS_HDR + 4 * slot; }
+__device__ __forceinline__ const double* ws_slot(const double* ws, int c, int slot) { return ws_chan(ws, c) + BN_WS_HDR + 4 * slot; }
 
 // Cursor over the V-element units [beg, end) of one channel of an [N][C][HW] tensor, stride 256 units per step:
 // (image, unit inside the plane) advance incrementally -- a 64-bit `i / hw4` per step cost more than the arithmetic
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const ZT* __restrict__ z,
     const int c = blockIdx.x % C, s = blockIdx.x / C;
     // blockIdx.y: group of a stacked batch (aide_bn_train_fwd_groups; N = images per group, a plain launch has one group)
     const int n0 = blockIdx.y * N;
-    partials += (long)blockIdx.y * C * splits * 2;
+    const int slot0 = blockIdx.y * splits;         // partials: slot group * splits + s of the channel's workspace block
     const long total4 = (long)N * HW / V;
     const long per = (total4 + splits - 1) / splits;
     const long beg = s * per, end = min(beg + per, total4);
@@ -145,8 +155,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const ZT* __restrict__ z,
     }
     block_sum_d<2>(acc, sm);
     if (threadIdx.x == 0) {
-        partials[((long)c * splits + s) * 2 + 0] = acc[0];
-        partials[((long)c * splits + s) * 2 + 1] = acc[1];
+        ws_slot(partials, c, slot0 + s)[0] = acc[0];
+        ws_slot(partials, c, slot0 + s)[1] = acc[1];
     }
 }
 
@@ -188,8 +198,8 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(
                     ss += (double)v[1];
                 }
             } else if ((int)threadIdx.x < splits) {
-                s = partials[(((long)gi * C + c) * splits + threadIdx.x) * 2 + 0];
-                ss = partials[(((long)gi * C + c) * splits + threadIdx.x) * 2 + 1];
+                s = ws_slot(partials, c, gi * splits + threadIdx.x)[0];
+                ss = ws_slot(partials, c, gi * splits + threadIdx.x)[1];
             }
             s = wave_sum_d(s);
             ss = wave_sum_d(ss);
@@ -352,9 +362,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const GT* __restrict
     }
     block_sum_d<3>(acc, sm);
     if (threadIdx.x == 0) {
-        partials[((long)c * splits + s) * 3 + 0] = acc[0];
-        partials[((long)c * splits + s) * 3 + 1] = acc[1];
-        partials[((long)c * splits + s) * 3 + 2] = acc[2];
+        ws_slot(partials, c, s)[0] = acc[0];
+        ws_slot(partials, c, s)[1] = acc[1];
+        ws_slot(partials, c, s)[2] = acc[2];
     }
 }
 
@@ -381,9 +391,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const GT* __restrict_
     if (threadIdx.x < 64) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         if ((int)threadIdx.x < splits) {
-            a0 = partials[((long)c * splits + threadIdx.x) * 3 + 0];
-            a1 = partials[((long)c * splits + threadIdx.x) * 3 + 1];
-            a2 = partials[((long)c * splits + threadIdx.x) * 3 + 2];
+            a0 = ws_slot(partials, c, threadIdx.x)[0];
+            a1 = ws_slot(partials, c, threadIdx.x)[1];
+            a2 = ws_slot(partials, c, threadIdx.x)[2];
         }
         a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2);
         if (threadIdx.x == 0) {
@@ -421,141 +431,355 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const GT* __restrict_
     }
 }
 
-// ---------------------------------------------------------------- small planes: one kernel per direction
-// When a channel holds <= 16384 values (the 64x64 ... 16x16 levels at N = 4) one workgroup owns the whole channel:
-// the values are read ONCE into registers (<= 16 float4 per thread), reduced in fp64 in a fixed order, and
-// normalised from the registers.  Saves a launch (~4.5 us) and one pass over the tensor per BatchNorm and direction.
-constexpr int BN_FQ = 16;
-template <typename ZT, typename AT, bool SLABS>
-__global__ __launch_bounds__(256) void bn_train_fused_kernel(
-    const ZT* __restrict__ z, long z_bs, AT* __restrict__ a, long a_bs, int N, int HW, double count,
+// ---------------------------------------------------------------- one pass, several workgroups per channel
+// Every channel is owned by S workgroups (blockIdx = c * S + s): each reads its share of the channel ONCE into registers
+// (Q units of V values per thread, all loads in flight at once) and reduces it to fp64 partial sums.  Workgroup s > 0 hands
+// its partials to the channel's LEADER (s = 0) and waits for the coefficients; the leader sums the S partials in slot order
+// (bit-reproducible: no dependence on arrival order), finishes the statistics and broadcasts the two coefficients every
+// workgroup needs; all of them normalise from their registers.  Forward 8 B / element instead of 12 (statistics pass + apply
+// pass), backward 12 instead of 20, one launch per direction -- and S x the workgroups of the round-5
+// one-workgroup-per-channel kernels, which left half of the chip idle at C = 128 and ran at 0.2 of the HBM roofline.
+//
+// The exchange uses no read-modify-write atomics and no cache maintenance (both measured: a counter per channel cost 0.5-1 us
+// per arrival -- same-address device-scope atomics serialise at the memory side -- and an agent-scope release / acquire pair
+// per workgroup writes back / invalidates the XCD's whole L2: the C = 32 @256x256 forward took 106 us and 262 us).  Partials,
+// generation flags and the broadcast move with agent-scope RELAXED atomic stores and loads (sc1: performed at the
+// device-coherent level, past the per-XCD L2s); "payload, then flag" is the order of ONE thread's own stores with
+// s_waitcnt vmcnt(0) between them (a store is counted until the level it was sent to acknowledges it), and a reader loads the
+// payload after the flag's value came back.  Generations: every channel has an epoch in the workspace that only its leader
+// advances (by `groups` per launch); a flag or broadcast is valid when it carries exactly the generation the launch expects,
+// so nothing is ever reset and stale entries of earlier launches (any S, any C) can never match.  The workspace must be
+// zero-filled once and used by one stream at a time.
+//
+// The waits cannot deadlock: the partners of a workgroup are its index neighbours (< S apart), the hardware dispatches
+// workgroups in index order, so the oldest waiting group's missing members are next in line on their XCDs and only workgroups
+// of older (never waiting) groups are ahead of them.  The spins are bounded anyway: a wait that runs out poisons the result
+// with NaN instead of hanging the queue.
+constexpr int BN_MAX_S = BN_SLOTS;
+constexpr int BN_SPIN_LIMIT = 1 << 21;
+
+__device__ __forceinline__ void coop_store(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coop_store_i(double* p, long long v) {
+    __hip_atomic_store(reinterpret_cast<long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double coop_load(const double* p) {
+    return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ long long coop_load_i(const double* p) {
+    return __hip_atomic_load(reinterpret_cast<const long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coop_fence() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ bool coop_wait(const double* flag, long long gen) {
+    for (int spins = 0; spins < BN_SPIN_LIMIT; ++spins) {
+        if (coop_load_i(flag) == gen) {
+            asm volatile("" ::: "memory");
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return false;
+}
+// One generation of the exchange.  In: thread 0 of every workgroup holds its NV partial sums in acc.  Out (leader): thread 0
+// holds the channel totals in acc and returns true from is_leader(); the leader then calls coop_publish(v0, v1), the others
+// coop_receive(v0, v1) (thread 0 each).  `ok` turns false when a bounded wait ran out.
+template <int NV>
+__device__ __forceinline__ void coop_gather(double* ws, int c, int s, int S, long long gen, double (&acc)[NV], double* sm, int* okf) {
+    if (s != 0) {
+        if (threadIdx.x == 0) {
+            double* slot = ws_slot(ws, c, s);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) coop_store(slot + i, acc[i]);
+            coop_fence();
+            coop_store_i(slot + 3, gen);
+        }
+        return;
+    }
+    // leader: thread t collects slot t (its own partials stand in for slot 0); totals in slot order
+    __syncthreads();                            // (thread 0 is done with sm from the block sum that produced acc)
+    double t[NV];
+    bool ok = true;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) t[i] = acc[i];
+    } else if ((int)threadIdx.x < S) {
+        const double* slot = ws_slot(ws, c, threadIdx.x);
+        ok = coop_wait(slot + 3, gen);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) t[i] = coop_load(slot + i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) t[i] = 0.0;
+    }
+    if (!ok) *okf = 0;                          // (benign race: every writer stores 0)
+    block_sum_d<NV>(t, sm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = t[i];
+    }
+}
+__device__ __forceinline__ void coop_publish(double* ws, int c, long long gen, float v0, float v1) {
+    double* h = ws_chan(ws, c);
+    coop_store(h + 1, __builtin_bit_cast(double, f32x2{v0, v1}));
+    coop_fence();
+    coop_store_i(h + 2, gen);
+}
+__device__ __forceinline__ bool coop_receive(const double* ws, int c, long long gen, float& v0, float& v1) {
+    const double* h = ws_chan(ws, c);
+    const bool ok = coop_wait(h + 2, gen);
+    const f32x2 v = __builtin_bit_cast(f32x2, coop_load(h + 1));
+    v0 = v[0]; v1 = v[1];
+    return ok;
+}
+
+// Q units of V values of slab-resident data: all Q loads of a slab in flight together, slabs in order s = 0, 1, ...
+template <int V, int Q>
+__device__ __forceinline__ void slab_sum_q(const SlabSrc& sl, const long (&off)[Q], const bool (&on)[Q], int c, float (&o)[Q][V]) {
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        if (on[k]) ldv<V>(sl.slabs + off[k], o[k]);
+        else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[k][e] = 0.f;
+        }
+    }
+#pragma unroll(Q <= 2 ? 2 : 1)
+    for (int s = 1; s < sl.splitk; ++s) {
+        float t[Q][V];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) if (on[k]) ldv<V>(sl.slabs + (long)s * sl.split_stride + off[k], t[k]);
+#pragma unroll
+        for (int k = 0; k < Q; ++k) if (on[k]) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[k][e] += t[k][e];
+        }
+    }
+    if (sl.bias) {
+        const float b = sl.bias[c];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) if (on[k]) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[k][e] += b;
+        }
+    }
+}
+
+template <int V, int Q, typename ZT, typename AT, bool SLABS>
+__global__ __launch_bounds__(256) void bn_fwd_coop_kernel(
+    const ZT* __restrict__ z, long z_bs, AT* __restrict__ a, long a_bs, int N, int C, int HW, int S, int per, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ scale_out,
-    float* __restrict__ shift_out, int relu, const SlabSrc sl, int groups) {
+    float* __restrict__ shift_out, int relu, const SlabSrc sl, int groups, double* __restrict__ ws) {
     __shared__ double sm[2 * 4];
     __shared__ float coef[2];
-    const int c = blockIdx.x, hw4 = HW / 4, total4 = N * hw4;
-    // groups > 1 (aide_bn_train_fwd_groups): the stacked batch holds `groups` runs of N images; the channel's block takes
-    // them one after the other -- statistics, running-statistics update and normalisation per group, in order
+    __shared__ int okf;
+    const int c = blockIdx.x / S, s = blockIdx.x - c * S;
+    const int hwv = HW / V, total = N * hwv;
+    const int beg = s * per, end = min(beg + per, total);
+    __shared__ long long e0s;
+    if (threadIdx.x == 0) {
+        okf = 1;
+        e0s = S > 1 ? coop_load_i(ws_chan(ws, c)) : 0;        // generations completed on this channel before this launch
+    }
+    int nn[Q], pp[Q];
+    bool on[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const int u = beg + (int)threadIdx.x + k * 256;
+        on[k] = u < end;
+        nn[k] = on[k] ? u / hwv : 0;
+        pp[k] = on[k] ? (u - nn[k] * hwv) * V : 0;
+    }
     for (int gi = 0; gi < groups; ++gi) {
         const long n0 = (long)gi * N;
-        f32x4 v[BN_FQ];
-        double acc[2] = {0.0, 0.0};
+        float v[Q][V];
+        if constexpr (SLABS) {
+            long off[Q];
 #pragma unroll
-        for (int k = 0; k < BN_FQ; ++k) {
-            const int i = threadIdx.x + k * 256;
-            v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i < total4) {
-                const int n = i / hw4, p = i - n * hw4;
-                float t4[4];
-                if constexpr (SLABS) {
-                    slab_sum<4>(sl, (n0 + n) * sl.slab_bs + (long)c * HW + p * 4, c, t4);
-                    stv<4>(const_cast<ZT*>(z) + (n0 + n) * z_bs + (long)c * HW + p * 4, t4);
+            for (int k = 0; k < Q; ++k) off[k] = (n0 + nn[k]) * sl.slab_bs + (long)c * HW + pp[k];
+            slab_sum_q<V, Q>(sl, off, on, c, v);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) t4[e] = as_stored(t4[e], (const ZT*)nullptr);
-                } else {
-                    ldv<4>(z + (n0 + n) * z_bs + (long)c * HW + p * 4, t4);
+            for (int k = 0; k < Q; ++k) if (on[k]) {
+                stv<V>(const_cast<ZT*>(z) + (n0 + nn[k]) * z_bs + (long)c * HW + pp[k], v[k]);
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[k][e] = as_stored(v[k][e], (const ZT*)nullptr);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                if (on[k]) ldv<V>(z + (n0 + nn[k]) * z_bs + (long)c * HW + pp[k], v[k]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) v[k][e] = 0.f;
                 }
-                v[k] = f32x4{t4[0], t4[1], t4[2], t4[3]};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const double d = (double)v[k][e]; acc[0] += d; acc[1] += d * d; }
             }
         }
-        if (gi > 0) __syncthreads();          // (the previous group's readers of sm / coef are done)
+        double acc[2] = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) { const double d = (double)v[k][e]; acc[0] += d; acc[1] = fma(d, d, acc[1]); }
+        }
         block_sum_d<2>(acc, sm);
+        const long long e0 = e0s, gen = e0 + 1 + gi;          // (every thread: block_sum_d synchronised behind thread 0's store)
+        if (S > 1) coop_gather<2>(ws, c, s, S, gen, acc, sm, &okf);
         if (threadIdx.x == 0) {
-            const double mean = acc[0] / count;
-            double var = acc[1] / count - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-            const float g = gamma ? gamma[c] : 1.0f, bb = beta ? beta[c] : 0.0f;
-            const float sc = g * rstd, sh = bb - (float)mean * sc;
-            coef[0] = sc; coef[1] = sh;
-            if (gi == groups - 1) { mean_out[c] = (float)mean; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh; }
-            if (running_mean) {
-                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
-                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+            if (s == 0) {
+                const double mean = acc[0] / count;
+                double var = acc[1] / count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+                const float g = gamma ? gamma[c] : 1.0f, bb = beta ? beta[c] : 0.0f;
+                const float sc = okf ? g * rstd : __builtin_nanf(""), sh = bb - (float)mean * sc;
+                coef[0] = sc; coef[1] = sh;
+                if (S > 1) coop_publish(ws, c, gen, sc, sh);
+                if (gi == groups - 1) { mean_out[c] = (float)mean; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh; }
+                if (running_mean) {
+                    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+                    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+                }
+                if (c == 0 && nbt) *nbt += 1;
+            } else {
+                float sc, sh;
+                if (!coop_receive(ws, c, gen, sc, sh)) sc = sh = __builtin_nanf("");
+                coef[0] = sc; coef[1] = sh;
             }
-            if (c == 0 && nbt) *nbt += 1;
         }
         __syncthreads();
         const float sc = coef[0], sh = coef[1];
 #pragma unroll
-        for (int k = 0; k < BN_FQ; ++k) {
-            const int i = threadIdx.x + k * 256;
-            if (i < total4) {
-                const int n = i / hw4, p = i - n * hw4;
-                float o[4];
+        for (int k = 0; k < Q; ++k) if (on[k]) {
+            float o[V];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float y = fmaf(v[k][e], sc, sh); o[e] = relu ? fmaxf(y, 0.0f) : y; }
-                stv<4>(a + (n0 + n) * a_bs + (long)c * HW + p * 4, o);
-            }
+            for (int e = 0; e < V; ++e) { const float y = fmaf(v[k][e], sc, sh); o[e] = relu ? fmaxf(y, 0.0f) : y; }
+            stv<V>(a + (n0 + nn[k]) * a_bs + (long)c * HW + pp[k], o);
         }
     }
+    if (S > 1 && s == 0 && threadIdx.x == 0) coop_store_i(ws_chan(ws, c), e0s + groups);
 }
 
 // SLABS: dA is still in the split-K slabs of the data-gradient convolution that produced it ([split][N][C][HW], fp32):
 // the kernel sums them itself in the order of the split reduce (s = 0, 1, ...) -- that launch and its pass disappear.
-template <typename ZT, typename DT, typename GT, bool SLABS = false>
-__global__ __launch_bounds__(256) void bn_bwd_fused_kernel(
-    const GT* __restrict__ dA, long d_bs, const ZT* __restrict__ z, long z_bs, DT* __restrict__ dz,
-    long dz_bs, int N, int HW, double count, const float* __restrict__ mean, const float* __restrict__ rstd,
+template <int V, int Q, typename ZT, typename DT, typename GT, bool SLABS>
+__global__ __launch_bounds__(256) void bn_bwd_coop_kernel(
+    const GT* __restrict__ dA, long d_bs, const ZT* __restrict__ z, long z_bs, DT* __restrict__ dz, long dz_bs, int N, int C,
+    int HW, int S, int per, double count, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ scale, const float* __restrict__ shift, int relu, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, float* __restrict__ dbias, const SlabSrc sl) {
+    float* __restrict__ dbeta, float* __restrict__ dbias, const SlabSrc sl, double* __restrict__ ws) {
     __shared__ double sm[3 * 4];
     __shared__ float coef[2];
-    const int c = blockIdx.x, hw4 = HW / 4, total4 = N * hw4;
+    __shared__ int okf;
+    const int c = blockIdx.x / S, s = blockIdx.x - c * S;
+    const int hwv = HW / V, total = N * hwv;
+    const int beg = s * per, end = min(beg + per, total);
+    __shared__ long long e0s;
+    if (threadIdx.x == 0) {
+        okf = 1;
+        e0s = S > 1 ? coop_load_i(ws_chan(ws, c)) : 0;
+    }
     const float mu = mean[c], rs = rstd[c], sc = scale[c], sh = shift[c];
-    f32x4 dy[BN_FQ], xh[BN_FQ];
-    double acc[3] = {0.0, 0.0, 0.0};
+    int nn[Q], pp[Q];
+    bool on[Q];
 #pragma unroll
-    for (int k = 0; k < BN_FQ; ++k) {
-        const int i = threadIdx.x + k * 256;
-        dy[k] = f32x4{0.f, 0.f, 0.f, 0.f}; xh[k] = dy[k];
-        if (i < total4) {
-            const int n = i / hw4, p = i - n * hw4;
-            float zv[4];
-            ldv<4>(z + (long)n * z_bs + (long)c * HW + p * 4, zv);
-            float dv[4];
-            if (SLABS) slab_sum<4>(sl, (long)n * sl.slab_bs + (long)c * HW + p * 4, c, dv);
-            else ldv<4>(dA + (long)n * d_bs + (long)c * HW + p * 4, dv);
+    for (int k = 0; k < Q; ++k) {
+        const int u = beg + (int)threadIdx.x + k * 256;
+        on[k] = u < end;
+        nn[k] = on[k] ? u / hwv : 0;
+        pp[k] = on[k] ? (u - nn[k] * hwv) * V : 0;
+    }
+    float dy[Q][V], xh[Q][V];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool on = !relu || fmaf(zv[e], sc, sh) > 0.0f;
-                dy[k][e] = on ? dv[e] : 0.0f;
-                xh[k][e] = (zv[e] - mu) * rs;
-                acc[0] += (double)dy[k][e];
-                acc[1] += (double)dy[k][e] * (double)xh[k][e];
-                acc[2] += (double)xh[k][e];
+    for (int k = 0; k < Q; ++k) {
+        if (on[k]) ldv<V>(z + (long)nn[k] * z_bs + (long)c * HW + pp[k], xh[k]);
+        else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) xh[k][e] = 0.f;
+        }
+    }
+    if constexpr (SLABS) {
+        long off[Q];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) off[k] = (long)nn[k] * sl.slab_bs + (long)c * HW + pp[k];
+        slab_sum_q<V, Q>(sl, off, on, c, dy);
+    } else {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            if (on[k]) ldv<V>(dA + (long)nn[k] * d_bs + (long)c * HW + pp[k], dy[k]);
+            else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) dy[k][e] = 0.f;
             }
         }
     }
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float zv = xh[k][e];
+            const bool live = on[k] && (!relu || fmaf(zv, sc, sh) > 0.0f);
+            dy[k][e] = live ? dy[k][e] : 0.0f;
+            xh[k][e] = on[k] ? (zv - mu) * rs : 0.0f;
+            acc[0] += (double)dy[k][e];
+            acc[1] = fma((double)dy[k][e], (double)xh[k][e], acc[1]);
+            acc[2] += (double)xh[k][e];
+        }
+    }
     block_sum_d<3>(acc, sm);
+    const long long e0 = e0s;
+    if (S > 1) coop_gather<3>(ws, c, s, S, e0 + 1, acc, sm, &okf);
     if (threadIdx.x == 0) {
-        const float c0f = (float)(acc[0] / count), c1f = (float)(acc[1] / count);
-        coef[0] = c0f; coef[1] = c1f;
-        if (dbeta) dbeta[c] = (float)acc[0];
-        if (dgamma) dgamma[c] = (float)acc[1];
-        if (dbias) dbias[c] = (float)((double)sc * ((acc[0] - count * (double)c0f) - (double)c1f * acc[2]));
+        if (s == 0) {
+            const float c0f = okf ? (float)(acc[0] / count) : __builtin_nanf(""), c1f = (float)(acc[1] / count);
+            coef[0] = c0f; coef[1] = c1f;
+            if (S > 1) coop_publish(ws, c, e0 + 1, c0f, c1f);
+            if (dbeta) dbeta[c] = (float)acc[0];
+            if (dgamma) dgamma[c] = (float)acc[1];
+            if (dbias) dbias[c] = (float)((double)sc * ((acc[0] - count * (double)c0f) - (double)c1f * acc[2]));
+        } else {
+            float c0f, c1f;
+            if (!coop_receive(ws, c, e0 + 1, c0f, c1f)) c0f = c1f = __builtin_nanf("");
+            coef[0] = c0f; coef[1] = c1f;
+        }
     }
     __syncthreads();
     const float c0 = coef[0], c1 = coef[1];
 #pragma unroll
-    for (int k = 0; k < BN_FQ; ++k) {
-        const int i = threadIdx.x + k * 256;
-        if (i < total4) {
-            const int n = i / hw4, p = i - n * hw4;
-            float o[4];
+    for (int k = 0; k < Q; ++k) if (on[k]) {
+        float o[V];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = sc * (dy[k][e] - c0 - xh[k][e] * c1);
-            stv<4>(dz + (long)n * dz_bs + (long)c * HW + p * 4, o);
-        }
+        for (int e = 0; e < V; ++e) o[e] = sc * (dy[k][e] - c0 - xh[k][e] * c1);
+        stv<V>(dz + (long)nn[k] * dz_bs + (long)c * HW + pp[k], o);
     }
+    if (S > 1 && s == 0 && threadIdx.x == 0) coop_store_i(ws_chan(ws, c), e0 + 1);
 }
 
-__host__ inline bool bn_fused_ok(int N, int C, int HW) { return (long)N * HW <= 256L * BN_FQ * 4 && C >= 64; }
+// which one-pass instantiation covers a channel of N * HW values: units of V values, Q per thread, S workgroups per channel.
+// V = 8 whenever the plane and every batch stride are multiples of 8 -- whatever the storage types, so that the bf16-stored
+// and the fp32-stored call partition the channel identically (bit-identical statistics) -- else V = 4.
+struct CoopPlan { int V, Q, S, per; };
+constexpr int BN_COOP_MIN_WGS = 1024;          // workgroups a launch should have before a thread takes more than 8 values
+__host__ inline bool coop_plan(int N, int C, int HW, bool mod8, CoopPlan& p) {
+    p.V = (mod8 && HW % 8 == 0) ? 8 : 4;
+    if (HW % p.V || (long)N * HW / p.V > (long)BN_MAX_S * 256 * 8) return false;
+    const int units = N * HW / p.V;
+    int q = 16 / p.V, s = (units + 256 * q - 1) / (256 * q);           // 16 values per thread ...
+    while (s > BN_MAX_S && q < 8) { q <<= 1; s = (units + 256 * q - 1) / (256 * q); }
+    if (s > BN_MAX_S) return false;
+    while (q > 1 && C * s < BN_COOP_MIN_WGS && s * 2 <= BN_MAX_S) { q >>= 1; s = (units + 256 * q - 1) / (256 * q); }   // ... fewer while the launch is small
+    p.S = s;
+    p.per = (units + s - 1) / s;
+    const int need = (p.per + 255) / 256;
+    p.Q = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
+    return true;
+}
+// (the stacked passes and the conv-epilogue statistics keep their round-5 meaning of "small plane": see aide_bn_two_pass)
+__host__ inline bool bn_fused_ok(int N, int C, int HW) { return (long)N * HW <= 256L * 16 * 4 && C >= 64; }
 
 int pick_splits(int N, int C, int HW) {
     const long total4 = (long)N * HW / ((HW % 4 == 0) ? 4 : 1);
@@ -572,7 +796,8 @@ int pick_splits(int N, int C, int HW) {
 extern "C" {
 
 // workspace doubles needed by the BN kernels for a C-channel tensor
-size_t aide_bn_ws_bytes(int C) { return (size_t)C * 64 * 3 * sizeof(double); }
+// (one block of BN_WS_STRIDE doubles per channel: see the top of this file).  ZERO-FILLED once by the caller.
+size_t aide_bn_ws_bytes(int C) { return (size_t)C * BN_WS_STRIDE * sizeof(double); }
 
 }  // extern "C"
 
@@ -590,17 +815,28 @@ int bn_train_fwd_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C,
     const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && a_bs % 4 == 0;
     if (SLABS && (!sl.slabs || sl.splitk < 1 || !v4)) return AIDE_ERR_ARG;
     int splits = pick_splits(N, C, HW);
-    if (groups > 1 && splits > 96 / groups) splits = 96 / groups > 0 ? 96 / groups : 1;   // partials [group][C][splits][2] in C * 192 doubles
+    if (groups > 1 && splits > 96 / groups) splits = 96 / groups > 0 ? 96 / groups : 1;   // partials: slots group * splits + s of a channel's block
     if ((long)groups * splits > 96) return AIDE_ERR_ARG;
     double* partials = (double*)ws;
     const double count = (double)N * HW;
     const int gx = max(1, min((HW / (v4 ? 4 : 1) + 255) / 256, 16));
     const int NT = N * groups;
-    if (v4 && bn_fused_ok(N, C, HW)) {
-        hipLaunchKernelGGL((bn_train_fused_kernel<ZT, AT, SLABS>), dim3(C), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, N, HW, count,
-                           gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd,
-                           scale, shift, relu, sl, groups);
-        return aide_launch_status();
+    // one pass, S workgroups per channel (all BASELINE shapes); the two-pass kernels below remain for planes that are not a
+    // multiple of 4 values and for channels beyond BN_MAX_S * 2048 units
+    {
+        CoopPlan cp;
+        if (v4 && coop_plan(N, C, HW, z_bs % 8 == 0 && a_bs % 8 == 0 && (!SLABS || sl.split_stride % 8 == 0), cp)) {
+#define AIDE_BN_FC(VV, QQ)                                                                                                    \
+            hipLaunchKernelGGL((bn_fwd_coop_kernel<VV, QQ, ZT, AT, SLABS>), dim3(C * cp.S), dim3(256), 0, stream, z,          \
+                               (long)z_bs, a, (long)a_bs, N, C, HW, cp.S, cp.per, count, gamma, beta, eps, momentum,          \
+                               running_mean, running_var, num_batches_tracked, mean, rstd, scale, shift, relu, sl, groups,    \
+                               (double*)ws)
+#define AIDE_BN_FQ(VV) do { if (cp.Q == 1) AIDE_BN_FC(VV, 1); else if (cp.Q == 2) AIDE_BN_FC(VV, 2); else if (cp.Q == 4) AIDE_BN_FC(VV, 4); else AIDE_BN_FC(VV, 8); } while (0)
+            if (cp.V == 8) AIDE_BN_FQ(8); else AIDE_BN_FQ(4);
+#undef AIDE_BN_FQ
+#undef AIDE_BN_FC
+            return aide_launch_status();
+        }
     }
     // 8 values per lane: 16-byte accesses for the bf16-stored tensors of the precision='bf16' mode
     // (for every storage type: the bf16-storage kernels stay bit-identical to the fp32-storage ones on the widened tensor)
@@ -647,10 +883,19 @@ int bn_relu_bwd_t(const GT* dA, int64_t d_bs, const ZT* z, int64_t z_bs, DT* dz,
     const int splits = pick_splits(N, C, HW);
     double* partials = (double*)ws;
     const double count = (double)N * HW;
-    if (v4 && bn_fused_ok(N, C, HW)) {
-        AIDE_LAUNCH_DONE(done, (bn_bwd_fused_kernel<ZT, DT, GT>), dim3(C), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs,
-                         N, HW, count, mean, rstd, scale, shift, relu, dgamma, dbeta, dbias, SlabSrc{});
-        return aide_launch_status();
+    {
+        CoopPlan cp;
+        if (v4 && coop_plan(N, C, HW, z_bs % 8 == 0 && d_bs % 8 == 0 && dz_bs % 8 == 0, cp)) {
+#define AIDE_BN_BC(VV, QQ)                                                                                                    \
+            AIDE_LAUNCH_DONE(done, (bn_bwd_coop_kernel<VV, QQ, ZT, DT, GT, false>), dim3(C * cp.S), dim3(256), 0,              \
+                             stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, cp.S, cp.per, count, mean,     \
+                             rstd, scale, shift, relu, dgamma, dbeta, dbias, SlabSrc{}, (double*)ws)
+#define AIDE_BN_BQ(VV) do { if (cp.Q == 1) AIDE_BN_BC(VV, 1); else if (cp.Q == 2) AIDE_BN_BC(VV, 2); else if (cp.Q == 4) AIDE_BN_BC(VV, 4); else AIDE_BN_BC(VV, 8); } while (0)
+            if (cp.V == 8) AIDE_BN_BQ(8); else AIDE_BN_BQ(4);
+#undef AIDE_BN_BQ
+#undef AIDE_BN_BC
+            return aide_launch_status();
+        }
     }
     const bool v8 = v4 && HW % 8 == 0 && z_bs % 8 == 0 && d_bs % 8 == 0 && dz_bs % 8 == 0;
     if (v8) {
@@ -750,6 +995,13 @@ int aide_bn_train_fwd_parts_strided(const void* z, int z_bf16, int64_t z_bs, voi
 // statistics save a launch
 int aide_bn_two_pass(int N, int C, int H, int W) { return bn_fused_ok(N, C, H * W) ? 0 : 1; }
 
+// does the one-pass form (S workgroups per channel, values held in registers) cover a channel of N * H * W values?
+// (batch strides that are multiples of 8 elements assumed when H * W is)
+int aide_bn_one_pass(int N, int C, int H, int W) {
+    CoopPlan cp;
+    return coop_plan(N, C, H * W, true, cp) ? 1 : 0;
+}
+
 // BatchNorm(train) WITHOUT its pass over z: from the conv epilogue's statistics of a stacked batch (parts as in
 // aide_bn_train_fwd_groups) to the per-group (scale, shift) table tab[groups][tab_C][2], entries [tab_c0, tab_c0 + C), that
 // the consumer convolution's loader applies (in_bn_tab of aide_conv3x3_wino4), plus the running-statistics updates of
@@ -821,19 +1073,26 @@ int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void
 }
 
 // Backward of relu(bn(z)) with dA taken from the split-K slabs [splitk][N][C][H][W] of the data-gradient convolution that
-// produced it (launched with accumulate = 2).  Small planes only: aide_bn_two_pass(N, C, H, W) == 0.
+// produced it (launched with accumulate = 2).  Shapes of the one-pass form: aide_bn_one_pass(N, C, H, W) == 1.
 int aide_bn_relu_bwd_slabs(const float* slabs, int splitk, int64_t split_stride, const float* z, int64_t z_bs, float* dz,
                            int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                            const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
-                           void* done, hipStream_t stream) {
+                           void* ws, void* done, hipStream_t stream) {
     const int HW = H * W;
-    if (!slabs || splitk < 1 || !z || !dz || HW % 4 || z_bs % 4 || dz_bs % 4 || split_stride % 4 || !bn_fused_ok(N, C, HW))
+    CoopPlan cp;
+    if (!slabs || splitk < 1 || !z || !dz || !ws || HW % 4 || z_bs % 4 || dz_bs % 4 || split_stride % 4 ||
+        !coop_plan(N, C, HW, z_bs % 8 == 0 && dz_bs % 8 == 0 && split_stride % 8 == 0, cp))
         return AIDE_ERR_ARG;
     SlabSrc sl;
     sl.slabs = slabs; sl.bias = nullptr; sl.split_stride = split_stride; sl.slab_bs = (long)C * HW; sl.splitk = splitk;
-    AIDE_LAUNCH_DONE(done, (bn_bwd_fused_kernel<float, float, float, true>), dim3(C), dim3(256), 0, stream, (const float*)nullptr, 0L,
-                     z, (long)z_bs, dz, (long)dz_bs, N, HW, (double)N * HW, mean, rstd, scale, shift, relu, dgamma, dbeta,
-                     dbias, sl);
+#define AIDE_BN_BS(VV, QQ)                                                                                                    \
+    AIDE_LAUNCH_DONE(done, (bn_bwd_coop_kernel<VV, QQ, float, float, float, true>), dim3(C * cp.S), dim3(256), 0, stream,     \
+                     (const float*)nullptr, 0L, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, cp.S, cp.per, (double)N * HW, mean, \
+                     rstd, scale, shift, relu, dgamma, dbeta, dbias, sl, (double*)ws)
+#define AIDE_BN_BQ(VV) do { if (cp.Q == 1) AIDE_BN_BS(VV, 1); else if (cp.Q == 2) AIDE_BN_BS(VV, 2); else if (cp.Q == 4) AIDE_BN_BS(VV, 4); else AIDE_BN_BS(VV, 8); } while (0)
+    if (cp.V == 8) AIDE_BN_BQ(8); else AIDE_BN_BQ(4);
+#undef AIDE_BN_BQ
+#undef AIDE_BN_BS
     return aide_launch_status();
 }
 

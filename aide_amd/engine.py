@@ -537,7 +537,7 @@ class Plan(object):
             if self.grad[id(src.root)].dtype != torch.float32 or prod['z'].dtype != torch.float32:
                 continue
             pn, pc, ph, pw = prod['z'].shape
-            if lib.aide_bn_two_pass(pn, pc, ph, pw) or (ph * pw) % 4:
+            if not lib.aide_bn_one_pass(pn, pc, ph, pw) or (ph * pw) % 4:
                 continue
             st['fold_dgrad'] = True
         self._bwd_ready = True
@@ -1089,7 +1089,7 @@ class Plan(object):
                 done = st['ev'] if (side is not None and not tail_ and self.cfg.handover_on_kernel) else None
                 if folded[0]:                  # dA is still in the split-K slabs of the conv after this one
                     ops.bn_relu_bwd_slabs(sk_ws, folded[0], z, dz, st['mean'], st['rstd'], st['scale'], st['shift'],
-                                          gslot(bn.weight), gslot(bn.bias), gslot(conv.bias), True, done=done)
+                                          gslot(bn.weight), gslot(bn.bias), gslot(conv.bias), bn_ws, True, done=done)
                     folded[0] = 0
                 else:
                     ops.bn_relu_bwd(self.gview(st['dst']), z, dz, st['mean'], st['rstd'], st['scale'],

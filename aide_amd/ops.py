@@ -249,7 +249,8 @@ def convT2x2_wgrad(x, dy, dw, ws=None):
 
 # ------------------------------------------------------------------------------- batch norm
 def bn_ws(c, device):
-    return torch.empty(lib.aide_bn_ws_bytes(c) // 8, device=device, dtype=torch.float64)
+    """workspace of the training-mode BatchNorm calls: zero-filled (arrival counters of the one-pass kernels), one stream at a time"""
+    return torch.zeros((lib.aide_bn_ws_bytes(c) + 7) // 8, device=device, dtype=torch.float64)
 
 
 def bn_train_fwd(z, a, gamma, beta, eps, momentum, running_mean, running_var, nbt, mean, rstd, scale, shift,
@@ -352,14 +353,15 @@ def bn_relu_bwd(dA, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, r
     return dz
 
 
-def bn_relu_bwd_slabs(slabs, splitk, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, relu=True, done=None):
+def bn_relu_bwd_slabs(slabs, splitk, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, relu=True, done=None):
     """bn_relu_bwd whose dA is the split-K slabs [splitk][N][C][H][W] (fp32 tensor `slabs`, at its start) left by the
-    data-gradient convolution (accumulate=2); fp32 z / dz, small planes (lib.aide_bn_two_pass(...) == 0)."""
+    data-gradient convolution (accumulate=2); fp32 z / dz, one-pass shapes (lib.aide_bn_one_pass(n, c, h, w) == 1)."""
     zp, zbs = planes(z)
     dp, dbs = planes(dz)
     n, c, h, w = z.shape
     check(lib.aide_bn_relu_bwd_slabs(ptr(slabs), splitk, n * c * h * w, zp, zbs, dp, dbs, n, c, h, w, ptr(mean), ptr(rstd),
-                                     ptr(scale), ptr(shift), int(relu), ptr(dgamma), ptr(dbeta), ptr(dbias), done, stream_ptr()),
+                                     ptr(scale), ptr(shift), int(relu), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws), done,
+                                     stream_ptr()),
           'bn_relu_bwd_slabs')
     return dz
 

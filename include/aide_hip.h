@@ -156,7 +156,15 @@ int aide_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t d
 
 /* ---- BatchNorm2d (+ReLU) -----------------------------------------------------------------------
  * replaces nn.BatchNorm2d + nn.ReLU: netblocks.py:25,27,28,18 ; UNet.py:20,22,23,13 */
+/* Workspace of the training-mode calls below: ZERO-FILLED once by the caller (it holds the arrival counters of the one-pass
+ * kernels, which every launch leaves at zero) and used by ONE stream at a time. */
 size_t aide_bn_ws_bytes(int C);
+/* 1: a channel of N * H * W values runs in the one-pass form -- S workgroups per channel hold the values in registers, exchange
+ * fp64 partial sums through the workspace (summed in slot order: bit-reproducible) and normalise from the registers: forward
+ * 8 B / element, backward 12, one launch each (units of 8 values when H * W and every batch stride are multiples of 8, whatever
+ * the storage types: a bf16-stored call has the statistics of the fp32-stored call on the widened tensor, bit for bit).
+ * 0: the two-pass fallbacks (planes that are no multiple of 4, channels of more than 2 M values). */
+int aide_bn_one_pass(int N, int C, int H, int W);
 /* Eval-mode BatchNorm folded into the convolution before it (the per-case inference loop,
  * trainchaos_comparison_1case.py:233-273: net.eval(), running statistics): aide_bn_eval_fold also writes
  * fbias = conv_bias * scale + shift; an aide_conv3x3_wino4 or aide_conv3x3_igemm launch given epi_scale = scale,
@@ -171,12 +179,12 @@ int aide_bn_eval_fold(int C, const float* gamma, const float* beta, const float*
  * orders another stream behind dz at ~1.4 us of this queue's time (aide_stream_order: ~5 us; tools/ubench/handover_cost.hip) */
 /* aide_bn_relu_bwd with dA still in the split-K slabs [splitk][N][C][H][W] (fp32, split_stride elements apart) of the
  * data-gradient convolution that produced it (aide_conv3x3_wino4 / aide_conv3x3_wino launched with accumulate = 2): the
- * kernel sums the slabs itself, in the order of the split reduce, so that launch and one pass over dA disappear.  Small
- * planes only (aide_bn_two_pass(N, C, H, W) == 0, where split-K is used); AIDE_ERR_ARG otherwise. */
+ * kernel sums the slabs itself, in the order of the split reduce, so that launch and one pass over dA disappear.  One-pass
+ * shapes only (aide_bn_one_pass(N, C, H, W) == 1); AIDE_ERR_ARG otherwise. */
 int aide_bn_relu_bwd_slabs(const float* slabs, int splitk, int64_t split_stride, const float* z, int64_t z_bs, float* dz,
                            int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                            const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,
-                           void* done, aide_stream_t stream);
+                           void* ws, void* done, aide_stream_t stream);
 /* Training-mode forward a = relu?(bn(z)) (batch statistics, running-statistics update; mean / rstd / scale / shift [C] are kept
  * by the caller for the backward), the plain apply a = relu?(z * scale + shift), and the backward dA -> dz, dgamma, dbeta (+ the
  * mathematically zero conv-bias gradient).  z_bf16 / a_bf16 / dz_bf16 give the element type behind the untyped pointers (0 = fp32;
@@ -197,8 +205,8 @@ int aide_bn_train_fwd_slabs(const float* slabs, int splitk, int64_t split_stride
 /* BatchNorm statistics from the convolution's epilogue: a forward aide_conv3x3_wino4 launch given stats_parts writes, per
  * output channel and workgroup tile, the fp32 sum and sum of squares of its pre-bias outputs to parts[Cout][nparts][2]
  * (nparts = aide_conv3x3_wino4_stats_parts); aide_bn_train_fwd_parts then normalises with ONE pass over z (replaces the
- * statistics pass of nn.BatchNorm2d in train mode, netblocks.py:25,27).  aide_bn_two_pass tells whether the plain
- * aide_bn_train_fwd_mixed would need two launches for this shape. */
+ * statistics pass of nn.BatchNorm2d in train mode, netblocks.py:25,27).  aide_bn_two_pass: 1 for the planes where that pays
+ * (more than 16384 values per channel, or fewer than 64 channels), 0 for the small deep-level planes. */
 int aide_conv3x3_wino4_stats_parts(int N, int H, int W);
 int aide_bn_two_pass(int N, int C, int H, int W);
 /* the same for ONE group of a stacked batch (Engine.run_groups): `parts` points at the group's first entry of channel 0,

@@ -1,0 +1,253 @@
+"""One-pass BatchNorm kernels (-m gpu): S workgroups per channel hold the channel in registers and exchange fp64 partial sums
+through the workspace (csrc/bn.hip, bn_fwd_coop_kernel / bn_bwd_coop_kernel).  Replaces nn.BatchNorm2d(train) + nn.ReLU and
+their autograd backward (reference: models_twomodalinputs/netblocks.py:24-28, models_singlemodalinput/UNet.py:19-23).
+Checked here: parity with aten (CPU) on shapes that hit every (units per thread, workgroups per channel) instantiation and
+ragged tails; the inter-workgroup exchange is bit-reproducible launch after launch on one workspace, also beside a kernel that fills the
+chip on another stream; a stacked batch equals sequential forwards bit for bit; the slab-fed forms equal reduce-then-normalise."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, rtol=2e-5, what=''):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, '%s: max abs err %.3e > %.3e (ref scale %.3e)' % (what, err, rtol * scale, scale)
+
+
+def _epochs(ws, c):
+    """generations completed per channel: the first int64 of every channel's workspace block (8 + 4 * 256 doubles)"""
+    return ws.view(torch.int64)[::8 + 4 * 256][:c]
+
+
+def _stats(c, dev):
+    return tuple(torch.empty(c, device=dev) for _ in range(4))
+
+
+# (N, C, H, W); workgroups per channel / values per thread: coop_plan (bn.hip)
+SHAPES = [
+    (4, 32, 256, 256),
+    (4, 64, 128, 128),
+    (4, 128, 64, 64),
+    (4, 256, 32, 32),
+    (4, 512, 16, 16),
+    (4, 1024, 16, 16),
+    (4, 64, 320, 320),
+    (3, 40, 36, 28),        # ragged: 756 units, last workgroup partly empty
+    (5, 8, 20, 20),         # 500 units, C * S small -> Q 1, S 2
+    (1, 16, 48, 32),
+    (2, 3, 16, 16),
+    (8, 16, 512, 256),      # 262144 units: Q 8, S 128 (the largest one-pass channel)
+]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_onepass_fwd_bwd_vs_aten(dev, shape):
+    from aide_amd import ops
+    from aide_amd._lib import lib
+    n, c, h, w = shape
+    assert lib.aide_bn_one_pass(n, c, h, w) == 1
+    g = torch.Generator().manual_seed(n * 1000 + c + h)
+    z = torch.randn(n, c, h, w, generator=g) * 1.7 + torch.randn(1, c, 1, 1, generator=g)
+    dA = torch.randn(n, c, h, w, generator=g)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    bn = torch.nn.BatchNorm2d(c).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    bn.train()
+    zr = z.double().requires_grad_(True)
+    ar = F.relu(bn(zr))
+    ar.backward(dA.double())
+
+    zd, dAd = z.to(dev), dA.to(dev)
+    rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    mean, rstd, scale, shift = _stats(c, dev)
+    ws = ops.bn_ws(c, dev)
+    a = torch.empty_like(zd)
+    ops.bn_train_fwd(zd, a, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rm, rv, nbt, mean, rstd, scale, shift, ws, True)
+    a2 = torch.empty_like(zd)
+    ops.bn_relu_apply(zd, a2, scale, shift, True)
+    assert torch.equal(a, a2)
+    _close(a, ar, what='fwd')
+    _close(rm, bn.running_mean, what='running_mean')
+    _close(rv, bn.running_var, what='running_var')
+    assert int(nbt.item()) == 1
+    dz = torch.empty_like(zd)
+    dg, db, dbias = (torch.empty(c, device=dev) for _ in range(3))
+    ops.bn_relu_bwd(dAd, zd, dz, mean, rstd, scale, shift, dg, db, dbias, ws, True)
+    # (the ReLU mask of an element within rounding of zero may differ from the float64 reference: compare where it agrees)
+    mask_ref = (ar > 0).cpu()
+    mask_got = (a > 0).cpu()
+    assert (mask_ref != mask_got).sum().item() <= 2
+    if torch.equal(mask_ref, mask_got):
+        _close(dz, zr.grad, rtol=5e-5, what='dz')
+        _close(dg, bn.weight.grad, rtol=5e-5, what='dgamma')
+        _close(db, bn.bias.grad, rtol=5e-5, what='dbeta')
+    assert dbias.abs().max().item() < 1e-3
+    ep = _epochs(ws, c)
+    assert int(ep.min().item()) == int(ep.max().item()) and int(ep[0].item()) in (0, 2)     # (one-workgroup channels exchange nothing)
+
+
+def test_onepass_repeatable_beside_a_full_chip(dev):
+    """the same workspace re-used back to back, alone and while another stream keeps every CU busy: identical bits"""
+    from aide_amd import ops
+    n, c, h, w = 4, 128, 64, 64
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(n, c, h, w, generator=g).to(dev) * 3.0
+    dA = torch.randn(n, c, h, w, generator=g).to(dev)
+    gamma, beta = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev)
+    ws = ops.bn_ws(c, dev)
+    mean, rstd, scale, shift = _stats(c, dev)
+
+    def run():
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        a, dz = torch.empty_like(z), torch.empty_like(z)
+        outs = [torch.empty(c, device=dev) for _ in range(3)]
+        ops.bn_train_fwd(z, a, gamma, beta, 1e-5, 0.1, rm, rv, nbt, mean, rstd, scale, shift, ws, True)
+        ops.bn_relu_bwd(dA, z, dz, mean, rstd, scale, shift, outs[0], outs[1], outs[2], ws, True)
+        return [a, dz, rm, rv] + outs
+
+    ref = run()
+    torch.cuda.synchronize()
+    big = torch.randn(8192, 8192, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    for it in range(12):
+        if it % 2:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    big @ big
+        got = run()
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('case', [(4, 4, 128, 64, 64, 0), (2, 4, 256, 32, 32, 0), (4, 4, 32, 128, 128, 0), (3, 2, 512, 16, 16, 0),
+                                  (4, 4, 128, 64, 64, 2), (4, 4, 512, 32, 32, 4), (2, 3, 256, 32, 32, 3)])
+def test_onepass_groups_equal_sequential_forwards(dev, case):
+    """a stacked batch (groups walked inside the kernel) against one launch per group: activations, running statistics, the
+    saved coefficients -- bit for bit; z as it is (splitk = 0) or summed from split-K slabs"""
+    from aide_amd import ops
+    m, groups, c, h, w, splitk = case
+    n = m * groups
+    g = torch.Generator().manual_seed(c + h + groups)
+    bn = torch.nn.BatchNorm2d(c).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, generator=g) * 0.2)
+    bias = torch.randn(c, generator=g).to(dev)
+    if splitk:
+        slabs = torch.randn(splitk, n, c, h, w, generator=g).to(dev)
+        zsum = slabs[0].clone()
+        for s in range(1, splitk):
+            zsum += slabs[s]
+        zsum += bias.view(1, c, 1, 1)
+    else:
+        zsum = (torch.randn(n, c, h, w, generator=g) * 2.0 + 0.5).to(dev)
+    import ctypes
+    # sequential reference
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    ws = ops.bn_ws(c, dev)
+    st_a = _stats(c, dev)
+    a_ref = torch.empty_like(zsum)
+    z_ref = torch.empty_like(zsum) if splitk else zsum
+    for gi in range(groups):
+        sl = slice(gi * m, (gi + 1) * m)
+        if splitk:
+            ptr = ctypes.c_void_p(slabs.data_ptr() + 4 * gi * m * c * h * w)
+            ops.bn_train_fwd_slabs(ptr, splitk, n * c * h * w, bias, z_ref[sl], a_ref[sl], bn.weight, bn.bias, bn.eps, bn.momentum,
+                                   bn.running_mean, bn.running_var, bn.num_batches_tracked, st_a[0], st_a[1], st_a[2], st_a[3],
+                                   ws, True)
+        else:
+            ops.bn_train_fwd(zsum[sl], a_ref[sl], bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                             bn.num_batches_tracked, st_a[0], st_a[1], st_a[2], st_a[3], ws, True)
+    rm_ref, rv_ref, nbt_ref = bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked.item())
+    if splitk:
+        assert torch.equal(z_ref, zsum)
+    # stacked
+    with torch.no_grad():
+        bn.running_mean.copy_(rm0)
+        bn.running_var.copy_(rv0)
+        bn.num_batches_tracked.zero_()
+    st_b = _stats(c, dev)
+    a = torch.empty_like(zsum)
+    zz = torch.empty_like(zsum) if splitk else zsum
+    if splitk:
+        ops.bn_train_fwd_groups(zz, a, groups, bn, st_b[0], st_b[1], st_b[2], st_b[3], ws, slabs=ctypes.c_void_p(slabs.data_ptr()),
+                                splitk=splitk, split_stride=n * c * h * w, slab_bias=bias)
+        assert torch.equal(zz, zsum)
+    else:
+        ops.bn_train_fwd_groups(zz, a, groups, bn, st_b[0], st_b[1], st_b[2], st_b[3], ws)
+    assert torch.equal(a, a_ref)
+    assert torch.equal(bn.running_mean, rm_ref) and torch.equal(bn.running_var, rv_ref)
+    assert int(bn.num_batches_tracked.item()) == nbt_ref == groups
+    for x, y in zip(st_a, st_b):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('case', [(4, 128, 64, 64, 2), (4, 512, 32, 32, 4), (4, 1024, 16, 16, 16), (4, 64, 128, 128, 3)])
+def test_onepass_fwd_from_splitk_slabs(dev, case):
+    """forward fed by split-K slabs == slab reduce (split order, + bias) followed by the plain forward, bit for bit"""
+    import ctypes
+    from aide_amd import ops
+    n, c, h, w, splitk = case
+    g = torch.Generator().manual_seed(c + splitk)
+    slabs = torch.randn(splitk, n, c, h, w, generator=g).to(dev)
+    bias = torch.randn(c, generator=g).to(dev)
+    zsum = slabs[0].clone()
+    for s in range(1, splitk):
+        zsum += slabs[s]
+    zsum += bias.view(1, c, 1, 1)
+    gamma, beta = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev)
+    ws = ops.bn_ws(c, dev)
+    outs = []
+    for fed in (False, True):
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        st = _stats(c, dev)
+        a = torch.empty_like(zsum)
+        if fed:
+            zz = torch.empty_like(zsum)
+            ops.bn_train_fwd_slabs(ctypes.c_void_p(slabs.data_ptr()), splitk, n * c * h * w, bias, zz, a, gamma, beta, 1e-5, 0.1,
+                                   rm, rv, nbt, st[0], st[1], st[2], st[3], ws, True)
+            assert torch.equal(zz, zsum)
+        else:
+            ops.bn_train_fwd(zsum, a, gamma, beta, 1e-5, 0.1, rm, rv, nbt, st[0], st[1], st[2], st[3], ws, True)
+        outs.append([a, rm, rv] + list(st))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('shape', [(8, 32, 512, 512), (4, 64, 64, 64), (2, 256, 16, 16), (4, 32, 72, 56)])
+def test_onepass_bf16_storage(dev, shape):
+    """bf16-stored z / a / dA / dz (precision='bf16'): the arithmetic is that of the fp32 kernels on the widened tensors --
+    bit-identical statistics and coefficient vectors, outputs equal to the fp32 outputs rounded to nearest even"""
+    from aide_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(h + c)
+    zb = (torch.randn(n, c, h, w, generator=g) * 2.0).to(dev).bfloat16()
+    db_ = torch.randn(n, c, h, w, generator=g).to(dev).bfloat16()
+    gamma, beta = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev)
+    res = []
+    for narrow in (False, True):
+        z = zb if narrow else zb.float()
+        dA = db_ if narrow else db_.float()
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        st = _stats(c, dev)
+        ws = ops.bn_ws(c, dev)
+        a, dz = torch.empty_like(z), torch.empty_like(z)
+        outs = [torch.empty(c, device=dev) for _ in range(3)]
+        ops.bn_train_fwd(z, a, gamma, beta, 1e-5, 0.1, rm, rv, nbt, st[0], st[1], st[2], st[3], ws, True)
+        ops.bn_relu_bwd(dA, z, dz, st[0], st[1], st[2], st[3], outs[0], outs[1], outs[2], ws, True)
+        res.append((a, dz, [rm, rv] + list(st) + outs))
+    (a32, dz32, v32), (a16, dz16, v16) = res
+    for x, y in zip(v32, v16):
+        assert torch.equal(x, y)
+    assert torch.equal(a32.bfloat16(), a16) and torch.equal(dz32.bfloat16(), dz16)

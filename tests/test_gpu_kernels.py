@@ -189,7 +189,7 @@ def test_bn_relu_bwd_from_splitk_slabs(dev, case):
     ref = [torch.empty_like(z)] + [torch.empty(c, device=dev) for _ in range(3)]
     ops.bn_relu_bwd(dA, z, ref[0], mean, rstd, scale, shift, ref[1], ref[2], ref[3], ws, True)
     out = [torch.empty_like(z)] + [torch.empty(c, device=dev) for _ in range(3)]
-    ops.bn_relu_bwd_slabs(slabs, splitk, z, out[0], mean, rstd, scale, shift, out[1], out[2], out[3], True)
+    ops.bn_relu_bwd_slabs(slabs, splitk, z, out[0], mean, rstd, scale, shift, out[1], out[2], out[3], ws, True)
     for a, b, what in zip(out, ref, ('dz', 'dgamma', 'dbeta', 'dbias')):
         assert torch.equal(a, b), what
     # the convolution side: accumulate = 2 leaves the slabs, their sum in split order is the reduced result
