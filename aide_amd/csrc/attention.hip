@@ -270,8 +270,8 @@ int aide_pwconv_fwd(const float* x, int64_t x_bs, const float* w, const float* b
     const bool vec = HW % 4 == 0 && x_bs % 4 == 0 && y_bs % 4 == 0;
     const long total = (long)N * (vec ? HW / 4 : HW);
     const dim3 grid(grid_for(total), R);
-    if (vec) hipLaunchKernelGGL(pw_fwd_kernel<4>, grid, dim3(256), C * sizeof(float), stream, x, (long)x_bs, w, b, y, (long)y_bs, C, HW, total);
-    else hipLaunchKernelGGL(pw_fwd_kernel<1>, grid, dim3(256), C * sizeof(float), stream, x, (long)x_bs, w, b, y, (long)y_bs, C, HW, total);
+    if (vec) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, pw_fwd_kernel<4>, grid, dim3(256), C * sizeof(float), stream, x, (long)x_bs, w, b, y, (long)y_bs, C, HW, total);
+    else AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, pw_fwd_kernel<1>, grid, dim3(256), C * sizeof(float), stream, x, (long)x_bs, w, b, y, (long)y_bs, C, HW, total);
     return aide_launch_status();
 }
 
@@ -283,15 +283,15 @@ int aide_pwconv_dgrad(const float* dt, int64_t dt_bs, const float* w, const floa
     const bool vec = HW % 4 == 0 && dt_bs % 4 == 0 && dx_bs % 4 == 0 && (!dout || dout_bs % 4 == 0);
     const long total = (long)N * (vec ? HW / 4 : HW);
     const dim3 grid(grid_for(total), C);
-    if (vec) hipLaunchKernelGGL(pw_dgrad_kernel<4>, grid, dim3(256), R * sizeof(float), stream, dt, (long)dt_bs, w, gate, dout, (long)dout_bs, dx, (long)dx_bs, C, R, HW, total, accumulate);
-    else hipLaunchKernelGGL(pw_dgrad_kernel<1>, grid, dim3(256), R * sizeof(float), stream, dt, (long)dt_bs, w, gate, dout, (long)dout_bs, dx, (long)dx_bs, C, R, HW, total, accumulate);
+    if (vec) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, pw_dgrad_kernel<4>, grid, dim3(256), R * sizeof(float), stream, dt, (long)dt_bs, w, gate, dout, (long)dout_bs, dx, (long)dx_bs, C, R, HW, total, accumulate);
+    else AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, pw_dgrad_kernel<1>, grid, dim3(256), R * sizeof(float), stream, dt, (long)dt_bs, w, gate, dout, (long)dout_bs, dx, (long)dx_bs, C, R, HW, total, accumulate);
     return aide_launch_status();
 }
 
 int aide_pwconv_wgrad(const float* dt, int64_t dt_bs, const float* x, int64_t x_bs, float* dw, float* db, int N,
                       int C, int R, int HW, hipStream_t stream) {
     if (!dt || !x || !dw || N <= 0 || C <= 0 || R <= 0 || HW <= 0) return AIDE_ERR_ARG;
-    hipLaunchKernelGGL(pw_wgrad_kernel, dim3(C + 1, R), dim3(256), 0, stream, dt, (long)dt_bs, x, (long)x_bs, N, C, HW, dw, db);
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, pw_wgrad_kernel, dim3(C + 1, R), dim3(256), 0, stream, dt, (long)dt_bs, x, (long)x_bs, N, C, HW, dw, db);
     return aide_launch_status();
 }
 
@@ -302,10 +302,10 @@ int aide_dconv3x3_small(const float* x, const float* w, const float* b, float* y
     if (!x || !w || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Cin > 1024 || Cout > 1024 || dilation < 1) return AIDE_ERR_ARG;
     const long total = (long)N * H * W;
     if (transposed)     // reads Cout planes, writes Cin planes
-        hipLaunchKernelGGL(dconv_kernel, dim3(grid_for(total), Cin), dim3(256), Cout * 9 * sizeof(float), stream, x, w,
+        AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, dconv_kernel, dim3(grid_for(total), Cin), dim3(256), Cout * 9 * sizeof(float), stream, x, w,
                            (const float*)nullptr, y, N, Cout, Cin, H, W, dilation, 1);
     else
-        hipLaunchKernelGGL(dconv_kernel, dim3(grid_for(total), Cout), dim3(256), Cin * 9 * sizeof(float), stream, x, w, b,
+        AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, dconv_kernel, dim3(grid_for(total), Cout), dim3(256), Cin * 9 * sizeof(float), stream, x, w, b,
                            y, N, Cin, Cout, H, W, dilation, 0);
     return aide_launch_status();
 }
@@ -313,7 +313,7 @@ int aide_dconv3x3_small(const float* x, const float* w, const float* b, float* y
 int aide_dconv3x3_small_wgrad(const float* dy, const float* x, float* dw, float* db, int N, int Cout, int Cin, int H,
                               int W, int dilation, hipStream_t stream) {
     if (!dy || !x || !dw || N <= 0 || Cin <= 0 || Cout <= 0) return AIDE_ERR_ARG;
-    hipLaunchKernelGGL(dconv_wgrad_kernel, dim3(Cin * 9 + 1, Cout), dim3(256), 0, stream, dy, x, dw, db, N, Cout, Cin, H,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, dconv_wgrad_kernel, dim3(Cin * 9 + 1, Cout), dim3(256), 0, stream, dy, x, dw, db, N, Cout, Cin, H,
                        W, dilation);
     return aide_launch_status();
 }
@@ -323,9 +323,9 @@ int aide_sa_gate_fwd(const float* t4, const float* gamma, const float* beta, flo
                      int64_t* num_batches_tracked, float eps, float momentum, int training, float* stat, float* gate,
                      int64_t M, hipStream_t stream) {
     if (!t4 || !gamma || !beta || !running_mean || !running_var || !stat || !gate || M <= 0) return AIDE_ERR_ARG;
-    hipLaunchKernelGGL(bn1_stats_kernel, dim3(1), dim3(1024), 0, stream, t4, (long)M, eps, momentum, training,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, bn1_stats_kernel, dim3(1), dim3(1024), 0, stream, t4, (long)M, eps, momentum, training,
                        running_mean, running_var, (long long*)num_batches_tracked, stat);
-    hipLaunchKernelGGL(sa_gate_kernel, dim3(grid_for(M)), dim3(256), 0, stream, t4, stat, gamma, beta, gate, (long)M);
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, sa_gate_kernel, dim3(grid_for(M)), dim3(256), 0, stream, t4, stat, gamma, beta, gate, (long)M);
     return aide_launch_status();
 }
 
@@ -335,8 +335,8 @@ int aide_sa_mul(const float* gate, const float* y, int64_t y_bs, float* out, int
     if (!gate || !y || !out || N <= 0 || C <= 0 || HW <= 0) return AIDE_ERR_ARG;
     const bool vec = HW % 4 == 0 && y_bs % 4 == 0 && out_bs % 4 == 0;
     const long total = (long)N * (vec ? HW / 4 : HW);
-    if (vec) hipLaunchKernelGGL(sa_mul_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, gate, y, (long)y_bs, out, (long)out_bs, C, HW, total);
-    else hipLaunchKernelGGL(sa_mul_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, gate, y, (long)y_bs, out, (long)out_bs, C, HW, total);
+    if (vec) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, sa_mul_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, gate, y, (long)y_bs, out, (long)out_bs, C, HW, total);
+    else AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, sa_mul_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, gate, y, (long)y_bs, out, (long)out_bs, C, HW, total);
     return aide_launch_status();
 }
 
@@ -350,10 +350,10 @@ int aide_sa_gate_bwd(const float* dout, int64_t dout_bs, const float* y, int64_t
     float* ds = ws + 4;
     const bool vec = HW % 4 == 0 && dout_bs % 4 == 0 && y_bs % 4 == 0;
     const long total = (long)N * (vec ? HW / 4 : HW);
-    if (vec) hipLaunchKernelGGL(sa_mul_bwd_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, dout, (long)dout_bs, y, (long)y_bs, gate, ds, C, HW, total);
-    else hipLaunchKernelGGL(sa_mul_bwd_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, dout, (long)dout_bs, y, (long)y_bs, gate, ds, C, HW, total);
-    hipLaunchKernelGGL(bn1_bwd_reduce_kernel, dim3(1), dim3(1024), 0, stream, ds, t4, stat, M, sums, dgamma, dbeta);
-    hipLaunchKernelGGL(bn1_bwd_apply_kernel, dim3(grid_for(M)), dim3(256), 0, stream, ds, t4, stat, gamma, sums, dt4, M);
+    if (vec) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, sa_mul_bwd_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, dout, (long)dout_bs, y, (long)y_bs, gate, ds, C, HW, total);
+    else AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, sa_mul_bwd_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, dout, (long)dout_bs, y, (long)y_bs, gate, ds, C, HW, total);
+    AIDE_LAUNCH_TIMED(AIDE_KT_REDUCE, 0.0, bn1_bwd_reduce_kernel, dim3(1), dim3(1024), 0, stream, ds, t4, stat, M, sums, dgamma, dbeta);
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, bn1_bwd_apply_kernel, dim3(grid_for(M)), dim3(256), 0, stream, ds, t4, stat, gamma, sums, dt4, M);
     return aide_launch_status();
 }
 

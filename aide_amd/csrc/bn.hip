@@ -764,8 +764,15 @@ __global__ __launch_bounds__(256) void bn_bwd_coop_kernel(
 // and the fp32-stored call partition the channel identically (bit-identical statistics) -- else V = 4.
 struct CoopPlan { int V, Q, S, per; };
 constexpr int BN_COOP_MIN_WGS = 1024;          // workgroups a launch should have before a thread takes more than 8 values
-__host__ inline bool coop_plan(int N, int C, int HW, bool mod8, CoopPlan& p) {
+// Tensors beyond this many values take the two-pass kernels: the one-pass form keeps the channel in registers, so at most the
+// register file's worth of a tensor (~10 M values) is in flight and every workgroup sits through the exchange (~10 us); on
+// tensors several times that size the two streaming passes win.  Same-box step A/B, limit none / 34 M / 17 M / 9 M / 0
+// (profiles/r06_bn_onepass_ab.txt): C2 630 / 631 / 632 / 629 / 614 images/s, C4 399 / 399 / 397 / 396 / 394 (fp32 storage),
+// C5 465 / 491 / 501 / 504 / 504 (bf16 storage: half the bytes in flight per value).
+constexpr long BN_ONEPASS_MAX_VALUES = 34L << 20, BN_ONEPASS_MAX_VALUES_NARROW = 9L << 20;
+__host__ inline bool coop_plan(int N, int C, int HW, bool mod8, CoopPlan& p, bool narrow = false) {
     p.V = (mod8 && HW % 8 == 0) ? 8 : 4;
+    if ((long)N * C * HW > (narrow ? BN_ONEPASS_MAX_VALUES_NARROW : BN_ONEPASS_MAX_VALUES)) return false;
     if (HW % p.V || (long)N * HW / p.V > (long)BN_MAX_S * 256 * 8) return false;
     const int units = N * HW / p.V;
     int q = 16 / p.V, s = (units + 256 * q - 1) / (256 * q);           // 16 values per thread ...
@@ -821,13 +828,16 @@ int bn_train_fwd_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C,
     const double count = (double)N * HW;
     const int gx = max(1, min((HW / (v4 ? 4 : 1) + 255) / 256, 16));
     const int NT = N * groups;
+    // algorithmic bytes of the layer (kernel timer): the input read once (z, or the slabs + the z it writes), a written once
+    const double kt_bytes = (double)NT * C * HW * ((SLABS ? 4.0 * sl.splitk : 0.0) + sizeof(ZT) + sizeof(AT));
     // one pass, S workgroups per channel (all BASELINE shapes); the two-pass kernels below remain for planes that are not a
     // multiple of 4 values and for channels beyond BN_MAX_S * 2048 units
     {
         CoopPlan cp;
-        if (v4 && coop_plan(N, C, HW, z_bs % 8 == 0 && a_bs % 8 == 0 && (!SLABS || sl.split_stride % 8 == 0), cp)) {
+        constexpr bool narrow = !(std::is_same<ZT, float>::value && std::is_same<AT, float>::value);
+        if (v4 && coop_plan(N, C, HW, z_bs % 8 == 0 && a_bs % 8 == 0 && (!SLABS || sl.split_stride % 8 == 0), cp, narrow)) {
 #define AIDE_BN_FC(VV, QQ)                                                                                                    \
-            hipLaunchKernelGGL((bn_fwd_coop_kernel<VV, QQ, ZT, AT, SLABS>), dim3(C * cp.S), dim3(256), 0, stream, z,          \
+            AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, kt_bytes, (bn_fwd_coop_kernel<VV, QQ, ZT, AT, SLABS>), dim3(C * cp.S), dim3(256), 0, stream, z, \
                                (long)z_bs, a, (long)a_bs, N, C, HW, cp.S, cp.per, count, gamma, beta, eps, momentum,          \
                                running_mean, running_var, num_batches_tracked, mean, rstd, scale, shift, relu, sl, groups,    \
                                (double*)ws)
@@ -843,18 +853,18 @@ int bn_train_fwd_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C,
     const bool v8 = v4 && !SLABS && HW % 8 == 0 && z_bs % 8 == 0 && a_bs % 8 == 0;
     if (v8) {
         const int gx8 = max(1, min((HW / 8 + 255) / 256, 16));
-        hipLaunchKernelGGL((bn_stats_kernel<8, ZT, false>), dim3(C * splits, groups), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
-        hipLaunchKernelGGL((bn_train_apply_kernel<8, ZT, AT>), dim3(NT * C, gx8), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+        AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, 0.0, (bn_stats_kernel<8, ZT, false>), dim3(C * splits, groups), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
+        AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, kt_bytes, (bn_train_apply_kernel<8, ZT, AT>), dim3(NT * C, gx8), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
                            num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0, N, groups);
     } else if (v4) {
-        hipLaunchKernelGGL((bn_stats_kernel<4, ZT, SLABS>), dim3(C * splits, groups), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
-        hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(NT * C, gx), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+        AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, 0.0, (bn_stats_kernel<4, ZT, SLABS>), dim3(C * splits, groups), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
+        AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, kt_bytes, (bn_train_apply_kernel<4, ZT, AT>), dim3(NT * C, gx), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
                            num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0, N, groups);
     } else {
-        hipLaunchKernelGGL((bn_stats_kernel<1, ZT, false>), dim3(C * splits, groups), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
-        hipLaunchKernelGGL((bn_train_apply_kernel<1, ZT, AT>), dim3(NT * C, gx), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
+        AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, 0.0, (bn_stats_kernel<1, ZT, false>), dim3(C * splits, groups), dim3(256), 0, stream, z, (long)z_bs, N, C, HW, splits, partials, sl);
+        AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, kt_bytes, (bn_train_apply_kernel<1, ZT, AT>), dim3(NT * C, gx), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW,
                            partials, splits, count, gamma, beta, eps, momentum, running_mean, running_var,
                            num_batches_tracked, mean, rstd, scale, shift, relu, (const float*)nullptr, 0, (const float*)nullptr, 0, N, groups);
     }
@@ -867,8 +877,8 @@ int bn_relu_apply_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C
     const int HW = H * W;
     const bool v4 = HW % 4 == 0 && z_bs % 4 == 0 && a_bs % 4 == 0;
     const int gx = max(1, min((HW / (v4 ? 4 : 1) + 255) / 256, 16));
-    if (v4) hipLaunchKernelGGL((bn_relu_apply_kernel<4, ZT, AT>), dim3(N * C, gx), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
-    else hipLaunchKernelGGL((bn_relu_apply_kernel<1, ZT, AT>), dim3(N * C, gx), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
+    if (v4) AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, (double)N * C * HW * (sizeof(ZT) + sizeof(AT)), (bn_relu_apply_kernel<4, ZT, AT>), dim3(N * C, gx), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
+    else AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, (double)N * C * HW * (sizeof(ZT) + sizeof(AT)), (bn_relu_apply_kernel<1, ZT, AT>), dim3(N * C, gx), dim3(256), 0, stream, z, (long)z_bs, a, (long)a_bs, C, HW, scale, shift, relu);
     return aide_launch_status();
 }
 
@@ -883,11 +893,13 @@ int bn_relu_bwd_t(const GT* dA, int64_t d_bs, const ZT* z, int64_t z_bs, DT* dz,
     const int splits = pick_splits(N, C, HW);
     double* partials = (double*)ws;
     const double count = (double)N * HW;
+    const double kt_bytes = (double)N * C * HW * (sizeof(GT) + sizeof(ZT) + sizeof(DT));     // dA, z read once, dz written once
     {
         CoopPlan cp;
-        if (v4 && coop_plan(N, C, HW, z_bs % 8 == 0 && d_bs % 8 == 0 && dz_bs % 8 == 0, cp)) {
+        constexpr bool narrow = !(std::is_same<ZT, float>::value && std::is_same<DT, float>::value && std::is_same<GT, float>::value);
+        if (v4 && coop_plan(N, C, HW, z_bs % 8 == 0 && d_bs % 8 == 0 && dz_bs % 8 == 0, cp, narrow)) {
 #define AIDE_BN_BC(VV, QQ)                                                                                                    \
-            AIDE_LAUNCH_DONE(done, (bn_bwd_coop_kernel<VV, QQ, ZT, DT, GT, false>), dim3(C * cp.S), dim3(256), 0,              \
+            AIDE_LAUNCH_DONE_TIMED(AIDE_KT_BN_BWD, kt_bytes, done, (bn_bwd_coop_kernel<VV, QQ, ZT, DT, GT, false>), dim3(C * cp.S), dim3(256), 0, \
                              stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, cp.S, cp.per, count, mean,     \
                              rstd, scale, shift, relu, dgamma, dbeta, dbias, SlabSrc{}, (double*)ws)
 #define AIDE_BN_BQ(VV) do { if (cp.Q == 1) AIDE_BN_BC(VV, 1); else if (cp.Q == 2) AIDE_BN_BC(VV, 2); else if (cp.Q == 4) AIDE_BN_BC(VV, 4); else AIDE_BN_BC(VV, 8); } while (0)
@@ -899,14 +911,14 @@ int bn_relu_bwd_t(const GT* dA, int64_t d_bs, const ZT* z, int64_t z_bs, DT* dz,
     }
     const bool v8 = v4 && HW % 8 == 0 && z_bs % 8 == 0 && d_bs % 8 == 0 && dz_bs % 8 == 0;
     if (v8) {
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<8, ZT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
-        AIDE_LAUNCH_DONE(done, (bn_bwd_apply_kernel<8, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
+        AIDE_LAUNCH_TIMED(AIDE_KT_BN_BWD, 0.0, (bn_bwd_reduce_kernel<8, ZT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
+        AIDE_LAUNCH_DONE_TIMED(AIDE_KT_BN_BWD, kt_bytes, done, (bn_bwd_apply_kernel<8, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
     } else if (v4) {
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, ZT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
-        AIDE_LAUNCH_DONE(done, (bn_bwd_apply_kernel<4, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
+        AIDE_LAUNCH_TIMED(AIDE_KT_BN_BWD, 0.0, (bn_bwd_reduce_kernel<4, ZT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
+        AIDE_LAUNCH_DONE_TIMED(AIDE_KT_BN_BWD, kt_bytes, done, (bn_bwd_apply_kernel<4, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
     } else {
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, ZT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
-        AIDE_LAUNCH_DONE(done, (bn_bwd_apply_kernel<1, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
+        AIDE_LAUNCH_TIMED(AIDE_KT_BN_BWD, 0.0, (bn_bwd_reduce_kernel<1, ZT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, N, C, HW, splits, mean, rstd, scale, shift, relu, partials);
+        AIDE_LAUNCH_DONE_TIMED(AIDE_KT_BN_BWD, kt_bytes, done, (bn_bwd_apply_kernel<1, ZT, DT, GT>), dim3(C * splits), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, splits, count, mean, rstd, scale, shift, relu, partials, dgamma, dbeta, dbias);
     }
     return aide_launch_status();
 }
@@ -961,7 +973,7 @@ static int bn_parts_launch(const void* z, int z_bf16, int64_t z_bs, void* a, int
     const double count = (double)N * HW;
     const int gx = max(1, min((HW / 4 + 255) / 256, 16));
 #define AIDE_BN_PARTS(ZT, AT)                                                                                                  \
-    hipLaunchKernelGGL((bn_train_apply_kernel<4, ZT, AT>), dim3(N * groups * C, gx), dim3(256), 0, stream, (const ZT*)z, (long)z_bs,    \
+    AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, (double)N * groups * C * HW * (sizeof(ZT) + sizeof(AT)), (bn_train_apply_kernel<4, ZT, AT>), dim3(N * groups * C, gx), dim3(256), 0, stream, (const ZT*)z, (long)z_bs, \
                        (AT*)a, (long)a_bs, C, HW, (const double*)nullptr, 0, count, gamma, beta, eps, momentum, running_mean, \
                        running_var, num_batches_tracked, mean, rstd, scale, shift, relu, parts, nparts, conv_bias, parts_stride, N, groups)
     if (z_bf16) { if (a_bf16) AIDE_BN_PARTS(bf16_t, bf16_t); else AIDE_BN_PARTS(bf16_t, float); }
@@ -1013,7 +1025,7 @@ int aide_bn_finalize_groups(int N, int groups, int C, int H, int W, const float*
     if (!parts || !tab || N < 1 || groups < 1 || C < 1 || nparts < 1 || parts_stride < nparts * groups || tab_c0 < 0 ||
         tab_c0 + C > tab_C || !mean || !rstd || !scale || !shift)
         return AIDE_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_groups_kernel, dim3(C), dim3(64), 0, stream, parts, nparts, parts_stride, conv_bias,
+    AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, 0.0, bn_finalize_groups_kernel, dim3(C), dim3(64), 0, stream, parts, nparts, parts_stride, conv_bias,
                        (double)N * H * W, groups, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
                        mean, rstd, scale, shift, tab, tab_C, tab_c0);
     return aide_launch_status();
@@ -1086,7 +1098,7 @@ int aide_bn_relu_bwd_slabs(const float* slabs, int splitk, int64_t split_stride,
     SlabSrc sl;
     sl.slabs = slabs; sl.bias = nullptr; sl.split_stride = split_stride; sl.slab_bs = (long)C * HW; sl.splitk = splitk;
 #define AIDE_BN_BS(VV, QQ)                                                                                                    \
-    AIDE_LAUNCH_DONE(done, (bn_bwd_coop_kernel<VV, QQ, float, float, float, true>), dim3(C * cp.S), dim3(256), 0, stream,     \
+    AIDE_LAUNCH_DONE_TIMED(AIDE_KT_BN_BWD, (double)N * C * HW * (4.0 * splitk + 8.0), done, (bn_bwd_coop_kernel<VV, QQ, float, float, float, true>), dim3(C * cp.S), dim3(256), 0, stream, \
                      (const float*)nullptr, 0L, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, cp.S, cp.per, (double)N * HW, mean, \
                      rstd, scale, shift, relu, dgamma, dbeta, dbias, sl, (double*)ws)
 #define AIDE_BN_BQ(VV) do { if (cp.Q == 1) AIDE_BN_BS(VV, 1); else if (cp.Q == 2) AIDE_BN_BS(VV, 2); else if (cp.Q == 4) AIDE_BN_BS(VV, 4); else AIDE_BN_BS(VV, 8); } while (0)
@@ -1100,7 +1112,7 @@ int aide_bn_eval_fold(int C, const float* gamma, const float* beta, const float*
                       const float* running_var, float eps, const float* conv_bias, float* scale, float* shift,
                       float* fbias, hipStream_t stream) {
     if (C <= 0 || !running_mean || !running_var || !scale || !shift || !fbias) return AIDE_ERR_ARG;
-    hipLaunchKernelGGL(bn_eval_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, C, gamma, beta,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, bn_eval_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, C, gamma, beta,
                        running_mean, running_var, eps, conv_bias, scale, shift, fbias);
     return aide_launch_status();
 }

@@ -87,14 +87,17 @@ struct AideLdsOptIn {
 };
 
 // ---- optional per-kernel timing (ktimer.hip; include/aide_hip.h "kernel timer"): a launch of an armed family carries
-// a start / stop event pair that receives the dispatch's own begin / end timestamps
+// a start / stop event pair that receives the dispatch's own begin / end timestamps.  Families 0-9: the MFMA convolution
+// kernels (work = algorithmic flop); 10-15: the streaming kernels (work = algorithmic bytes; 0 where nobody prices it)
 enum { AIDE_KT_IGEMM = 0, AIDE_KT_WINO2 = 1, AIDE_KT_WINO4 = 2, AIDE_KT_WGRAD = 3, AIDE_KT_WGRAD_WINO2 = 4,
-       AIDE_KT_WGRAD4 = 5, AIDE_KT_WGRAD_STEM = 6, AIDE_KT_BF16 = 7, AIDE_KT_WGRAD_BF16 = 8, AIDE_KT_CONVT = 9 };
-extern "C" int aide_ktimer_slot(int family, double flops, hipEvent_t* e0, hipEvent_t* e1);
+       AIDE_KT_WGRAD4 = 5, AIDE_KT_WGRAD_STEM = 6, AIDE_KT_BF16 = 7, AIDE_KT_WGRAD_BF16 = 8, AIDE_KT_CONVT = 9,
+       AIDE_KT_BN_FWD = 10, AIDE_KT_BN_BWD = 11, AIDE_KT_POOL = 12, AIDE_KT_UPSAMPLE = 13, AIDE_KT_REDUCE = 14,
+       AIDE_KT_OTHER = 15 };
+extern "C" int aide_ktimer_slot(int family, double work, hipStream_t stream, hipEvent_t* e0, hipEvent_t* e1);
 #define AIDE_LAUNCH_TIMED(FAM, FLOPS, kernel, grid, block, lds, stream, ...)                                  \
     do {                                                                                                      \
         hipEvent_t kt_e0_, kt_e1_;                                                                            \
-        if (aide_ktimer_slot(FAM, FLOPS, &kt_e0_, &kt_e1_))                                                   \
+        if (aide_ktimer_slot(FAM, FLOPS, stream, &kt_e0_, &kt_e1_))                                           \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, kt_e0_, kt_e1_, 0, __VA_ARGS__);          \
         else                                                                                                  \
             hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                \
@@ -105,6 +108,17 @@ extern "C" int aide_ktimer_slot(int family, double flops, hipEvent_t* e0, hipEve
 #define AIDE_LAUNCH_DONE(DONE, kernel, grid, block, lds, stream, ...)                                                 \
     do {                                                                                                              \
         if (DONE) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, (hipEvent_t)(DONE), 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                      \
+    } while (0)
+// ... of a timed family: while the timer is armed the dispatch's stop event is the timer's, and the hand-over event is a
+// record packet of its own behind it (instrumented steps only)
+#define AIDE_LAUNCH_DONE_TIMED(FAM, WORK, DONE, kernel, grid, block, lds, stream, ...)                                \
+    do {                                                                                                              \
+        hipEvent_t kt_e0_, kt_e1_;                                                                                    \
+        if (aide_ktimer_slot(FAM, WORK, stream, &kt_e0_, &kt_e1_)) {                                                  \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, kt_e0_, kt_e1_, 0, __VA_ARGS__);                  \
+            if (DONE) (void)hipEventRecord((hipEvent_t)(DONE), stream);                                               \
+        } else if (DONE) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, (hipEvent_t)(DONE), 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                      \
     } while (0)
 #define AIDE_CONV_FLOPS(N, H, W, Co, Ci) (2.0 * (double)(N) * (double)(H) * (double)(W) * (double)(Co) * (double)(Ci) * 9.0)

@@ -431,7 +431,7 @@ int aide_conv3x3_pack_weights(const float* w, float* wf, float* wd, int Co, int 
                               int co_pad, hipStream_t stream) {
     const long total = (long)ci_pad * 9 * Co + (wd ? (long)co_pad * 9 * Ci : 0);
     const int blocks = (int)min((total + 255) / 256, (long)4096);
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, w, wf, wd, Co, Ci,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, w, wf, wd, Co, Ci,
                        ci_pad, co_pad);
     return aide_launch_status();
 }
@@ -441,7 +441,7 @@ int aide_conv3x3_pack_weights(const float* w, float* wf, float* wd, int Co, int 
 int aide_conv3x3_pack_weights_multi(const void* descs, int n, int64_t total_blocks, hipStream_t stream) {
     if (!descs || n <= 0 || total_blocks <= 0) return AIDE_ERR_ARG;
     static_assert(sizeof(PackDesc) == 48, "descriptor layout");
-    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, pack_weights_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream,
                        (const PackDesc*)descs, n);
     return aide_launch_status();
 }
@@ -515,7 +515,7 @@ int aide_conv3x3_igemm(const float* x, int64_t x_bs, const float* wp, int ldw, c
     if (splitk > 1 && accumulate != 2) {           // accumulate == 2: the caller consumes the slabs itself
         const long total = (long)N * Cout * H * W;
         const int blocks = (int)min((total + 255) / 256, (long)2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws,
+        AIDE_LAUNCH_TIMED(AIDE_KT_REDUCE, 0.0, splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws,
                            (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias,
                            accumulate, total);
         rc = aide_launch_status();

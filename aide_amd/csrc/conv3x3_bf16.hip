@@ -864,7 +864,7 @@ int aide_conv3x3_bf16_pack_blocks(int Cout, int Cin) { return ((Cout + BP_CO - 1
 int aide_conv3x3_bf16_pack_multi(const void* descs, int n, int64_t total_blocks, hipStream_t stream) {
     if (!descs || n <= 0 || total_blocks <= 0) return AIDE_ERR_ARG;
     static_assert(sizeof(BfPackDesc) == 48, "descriptor layout");
-    hipLaunchKernelGGL(bf16_pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, bf16_pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream,
                        (const BfPackDesc*)descs, n);
     return aide_launch_status();
 }
@@ -904,10 +904,10 @@ int aide_conv3x3_bf16_mixed(const void* x, int x_bf16, int64_t x_bs, const uint1
         const long total4 = (long)N * Cout * H * W / 4;
         const int blocks = (int)min((total4 + 255) / 256, (long)2048);
         if (y_bf16)
-            hipLaunchKernelGGL(bf16_splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, stream, ws,
+            AIDE_LAUNCH_TIMED(AIDE_KT_REDUCE, 0.0, bf16_splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, stream, ws,
                                (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias, accumulate, total4);
         else
-            hipLaunchKernelGGL(bf16_splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, stream, ws,
+            AIDE_LAUNCH_TIMED(AIDE_KT_REDUCE, 0.0, bf16_splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, stream, ws,
                                (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias, accumulate, total4);
         rc = aide_launch_status();
     }

@@ -348,13 +348,13 @@ static int launch_wgrad_reduce(const float* ws, int splits, int Co, int Ci, floa
     const bool narrow = cc / 64 < 256 && splits >= 16;
     const unsigned nb = (unsigned)((cc + (narrow ? 15 : 63)) / (narrow ? 16 : 64));
     if (narrow)
-        hipLaunchKernelGGL((wgrad_reduce_kernel<16, 64>), dim3(nb), dim3(1024), 0, stream, ws, splits, Co, Ci, dw);
+        AIDE_LAUNCH_TIMED(AIDE_KT_REDUCE, 0.0, (wgrad_reduce_kernel<16, 64>), dim3(nb), dim3(1024), 0, stream, ws, splits, Co, Ci, dw);
     else if (splits >= 32)
-        hipLaunchKernelGGL((wgrad_reduce_kernel<64, 16>), dim3(nb), dim3(1024), 0, stream, ws, splits, Co, Ci, dw);
+        AIDE_LAUNCH_TIMED(AIDE_KT_REDUCE, 0.0, (wgrad_reduce_kernel<64, 16>), dim3(nb), dim3(1024), 0, stream, ws, splits, Co, Ci, dw);
     else if (splits >= 3)
-        hipLaunchKernelGGL((wgrad_reduce_kernel<64, 4>), dim3(nb), dim3(256), 0, stream, ws, splits, Co, Ci, dw);
+        AIDE_LAUNCH_TIMED(AIDE_KT_REDUCE, 0.0, (wgrad_reduce_kernel<64, 4>), dim3(nb), dim3(256), 0, stream, ws, splits, Co, Ci, dw);
     else
-        hipLaunchKernelGGL((wgrad_reduce_kernel<64, 1>), dim3(nb), dim3(64), 0, stream, ws, splits, Co, Ci, dw);
+        AIDE_LAUNCH_TIMED(AIDE_KT_REDUCE, 0.0, (wgrad_reduce_kernel<64, 1>), dim3(nb), dim3(64), 0, stream, ws, splits, Co, Ci, dw);
     return aide_launch_status();
 }
 
@@ -512,7 +512,7 @@ static int launch_wgrad_reduce_vec(const float* ws, int splits, int Co, int Ci, 
     r.narrow = reduce_groups(splits, cc);
     r.block_start = 0;
     const int R = 1024 / r.narrow;
-    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)((cc + R - 1) / R)), dim3(256), 0, stream, b);
+    AIDE_LAUNCH_TIMED(AIDE_KT_REDUCE, 0.0, wgrad_reduce_multi_kernel, dim3((unsigned)((cc + R - 1) / R)), dim3(256), 0, stream, b);
     return aide_launch_status();
 }
 
@@ -571,7 +571,7 @@ extern "C" int aide_wgrad_queue_flush(void* queue, hipStream_t stream) {
             blocks += (cc + R - 1) / R;
             b.d[b.n++] = r;
         }
-        hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, b);
+        AIDE_LAUNCH_TIMED(AIDE_KT_REDUCE, 0.0, wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, b);
         rc = aide_launch_status();
     }
     g_red.n = 0;

@@ -682,7 +682,7 @@ int aide_conv3x3_wino4_pack_multi(const void* descs, int n, int64_t total_blocks
     if (!descs || n <= 0 || total_blocks <= 0) return AIDE_ERR_ARG;
     static_assert(sizeof(W4PackDesc) == 48, "descriptor layout");
     const long grid = total_blocks;                       // one workgroup per tile (a capped grid-stride grid only got slower)
-    hipLaunchKernelGGL(wino4_pack_multi_kernel, dim3((unsigned)grid), dim3(128), 0, stream,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, wino4_pack_multi_kernel, dim3((unsigned)grid), dim3(128), 0, stream,
                        (const W4PackDesc*)descs, n, (long)total_blocks);
     return aide_launch_status();
 }
@@ -788,7 +788,7 @@ int aide_conv3x3_wino4(const float* x, int64_t x_bs, const float* u, const float
     if (rc != 0) return rc;
     if (splitk > 1 && accumulate != 2) {           // accumulate == 2: the caller consumes the slabs itself
         const long total4 = (long)N * Cout * H * W / 4;
-        hipLaunchKernelGGL(w4_splitk_reduce_kernel, dim3((unsigned)min((total4 + 255) / 256, 4096L)), dim3(256), 0,
+        AIDE_LAUNCH_TIMED(AIDE_KT_REDUCE, 0.0, w4_splitk_reduce_kernel, dim3((unsigned)min((total4 + 255) / 256, 4096L)), dim3(256), 0,
                            stream, ws, (long)N * Cout * H * W, splitk, y, (long)y_bs, Cout, H * W, bias, accumulate,
                            total4, aff, aff_relu);
         rc = aide_launch_status();

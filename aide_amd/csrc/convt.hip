@@ -129,7 +129,7 @@ extern "C" {
 int aide_convT2x2_fwd(const float* x, int64_t x_bs, const float* w, const float* b, float* y, int64_t y_bs,
                       int N, int Ci, int Co, int H, int W, hipStream_t stream) {
     const int HW = H * W;
-    hipLaunchKernelGGL(convt_fwd_kernel, dim3((HW + TN - 1) / TN, (Co + TM - 1) / TM, N * 4), dim3(256), 0,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, convt_fwd_kernel, dim3((HW + TN - 1) / TN, (Co + TM - 1) / TM, N * 4), dim3(256), 0,
                        stream, x, (long)x_bs, w, b, y, (long)y_bs, Ci, Co, H, W);
     return aide_launch_status();
 }
@@ -138,7 +138,7 @@ int aide_convT2x2_fwd(const float* x, int64_t x_bs, const float* w, const float*
 int aide_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* w, float* dx, int64_t dx_bs, int N,
                         int Ci, int Co, int H, int W, hipStream_t stream) {
     const int HW = H * W;
-    hipLaunchKernelGGL(convt_dgrad_kernel, dim3((HW + TN - 1) / TN, (Ci + TM - 1) / TM, N), dim3(256), 0,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, convt_dgrad_kernel, dim3((HW + TN - 1) / TN, (Ci + TM - 1) / TM, N), dim3(256), 0,
                        stream, dy, (long)dy_bs, w, dx, (long)dx_bs, Ci, Co, H, W);
     return aide_launch_status();
 }
@@ -151,10 +151,10 @@ int aide_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t d
                         int Ci, int Co, int H, int W, float* ws, hipStream_t stream) {
     if (!ws) return AIDE_ERR_ARG;
     const int splits = wgrad_splits(N, Ci, Co, H, W);
-    hipLaunchKernelGGL(convt_wgrad_kernel, dim3((Co * 4 + TN - 1) / TN, (Ci + TM - 1) / TM, splits), dim3(256),
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, convt_wgrad_kernel, dim3((Co * 4 + TN - 1) / TN, (Ci + TM - 1) / TM, splits), dim3(256),
                        0, stream, x, (long)x_bs, dy, (long)dy_bs, ws, N, Ci, Co, H, W, splits);
     const long n = (long)Ci * Co * 4;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)min((n + 255) / 256, 2048L)), dim3(256), 0, stream, ws,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, slab_sum_kernel, dim3((unsigned)min((n + 255) / 256, 2048L)), dim3(256), 0, stream, ws,
                        splits, n, dw);
     return aide_launch_status();
 }

@@ -398,7 +398,7 @@ int aide_kl_map(const float* z1, int64_t b1, const float* z2, int64_t b2, int N,
                 const float* gout, float* g1, int64_t gb1, float* g2, int64_t gb2, hipStream_t stream) {
     if (!z1 || !z2 || N <= 0 || HW <= 0 || (!out && !gout) || (gout && (!g1 || !g2))) return AIDE_ERR_ARG;
     const long total = (long)N * HW;
-    hipLaunchKernelGGL(kl_map_kernel, dim3(grid1(total)), dim3(256), 0, stream, z1, (long)b1, z2, (long)b2, HW, total,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, kl_map_kernel, dim3(grid1(total)), dim3(256), 0, stream, z1, (long)b1, z2, (long)b2, HW, total,
                        out, gout, g1, (long)gb1, g2, (long)gb2);
     return aide_launch_status();
 }
@@ -407,7 +407,7 @@ int aide_region_ce_fwd(const float* z, int64_t zb, const long long* t, int64_t t
                        int ignore_index, float* loss, unsigned char* aux, hipStream_t stream) {
     if (!z || !t || !loss || !aux || N <= 0 || H % 2 || W % 2) return AIDE_ERR_ARG;
     const long total = (long)N * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(region_ce_kernel, dim3(grid1(total)), dim3(256), 0, stream, z, (long)zb, t, (long)tb, H, W,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, region_ce_kernel, dim3(grid1(total)), dim3(256), 0, stream, z, (long)zb, t, (long)tb, H, W,
                        ignore_index, total, loss, aux);
     return aide_launch_status();
 }
@@ -416,7 +416,7 @@ int aide_region_ce_bwd(const float* z, int64_t zb, const unsigned char* aux, con
                        const float* coeff, int N, int H, int W, float* dz, int64_t db, hipStream_t stream) {
     if (!z || !aux || !mask || !coeff || !dz || N <= 0 || H % 2 || W % 2) return AIDE_ERR_ARG;
     const long total = (long)N * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(region_ce_bwd_kernel, dim3(grid1(total)), dim3(256), 0, stream, z, (long)zb, aux, mask, coeff,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, region_ce_bwd_kernel, dim3(grid1(total)), dim3(256), 0, stream, z, (long)zb, aux, mask, coeff,
                        H, W, total, dz, (long)db);
     return aide_launch_status();
 }
@@ -426,7 +426,7 @@ int aide_region_ce_fwd_win(const float* z, int64_t zb, const long long* t, int64
     if (!z || !t || !loss || !aux || N <= 0 || C < 2 || C > 8 || KH < 1 || KW < 1 || H < 1 || W < 1 || (long)H * W >= (1L << 31))
         return AIDE_ERR_ARG;
     const long total = (long)N * ((H + KH - 1) / KH) * ((W + KW - 1) / KW);
-    hipLaunchKernelGGL(region_ce_win_kernel<8>, dim3(grid1(total)), dim3(256), 0, stream, z, (long)zb, t, (long)tb, C, H, W, KH,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, region_ce_win_kernel<8>, dim3(grid1(total)), dim3(256), 0, stream, z, (long)zb, t, (long)tb, C, H, W, KH,
                        KW, ignore_index, total, loss, aux);
     return aide_launch_status();
 }
@@ -435,7 +435,7 @@ int aide_region_ce_bwd_win(const float* z, int64_t zb, const int* aux, const uns
                            int N, int H, int W, int KH, int KW, float* dz, int64_t db, hipStream_t stream) {
     if (!z || !aux || !mask || !coeff || !dz || N <= 0 || C < 2 || C > 8 || KH < 1 || KW < 1) return AIDE_ERR_ARG;
     const long total = (long)N * ((H + KH - 1) / KH) * ((W + KW - 1) / KW);
-    hipLaunchKernelGGL(region_ce_win_bwd_kernel<8>, dim3(grid1(total)), dim3(256), 0, stream, z, (long)zb, aux, mask, coeff, C,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, region_ce_win_bwd_kernel<8>, dim3(grid1(total)), dim3(256), 0, stream, z, (long)zb, aux, mask, coeff, C,
                        H, W, KH, KW, total, dz, (long)db);
     return aide_launch_status();
 }
@@ -444,7 +444,7 @@ int aide_select_smallest(const float* sel_vals, const float* sum_vals, int64_t s
                          int64_t k_host, double rr, const long long* k_in, int only_positive, unsigned char* mask,
                          double* sums, long long* ks, hipStream_t stream) {
     if (!sel_vals || !sum_vals || !mask || !sums || !ks || nseg <= 0 || M <= 0) return AIDE_ERR_ARG;
-    hipLaunchKernelGGL(select_smallest_kernel, dim3(nseg), dim3(1024), 0, stream, sel_vals, sum_vals, (long)seg_stride,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, select_smallest_kernel, dim3(nseg), dim3(1024), 0, stream, sel_vals, sum_vals, (long)seg_stride,
                        M, (long)k_host, rr, k_in, only_positive, mask, sums, ks);
     return aide_launch_status();
 }
@@ -454,7 +454,7 @@ int aide_pixelcoreg_map(const float* z1, const float* z2, const float* z3, const
                         int HW, float kd, float* key, float* val, float* tf, hipStream_t stream) {
     if (!z1 || !z2 || !t || !key || !tf || (z3 && !val) || N <= 0 || HW <= 0) return AIDE_ERR_ARG;
     const long total = (long)N * HW;
-    hipLaunchKernelGGL(pixelcoreg_map_kernel, dim3(grid1(total)), dim3(256), 0, stream, z1, z2, z3, t, (long)tb, HW, kd,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, pixelcoreg_map_kernel, dim3(grid1(total)), dim3(256), 0, stream, z1, z2, z3, t, (long)tb, HW, kd,
                        total, key, val, tf);
     return aide_launch_status();
 }
@@ -464,7 +464,7 @@ int aide_pixelcoreg_bwd(const float* z1, const float* z2, const float* z3, const
                         float* g3, hipStream_t stream) {
     if (!z1 || !z2 || !t || !mask || !coeff || N <= 0 || HW <= 0 || (z3 ? !g3 : (!g1 || !g2))) return AIDE_ERR_ARG;
     const long total = (long)N * HW;
-    hipLaunchKernelGGL(pixelcoreg_bwd_kernel, dim3(grid1(total)), dim3(256), 0, stream, z1, z2, z3, t, (long)tb, HW, kd,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, pixelcoreg_bwd_kernel, dim3(grid1(total)), dim3(256), 0, stream, z1, z2, z3, t, (long)tb, HW, kd,
                        total, mask, coeff, g1, g2, g3);
     return aide_launch_status();
 }
@@ -472,7 +472,7 @@ int aide_pixelcoreg_bwd(const float* z1, const float* z2, const float* z3, const
 int aide_droppixel_map(const float* z1, int64_t b1, const float* z2, int64_t b2, const long long* t, int64_t tb,
                        const long long* idx, int ndrop, int HW, int which, float* v, hipStream_t stream) {
     if (!z1 || !z2 || !t || !idx || !v || ndrop <= 0 || HW <= 0) return AIDE_ERR_ARG;
-    hipLaunchKernelGGL(droppixel_map_kernel, dim3(min((HW + 255) / 256, 256), ndrop), dim3(256), 0, stream, z1, (long)b1,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, droppixel_map_kernel, dim3(min((HW + 255) / 256, 256), ndrop), dim3(256), 0, stream, z1, (long)b1,
                        z2, (long)b2, t, (long)tb, idx, HW, which, v);
     return aide_launch_status();
 }
@@ -481,7 +481,7 @@ int aide_droppixel_bwd(const float* z1, int64_t b1, const float* z2, int64_t b2,
                        const long long* idx, int ndrop, int HW, int which, const unsigned char* mask,
                        const float* coeff, float* g1, float* g2, hipStream_t stream) {
     if (!z1 || !z2 || !t || !idx || !mask || !coeff || !g1 || !g2 || ndrop <= 0 || HW <= 0) return AIDE_ERR_ARG;
-    hipLaunchKernelGGL(droppixel_bwd_kernel, dim3(min((HW + 255) / 256, 256), ndrop), dim3(256), 0, stream, z1, (long)b1,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, droppixel_bwd_kernel, dim3(min((HW + 255) / 256, 256), ndrop), dim3(256), 0, stream, z1, (long)b1,
                        z2, (long)b2, t, (long)tb, idx, HW, which, mask, coeff, g1, g2);
     return aide_launch_status();
 }

@@ -181,7 +181,7 @@ int grid_for(long total) { return (int)max(1L, min((total + 255) / 256, 4096L));
 template <int K, typename XT>
 int head_wgrad_launch(const float* dy, long dy_bs, const XT* x, long x_bs, int C, int HW, long total4,
                       double* partials, int nblocks, hipStream_t s) {
-    hipLaunchKernelGGL((head_wgrad_kernel<K, XT>), dim3(nblocks), dim3(256), 0, s, dy, dy_bs, x, x_bs, C, HW,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, (head_wgrad_kernel<K, XT>), dim3(nblocks), dim3(256), 0, s, dy, dy_bs, x, x_bs, C, HW,
                        total4, partials);
     return aide_launch_status();
 }
@@ -194,7 +194,7 @@ int head_fwd_t(const XT* x, int64_t x_bs, const float* w, const float* b, float*
     const long total4 = (long)N * HW / 4;
     const int grid = grid_for(total4);
     const size_t sh = (size_t)K * C * sizeof(float);
-#define AIDE_HEAD_FWD(KK) hipLaunchKernelGGL((head_fwd_kernel<KK, XT>), dim3(grid), dim3(256), sh, stream, x, (long)x_bs, w, b, y, (long)y_bs, C, HW, total4)
+#define AIDE_HEAD_FWD(KK) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, (head_fwd_kernel<KK, XT>), dim3(grid), dim3(256), sh, stream, x, (long)x_bs, w, b, y, (long)y_bs, C, HW, total4)
     switch (K) { case 1: AIDE_HEAD_FWD(1); break; case 2: AIDE_HEAD_FWD(2); break; case 3: AIDE_HEAD_FWD(3); break; case 4: AIDE_HEAD_FWD(4); break;
                  case 5: AIDE_HEAD_FWD(5); break; case 6: AIDE_HEAD_FWD(6); break; case 7: AIDE_HEAD_FWD(7); break; default: AIDE_HEAD_FWD(8); }
 #undef AIDE_HEAD_FWD
@@ -210,7 +210,7 @@ int head_bwd_t(const float* dy, int64_t dy_bs, const XT* x, int64_t x_bs, const 
     const size_t sh = (size_t)K * C * sizeof(float);
     if (dx) {
         const int grid = grid_for(total4);
-#define AIDE_HEAD_DG(KK) hipLaunchKernelGGL((head_dgrad_kernel<KK, DT>), dim3(grid), dim3(256), sh, stream, dy, (long)dy_bs, w, dx, (long)dx_bs, C, HW, total4)
+#define AIDE_HEAD_DG(KK) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, (head_dgrad_kernel<KK, DT>), dim3(grid), dim3(256), sh, stream, dy, (long)dy_bs, w, dx, (long)dx_bs, C, HW, total4)
         switch (K) { case 1: AIDE_HEAD_DG(1); break; case 2: AIDE_HEAD_DG(2); break; case 3: AIDE_HEAD_DG(3); break; case 4: AIDE_HEAD_DG(4); break;
                      case 5: AIDE_HEAD_DG(5); break; case 6: AIDE_HEAD_DG(6); break; case 7: AIDE_HEAD_DG(7); break; default: AIDE_HEAD_DG(8); }
 #undef AIDE_HEAD_DG
@@ -229,7 +229,7 @@ int head_bwd_t(const float* dy, int64_t dy_bs, const XT* x, int64_t x_bs, const 
         default: rc = head_wgrad_launch<8>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream);
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(head_wgrad_finalize_kernel, dim3(K * C + K), dim3(64), 0, stream,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, head_wgrad_finalize_kernel, dim3(K * C + K), dim3(64), 0, stream,
                        (const double*)ws, nblocks, K * C, K, dw, db);
     return aide_launch_status();
 }
@@ -270,7 +270,7 @@ int aide_adam_amsgrad_multi(float* const* p, const float* const* g, float* const
     a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     a.amsgrad = amsgrad;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, a);
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, adam_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, a);
     return aide_launch_status();
 }
 

@@ -1,4 +1,5 @@
-// Optional per-kernel timing of the MFMA convolution kernels (bench.py's `roofline` object).
+// Optional per-kernel timing (bench.py's `roofline` object: the MFMA convolution kernels; its `critical` and `streaming`
+// blocks: every kernel family of the step with its launch stream).
 //
 // When a timer is armed for a kernel family, its launcher passes a start/stop event pair to hipExtLaunchKernelGGL:
 // the pair then carries the DISPATCH's own begin / end timestamps (what rocprofv3 --kernel-trace reports for the
@@ -15,16 +16,17 @@ struct KTimer {
     std::vector<hipEvent_t> ev;        // 2 per slot
     std::vector<int> fam;
     std::vector<double> flops;
+    std::vector<hipStream_t> stream;
 } T;
 }  // namespace
 
 extern "C" {
 
-int aide_ktimer_slot(int family, double flops, hipEvent_t* e0, hipEvent_t* e1) {
+int aide_ktimer_slot(int family, double flops, hipStream_t stream, hipEvent_t* e0, hipEvent_t* e1) {
     if (!(T.mask >> family & 1u)) return 0;
     if (T.used >= T.fam.size()) { ++T.dropped; return 0; }
     const size_t s = T.used++;
-    T.fam[s] = family; T.flops[s] = flops;
+    T.fam[s] = family; T.flops[s] = flops; T.stream[s] = stream;
     *e0 = T.ev[2 * s]; *e1 = T.ev[2 * s + 1];
     return 1;
 }
@@ -39,7 +41,7 @@ int aide_ktimer_start(int family_mask, int capacity) {
         if (rc != hipSuccess) return (int)rc;
         T.ev.push_back(e);
     }
-    T.fam.assign(capacity, 0); T.flops.assign(capacity, 0.0);
+    T.fam.assign(capacity, 0); T.flops.assign(capacity, 0.0); T.stream.assign(capacity, (hipStream_t)0);
     T.used = 0; T.dropped = 0;
     T.mask = (unsigned)family_mask;
     return AIDE_OK;
@@ -68,6 +70,22 @@ int aide_ktimer_read(int family, int64_t* launches, double* ms, double* flops, d
     return (int)(T.dropped > 0x7fffffff ? 0x7fffffff : T.dropped);
 }
 
+// after the device is idle: every recorded launch in launch order -- family, work, the dispatch's begin / end in milliseconds
+// after the begin of the first recorded launch (negative for a dispatch that started before it on another stream), launch
+// stream.  Arrays of `capacity` entries; returns the number of launches written or a negative / hip error code.
+int aide_ktimer_dump(int capacity, int* family, double* work, double* begin_ms, double* end_ms, uint64_t* stream) {
+    if (capacity < 0 || !family || !work || !begin_ms || !end_ms || !stream) return AIDE_ERR_ARG;
+    const size_t n = T.used < (size_t)capacity ? T.used : (size_t)capacity;
+    for (size_t s = 0; s < n; ++s) {
+        float b = 0.f, d = 0.f;
+        hipError_t rc = s ? hipEventElapsedTime(&b, T.ev[0], T.ev[2 * s]) : hipSuccess;
+        if (rc == hipSuccess) rc = hipEventElapsedTime(&d, T.ev[2 * s], T.ev[2 * s + 1]);
+        if (rc != hipSuccess) return -(int)rc - 1000;
+        family[s] = T.fam[s]; work[s] = T.flops[s]; begin_ms[s] = b; end_ms[s] = (double)b + d;
+        stream[s] = (uint64_t)(uintptr_t)T.stream[s];
+    }
+    return (int)n;
+}
 
 // ---- stream ordering without torch objects (the engine's launch tapes re-issue these like any other call)
 int aide_event_create(void** ev) {

@@ -381,7 +381,7 @@ int aide_seg_stats(const float* logits, int64_t l_bs, const long long* targets, 
                    float w1, int ignore_index, const float* pseudo, int64_t p_bs, const float* wmap,
                    int64_t w_bs, int N, int HW, double* partials, hipStream_t stream) {
     if (!logits || !targets || !partials || N <= 0 || HW <= 0) return AIDE_ERR_ARG;
-    hipLaunchKernelGGL(seg_stats_kernel, dim3(bpi_for(HW), N), dim3(256), 0, stream, logits, (long)l_bs,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, seg_stats_kernel, dim3(bpi_for(HW), N), dim3(256), 0, stream, logits, (long)l_bs,
                        targets, (long)t_bs, w0, w1, ignore_index, pseudo, (long)p_bs, wmap, (long)w_bs, HW,
                        partials);
     return aide_launch_status();
@@ -394,7 +394,7 @@ int aide_seg_loss_finalize(const double* partials, int N, int HW, int reduction,
     a.partials = partials; a.N = N; a.bpi = bpi_for(HW); a.HW = HW; a.reduction = reduction;
     a.w_ce = w_ce; a.w_dice = w_dice; a.smooth = smooth; a.stats = stats; a.out = out;
     a.per_image = per_image; a.idx = idx; a.coef = coef; a.hard_dice = hard_dice;
-    hipLaunchKernelGGL(seg_finalize_kernel, dim3(1), dim3(256), N * sizeof(float), stream, a);
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, seg_finalize_kernel, dim3(1), dim3(256), N * sizeof(float), stream, a);
     return aide_launch_status();
 }
 
@@ -411,7 +411,7 @@ int aide_coteach_finalize_mc(const double* partials1, const double* partials2, i
     a.w_seg = w_seg; a.w_cor = w_cor; a.stats1 = stats1; a.stats2 = stats2; a.loss = loss;
     a.per_image1 = per_image1; a.per_image2 = per_image2; a.idx1 = idx1; a.idx2 = idx2;
     a.coef1 = coef1; a.coef2 = coef2; a.hard_dice = hard_dice;
-    hipLaunchKernelGGL(coteach_finalize_kernel, dim3(1), dim3(256), 2 * N * sizeof(float), stream, a);
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, coteach_finalize_kernel, dim3(1), dim3(256), 2 * N * sizeof(float), stream, a);
     return aide_launch_status();
 }
 
@@ -429,7 +429,7 @@ int aide_seg_loss_bwd(const float* logits, int64_t l_bs, const long long* target
                       float w1, int ignore_index, const float* pseudo, int64_t p_bs, const float* wmap,
                       int64_t w_bs, int N, int HW, const double* stats, const float* coef, float smooth,
                       const float* gout, int g_stride, float* dlogits, int64_t d_bs, hipStream_t stream) {
-    hipLaunchKernelGGL(seg_loss_bwd_kernel, dim3(bpi_for(HW) * 4, N), dim3(256), 0, stream, logits,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, seg_loss_bwd_kernel, dim3(bpi_for(HW) * 4, N), dim3(256), 0, stream, logits,
                        (long)l_bs, targets, (long)t_bs, w0, w1, ignore_index, pseudo, (long)p_bs, wmap,
                        (long)w_bs, HW, stats, coef, N, smooth, gout, g_stride, dlogits, (long)d_bs);
     return aide_launch_status();
@@ -439,14 +439,14 @@ int aide_seg_loss_bwd(const float* logits, int64_t l_bs, const long long* target
 int aide_ce_map(const float* logits, int64_t l_bs, const long long* targets, int64_t t_bs, float w0, float w1,
                 int ignore_index, int N, int HW, float* out, const float* gout, float* dlogits, int64_t d_bs,
                 hipStream_t stream) {
-    hipLaunchKernelGGL(ce_map_kernel, dim3(bpi_for(HW) * 4, N), dim3(256), 0, stream, logits, (long)l_bs,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, ce_map_kernel, dim3(bpi_for(HW) * 4, N), dim3(256), 0, stream, logits, (long)l_bs,
                        targets, (long)t_bs, w0, w1, ignore_index, HW, out, gout, dlogits, (long)d_bs);
     return aide_launch_status();
 }
 
 int aide_mse_map(const float* logits, int64_t l_bs, const float* target, int64_t q_bs, int N, int HW,
                  float* out, const float* gout, float* dlogits, int64_t d_bs, hipStream_t stream) {
-    hipLaunchKernelGGL(mse_map_kernel, dim3(bpi_for(HW) * 4, N), dim3(256), 0, stream, logits, (long)l_bs,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, mse_map_kernel, dim3(bpi_for(HW) * 4, N), dim3(256), 0, stream, logits, (long)l_bs,
                        target, (long)q_bs, HW, out, gout, dlogits, (long)d_bs);
     return aide_launch_status();
 }
@@ -454,7 +454,7 @@ int aide_mse_map(const float* logits, int64_t l_bs, const float* target, int64_t
 int aide_label_map(const float* logits, int64_t l_bs, int N, int HW, long long* labels, hipStream_t stream) {
     if (!logits || !labels || N <= 0 || HW <= 0) return AIDE_ERR_ARG;
     const long total = (long)N * HW;
-    hipLaunchKernelGGL(label_map_kernel, dim3((unsigned)min((total + 255) / 256, 8192L)), dim3(256), 0, stream,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, label_map_kernel, dim3((unsigned)min((total + 255) / 256, 8192L)), dim3(256), 0, stream,
                        logits, (long)l_bs, HW, labels, total);
     return aide_launch_status();
 }
@@ -465,7 +465,7 @@ int aide_pseudo_label(const float* const* logits, int K, int64_t l_bs, int N, in
     PseudoArgs a;
     for (int k = 0; k < 8; ++k) a.logits[k] = k < K ? logits[k] : nullptr;
     a.K = K; a.HW = HW; a.l_bs = (long)l_bs; a.temperature = temperature; a.pl = pl; a.wm = wm;
-    hipLaunchKernelGGL(pseudo_label_kernel, dim3(bpi_for(HW) * 4, N), dim3(256), 0, stream, a);
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, pseudo_label_kernel, dim3(bpi_for(HW) * 4, N), dim3(256), 0, stream, a);
     return aide_launch_status();
 }
 
@@ -596,7 +596,7 @@ extern "C" {
 int aide_onehot_argmax(const float* t, int64_t t_bs, int N, int C, int HW, long long* idx, hipStream_t stream) {
     if (!t || !idx || N <= 0 || C <= 0 || HW <= 0) return AIDE_ERR_ARG;
     const long total = (long)N * HW;
-    hipLaunchKernelGGL(onehot_argmax_kernel, dim3((unsigned)min((total + 255) / 256, 8192L)), dim3(256), 0, stream, t,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, onehot_argmax_kernel, dim3((unsigned)min((total + 255) / 256, 8192L)), dim3(256), 0, stream, t,
                        (long)t_bs, C, HW, idx, total);
     return aide_launch_status();
 }
@@ -612,9 +612,9 @@ int aide_dice_terms_fwd(const float* x, int64_t x_bs, const float* t, int64_t t_
         return AIDE_ERR_ARG;
     const int bpi = bpi_for(HW);
     double* stats = ws + (size_t)N * bpi * 3 * K;
-    if (K == 1) hipLaunchKernelGGL(dice_terms_stats_kernel<1>, dim3(bpi, N), dim3(256), 0, stream, x, (long)x_bs, t, (long)t_bs, HW, bpi, ws);
-    else hipLaunchKernelGGL(dice_terms_stats_kernel<2>, dim3(bpi, N), dim3(256), 0, stream, x, (long)x_bs, t, (long)t_bs, HW, bpi, ws);
-    hipLaunchKernelGGL(dice_terms_finalize_kernel, dim3(1), dim3(256), 0, stream, (const double*)ws, N, bpi, K, w0, w1,
+    if (K == 1) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, dice_terms_stats_kernel<1>, dim3(bpi, N), dim3(256), 0, stream, x, (long)x_bs, t, (long)t_bs, HW, bpi, ws);
+    else AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, dice_terms_stats_kernel<2>, dim3(bpi, N), dim3(256), 0, stream, x, (long)x_bs, t, (long)t_bs, HW, bpi, ws);
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, dice_terms_finalize_kernel, dim3(1), dim3(256), 0, stream, (const double*)ws, N, bpi, K, w0, w1,
                        smooth, reduction, stats, per_image, out);
     return aide_launch_status();
 }
@@ -625,8 +625,8 @@ int aide_dice_terms_bwd(const float* x, int64_t x_bs, const float* t, int64_t t_
     if (!x || !t || !ws || !g || !dx || (K != 1 && K != 2)) return AIDE_ERR_ARG;
     const int bpi = bpi_for(HW);
     const double* stats = ws + (size_t)N * bpi * 3 * K;
-    if (K == 1) hipLaunchKernelGGL(dice_terms_bwd_kernel<1>, dim3(bpi * 4, N), dim3(256), 0, stream, x, (long)x_bs, t, (long)t_bs, HW, N, stats, w0, w1, smooth, reduction, g, dx, (long)dx_bs);
-    else hipLaunchKernelGGL(dice_terms_bwd_kernel<2>, dim3(bpi * 4, N), dim3(256), 0, stream, x, (long)x_bs, t, (long)t_bs, HW, N, stats, w0, w1, smooth, reduction, g, dx, (long)dx_bs);
+    if (K == 1) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, dice_terms_bwd_kernel<1>, dim3(bpi * 4, N), dim3(256), 0, stream, x, (long)x_bs, t, (long)t_bs, HW, N, stats, w0, w1, smooth, reduction, g, dx, (long)dx_bs);
+    else AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, dice_terms_bwd_kernel<2>, dim3(bpi * 4, N), dim3(256), 0, stream, x, (long)x_bs, t, (long)t_bs, HW, N, stats, w0, w1, smooth, reduction, g, dx, (long)dx_bs);
     return aide_launch_status();
 }
 

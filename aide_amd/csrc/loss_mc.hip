@@ -563,7 +563,7 @@ int aide_seg_stats_mc(const float* logits, int64_t l_bs, const long long* target
     ClassW cw;
     if (!logits || !targets || !partials || N <= 0 || HW <= 0 || !load_w(class_w, C, cw)) return AIDE_ERR_ARG;
     const dim3 grid(aide_seg_loss_blocks(HW), N);
-#define L(CC) hipLaunchKernelGGL(seg_stats_mc_kernel<CC>, grid, dim3(256), 0, stream, logits, (long)l_bs, targets, \
+#define L(CC) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, seg_stats_mc_kernel<CC>, grid, dim3(256), 0, stream, logits, (long)l_bs, targets, \
                                  (long)t_bs, cw, ignore_index, pseudo, (long)p_bs, wmap, (long)w_bs, HW, partials)
     AIDE_MC_SWITCH(C, L)
 #undef L
@@ -578,7 +578,7 @@ int aide_seg_loss_bwd_mc(const float* logits, int64_t l_bs, const long long* tar
     ClassW cw;
     if (!logits || !targets || !stats || !coef || !gout || !dlogits || !load_w(class_w, C, cw)) return AIDE_ERR_ARG;
     const dim3 grid(aide_seg_loss_blocks(HW) * 4, N);
-#define L(CC) hipLaunchKernelGGL(seg_loss_bwd_mc_kernel<CC>, grid, dim3(256), 0, stream, logits, (long)l_bs, targets, \
+#define L(CC) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, seg_loss_bwd_mc_kernel<CC>, grid, dim3(256), 0, stream, logits, (long)l_bs, targets, \
                                  (long)t_bs, cw, ignore_index, pseudo, (long)p_bs, wmap, (long)w_bs, HW, stats, coef, N, \
                                  smooth, gout, g_stride, dlogits, (long)d_bs)
     AIDE_MC_SWITCH(C, L)
@@ -593,7 +593,7 @@ int aide_ce_map_mc(const float* logits, int64_t l_bs, const long long* targets, 
     ClassW cw;
     if (!logits || !targets || (!out && !gout) || !load_w(class_w, C, cw)) return AIDE_ERR_ARG;
     const dim3 grid(aide_seg_loss_blocks(HW) * 4, N);
-#define L(CC) hipLaunchKernelGGL(ce_map_mc_kernel<CC>, grid, dim3(256), 0, stream, logits, (long)l_bs, targets, \
+#define L(CC) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, ce_map_mc_kernel<CC>, grid, dim3(256), 0, stream, logits, (long)l_bs, targets, \
                                  (long)t_bs, cw, ignore_index, HW, out, gout, dlogits, (long)d_bs)
     AIDE_MC_SWITCH(C, L)
 #undef L
@@ -604,7 +604,7 @@ int aide_mse_map_mc(const float* logits, int64_t l_bs, const float* target, int6
                     float* out, const float* gout, float* dlogits, int64_t d_bs, hipStream_t stream) {
     if (!logits || !target || (!out && !gout) || C < 3 || C > MAXC) return AIDE_ERR_ARG;
     const dim3 grid(aide_seg_loss_blocks(HW) * 4, N);
-#define L(CC) hipLaunchKernelGGL(mse_map_mc_kernel<CC>, grid, dim3(256), 0, stream, logits, (long)l_bs, target, \
+#define L(CC) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, mse_map_mc_kernel<CC>, grid, dim3(256), 0, stream, logits, (long)l_bs, target, \
                                  (long)q_bs, HW, out, gout, dlogits, (long)d_bs)
     AIDE_MC_SWITCH(C, L)
 #undef L
@@ -615,7 +615,7 @@ int aide_label_map_mc(const float* logits, int64_t l_bs, int C, int N, int HW, l
     if (!logits || !labels || N <= 0 || HW <= 0 || C < 3 || C > MAXC) return AIDE_ERR_ARG;
     const long total = (long)N * HW;
     const dim3 grid((unsigned)min((total + 255) / 256, 8192L));
-#define L(CC) hipLaunchKernelGGL(label_map_mc_kernel<CC>, grid, dim3(256), 0, stream, logits, (long)l_bs, HW, labels, total)
+#define L(CC) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, label_map_mc_kernel<CC>, grid, dim3(256), 0, stream, logits, (long)l_bs, HW, labels, total)
     AIDE_MC_SWITCH(C, L)
 #undef L
     return aide_launch_status();
@@ -628,7 +628,7 @@ int aide_pseudo_label_mc(const float* const* logits, int K, int C, int64_t l_bs,
     for (int k = 0; k < 8; ++k) a.logits[k] = k < K ? logits[k] : nullptr;
     a.K = K; a.HW = HW; a.l_bs = (long)l_bs; a.temperature = temperature; a.pl = pl; a.wm = wm;
     const dim3 grid(aide_seg_loss_blocks(HW) * 4, N);
-#define L(CC) hipLaunchKernelGGL(pseudo_label_mc_kernel<CC>, grid, dim3(256), 0, stream, a)
+#define L(CC) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, pseudo_label_mc_kernel<CC>, grid, dim3(256), 0, stream, a)
     AIDE_MC_SWITCH(C, L)
 #undef L
     return aide_launch_status();
@@ -649,11 +649,11 @@ int aide_dice_terms_mc_fwd(const float* x, int64_t x_bs, const float* t, int64_t
         return AIDE_ERR_ARG;
     const int bpi = aide_seg_loss_blocks(HW);
     double* stats = ws + (size_t)N * bpi * 3 * C;
-#define L(CC) hipLaunchKernelGGL(dice_terms_mc_stats_kernel<CC>, dim3(bpi, N), dim3(256), 0, stream, x, (long)x_bs, t, \
+#define L(CC) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, dice_terms_mc_stats_kernel<CC>, dim3(bpi, N), dim3(256), 0, stream, x, (long)x_bs, t, \
                                  (long)t_bs, HW, bpi, ws)
     AIDE_MC_SWITCH(C, L)
 #undef L
-    hipLaunchKernelGGL(dice_terms_mc_finalize_kernel, dim3(1), dim3(256), 0, stream, (const double*)ws, N, bpi, C, cw,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, dice_terms_mc_finalize_kernel, dim3(1), dim3(256), 0, stream, (const double*)ws, N, bpi, C, cw,
                        smooth, reduction, stats, per_image, out);
     return aide_launch_status();
 }
@@ -665,7 +665,7 @@ int aide_dice_terms_mc_bwd(const float* x, int64_t x_bs, const float* t, int64_t
     if (!x || !t || !ws || !g || !dx || !load_w(class_w, C, cw)) return AIDE_ERR_ARG;
     const int bpi = aide_seg_loss_blocks(HW);
     const double* stats = ws + (size_t)N * bpi * 3 * C;
-#define L(CC) hipLaunchKernelGGL(dice_terms_mc_bwd_kernel<CC>, dim3(bpi * 4, N), dim3(256), 0, stream, x, (long)x_bs, t, \
+#define L(CC) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, dice_terms_mc_bwd_kernel<CC>, dim3(bpi * 4, N), dim3(256), 0, stream, x, (long)x_bs, t, \
                                  (long)t_bs, HW, N, stats, cw, smooth, reduction, g, dx, (long)dx_bs)
     AIDE_MC_SWITCH(C, L)
 #undef L
@@ -677,7 +677,7 @@ int aide_kl_map_mc(const float* z1, int64_t b1, const float* z2, int64_t b2, int
     if (!z1 || !z2 || N <= 0 || HW <= 0 || C < 3 || C > MAXC || (!out && !gout) || (gout && (!g1 || !g2))) return AIDE_ERR_ARG;
     const long total = (long)N * HW;
     const dim3 grid((unsigned)max(1L, min((total + 255) / 256, 4096L)));
-#define L(CC) hipLaunchKernelGGL(kl_map_mc_kernel<CC>, grid, dim3(256), 0, stream, z1, (long)b1, z2, (long)b2, HW, total, out, \
+#define L(CC) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, kl_map_mc_kernel<CC>, grid, dim3(256), 0, stream, z1, (long)b1, z2, (long)b2, HW, total, out, \
                                  gout, g1, (long)gb1, g2, (long)gb2)
     AIDE_MC_SWITCH(C, L)
 #undef L
@@ -690,7 +690,7 @@ int aide_region_ce_fwd_mc(const float* z, int64_t zb, const long long* t, int64_
     if (!z || !t || !loss || !aux || N <= 0 || H % 2 || W % 2 || C < 3 || C > MAXC) return AIDE_ERR_ARG;
     const long total = (long)N * (H / 2) * (W / 2);
     const dim3 grid((unsigned)max(1L, min((total + 255) / 256, 4096L)));
-#define L(CC) hipLaunchKernelGGL(region_ce_mc_kernel<CC>, grid, dim3(256), 0, stream, z, (long)zb, t, (long)tb, H, W, \
+#define L(CC) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, region_ce_mc_kernel<CC>, grid, dim3(256), 0, stream, z, (long)zb, t, (long)tb, H, W, \
                                  ignore_index, total, loss, aux)
     AIDE_MC_SWITCH(C, L)
 #undef L
@@ -702,7 +702,7 @@ int aide_region_ce_bwd_mc(const float* z, int64_t zb, const unsigned* aux, const
     if (!z || !aux || !mask || !coeff || !dz || N <= 0 || H % 2 || W % 2 || C < 3 || C > MAXC) return AIDE_ERR_ARG;
     const long total = (long)N * (H / 2) * (W / 2);
     const dim3 grid((unsigned)max(1L, min((total + 255) / 256, 4096L)));
-#define L(CC) hipLaunchKernelGGL(region_ce_bwd_mc_kernel<CC>, grid, dim3(256), 0, stream, z, (long)zb, aux, mask, coeff, H, W, \
+#define L(CC) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, region_ce_bwd_mc_kernel<CC>, grid, dim3(256), 0, stream, z, (long)zb, aux, mask, coeff, H, W, \
                                  total, dz, (long)db)
     AIDE_MC_SWITCH(C, L)
 #undef L
@@ -714,7 +714,7 @@ int aide_droppixel_map_mc(const float* z1, int64_t b1, const float* z2, int64_t 
                           hipStream_t stream) {
     if (!z1 || !z2 || !t || !idx || !v || ndrop <= 0 || HW <= 0 || C < 3 || C > MAXC) return AIDE_ERR_ARG;
     const dim3 grid(min((HW + 255) / 256, 256), ndrop);
-#define L(CC) hipLaunchKernelGGL(droppixel_map_mc_kernel<CC>, grid, dim3(256), 0, stream, z1, (long)b1, z2, (long)b2, t, \
+#define L(CC) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, droppixel_map_mc_kernel<CC>, grid, dim3(256), 0, stream, z1, (long)b1, z2, (long)b2, t, \
                                  (long)tb, idx, HW, which, ignore_index, v)
     AIDE_MC_SWITCH(C, L)
 #undef L
@@ -727,7 +727,7 @@ int aide_droppixel_bwd_mc(const float* z1, int64_t b1, const float* z2, int64_t 
     if (!z1 || !z2 || !t || !idx || !mask || !coeff || !g1 || !g2 || ndrop <= 0 || HW <= 0 || C < 3 || C > MAXC)
         return AIDE_ERR_ARG;
     const dim3 grid(min((HW + 255) / 256, 256), ndrop);
-#define L(CC) hipLaunchKernelGGL(droppixel_bwd_mc_kernel<CC>, grid, dim3(256), 0, stream, z1, (long)b1, z2, (long)b2, t, \
+#define L(CC) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, droppixel_bwd_mc_kernel<CC>, grid, dim3(256), 0, stream, z1, (long)b1, z2, (long)b2, t, \
                                  (long)tb, idx, HW, which, ignore_index, mask, coeff, g1, g2)
     AIDE_MC_SWITCH(C, L)
 #undef L

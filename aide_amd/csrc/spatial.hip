@@ -113,14 +113,14 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
 template <typename XT, typename YT>
 __global__ __launch_bounds__(256) void upsample2x_fwd_vec_kernel(const XT* __restrict__ x, long x_bs,
                                                                  YT* __restrict__ y, long y_bs, int C, int H,
-                                                                 int W, int per_plane4) {
+                                                                 int W, int per_plane4, int gx) {
     const int Ho = 2 * H, Wo = 2 * W, Wo4 = Wo / 4;
     const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
-    const int plane = blockIdx.y, n = plane / C, c = plane - n * C;
+    const int plane = blockIdx.x / gx, bx = blockIdx.x - plane * gx, n = plane / C, c = plane - n * C;     // (1-D grid: gridDim.y stops at 65535 planes)
     const XT* xp = x + (long)n * x_bs + (long)c * H * W;
     YT* yp = y + (long)n * y_bs + (long)c * Ho * Wo;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < per_plane4; e += gridDim.x * 256) {
+    for (int e = bx * 256 + threadIdx.x; e < per_plane4; e += gx * 256) {
         const int oh = e / Wo4, ow4 = e - oh * Wo4;
         int h0, h1; float lh;
         src_index(oh, sh, H, h0, h1, lh);
@@ -248,7 +248,7 @@ __device__ __forceinline__ int up_bwd_weights(int i, int in_size, int out_size, 
 template <typename GT, typename DT, bool FAST>
 __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const GT* __restrict__ dy, long dy_bs,
                                                                    DT* __restrict__ dx, long dx_bs, int C, int H,
-                                                                   int W, int tiles_w, int accumulate) {
+                                                                   int W, int tiles_w, int tiles, int accumulate) {
     constexpr int HW2 = UB_RW / 2;                          // 66 column pairs
     // bf16-stored gradients keep their two bytes in the window: one packed word per column pair instead of two floats --
     // 21 KB of LDS per workgroup instead of 31 KB, i.e. seven resident workgroups per CU instead of five (and more of them
@@ -267,8 +267,9 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const GT* __r
     const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     const int tid = threadIdx.x;
-    const int h0 = (blockIdx.x / tiles_w) * UB_TH, w0 = (blockIdx.x % tiles_w) * UB_TW;
-    const int plane = blockIdx.y, n = plane / C, c = plane - n * C;
+    // 1-D grid, tile index fastest (gridDim.y would stop at 65535 planes: a stacked batch of 4 x 32 images at C = 512)
+    const int plane = blockIdx.x / tiles, tile = blockIdx.x - plane * tiles, n = plane / C, c = plane - n * C;
+    const int h0 = (tile / tiles_w) * UB_TH, w0 = (tile % tiles_w) * UB_TW;
     const int R0 = 2 * h0 - 2, C0 = 2 * w0 - 2;            // destination window origin (may be -2, always even)
     const int x = tid & 63, rq = tid >> 6;                  // this thread's source column / first source row
     // tap-weight tables, built once per workgroup by 80 threads (every thread building its own cost more VALU time
@@ -553,7 +554,7 @@ namespace {
 template <typename XT, typename YT>
 int maxpool_fwd_t(const XT* x, int64_t x_bs, YT* y, int64_t y_bs, int N, int C, int H, int W, hipStream_t stream) {
     const long total = (long)N * C * (H / 2) * (W / 4);
-    hipLaunchKernelGGL((maxpool2x2_fwd_kernel<XT, YT>), dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
+    AIDE_LAUNCH_TIMED(AIDE_KT_POOL, (double)N * C * H * W * (sizeof(XT) + 0.25 * sizeof(YT)), (maxpool2x2_fwd_kernel<XT, YT>), dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
                        (long)y_bs, C, H, W, total);
     return aide_launch_status();
 }
@@ -561,23 +562,26 @@ template <typename XT, typename GT, typename DT>
 int maxpool_bwd_t(const XT* x, int64_t x_bs, const GT* dy, int64_t dy_bs, DT* dx, int64_t dx_bs, int N, int C, int H,
                   int W, int accumulate, hipStream_t stream) {
     const long total = (long)N * C * (H / 2) * (W / 4);
-    hipLaunchKernelGGL((maxpool2x2_bwd_kernel<XT, GT, DT>), dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, dy,
+    // (x to find the arg-max, dy, dx written; an accumulating launch reads dx as well)
+    AIDE_LAUNCH_TIMED(AIDE_KT_POOL, (double)N * C * H * W * (sizeof(XT) + 0.25 * sizeof(GT) + (accumulate ? 2.0 : 1.0) * sizeof(DT)),
+                      (maxpool2x2_bwd_kernel<XT, GT, DT>), dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, dy,
                        (long)dy_bs, dx, (long)dx_bs, C, H, W, accumulate, total);
     return aide_launch_status();
 }
 template <typename XT, typename YT>
 int upsample_fwd_t(const XT* x, int64_t x_bs, YT* y, int64_t y_bs, int N, int C, int H, int W, hipStream_t stream) {
+    const double kt_bytes = (double)N * C * H * W * (sizeof(XT) + 4.0 * sizeof(YT));      // source read once, 4x the pixels written
     if ((2 * H) % UF_TR == 0 && (2 * W) % UF_TC == 0 && x_bs % 4 == 0 && y_bs % 8 == 0) {   // whole 32 x 128 output tiles
         const int tiles_w = 2 * W / UF_TC, tiles_h = 2 * H / UF_TR;
-        hipLaunchKernelGGL((upsample2x_fwd_tiled_kernel<XT, YT>), dim3((unsigned)((long)tiles_w * tiles_h * N * C)), dim3(256),
+        AIDE_LAUNCH_TIMED(AIDE_KT_UPSAMPLE, kt_bytes, (upsample2x_fwd_tiled_kernel<XT, YT>), dim3((unsigned)((long)tiles_w * tiles_h * N * C)), dim3(256),
                            0, stream, x, (long)x_bs, y, (long)y_bs, C, H, W, tiles_w, tiles_h,
                            (float)(H - 1) / (float)(2 * H - 1), (float)(W - 1) / (float)(2 * W - 1));
         return aide_launch_status();
     }
     const int per_plane4 = H * W;                       // (2H * 2W) / 4 four-pixel outputs per plane
     const int gx = max(1, min((per_plane4 + 255) / 256, 64));
-    hipLaunchKernelGGL((upsample2x_fwd_vec_kernel<XT, YT>), dim3(gx, N * C), dim3(256), 0, stream, x, (long)x_bs, y,
-                       (long)y_bs, C, H, W, per_plane4);
+    AIDE_LAUNCH_TIMED(AIDE_KT_UPSAMPLE, kt_bytes, (upsample2x_fwd_vec_kernel<XT, YT>), dim3((unsigned)((long)gx * N * C)), dim3(256), 0, stream, x,
+                      (long)x_bs, y, (long)y_bs, C, H, W, per_plane4, gx);
     return aide_launch_status();
 }
 }  // namespace
@@ -589,7 +593,7 @@ int aide_maxpool2x2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, in
     if (H % 2 || W % 2) return AIDE_ERR_ARG;
     if (W % 4 || x_bs % 4 || y_bs % 2) {
         const long total = (long)N * C * (H / 2) * (W / 2);
-        hipLaunchKernelGGL(maxpool2x2_fwd_scalar_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x,
+        AIDE_LAUNCH_TIMED(AIDE_KT_POOL, (double)N * C * H * W * 5.0, maxpool2x2_fwd_scalar_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x,
                            (long)x_bs, y, (long)y_bs, C, H, W, total);
         return aide_launch_status();
     }
@@ -611,7 +615,7 @@ int aide_maxpool2x2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t d
     if (H % 2 || W % 2) return AIDE_ERR_ARG;
     if (W % 4 || x_bs % 4 || dx_bs % 4 || dy_bs % 2) {
         const long total = (long)N * C * (H / 2) * (W / 2);
-        hipLaunchKernelGGL(maxpool2x2_bwd_scalar_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x,
+        AIDE_LAUNCH_TIMED(AIDE_KT_POOL, (double)N * C * H * W * (accumulate ? 13.0 : 9.0), maxpool2x2_bwd_scalar_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x,
                            (long)x_bs, dy, (long)dy_bs, dx, (long)dx_bs, C, H, W, accumulate, total);
         return aide_launch_status();
     }
@@ -639,7 +643,7 @@ int aide_upsample2x_bilinear_fwd(const float* x, int64_t x_bs, float* y, int64_t
                                  int W, hipStream_t stream) {
     const long total = (long)N * C * 4 * H * W;
     if ((2 * W) % 4 == 0 && y_bs % 4 == 0) return upsample_fwd_t<float, float>(x, x_bs, y, y_bs, N, C, H, W, stream);
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
+    AIDE_LAUNCH_TIMED(AIDE_KT_UPSAMPLE, (double)N * C * H * W * 20.0, upsample2x_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
                        (long)y_bs, C, H, W, total);
     return aide_launch_status();
 }
@@ -657,17 +661,19 @@ int aide_upsample2x_bilinear_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, 
 int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int N, int C,
                                  int H, int W, int accumulate, hipStream_t stream) {
     const long total = (long)N * C * H * W;
-    if (dy_bs % 2 == 0 && (long)N * C <= 65535) {          // 8-byte loads of the destination rows
+    const double kt_bytes = (double)total * (16.0 + (accumulate ? 8.0 : 4.0));     // 4x the pixels read, dx written (read: accumulate)
+    if (dy_bs % 2 == 0) {                                  // 8-byte loads of the destination rows
         const int tw = (W + UB_TW - 1) / UB_TW, th = (H + UB_TH - 1) / UB_TH;
+        const dim3 grid((unsigned)((long)tw * th * N * C));
         if (ub_fast(dy, dy_bs, W, 4))
-            hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<float, float, true>), dim3(tw * th, N * C), dim3(256), 0, stream, dy,
-                               (long)dy_bs, dx, (long)dx_bs, C, H, W, tw, accumulate);
+            AIDE_LAUNCH_TIMED(AIDE_KT_UPSAMPLE, kt_bytes, (upsample2x_bwd_tiled_kernel<float, float, true>), grid, dim3(256), 0, stream, dy,
+                              (long)dy_bs, dx, (long)dx_bs, C, H, W, tw, tw * th, accumulate);
         else
-            hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<float, float, false>), dim3(tw * th, N * C), dim3(256), 0, stream, dy,
-                               (long)dy_bs, dx, (long)dx_bs, C, H, W, tw, accumulate);
+            AIDE_LAUNCH_TIMED(AIDE_KT_UPSAMPLE, kt_bytes, (upsample2x_bwd_tiled_kernel<float, float, false>), grid, dim3(256), 0, stream, dy,
+                              (long)dy_bs, dx, (long)dx_bs, C, H, W, tw, tw * th, accumulate);
         return aide_launch_status();
     }
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, (long)dy_bs,
+    AIDE_LAUNCH_TIMED(AIDE_KT_UPSAMPLE, kt_bytes, upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, (long)dy_bs,
                        dx, (long)dx_bs, C, H, W, accumulate, total);
     return aide_launch_status();
 }
@@ -675,15 +681,17 @@ int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int6
 // the transpose on bf16-stored activation gradients (precision='bf16'); arithmetic in fp32
 int aide_upsample2x_bilinear_bwd_mixed(const void* dy, int dy_bf16, int64_t dy_bs, void* dx, int dx_bf16, int64_t dx_bs,
                                        int N, int C, int H, int W, int accumulate, hipStream_t stream) {
-    if (dy_bs % 2 || (long)N * C > 65535) return AIDE_ERR_ARG;
+    if (dy_bs % 2) return AIDE_ERR_ARG;
     const int tw = (W + UB_TW - 1) / UB_TW, th = (H + UB_TH - 1) / UB_TH;
     const bool fast = ub_fast(dy, dy_bs, W, dy_bf16 ? 2 : 4);
+    const dim3 grid((unsigned)((long)tw * th * N * C));
+    const double kt_bytes = (double)N * C * H * W * (4.0 * (dy_bf16 ? 2 : 4) + (accumulate ? 2.0 : 1.0) * (dx_bf16 ? 2 : 4));
 #define AIDE_UB(GT, DT)                                                                                                          \
     do {                                                                                                                         \
-        if (fast) hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<GT, DT, true>), dim3(tw * th, N * C), dim3(256), 0, stream,      \
-                                     (const GT*)dy, (long)dy_bs, (DT*)dx, (long)dx_bs, C, H, W, tw, accumulate);                   \
-        else hipLaunchKernelGGL((upsample2x_bwd_tiled_kernel<GT, DT, false>), dim3(tw * th, N * C), dim3(256), 0, stream,         \
-                                (const GT*)dy, (long)dy_bs, (DT*)dx, (long)dx_bs, C, H, W, tw, accumulate);                        \
+        if (fast) AIDE_LAUNCH_TIMED(AIDE_KT_UPSAMPLE, kt_bytes, (upsample2x_bwd_tiled_kernel<GT, DT, true>), grid, dim3(256), 0, stream, \
+                                    (const GT*)dy, (long)dy_bs, (DT*)dx, (long)dx_bs, C, H, W, tw, tw * th, accumulate);           \
+        else AIDE_LAUNCH_TIMED(AIDE_KT_UPSAMPLE, kt_bytes, (upsample2x_bwd_tiled_kernel<GT, DT, false>), grid, dim3(256), 0, stream, \
+                               (const GT*)dy, (long)dy_bs, (DT*)dx, (long)dx_bs, C, H, W, tw, tw * th, accumulate);                \
     } while (0)
     if (dy_bf16) { if (dx_bf16) AIDE_UB(bf16_store_t, bf16_store_t); else AIDE_UB(bf16_store_t, float); }
     else { if (dx_bf16) AIDE_UB(float, bf16_store_t); else AIDE_UB(float, float); }
@@ -697,7 +705,7 @@ int aide_reverse_aug(const float* x, int64_t x_bs, float* y, int64_t y_bs, const
                      int H, int W, hipStream_t stream) {
     if (!x || !y || !par || x == y) return AIDE_ERR_ARG;
     const long total = (long)N * C * H * W;
-    hipLaunchKernelGGL(reverse_aug_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, reverse_aug_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, (long)x_bs, y,
                        (long)y_bs, par, C, H, W, total);
     return aide_launch_status();
 }
@@ -706,11 +714,11 @@ int aide_fill_zero(float* p, int64_t bs, int N, int C, int H, int W, hipStream_t
     const long chw = (long)C * H * W;
     if (chw % 4 || bs % 4) {
         const long total = (long)N * chw;
-        hipLaunchKernelGGL(fill_zero_scalar_kernel, dim3(grid_for(total)), dim3(256), 0, stream, p, (long)bs, chw, total);
+        AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, fill_zero_scalar_kernel, dim3(grid_for(total)), dim3(256), 0, stream, p, (long)bs, chw, total);
         return aide_launch_status();
     }
     const long total4 = (long)N * chw / 4;
-    hipLaunchKernelGGL(fill_zero_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, p, (long)bs, chw / 4,
+    AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, fill_zero_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, p, (long)bs, chw / 4,
                        total4);
     return aide_launch_status();
 }

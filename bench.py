@@ -238,6 +238,46 @@ def roofline_block(timer, ev_steps, steps, peak, args, precision, batch, world):
     return roof, kernels
 
 
+QUEUE_STEPS = 3
+
+
+def queue_blocks(step, args, device, peak, ms_step, world):
+    """`roofline.critical` + `streaming`, measured AFTER the timed region on QUEUE_STEPS extra steps in
+    which EVERY kernel family of the C ABI carries its dispatch's start / stop events (aide_ktimer_dump: begin, end, launch
+    stream of every launch): which launch stream bounds the step, what it is busy with, and what the HBM-bound families
+    (BatchNorm, pooling, up-sampling) stream against 8 TB/s.  Every rank runs the steps (collectives), rank 0 reports."""
+    if args.no_kernel_events:
+        return None, None
+    from aide_amd.profiling import DispatchTimer, KT_ALL, queue_report
+    from aide_amd import engine as _eng
+    t = DispatchTimer(capacity=1600 * QUEUE_STEPS, families=KT_ALL)
+    t.start()
+    t.stop()
+    step()                                        # (a step between the timed region and the window: nothing of it is recorded)
+    torch.cuda.synchronize()
+    t.arm()
+    for _ in range(QUEUE_STEPS):
+        step()
+    torch.cuda.synchronize()
+    t.stop()
+    rows = t.timeline()
+    names = {torch.cuda.current_stream().cuda_stream: 'main'}
+    pref = _eng._preferred(device)
+    for k, label in (('side', 'weight-gradient'), ('lane', 'lane')):
+        if pref.get(k) is not None:
+            names.setdefault(pref[k].cuda_stream, label)
+    critical, streaming = queue_report(rows, QUEUE_STEPS, names, peak)
+    if critical is not None:
+        # the instrumented steps run longer (every event pair opens a few us behind its dispatch): the gaps of the critical
+        # stream are priced against the UNINSTRUMENTED step of the timed region
+        critical['gaps_ms_per_step'] = round(ms_step - critical['busy_ms_per_step'], 4)
+        critical['ms_per_step'] = round(ms_step, 4)
+        critical['timing'] = ('dispatch begin / end events of every launch of %d extra steps after the timed region, all '
+                              'kernel families armed; busy = summed dispatch time per launch stream' % QUEUE_STEPS)
+        critical['dropped_launches'] = t.dropped
+    return critical, streaming
+
+
 def build(model_name, device):
     from aide_amd.models_twomodalinputs import fuseunet
     from aide_amd.models_singlemodalinput import UNet
@@ -406,11 +446,16 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img, act, probes)
     el, _, per_rank, r = timed_steps(step, args, world, device, timer, ev_steps)
     final = [round(float(r['loss1']), 6), round(float(r['loss2']), 6)]
     check = replica_check([n1, n2], reducers, world, device)
+    if timer is not None:
+        timer.summary()                           # (read before queue_blocks re-arms the library's one timer)
+    critical, streaming = queue_blocks(step, args, device, peak, el / args.steps * 1e3, world)
     if rank != 0:
         return
     value = batch * world * args.steps / el
     roof, kernels = (None, {}) if timer is None else roofline_block(timer, ev_steps, args.steps, peak, args, precision,
                                                                     batch, world)
+    if roof is not None:
+        roof['critical'] = critical
     cpu = None
     cpu_steps = args.cpu_steps if args.cpu_steps is not None else 1
     if world == 1 and not args.no_cpu_baseline and cpu_steps > 0:
@@ -428,7 +473,7 @@ def main_coteach(args, rank, world, device, batch, size, gflop_img, act, probes)
                 step_algorithmic_frac=round(value * gflop_img / 1e3 / world / peak, 4),
                 mfma_executed_frac=None if roof is None else roof['all_mfma_kernels']['executed_frac'],
                 final_loss=final, comm=comm_block(world, reducers, per_rank, args.steps, check), switches=act,
-                roofline=roof, kernels=kernels, cpu_baseline=cpu)
+                roofline=roof, streaming=streaming, kernels=kernels, cpu_baseline=cpu)
     if probes:
         line['INVALID'] = 'non-default library build: %s' % ', '.join(probes)
     print(json.dumps(line))
@@ -516,12 +561,17 @@ def main():
     elapsed, _, per_rank, loss = timed_steps(step, args, world, device, timer, ev_steps)
     final_loss = float(loss.item())
     check = replica_check([net], reducers, world, device)
+    if timer is not None:
+        timer.summary()                           # (read before queue_blocks re-arms the library's one timer)
+    critical, streaming = queue_blocks(step, args, device, peak, elapsed / args.steps * 1e3, world)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = batch * world * args.steps / elapsed
         roof, kernels = (None, {}) if timer is None else roofline_block(timer, ev_steps, args.steps, peak, args,
                                                                         precision, batch, world)
+        if roof is not None:
+            roof['critical'] = critical
         cpu = None
         cpu_steps = args.cpu_steps if args.cpu_steps is not None else (5 if args.workload in ('c2', 'tiny') else 2)
         if world == 1 and not args.no_cpu_baseline and cpu_steps > 0:
@@ -546,7 +596,7 @@ def main():
                     mfma_executed_frac=None if roof is None else roof['all_mfma_kernels']['executed_frac'],
                     final_loss=round(final_loss, 6),
                     comm=comm_block(world, reducers, per_rank, args.steps, check), switches=act,
-                    roofline=roof, kernels=kernels, cpu_baseline=cpu)
+                    roofline=roof, streaming=streaming, kernels=kernels, cpu_baseline=cpu)
         if probes:
             line['INVALID'] = 'non-default library build: %s' % ', '.join(probes)
         print(json.dumps(line))

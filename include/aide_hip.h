@@ -314,23 +314,28 @@ int aide_wgrad_queue_pending(const void* queue);
 int aide_wgrad_queue_flush(void* queue, aide_stream_t stream);
 int aide_wgrad_queue_discard(void* queue);
 
-/* ---- kernel timer (measurement only; bench.py `roofline`) --------------------------------------------------------
+/* ---- kernel timer (measurement only; bench.py `roofline`, `critical`, `streaming`) ----------------------------------
  * While armed for a family, every launch of that family's MAIN kernel carries a start / stop HIP event pair on its own
  * stream (hipExtLaunchKernelGGL): the pair records the dispatch's begin / end timestamps -- the duration rocprofv3
  * --kernel-trace reports -- without extra packets in the queue, so the two-stream schedule of the timed steps is
  * measured as it runs.  Families (bit ids of `family_mask`): 0 conv3x3_mfma_kernel, 1 conv3x3_wino_kernel,
  * 2 conv3x3_wino4_kernel, 3 conv3x3_wgrad_kernel, 4 conv3x3_wgrad_wino_kernel, 5 conv3x3_wgrad4_kernel,
- * 6 wgrad_stem_kernel, 7 conv3x3_bf16_kernel, 8 conv3x3_wgrad_bf16_kernel, 9 convT kernels,
- * (family 10 is unused).
- * aide_ktimer_start creates the events (call it outside the timed region); aide_ktimer_read needs an idle device and
- * returns the number of launches that found no free slot (>= 0) or an error (< 0).  `flops` = algorithmic
- * (direct-convolution) flop, 2 N H W Co Ci 9 per launch. */
+ * 6 wgrad_stem_kernel, 7 conv3x3_bf16_kernel, 8 conv3x3_wgrad_bf16_kernel, 9 convT kernels (work = algorithmic
+ * direct-convolution flop, 2 N H W Co Ci 9 per launch); the streaming families 10 BatchNorm forward, 11 BatchNorm backward,
+ * 12 max-pooling, 13 bilinear up-sampling (work = algorithmic bytes of the launch: every operand read once, the result written
+ * once), 14 split-K / slab reduces, 15 head, loss, Adam, filter packs (work 0).  A timed launch that also carries a hand-over
+ * event (`done`) records that event with a packet of its own while the timer is armed.
+ * aide_ktimer_start creates the events (call it outside the timed region); aide_ktimer_read / aide_ktimer_dump need an idle
+ * device; aide_ktimer_read returns the number of launches that found no free slot (>= 0) or an error (< 0). */
 int aide_ktimer_start(int family_mask, int capacity);
-/* the launchers' own hook (not for callers): claims an event pair (hipEvent_t*) for one launch of `family`; 0 = not armed */
-int aide_ktimer_slot(int family, double flops, void** e0, void** e1);
+/* the launchers' own hook (not for callers): claims an event pair (hipEvent_t*) for one launch of `family` on `stream`; 0 = not armed */
+int aide_ktimer_slot(int family, double work, aide_stream_t stream, void** e0, void** e1);
 int aide_ktimer_stop(void);
 int aide_ktimer_arm(int family_mask);        /* re-arm after a stop, keeping what was recorded */
 int aide_ktimer_read(int family, int64_t* launches, double* ms, double* flops, double* max_ms);
+/* every recorded launch in launch order: family, work, begin / end of the dispatch in ms after the begin of the first recorded
+ * launch, launch stream (arrays of `capacity` entries) -> number of launches written, or an error (< 0) */
+int aide_ktimer_dump(int capacity, int* family, double* work, double* begin_ms, double* end_ms, uint64_t* stream);
 
 /* ---- Spatial_Attention branch of the attention variants (fuseunetsa / UNetsa) -----------------------------------
  * replaces Spatial_Attention.forward (models_twomodalinputs/netblocks.py:68-89, models_singlemodalinput/UNet.py:85-107)

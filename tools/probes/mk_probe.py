@@ -38,7 +38,13 @@ G4_VREAD = "            if (st >= 1 && st < 7) v_read(st - 1, kcur ? xr0 : xr1);
 G4_FRAG = "            if (w == 0 && gq + 2 < 9) frag(gq + 2, (gq + 2) % 3);\n"
 
 # name -> (source file, [(old, new), ...])
+BN_LIM = 'constexpr long BN_ONEPASS_MAX_VALUES = 34L << 20, BN_ONEPASS_MAX_VALUES_NARROW = 9L << 20;'
 PROBES = {
+    # one-pass BatchNorm only below a tensor size (round 6): 0 = the two-pass kernels everywhere
+    'bn_2pass': ('bn.hip', [(BN_LIM, 'constexpr long BN_ONEPASS_MAX_VALUES = 0, BN_ONEPASS_MAX_VALUES_NARROW = 0;')]),
+    'bn_lim8m': ('bn.hip', [(BN_LIM, 'constexpr long BN_ONEPASS_MAX_VALUES = 9L << 20, BN_ONEPASS_MAX_VALUES_NARROW = 9L << 20;')]),
+    'bn_lim17m': ('bn.hip', [(BN_LIM, 'constexpr long BN_ONEPASS_MAX_VALUES = 17L << 20, BN_ONEPASS_MAX_VALUES_NARROW = 17L << 20;')]),
+    'bn_lim34m': ('bn.hip', [(BN_LIM, 'constexpr long BN_ONEPASS_MAX_VALUES = 34L << 20, BN_ONEPASS_MAX_VALUES_NARROW = 34L << 20;')]),
     # hand-over events with a device-scope release instead of the default (round 5: the 5-7 us hole behind every kernel that carries a
     # completion event in the backward pass -- is it the system-scope fence of the event?)
     'ev_device': ('ktimer.hip', [("hipEventCreateWithFlags(&e, hipEventDisableTiming);", "hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice);")]),
