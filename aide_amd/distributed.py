@@ -69,6 +69,11 @@ def first_contact(device=None, topo=True):
             out['rccl_log'] = [ln for ln in txt.splitlines() if 'channels' in ln or 'Init COMPLETE' in ln or 'Using network' in ln][-6:]
         except Exception as e:                      # noqa: BLE001
             out['rccl_log'] = 'unreadable: %s' % (e,)
+        try:                                        # parsed: the per-pid temp file is not left behind
+            os.remove(path)
+            _RCCL_LOG[0] = None
+        except OSError:
+            pass
     if not PICK_STREAMS[0]:
         out['streams_fallback'] = 'AIDE_PICK_STREAMS=0: streams as the runtime hands them out (no hardware-queue measurement)'
     else:
@@ -127,11 +132,15 @@ class BucketScheduler(object):
         return ready
 
 
-def init_from_env(device_ids=None):
+def init_from_env(device_ids=None, rccl_log=False):
     """One process per GPU under `python -m torch.distributed.run`: reads RANK / LOCAL_RANK / WORLD_SIZE, selects this
     rank's device (device_ids[local_rank] if given -- the train scripts' --gpu_order -- else local_rank) and, for
     WORLD_SIZE > 1, joins the RCCL process group.  -> (rank, world, device).  AIDE_DIST_BACKEND=gloo is a dry-run backend
-    for boxes with fewer GPUs than ranks (ranks wrap around the visible devices; RCCL refuses two ranks per device)."""
+    for boxes with fewer GPUs than ranks (ranks wrap around the visible devices; RCCL refuses two ranks per device).
+    A --gpu_order index the box does not have (the reference's defaults name GPU 1; there CUDA_VISIBLE_DEVICES would leave no
+    device and the script would silently train on the CPU -- a path this package does not have) wraps around the visible
+    devices with a warning.  rccl_log=True (bench.py): rank 0 routes RCCL's INIT log to a temp file for first_contact(),
+    which removes it."""
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -144,6 +153,11 @@ def init_from_env(device_ids=None):
         index = local_rank
     if backend != 'nccl':
         index %= torch.cuda.device_count()
+    elif index >= torch.cuda.device_count():
+        import warnings
+        warnings.warn('aide_amd: device %d requested (--gpu_order) but %d visible: using device %d'
+                      % (index, torch.cuda.device_count(), index % torch.cuda.device_count()))
+        index %= torch.cuda.device_count()
     torch.cuda.set_device(index)
     device = torch.device('cuda', index)
     if world > 1 and not dist.is_initialized():
@@ -152,7 +166,7 @@ def init_from_env(device_ids=None):
             if PICK_STREAMS[0]:
                 from . import streams
                 streams.reserve_queue(device)            # RCCL's stream then gets a hardware queue of its own (streams.py)
-            if rank == 0 and 'NCCL_DEBUG' not in os.environ and 'NCCL_DEBUG_FILE' not in os.environ:
+            if rccl_log and rank == 0 and 'NCCL_DEBUG' not in os.environ and 'NCCL_DEBUG_FILE' not in os.environ:
                 # rank 0 keeps RCCL's own account of the communicator (channel count, transport) for first_contact()
                 import tempfile
                 _RCCL_LOG[0] = os.path.join(tempfile.gettempdir(), 'aide_rccl_rank0_%d.log' % os.getpid())
@@ -290,6 +304,12 @@ class GradAllReduce(object):
         if timed:
             e1.record()
             self._exposed.append((e0, e1))
+        # the Work objects hold their bucket views (and `flat` the arena): dropped here, not at the next _begin -- the engine's
+        # "is a gradient of the last pass still held by somebody?" check (engine._views_held_elsewhere: storage use count of
+        # the arena) runs BEFORE the next pass' before_backward and would see them as a caller's aliases, i.e. take a fresh
+        # 107 MB arena every step
+        self.works = []
+        self.flat = None
 
     # ---- what bench.py reports about the exchange
     def describe(self):

@@ -20,7 +20,7 @@ def parse_args(argv=None):
     p.add_argument('--data_std', default=None, nargs='+', type=float)
     p.add_argument('--rotation', default=60, type=float)
     p.add_argument('--batch_size', default=4, type=int)
-    p.add_argument('--gpu_order', default='0', type=str)
+    p.add_argument('--gpu_order', default='0,1', type=str)
     p.add_argument('--torch_seed', default=2, type=int)
     p.add_argument('--lr', default=1e-5, type=float)
     p.add_argument('--warmup_epoch', default=20, type=int)
@@ -38,6 +38,7 @@ def parse_args(argv=None):
     p.add_argument('--history', default='history_breastdata3_proposed272cases25labels')
     p.add_argument('--cudnn', default=0, type=int)
     p.add_argument('--repetition', default=1, type=int)
+    # not in the reference: size of the synthetic epoch (there is no dataset on this path)
     p.add_argument('--steps_per_epoch', default=8, type=int)
     return p.parse_args(argv)
 

@@ -34,8 +34,8 @@ def parse_args(argv=None):
     p.add_argument('--cedice_weight', default=[1.0, 1.0], nargs='+', type=float)
     p.add_argument('--ceclass_weight', default=[1.0, 1.0], nargs='+', type=float)
     p.add_argument('--diceclass_weight', default=[1.0, 1.0], nargs='+', type=float)
-    p.add_argument('--checkpoint', default='checkpoint_comparison_1case/')
-    p.add_argument('--history', default='history_comparison_1case')
+    p.add_argument('--checkpoint', default='checkpoint_chaos_comparison1case/')
+    p.add_argument('--history', default='history_chaos_comparison1case')
     p.add_argument('--cudnn', default=0, type=int)
     p.add_argument('--repetition', default=2, type=int)
     # not in the reference: size of the synthetic epoch (there is no dataset on this path)

@@ -24,7 +24,7 @@ def parse_args(argv=None):
     p.add_argument('--data_mean', default=None, nargs='+', type=float)
     p.add_argument('--data_std', default=None, nargs='+', type=float)
     p.add_argument('--batch_size', default=4, type=int)
-    p.add_argument('--gpu_order', default='0', type=str)
+    p.add_argument('--gpu_order', default='1', type=str)
     p.add_argument('--torch_seed', default=2, type=int)
     p.add_argument('--lr', default=1e-4, type=float)
     p.add_argument('--num_epoch', default=100, type=int)
@@ -38,10 +38,11 @@ def parse_args(argv=None):
     p.add_argument('--warmup_epoch', default=20, type=int)
     p.add_argument('--temperature', default=1.0, type=float)
     p.add_argument('--segcor_weight', default=[1.0, 10.0], nargs='+', type=float)
-    p.add_argument('--checkpoint', default='checkpoint_proposed/')
-    p.add_argument('--history', default='history_proposed')
+    p.add_argument('--checkpoint', default='checkpoint_chaos_proposed30cases1label/')
+    p.add_argument('--history', default='history_chaos_proposed30cases1label')
     p.add_argument('--cudnn', default=0, type=int)
-    p.add_argument('--repetition', default=1, type=int)
+    p.add_argument('--repetition', default=200, type=int)
+    # not in the reference: size of the synthetic epoch (there is no dataset on this path)
     p.add_argument('--steps_per_epoch', default=8, type=int)
     return p.parse_args(argv)
 
@@ -90,9 +91,10 @@ def coteach_step(net1, net2, opt1, opt2, loss_op, inphase, outphase, aug_pairs, 
                  temperature=1.0, augset=None, pipeline=False, eval_aug=False, sharpen='pow'):
     """One step of trainchaos_proposed_30cases1labeled.py:260-325 on device tensors. `augset` (the
     loader's dict with 'augno', 'hflip{k}', 'degree{k}') triggers the on-device reverseaug (:271-272).
-    The single-modal form of the eight UNet `*_proposed_*` scripts: outphase=None, aug_pairs a list of tensors (or 1-tuples),
-    eval_aug=True (the nets are in eval() for the augmentation passes and back in train() for the step:
-    trainkidney_proposed_mask1.py:265-266,290-291), sharpen='root' (p^(1/T), :113-117); the keep count is the loss
+    The single-modal forms of the eight UNet `*_proposed_*` scripts: outphase=None, aug_pairs a list of tensors (or 1-tuples);
+    kidney / breast: eval_aug=True (the nets are in eval() for the augmentation passes and back in train() for the step:
+    trainkidney_proposed_mask1.py:265-266,290-291), sharpen='root' (p^(1/T), :113-117); prostate: eval_aug=False, sharpen='pow'
+    (trainprostate_proposed_isbi3ttransferisbidx.py:96-100 -- no eval() in its step); the keep count is the loss
     operator's (`CoTeachingProposedLoss(keep=...)`: 2, or int(batch_size / 2) in the breast scripts,
     trainbreast_dataset3_proposed_272cases25labeled.py:304).
     pipeline: network 2's backward pass and optimizer step (:324-325) stay on network 2's stream and the call returns
@@ -153,12 +155,49 @@ def coteach_step(net1, net2, opt1, opt2, loss_op, inphase, outphase, aug_pairs, 
                 indx1=indx1, indx2=indx2, extra=loss_op.last, pl1=pl1, pl2=pl2, wm1=wm1, wm2=wm2)
 
 
-# The three forms of the reference's nine `*_proposed_*` scripts (oracle.steps.proposed_step; fixture g20 executes their loop bodies)
+# The four forms of the reference's nine `*_proposed_*` scripts (oracle.steps.proposed_step; fixture g20 executes their loop
+# bodies).  names: which flags name the two networks; ckpt: the best-checkpoint file names --
+#   chaos    '{model}_temp{T}_r{R}_net1_besttraincasedice.pkl' / '..._net2_besttraincasedicde.pkl' (the reference's own spelling,
+#            which its test scripts open: trainchaos_proposed_30cases1labeled.py:178-179, :512-513, :524-525)
+#   kidney / breast  '{model k}_warmup{W}_temp{T}_r{R}_net{k}_besttraindice.pkl' (trainkidney_proposed_mask1.py:173-176, :451, :461)
+#   prostate '{model}_temp{T}_r{R}_net{k}_besttraincasedice.pkl' (trainprostate_proposed_isbi3ttransferisbidx.py:173-174, :489-503)
+# resume: kidney initialises BOTH networks from --resumefile (trainkidney_proposed_mask1.py:180-182).
+def _ckpt_chaos(args, names, k):
+    return '%s_temp%s_r%d_net%d_%s.pkl' % (names[0], args.temperature, args.repetition, k,
+                                           'besttraincasedice' if k == 1 else 'besttraincasedicde')
+
+
+def _ckpt_warmup(args, names, k):
+    return '%s_warmup%s_temp%s_r%d_net%d_besttraindice.pkl' % (names[k - 1], args.warmup_epoch, args.temperature, args.repetition, k)
+
+
+def _ckpt_prostate(args, names, k):
+    return '%s_temp%s_r%d_net%d_besttraincasedice.pkl' % (names[0], args.temperature, args.repetition, k)
+
+
 VARIANTS = {
-    'chaos': dict(two_modal=True, eval_aug=False, sharpen='pow', keep=lambda bs: min(2, bs)),
-    'kidney': dict(two_modal=False, eval_aug=True, sharpen='root', keep=lambda bs: min(2, bs)),        # also prostate
-    'breast': dict(two_modal=False, eval_aug=True, sharpen='root', keep=lambda bs: int(bs / 2)),
+    'chaos': dict(two_modal=True, eval_aug=False, sharpen='pow', keep=lambda bs: min(2, bs), ckpt=_ckpt_chaos, resume=False),
+    'kidney': dict(two_modal=False, eval_aug=True, sharpen='root', keep=lambda bs: min(2, bs), ckpt=_ckpt_warmup, resume=True),
+    'breast': dict(two_modal=False, eval_aug=True, sharpen='root', keep=lambda bs: int(bs / 2), ckpt=_ckpt_warmup, resume=False),
+    # the prostate scripts never call eval() inside the step (their augmentation passes run in train mode and move the
+    # BatchNorm statistics) and sharpen with p^T (trainprostate_proposed_isbi3ttransferisbidx.py:96-100, :253-327)
+    'prostate': dict(two_modal=False, eval_aug=False, sharpen='pow', keep=lambda bs: min(2, bs), ckpt=_ckpt_prostate, resume=False),
 }
+
+
+def load_resumefile(path, nets):
+    """trainkidney_proposed_mask1.py:180-182: `torch.load(args.resumefile)['net']` into BOTH networks before the loop.  The
+    reference fails when the file is missing; the mirror (whose default path names a file only the reference's authors have)
+    warns and keeps the seeded random initialisation -> True when loaded."""
+    if not path:
+        return False
+    if not os.path.exists(path):
+        logging.warning('resumefile %s not found: both networks keep their random initialisation', path)
+        return False
+    state = torch.load(path, map_location='cpu')['net']
+    for net in nets:
+        net.load_state_dict(state)
+    return True
 
 
 def Train(args=None, variant='chaos'):
@@ -170,12 +209,17 @@ def Train(args=None, variant='chaos'):
     from aide_amd.train_files.trainchaos_comparison_1case import build_model, evaluate_case
     args = args or parse_args()
     var = VARIANTS[variant]
+    if args.loss != 'cedice':
+        # the reference selects its criterion from --loss (:217-225), but its loop sorts the criterion's PER-IMAGE vector (:303-306):
+        # only 'cedice' (CEMDiceLossImage) yields one -- 'ce' / 'dice' return scalars and the script fails at .sort()
+        raise ValueError("--loss %s: the proposed loop needs the per-image criterion ('cedice')" % args.loss)
     if var['two_modal']:
         if args.model_name != 'fuseunet':                                # :75-78
             raise ValueError('Model not implemented')
         names = (args.model_name, args.model_name)
     else:
-        names = (args.model1_name, args.model2_name)
+        # kidney / breast name the two networks separately, the prostate scripts share --model_name
+        names = (args.model1_name, args.model2_name) if hasattr(args, 'model1_name') else (args.model_name, args.model_name)
         if any(nm not in ('UNet', 'UNetsa') for nm in names):            # trainkidney_proposed_mask1.py:73-80
             raise ValueError('Model not implemented')
     torch.manual_seed(args.torch_seed)
@@ -185,7 +229,10 @@ def Train(args=None, variant='chaos'):
     # reference: nn.DataParallel over --gpu_order (:183-186); here one process per GPU, rank r on gpu_order[r], per-replica
     # BatchNorm statistics and small-loss selection, both networks' gradients mean-all-reduced over RCCL
     rank, world, device = init_from_env([int(d) for d in args.gpu_order.split(',')])
-    net1, net2 = build_model(names[0], 2).to(device), build_model(names[1], 2).to(device)
+    net1, net2 = build_model(names[0], 2), build_model(names[1], 2)
+    if var['resume']:
+        load_resumefile(getattr(args, 'resumefile', None), (net1, net2))
+    net1, net2 = net1.to(device), net2.to(device)
     reducers = (attach(net1), attach(net2))          # noqa: F841
     loss_op = CoTeachingProposedLoss(cediceweight=args.cedice_weight, ceclassweight=args.ceclass_weight,
                                      segcor_weight=args.segcor_weight, keep=var['keep'](args.batch_size))
@@ -237,13 +284,10 @@ def Train(args=None, variant='chaos'):
             if args.checkpoint and (cd1 + cd2) / 2.0 > best:
                 best = (cd1 + cd2) / 2.0
                 os.makedirs(args.checkpoint, exist_ok=True)
-                # file names of :178-179, :512-513, :524-525 -- including the reference's own spelling of the second one
-                # ('..._net2_besttraincasedicde.pkl'), which its test scripts open
-                stem = '%s_temp%s_r%d' % (names[0], args.temperature, args.repetition)
-                for k, net, suffix in ((1, net1, 'besttraincasedice'), (2, net2, 'besttraincasedicde')):
+                for k, net in ((1, net1), (2, net2)):       # file names per variant: see VARIANTS
                     torch.save({'net': net.state_dict(), 'loss': float(l1 if k == 1 else l2) / args.steps_per_epoch,
                                 'epoch': epoch + 1},
-                               os.path.join(args.checkpoint, '%s_net%d_%s.pkl' % (stem, k, suffix)))
+                               os.path.join(args.checkpoint, var['ckpt'](args, names, k)))
     return net1, net2
 
 

@@ -3,7 +3,8 @@
 
 Two U-Nets (`--model1_name / --model2_name`: UNet | UNetsa) are co-trained; per step the nets are put in eval() for the four
 augmentation passes (:265-266, back to train() :290-291), the pseudo labels are sharpened with p^(1/T) (:113-117) and the small-loss
-selection keeps two images.  Everything else -- stacked augmentation pass, on-device reverse augmentation, fused
+selection keeps two images; both networks start from `--resumefile` (:180-182) and the best checkpoints are named
+'{model k}_warmup{W}_temp{T}_r{R}_net{k}_besttraindice.pkl' (:173-176, :451, :461).  Everything else -- stacked augmentation pass, on-device reverse augmentation, fused
 selection and losses, Adam, evaluation, checkpoints -- is the machinery of aide_amd.train_files.trainchaos_proposed_30cases1labeled.
 """
 import argparse
@@ -20,7 +21,7 @@ def parse_args(argv=None):
     p.add_argument('--data_std', default=None, nargs='+', type=float)
     p.add_argument('--rotation', default=60, type=float)
     p.add_argument('--batch_size', default=4, type=int)
-    p.add_argument('--gpu_order', default='0', type=str)
+    p.add_argument('--gpu_order', default='0,1', type=str)
     p.add_argument('--torch_seed', default=2, type=int)
     p.add_argument('--lr', default=1e-5, type=float)
     p.add_argument('--warmup_epoch', default=20, type=int)
@@ -40,6 +41,7 @@ def parse_args(argv=None):
     p.add_argument('--history', default='history_kidney_proposedmask1')
     p.add_argument('--cudnn', default=0, type=int)
     p.add_argument('--repetition', default=100, type=int)
+    # not in the reference: size of the synthetic epoch (there is no dataset on this path)
     p.add_argument('--steps_per_epoch', default=8, type=int)
     return p.parse_args(argv)
 

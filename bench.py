@@ -509,7 +509,7 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)
     from aide_amd.distributed import init_from_env
-    rank, world, device = init_from_env()      # one process per GPU; RCCL group when WORLD_SIZE > 1
+    rank, world, device = init_from_env(rccl_log=True)      # one process per GPU; RCCL group when WORLD_SIZE > 1
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if world > 1:

@@ -1072,6 +1072,7 @@ def g20_proposed_variants(ref_f, ref_u, ref_utils):
       chaos   trainchaos_proposed_30cases1labeled.py:262-330   fuseunet, bs 4, train-mode passes, p^T, keep 2
       kidney  trainkidney_proposed_mask1.py:266-338            UNet, bs 4, eval-mode passes, p^(1/T), keep 2
       breast  trainbreast_dataset3_proposed_272cases25labeled.py:258-336   UNet, bs 8, eval-mode passes, p^(1/T), keep 4
+      prostate trainprostate_proposed_isbi3ttransferisbidx.py:253-327     UNet, bs 4, train-mode passes, p^T, keep 2
     and oracle.steps.proposed_step (oracle nets and losses, same seeds) must reproduce loss / indices / gradients bit for bit."""
     import types
     import warnings
@@ -1082,7 +1083,11 @@ def g20_proposed_variants(ref_f, ref_u, ref_utils):
     cases = [('chaos', os.path.join(tf, 'trainchaos_proposed_30cases1labeled.py'), 'reverseaug', True, 4, 0.5, 2, False, losses.sharpen),
              ('kidney', os.path.join(tf, 'trainkidney_proposed_mask1.py'), 'reverseaugbatch', False, 4, 0.5, 2, True, losses.sharpen_root),
              ('breast', os.path.join(tf, 'trainbreast_dataset3_proposed_272cases25labeled.py'), 'reverseaugbatch', False, 8, 2.0, 4, True,
-              losses.sharpen_root)]
+              losses.sharpen_root),
+             # round 6: the prostate scripts are a fourth form -- UNet like kidney / breast, but NO eval() around the
+             # augmentation passes (they update the BatchNorm statistics) and p^T like chaos
+             ('prostate', os.path.join(tf, 'trainprostate_proposed_isbi3ttransferisbidx.py'), 'reverseaug', False, 4, 0.5, 2, False,
+              losses.sharpen)]
     fx = {}
     s = 32
     w = torch.tensor([1.0, 1.0])
@@ -1192,8 +1197,37 @@ def g20_proposed_variants(ref_f, ref_u, ref_utils):
     np.savez_compressed(os.path.join(OUT, 'g20_proposed_variants.npz'), **fx)
 
 
+CLI_SCRIPTS = ('trainchaos_comparison_1case.py', 'trainchaos_proposed_30cases1labeled.py', 'trainkidney_proposed_mask1.py',
+               'trainbreast_dataset3_proposed_272cases25labeled.py', 'trainprostate_proposed_isbi3ttransferisbidx.py')
+
+
+def g21_cli_defaults():
+    """The flag tables of the reference train scripts the package mirrors, read from their `parser.add_argument(...)` lines
+    (syntax tree; nothing is executed): per script the flag names and the JSON text of their defaults and types -- strings
+    and numbers only.  tests/test_abi_and_host.py compares the mirrors' parse_args([]) against it."""
+    import ast
+    import json
+    fx = {}
+    for fn in CLI_SCRIPTS:
+        tree = ast.parse(open(os.path.join(REF, 'train_files', fn)).read())
+        flags, defaults, types = [], [], []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == 'add_argument':
+                name = ast.literal_eval(node.args[0])
+                kw = {k.arg: k.value for k in node.keywords}
+                flags.append(name)
+                defaults.append(json.dumps(ast.literal_eval(kw['default']) if 'default' in kw else None))
+                types.append(kw['type'].id if 'type' in kw else 'str')
+        key = fn[:-3]
+        fx[key + '/flags'], fx[key + '/defaults'], fx[key + '/types'] = np.asarray(flags), np.asarray(defaults), np.asarray(types)
+        print('g21 %-55s %d flags' % (fn, len(flags)))
+    np.savez_compressed(os.path.join(OUT, 'g21_cli_defaults.npz'), **fx)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['g21']:
+        return g21_cli_defaults()
     if sys.argv[1:] == ['g20']:
         torch.set_num_threads(8)
         ref_f, ref_u, ref_utils = _import_reference()

@@ -302,3 +302,51 @@ def test_engine_config_is_per_engine_and_drops_plans():
     assert calls == ['a', 'a'] and a.snapshot() == s0
     with pytest.raises(AttributeError, match='no switch'):
         a.use_winogard = False
+
+
+def test_cli_defaults_match_reference_g21():
+    """The mirrored train scripts' parse_args([]) against the reference's own `add_argument` tables (fixture g21, written by
+    oracle/gen_golden.py::g21_cli_defaults from the scripts' syntax trees): every reference flag exists with the same default
+    and type; the only flag the reference does not have is --steps_per_epoch (size of the synthetic epoch)."""
+    import importlib
+    import json
+    import os
+    import numpy as np
+    fx = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g21_cli_defaults.npz'))
+    scripts = sorted(set(k.split('/')[0] for k in fx.files))
+    assert len(scripts) == 5
+    for name in scripts:
+        mod = importlib.import_module('aide_amd.train_files.' + name)
+        args = vars(mod.parse_args([]))
+        flags = [str(f) for f in fx[name + '/flags']]
+        for flag, dflt, ty in zip(flags, fx[name + '/defaults'], fx[name + '/types']):
+            key = flag.lstrip('-')
+            assert key in args, '%s: missing flag %s' % (name, flag)
+            want = json.loads(str(dflt))
+            assert args[key] == want, '%s %s: default %r, reference %r' % (name, flag, args[key], want)
+            if not isinstance(want, list) and 'data_' not in key:            # the flag's type=: what a command-line value becomes
+                got = vars(mod.parse_args([flag, '1']))[key]
+                assert type(got).__name__ == str(ty), (name, flag, type(got).__name__, str(ty))
+        assert sorted(set(args) - set(f.lstrip('-') for f in flags)) == ['steps_per_epoch'], name
+
+
+def test_resumefile_initialises_both_networks(tmp_path):
+    """trainkidney_proposed_mask1.py:180-182: torch.load(args.resumefile)['net'] goes into BOTH networks before the loop; a
+    missing file warns and leaves the seeded initialisation (the reference would fail)."""
+    import oracle
+    from aide_amd.models_singlemodalinput import UNet
+    from aide_amd.train_files.trainchaos_proposed_30cases1labeled import load_resumefile, VARIANTS
+    assert VARIANTS['kidney']['resume'] and not VARIANTS['breast']['resume'] and not VARIANTS['prostate']['resume']
+    torch.manual_seed(5)
+    ref = oracle.UNet(2)
+    path = str(tmp_path / 'UNet_besttraindice_Task1Mask1.pkl')
+    torch.save({'net': ref.state_dict(), 'loss': 0.1, 'epoch': 7}, path)
+    torch.manual_seed(6)
+    n1, n2 = UNet(2), UNet(2)
+    assert not torch.equal(n1.state_dict()['last_conv1.weight'], ref.state_dict()['last_conv1.weight'])
+    assert load_resumefile(path, (n1, n2)) is True
+    for net in (n1, n2):
+        sd = net.state_dict()
+        assert list(sd) == list(ref.state_dict()) and all(torch.equal(sd[k], v) for k, v in ref.state_dict().items())
+    assert load_resumefile(str(tmp_path / 'nothing.pkl'), (n1, n2)) is False
+    assert load_resumefile(None, (n1, n2)) is False

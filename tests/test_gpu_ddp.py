@@ -66,9 +66,14 @@ def _worker(rank, world, port, kind, out, backend='gloo'):
     eng.after_backward_op, eng.grad_hook, eng.before_backward = hooks
     # three steps through the reducer: the first records the backward launch tape (bucket hooks are tape entries), the
     # later ones replay it -- the replayed exchange must produce the same mean
+    arenas = []
     for _ in range(3):
         net.zero_grad()
         crit(net(*args), t.to(dev)).backward()
+        arenas.append(eng._arena.data_ptr())
+    # the reducer's bucket views / Work objects must not look like a caller's aliases of the gradient arena: the engine would
+    # take (and zero-fill) a fresh arena every step and Adam would lose its cached pointer table
+    assert len(set(arenas)) == 1, 'the gradient arena moved between data-parallel steps: %s' % (arenas,)
     worst = 0.0
     for p, g in zip(net.parameters(), local):
         parts = [torch.empty_like(g) for _ in range(world)]

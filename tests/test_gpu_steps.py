@@ -76,13 +76,14 @@ def test_proposed_coteaching_step(dev):
         assert np.median(np.abs(gn[live] - fx[key + 'g1'][live]) / fx[key + 'g1'][live]) < 1e-3
 
 
-@pytest.mark.parametrize('name', ['chaos', 'kidney', 'breast'])
+@pytest.mark.parametrize('name', ['chaos', 'kidney', 'breast', 'prostate'])
 def test_proposed_step_variants_g20(dev, name):
-    """The co-teaching step in the three forms of the reference's nine `*_proposed_*` scripts against fixture g20, which was
+    """The co-teaching step in the four forms of the reference's nine `*_proposed_*` scripts against fixture g20, which was
     produced by EXECUTING the scripts' own loop bodies (oracle/gen_golden.py::g20_proposed_variants):
       chaos   fuseunet, bs 4, train-mode augmentation passes, p^T, keep 2     (trainchaos_proposed_30cases1labeled.py:262-330)
       kidney  UNet, bs 4, eval-mode passes, p^(1/T), keep 2                    (trainkidney_proposed_mask1.py:266-338)
       breast  UNet, bs 8, eval-mode passes, p^(1/T), keep int(bs / 2) = 4      (trainbreast_dataset3_proposed_272cases25labeled.py:258-336)
+      prostate UNet, bs 4, TRAIN-mode passes (no eval() in the step), p^T, keep 2 (trainprostate_proposed_isbi3ttransferisbidx.py:253-327)
     with non-identity flips / rotations through the on-device reverse augmentation.  Index vectors bit-exact (the recorded
     adjacent-loss gaps exceed the per-image loss error tenfold), losses / pseudo labels / weight maps / gradient norms <= 1e-3."""
     from aide_amd.models_twomodalinputs import fuseunet
@@ -119,7 +120,7 @@ def test_proposed_step_variants_g20(dev, name):
     for k in ('pl1', 'pl2', 'wm1', 'wm2'):
         assert np.abs(sub(r[k].cpu().numpy(), 2048) - fx[key + k]).max() < 1e-3, k
     bn = [m for m in n1.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
-    assert int(bn.num_batches_tracked) == int(fx[key + 'nbt']) == (5 if name == 'chaos' else 1)
+    assert int(bn.num_batches_tracked) == int(fx[key + 'nbt']) == (5 if name in ('chaos', 'prostate') else 1)
     assert np.abs(bn.running_mean.cpu().numpy() - fx[key + 'rm']).max() < 1e-5
     for net, gk in ((n1, 'g1'), (n2, 'g2')):
         live = fx[key + gk] > 1e-5
@@ -284,22 +285,40 @@ def test_cli_smoke_default_size(dev):
 
 
 def test_cli_unet_proposed_smoke(dev, tmp_path):
-    """The single-modal co-teaching CLIs (flag tables of trainkidney_proposed_mask1.py:28-60 and
-    trainbreast_dataset3_proposed_272cases25labeled.py): --model1_name / --model2_name, eval-mode augmentation passes,
-    p^(1/T), keep 2 resp. int(batch_size / 2)."""
-    from aide_amd.train_files import trainkidney_proposed_mask1 as K, trainbreast_dataset3_proposed_272cases25labeled as B
-    a = K.parse_args([])
-    assert (a.model1_name, a.model2_name, a.img_size, a.lr, a.repetition) == ('UNet', 'UNet', 512, 1e-5, 100)
-    b = B.parse_args([])
-    assert (b.img_size, b.repetition, b.checkpoint) == (384, 1, 'checkpoint_breastdata3_proposed272cases25labels')
-    for mod, bs in ((K, 2), (B, 4)):
-        args = mod.parse_args(['--batch_size', str(bs), '--img_size', '64', '--num_epoch', '2', '--steps_per_epoch', '2',
-                               '--warmup_epoch', '2', '--temperature', '0.5', '--checkpoint', str(tmp_path / mod.__name__)])
+    """The single-modal co-teaching CLIs (flag tables of trainkidney_proposed_mask1.py:28-60,
+    trainbreast_dataset3_proposed_272cases25labeled.py and trainprostate_proposed_isbi3ttransferisbidx.py:26-58): eval-mode
+    augmentation passes + p^(1/T) (kidney, breast) or train-mode passes + p^T (prostate), keep 2 resp. int(batch_size / 2); the
+    kidney script initialises BOTH networks from --resumefile (:180-182); best checkpoints under the reference's file names
+    (kidney / breast :173-176, :451, :461; prostate :173-174, :489-503)."""
+    import oracle
+    from aide_amd.train_files import (trainkidney_proposed_mask1 as K, trainbreast_dataset3_proposed_272cases25labeled as B,
+                                      trainprostate_proposed_isbi3ttransferisbidx as P)
+    torch.manual_seed(11)
+    init = oracle.UNet(2).state_dict()                       # a checkpoint as the reference's UNet writes it
+    resume = str(tmp_path / 'init.pkl')
+    torch.save({'net': init, 'loss': 0.0, 'epoch': 1}, resume)
+    for mod, bs in ((K, 2), (B, 4), (P, 2)):
+        ck = tmp_path / mod.__name__.split('.')[-1]
+        args = mod.parse_args(['--batch_size', str(bs), '--img_size', '64', '--num_epoch', '2', '--steps_per_epoch', '2', '--lr', '0.0',
+                               '--warmup_epoch', '2', '--temperature', '0.5', '--checkpoint', str(ck)] +
+                              (['--resumefile', resume] if mod is K else []))
         n1, n2 = mod.Train(args)
         assert all(torch.isfinite(p).all() for p in list(n1.parameters()) + list(n2.parameters()))
         assert n1.training and n2.training
+        if mod is K:                                         # lr 0: both networks still hold the resumed weights
+            for net in (n1, n2):
+                sd = net.state_dict()
+                assert all(torch.equal(sd[k].cpu(), init[k]) for k in init if 'running_' not in k and 'num_batches' not in k)
+        files = sorted(os.listdir(str(ck))) if os.path.isdir(str(ck)) else []
+        if mod is P:
+            want = ['UNet_temp0.5_r100_net1_besttraincasedice.pkl', 'UNet_temp0.5_r100_net2_besttraincasedice.pkl']
+        else:
+            want = ['UNet_warmup2_temp0.5_r%d_net%d_besttraindice.pkl' % (args.repetition, k) for k in (1, 2)]
+        assert files in ([], want), files                   # (best starts at 0.0: a case Dice of 0 writes nothing)
     with pytest.raises(ValueError, match='Model not implemented'):
         K.Train(K.parse_args(['--model1_name', 'fuseunet']))
+    with pytest.raises(ValueError, match='Model not implemented'):
+        P.Train(P.parse_args(['--model_name', 'fuseunet']))
 
 
 def test_cli_proposed_smoke(dev, tmp_path):

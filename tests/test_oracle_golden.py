@@ -414,7 +414,7 @@ def test_g19_reverseaug_and_sharpen_pinned_to_reference_text():
         assert torch.equal(losses.sharpen_root(p.clone(), T), torch.from_numpy(fx['sharpen/pow_invT_%g' % T]))
 
 
-G20 = {'chaos': (True, None), 'kidney': (False, None), 'breast': (False, None)}
+G20 = {'chaos': (True, None), 'kidney': (False, None), 'breast': (False, None), 'prostate': (False, None)}
 
 
 def g20_case(fx, name):
@@ -432,11 +432,12 @@ def g20_case(fx, name):
                 augset=augset, n=n, temp=temp, keep=keep, eval_aug=bool(eval_aug), rate=rate, two_modal=nin == 2)
 
 
-@pytest.mark.parametrize('name', ['chaos', 'kidney', 'breast'])
+@pytest.mark.parametrize('name', ['chaos', 'kidney', 'breast', 'prostate'])
 def test_g20_proposed_step_variants(name):
-    """oracle.steps.proposed_step in the three forms of the reference's `*_proposed_*` scripts against what the scripts' OWN
+    """oracle.steps.proposed_step in the four forms of the reference's `*_proposed_*` scripts against what the scripts' OWN
     loop bodies produced (gen_golden.g20_proposed_variants executes them from the syntax tree with the imported reference
-    modules): fuseunet / train-mode passes / p^T / keep 2; UNet / eval-mode passes / p^(1/T) / keep 2; UNet, bs 8, keep 4."""
+    modules): fuseunet / train-mode passes / p^T / keep 2; UNet / eval-mode passes / p^(1/T) / keep 2; UNet, bs 8, keep 4;
+    UNet / train-mode passes / p^T / keep 2 (the prostate scripts: no eval() in the step)."""
     import warnings
     from oracle import losses
     fx = load('g20_proposed_variants.npz')
@@ -455,7 +456,7 @@ def test_g20_proposed_step_variants(name):
                                 c['xs'][0], c['xs'][1] if c['two_modal'] else None, c['augs'], c['t1'], c['t2'], c['rate'],
                                 temperature=c['temp'], reverse=lambda lst: steps.reverseaug(c['augset'], lst, 2),
                                 keep=c['keep'], eval_aug=c['eval_aug'],
-                                sharpen_fn=losses.sharpen if name == 'chaos' else losses.sharpen_root)
+                                sharpen_fn=losses.sharpen if name in ('chaos', 'prostate') else losses.sharpen_root)
     assert r['indx1'].tolist() == fx[key + 'indx1'].tolist()
     assert r['indx2'].tolist() == fx[key + 'indx2'].tolist()
     close(r['loss1'], fx[key + 'loss1'], rtol=1e-4)
@@ -464,5 +465,5 @@ def test_g20_proposed_step_variants(name):
     close(sub(r['pl1'], 2048), fx[key + 'pl1'], rtol=1e-4)
     close(sub(r['wm2'], 2048), fx[key + 'wm2'], rtol=1e-4)
     bn = [m for m in n1.modules() if isinstance(m, torch.nn.BatchNorm2d)][0]
-    assert int(bn.num_batches_tracked) == int(fx[key + 'nbt']) == (5 if name == 'chaos' else 1)   # eval-mode passes update nothing
+    assert int(bn.num_batches_tracked) == int(fx[key + 'nbt']) == (5 if name in ('chaos', 'prostate') else 1)   # eval-mode passes update nothing
     assert n1.training and n2.training
