@@ -546,7 +546,7 @@ __device__ __forceinline__ void slab_sum_q(const SlabSrc& sl, const long (&off)[
             for (int e = 0; e < V; ++e) o[k][e] = 0.f;
         }
     }
-#pragma unroll(Q <= 2 ? 2 : 1)
+#pragma unroll(Q * V <= 8 ? 4 : Q <= 2 ? 2 : 1)
     for (int s = 1; s < sl.splitk; ++s) {
         float t[Q][V];
 #pragma unroll
@@ -771,7 +771,8 @@ constexpr int BN_COOP_MIN_WGS = 1024;          // workgroups a launch should hav
 // C5 465 / 491 / 501 / 504 / 504 (bf16 storage: half the bytes in flight per value).
 constexpr long BN_ONEPASS_MAX_VALUES = 34L << 20, BN_ONEPASS_MAX_VALUES_NARROW = 9L << 20;
 __host__ inline bool coop_plan(int N, int C, int HW, bool mod8, CoopPlan& p, bool narrow = false) {
-    p.V = (mod8 && HW % 8 == 0) ? 8 : 4;
+    // (a channel of fewer than 2048 values: units of 4, so that all 256 threads of its workgroup hold one)
+    p.V = (mod8 && HW % 8 == 0 && (long)N * HW >= 2048) ? 8 : 4;
     if ((long)N * C * HW > (narrow ? BN_ONEPASS_MAX_VALUES_NARROW : BN_ONEPASS_MAX_VALUES)) return false;
     if (HW % p.V || (long)N * HW / p.V > (long)BN_MAX_S * 256 * 8) return false;
     const int units = N * HW / p.V;

@@ -34,6 +34,7 @@ struct G4Args {
     int N, Co, Ci, H, W;
     int rows_t, cols_c, n_co_tiles, n_ci_tiles, splits, chunks_total;
     int gco, gci;        // XCD group: gco x gci neighbouring (co, ci) tiles are consecutive logical blocks (see the launcher)
+    int b_off;           // first logical block of this launch (a layer of >= 2 x target blocks runs as several launches)
 };
 
 constexpr int G4_NAGPR = 16;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad4_kernel(const G4Args g) 
     // xcd_remap gives every XCD a contiguous range of logical blocks; inside a pixel split they are ordered by RECTANGLES of
     // gco x gci tiles, so the workgroups of one XCD (which run in step: same chunk count) re-use gco slices of dz and gci
     // slices of the input from their private L2 instead of one dz slice and every input slice
-    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = g.b_off + xcd_remap(blockIdx.x, gridDim.x);
     const int per_split = g.n_co_tiles * g.n_ci_tiles;
     const int split = b / per_split, rb = b - split * per_split;
     const int gsz = g.gco * g.gci, grp = rb / gsz, within = rb - grp * gsz;
@@ -463,8 +464,15 @@ int aide_conv3x3_wgrad_wino4_t(const float* dz, int64_t dz_bs, const float* a, i
     // rectangle COLUMN that needs it, every input slice (1.5x with its halo rows) once per rectangle ROW:
     //   bytes ~ |dz| * n_ci / gci + 1.5 |x| * n_co / gco,  gco * gci <= blocks per XCD  ->  2 / gci + 1.5 / gco minimal.
     // (ci-fastest order = a 1 x n_ci rectangle read 1024->512 @32x32's input 8 times: 208 MB of fetches for 34 MB of operands.)
+    // A layer with >= 2 x target (co, ci) tiles (1024 -> 512: 256 tiles; the 1024-channel layers of the U-Net: 512) puts a
+    // 144 KB workgroup on EVERY CU and the main stream's kernels wait for CUs meanwhile (~100 us stalls of the dependent chain
+    // at 4.80 / 4.92 ms of the C2 step, profiles/r06_timeline_c2.txt).  Running such a layer as consecutive launches of
+    // `target` workgroups (b_off) was built and measured in round 6 -- same-box step A/B, split / one launch: C2 614.7 / 627.5,
+    // C4 382.1 / 397.3, C3 155.0 / 155.7 images/s (profiles/r06_wgrad4_split_ab.txt): the stall costs less than the second
+    // launch's ramp and the halved rate of these, the most efficient, layers.  One launch.
+    const long per_launch = nb;
     {
-        const long per_xcd = nb / 8 > 0 ? nb / 8 : 1;
+        const long per_xcd = per_launch / 8 > 0 ? per_launch / 8 : 1;
         int bco = 1, bci = g.n_ci_tiles;
         double best = 1e30;
         for (int gco = 1; gco <= g.n_co_tiles; ++gco) {
@@ -477,8 +485,12 @@ int aide_conv3x3_wgrad_wino4_t(const float* dz, int64_t dz_bs, const float* a, i
         }
         g.gco = bco; g.gci = bci;
     }
-    AIDE_LAUNCH_TIMED(AIDE_KT_WGRAD4, AIDE_CONV_FLOPS(N, H, W, Co, Ci), conv3x3_wgrad4_kernel, dim3((unsigned)nb), dim3(256),
-                      G4_LDS * sizeof(float), stream, g);
+    for (long off = 0; off < nb; off += per_launch) {
+        const long cnt = nb - off < per_launch ? nb - off : per_launch;
+        g.b_off = (int)off;
+        AIDE_LAUNCH_TIMED(AIDE_KT_WGRAD4, AIDE_CONV_FLOPS(N, H, W, Co, Ci) * (double)cnt / (double)nb, conv3x3_wgrad4_kernel,
+                          dim3((unsigned)cnt), dim3(256), G4_LDS * sizeof(float), stream, g);
+    }
     const int rc = aide_launch_status();
     if (rc != 0) return rc;
     return aide_wgrad_reduce_launch(ws, g.splits, Co, Ci, dw, queue, stream);

@@ -160,6 +160,11 @@ def conv_mode(cfg, n, cin, h, w, cout):
     return 2 if use_winograd(cfg, n, cin, h, w, cout) else 0
 
 
+# layer -> weight-gradient algorithm, for measurement only (tools/r6_wgrad_choice.py): {(cout, cin, h, w): 2 | 4}.  Empty in
+# the product: the static rule in Plan.__init__ decides.
+WGRAD_OVERRIDE = {}
+
+
 def use_winograd(cfg, n, cin, h, w, cout):
     """Static (deterministic) choice between the Winograd and the direct conv kernel: the layer sweep
     (tools/bench_conv.py all) has Winograd ahead on every layer shape it supports (1.2x-1.9x; the one
@@ -306,6 +311,7 @@ class Plan(object):
                         st['wino_w'] = BF16
                         st['wg_bytes'] = lib.aide_conv3x3_wgrad_bf16_ws_bytes(n, cout, cin, hh, ww, 0)
                     elif cfg.use_winograd and cfg.use_winograd4 and (cout % 64 == 0 or cfg.w4_half_tile) and \
+                            WGRAD_OVERRIDE.get((cout, cin, hh, ww), 4) == 4 and \
                             lib.aide_conv3x3_wgrad_wino4_supported(cout, cin, hh, ww):
                         # (a trailing half tile -- 32->32 @256x256 -- is 71 -> 56 us alone.  In round 2 the step lost 0.5 % with it:
                         # the 144 KB workgroups kept the main stream's kernels off the CUs; with the backward pass as it is now

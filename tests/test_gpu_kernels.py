@@ -128,6 +128,28 @@ def test_bn_relu_fwd_bwd(dev, shape):
     assert dbias.abs().max().item() < 1e-3      # mathematically zero (dead conv bias)
 
 
+def test_bn_more_planes_than_a_grid_dimension(dev):
+    """N * C >= 65536 planes (a stacked batch of 4 x 33 images at C = 512 on the deepest level): the plane index of the BatchNorm
+    apply kernels rides on gridDim.x, the one-pass kernels take channels * splits workgroups -- every form against aten"""
+    from aide_amd import ops
+    n, c, h, w = 132, 512, 2, 2
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(n, c, h, w, generator=g)
+    bn = torch.nn.BatchNorm2d(c)
+    bn.train()
+    ar = F.relu(bn(z))
+    zd = z.to(dev)
+    st = [torch.empty(c, device=dev) for _ in range(4)]
+    a = torch.empty_like(zd)
+    ops.bn_train_fwd(zd, a, torch.ones(c, device=dev), torch.zeros(c, device=dev), 1e-5, 0.1, torch.zeros(c, device=dev),
+                     torch.ones(c, device=dev), torch.zeros((), dtype=torch.int64, device=dev), st[0], st[1], st[2], st[3],
+                     ops.bn_ws(c, dev), True)
+    _close(a, ar, what='train forward')
+    a2 = torch.empty_like(zd)
+    ops.bn_relu_apply(zd, a2, st[2], st[3], True)          # grid = (planes, chunks)
+    assert torch.equal(a, a2)
+
+
 @pytest.mark.parametrize('shape', [(8, 64, 256, 256), (4, 128, 64, 64), (3, 8, 20, 20)])
 def test_bn_relu_bwd_completion_event(dev, shape):
     """`done` of aide_bn_relu_bwd*: an event recorded when dz is complete, attached to the call's last dispatch (two-pass,
@@ -237,7 +259,8 @@ def test_maxpool_ties_and_backward(dev):
 
 
 @pytest.mark.parametrize('shape', [(2, 8, 16, 16), (1, 4, 20, 12), (2, 3, 1, 1),
-                                   (1, 3, 64, 64), (2, 2, 16, 128), (1, 2, 48, 192)])      # whole 32 x 128 output tiles
+                                   (1, 3, 64, 64), (2, 2, 16, 128), (1, 2, 48, 192),      # whole 32 x 128 output tiles
+                                   (132, 512, 2, 2)])      # 67 584 planes: more than gridDim.y holds (a stacked batch at C = 512)
 def test_upsample_bilinear(dev, shape):
     from aide_amd import ops
     n, c, h, w = shape
@@ -255,7 +278,7 @@ def test_upsample_bilinear(dev, shape):
     _close(dx, xr.grad, rtol=1e-5, what='upsample bwd')
     # the tiled backward reads aligned 16-byte pieces when it can: a gradient that starts 4 bytes into an allocation takes
     # the other loader and must give the same values bit for bit, as must the accumulating form on top of ones
-    if (2 * w) % 2 == 0 and n * c <= 65535:
+    if (2 * w) % 2 == 0:
         raw = torch.empty(dy.numel() + 4, device=dev)
         dyo = raw[1:1 + dy.numel()].view(dy.shape)
         dyo.copy_(dy.to(dev))

@@ -40,6 +40,8 @@ G4_FRAG = "            if (w == 0 && gq + 2 < 9) frag(gq + 2, (gq + 2) % 3);\n"
 # name -> (source file, [(old, new), ...])
 BN_LIM = 'constexpr long BN_ONEPASS_MAX_VALUES = 34L << 20, BN_ONEPASS_MAX_VALUES_NARROW = 9L << 20;'
 PROBES = {
+    # round 6: layers of >= 256 (co, ci) tiles as consecutive half-chip launches instead of one whole-chip launch (measured: loses)
+    'g4_split': ('conv3x3_wgrad4.hip', [("    const long per_launch = nb;\n", "    const long target = target_wgs > 0 ? target_wgs : 128;\n    const long per_launch = (target < 256 && nb >= 2 * target) ? target : nb;\n")]),
     # one-pass BatchNorm only below a tensor size (round 6): 0 = the two-pass kernels everywhere
     'bn_2pass': ('bn.hip', [(BN_LIM, 'constexpr long BN_ONEPASS_MAX_VALUES = 0, BN_ONEPASS_MAX_VALUES_NARROW = 0;')]),
     'bn_lim8m': ('bn.hip', [(BN_LIM, 'constexpr long BN_ONEPASS_MAX_VALUES = 9L << 20, BN_ONEPASS_MAX_VALUES_NARROW = 9L << 20;')]),
