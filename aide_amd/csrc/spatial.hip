@@ -245,14 +245,19 @@ __device__ __forceinline__ int up_bwd_weights(int i, int in_size, int out_size, 
 // 2 W0 - 2) -- 3 / 5 loads per thread instead of ten 4- / 8-byte ones, and one ds_write_b128 / two ds_write_b64 each: the
 // kernel is a stream of the destination tensor and spends most of its life beside the weight gradient on a quarter of the
 // CUs, where the bytes a wave has in flight are what it gets done.
+// Round 6: a workgroup owns ONE tile position and walks the planes plane0, plane0 + pstep, ... with it: the tap-weight
+// tables are built once per workgroup instead of once per tile, and the window of the NEXT plane is loaded into registers
+// while the two passes of the current one run (the kernel lives beside the weight gradient on the CUs that one leaves: what
+// a wave has in flight there is what it gets done -- one tile per workgroup streamed 1.0 TB/s in the C2 step, 0.5 in C5).
 template <typename GT, typename DT, bool FAST>
 __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const GT* __restrict__ dy, long dy_bs,
                                                                    DT* __restrict__ dx, long dx_bs, int C, int H,
-                                                                   int W, int tiles_w, int tiles, int accumulate) {
+                                                                   int W, int tiles_w, int tiles, int planes, int pstep,
+                                                                   int accumulate) {
     constexpr int HW2 = UB_RW / 2;                          // 66 column pairs
     // bf16-stored gradients keep their two bytes in the window: one packed word per column pair instead of two floats --
     // 21 KB of LDS per workgroup instead of 31 KB, i.e. seven resident workgroups per CU instead of five (and more of them
-    // beside the weight-gradient workgroups of the side stream, where this kernel ran at 1.3 TB/s)
+    // beside the weight-gradient workgroups of the side stream)
     constexpr bool PK = sizeof(GT) == 2;
     constexpr int CPX = PK ? 8 : 4;                         // FAST: pixels per 16-byte piece
     constexpr int LEAD = PK ? 6 : 2;                        //       the aligned range starts LEAD pixels left of the window
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const GT* __r
     const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     const int tid = threadIdx.x;
     // 1-D grid, tile index fastest (gridDim.y would stop at 65535 planes: a stacked batch of 4 x 32 images at C = 512)
-    const int plane = blockIdx.x / tiles, tile = blockIdx.x - plane * tiles, n = plane / C, c = plane - n * C;
+    const int plane0 = blockIdx.x / tiles, tile = blockIdx.x - plane0 * tiles;
     const int h0 = (tile / tiles_w) * UB_TH, w0 = (tile % tiles_w) * UB_TW;
     const int R0 = 2 * h0 - 2, C0 = 2 * w0 - 2;            // destination window origin (may be -2, always even)
     const int x = tid & 63, rq = tid >> 6;                  // this thread's source column / first source row
@@ -284,105 +289,115 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled_kernel(const GT* __r
         for (int k = 0; k < 6; ++k) wtab[tid][k] = wt[k];
         otab[tid] = lo - (row ? R0 : C0);
     }
-    // destination window -> LDS (zero outside the plane); 8-byte coalesced loads
-    const GT* g = dy + (long)n * dy_bs + (long)c * Ho * Wo;
-    // all ten loads of a thread are issued before the first LDS store (a load -> wait -> store loop exposed the full
-    // memory latency ten times per workgroup: 0.9 TB/s); out-of-plane elements read a clamped address and are zeroed
+    // the window of one plane as this thread's registers: element offsets inside a destination plane (fixed: the tile does not
+    // move), -1 = outside the plane (reads a clamped address, zeroed).  All loads of a thread are issued before the first LDS
+    // store (a load -> wait -> store loop exposed the full memory latency ten times per workgroup: 0.9 TB/s).
     constexpr int NLD = (UB_RH * HW2 + 255) / 256;
-    if constexpr (FAST) {
-        constexpr int NLF = (UB_RH * NCHK + 255) / 256;
-        u32x4 v[NLF];
+    constexpr int NLF = (UB_RH * NCHK + 255) / 256;
+    constexpr int NV = FAST ? NLF : NLD;
+    int woff[NV];
 #pragma unroll
-        for (int k = 0; k < NLF; ++k) {
-            const int e = tid + k * 256;
+    for (int k = 0; k < NV; ++k) {
+        const int e = tid + k * 256;
+        if constexpr (FAST) {
             const int r = e / NCHK, ck = e - r * NCHK;
             const int oh = R0 + r, ow = C0 - LEAD + ck * CPX;          // (a multiple of CPX, as Wo is: a piece is all in or all out)
-            const bool ok = e < UB_RH * NCHK && oh >= 0 && oh < Ho && ow >= 0 && ow + CPX <= Wo;
-            const u32x4 t = *reinterpret_cast<const u32x4*>(g + (ok ? (long)oh * Wo + ow : 0L));
-            v[k] = ok ? t : u32x4{0u, 0u, 0u, 0u};
+            woff[k] = (e < UB_RH * NCHK && oh >= 0 && oh < Ho && ow >= 0 && ow + CPX <= Wo) ? oh * Wo + ow : -1;
+        } else {
+            const int r = e / HW2, c2 = e - r * HW2;
+            const int oh = R0 + r, ow = C0 + 2 * c2;
+            woff[k] = (e < UB_RH * HW2 && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo) ? oh * Wo + ow : -1;
         }
+    }
+    u32x4 vf[FAST ? NLF : 1];
+    unsigned vp[(!FAST && PK) ? NLD : 1];
+    float2 v2[(!FAST && !PK) ? NLD : 1];
+    auto fetch = [&](int plane) {
+        const int n = plane / C, c = plane - n * C;
+        const GT* g = dy + (long)n * dy_bs + (long)c * Ho * Wo;
 #pragma unroll
-        for (int k = 0; k < NLF; ++k) {
+        for (int k = 0; k < NV; ++k) {
+            const bool ok = woff[k] >= 0;
+            const GT* q = g + (ok ? woff[k] : 0);
+            if constexpr (FAST) {
+                const u32x4 t = *reinterpret_cast<const u32x4*>(q);
+                vf[k] = ok ? t : u32x4{0u, 0u, 0u, 0u};
+            } else if constexpr (PK) {
+                const unsigned t = *reinterpret_cast<const unsigned*>(q);
+                vp[k] = ok ? t : 0u;
+            } else {
+                const f32x2 t = ld2(q);
+                v2[k] = ok ? make_float2(t[0], t[1]) : make_float2(0.f, 0.f);
+            }
+        }
+    };
+    auto put = [&]() {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
             const int e = tid + k * 256;
-            if (e < UB_RH * NCHK) {
-                const int r = e / NCHK, ck = e - r * NCHK;
-                if constexpr (PK) {
-                    *reinterpret_cast<u32x4*>(&tp[r][ck * 4]) = v[k];
-                } else {                                    // (e0, o0, e1, o1) -> even / odd column arrays
-                    *reinterpret_cast<u32x2*>(&te[r][ck * 2]) = u32x2{v[k][0], v[k][2]};
-                    *reinterpret_cast<u32x2*>(&to[r][ck * 2]) = u32x2{v[k][1], v[k][3]};
+            if constexpr (FAST) {
+                if (e < UB_RH * NCHK) {
+                    const int r = e / NCHK, ck = e - r * NCHK;
+                    if constexpr (PK) {
+                        *reinterpret_cast<u32x4*>(&tp[r][ck * 4]) = vf[k];
+                    } else {                                    // (e0, o0, e1, o1) -> even / odd column arrays
+                        *reinterpret_cast<u32x2*>(&te[r][ck * 2]) = u32x2{vf[k][0], vf[k][2]};
+                        *reinterpret_cast<u32x2*>(&to[r][ck * 2]) = u32x2{vf[k][1], vf[k][3]};
+                    }
+                }
+            } else if constexpr (PK) {
+                if (e < UB_RH * HW2) tp[e / HW2][e % HW2] = vp[k];
+            } else {
+                if (e < UB_RH * HW2) {
+                    const int r = e / HW2, c2 = e - r * HW2;
+                    te[r][c2] = v2[k].x; to[r][c2] = v2[k].y;
                 }
             }
         }
-    } else if constexpr (PK) {
-        unsigned v[NLD];
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = tid + k * 256;
-            const int r = e / HW2, c2 = e - r * HW2;
-            const int oh = R0 + r, ow = C0 + 2 * c2;
-            const bool ok = e < UB_RH * HW2 && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
-            const unsigned t = *reinterpret_cast<const unsigned*>(g + (ok ? (long)oh * Wo + ow : 0L));
-            v[k] = ok ? t : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = tid + k * 256;
-            if (e < UB_RH * HW2) tp[e / HW2][e % HW2] = v[k];
-        }
-    } else {
-        float2 v[NLD];
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = tid + k * 256;
-            const int r = e / HW2, c2 = e - r * HW2;
-            const int oh = R0 + r, ow = C0 + 2 * c2;
-            const bool ok = e < UB_RH * HW2 && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
-            const f32x2 t = ld2(g + (ok ? (long)oh * Wo + ow : 0L));
-            v[k] = ok ? make_float2(t[0], t[1]) : make_float2(0.f, 0.f);
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = tid + k * 256;
-            if (e < UB_RH * HW2) {
-                const int r = e / HW2, c2 = e - r * HW2;
-                te[r][c2] = v[k].x; to[r][c2] = v[k].y;
-            }
-        }
-    }
-    __syncthreads();
+    };
+    if (plane0 >= planes) return;
+    fetch(plane0);
+    __syncthreads();                                        // the tables
     float wc[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) wc[k] = wtab[UB_TH + x][k];
     const int oc = otab[UB_TH + x];                         // first candidate column inside the window
-    // column pass: hp[r][x] = sum_l wc[l] * window[r][oc + l]; window column q lives in (q & 1 ? to : te)[r][q >> 1]
     const int q0 = (oc >> 1) + QL;                          // oc is even: candidates start at max(0, 2 i - 2), C0 is even
-    for (int r = rq; r < UB_RH; r += 4) {
-        if constexpr (PK) {
-            const unsigned a = tp[r][q0], b = tp[r][q0 + 1], d = tp[r][q0 + 2];       // (even | odd << 16) column pairs
-            hp[r][x] = wc[0] * __builtin_bit_cast(float, a << 16) + wc[1] * __builtin_bit_cast(float, a & 0xffff0000u) +
-                       wc[2] * __builtin_bit_cast(float, b << 16) + wc[3] * __builtin_bit_cast(float, b & 0xffff0000u) +
-                       wc[4] * __builtin_bit_cast(float, d << 16) + wc[5] * __builtin_bit_cast(float, d & 0xffff0000u);
-        } else {
-            hp[r][x] = wc[0] * te[r][q0] + wc[1] * to[r][q0] + wc[2] * te[r][q0 + 1] + wc[3] * to[r][q0 + 1] +
-                       wc[4] * te[r][q0 + 2] + wc[5] * to[r][q0 + 2];
+    for (int plane = plane0; plane < planes; plane += pstep) {
+        put();
+        __syncthreads();
+        if (plane + pstep < planes) fetch(plane + pstep);   // in flight while this plane's two passes run
+        // column pass: hp[r][x] = sum_l wc[l] * window[r][oc + l]; window column q lives in (q & 1 ? to : te)[r][q >> 1]
+        for (int r = rq; r < UB_RH; r += 4) {
+            if constexpr (PK) {
+                const unsigned a = tp[r][q0], b = tp[r][q0 + 1], d = tp[r][q0 + 2];       // (even | odd << 16) column pairs
+                hp[r][x] = wc[0] * __builtin_bit_cast(float, a << 16) + wc[1] * __builtin_bit_cast(float, a & 0xffff0000u) +
+                           wc[2] * __builtin_bit_cast(float, b << 16) + wc[3] * __builtin_bit_cast(float, b & 0xffff0000u) +
+                           wc[4] * __builtin_bit_cast(float, d << 16) + wc[5] * __builtin_bit_cast(float, d & 0xffff0000u);
+            } else {
+                hp[r][x] = wc[0] * te[r][q0] + wc[1] * to[r][q0] + wc[2] * te[r][q0 + 1] + wc[3] * to[r][q0 + 1] +
+                           wc[4] * te[r][q0 + 2] + wc[5] * to[r][q0 + 2];
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        const int n = plane / C, c = plane - n * C;
 #pragma unroll
-    for (int k4 = 0; k4 < UB_TH / 4; ++k4) {
-        const int r = rq + 4 * k4;
-        float wr[6];
+        for (int k4 = 0; k4 < UB_TH / 4; ++k4) {
+            const int r = rq + 4 * k4;
+            float wr[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) wr[k] = wtab[r][k];     // wave-uniform: LDS broadcast
-        const int o = otab[r];
-        if (h0 + r < H && w0 + x < W) {
-            float a = 0.f;
+            for (int k = 0; k < 6; ++k) wr[k] = wtab[r][k];     // wave-uniform: LDS broadcast
+            const int o = otab[r];
+            if (h0 + r < H && w0 + x < W) {
+                float a = 0.f;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) a += wr[k] * hp[o + k][x];
-            DT* q = dx + (long)n * dx_bs + (long)c * H * W + (long)(h0 + r) * W + w0 + x;
-            st1(q, accumulate ? (ld1(q) + a) : a);
+                for (int k = 0; k < 6; ++k) a += wr[k] * hp[o + k][x];
+                DT* q = dx + (long)n * dx_bs + (long)c * H * W + (long)(h0 + r) * W + w0 + x;
+                st1(q, accumulate ? (ld1(q) + a) : a);
+            }
         }
+        // (the next put() overwrites te / to / tp, which the column pass has left behind the barrier above; hp is rewritten
+        // only after the next put()'s barrier, behind this plane's row pass)
     }
 }
 
@@ -633,6 +648,16 @@ int aide_maxpool2x2_bwd_mixed(const void* x, int x_bf16, int64_t x_bs, const voi
 #undef AIDE_PB
 }
 
+// workgroups of the tiled up-sampling backward per tile position: each walks planes g, g + groups, ... -- about UB_WGS
+// workgroups per launch (five per CU: what its 31 KB of LDS allow)
+constexpr int UB_WGS = 1280;
+static inline int ub_plane_groups(int tiles, int planes) {
+    long g = (UB_WGS + tiles - 1) / tiles;
+    if (g > planes) g = planes;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
 // may the tiled up-sampling backward read its destination rows as aligned 16-byte pieces?  (es = bytes per element)
 static inline bool ub_fast(const void* dy, int64_t dy_bs, int W, int es) {
     const int per = 16 / es;
@@ -664,13 +689,14 @@ int aide_upsample2x_bilinear_bwd(const float* dy, int64_t dy_bs, float* dx, int6
     const double kt_bytes = (double)total * (16.0 + (accumulate ? 8.0 : 4.0));     // 4x the pixels read, dx written (read: accumulate)
     if (dy_bs % 2 == 0) {                                  // 8-byte loads of the destination rows
         const int tw = (W + UB_TW - 1) / UB_TW, th = (H + UB_TH - 1) / UB_TH;
-        const dim3 grid((unsigned)((long)tw * th * N * C));
+        const int pstep = ub_plane_groups(tw * th, N * C);
+        const dim3 grid((unsigned)((long)tw * th * pstep));
         if (ub_fast(dy, dy_bs, W, 4))
             AIDE_LAUNCH_TIMED(AIDE_KT_UPSAMPLE, kt_bytes, (upsample2x_bwd_tiled_kernel<float, float, true>), grid, dim3(256), 0, stream, dy,
-                              (long)dy_bs, dx, (long)dx_bs, C, H, W, tw, tw * th, accumulate);
+                              (long)dy_bs, dx, (long)dx_bs, C, H, W, tw, tw * th, N * C, pstep, accumulate);
         else
             AIDE_LAUNCH_TIMED(AIDE_KT_UPSAMPLE, kt_bytes, (upsample2x_bwd_tiled_kernel<float, float, false>), grid, dim3(256), 0, stream, dy,
-                              (long)dy_bs, dx, (long)dx_bs, C, H, W, tw, tw * th, accumulate);
+                              (long)dy_bs, dx, (long)dx_bs, C, H, W, tw, tw * th, N * C, pstep, accumulate);
         return aide_launch_status();
     }
     AIDE_LAUNCH_TIMED(AIDE_KT_UPSAMPLE, kt_bytes, upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, (long)dy_bs,
@@ -684,14 +710,15 @@ int aide_upsample2x_bilinear_bwd_mixed(const void* dy, int dy_bf16, int64_t dy_b
     if (dy_bs % 2) return AIDE_ERR_ARG;
     const int tw = (W + UB_TW - 1) / UB_TW, th = (H + UB_TH - 1) / UB_TH;
     const bool fast = ub_fast(dy, dy_bs, W, dy_bf16 ? 2 : 4);
-    const dim3 grid((unsigned)((long)tw * th * N * C));
+    const int pstep = ub_plane_groups(tw * th, N * C);
+    const dim3 grid((unsigned)((long)tw * th * pstep));
     const double kt_bytes = (double)N * C * H * W * (4.0 * (dy_bf16 ? 2 : 4) + (accumulate ? 2.0 : 1.0) * (dx_bf16 ? 2 : 4));
 #define AIDE_UB(GT, DT)                                                                                                          \
     do {                                                                                                                         \
         if (fast) AIDE_LAUNCH_TIMED(AIDE_KT_UPSAMPLE, kt_bytes, (upsample2x_bwd_tiled_kernel<GT, DT, true>), grid, dim3(256), 0, stream, \
-                                    (const GT*)dy, (long)dy_bs, (DT*)dx, (long)dx_bs, C, H, W, tw, tw * th, accumulate);           \
+                                    (const GT*)dy, (long)dy_bs, (DT*)dx, (long)dx_bs, C, H, W, tw, tw * th, N * C, pstep, accumulate); \
         else AIDE_LAUNCH_TIMED(AIDE_KT_UPSAMPLE, kt_bytes, (upsample2x_bwd_tiled_kernel<GT, DT, false>), grid, dim3(256), 0, stream, \
-                               (const GT*)dy, (long)dy_bs, (DT*)dx, (long)dx_bs, C, H, W, tw, tw * th, accumulate);                \
+                               (const GT*)dy, (long)dy_bs, (DT*)dx, (long)dx_bs, C, H, W, tw, tw * th, N * C, pstep, accumulate); \
     } while (0)
     if (dy_bf16) { if (dx_bf16) AIDE_UB(bf16_store_t, bf16_store_t); else AIDE_UB(bf16_store_t, float); }
     else { if (dx_bf16) AIDE_UB(float, bf16_store_t); else AIDE_UB(float, float); }

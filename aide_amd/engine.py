@@ -151,7 +151,8 @@ def conv_mode(cfg, n, cin, h, w, cout):
     is supported."""
     if cfg.use_winograd and cfg.use_winograd4 and lib.aide_conv3x3_wino4_supported(cin, h, w, cout) and w != 16:
         # (w == 16: the kernel's image-pair tile is 11 % faster than F(2x2) there, the step 0.6 % slower -- 4x larger
-        # filter pack for the 8 M bottleneck parameters, twice the slabs for BatchNorm to sum)
+        # filter pack for the 8 M bottleneck parameters, twice the slabs for BatchNorm to sum; round 6, with the one-pass
+        # BatchNorm kernels: 622.0 -> 619.6 images/s, same process, tools/r6_ab_config.py)
         flops = 2.0 * n * h * w * cin * cout * 9
         if cout % 64:                       # trailing half block computed and dropped: 42 vs 52 us on 32->32 @256x256 alone,
             return 0                        # level in the step (round 4 again: C2 620.2 / 620.4, C3 155.2 / 155.4)
@@ -598,7 +599,10 @@ class Plan(object):
                         ops.bf16_pack_table(b16, self.dev) if b16 else None)
                 return tabs if any(t is not None for t in tabs) else None
             rest = convs[split:]
-            # (the dgrad-direction packs launched later, under the decoder forward, measured +-0 twice: one launch)
+            # (the dgrad-direction packs launched later, under the decoder forward, measured +-0 twice: one launch.  Round 6: the
+            # whole re-layout of the level >= 2 filters started behind the first level instead of beside it -- the stems and the
+            # 33 MB BatchNorm passes of level 0 run 3-8x slower next to it than alone -- 633.8 -> 629.1 images/s (C2), 398.6 ->
+            # 397.1 (C4): the contention only moves to level 1.  Not kept.)
             rest_tabs = tables(rest, True, True) if rest else None
             cached = (tables(convs[:split]), rest_tabs, convs[split] if rest_tabs is not None else None)
             if len(self._pack_tabs) > 8:

@@ -66,6 +66,8 @@ PROBES = {
     'g4_t144': ('conv3x3_wgrad4.hip', [("target_wgs > 0 ? target_wgs : 128;", "target_wgs > 0 ? target_wgs : 144;")]),
     'g4_t160': ('conv3x3_wgrad4.hip', [("target_wgs > 0 ? target_wgs : 128;", "target_wgs > 0 ? target_wgs : 160;")]),
     # workgroup target of the bf16 weight gradient (its 128-co tile fills a CU: what it leaves is what the main stream gets)
+    'wb_t128': ('conv3x3_bf16.hip', [("const long target = tco == 32 ? 512 : 192;", "const long target = tco == 32 ? 512 : 128;")]),
+    'wb_t144': ('conv3x3_bf16.hip', [("const long target = tco == 32 ? 512 : 192;", "const long target = tco == 32 ? 512 : 144;")]),
     'wb_t160': ('conv3x3_bf16.hip', [("const long target = tco == 32 ? 512 : 192;", "const long target = tco == 32 ? 512 : 160;")]),
     'wb_t176': ('conv3x3_bf16.hip', [("const long target = tco == 32 ? 512 : 192;", "const long target = tco == 32 ? 512 : 176;")]),
     'wb_t208': ('conv3x3_bf16.hip', [("const long target = tco == 32 ? 512 : 192;", "const long target = tco == 32 ? 512 : 208;")]),
