@@ -27,6 +27,7 @@ for w in c2 c5; do
   python tools/traffic_report.py $(find $O/pmc_${tag}_${w}_fetch -name '*counter_collection.csv') $(find $O/pmc_${tag}_${w}_write -name '*counter_collection.csv') 3 \
       $O/${tag}_hbm_traffic_$w.md $O/${tag}_traffic_$w.json "$w step" > /dev/null 2>&1
 done
+for w in c2 c5; do bash tools/r4/gpu_trace.sh $w > /dev/null 2>&1; cp $O/tr_${w}_timeline.txt $O/${tag}_timeline_$w.txt; done
 python tools/phase_trace.py c2 > $O/${tag}_phase_c2.txt 2>&1
 python tools/host_profile.py c2 8 > $O/${tag}_host_c2.txt 2>&1
 ls $O | grep "^${tag}_" | tr '\n' ' '
