@@ -763,7 +763,9 @@ __global__ __launch_bounds__(256) void bn_bwd_coop_kernel(
 // V = 8 whenever the plane and every batch stride are multiples of 8 -- whatever the storage types, so that the bf16-stored
 // and the fp32-stored call partition the channel identically (bit-identical statistics) -- else V = 4.
 struct CoopPlan { int V, Q, S, per; };
-constexpr int BN_COOP_MIN_WGS = 1024;          // workgroups a launch should have before a thread takes more than 8 values
+// Granularity from same-box step A/B (profiles/r06_bn_granularity_ab.txt): values per thread 8 / 16 / 32 / 64 -> C2 619 / 632 / 639 /
+// 630 images/s, C4 390 / 397 / 399 / 397; smallest launch 2048 / 1024 / 512 workgroups -> C2 630 / 632 / 633 (with 32 values: 635).
+constexpr int BN_COOP_MIN_WGS = 512;           // workgroups a launch should have before a thread takes more than 8 values
 // Tensors beyond this many values take the two-pass kernels: the one-pass form keeps the channel in registers, so at most the
 // register file's worth of a tensor (~10 M values) is in flight and every workgroup sits through the exchange (~10 us); on
 // tensors several times that size the two streaming passes win.  Same-box step A/B, limit none / 34 M / 17 M / 9 M / 0
@@ -776,7 +778,7 @@ __host__ inline bool coop_plan(int N, int C, int HW, bool mod8, CoopPlan& p, boo
     if ((long)N * C * HW > (narrow ? BN_ONEPASS_MAX_VALUES_NARROW : BN_ONEPASS_MAX_VALUES)) return false;
     if (HW % p.V || (long)N * HW / p.V > (long)BN_MAX_S * 256 * 8) return false;
     const int units = N * HW / p.V;
-    int q = 16 / p.V, s = (units + 256 * q - 1) / (256 * q);           // 16 values per thread ...
+    int q = 32 / p.V, s = (units + 256 * q - 1) / (256 * q);           // 32 values per thread ...
     while (s > BN_MAX_S && q < 8) { q <<= 1; s = (units + 256 * q - 1) / (256 * q); }
     if (s > BN_MAX_S) return false;
     while (q > 1 && C * s < BN_COOP_MIN_WGS && s * 2 <= BN_MAX_S) { q >>= 1; s = (units + 256 * q - 1) / (256 * q); }   // ... fewer while the launch is small

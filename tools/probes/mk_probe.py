@@ -42,6 +42,14 @@ BN_LIM = 'constexpr long BN_ONEPASS_MAX_VALUES = 34L << 20, BN_ONEPASS_MAX_VALUE
 PROBES = {
     # round 6: layers of >= 256 (co, ci) tiles as consecutive half-chip launches instead of one whole-chip launch (measured: loses)
     'g4_split': ('conv3x3_wgrad4.hip', [("    const long per_launch = nb;\n", "    const long target = target_wgs > 0 ? target_wgs : 128;\n    const long per_launch = (target < 256 && nb >= 2 * target) ? target : nb;\n")]),
+    # one-pass BatchNorm: values per thread (16 shipped) and the launch size below which a thread takes fewer
+    'bn_v32': ('bn.hip', [("int q = 32 / p.V, s = (units + 256 * q - 1) / (256 * q);           // 32 values per thread ...", "int q = 32 / p.V, s = (units + 256 * q - 1) / (256 * q);")]),
+    'bn_v64': ('bn.hip', [("int q = 32 / p.V, s = (units + 256 * q - 1) / (256 * q);           // 32 values per thread ...", "int q = 64 / p.V, s = (units + 256 * q - 1) / (256 * q);")]),
+    'bn_v32w512': ('bn.hip', [("int q = 32 / p.V, s = (units + 256 * q - 1) / (256 * q);           // 32 values per thread ...", "int q = 32 / p.V, s = (units + 256 * q - 1) / (256 * q);"), ("constexpr int BN_COOP_MIN_WGS = 512;", "constexpr int BN_COOP_MIN_WGS = 512;")]),
+    'bn_v64w512': ('bn.hip', [("int q = 32 / p.V, s = (units + 256 * q - 1) / (256 * q);           // 32 values per thread ...", "int q = 64 / p.V, s = (units + 256 * q - 1) / (256 * q);"), ("constexpr int BN_COOP_MIN_WGS = 512;", "constexpr int BN_COOP_MIN_WGS = 512;")]),
+    'bn_v8': ('bn.hip', [("int q = 32 / p.V, s = (units + 256 * q - 1) / (256 * q);           // 32 values per thread ...", "int q = 8 / p.V, s = (units + 256 * q - 1) / (256 * q);")]),
+    'bn_wg2048': ('bn.hip', [("constexpr int BN_COOP_MIN_WGS = 512;", "constexpr int BN_COOP_MIN_WGS = 2048;")]),
+    'bn_wg512': ('bn.hip', [("constexpr int BN_COOP_MIN_WGS = 512;", "constexpr int BN_COOP_MIN_WGS = 512;")]),
     # one-pass BatchNorm only below a tensor size (round 6): 0 = the two-pass kernels everywhere
     'bn_2pass': ('bn.hip', [(BN_LIM, 'constexpr long BN_ONEPASS_MAX_VALUES = 0, BN_ONEPASS_MAX_VALUES_NARROW = 0;')]),
     'bn_lim8m': ('bn.hip', [(BN_LIM, 'constexpr long BN_ONEPASS_MAX_VALUES = 9L << 20, BN_ONEPASS_MAX_VALUES_NARROW = 9L << 20;')]),
