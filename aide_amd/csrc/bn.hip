@@ -456,6 +456,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const GT* __restrict_
 // of older (never waiting) groups are ahead of them.  The spins are bounded anyway: a wait that runs out poisons the result
 // with NaN instead of hanging the queue.
 constexpr int BN_MAX_S = BN_SLOTS;
+// which workgroup of a channel leads: the LAST one (s = S - 1) is dispatched last and tends to finish its loads last -- as the leader it
+// finds the other partials already posted and the broadcast leaves one poll round trip earlier than with s = 0
+constexpr bool BN_LEADER_LAST = true;
+__device__ __forceinline__ int coop_leader(int S) { return BN_LEADER_LAST ? S - 1 : 0; }
 constexpr int BN_SPIN_LIMIT = 1 << 21;
 
 __device__ __forceinline__ void coop_store(double* p, double v) {
@@ -488,7 +492,7 @@ __device__ __forceinline__ bool coop_wait(const double* flag, long long gen) {
 // coop_receive(v0, v1) (thread 0 each).  `ok` turns false when a bounded wait ran out.
 template <int NV>
 __device__ __forceinline__ void coop_gather(double* ws, int c, int s, int S, long long gen, double (&acc)[NV], double* sm, int* okf) {
-    if (s != 0) {
+    if (s != coop_leader(S)) {
         if (threadIdx.x == 0) {
             double* slot = ws_slot(ws, c, s);
 #pragma unroll
@@ -506,7 +510,9 @@ __device__ __forceinline__ void coop_gather(double* ws, int c, int s, int S, lon
 #pragma unroll
         for (int i = 0; i < NV; ++i) t[i] = acc[i];
     } else if ((int)threadIdx.x < S) {
-        const double* slot = ws_slot(ws, c, threadIdx.x);
+        // (thread 0 holds the leader's own partials; thread t > 0 collects the t-th of the other workgroups, in index order)
+        const int other = BN_LEADER_LAST ? (int)threadIdx.x - 1 : (int)threadIdx.x;
+        const double* slot = ws_slot(ws, c, other);
         ok = coop_wait(slot + 3, gen);
 #pragma unroll
         for (int i = 0; i < NV; ++i) t[i] = coop_load(slot + i);
@@ -628,7 +634,7 @@ __global__ __launch_bounds__(256) void bn_fwd_coop_kernel(
         const long long e0 = e0s, gen = e0 + 1 + gi;          // (every thread: block_sum_d synchronised behind thread 0's store)
         if (S > 1) coop_gather<2>(ws, c, s, S, gen, acc, sm, &okf);
         if (threadIdx.x == 0) {
-            if (s == 0) {
+            if (s == coop_leader(S)) {
                 const double mean = acc[0] / count;
                 double var = acc[1] / count - mean * mean;
                 if (var < 0.0) var = 0.0;
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(256) void bn_fwd_coop_kernel(
             stv<V>(a + (n0 + nn[k]) * a_bs + (long)c * HW + pp[k], o);
         }
     }
-    if (S > 1 && s == 0 && threadIdx.x == 0) coop_store_i(ws_chan(ws, c), e0s + groups);
+    if (S > 1 && s == coop_leader(S) && threadIdx.x == 0) coop_store_i(ws_chan(ws, c), e0s + groups);
 }
 
 // SLABS: dA is still in the split-K slabs of the data-gradient convolution that produced it ([split][N][C][HW], fp32):
@@ -734,7 +740,7 @@ __global__ __launch_bounds__(256) void bn_bwd_coop_kernel(
     const long long e0 = e0s;
     if (S > 1) coop_gather<3>(ws, c, s, S, e0 + 1, acc, sm, &okf);
     if (threadIdx.x == 0) {
-        if (s == 0) {
+        if (s == coop_leader(S)) {
             const float c0f = okf ? (float)(acc[0] / count) : __builtin_nanf(""), c1f = (float)(acc[1] / count);
             coef[0] = c0f; coef[1] = c1f;
             if (S > 1) coop_publish(ws, c, e0 + 1, c0f, c1f);
@@ -756,7 +762,7 @@ __global__ __launch_bounds__(256) void bn_bwd_coop_kernel(
         for (int e = 0; e < V; ++e) o[e] = sc * (dy[k][e] - c0 - xh[k][e] * c1);
         stv<V>(dz + (long)nn[k] * dz_bs + (long)c * HW + pp[k], o);
     }
-    if (S > 1 && s == 0 && threadIdx.x == 0) coop_store_i(ws_chan(ws, c), e0 + 1);
+    if (S > 1 && s == coop_leader(S) && threadIdx.x == 0) coop_store_i(ws_chan(ws, c), e0 + 1);
 }
 
 // which one-pass instantiation covers a channel of N * HW values: units of V values, Q per thread, S workgroups per channel.

@@ -50,6 +50,9 @@ PROBES = {
     'bn_v8': ('bn.hip', [("int q = 32 / p.V, s = (units + 256 * q - 1) / (256 * q);           // 32 values per thread ...", "int q = 8 / p.V, s = (units + 256 * q - 1) / (256 * q);")]),
     'bn_wg2048': ('bn.hip', [("constexpr int BN_COOP_MIN_WGS = 512;", "constexpr int BN_COOP_MIN_WGS = 2048;")]),
     'bn_wg512': ('bn.hip', [("constexpr int BN_COOP_MIN_WGS = 512;", "constexpr int BN_COOP_MIN_WGS = 512;")]),
+    'bn_lead0': ('bn.hip', [("constexpr bool BN_LEADER_LAST = true;", "constexpr bool BN_LEADER_LAST = false;")]),
+    'bn_sleep1': ('bn.hip', [("        __builtin_amdgcn_s_sleep(4);\n", "        __builtin_amdgcn_s_sleep(1);\n")]),
+    'bn_sleep16': ('bn.hip', [("        __builtin_amdgcn_s_sleep(4);\n", "        __builtin_amdgcn_s_sleep(16);\n")]),
     # one-pass BatchNorm only below a tensor size (round 6): 0 = the two-pass kernels everywhere
     'bn_2pass': ('bn.hip', [(BN_LIM, 'constexpr long BN_ONEPASS_MAX_VALUES = 0, BN_ONEPASS_MAX_VALUES_NARROW = 0;')]),
     'bn_lim8m': ('bn.hip', [(BN_LIM, 'constexpr long BN_ONEPASS_MAX_VALUES = 9L << 20, BN_ONEPASS_MAX_VALUES_NARROW = 9L << 20;')]),
