@@ -245,39 +245,51 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(
 // and channel, the (scale, shift) pair of tab[group][tab_c][2] at channel offset tab_c0 -- the table the consumer
 // convolution's loader applies (conv3x3_wino4_kernel<.., BNIN>) -- and the running statistics move once per group, in order
 // (the arithmetic of bn_train_apply_kernel's publishing block, bit for bit).  One wave per channel.
-__global__ __launch_bounds__(64) void bn_finalize_groups_kernel(
+__global__ __launch_bounds__(256) void bn_finalize_groups_kernel(
     const float* __restrict__ fparts, int nparts, int pstride, const float* __restrict__ cbias, double count, int groups,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out,
     float* __restrict__ tab, int tab_c, int tab_c0) {
-    const int c = blockIdx.x;
-    for (int gi = 0; gi < groups; ++gi) {
-        double s = 0.0, ss = 0.0;
-        for (int i = threadIdx.x; i < nparts; i += 64) {
-            const f32x2 v = *reinterpret_cast<const f32x2*>(fparts + ((long)c * pstride + (long)gi * nparts + i) * 2);
-            s += (double)v[0];
-            ss += (double)v[1];
-        }
-        s = wave_sum_d(s);
-        ss = wave_sum_d(ss);
-        if (threadIdx.x == 0) {
-            double mean = s / count;
-            double var = ss / count - mean * mean;
-            if (cbias) mean += (double)cbias[c];                     // the sums are of z - bias
-            if (var < 0.0) var = 0.0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-            const float g = gamma ? gamma[c] : 1.0f, bb = beta ? beta[c] : 0.0f;
-            const float sc = g * rstd, sh = bb - (float)mean * sc;
-            *reinterpret_cast<f32x2*>(tab + ((long)gi * tab_c + tab_c0 + c) * 2) = f32x2{sc, sh};
-            if (gi == groups - 1) { mean_out[c] = (float)mean; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh; }
-            if (running_mean) {
-                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
-                running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    // four waves per channel: wave w sums the entries of groups w, w + 4, ... (each group exactly as the one-wave form did: lane i
+    // takes entries i, i + 64, ...), then thread 0 walks the groups in order.  (One wave per channel walking the groups took 45 us
+    // per launch in the co-teaching step: 64 .. 512 waves on the chip, each a chain of dependent loads.)
+    __shared__ double sums[32][2];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int g0 = 0; g0 < groups; g0 += 32) {
+        const int ng = min(32, groups - g0);
+        for (int gi = w; gi < ng; gi += 4) {
+            double s = 0.0, ss = 0.0;
+            for (int i = lane; i < nparts; i += 64) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(fparts + ((long)c * pstride + (long)(g0 + gi) * nparts + i) * 2);
+                s += (double)v[0];
+                ss += (double)v[1];
             }
-            if (c == 0 && nbt) *nbt += 1;
+            s = wave_sum_d(s);
+            ss = wave_sum_d(ss);
+            if (lane == 0) { sums[gi][0] = s; sums[gi][1] = ss; }
         }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int gi = 0; gi < ng; ++gi) {
+                double mean = sums[gi][0] / count;
+                double var = sums[gi][1] / count - mean * mean;
+                if (cbias) mean += (double)cbias[c];                     // the sums are of z - bias
+                if (var < 0.0) var = 0.0;
+                const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+                const float g = gamma ? gamma[c] : 1.0f, bb = beta ? beta[c] : 0.0f;
+                const float sc = g * rstd, sh = bb - (float)mean * sc;
+                *reinterpret_cast<f32x2*>(tab + ((long)(g0 + gi) * tab_c + tab_c0 + c) * 2) = f32x2{sc, sh};
+                if (g0 + gi == groups - 1) { mean_out[c] = (float)mean; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = sh; }
+                if (running_mean) {
+                    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+                    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+                }
+                if (c == 0 && nbt) *nbt += 1;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -453,8 +465,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const GT* __restrict_
 //
 // The waits cannot deadlock: the partners of a workgroup are its index neighbours (< S apart), the hardware dispatches
 // workgroups in index order, so the oldest waiting group's missing members are next in line on their XCDs and only workgroups
-// of older (never waiting) groups are ahead of them.  The spins are bounded anyway: a wait that runs out poisons the result
-// with NaN instead of hanging the queue.
+// of older (never waiting) groups are ahead of them.  Several such kernels at once (the two lanes of a forward pass, the two
+// networks of the co-teaching step): the waiting workgroups of a kernel all belong to its ONE partly dispatched group (< S of them), so
+// k concurrent kernels hold fewer than k * S workgroup slots while they wait -- with S <= 130 on every shape the size rule below admits
+// (<= 36 on the BASELINE shapes) and >= 1024 slots on the chip (4 workgroups per CU at <= 128 VGPRs) there is always room for the
+// missing members once the other kernels on the CUs (which never wait for these) retire.  The spins are bounded anyway: a wait that
+// runs out poisons the result with NaN instead of hanging the queue.
 constexpr int BN_MAX_S = BN_SLOTS;
 // which workgroup of a channel leads: the LAST one (s = S - 1) is dispatched last and tends to finish its loads last -- as the leader it
 // finds the other partials already posted and the broadcast leaves one poll round trip earlier than with s = 0
@@ -1034,7 +1050,7 @@ int aide_bn_finalize_groups(int N, int groups, int C, int H, int W, const float*
     if (!parts || !tab || N < 1 || groups < 1 || C < 1 || nparts < 1 || parts_stride < nparts * groups || tab_c0 < 0 ||
         tab_c0 + C > tab_C || !mean || !rstd || !scale || !shift)
         return AIDE_ERR_ARG;
-    AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, 0.0, bn_finalize_groups_kernel, dim3(C), dim3(64), 0, stream, parts, nparts, parts_stride, conv_bias,
+    AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, 0.0, bn_finalize_groups_kernel, dim3(C), dim3(256), 0, stream, parts, nparts, parts_stride, conv_bias,
                        (double)N * H * W, groups, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
                        mean, rstd, scale, shift, tab, tab_C, tab_c0);
     return aide_launch_status();

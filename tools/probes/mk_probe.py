@@ -50,6 +50,8 @@ PROBES = {
     'bn_v8': ('bn.hip', [("int q = 32 / p.V, s = (units + 256 * q - 1) / (256 * q);           // 32 values per thread ...", "int q = 8 / p.V, s = (units + 256 * q - 1) / (256 * q);")]),
     'bn_wg2048': ('bn.hip', [("constexpr int BN_COOP_MIN_WGS = 512;", "constexpr int BN_COOP_MIN_WGS = 2048;")]),
     'bn_wg512': ('bn.hip', [("constexpr int BN_COOP_MIN_WGS = 512;", "constexpr int BN_COOP_MIN_WGS = 512;")]),
+    'bn_sp4096': ('bn.hip', [("    int s = (int)((2048 + C - 1) / C);", "    int s = (int)((4096 + C - 1) / C);")]),
+    'bn_sp1024': ('bn.hip', [("    int s = (int)((2048 + C - 1) / C);", "    int s = (int)((1024 + C - 1) / C);")]),
     'bn_lead0': ('bn.hip', [("constexpr bool BN_LEADER_LAST = true;", "constexpr bool BN_LEADER_LAST = false;")]),
     'bn_sleep1': ('bn.hip', [("        __builtin_amdgcn_s_sleep(4);\n", "        __builtin_amdgcn_s_sleep(1);\n")]),
     'bn_sleep16': ('bn.hip', [("        __builtin_amdgcn_s_sleep(4);\n", "        __builtin_amdgcn_s_sleep(16);\n")]),
