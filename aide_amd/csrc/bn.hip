@@ -100,6 +100,15 @@ struct SlabSrc {
     long split_stride, slab_bs;       // elements between splits / between images inside a slab
     int splitk;
 };
+// The gradient of a 2x2 max-pooling of this layer's activation, folded into its BatchNorm backward (round 6): the layer's dA is
+// dA (the other readers' gradient, e.g. the decoder's skip path) + the pooled gradient routed to the arg-max of every window -- the
+// activation is recomputed from z (the same fmaf + max as the forward pass: bit-identical), first maximum in row-major window order as
+// nn.MaxPool2d's backward picks it.  pdy: [N][C][H/2][W/2] fp32 at this layer's channel 0, batch stride pdy_bs.
+struct PoolSrc {
+    const float* pdy;
+    long pdy_bs;
+    int W;
+};
 template <int V> __device__ __forceinline__ void slab_sum(const SlabSrc& sl, long off, int c, float (&o)[V]) {
     ldv<V>(sl.slabs + off, o);
     for (int s = 1; s < sl.splitk; ++s) {
@@ -687,12 +696,12 @@ __global__ __launch_bounds__(256) void bn_fwd_coop_kernel(
 
 // SLABS: dA is still in the split-K slabs of the data-gradient convolution that produced it ([split][N][C][HW], fp32):
 // the kernel sums them itself in the order of the split reduce (s = 0, 1, ...) -- that launch and its pass disappear.
-template <int V, int Q, typename ZT, typename DT, typename GT, bool SLABS>
+template <int V, int Q, typename ZT, typename DT, typename GT, bool SLABS, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_coop_kernel(
     const GT* __restrict__ dA, long d_bs, const ZT* __restrict__ z, long z_bs, DT* __restrict__ dz, long dz_bs, int N, int C,
     int HW, int S, int per, double count, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ scale, const float* __restrict__ shift, int relu, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, float* __restrict__ dbias, const SlabSrc sl, double* __restrict__ ws) {
+    float* __restrict__ dbeta, float* __restrict__ dbias, const SlabSrc sl, double* __restrict__ ws, const PoolSrc pl) {
     __shared__ double sm[3 * 4];
     __shared__ float coef[2];
     __shared__ int okf;
@@ -735,6 +744,34 @@ __global__ __launch_bounds__(256) void bn_bwd_coop_kernel(
             else {
 #pragma unroll
                 for (int e = 0; e < V; ++e) dy[k][e] = 0.f;
+            }
+        }
+    }
+    if constexpr (POOL) {
+        // (V = 8, W % 8 == 0: a unit lies in one image row and covers four windows' columns; the partner row comes from L1 / L2 --
+        // its own thread is 32 .. 40 units away)
+        static_assert(V == 8, "pool-fused backward: units of 8");
+#pragma unroll
+        for (int k = 0; k < Q; ++k) if (on[k]) {
+            const int row = pp[k] / pl.W, col = pp[k] - row * pl.W;
+            const bool lower = row & 1;
+            float zp[V], g4[4];
+            ldv<V>(z + (long)nn[k] * z_bs + (long)c * HW + pp[k] + (lower ? -pl.W : pl.W), zp);
+            ldv<4>(pl.pdy + (long)nn[k] * pl.pdy_bs + (long)c * (HW >> 2) + (row >> 1) * (pl.W >> 1) + (col >> 1), g4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float o0 = fmaf(xh[k][2 * j], sc, sh), o1 = fmaf(xh[k][2 * j + 1], sc, sh);
+                float q0 = fmaf(zp[2 * j], sc, sh), q1 = fmaf(zp[2 * j + 1], sc, sh);
+                if (relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); q0 = fmaxf(q0, 0.f); q1 = fmaxf(q1, 0.f); }
+                const float t0 = lower ? q0 : o0, t1 = lower ? q1 : o1, b0 = lower ? o0 : q0, b1 = lower ? o1 : q1;
+                int idx = 0;
+                float m = t0;
+                if (t1 > m) { m = t1; idx = 1; }
+                if (b0 > m) { m = b0; idx = 2; }
+                if (b1 > m) { m = b1; idx = 3; }
+                const int mine = lower ? 2 : 0;
+                if (idx == mine) dy[k][2 * j] += g4[j];
+                else if (idx == mine + 1) dy[k][2 * j + 1] += g4[j];
             }
         }
     }
@@ -926,7 +963,7 @@ int bn_relu_bwd_t(const GT* dA, int64_t d_bs, const ZT* z, int64_t z_bs, DT* dz,
 #define AIDE_BN_BC(VV, QQ)                                                                                                    \
             AIDE_LAUNCH_DONE_TIMED(AIDE_KT_BN_BWD, kt_bytes, done, (bn_bwd_coop_kernel<VV, QQ, ZT, DT, GT, false>), dim3(C * cp.S), dim3(256), 0, \
                              stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, cp.S, cp.per, count, mean,     \
-                             rstd, scale, shift, relu, dgamma, dbeta, dbias, SlabSrc{}, (double*)ws)
+                             rstd, scale, shift, relu, dgamma, dbeta, dbias, SlabSrc{}, (double*)ws, PoolSrc{})
 #define AIDE_BN_BQ(VV) do { if (cp.Q == 1) AIDE_BN_BC(VV, 1); else if (cp.Q == 2) AIDE_BN_BC(VV, 2); else if (cp.Q == 4) AIDE_BN_BC(VV, 4); else AIDE_BN_BC(VV, 8); } while (0)
             if (cp.V == 8) AIDE_BN_BQ(8); else AIDE_BN_BQ(4);
 #undef AIDE_BN_BQ
@@ -1125,11 +1162,41 @@ int aide_bn_relu_bwd_slabs(const float* slabs, int splitk, int64_t split_stride,
 #define AIDE_BN_BS(VV, QQ)                                                                                                    \
     AIDE_LAUNCH_DONE_TIMED(AIDE_KT_BN_BWD, (double)N * C * HW * (4.0 * splitk + 8.0), done, (bn_bwd_coop_kernel<VV, QQ, float, float, float, true>), dim3(C * cp.S), dim3(256), 0, stream, \
                      (const float*)nullptr, 0L, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, cp.S, cp.per, (double)N * HW, mean, \
-                     rstd, scale, shift, relu, dgamma, dbeta, dbias, sl, (double*)ws)
+                     rstd, scale, shift, relu, dgamma, dbeta, dbias, sl, (double*)ws, PoolSrc{})
 #define AIDE_BN_BQ(VV) do { if (cp.Q == 1) AIDE_BN_BS(VV, 1); else if (cp.Q == 2) AIDE_BN_BS(VV, 2); else if (cp.Q == 4) AIDE_BN_BS(VV, 4); else AIDE_BN_BS(VV, 8); } while (0)
     if (cp.V == 8) AIDE_BN_BQ(8); else AIDE_BN_BQ(4);
 #undef AIDE_BN_BQ
 #undef AIDE_BN_BS
+    return aide_launch_status();
+}
+
+// Backward of relu(bn(z)) whose activation also fed a MaxPool2d(2, 2): dA (the gradient from the activation's other readers, fp32) +
+// the pooled gradient pdy [N][C][H/2][W/2] routed to every window's arg-max -- the max-pooling backward never runs as a pass of its
+// own.  fp32 storage, one-pass shapes with units of 8 (aide_bn_relu_bwd_pool_supported).
+int aide_bn_relu_bwd_pool_supported(int N, int C, int H, int W) {
+    CoopPlan cp;
+    return (H % 2 == 0 && W % 8 == 0 && coop_plan(N, C, H * W, true, cp) && cp.V == 8) ? 1 : 0;
+}
+
+int aide_bn_relu_bwd_pool(const float* dA, int64_t d_bs, const float* pdy, int64_t pdy_bs, const float* z, int64_t z_bs, float* dz,
+                          int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
+                          const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws, void* done,
+                          hipStream_t stream) {
+    const int HW = H * W;
+    CoopPlan cp;
+    if (!dA || !pdy || !z || !dz || !ws || !aide_bn_relu_bwd_pool_supported(N, C, H, W) || z_bs % 8 || d_bs % 8 || dz_bs % 8 ||
+        pdy_bs % 4 || !coop_plan(N, C, HW, true, cp))
+        return AIDE_ERR_ARG;
+    PoolSrc pl;
+    pl.pdy = pdy; pl.pdy_bs = pdy_bs; pl.W = W;
+    // dA, z read once, dz written once, the pooled gradient read once (the partner rows of z come from cache)
+    const double kt_bytes = (double)N * C * HW * 12.0 + (double)N * C * (HW / 4) * 4.0;
+#define AIDE_BN_BP(QQ)                                                                                                        \
+    AIDE_LAUNCH_DONE_TIMED(AIDE_KT_BN_BWD, kt_bytes, done, (bn_bwd_coop_kernel<8, QQ, float, float, float, false, true>),     \
+                           dim3(C * cp.S), dim3(256), 0, stream, dA, (long)d_bs, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, cp.S, \
+                           cp.per, (double)N * HW, mean, rstd, scale, shift, relu, dgamma, dbeta, dbias, SlabSrc{}, (double*)ws, pl)
+    if (cp.Q == 1) AIDE_BN_BP(1); else if (cp.Q == 2) AIDE_BN_BP(2); else if (cp.Q == 4) AIDE_BN_BP(4); else AIDE_BN_BP(8);
+#undef AIDE_BN_BP
     return aide_launch_status();
 }
 

@@ -121,6 +121,7 @@ class EngineConfig(object):
         grouped_bn=True,            # stacked plans: BatchNorm of all groups in one launch sequence
         lazy_bn=True,               # forward-only stacked plans: BatchNorm + ReLU of a layer in its reader's loader
         direct_grads=_os.environ.get('AIDE_DIRECT_GRADS', '1') != '0',   # parameter gradients assigned by the engine
+        fuse_pool_bwd=True,         # max-pooling backward inside the BatchNorm backward of the layer(s) it pooled
     )
 
     def __init__(self, on_change=None):
@@ -547,6 +548,37 @@ class Plan(object):
             if not lib.aide_bn_one_pass(pn, pc, ph, pw) or (ph * pw) % 4:
                 continue
             st['fold_dgrad'] = True
+        # A max-pooling whose source is exactly the output of one or several conv + BN + ReLU layers (the level's skip tensor:
+        # both encoders' second convolutions in the FuseUNet) and whose gradient ACCUMULATES into a skip gradient the decoder has
+        # written: its backward pass disappears -- every such layer's BatchNorm backward routes the pooled gradient to the window
+        # arg-max itself (the activation recomputed from z, bit-identical) while it reads dA (ops.bn_relu_bwd_pool).
+        for st in self.steps:
+            st.pop('pool_fuse', None)
+            st.pop('bwd_fused', None)
+        if self.cfg.fuse_pool_bwd:
+            for pst in self.steps:
+                sg = pst.get('src_grad')
+                if pst['kind'] != 'pool' or sg is None or not sg['accumulate'] or sg['gaps']:
+                    continue
+                src, dst = pst['src'], pst['dst']
+                if self.grad[id(src.root)].dtype != torch.float32 or self.grad[id(dst.root)].dtype != torch.float32:
+                    continue
+                prods = [o for o in self.steps if o['kind'] == 'conv' and o['dst'].root is src.root
+                         and src.c0 <= o['dst'].c0 and o['dst'].c0 + o['dst'].C <= src.c0 + src.C]
+                cover = sorted((o['dst'].c0, o['dst'].c0 + o['dst'].C) for o in prods)
+                if not cover or cover[0][0] != src.c0 or cover[-1][1] != src.c0 + src.C or \
+                        any(a[1] != b[0] for a, b in zip(cover, cover[1:])):
+                    continue                                   # the producers do not tile the pooled channels exactly
+                ok = True
+                for o in prods:
+                    zn, zc, zh, zw = o['z'].shape
+                    if o['z'].dtype != torch.float32 or o.get('dz_bf16') or not lib.aide_bn_relu_bwd_pool_supported(zn, zc, zh, zw):
+                        ok = False
+                if not ok:
+                    continue
+                for o in prods:
+                    o['pool_fuse'] = dst.slice(o['dst'].c0 - src.c0, o['dst'].C)
+                pst['bwd_fused'] = True
         self._bwd_ready = True
 
     # ------------------------------------------------------------------ forward
@@ -1097,7 +1129,12 @@ class Plan(object):
                 # between this launch and the data-gradient convolution on this queue
                 tail_ = self.cfg.tail_wgrad_main and st is self.steps[0] and sg is None and self.profiler is None
                 done = st['ev'] if (side is not None and not tail_ and self.cfg.handover_on_kernel) else None
-                if folded[0]:                  # dA is still in the split-K slabs of the conv after this one
+                if st.get('pool_fuse') is not None and not folded[0]:
+                    # (its activation was max-pooled: the pooled gradient joins dA inside this kernel, no pooling backward pass)
+                    ops.bn_relu_bwd_pool(self.gview(st['dst']), self.gview(st['pool_fuse']), z, dz, st['mean'], st['rstd'],
+                                         st['scale'], st['shift'], gslot(bn.weight), gslot(bn.bias), gslot(conv.bias), bn_ws,
+                                         True, done=done)
+                elif folded[0]:                  # dA is still in the split-K slabs of the conv after this one
                     ops.bn_relu_bwd_slabs(sk_ws, folded[0], z, dz, st['mean'], st['rstd'], st['scale'], st['shift'],
                                           gslot(bn.weight), gslot(bn.bias), gslot(conv.bias), bn_ws, True, done=done)
                     folded[0] = 0
@@ -1201,7 +1238,7 @@ class Plan(object):
                 ops.pwconv_dgrad(da, m.conv1.weight, self.gview(st['src']), gate=st['gate'], dout=dout,
                                  accumulate=sg['accumulate'])
             elif kind == 'pool':
-                if sg is not None:
+                if sg is not None and not st.get('bwd_fused'):
                     ops.maxpool2x2_bwd(self.view(st['src'], inputs), self.gview(st['dst']),
                                        self.gview(st['src']), accumulate=sg['accumulate'])
             elif kind == 'up':

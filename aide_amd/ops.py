@@ -353,6 +353,19 @@ def bn_relu_bwd(dA, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, r
     return dz
 
 
+def bn_relu_bwd_pool(dA, pdy, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, relu=True, done=None):
+    """bn_relu_bwd of a layer whose activation also fed a 2x2 max-pooling: dA + the pooled gradient `pdy` routed to the arg-max of
+    every window (no max-pooling backward pass); fp32, lib.aide_bn_relu_bwd_pool_supported(n, c, h, w) shapes"""
+    gp, gbs = planes(dA)
+    pp, pbs = planes(pdy)
+    zp, zbs = planes(z)
+    dp, dbs = planes(dz)
+    n, c, h, w = z.shape
+    check(lib.aide_bn_relu_bwd_pool(gp, gbs, pp, pbs, zp, zbs, dp, dbs, n, c, h, w, ptr(mean), ptr(rstd), ptr(scale), ptr(shift),
+                                    int(relu), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws), done, stream_ptr()), 'bn_relu_bwd_pool')
+    return dz
+
+
 def bn_relu_bwd_slabs(slabs, splitk, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, relu=True, done=None):
     """bn_relu_bwd whose dA is the split-K slabs [splitk][N][C][H][W] (fp32 tensor `slabs`, at its start) left by the
     data-gradient convolution (accumulate=2); fp32 z / dz, one-pass shapes (lib.aide_bn_one_pass(n, c, h, w) == 1)."""

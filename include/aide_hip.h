@@ -241,6 +241,17 @@ int aide_bn_finalize_groups(int N, int groups, int C, int H, int W, const float*
                             float* rstd, float* scale, float* shift, float* tab, int tab_C, int tab_c0, aide_stream_t stream);
 int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, int a_bf16, int64_t a_bs, int N, int C,
                              int H, int W, const float* scale, const float* shift, int relu, aide_stream_t stream);
+/* Backward of relu?(bn(z)) of a layer whose activation ALSO fed an nn.MaxPool2d(2, 2) (fuseunet.py:13-31 / :51-78, UNet.py:114): dA is
+ * the gradient from the activation's other readers (the decoder's skip path), pdy [N][C][H/2][W/2] (batch stride pdy_bs) the gradient of
+ * the pooled tensor; the kernel routes pdy to the arg-max of every window (activation recomputed from z exactly as the forward pass
+ * computed it; first maximum in row-major window order, as nn.MaxPool2d's backward) and adds it to dA on the way in -- bit-identical to
+ * aide_maxpool2x2_bwd(accumulate = 1) followed by aide_bn_relu_bwd_mixed, without the pooling backward's pass.  fp32 storage, shapes of
+ * aide_bn_relu_bwd_pool_supported (one-pass form with units of 8: H even, W % 8 == 0). */
+int aide_bn_relu_bwd_pool_supported(int N, int C, int H, int W);
+int aide_bn_relu_bwd_pool(const float* dA, int64_t d_bs, const float* pdy, int64_t pdy_bs, const float* z, int64_t z_bs, float* dz,
+                          int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
+                          const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws, void* done,
+                          aide_stream_t stream);
 int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz,
                            int dz_bf16, int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                            const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,

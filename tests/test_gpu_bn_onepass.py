@@ -251,3 +251,46 @@ def test_onepass_bf16_storage(dev, shape):
     for x, y in zip(v32, v16):
         assert torch.equal(x, y)
     assert torch.equal(a32.bfloat16(), a16) and torch.equal(dz32.bfloat16(), dz16)
+
+
+@pytest.mark.parametrize('shape', [(4, 64, 256, 256), (4, 128, 64, 64), (2, 512, 32, 32), (3, 24, 40, 48), (1, 8, 64, 32)])
+def test_onepass_bwd_with_pooled_gradient(dev, shape):
+    """aide_bn_relu_bwd_pool: dA + the gradient of MaxPool2d(2, 2)(relu(bn(z))) routed to the window arg-max inside the BatchNorm
+    backward == aide_maxpool2x2_bwd(accumulate) into dA followed by the plain backward, bit for bit -- on activations with many
+    tied windows (half of the values are clipped to zero by the ReLU: the first maximum in row-major order takes the gradient, as in
+    nn.MaxPool2d's backward, fuseunet.py:13-31) and with exact ties between positive values."""
+    from aide_amd import ops
+    from aide_amd._lib import lib
+    n, c, h, w = shape
+    assert lib.aide_bn_relu_bwd_pool_supported(n, c, h, w) == 1
+    g = torch.Generator().manual_seed(h * 7 + c)
+    z = (torch.randn(n, c, h, w, generator=g) * 2.0).to(dev)
+    z[:, :, 0::2, 0::2] = z[:, :, 1::2, 1::2] * torch.where(torch.rand(n, c, h // 2, w // 2, generator=g) > 0.7, 1.0, 0.3).to(dev)
+    dA = torch.randn(n, c, h, w, generator=g).to(dev)
+    pdy = torch.randn(n, c, h // 2, w // 2, generator=g).to(dev)
+    gamma, beta = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.3
+    ws = ops.bn_ws(c, dev)
+    st = _stats(c, dev)
+    a = torch.empty_like(z)
+    ops.bn_train_fwd(z, a, gamma, beta, 1e-5, 0.1, torch.zeros(c, device=dev), torch.ones(c, device=dev),
+                     torch.zeros((), dtype=torch.int64, device=dev), st[0], st[1], st[2], st[3], ws, True)
+    # reference sequence
+    dsum = dA.clone()
+    ops.maxpool2x2_bwd(a, pdy, dsum, accumulate=True)
+    ref = [torch.empty_like(z)] + [torch.empty(c, device=dev) for _ in range(3)]
+    ops.bn_relu_bwd(dsum, z, ref[0], st[0], st[1], st[2], st[3], ref[1], ref[2], ref[3], ws, True)
+    out = [torch.empty_like(z)] + [torch.empty(c, device=dev) for _ in range(3)]
+    ops.bn_relu_bwd_pool(dA, pdy, z, out[0], st[0], st[1], st[2], st[3], out[1], out[2], out[3], ws, True)
+    for x, y, what in zip(out, ref, ('dz', 'dgamma', 'dbeta', 'dbias')):
+        assert torch.equal(x, y), what
+    # ... and against autograd: relu(bn(z)) feeding a max-pooling and a second reader
+    zr = z.detach().cpu().double().requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(c).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma.cpu())
+        bn.bias.copy_(beta.cpu())
+    ar = F.relu(bn(zr))
+    (F.max_pool2d(ar, 2) * pdy.cpu().double()).sum().backward(retain_graph=True)
+    (ar * dA.cpu().double()).sum().backward()
+    if torch.equal((ar > 0).cpu(), (a > 0).cpu()):
+        _close(out[0], zr.grad, rtol=1e-4, what='dz vs autograd')

@@ -441,6 +441,37 @@ def test_two_lane_schedules_are_bit_identical(dev):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('kind', ['fuseunet', 'unet'])
+def test_pool_backward_inside_batchnorm_is_bit_identical(dev, kind):
+    """config.fuse_pool_bwd: the max-pooling backward of every level folded into the BatchNorm backward of the layer(s) it pooled
+    (aide_bn_relu_bwd_pool) against the plain sequence (aide_maxpool2x2_bwd accumulating into the skip gradient, then the BatchNorm
+    backward): every gradient bit for bit, over a recorded pass and two tape replays; the fused plan launches no pooling backward."""
+    from aide_amd import utils as U
+    net, _ = build_pair(kind, False, dev)
+    g = torch.Generator().manual_seed(21)
+    nin = 2 if kind == 'fuseunet' else 1
+    xs = [torch.randn(4, 3, 128, 128, generator=g).to(dev) for _ in range(nin)]
+    t = (torch.rand(4, 128, 128, generator=g) > 0.8).long().to(dev)
+    w = torch.tensor([1.0, 1.0])
+    results = []
+    for fuse in (False, True):
+        net.engine.config.fuse_pool_bwd = fuse
+        outs = None
+        for _ in range(3):
+            net.zero_grad()
+            out = net(*xs)
+            U.CEMDiceLoss(w, w, w)(out, t).backward()
+            outs = [out.detach().clone()] + [p.grad.clone() for p in net.parameters()]
+        results.append(outs)
+        plan = list(net.engine.plans.values())[-1]
+        fused = [st for st in plan.steps if st['kind'] == 'pool' and st.get('bwd_fused')]
+        # (128 x 128 inputs: the 16 x 16 level holds 1024 values per channel -- units of 4, which the fused form does not take)
+        assert len(fused) == (3 if fuse else 0)
+        torch.cuda.synchronize()
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+
+
 def test_unet_ragged_sizes(dev):
     """UNet at 160x176 (levels 160x176 ... 10x11): exercises the PT_W = 16 / 8 tiles, widths that are
     not multiples of 4 (dword loaders), ragged wgrad tiles and the scalar BN / pool kernels."""
