@@ -108,6 +108,10 @@ struct PoolSrc {
     const float* pdy;
     long pdy_bs;
     int W;
+    // ... or (HEAD) the layer's activation fed the 1x1 head: dA = sum_k w[k][c] * dlogits[n][k][p], computed on the way in (the head's
+    // data-gradient pass -- 67 MB written and read back per C2 step -- never runs); same products and order as head_dgrad_kernel
+    const float* hw;          // [K][C] head weights
+    int K;
 };
 template <int V> __device__ __forceinline__ void slab_sum(const SlabSrc& sl, long off, int c, float (&o)[V]) {
     ldv<V>(sl.slabs + off, o);
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(256) void bn_fwd_coop_kernel(
 
 // SLABS: dA is still in the split-K slabs of the data-gradient convolution that produced it ([split][N][C][HW], fp32):
 // the kernel sums them itself in the order of the split reduce (s = 0, 1, ...) -- that launch and its pass disappear.
-template <int V, int Q, typename ZT, typename DT, typename GT, bool SLABS, bool POOL = false>
+template <int V, int Q, typename ZT, typename DT, typename GT, bool SLABS, bool POOL = false, bool HEAD = false>
 __global__ __launch_bounds__(256) void bn_bwd_coop_kernel(
     const GT* __restrict__ dA, long d_bs, const ZT* __restrict__ z, long z_bs, DT* __restrict__ dz, long dz_bs, int N, int C,
     int HW, int S, int per, double count, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -737,6 +741,23 @@ __global__ __launch_bounds__(256) void bn_bwd_coop_kernel(
 #pragma unroll
         for (int k = 0; k < Q; ++k) off[k] = (long)nn[k] * sl.slab_bs + (long)c * HW + pp[k];
         slab_sum_q<V, Q>(sl, off, on, c, dy);
+    } else if constexpr (HEAD) {
+        // pl.pdy = dlogits [N][K][HW] (batch stride pl.pdy_bs), pl.hw = head weights [K][C]
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) dy[k][e] = 0.f;
+        }
+        for (int kc = 0; kc < pl.K; ++kc) {
+            const float wk = pl.hw[kc * C + c];
+#pragma unroll
+            for (int k = 0; k < Q; ++k) if (on[k]) {
+                float g[V];
+                ldv<V>(pl.pdy + (long)nn[k] * pl.pdy_bs + (long)kc * HW + pp[k], g);
+#pragma unroll
+                for (int e = 0; e < V; ++e) dy[k][e] = kc ? __builtin_fmaf(wk, g[e], dy[k][e]) : wk * g[e];
+            }
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < Q; ++k) {
@@ -1188,7 +1209,7 @@ int aide_bn_relu_bwd_pool(const float* dA, int64_t d_bs, const float* pdy, int64
         pdy_bs % 4 || !coop_plan(N, C, HW, true, cp))
         return AIDE_ERR_ARG;
     PoolSrc pl;
-    pl.pdy = pdy; pl.pdy_bs = pdy_bs; pl.W = W;
+    pl.pdy = pdy; pl.pdy_bs = pdy_bs; pl.W = W; pl.hw = nullptr; pl.K = 0;
     // dA, z read once, dz written once, the pooled gradient read once (the partner rows of z come from cache)
     const double kt_bytes = (double)N * C * HW * 12.0 + (double)N * C * (HW / 4) * 4.0;
 #define AIDE_BN_BP(QQ)                                                                                                        \
@@ -1197,6 +1218,32 @@ int aide_bn_relu_bwd_pool(const float* dA, int64_t d_bs, const float* pdy, int64
                            cp.per, (double)N * HW, mean, rstd, scale, shift, relu, dgamma, dbeta, dbias, SlabSrc{}, (double*)ws, pl)
     if (cp.Q == 1) AIDE_BN_BP(1); else if (cp.Q == 2) AIDE_BN_BP(2); else if (cp.Q == 4) AIDE_BN_BP(4); else AIDE_BN_BP(8);
 #undef AIDE_BN_BP
+    return aide_launch_status();
+}
+
+// Backward of relu(bn(z)) of the layer whose activation feeds the 1x1 head (fuseunet.py:41, :88; UNet.py:120): its dA is the head's data
+// gradient sum_k w[k][c] dlogits[n][k][p], formed while dlogits is read -- aide_head1x1_bwd's dx pass (a write and a read of the widest
+// feature map) does not run.  fp32 storage, one-pass shapes, 1 <= K <= 8.
+int aide_bn_relu_bwd_head(const float* dlogits, int64_t dl_bs, const float* head_w, int K, const float* z, int64_t z_bs, float* dz,
+                          int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
+                          const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws, void* done,
+                          hipStream_t stream) {
+    const int HW = H * W;
+    CoopPlan cp;
+    if (!dlogits || !head_w || K < 1 || K > 8 || !z || !dz || !ws || HW % 4 || z_bs % 4 || dz_bs % 4 || dl_bs % 4 ||
+        !coop_plan(N, C, HW, z_bs % 8 == 0 && dz_bs % 8 == 0 && dl_bs % 8 == 0, cp))
+        return AIDE_ERR_ARG;
+    PoolSrc pl;
+    pl.pdy = dlogits; pl.pdy_bs = dl_bs; pl.W = W; pl.hw = head_w; pl.K = K;
+    const double kt_bytes = (double)N * C * HW * 8.0 + (double)N * K * HW * 4.0;       // z, dz; dlogits once (re-read from cache per channel)
+#define AIDE_BN_BH(VV, QQ)                                                                                                    \
+    AIDE_LAUNCH_DONE_TIMED(AIDE_KT_BN_BWD, kt_bytes, done, (bn_bwd_coop_kernel<VV, QQ, float, float, float, false, false, true>), \
+                           dim3(C * cp.S), dim3(256), 0, stream, (const float*)nullptr, 0L, z, (long)z_bs, dz, (long)dz_bs, N, C, HW, \
+                           cp.S, cp.per, (double)N * HW, mean, rstd, scale, shift, relu, dgamma, dbeta, dbias, SlabSrc{}, (double*)ws, pl)
+#define AIDE_BN_BQ(VV) do { if (cp.Q == 1) AIDE_BN_BH(VV, 1); else if (cp.Q == 2) AIDE_BN_BH(VV, 2); else if (cp.Q == 4) AIDE_BN_BH(VV, 4); else AIDE_BN_BH(VV, 8); } while (0)
+    if (cp.V == 8) AIDE_BN_BQ(8); else AIDE_BN_BQ(4);
+#undef AIDE_BN_BQ
+#undef AIDE_BN_BH
     return aide_launch_status();
 }
 

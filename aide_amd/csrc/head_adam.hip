@@ -54,9 +54,13 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
         for (int k = 0; k < K; ++k) g[k] = *reinterpret_cast<const f32x4*>(dy + n * dy_bs + (long)k * HW + p * 4);
         DT* xp = dx + n * dx_bs + p * 4;
         for (int c = 0; c < C; ++c) {
-            f32x4 v = ws[c] * g[0];
-#pragma unroll
-            for (int k = 1; k < K; ++k) v += ws[k * C + c] * g[k];
+            f32x4 v = ws[c] * g[0];                    // (explicit fused multiply-adds, k ascending: aide_bn_relu_bwd_head forms
+#pragma unroll                                         //  the same sums inside the BatchNorm backward, bit for bit)
+            for (int k = 1; k < K; ++k) {
+                const float wk = ws[k * C + c];
+                v = f32x4{__builtin_fmaf(wk, g[k][0], v[0]), __builtin_fmaf(wk, g[k][1], v[1]), __builtin_fmaf(wk, g[k][2], v[2]),
+                          __builtin_fmaf(wk, g[k][3], v[3])};
+            }
             st4(xp + (long)c * HW, v);
         }
     }

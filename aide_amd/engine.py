@@ -122,6 +122,7 @@ class EngineConfig(object):
         lazy_bn=True,               # forward-only stacked plans: BatchNorm + ReLU of a layer in its reader's loader
         direct_grads=_os.environ.get('AIDE_DIRECT_GRADS', '1') != '0',   # parameter gradients assigned by the engine
         fuse_pool_bwd=True,         # max-pooling backward inside the BatchNorm backward of the layer(s) it pooled
+        fuse_head_bwd=True,         # the head's data gradient formed inside the BatchNorm backward of the layer under it
     )
 
     def __init__(self, on_change=None):
@@ -555,6 +556,8 @@ class Plan(object):
         for st in self.steps:
             st.pop('pool_fuse', None)
             st.pop('bwd_fused', None)
+            st.pop('head_fuse', None)
+            st.pop('dgrad_fused', None)
         if self.cfg.fuse_pool_bwd:
             for pst in self.steps:
                 sg = pst.get('src_grad')
@@ -579,6 +582,27 @@ class Plan(object):
                 for o in prods:
                     o['pool_fuse'] = dst.slice(o['dst'].c0 - src.c0, o['dst'].C)
                 pst['bwd_fused'] = True
+        # The 1x1 head's data gradient (a write and a read of the widest feature map) is formed inside the BatchNorm backward of the
+        # layer under the head when that layer's activation has no other reader (ops.bn_relu_bwd_head).
+        if self.cfg.fuse_head_bwd:
+            for hst in self.steps:
+                sg = hst.get('src_grad')
+                if hst['kind'] != 'head' or sg is None or sg['accumulate'] or sg['gaps']:
+                    continue
+                src = hst['src']
+                readers = [o for o in self.steps if o.get('src') is not None and o['src'].root is src.root
+                           and o['src'].c0 < src.c0 + src.C and src.c0 < o['src'].c0 + o['src'].C]
+                prods = [o for o in self.steps if o['kind'] == 'conv' and o['dst'].root is src.root
+                         and (o['dst'].c0, o['dst'].C) == (src.c0, src.C)]
+                if len(readers) != 1 or len(prods) != 1:
+                    continue
+                o = prods[0]
+                zn, zc, zh, zw = o['z'].shape
+                if o['z'].dtype != torch.float32 or o.get('dz_bf16') or o.get('pool_fuse') is not None or \
+                        not lib.aide_bn_one_pass(zn, zc, zh, zw) or (zh * zw) % 4:
+                    continue
+                o['head_fuse'] = hst
+                hst['dgrad_fused'] = True
         self._bwd_ready = True
 
     # ------------------------------------------------------------------ forward
@@ -1108,17 +1132,19 @@ class Plan(object):
                 conv = st['conv']
                 k = conv.out_channels
                 assert sg is None or not sg['accumulate']
+                fused = bool(st.get('dgrad_fused'))     # the data gradient is formed by the BatchNorm backward of the layer below
+                dsrc = self.gview(st['src']) if (sg is not None and not fused) else None
                 if side is not None and sg is not None:
                     # the head's weight gradient (one pass over the widest feature map) has no consumer until the
                     # optimizer: side stream, so that the dependent chain starts with the data gradient alone
                     with ops.use_stream(side):
                         ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1), None,
                                         gslot(conv.weight).view(k, -1), gslot(conv.bias), ws=self.head_ws)
-                    ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1),
-                                    self.gview(st['src']), None, None, ws=self.head_ws)
+                    if dsrc is not None:
+                        ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1), dsrc, None, None,
+                                        ws=self.head_ws)
                 else:
-                    ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1),
-                                    self.gview(st['src']) if sg is not None else None,
+                    ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1), dsrc,
                                     gslot(conv.weight).view(k, -1), gslot(conv.bias), ws=self.head_ws)
             elif kind in ('conv', 'convT'):
                 conv, bn = st['conv'], st['bn']
@@ -1129,7 +1155,11 @@ class Plan(object):
                 # between this launch and the data-gradient convolution on this queue
                 tail_ = self.cfg.tail_wgrad_main and st is self.steps[0] and sg is None and self.profiler is None
                 done = st['ev'] if (side is not None and not tail_ and self.cfg.handover_on_kernel) else None
-                if st.get('pool_fuse') is not None and not folded[0]:
+                if st.get('head_fuse') is not None and not folded[0]:
+                    hconv = st['head_fuse']['conv']
+                    ops.bn_relu_bwd_head(dlogits, hconv.weight.view(hconv.out_channels, -1), z, dz, st['mean'], st['rstd'], st['scale'],
+                                         st['shift'], gslot(bn.weight), gslot(bn.bias), gslot(conv.bias), bn_ws, True, done=done)
+                elif st.get('pool_fuse') is not None and not folded[0]:
                     # (its activation was max-pooled: the pooled gradient joins dA inside this kernel, no pooling backward pass)
                     ops.bn_relu_bwd_pool(self.gview(st['dst']), self.gview(st['pool_fuse']), z, dz, st['mean'], st['rstd'],
                                          st['scale'], st['shift'], gslot(bn.weight), gslot(bn.bias), gslot(conv.bias), bn_ws,

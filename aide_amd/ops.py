@@ -366,6 +366,21 @@ def bn_relu_bwd_pool(dA, pdy, z, dz, mean, rstd, scale, shift, dgamma, dbeta, db
     return dz
 
 
+def bn_relu_bwd_head(dlogits, head_w, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, relu=True, done=None):
+    """bn_relu_bwd of the layer under the 1x1 head: dA = head_w^T dlogits formed inside the kernel (no head data-gradient pass);
+    head_w [K, C] fp32, dlogits [N, K, H, W] fp32"""
+    lp, lbs = planes(dlogits)
+    zp, zbs = planes(z)
+    dp, dbs = planes(dz)
+    n, c, h, w = z.shape
+    k = dlogits.shape[1]
+    assert head_w.shape == (k, c) and head_w.is_contiguous()
+    check(lib.aide_bn_relu_bwd_head(lp, lbs, ptr(head_w), k, zp, zbs, dp, dbs, n, c, h, w, ptr(mean), ptr(rstd), ptr(scale),
+                                    ptr(shift), int(relu), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws), done, stream_ptr()),
+          'bn_relu_bwd_head')
+    return dz
+
+
 def bn_relu_bwd_slabs(slabs, splitk, z, dz, mean, rstd, scale, shift, dgamma, dbeta, dbias, ws, relu=True, done=None):
     """bn_relu_bwd whose dA is the split-K slabs [splitk][N][C][H][W] (fp32 tensor `slabs`, at its start) left by the
     data-gradient convolution (accumulate=2); fp32 z / dz, one-pass shapes (lib.aide_bn_one_pass(n, c, h, w) == 1)."""

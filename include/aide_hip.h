@@ -252,6 +252,13 @@ int aide_bn_relu_bwd_pool(const float* dA, int64_t d_bs, const float* pdy, int64
                           int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
                           const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws, void* done,
                           aide_stream_t stream);
+/* Backward of relu?(bn(z)) of the layer whose activation feeds the 1x1 head (last_conv1: fuseunet.py:41 / :88, UNet.py:120): dA =
+ * sum_k head_w[k][c] * dlogits[n][k][p] is formed inside the kernel (k ascending, fused multiply-adds: the sums of aide_head1x1_bwd's dx,
+ * bit for bit) -- the head's data-gradient pass does not run.  fp32 storage, shapes of aide_bn_one_pass, 1 <= K <= 8. */
+int aide_bn_relu_bwd_head(const float* dlogits, int64_t dl_bs, const float* head_w, int K, const float* z, int64_t z_bs, float* dz,
+                          int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
+                          const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws, void* done,
+                          aide_stream_t stream);
 int aide_bn_relu_bwd_mixed(const void* dA, int dA_bf16, int64_t d_bs, const void* z, int z_bf16, int64_t z_bs, void* dz,
                            int dz_bf16, int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd,
                            const float* scale, const float* shift, int relu, float* dgamma, float* dbeta, float* dbias,

@@ -294,3 +294,30 @@ def test_onepass_bwd_with_pooled_gradient(dev, shape):
     (ar * dA.cpu().double()).sum().backward()
     if torch.equal((ar > 0).cpu(), (a > 0).cpu()):
         _close(out[0], zr.grad, rtol=1e-4, what='dz vs autograd')
+
+
+@pytest.mark.parametrize('case', [(4, 64, 256, 256, 2), (2, 64, 64, 48, 3), (3, 32, 20, 20, 8), (1, 16, 32, 32, 1)])
+def test_onepass_bwd_with_head_gradient(dev, case):
+    """aide_bn_relu_bwd_head: the 1x1 head's data gradient sum_k w[k][c] dlogits[k] formed inside the BatchNorm backward of the layer
+    under the head == aide_head1x1_bwd's dx followed by the plain backward, bit for bit (2 .. 8 classes; last_conv1, fuseunet.py:41)."""
+    from aide_amd import ops
+    n, c, h, w, k = case
+    g = torch.Generator().manual_seed(c + k)
+    z = (torch.randn(n, c, h, w, generator=g) * 2.0).to(dev)
+    dl = torch.randn(n, k, h, w, generator=g).to(dev)
+    hw_ = (torch.randn(k, c, generator=g) * 0.2).to(dev)
+    x = torch.randn(n, c, h, w, generator=g).to(dev)
+    gamma, beta = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.3
+    ws = ops.bn_ws(c, dev)
+    st = _stats(c, dev)
+    ops.bn_train_fwd(z, torch.empty_like(z), gamma, beta, 1e-5, 0.1, torch.zeros(c, device=dev), torch.ones(c, device=dev),
+                     torch.zeros((), dtype=torch.int64, device=dev), st[0], st[1], st[2], st[3], ws, True)
+    dA = torch.empty_like(z)
+    ops.head1x1_bwd(dl, x, hw_, dA, None, None)
+    ref = [torch.empty_like(z)] + [torch.empty(c, device=dev) for _ in range(3)]
+    ops.bn_relu_bwd(dA, z, ref[0], st[0], st[1], st[2], st[3], ref[1], ref[2], ref[3], ws, True)
+    out = [torch.empty_like(z)] + [torch.empty(c, device=dev) for _ in range(3)]
+    ops.bn_relu_bwd_head(dl, hw_, z, out[0], st[0], st[1], st[2], st[3], out[1], out[2], out[3], ws, True)
+    for a, b, what in zip(out, ref, ('dz', 'dgamma', 'dbeta', 'dbias')):
+        assert torch.equal(a, b), what
+    _close(dA, torch.einsum('nkhw,kc->nchw', dl.cpu().double(), hw_.cpu().double()), rtol=1e-6, what='head dx')

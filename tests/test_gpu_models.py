@@ -456,6 +456,7 @@ def test_pool_backward_inside_batchnorm_is_bit_identical(dev, kind):
     results = []
     for fuse in (False, True):
         net.engine.config.fuse_pool_bwd = fuse
+        net.engine.config.fuse_head_bwd = fuse              # (... and the head's data gradient inside the last BatchNorm backward)
         outs = None
         for _ in range(3):
             net.zero_grad()
@@ -467,6 +468,7 @@ def test_pool_backward_inside_batchnorm_is_bit_identical(dev, kind):
         fused = [st for st in plan.steps if st['kind'] == 'pool' and st.get('bwd_fused')]
         # (128 x 128 inputs: the 16 x 16 level holds 1024 values per channel -- units of 4, which the fused form does not take)
         assert len(fused) == (3 if fuse else 0)
+        assert sum(1 for st in plan.steps if st.get('head_fuse') is not None) == (1 if fuse else 0)
         torch.cuda.synchronize()
     for a, b in zip(*results):
         assert torch.equal(a, b)
