@@ -17,7 +17,11 @@ template <int K, typename XT>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const XT* __restrict__ x, long x_bs,
                                                        const float* __restrict__ w, const float* __restrict__ b,
                                                        float* __restrict__ y, long y_bs, int C, int HW,
-                                                       long total4) {
+                                                       long total4, const float* __restrict__ in_scale,
+                                                       const float* __restrict__ in_shift) {
+    // in_scale / in_shift (round 6): x is the RAW output z of the layer under the head and its training-mode BatchNorm + ReLU is
+    // applied here, a = max(fma(z, scale[c], shift[c]), 0) -- the same expression as the BatchNorm apply kernels, bit for bit -- so
+    // that layer's normalising pass (134 MB per C2 step) never runs and its activation is never stored
     extern __shared__ float ws[];                 // [K][C]
     for (int i = threadIdx.x; i < K * C; i += 256) ws[i] = w[i];
     __syncthreads();
@@ -29,7 +33,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const XT* __restrict__ x,
 #pragma unroll
         for (int k = 0; k < K; ++k) { const float bk = b ? b[k] : 0.f; acc[k] = f32x4{bk, bk, bk, bk}; }
         for (int c = 0; c < C; ++c) {
-            const f32x4 v = ld4(xp + (long)c * HW);
+            f32x4 v = ld4(xp + (long)c * HW);
+            if (in_scale) {
+                const float sc = in_scale[c], sh = in_shift[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(v[e], sc, sh), 0.0f);
+            }
 #pragma unroll
             for (int k = 0; k < K; ++k) acc[k] += ws[k * C + c] * v;
         }
@@ -72,7 +81,8 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
 template <int K, typename XT>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dy, long dy_bs,
                                                          const XT* __restrict__ x, long x_bs, int C, int HW,
-                                                         long total4, double* __restrict__ partials) {
+                                                         long total4, double* __restrict__ partials,
+                                                         const float* __restrict__ in_scale, const float* __restrict__ in_shift) {
     constexpr int G = K > 4 ? 4 : 8;          // (G x K fp64 accumulators per thread)
     __shared__ double sm[4][G * K];
     const int hw4 = HW / 4;
@@ -94,7 +104,14 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
             for (int g = 0; g < G; ++g) {
                 const int c = c0 + g;
                 v[g] = f32x4{1.f, 1.f, 1.f, 1.f};
-                if (c >= 0 && c < C) v[g] = ld4(x + n * x_bs + (long)c * HW + p * 4);
+                if (c >= 0 && c < C) {
+                    v[g] = ld4(x + n * x_bs + (long)c * HW + p * 4);
+                    if (in_scale) {                    // (x is z: the activation is recomputed as head_fwd_kernel computed it)
+                        const float sc = in_scale[c], sh = in_shift[c];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(__builtin_fmaf(v[g][e], sc, sh), 0.0f);
+                    }
+                }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g)
@@ -184,21 +201,21 @@ int grid_for(long total) { return (int)max(1L, min((total + 255) / 256, 4096L));
 
 template <int K, typename XT>
 int head_wgrad_launch(const float* dy, long dy_bs, const XT* x, long x_bs, int C, int HW, long total4,
-                      double* partials, int nblocks, hipStream_t s) {
+                      double* partials, int nblocks, hipStream_t s, const float* in_scale = nullptr, const float* in_shift = nullptr) {
     AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, (head_wgrad_kernel<K, XT>), dim3(nblocks), dim3(256), 0, s, dy, dy_bs, x, x_bs, C, HW,
-                       total4, partials);
+                       total4, partials, in_scale, in_shift);
     return aide_launch_status();
 }
 
 template <typename XT>
 int head_fwd_t(const XT* x, int64_t x_bs, const float* w, const float* b, float* y, int64_t y_bs, int N, int C, int K,
-               int H, int W, hipStream_t stream) {
+               int H, int W, hipStream_t stream, const float* in_scale = nullptr, const float* in_shift = nullptr) {
     const int HW = H * W;
     if (K < 1 || K > MAXK || HW % 4 || x_bs % 4 || y_bs % 4) return AIDE_ERR_ARG;
     const long total4 = (long)N * HW / 4;
     const int grid = grid_for(total4);
     const size_t sh = (size_t)K * C * sizeof(float);
-#define AIDE_HEAD_FWD(KK) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, (head_fwd_kernel<KK, XT>), dim3(grid), dim3(256), sh, stream, x, (long)x_bs, w, b, y, (long)y_bs, C, HW, total4)
+#define AIDE_HEAD_FWD(KK) AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, (head_fwd_kernel<KK, XT>), dim3(grid), dim3(256), sh, stream, x, (long)x_bs, w, b, y, (long)y_bs, C, HW, total4, in_scale, in_shift)
     switch (K) { case 1: AIDE_HEAD_FWD(1); break; case 2: AIDE_HEAD_FWD(2); break; case 3: AIDE_HEAD_FWD(3); break; case 4: AIDE_HEAD_FWD(4); break;
                  case 5: AIDE_HEAD_FWD(5); break; case 6: AIDE_HEAD_FWD(6); break; case 7: AIDE_HEAD_FWD(7); break; default: AIDE_HEAD_FWD(8); }
 #undef AIDE_HEAD_FWD
@@ -207,7 +224,8 @@ int head_fwd_t(const XT* x, int64_t x_bs, const float* w, const float* b, float*
 
 template <typename XT, typename DT>
 int head_bwd_t(const float* dy, int64_t dy_bs, const XT* x, int64_t x_bs, const float* w, DT* dx, int64_t dx_bs,
-               float* dw, float* db, int N, int C, int K, int H, int W, void* ws, hipStream_t stream) {
+               float* dw, float* db, int N, int C, int K, int H, int W, void* ws, hipStream_t stream,
+               const float* in_scale = nullptr, const float* in_shift = nullptr) {
     const int HW = H * W;
     if (K < 1 || K > MAXK || HW % 4 || x_bs % 4 || dy_bs % 4 || (dx && dx_bs % 4) || !ws) return AIDE_ERR_ARG;
     const long total4 = (long)N * HW / 4;
@@ -223,14 +241,14 @@ int head_bwd_t(const float* dy, int64_t dy_bs, const XT* x, int64_t x_bs, const 
     const int nblocks = (int)max(1L, min((total4 + 255) / 256, (long)HEAD_WG_BLOCKS));
     int rc;
     switch (K) {
-        case 1: rc = head_wgrad_launch<1>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
-        case 2: rc = head_wgrad_launch<2>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
-        case 3: rc = head_wgrad_launch<3>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
-        case 4: rc = head_wgrad_launch<4>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
-        case 5: rc = head_wgrad_launch<5>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
-        case 6: rc = head_wgrad_launch<6>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
-        case 7: rc = head_wgrad_launch<7>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream); break;
-        default: rc = head_wgrad_launch<8>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream);
+        case 1: rc = head_wgrad_launch<1>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream, in_scale, in_shift); break;
+        case 2: rc = head_wgrad_launch<2>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream, in_scale, in_shift); break;
+        case 3: rc = head_wgrad_launch<3>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream, in_scale, in_shift); break;
+        case 4: rc = head_wgrad_launch<4>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream, in_scale, in_shift); break;
+        case 5: rc = head_wgrad_launch<5>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream, in_scale, in_shift); break;
+        case 6: rc = head_wgrad_launch<6>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream, in_scale, in_shift); break;
+        case 7: rc = head_wgrad_launch<7>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream, in_scale, in_shift); break;
+        default: rc = head_wgrad_launch<8>(dy, dy_bs, x, x_bs, C, HW, total4, (double*)ws, nblocks, stream, in_scale, in_shift);
     }
     if (rc) return rc;
     AIDE_LAUNCH_TIMED(AIDE_KT_OTHER, 0.0, head_wgrad_finalize_kernel, dim3(K * C + K), dim3(64), 0, stream,
@@ -258,6 +276,20 @@ int aide_head1x1_bwd_mixed(const float* dy, int64_t dy_bs, const void* x, int x_
     if (x_bf16) return dx_bf16 ? AIDE_HB(bf16_store_t, bf16_store_t) : AIDE_HB(bf16_store_t, float);
     return dx_bf16 ? AIDE_HB(float, bf16_store_t) : AIDE_HB(float, float);
 #undef AIDE_HB
+}
+
+// The head on the RAW conv output z of the layer under it, that layer's training-mode BatchNorm + ReLU applied on the way in
+// (in_scale / in_shift [C]: the layer's scale / shift, e.g. from aide_bn_finalize_groups): forward, and the weight / bias gradient
+// (the data gradient of such a layer is formed by aide_bn_relu_bwd_head).  fp32.
+int aide_head1x1_fwd_bn(const float* z, int64_t z_bs, const float* in_scale, const float* in_shift, const float* w, const float* b,
+                        float* y, int64_t y_bs, int N, int C, int K, int H, int W, hipStream_t stream) {
+    if (!z || !in_scale || !in_shift) return AIDE_ERR_ARG;
+    return head_fwd_t(z, z_bs, w, b, y, y_bs, N, C, K, H, W, stream, in_scale, in_shift);
+}
+int aide_head1x1_wgrad_bn(const float* dy, int64_t dy_bs, const float* z, int64_t z_bs, const float* in_scale, const float* in_shift,
+                          float* dw, float* db, int N, int C, int K, int H, int W, void* ws, hipStream_t stream) {
+    if (!z || !in_scale || !in_shift || !dw) return AIDE_ERR_ARG;
+    return head_bwd_t<float, float>(dy, dy_bs, z, z_bs, nullptr, nullptr, 0, dw, db, N, C, K, H, W, ws, stream, in_scale, in_shift);
 }
 
 // Pointer tables (device memory): p,g,m,v,vmax [ntensors]; sizes, block_start [ntensors] (int64).

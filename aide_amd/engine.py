@@ -123,6 +123,7 @@ class EngineConfig(object):
         direct_grads=_os.environ.get('AIDE_DIRECT_GRADS', '1') != '0',   # parameter gradients assigned by the engine
         fuse_pool_bwd=True,         # max-pooling backward inside the BatchNorm backward of the layer(s) it pooled
         fuse_head_bwd=True,         # the head's data gradient formed inside the BatchNorm backward of the layer under it
+        lazy_head=True,             # BatchNorm + ReLU of the layer under the head applied in the head's loaders (no pass, no activation)
     )
 
     def __init__(self, on_change=None):
@@ -379,6 +380,7 @@ class Plan(object):
                 st['stat'] = torch.empty(2, **f32)
             self.steps.append(st)
         self._plan_lazy_bn()
+        self._plan_lazy_head()
         # activation buffers.  bf16 mode stores an activation buffer as bf16 when everything that touches it can: written by
         # BatchNorm-apply / pooling / up-sampling, read by bf16 convolutions (forward AND weight gradient), pooling,
         # up-sampling or the head.  For a conv operand that is numerically free (the kernels round it anyway), max-pooling
@@ -467,6 +469,32 @@ class Plan(object):
             st['lazy_to'], st['tab_c0'] = rd, dst.c0 - src.c0
             st['z'] = None                 # the raw output lives in the reader's input slot
             self.lazy_bn += 1
+
+    def _plan_lazy_head(self):
+        """Training plans: the layer under the 1x1 head (its only reader) with statistics from its conv epilogue never runs its
+        normalising pass -- a one-wave-per-channel launch turns the statistics into (scale, shift), the head's forward and weight
+        gradient apply BatchNorm + ReLU while they read z (ops.head1x1_fwd_bn / head1x1_wgrad_bn), and the head's data gradient is
+        formed inside that layer's BatchNorm backward (fuse_head_bwd): its activation is never stored."""
+        if not (self.training and self.groups == 1 and self.cfg.lazy_head and self.cfg.fuse_head_bwd):
+            return
+        for hst in self.steps:
+            if hst['kind'] != 'head':
+                continue
+            src = hst['src']
+            readers = [o for o in self.steps if o.get('src') is not None and o['src'].root is src.root
+                       and o['src'].c0 < src.c0 + src.C and src.c0 < o['src'].c0 + o['src'].C]
+            prods = [o for o in self.steps if o['kind'] == 'conv' and o['dst'].root is src.root
+                     and (o['dst'].c0, o['dst'].C) == (src.c0, src.C)]
+            if len(readers) != 1 or len(prods) != 1:
+                continue
+            o = prods[0]
+            zn, zc, zh, zw = o['z'].shape
+            if o.get('stats') is None or o['z'].dtype != torch.float32 or o.get('dz_bf16') or o.get('lazy_to') is not None or \
+                    not lib.aide_bn_one_pass(zn, zc, zh, zw):
+                continue
+            o['head_lazy'] = True
+            o['head_tab'] = torch.zeros(1, zc, 2, device=self.dev, dtype=torch.float32)
+            hst['lazy_prod'] = o
 
     # ------------------------------------------------------------------ helpers
     def view(self, t, inputs=None):
@@ -929,7 +957,11 @@ class Plan(object):
                     ops.conv3x3_igemm(x, st['wf'], conv.bias, st['z'], accumulate=acc, plan=st['plan_f'], ws=sk_ws)
                 if prof is not None:
                     prof.end()
-                if lazy is not None:               # statistics -> the reader's (scale, shift) table; no pass over the tensor
+                if st.get('head_lazy'):            # statistics -> (scale, shift); the head applies them while it reads z
+                    zn, zc, zh, zw = st['z'].shape
+                    ops.bn_finalize_groups(zn, 1, zc, zh, zw, bn, st['stats'], st['stats_parts'], st['stats_parts'], conv.bias,
+                                           st['mean'], st['rstd'], st['scale'], st['shift'], st['head_tab'], 0)
+                elif lazy is not None:               # statistics -> the reader's (scale, shift) table; no pass over the tensor
                     zz = self.view(st['dst'])
                     ops.bn_finalize_groups(self.N // self.groups, self.groups, zz.shape[1], zz.shape[2], zz.shape[3], bn,
                                            st['stats'], st['stats_parts'] // self.groups, st['stats_parts'], conv.bias,
@@ -946,8 +978,12 @@ class Plan(object):
                 ops.upsample2x_fwd(self.view(st['src'], inputs), self.view(st['dst']))
             elif kind == 'head':
                 conv = st['conv']
-                ops.head1x1_fwd(self.view(st['src'], inputs), conv.weight.view(conv.out_channels, -1),
-                                conv.bias, out)
+                lp = st.get('lazy_prod')
+                if lp is not None:
+                    ops.head1x1_fwd_bn(lp['z'], lp['scale'], lp['shift'], conv.weight.view(conv.out_channels, -1), conv.bias, out)
+                else:
+                    ops.head1x1_fwd(self.view(st['src'], inputs), conv.weight.view(conv.out_channels, -1),
+                                    conv.bias, out)
             elif kind == 'sa':
                 m = st['mod']
                 y = self.view(st['src'], inputs)
@@ -1134,15 +1170,27 @@ class Plan(object):
                 assert sg is None or not sg['accumulate']
                 fused = bool(st.get('dgrad_fused'))     # the data gradient is formed by the BatchNorm backward of the layer below
                 dsrc = self.gview(st['src']) if (sg is not None and not fused) else None
+                lp = st.get('lazy_prod')              # the activation under the head was never stored: recomputed from z
+
+                def wgrad_only():
+                    if lp is not None:
+                        ops.head1x1_wgrad_bn(dlogits, lp['z'], lp['scale'], lp['shift'], gslot(conv.weight).view(k, -1),
+                                             gslot(conv.bias), ws=self.head_ws)
+                    else:
+                        ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1), None,
+                                        gslot(conv.weight).view(k, -1), gslot(conv.bias), ws=self.head_ws)
                 if side is not None and sg is not None:
                     # the head's weight gradient (one pass over the widest feature map) has no consumer until the
                     # optimizer: side stream, so that the dependent chain starts with the data gradient alone
                     with ops.use_stream(side):
-                        ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1), None,
-                                        gslot(conv.weight).view(k, -1), gslot(conv.bias), ws=self.head_ws)
+                        wgrad_only()
                     if dsrc is not None:
                         ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1), dsrc, None, None,
                                         ws=self.head_ws)
+                elif lp is not None:
+                    wgrad_only()
+                    if dsrc is not None:
+                        ops.head1x1_bwd(dlogits, lp['z'], conv.weight.view(k, -1), dsrc, None, None, ws=self.head_ws)
                 else:
                     ops.head1x1_bwd(dlogits, self.view(st['src'], inputs), conv.weight.view(k, -1), dsrc,
                                     gslot(conv.weight).view(k, -1), gslot(conv.bias), ws=self.head_ws)

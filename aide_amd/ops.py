@@ -468,6 +468,29 @@ def head1x1_fwd(x, w, b, y):
     return y
 
 
+def head1x1_fwd_bn(z, scale, shift, w, b, y):
+    """logits of the head on relu(z * scale[c] + shift[c]) formed while the raw conv output z is read (fp32)"""
+    zp, zbs = planes(z)
+    yp, ybs = planes(y)
+    n, c, h, wd = z.shape
+    k = w.shape[0]
+    check(lib.aide_head1x1_fwd_bn(zp, zbs, ptr(scale), ptr(shift), ptr(w), ptr(b), yp, ybs, n, c, k, h, wd, stream_ptr()),
+          'head1x1_fwd_bn')
+    return y
+
+
+def head1x1_wgrad_bn(dy, z, scale, shift, dw, db, ws=None):
+    """weight / bias gradient of the head on relu(z * scale[c] + shift[c]) (the activation recomputed from z)"""
+    gp, gbs = planes(dy)
+    zp, zbs = planes(z)
+    n, c, h, wd = z.shape
+    k = dw.shape[0]
+    if ws is None:
+        ws = torch.empty(lib.aide_head1x1_ws_bytes(c, k) // 8, device=z.device, dtype=torch.float64)
+    check(lib.aide_head1x1_wgrad_bn(gp, gbs, zp, zbs, ptr(scale), ptr(shift), ptr(dw), ptr(db), n, c, k, h, wd, ptr(ws),
+                                    stream_ptr()), 'head1x1_wgrad_bn')
+
+
 def head1x1_bwd(dy, x, w, dx, dw, db, ws=None):
     gp, gbs = planes(dy)
     xp, xbs = planes(x, bf16_ok=True)

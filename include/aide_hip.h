@@ -389,6 +389,15 @@ int aide_sa_gate_bwd(const float* dout, int64_t dout_bs, const float* y, int64_t
  * replaces last_conv1 = nn.Conv2d(64, num_classes, 1): fuseunet.py:41,89 ; UNet.py:150,164.  K = num_classes, 1 .. 8 */
 size_t aide_head1x1_ws_bytes(int C, int K);
 /* x_bf16 / dx_bf16 = 1: the head on a bf16-stored feature map (precision='bf16'); logits and every gradient stay fp32 */
+/* The head on the RAW output z of the conv layer under it (round 6): that layer's training-mode BatchNorm + ReLU
+ * (netblocks.py:27-28 in front of last_conv1, fuseunet.py:88-89) is applied while z is read -- a = max(fma(z, scale[c], shift[c]), 0), the
+ * expression of the BatchNorm apply kernels -- so the layer's normalising pass never runs and its activation is never stored.  in_scale /
+ * in_shift [C]: e.g. from aide_bn_finalize_groups (statistics of the conv epilogue).  aide_head1x1_wgrad_bn: dw [K][C], db [K] from dlogits
+ * and the recomputed activation; the data gradient belongs to aide_bn_relu_bwd_head.  fp32; ws: aide_head1x1_ws_bytes. */
+int aide_head1x1_fwd_bn(const float* z, int64_t z_bs, const float* in_scale, const float* in_shift, const float* w, const float* b,
+                        float* y, int64_t y_bs, int N, int C, int K, int H, int W, aide_stream_t stream);
+int aide_head1x1_wgrad_bn(const float* dy, int64_t dy_bs, const float* z, int64_t z_bs, const float* in_scale, const float* in_shift,
+                          float* dw, float* db, int N, int C, int K, int H, int W, void* ws, aide_stream_t stream);
 int aide_head1x1_fwd_mixed(const void* x, int x_bf16, int64_t x_bs, const float* w, const float* b, float* y,
                            int64_t y_bs, int N, int C, int K, int H, int W, aide_stream_t stream);
 int aide_head1x1_bwd_mixed(const float* dy, int64_t dy_bs, const void* x, int x_bf16, int64_t x_bs, const float* w,
