@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const GT* __restrict_
 
 // ---------------------------------------------------------------- one pass, several workgroups per channel
 // Every channel is owned by S workgroups (blockIdx = c * S + s): each reads its share of the channel ONCE into registers
-// (Q units of V values per thread, all loads in flight at once) and reduces it to fp64 partial sums.  Workgroup s > 0 hands
+// (Q units of V values per thread, all loads in flight at once) and reduces it to fp64 partial sums.  Every workgroup but one hands
 // its partials to the channel's LEADER (the last one, coop_leader) and waits for the coefficients; the leader sums the S partials in slot order
 // (bit-reproducible: no dependence on arrival order), finishes the statistics and broadcasts the two coefficients every
 // workgroup needs; all of them normalise from their registers.  Forward 8 B / element instead of 12 (statistics pass + apply
