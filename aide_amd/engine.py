@@ -1393,6 +1393,14 @@ class _NetFunction(torch.autograd.Function):
         n, _, h, w = inputs[0].shape
         out = torch.empty(n, k, h, w, device=inputs[0].device, dtype=torch.float32)
         plan.forward(inputs, out)
+        # The backward pass reads the network inputs again (stem weight gradients) -- on THIS stream and on the weight-gradient
+        # stream, possibly after the caller has dropped them: a pipelined co-teaching step leaves network 2's backward on its own
+        # stream past the end of the call, and the caching allocator would hand a dropped batch to the next main-stream allocation
+        # while that stream still reads it (found in round 6: both stems' weight gradients of the pipelined form differed in 1 of 3
+        # runs of tools/r6_flaky_c3.py).  record_stream defers the reuse behind what this stream has enqueued when the tensor dies.
+        cur = torch.cuda.current_stream(inputs[0].device)
+        for x in inputs:
+            x.record_stream(cur)
         ctx.engine, ctx.plan, ctx.serial, ctx.inputs, ctx.direct = engine, plan, plan.serial, inputs, direct
         ctx.ntensors = len(tensors)
         return out
@@ -1406,6 +1414,7 @@ class _NetFunction(torch.autograd.Function):
         if not plan.training:
             raise RuntimeError('aide_amd: backward through an eval-mode forward is not supported')
         dlogits = dlogits.contiguous()
+        dlogits.record_stream(torch.cuda.current_stream(dlogits.device))      # (as the inputs in forward: read on this pass' streams)
         params = eng.params
         mode = 0                         # 0: plain autograd outputs; 1: fresh gradients = arena views; 2: arena += ; 3: per parameter
         if ctx.direct:

@@ -186,6 +186,11 @@ def test_coteaching_two_streams_is_bit_identical(dev):
                 r = M.coteach_step(n1, n2, o1, o2, op, T('xin'), T('xout'), augs, T('t1'), T('t2'), 0.25, augset=augset,
                                    pipeline=(two == 'pipelined'))
                 trace.append((r['loss1'].clone(), r['loss2'].clone(), r['indx1'].clone(), r['indx2'].clone()))
+                # the batch of the step is dropped here while (pipelined) network 2's backward pass may still read it on its own
+                # stream: what the caller allocates next on the main stream -- the next batch -- must not land in that memory
+                # (round 6: the engine record_stream()s its inputs; without it both stems' weight gradients were corrupted)
+                junk = [torch.full_like(T('xin'), float('nan')) for _ in range(14)]
+                del junk
             M.join_networks()
             torch.cuda.synchronize()
             res[two] = (trace, [p.detach().clone() for p in list(n1.parameters()) + list(n2.parameters())],
