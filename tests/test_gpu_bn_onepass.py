@@ -321,3 +321,44 @@ def test_onepass_bwd_with_head_gradient(dev, case):
     for a, b, what in zip(out, ref, ('dz', 'dgamma', 'dbeta', 'dbias')):
         assert torch.equal(a, b), what
     _close(dA, torch.einsum('nkhw,kc->nchw', dl.cpu().double(), hw_.cpu().double()), rtol=1e-6, what='head dx')
+
+
+def test_onepass_two_kernels_at_once(dev):
+    """two one-pass launches in flight together (the two lanes of a forward pass, the two networks of the co-teaching step): each on
+    its own stream and workspace, many workgroups per channel on both, 40 rounds back to back -- every result equals the one the launch
+    gives alone, bit for bit (the waits of one kernel must never starve the other's missing workgroups)"""
+    from aide_amd import ops
+    shapes = [(4, 32, 256, 256), (4, 64, 128, 128)]
+    streams = [torch.cuda.Stream(device=dev) for _ in shapes]
+    jobs = []
+    for k, (n, c, h, w) in enumerate(shapes):
+        g = torch.Generator().manual_seed(90 + k)
+        z = (torch.randn(n, c, h, w, generator=g) * 2.0).to(dev)
+        dA = torch.randn(n, c, h, w, generator=g).to(dev)
+        gamma, beta = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.3
+        jobs.append(dict(z=z, dA=dA, gamma=gamma, beta=beta, ws=ops.bn_ws(c, dev), st=_stats(c, dev), c=c,
+                         a=torch.empty_like(z), dz=torch.empty_like(z), outs=[torch.empty(c, device=dev) for _ in range(3)]))
+
+    def launch(j):
+        c = j['c']
+        ops.bn_train_fwd(j['z'], j['a'], j['gamma'], j['beta'], 1e-5, 0.1, torch.zeros(c, device=dev), torch.ones(c, device=dev),
+                         torch.zeros((), dtype=torch.int64, device=dev), j['st'][0], j['st'][1], j['st'][2], j['st'][3], j['ws'], True)
+        ops.bn_relu_bwd(j['dA'], j['z'], j['dz'], j['st'][0], j['st'][1], j['st'][2], j['st'][3], j['outs'][0], j['outs'][1],
+                        j['outs'][2], j['ws'], True)
+    refs = []
+    for j in jobs:                                   # alone
+        launch(j)
+        torch.cuda.synchronize()
+        refs.append([j['a'].clone(), j['dz'].clone()] + [o.clone() for o in j['outs']])
+    for _ in range(40):
+        for j in jobs:
+            j['a'].fill_(float('nan'))
+            j['dz'].fill_(float('nan'))
+        torch.cuda.synchronize()
+        for j, s in zip(jobs, streams):
+            with torch.cuda.stream(s):
+                launch(j)
+        torch.cuda.synchronize()
+        for j, ref in zip(jobs, refs):
+            for x, y in zip([j['a'], j['dz']] + j['outs'], ref):
+                assert torch.equal(x, y)
