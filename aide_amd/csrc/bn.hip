@@ -602,13 +602,16 @@ __device__ __forceinline__ void slab_sum_q(const SlabSrc& sl, const long (&off)[
     }
 }
 
-template <int V, int Q, typename ZT, typename AT, bool SLABS>
+template <int V, int Q, typename ZT, typename AT, bool SLABS, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_fwd_coop_kernel(
     const ZT* __restrict__ z, long z_bs, AT* __restrict__ a, long a_bs, int N, int C, int HW, int S, int per, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ scale_out,
-    float* __restrict__ shift_out, int relu, const SlabSrc sl, int groups, double* __restrict__ ws) {
+    float* __restrict__ shift_out, int relu, const SlabSrc sl, int groups, double* __restrict__ ws, const PoolSrc pl) {
+    // POOL (round 6): the layer's activation also feeds nn.MaxPool2d(2, 2) -- the threads of the even image rows fetch the row below from
+    // z (cache: its own thread is 32 .. 40 units away), normalise it as well and store the four window maxima of their unit to the pooled
+    // tensor pl.pdy ([N][C][H/2][W/2] at this layer's channel 0): aide_maxpool2x2_fwd's pass disappears, same values (a maximum is exact)
     __shared__ double sm[2 * 4];
     __shared__ float coef[2];
     __shared__ int okf;
@@ -693,6 +696,22 @@ __global__ __launch_bounds__(256) void bn_fwd_coop_kernel(
 #pragma unroll
             for (int e = 0; e < V; ++e) { const float y = fmaf(v[k][e], sc, sh); o[e] = relu ? fmaxf(y, 0.0f) : y; }
             stv<V>(a + (n0 + nn[k]) * a_bs + (long)c * HW + pp[k], o);
+            if constexpr (POOL) {
+                static_assert(V == 8 && !SLABS, "pool-fused forward: units of 8, z as it is");
+                const int row = pp[k] / pl.W, col = pp[k] - row * pl.W;
+                if (!(row & 1)) {
+                    float zp[V];
+                    ldv<V>(z + (n0 + nn[k]) * z_bs + (long)c * HW + pp[k] + pl.W, zp);
+                    float m[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float q0 = fmaf(zp[2 * j], sc, sh), q1 = fmaf(zp[2 * j + 1], sc, sh);
+                        if (relu) { q0 = fmaxf(q0, 0.0f); q1 = fmaxf(q1, 0.0f); }
+                        m[j] = fmaxf(fmaxf(o[2 * j], o[2 * j + 1]), fmaxf(q0, q1));
+                    }
+                    stv<4>(const_cast<float*>(pl.pdy) + (n0 + nn[k]) * pl.pdy_bs + (long)c * (HW >> 2) + (row >> 1) * (pl.W >> 1) + (col >> 1), m);
+                }
+            }
         }
     }
     if (S > 1 && s == coop_leader(S) && threadIdx.x == 0) coop_store_i(ws_chan(ws, c), e0s + groups);
@@ -923,7 +942,7 @@ int bn_train_fwd_t(const ZT* z, int64_t z_bs, AT* a, int64_t a_bs, int N, int C,
             AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, kt_bytes, (bn_fwd_coop_kernel<VV, QQ, ZT, AT, SLABS>), dim3(C * cp.S), dim3(256), 0, stream, z, \
                                (long)z_bs, a, (long)a_bs, N, C, HW, cp.S, cp.per, count, gamma, beta, eps, momentum,          \
                                running_mean, running_var, num_batches_tracked, mean, rstd, scale, shift, relu, sl, groups,    \
-                               (double*)ws)
+                               (double*)ws, PoolSrc{})
 #define AIDE_BN_FQ(VV) do { if (cp.Q == 1) AIDE_BN_FC(VV, 1); else if (cp.Q == 2) AIDE_BN_FC(VV, 2); else if (cp.Q == 4) AIDE_BN_FC(VV, 4); else AIDE_BN_FC(VV, 8); } while (0)
             if (cp.V == 8) AIDE_BN_FQ(8); else AIDE_BN_FQ(4);
 #undef AIDE_BN_FQ
@@ -1188,6 +1207,30 @@ int aide_bn_relu_bwd_slabs(const float* slabs, int splitk, int64_t split_stride,
     if (cp.V == 8) AIDE_BN_BQ(8); else AIDE_BN_BQ(4);
 #undef AIDE_BN_BQ
 #undef AIDE_BN_BS
+    return aide_launch_status();
+}
+
+// BatchNorm(train)+ReLU forward of a layer whose activation also feeds nn.MaxPool2d(2, 2) (fuseunet.py:51-78, UNet.py:114): writes the
+// activation AND the pooled tensor [N * groups][C][H/2][W/2] (at this layer's channel 0, batch stride pooled_bs) -- the pooling pass does
+// not run.  fp32 storage, z as it is (no slabs), shapes of aide_bn_relu_bwd_pool_supported(N, C, H, W) (N = images per group).
+int aide_bn_train_fwd_pool(const float* z, int64_t z_bs, float* a, int64_t a_bs, float* pooled, int64_t pooled_bs, int N, int groups,
+                           int C, int H, int W, const float* gamma, const float* beta, float eps, float momentum,
+                           float* running_mean, float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                           float* scale, float* shift, int relu, void* ws, hipStream_t stream) {
+    const int HW = H * W;
+    CoopPlan cp;
+    if (!z || !a || !pooled || !ws || groups < 1 || H % 2 || W % 8 || z_bs % 8 || a_bs % 8 || pooled_bs % 4 ||
+        !coop_plan(N, C, HW, true, cp) || cp.V != 8)
+        return AIDE_ERR_ARG;
+    PoolSrc pl;
+    pl.pdy = pooled; pl.pdy_bs = pooled_bs; pl.W = W; pl.hw = nullptr; pl.K = 0;
+    const double kt_bytes = (double)N * groups * C * HW * 9.0;      // z in, a out, a quarter of it once more
+#define AIDE_BN_FP(QQ)                                                                                                        \
+    AIDE_LAUNCH_TIMED(AIDE_KT_BN_FWD, kt_bytes, (bn_fwd_coop_kernel<8, QQ, float, float, false, true>), dim3(C * cp.S), dim3(256), 0,   \
+                      stream, z, (long)z_bs, a, (long)a_bs, N, C, HW, cp.S, cp.per, (double)N * HW, gamma, beta, eps, momentum,          \
+                      running_mean, running_var, num_batches_tracked, mean, rstd, scale, shift, relu, SlabSrc{}, groups, (double*)ws, pl)
+    if (cp.Q == 1) AIDE_BN_FP(1); else if (cp.Q == 2) AIDE_BN_FP(2); else if (cp.Q == 4) AIDE_BN_FP(4); else AIDE_BN_FP(8);
+#undef AIDE_BN_FP
     return aide_launch_status();
 }
 

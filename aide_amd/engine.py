@@ -124,6 +124,7 @@ class EngineConfig(object):
         fuse_pool_bwd=True,         # max-pooling backward inside the BatchNorm backward of the layer(s) it pooled
         fuse_head_bwd=True,         # the head's data gradient formed inside the BatchNorm backward of the layer under it
         lazy_head=True,             # BatchNorm + ReLU of the layer under the head applied in the head's loaders (no pass, no activation)
+        fuse_pool_fwd=True,         # max-pooling forward inside the BatchNorm forward of the layer(s) it pools
     )
 
     def __init__(self, on_change=None):
@@ -399,6 +400,7 @@ class Plan(object):
         for t in graph.roots:
             dt = torch.bfloat16 if narrow.get(id(t)) else torch.float32
             self.act[id(t)] = torch.empty(n, t.C, h >> t.level, w >> t.level, device=device, dtype=dt)
+        self._plan_pool_fwd()
         # the gradient of a bf16-stored activation buffer is stored as bf16 too when every conv that reads the buffer also
         # runs its dgrad on the bf16 kernel (the other writers / readers -- pooling, up-sampling, head, BatchNorm backward --
         # are storage-generic).  Writers after the first accumulate in fp32 and round once per write (torch.autocast's
@@ -495,6 +497,39 @@ class Plan(object):
             o['head_lazy'] = True
             o['head_tab'] = torch.zeros(1, zc, 2, device=self.dev, dtype=torch.float32)
             hst['lazy_prod'] = o
+
+    def _plan_pool_fwd(self):
+        """Training plans: a max-pooling whose source is exactly the output of one or several conv + BN + ReLU layers that run the
+        one-pass BatchNorm on z as it is (no split-K slabs, no conv-epilogue statistics) is written by those layers' BatchNorm
+        kernels themselves (ops.bn_train_fwd_pool): the pooling pass and its launch disappear (the first two levels of the U-Nets)."""
+        if not (self.training and self.cfg.fuse_pool_fwd) or (self.groups > 1 and not self.cfg.grouped_bn):
+            return
+        m = self.N // max(self.groups, 1)
+        for pst in self.steps:
+            if pst['kind'] != 'pool':
+                continue
+            src, dst = pst['src'], pst['dst']
+            if src.root.is_input or self.act[id(src.root)].dtype != torch.float32 or self.act[id(dst.root)].dtype != torch.float32:
+                continue
+            prods = [o for o in self.steps if o['kind'] == 'conv' and o['dst'].root is src.root
+                     and src.c0 <= o['dst'].c0 and o['dst'].c0 + o['dst'].C <= src.c0 + src.C]
+            cover = sorted((o['dst'].c0, o['dst'].c0 + o['dst'].C) for o in prods)
+            if not cover or cover[0][0] != src.c0 or cover[-1][1] != src.c0 + src.C or any(a[1] != b[0] for a, b in zip(cover, cover[1:])):
+                continue
+            ok = True
+            for o in prods:
+                if o.get('z') is None or o['z'].dtype != torch.float32:
+                    ok = False
+                    break
+                zn, zc, zh, zw = o['z'].shape
+                if o.get('stats') is not None or (o['plan_f'] >> 8) > 1 or o.get('lazy_to') is not None or o.get('head_lazy') or \
+                        not lib.aide_bn_relu_bwd_pool_supported(m, zc, zh, zw):
+                    ok = False
+            if not ok:
+                continue
+            for o in prods:
+                o['pool_out'] = dst.slice(o['dst'].c0 - src.c0, o['dst'].C)
+            pst['fwd_fused'] = True
 
     # ------------------------------------------------------------------ helpers
     def view(self, t, inputs=None):
@@ -883,13 +918,16 @@ class Plan(object):
                     src, dst = st['src'], st['dst']
                     sa, da, sb, db = src.slice(0, c), dst.slice(0, c), src.slice(c, src.C - c), dst.slice(c, dst.C - c)
                     fork_if_needed([sb], [db])
-                    with ops.use_stream(bp):
-                        ops.maxpool2x2_fwd(self.view(sb, inputs), self.view(db))
+                    fused = bool(st.get('fwd_fused'))      # both halves were written by their producers' BatchNorm kernels
+                    if not fused:
+                        with ops.use_stream(bp):
+                            ops.maxpool2x2_fwd(self.view(sb, inputs), self.view(db))
                     ops.record(st['ev_b'], bp)
                     pooled.append((db.root, db.c0, db.C, st['ev_b']))
                     b_reads.append((sb.root, sb.c0, sb.C))
                     main_deps([sa], [da])
-                    ops.maxpool2x2_fwd(self.view(sa, inputs), self.view(da))
+                    if not fused:
+                        ops.maxpool2x2_fwd(self.view(sa, inputs), self.view(da))
                     touched.extend((t.root, t.c0, t.C) for t in (sa, da))
                 elif lane:
                     fork_if_needed(srcs, dsts)
@@ -973,7 +1011,8 @@ class Plan(object):
                 ops.convT2x2_fwd(self.view(st['src'], inputs), conv.weight, conv.bias, st['z'])
                 self._bn_apply(st, bn, None, 0, bn_ws, sk_ws)
             elif kind == 'pool':
-                ops.maxpool2x2_fwd(self.view(st['src'], inputs), self.view(st['dst']))
+                if not (st.get('fwd_fused') and self.training):
+                    ops.maxpool2x2_fwd(self.view(st['src'], inputs), self.view(st['dst']))
             elif kind == 'up':
                 ops.upsample2x_fwd(self.view(st['src'], inputs), self.view(st['dst']))
             elif kind == 'head':
@@ -1009,7 +1048,10 @@ class Plan(object):
         sk_ws = self.sk_ws if sk_ws is None else sk_ws
         ngroups = self.groups if (self.training and self.groups > 1) else 1
         m = self.N // ngroups
-        if self.training and ngroups > 1 and self.cfg.grouped_bn:
+        if self.training and st.get('pool_out') is not None and splitk == 0:
+            # (its activation is max-pooled: the pooled tensor is written here as well, no pooling pass)
+            ops.bn_train_fwd_pool(z, a, self.view(st['pool_out']), ngroups, bn, st['mean'], st['rstd'], st['scale'], st['shift'], bn_ws)
+        elif self.training and ngroups > 1 and self.cfg.grouped_bn:
             # the stacked augmentation pass: every group's statistics / running-statistics update in ONE launch sequence
             # (one launch sequence per group cost 3 x 2 x 32 small launches per co-teaching step)
             if st.get('stats') is not None:

@@ -299,6 +299,19 @@ def bn_train_fwd_groups(z, a, groups, bn, mean, rstd, scale, shift, ws, relu=Tru
     return a
 
 
+def bn_train_fwd_pool(z, a, pooled, groups, bn, mean, rstd, scale, shift, ws, relu=True):
+    """bn_train_fwd(_groups) that also writes max_pool2d(a, 2) into `pooled` (this layer's channel slice of the pooled buffer): fp32,
+    lib.aide_bn_relu_bwd_pool_supported(n // groups, c, h, w) shapes"""
+    zp, zbs = planes(z)
+    ap, abs_ = planes(a)
+    pp, pbs = planes(pooled)
+    n, c, h, w = z.shape
+    check(lib.aide_bn_train_fwd_pool(zp, zbs, ap, abs_, pp, pbs, n // groups, groups, c, h, w, ptr(bn.weight), ptr(bn.bias), bn.eps,
+                                     bn.momentum, ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(mean),
+                                     ptr(rstd), ptr(scale), ptr(shift), int(relu), ptr(ws), stream_ptr()), 'bn_train_fwd_pool')
+    return a
+
+
 def bn_finalize_groups(n_per_group, groups, c, h, w, bn, parts, nparts, parts_stride, conv_bias, mean, rstd, scale, shift,
                        tab, tab_c0):
     """statistics -> per-group (scale, shift) entries [tab_c0, tab_c0 + c) of tab [groups, tab_C, 2] + running statistics;

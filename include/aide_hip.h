@@ -248,6 +248,13 @@ int aide_bn_relu_apply_mixed(const void* z, int z_bf16, int64_t z_bs, void* a, i
  * aide_maxpool2x2_bwd(accumulate = 1) followed by aide_bn_relu_bwd_mixed, without the pooling backward's pass.  fp32 storage, shapes of
  * aide_bn_relu_bwd_pool_supported (one-pass form with units of 8: H even, W % 8 == 0). */
 int aide_bn_relu_bwd_pool_supported(int N, int C, int H, int W);
+/* ... and the forward half: BatchNorm(train)+ReLU of such a layer writes the activation AND the pooled tensor [N * groups][C][H/2][W/2]
+ * (at the layer's channel 0 of the pooled buffer) -- aide_maxpool2x2_fwd's pass does not run; `groups` as aide_bn_train_fwd_groups.  fp32,
+ * z as it is, the shapes of aide_bn_relu_bwd_pool_supported(N, C, H, W) with N = images per group. */
+int aide_bn_train_fwd_pool(const float* z, int64_t z_bs, float* a, int64_t a_bs, float* pooled, int64_t pooled_bs, int N, int groups,
+                           int C, int H, int W, const float* gamma, const float* beta, float eps, float momentum,
+                           float* running_mean, float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                           float* scale, float* shift, int relu, void* ws, aide_stream_t stream);
 int aide_bn_relu_bwd_pool(const float* dA, int64_t d_bs, const float* pdy, int64_t pdy_bs, const float* z, int64_t z_bs, float* dz,
                           int64_t dz_bs, int N, int C, int H, int W, const float* mean, const float* rstd, const float* scale,
                           const float* shift, int relu, float* dgamma, float* dbeta, float* dbias, void* ws, void* done,

@@ -362,3 +362,35 @@ def test_onepass_two_kernels_at_once(dev):
         for j, ref in zip(jobs, refs):
             for x, y in zip([j['a'], j['dz']] + j['outs'], ref):
                 assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('case', [(4, 1, 32, 256, 256), (4, 4, 64, 128, 128), (2, 3, 24, 40, 48), (4, 1, 128, 64, 64)])
+def test_onepass_fwd_with_pooled_output(dev, case):
+    """aide_bn_train_fwd_pool: the activation AND max_pool2d(activation, 2) from one launch == the plain forward (per group, in order)
+    followed by aide_maxpool2x2_fwd, bit for bit -- activations, pooled tensor, running statistics, saved coefficients."""
+    from aide_amd import ops
+    from aide_amd._lib import lib
+    m, groups, c, h, w = case
+    n = m * groups
+    assert lib.aide_bn_relu_bwd_pool_supported(m, c, h, w) == 1
+    g = torch.Generator().manual_seed(c + h + groups)
+    z = (torch.randn(n, c, h, w, generator=g) * 2.0 + 0.3).to(dev)
+    res = []
+    for fused in (False, True):
+        bn = torch.nn.BatchNorm2d(c).to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(c, generator=torch.Generator().manual_seed(7)) + 0.5)
+            bn.bias.copy_(torch.randn(c, generator=torch.Generator().manual_seed(8)) * 0.2)
+        st = _stats(c, dev)
+        ws = ops.bn_ws(c, dev)
+        a = torch.empty_like(z)
+        pooled = torch.full((n, c + 8, h // 2, w // 2), float('nan'), device=dev)[:, 8:]        # a channel slice of a wider buffer
+        if fused:
+            ops.bn_train_fwd_pool(z, a, pooled, groups, bn, st[0], st[1], st[2], st[3], ws)
+        else:
+            ops.bn_train_fwd_groups(z, a, groups, bn, st[0], st[1], st[2], st[3], ws)
+            ops.maxpool2x2_fwd(a, pooled)
+        res.append([a, pooled.clone(), bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()] + list(st))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    assert torch.equal(res[1][1], F.max_pool2d(res[1][0], 2))

@@ -460,11 +460,13 @@ def test_pool_backward_inside_batchnorm_is_bit_identical(dev, kind):
     xs = [torch.randn(4, 3, 128, 128, generator=g).to(dev) for _ in range(nin)]
     t = (torch.rand(4, 128, 128, generator=g) > 0.8).long().to(dev)
     w = torch.tensor([1.0, 1.0])
+    nfwd = 1 if kind == 'fuseunet' else 0          # at least the 32-channel first level of the FuseUNet: one-pass BatchNorm on z as it is (no slabs, no epilogue statistics)
     results = []
     for fuse in (False, True):
         net.engine.config.fuse_pool_bwd = fuse
         net.engine.config.fuse_head_bwd = fuse              # (... and the head's data gradient inside the last BatchNorm backward)
         net.engine.config.lazy_head = fuse                  # (... and that layer's BatchNorm + ReLU inside the head's loaders)
+        net.engine.config.fuse_pool_fwd = fuse              # (... and the pooling forward inside the BatchNorm forward, levels 0-1)
         outs = None
         for _ in range(3):
             net.zero_grad()
@@ -477,6 +479,8 @@ def test_pool_backward_inside_batchnorm_is_bit_identical(dev, kind):
         # (128 x 128 inputs: the 16 x 16 level holds 1024 values per channel -- units of 4, which the fused form does not take)
         assert len(fused) == (3 if fuse else 0)
         assert sum(1 for st in plan.steps if st.get('head_fuse') is not None) == (1 if fuse else 0)
+        nf = sum(1 for st in plan.steps if st['kind'] == 'pool' and st.get('fwd_fused'))
+        assert nf == 0 if not fuse else nf >= nfwd
         torch.cuda.synchronize()
     for a, b in zip(*results):
         assert torch.equal(a, b)
